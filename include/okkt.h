@@ -1,0 +1,185 @@
+/*
+ * okkt.h -- C ABI of libonephase_kkt.so: the MI355X-native KKT linear-system path of the
+ * one-phase interior point method (reference behaviour: ohinder/OnePhase.jl).
+ *
+ * Two drop-in levels:
+ *
+ *  (1) linear-solver level -- what a `linear_solver_HIP <: abstract_linear_system_solver`
+ *      binds in place of `linear_solver_JULIA` (CHOLMOD):
+ *        initialize!  src/linear_system_solvers/linear_system_solvers.jl:40   -> okkt_create
+ *        ls_factor!   src/linear_system_solvers/julia.jl:21-97                -> okkt_analyze + okkt_factor
+ *        ls_solve!    src/linear_system_solvers/julia.jl:99-103               -> okkt_solve
+ *        ls_solve     src/linear_system_solvers/julia.jl:105-113              -> okkt_solve
+ *        finalize!    src/linear_system_solvers/linear_system_solvers.jl:44   -> okkt_destroy
+ *        inertia_status  src/linear_system_solvers/linear_system_solvers.jl:48-91 -> okkt_inertia + return code
+ *
+ *  (2) KKT-system level -- what a `HIP_KKT_solver <: abstract_KKT_system_solver` binds in
+ *      place of Schur_KKT_solver / Symmetric_KKT_solver, keeping everything device-resident:
+ *        form_system!                      src/kkt_system_solver/schur.jl:47-62, symmetric.jl:35-53 -> okkt_kkt_form_system
+ *        update_delta_vecs! + factor!      schur.jl:64-87, symmetric.jl:55-57,85-102, kkt_system_solver.jl:98-113,190-204 -> okkt_kkt_factor
+ *        compute_direction_implementation! schur.jl:89-182, symmetric.jl:59-83 (+ update_kkt_error! kkt_system_solver.jl:67-96) -> okkt_kkt_compute_direction
+ *        ipopt_strategy!                   src/IPM/delta_strategy.jl:37-114 -> okkt_kkt_ipopt_strategy
+ *
+ * Conventions: plain pointers and sizes only; no exceptions cross the boundary.  Functions
+ * return OKKT_OK (0) or a negative okkt_status; the factor calls return 1 (inertia correct),
+ * 0 (inertia wrong / zero or non-finite pivot) or a negative error -- the same 1/0 contract as
+ * ls_factor!.  All calls are blocking (the handle's HIP stream is synchronised before return).
+ * A handle is not thread-safe; several handles may coexist.
+ *
+ * There is NO CPU fallback: without a usable HIP device every compute entry point fails with
+ * OKKT_ERR_NO_DEVICE (okkt_create succeeds only with opts.host_symbolic_only = 1, which permits
+ * okkt_analyze and the query functions and nothing else).
+ */
+#ifndef OKKT_H
+#define OKKT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct okkt_solver_s* okkt_handle;
+typedef struct okkt_kkt_s* okkt_kkt_handle;
+
+typedef enum {
+  OKKT_OK = 0,
+  OKKT_ERR_INVALID = -1,     /* bad argument / call out of order */
+  OKKT_ERR_NO_DEVICE = -2,   /* no HIP device, or handle is host_symbolic_only */
+  OKKT_ERR_HIP = -3,         /* a HIP runtime call failed (see okkt_last_error) */
+  OKKT_ERR_ALLOC = -4,
+  OKKT_ERR_INTERNAL = -5
+} okkt_status;
+
+/* sym_kind: the `sym` symbol of the reference's solver constructors (julia.jl:11) */
+#define OKKT_SYM_DEFINITE 0   /* :definite  -- Cholesky semantics: success <=> every pivot > 0     */
+#define OKKT_SYM_SYMMETRIC 1  /* :symmetric -- LDL^T, inertia from sign(D) with tolerance 1e-20   */
+
+/* kkt_kind: pars.kkt.kkt_solver_type (parameters.jl:30) */
+#define OKKT_KKT_SCHUR 0      /* Q = H + J' diag(y/s) J       (n x n),     Cholesky semantics */
+#define OKKT_KKT_SYMMETRIC 1  /* K = [[H J'];[J -diag(s/y)]]  (n+m square), LDL^T inertia (n,m,0) */
+
+typedef struct {
+  int32_t device;             /* HIP device ordinal; -1 = current device */
+  int32_t host_symbolic_only; /* 1: never touch the GPU (analysis + queries only; CPU-side tests) */
+  int32_t ordering;           /* 0 AMD (default), 1 natural, 2 user permutation (okkt_set_perm) */
+  int32_t relax_always;       /* supernode amalgamation knobs, <=0 = default */
+  int32_t relax_small;
+  int32_t relax_mid;
+  double relax_small_frac;
+  double relax_mid_frac;
+  double relax_any_frac;
+  double inertia_tol;         /* |d| <= tol counts as a zero pivot (julia.jl:73); default 1e-20 */
+  int32_t small_front_max;    /* fronts of order <= this use the LDS-resident kernel; <=0 default */
+  int32_t panel_nb;           /* block-column width in the big-front kernels; <=0 default */
+  int32_t use_graph;          /* 1: replay the numeric factorisation as a hipGraph (default 1) */
+  int32_t reserved;
+} okkt_opts;
+
+typedef struct {
+  int64_t pos, neg, zero, nonfinite; /* counts over diag(D); julia.jl:72-78 */
+} okkt_inertia;
+
+typedef struct {
+  int64_t n;              /* order of the analysed matrix */
+  int64_t nnz_lower;      /* input entries with row >= col */
+  int64_t nnzL;           /* sum_j c_j (structural, no relaxation zeros) */
+  int64_t nnzL_stored;    /* panel entries actually stored (with relaxation zeros) */
+  double flops_exact;     /* sum_j c_j^2  (SURVEY 8d factor flops) */
+  double flops_stored;    /* dense-front flops executed */
+  int64_t arena_bytes;    /* HBM bytes of the front arena (sum f^2 * 8) */
+  int64_t nsuper;
+  int64_t nlevels;
+  int64_t max_front;
+  int64_t n_small_fronts, n_big_fronts;
+  int64_t sum_rowidx;     /* sum_s f_s (row-index entries) */
+  double analyze_seconds; /* host time of the last analysis */
+  double last_factor_ms;  /* device time of the last numeric factorisation (hipEvent) */
+  double last_solve_ms;   /* device time of the last solve */
+  uint64_t pattern_hash;
+  int64_t n_analyze_calls; /* how many times a new pattern forced a re-analysis */
+} okkt_stats;
+
+/* ---- level 1: linear solver ------------------------------------------------------------ */
+int okkt_default_opts(okkt_opts* opts);
+int okkt_create(okkt_handle* out, const okkt_opts* opts /* NULL = defaults */);
+int okkt_destroy(okkt_handle h);
+const char* okkt_last_error(okkt_handle h);
+const char* okkt_version(void);
+
+/* user permutation for opts.ordering == 2: perm[new] = old, 0-based; call before okkt_analyze */
+int okkt_set_perm(okkt_handle h, const int64_t* perm, int64_t n);
+/* pattern of a square CSC matrix (only row >= col is used; upper entries are ignored, as under
+ * Symmetric(A,:L), julia.jl:34,52).  Cached by pattern hash: re-calling with the same pattern
+ * is free, so the reference-shaped ls_factor!(A,...) can call it every time. */
+int okkt_analyze(okkt_handle h, int64_t dim, const int64_t* colptr, const int64_t* rowval, int index_base);
+int okkt_get_perm(okkt_handle h, int64_t* perm_out /* [dim], perm[new]=old, 0-based */);
+int okkt_get_stats(okkt_handle h, okkt_stats* out);
+int okkt_get_etree(okkt_handle h, int64_t* parent_out /* [dim] */, int64_t* colcount_out /* [dim] */);
+
+/* numeric factorisation of the analysed pattern with values nzval (same order as rowval).
+ * n + m must equal dim.  Returns 1 / 0 / <0 like ls_factor! (julia.jl:21-97). */
+int okkt_factor(okkt_handle h, const double* nzval, int64_t n, int64_t m, int sym_kind, okkt_inertia* inertia_out);
+/* same, nzval already resident in HBM (device pointer) */
+int okkt_factor_dev(okkt_handle h, const double* d_nzval, int64_t n, int64_t m, int sym_kind, okkt_inertia* inertia_out);
+/* sol = F \ rhs for nrhs right-hand sides stored one after another (julia.jl:101,110).  rhs may alias sol. */
+int okkt_solve(okkt_handle h, const double* rhs, double* sol, int64_t nrhs);
+int okkt_solve_dev(okkt_handle h, const double* d_rhs, double* d_sol, int64_t nrhs);
+/* diag(F): the D of LDL^T in pivot (permuted) order, as `diag(solver._factor)` (julia.jl:72) */
+int okkt_get_diag(okkt_handle h, double* d_out /* [dim] */);
+/* L as CSC in permuted numbering (unit diagonal not stored), for parity tests; pass NULLs to size */
+int okkt_get_factor_csc(okkt_handle h, int64_t* colptr_out, int64_t* rowval_out, double* val_out, int64_t* nnz_out);
+
+/* device-memory helpers so that callers without a HIP binding (ctypes, Julia) can keep inputs in HBM */
+int okkt_dev_alloc(okkt_handle h, int64_t bytes, void** d_ptr_out);
+int okkt_dev_free(okkt_handle h, void* d_ptr);
+int okkt_dev_upload(okkt_handle h, void* d_dst, const void* src, int64_t bytes);
+int okkt_dev_download(okkt_handle h, void* dst, const void* d_src, int64_t bytes);
+/* the handle's HIP stream (hipStream_t as void*), for callers that time with their own events */
+void* okkt_get_stream(okkt_handle h);
+
+/* ---- level 2: device-resident KKT system solver ----------------------------------------- */
+typedef struct {
+  double delta_start, delta_min, delta_max, delta_inc, delta_dec, delta_zero; /* parameters.jl:147-158 */
+  int32_t ItRefine_Num;   /* parameters.jl:20 (3) -- Schur refinement rounds (first one is the plain solve) */
+  int32_t max_it;         /* delta_strategy.jl:40 (500) */
+} okkt_kkt_pars;
+
+typedef struct {
+  double error_D, error_P, error_mu, overall, rhs_norm, ratio; /* Class_kkt_error, kkt_system_solver.jl:49-65 */
+} okkt_kkt_error;
+
+int okkt_kkt_default_pars(okkt_kkt_pars* pars);
+int okkt_kkt_create(okkt_kkt_handle* out, const okkt_opts* opts, int kkt_kind);
+int okkt_kkt_destroy(okkt_kkt_handle k);
+const char* okkt_kkt_last_error(okkt_kkt_handle k);
+/* the underlying linear-solver handle (for stats / permutation queries) */
+okkt_handle okkt_kkt_linear_solver(okkt_kkt_handle k);
+/* structure of the iterate cache (Class_iterate.jl:4-20): H n x n CSC lower triangle only
+ * (Class_cutest.jl:548), J m x n CSC.  Builds the pattern of Q or K, analyses it, builds maps. */
+int okkt_kkt_set_structure(okkt_kkt_handle k, int64_t n, int64_t m,
+                           const int64_t* H_colptr, const int64_t* H_rowval,
+                           const int64_t* J_colptr, const int64_t* J_rowval, int index_base);
+/* form_system!: values of H and J and the point (s, y); computes schur_diag on the device */
+int okkt_kkt_form_system(okkt_kkt_handle k, const double* H_nzval, const double* J_nzval,
+                         const double* s, const double* y);
+/* diag_min(kkt_solver) (kkt_system_solver.jl:291-294) */
+int okkt_kkt_diag_min(okkt_kkt_handle k, double* out);
+/* factor!(kkt_solver, delta): shift the first n diagonal entries by delta, refactor; 1 / 0 / <0 */
+int okkt_kkt_factor(okkt_kkt_handle k, double delta, okkt_inertia* inertia_out);
+/* ipopt_strategy!: returns 1 on :success, 0 on :failure (delta > delta_max), <0 on error */
+int okkt_kkt_ipopt_strategy(okkt_kkt_handle k, double delta_prev, const okkt_kkt_pars* pars,
+                            int32_t* num_fac_out, double* delta_out);
+/* compute_direction!: rhs triple (dual_r[n], primal_r[m], comp_r[m]) -> (dx[n], dy[m], ds[m]) + N err */
+int okkt_kkt_compute_direction(okkt_kkt_handle k, const double* dual_r, const double* primal_r,
+                               const double* comp_r, int32_t ItRefine_Num,
+                               double* dx, double* dy, double* ds, okkt_kkt_error* err_out);
+/* the assembled matrix values in the order of the analysed pattern (tests), and schur_diag */
+int okkt_kkt_get_matrix(okkt_kkt_handle k, int64_t* dim_out, int64_t* nnz_out,
+                        int64_t* colptr_out, int64_t* rowval_out, double* nzval_out);
+int okkt_kkt_get_schur_diag(okkt_kkt_handle k, double* out /* [n] */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OKKT_H */

@@ -1,0 +1,401 @@
+// C ABI, linear-solver level (include/okkt.h): the entry points a
+// `linear_solver_HIP <: abstract_linear_system_solver` binds in place of linear_solver_JULIA
+// (/root/reference/src/linear_system_solvers/julia.jl).  No exception leaves this file.
+#include <chrono>
+#include <cstring>
+#include <new>
+
+#include "solver.h"
+
+using namespace okkt;
+
+namespace okkt {
+
+int solver_set_error(okkt_solver_s* h, int code, const std::string& msg) {
+  if (h) h->err = msg;
+  return code;
+}
+
+static int ensure_device(okkt_solver_s* h) {
+  if (h->opts.host_symbolic_only) return solver_set_error(h, OKKT_ERR_NO_DEVICE, "handle was created with host_symbolic_only");
+  if (h->device_ready) {
+    if (hipSetDevice(h->device) != hipSuccess) return solver_set_error(h, OKKT_ERR_HIP, "hipSetDevice failed");
+    return OKKT_OK;
+  }
+  return solver_set_error(h, OKKT_ERR_NO_DEVICE, "no HIP device");
+}
+
+static int ensure_numeric(okkt_solver_s* h) {
+  int rc = ensure_device(h);
+  if (rc != OKKT_OK) return rc;
+  if (!h->analyzed) return solver_set_error(h, OKKT_ERR_INVALID, "okkt_analyze has not been called");
+  if (h->numeric_ready) return OKKT_OK;
+  std::string e = numeric_setup(h->S, h->sopts, h->stream, h->N);
+  if (!e.empty()) { numeric_release(h->N); return solver_set_error(h, OKKT_ERR_HIP, e); }
+  h->numeric_ready = true;
+  return OKKT_OK;
+}
+
+int solver_factor_device(okkt_solver_s* h, const double* d_vals, int64_t n, int64_t m, int sym_kind,
+                         okkt_inertia* out) {
+  int rc = ensure_numeric(h);
+  if (rc != OKKT_OK) return rc;
+  if (n < 0 || m < 0 || n + m != h->S.n) return solver_set_error(h, OKKT_ERR_INVALID, "n + m does not match the analysed dimension");
+  if (sym_kind != OKKT_SYM_DEFINITE && sym_kind != OKKT_SYM_SYMMETRIC) return solver_set_error(h, OKKT_ERR_INVALID, "unknown sym_kind");
+  if (sym_kind == OKKT_SYM_DEFINITE && m != 0) return solver_set_error(h, OKKT_ERR_INVALID, ":definite requires m == 0 (julia.jl:30)");
+  const double tol = sym_kind == OKKT_SYM_DEFINITE ? 0.0 : h->opts.inertia_tol;
+  h->factored = false;
+  (void)hipEventRecord(h->ev0, h->stream);
+  std::string e = numeric_factor_enqueue(h->N, d_vals, tol);
+  if (!e.empty()) return solver_set_error(h, OKKT_ERR_HIP, e);
+  (void)hipEventRecord(h->ev1, h->stream);
+  unsigned long long cnt[4];
+  hipError_t he = hipMemcpyAsync(cnt, h->N.d.counters, sizeof(cnt), hipMemcpyDeviceToHost, h->stream);
+  if (he == hipSuccess) he = hipStreamSynchronize(h->stream);
+  if (he != hipSuccess) return solver_set_error(h, OKKT_ERR_HIP, std::string("numeric factorisation failed: ") + hipGetErrorString(he));
+  float ms = 0;
+  if (hipEventElapsedTime(&ms, h->ev0, h->ev1) == hipSuccess) h->last_factor_ms = ms;
+  okkt_inertia in;
+  in.pos = (int64_t)cnt[0]; in.neg = (int64_t)cnt[1]; in.zero = (int64_t)cnt[2]; in.nonfinite = (int64_t)cnt[3];
+  if (out) *out = in;
+  h->factored = true;
+  if (in.pos + in.neg + in.zero + in.nonfinite != h->S.n)
+    return solver_set_error(h, OKKT_ERR_INTERNAL, "pivot counts do not add up to the matrix order");
+  if (in.nonfinite > 0) return 0;                       // julia.jl:77-89
+  if (sym_kind == OKKT_SYM_DEFINITE) return in.pos == n ? 1 : 0;  // PosDefException <=> some pivot <= 0
+  return (in.pos == n && in.neg == m) ? 1 : 0;          // linear_system_solvers.jl:73-74
+}
+
+int solver_solve_device(okkt_solver_s* h, const double* d_rhs, double* d_sol, int64_t nrhs) {
+  int rc = ensure_numeric(h);
+  if (rc != OKKT_OK) return rc;
+  if (!h->factored) return solver_set_error(h, OKKT_ERR_INVALID, "solve called before a factorisation");
+  if (nrhs < 0) return solver_set_error(h, OKKT_ERR_INVALID, "nrhs < 0");
+  (void)hipEventRecord(h->ev0, h->stream);
+  for (int64_t r = 0; r < nrhs; ++r) {
+    launch_permute_in(h->N, d_rhs + r * h->S.n);
+    std::string e = numeric_solve_enqueue(h->N);
+    if (!e.empty()) return solver_set_error(h, OKKT_ERR_HIP, e);
+    launch_permute_out(h->N, d_sol + r * h->S.n);
+  }
+  (void)hipEventRecord(h->ev1, h->stream);
+  hipError_t he = hipStreamSynchronize(h->stream);
+  if (he != hipSuccess) return solver_set_error(h, OKKT_ERR_HIP, std::string("solve failed: ") + hipGetErrorString(he));
+  float ms = 0;
+  if (hipEventElapsedTime(&ms, h->ev0, h->ev1) == hipSuccess) h->last_solve_ms = ms;
+  return OKKT_OK;
+}
+
+}  // namespace okkt
+
+extern "C" {
+
+const char* okkt_version(void) { return "onephase-kkt-mi355x 0.1 (gfx950)"; }
+
+int okkt_default_opts(okkt_opts* o) {
+  if (!o) return OKKT_ERR_INVALID;
+  std::memset(o, 0, sizeof(*o));
+  SymbolicOptions d;
+  o->device = -1;
+  o->host_symbolic_only = 0;
+  o->ordering = 0;
+  o->relax_always = d.relax_always;
+  o->relax_small = d.relax_small;
+  o->relax_mid = d.relax_mid;
+  o->relax_small_frac = d.relax_small_frac;
+  o->relax_mid_frac = d.relax_mid_frac;
+  o->relax_any_frac = d.relax_any_frac;
+  o->inertia_tol = 1e-20;
+  o->small_front_max = 128;
+  o->panel_nb = 64;
+  o->use_graph = 1;
+  return OKKT_OK;
+}
+
+int okkt_create(okkt_handle* out, const okkt_opts* opts) {
+  if (!out) return OKKT_ERR_INVALID;
+  *out = nullptr;
+  okkt_solver_s* h = new (std::nothrow) okkt_solver_s();
+  if (!h) return OKKT_ERR_ALLOC;
+  okkt_opts def;
+  okkt_default_opts(&def);
+  h->opts = opts ? *opts : def;
+  okkt_opts& o = h->opts;
+  if (o.relax_always <= 0) o.relax_always = def.relax_always;
+  if (o.relax_small <= 0) o.relax_small = def.relax_small;
+  if (o.relax_mid <= 0) o.relax_mid = def.relax_mid;
+  if (o.relax_small_frac <= 0) o.relax_small_frac = def.relax_small_frac;
+  if (o.relax_mid_frac <= 0) o.relax_mid_frac = def.relax_mid_frac;
+  if (o.relax_any_frac <= 0) o.relax_any_frac = def.relax_any_frac;
+  if (o.inertia_tol < 0) o.inertia_tol = def.inertia_tol;
+  if (o.small_front_max <= 0) o.small_front_max = def.small_front_max;
+  if (o.panel_nb <= 0) o.panel_nb = def.panel_nb;
+  h->sopts.ordering = o.ordering;
+  h->sopts.relax_always = o.relax_always;
+  h->sopts.relax_small = o.relax_small;
+  h->sopts.relax_mid = o.relax_mid;
+  h->sopts.relax_small_frac = o.relax_small_frac;
+  h->sopts.relax_mid_frac = o.relax_mid_frac;
+  h->sopts.relax_any_frac = o.relax_any_frac;
+  h->sopts.small_front_max = o.small_front_max;
+  h->sopts.panel_nb = o.panel_nb;
+  if (!o.host_symbolic_only) {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) { delete h; return OKKT_ERR_NO_DEVICE; }
+    int dev = o.device;
+    if (dev < 0) { if (hipGetDevice(&dev) != hipSuccess) dev = 0; }
+    if (dev >= count || hipSetDevice(dev) != hipSuccess) { delete h; return OKKT_ERR_NO_DEVICE; }
+    h->device = dev;
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return OKKT_ERR_HIP; }
+    if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) { delete h; return OKKT_ERR_HIP; }
+    h->device_ready = true;
+  }
+  *out = h;
+  return OKKT_OK;
+}
+
+int okkt_destroy(okkt_handle h) {
+  if (!h) return OKKT_ERR_INVALID;
+  if (h->device_ready) {
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    numeric_release(h->N);
+    if (h->d_rhs_stage) (void)hipFree(h->d_rhs_stage);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+  }
+  delete h;
+  return OKKT_OK;
+}
+
+const char* okkt_last_error(okkt_handle h) { return h ? h->err.c_str() : "null handle"; }
+
+int okkt_set_perm(okkt_handle h, const int64_t* perm, int64_t n) {
+  if (!h || !perm || n < 0) return OKKT_ERR_INVALID;
+  h->user_perm.assign(perm, perm + n);
+  h->analyzed = false;  // force re-analysis with the new permutation
+  return OKKT_OK;
+}
+
+int okkt_analyze(okkt_handle h, int64_t dim, const int64_t* colptr, const int64_t* rowval, int index_base) {
+  if (!h || !colptr || (dim > 0 && !rowval && colptr[dim] != colptr[0])) return OKKT_ERR_INVALID;
+  if (dim < 0) return solver_set_error(h, OKKT_ERR_INVALID, "dim < 0");
+  try {
+    if (h->analyzed && h->S.n == dim) {
+      // same pattern as last time?  (the reference rebuilds Q every outer iteration with an
+      // identical structure; ls_factor! may therefore call this unconditionally)
+      if (colptr[dim] - colptr[0] == h->S.nnz_in && hash_pattern(dim, colptr, rowval) == h->S.pattern_hash) return OKKT_OK;
+    }
+    if (h->opts.ordering == 2 && (int64_t)h->user_perm.size() != dim)
+      return solver_set_error(h, OKKT_ERR_INVALID, "ordering=user: okkt_set_perm must supply dim entries first");
+    auto t0 = std::chrono::steady_clock::now();
+    if (h->numeric_ready) {
+      (void)hipSetDevice(h->device);
+      (void)hipStreamSynchronize(h->stream);
+      numeric_release(h->N);
+      h->numeric_ready = false;
+    }
+    h->analyzed = false;
+    h->factored = false;
+    std::string e = analyze_pattern(dim, colptr, rowval, index_base, h->sopts,
+                                    h->opts.ordering == 2 ? h->user_perm.data() : nullptr, h->S);
+    if (!e.empty()) return solver_set_error(h, OKKT_ERR_INVALID, e);
+    h->analyze_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    h->analyzed = true;
+    ++h->n_analyze_calls;
+    return OKKT_OK;
+  } catch (const std::bad_alloc&) {
+    return solver_set_error(h, OKKT_ERR_ALLOC, "out of host memory in okkt_analyze");
+  } catch (...) {
+    return solver_set_error(h, OKKT_ERR_INTERNAL, "unexpected exception in okkt_analyze");
+  }
+}
+
+int okkt_get_perm(okkt_handle h, int64_t* perm_out) {
+  if (!h || !perm_out) return OKKT_ERR_INVALID;
+  if (!h->analyzed) return solver_set_error(h, OKKT_ERR_INVALID, "not analysed");
+  for (int64_t k = 0; k < h->S.n; ++k) perm_out[k] = h->S.perm[k];
+  return OKKT_OK;
+}
+
+int okkt_get_etree(okkt_handle h, int64_t* parent_out, int64_t* colcount_out) {
+  if (!h) return OKKT_ERR_INVALID;
+  if (!h->analyzed) return solver_set_error(h, OKKT_ERR_INVALID, "not analysed");
+  for (int64_t k = 0; k < h->S.n; ++k) {
+    if (parent_out) parent_out[k] = h->S.parent[k];
+    if (colcount_out) colcount_out[k] = h->S.colcount[k];
+  }
+  return OKKT_OK;
+}
+
+int okkt_get_stats(okkt_handle h, okkt_stats* out) {
+  if (!h || !out) return OKKT_ERR_INVALID;
+  std::memset(out, 0, sizeof(*out));
+  if (!h->analyzed) return solver_set_error(h, OKKT_ERR_INVALID, "not analysed");
+  const Symbolic& S = h->S;
+  out->n = S.n;
+  out->nnz_lower = S.nnz_lower;
+  out->nnzL = S.nnzL;
+  out->nnzL_stored = S.nnzL_stored;
+  out->flops_exact = S.flops_exact;
+  out->flops_stored = S.flops_stored;
+  out->arena_bytes = S.arena_doubles * 8;
+  out->nsuper = S.nsuper;
+  out->nlevels = S.nlevels;
+  out->max_front = S.max_front;
+  int64_t nsmall = 0, nbig = 0;
+  for (int s = 0; s < S.nsuper; ++s) {
+    int64_t f = S.row_ptr[s + 1] - S.row_ptr[s];
+    if (f <= std::max(32, std::min(h->sopts.small_front_max, 136))) ++nsmall; else ++nbig;
+  }
+  out->n_small_fronts = nsmall;
+  out->n_big_fronts = nbig;
+  out->sum_rowidx = (int64_t)S.rows.size();
+  out->analyze_seconds = h->analyze_seconds;
+  out->last_factor_ms = h->last_factor_ms;
+  out->last_solve_ms = h->last_solve_ms;
+  out->pattern_hash = S.pattern_hash;
+  out->n_analyze_calls = h->n_analyze_calls;
+  return OKKT_OK;
+}
+
+int okkt_factor_dev(okkt_handle h, const double* d_nzval, int64_t n, int64_t m, int sym_kind, okkt_inertia* out) {
+  if (!h || (!d_nzval && h->S.nnz_in > 0)) return OKKT_ERR_INVALID;
+  try {
+    return solver_factor_device(h, d_nzval, n, m, sym_kind, out);
+  } catch (...) {
+    return solver_set_error(h, OKKT_ERR_INTERNAL, "unexpected exception in okkt_factor_dev");
+  }
+}
+
+int okkt_factor(okkt_handle h, const double* nzval, int64_t n, int64_t m, int sym_kind, okkt_inertia* out) {
+  if (!h || (!nzval && h->S.nnz_in > 0)) return OKKT_ERR_INVALID;
+  try {
+    int rc = ensure_numeric(h);
+    if (rc != OKKT_OK) return rc;
+    if (h->S.nnz_in > 0) {
+      hipError_t he = hipMemcpyAsync(h->N.vals_owned, nzval, (size_t)h->S.nnz_in * sizeof(double), hipMemcpyHostToDevice, h->stream);
+      if (he != hipSuccess) return solver_set_error(h, OKKT_ERR_HIP, std::string("nzval upload: ") + hipGetErrorString(he));
+    }
+    return solver_factor_device(h, h->N.vals_owned, n, m, sym_kind, out);
+  } catch (...) {
+    return solver_set_error(h, OKKT_ERR_INTERNAL, "unexpected exception in okkt_factor");
+  }
+}
+
+int okkt_solve_dev(okkt_handle h, const double* d_rhs, double* d_sol, int64_t nrhs) {
+  if (!h || !d_rhs || !d_sol) return OKKT_ERR_INVALID;
+  try {
+    return solver_solve_device(h, d_rhs, d_sol, nrhs);
+  } catch (...) {
+    return solver_set_error(h, OKKT_ERR_INTERNAL, "unexpected exception in okkt_solve_dev");
+  }
+}
+
+int okkt_solve(okkt_handle h, const double* rhs, double* sol, int64_t nrhs) {
+  if (!h || !rhs || !sol) return OKKT_ERR_INVALID;
+  try {
+    int rc = ensure_numeric(h);
+    if (rc != OKKT_OK) return rc;
+    if (!h->factored) return solver_set_error(h, OKKT_ERR_INVALID, "solve called before a factorisation");
+    const int64_t len = h->S.n * std::max<int64_t>(nrhs, 0);
+    if (len == 0) return OKKT_OK;
+    if (h->rhs_stage_len < len) {
+      if (h->d_rhs_stage) (void)hipFree(h->d_rhs_stage);
+      h->d_rhs_stage = nullptr;
+      h->rhs_stage_len = 0;
+      if (hipMalloc((void**)&h->d_rhs_stage, (size_t)len * sizeof(double)) != hipSuccess)
+        return solver_set_error(h, OKKT_ERR_ALLOC, "rhs staging allocation failed");
+      h->rhs_stage_len = len;
+    }
+    hipError_t he = hipMemcpyAsync(h->d_rhs_stage, rhs, (size_t)len * sizeof(double), hipMemcpyHostToDevice, h->stream);
+    if (he != hipSuccess) return solver_set_error(h, OKKT_ERR_HIP, std::string("rhs upload: ") + hipGetErrorString(he));
+    rc = solver_solve_device(h, h->d_rhs_stage, h->d_rhs_stage, nrhs);
+    if (rc != OKKT_OK) return rc;
+    he = hipMemcpy(sol, h->d_rhs_stage, (size_t)len * sizeof(double), hipMemcpyDeviceToHost);
+    if (he != hipSuccess) return solver_set_error(h, OKKT_ERR_HIP, std::string("sol download: ") + hipGetErrorString(he));
+    return OKKT_OK;
+  } catch (...) {
+    return solver_set_error(h, OKKT_ERR_INTERNAL, "unexpected exception in okkt_solve");
+  }
+}
+
+int okkt_get_diag(okkt_handle h, double* d_out) {
+  if (!h || !d_out) return OKKT_ERR_INVALID;
+  int rc = ensure_numeric(h);
+  if (rc != OKKT_OK) return rc;
+  if (!h->factored) return solver_set_error(h, OKKT_ERR_INVALID, "no factorisation");
+  if (hipMemcpy(d_out, h->N.d.dvals, (size_t)h->S.n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
+    return solver_set_error(h, OKKT_ERR_HIP, "download of D failed");
+  return OKKT_OK;
+}
+
+int okkt_get_factor_csc(okkt_handle h, int64_t* colptr_out, int64_t* rowval_out, double* val_out, int64_t* nnz_out) {
+  if (!h) return OKKT_ERR_INVALID;
+  if (!h->analyzed) return solver_set_error(h, OKKT_ERR_INVALID, "not analysed");
+  const Symbolic& S = h->S;
+  const int64_t nnz = S.nnzL_stored - S.n;
+  if (nnz_out) *nnz_out = nnz;
+  if (!colptr_out || !rowval_out || !val_out) return OKKT_OK;
+  try {
+    int rc = ensure_numeric(h);
+    if (rc != OKKT_OK) return rc;
+    if (!h->factored) return solver_set_error(h, OKKT_ERR_INVALID, "no factorisation");
+    std::vector<double> front;
+    int64_t q = 0;
+    for (int s = 0; s < S.nsuper; ++s) {
+      const int64_t f = S.row_ptr[s + 1] - S.row_ptr[s];
+      const int64_t k = S.sn_col0[s + 1] - S.sn_col0[s];
+      front.resize((size_t)(f * k));
+      if (hipMemcpy(front.data(), h->N.d.arena + S.front_pos[s], (size_t)(f * k) * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
+        return solver_set_error(h, OKKT_ERR_HIP, "download of a front failed");
+      for (int64_t lc = 0; lc < k; ++lc) {
+        colptr_out[S.sn_col0[s] + lc] = q;
+        for (int64_t i = lc + 1; i < f; ++i) {
+          rowval_out[q] = S.rows[S.row_ptr[s] + i];
+          val_out[q] = front[(size_t)(lc * f + i)];
+          ++q;
+        }
+      }
+    }
+    colptr_out[S.n] = q;
+    return OKKT_OK;
+  } catch (...) {
+    return solver_set_error(h, OKKT_ERR_INTERNAL, "unexpected exception in okkt_get_factor_csc");
+  }
+}
+
+int okkt_dev_alloc(okkt_handle h, int64_t bytes, void** out) {
+  if (!h || !out || bytes < 0) return OKKT_ERR_INVALID;
+  int rc = ensure_device(h);
+  if (rc != OKKT_OK) return rc;
+  if (hipMalloc(out, (size_t)std::max<int64_t>(bytes, 8)) != hipSuccess) return solver_set_error(h, OKKT_ERR_ALLOC, "hipMalloc failed");
+  return OKKT_OK;
+}
+int okkt_dev_free(okkt_handle h, void* p) {
+  if (!h) return OKKT_ERR_INVALID;
+  int rc = ensure_device(h);
+  if (rc != OKKT_OK) return rc;
+  (void)hipStreamSynchronize(h->stream);
+  return hipFree(p) == hipSuccess ? OKKT_OK : solver_set_error(h, OKKT_ERR_HIP, "hipFree failed");
+}
+int okkt_dev_upload(okkt_handle h, void* d_dst, const void* src, int64_t bytes) {
+  if (!h || bytes < 0 || (bytes > 0 && (!d_dst || !src))) return OKKT_ERR_INVALID;
+  int rc = ensure_device(h);
+  if (rc != OKKT_OK) return rc;
+  if (bytes == 0) return OKKT_OK;
+  (void)hipStreamSynchronize(h->stream);
+  return hipMemcpy(d_dst, src, (size_t)bytes, hipMemcpyHostToDevice) == hipSuccess ? OKKT_OK : solver_set_error(h, OKKT_ERR_HIP, "upload failed");
+}
+int okkt_dev_download(okkt_handle h, void* dst, const void* d_src, int64_t bytes) {
+  if (!h || bytes < 0 || (bytes > 0 && (!dst || !d_src))) return OKKT_ERR_INVALID;
+  int rc = ensure_device(h);
+  if (rc != OKKT_OK) return rc;
+  if (bytes == 0) return OKKT_OK;
+  (void)hipStreamSynchronize(h->stream);
+  return hipMemcpy(dst, d_src, (size_t)bytes, hipMemcpyDeviceToHost) == hipSuccess ? OKKT_OK : solver_set_error(h, OKKT_ERR_HIP, "download failed");
+}
+void* okkt_get_stream(okkt_handle h) { return h ? (void*)h->stream : nullptr; }
+
+}  // extern "C"

@@ -1,0 +1,75 @@
+// Device-side plan and launchers of the numeric multifrontal LDL^T (HIP, gfx950).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "symbolic.h"
+
+namespace okkt {
+
+// Everything the kernels need, resident in HBM for the life of a pattern.
+struct DevPlan {
+  int n = 0, nsuper = 0;
+  int has_dup = 0;
+  // symbolic structure
+  int* sn_col0 = nullptr;
+  int64_t* row_ptr = nullptr;
+  int* rows = nullptr;
+  int64_t* front_pos = nullptr;
+  int64_t* child_ptr = nullptr;
+  int* children = nullptr;
+  int64_t* rel_ptr = nullptr;
+  int* rel = nullptr;
+  int64_t* cv_pos = nullptr;
+  int64_t* aent_ptr = nullptr;
+  int64_t* aent_src = nullptr;
+  int* aent_dst = nullptr;
+  int* perm = nullptr;
+  int* sched = nullptr;  // supernode ids grouped by (level, class)
+  // numeric state
+  double* arena = nullptr;    // all fronts, f x f column-major each
+  const double* vals = nullptr;  // caller's nzval in HBM
+  double* dvals = nullptr;    // D, permuted order
+  double* diagadd = nullptr;  // added to the diagonal at assembly (delta shift), permuted order
+  double* xwork = nullptr;    // permuted rhs / solution
+  double* cv = nullptr;       // solve contribution vectors
+  double* wbuf = nullptr;     // W = L21*D panels of the big fronts
+  int64_t* wbuf_pos = nullptr;  // [nsuper] offset of each big front's W panel, -1 for small fronts
+  unsigned long long* counters = nullptr;  // pos, neg, zero, nonfinite
+};
+
+// front classes by order f: 0: f<=32 (one wave), 1: f<=64, 2: f<=small_max (256 threads, LDS), 3: big
+constexpr int kNumClasses = 4;
+struct Segment { int off = 0, cnt = 0, maxf = 0, maxk = 0; };
+struct LevelSchedule { Segment seg[kNumClasses]; };
+
+struct Numeric {
+  DevPlan d;
+  std::vector<LevelSchedule> levels;
+  std::vector<void*> allocations;
+  int nb = 64;
+  int small_max = 128;
+  int64_t n_small = 0, n_big = 0;
+  hipStream_t stream = nullptr;
+  double* vals_owned = nullptr;  // staging buffer for host-side nzval
+  int64_t nnz_in = 0;
+};
+
+// returns "" or an error message
+std::string numeric_setup(const Symbolic& S, const SymbolicOptions& opts, hipStream_t stream, Numeric& N);
+void numeric_release(Numeric& N);
+
+// enqueue the whole numeric factorisation on N.stream (no sync); values read from d_vals
+std::string numeric_factor_enqueue(Numeric& N, const double* d_vals, double tol);
+// enqueue forward/diagonal/backward solves for the rhs already stored (permuted) in d.xwork
+std::string numeric_solve_enqueue(Numeric& N);
+// permute helpers: xwork[k] = rhs[perm[k]]  /  sol[perm[k]] = xwork[k]
+void launch_permute_in(const Numeric& N, const double* d_rhs);
+void launch_permute_out(const Numeric& N, double* d_sol);
+// diagadd[iperm] = (orig index < nshift) ? delta : 0, via perm
+void launch_set_shift(const Numeric& N, double delta, int64_t nshift);
+
+}  // namespace okkt

@@ -1,0 +1,38 @@
+// Internal C++ object behind okkt_handle.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/okkt.h"
+#include "numeric.h"
+#include "symbolic.h"
+
+struct okkt_solver_s {
+  okkt_opts opts;
+  okkt::SymbolicOptions sopts;
+  okkt::Symbolic S;
+  okkt::Numeric N;
+  bool analyzed = false;
+  bool factored = false;
+  bool device_ready = false;  // HIP device selected and stream created
+  bool numeric_ready = false; // device plan uploaded for the current pattern
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::vector<int64_t> user_perm;
+  std::string err;
+  double analyze_seconds = 0, last_factor_ms = 0, last_solve_ms = 0;
+  int64_t n_analyze_calls = 0;
+  double* d_rhs_stage = nullptr;  // staging for host-side rhs/sol
+  int64_t rhs_stage_len = 0;
+};
+
+namespace okkt {
+// shared by the linear-solver level and the KKT level
+int solver_factor_device(okkt_solver_s* h, const double* d_vals, int64_t n, int64_t m, int sym_kind,
+                         okkt_inertia* out);
+int solver_solve_device(okkt_solver_s* h, const double* d_rhs, double* d_sol, int64_t nrhs);
+int solver_set_error(okkt_solver_s* h, int code, const std::string& msg);
+}  // namespace okkt

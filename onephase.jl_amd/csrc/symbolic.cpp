@@ -1,0 +1,424 @@
+// Host symbolic analysis: ordering -> elimination tree -> postorder -> column counts ->
+// relaxed supernodes -> front layout, scatter maps, extend-add lists, level schedule.
+// See symbolic.h for the role of this step relative to the reference.
+#include "symbolic.h"
+
+#include <algorithm>
+#include <cstring>
+#include <numeric>
+
+namespace okkt {
+
+uint64_t hash_pattern(int64_t n, const int64_t* colptr, const int64_t* rowval) {
+  // FNV-1a over (n, colptr, rowval): identifies a sparsity pattern so that the
+  // reference-shaped ls_factor!(A, ...) call can skip re-analysis when only values changed.
+  uint64_t h = 1469598103934665603ull;
+  auto mix = [&h](uint64_t v) {
+    for (int b = 0; b < 8; ++b) { h ^= (v >> (8 * b)) & 0xffu; h *= 1099511628211ull; }
+  };
+  mix((uint64_t)n);
+  for (int64_t j = 0; j <= n; ++j) mix((uint64_t)colptr[j]);
+  const int64_t nnz = colptr[n] - colptr[0];
+  for (int64_t p = 0; p < nnz; ++p) mix((uint64_t)rowval[p]);
+  return h;
+}
+
+namespace {
+
+inline int64_t trapezoid(int64_t f, int64_t k) { return f * k - k * (k - 1) / 2; }
+
+}  // namespace
+
+std::string analyze_pattern(int64_t n64, const int64_t* colptr, const int64_t* rowval,
+                            int index_base, const SymbolicOptions& opts,
+                            const int64_t* user_perm, Symbolic& S) {
+  if (n64 < 0 || n64 > 0x7ffffff0) return "matrix order out of range";
+  if (index_base != 0 && index_base != 1) return "index_base must be 0 or 1";
+  const int n = (int)n64;
+  S = Symbolic();
+  S.n = n;
+  const int64_t base = index_base;
+  if (colptr[0] != base) return "colptr[0] does not equal index_base";
+  const int64_t nnz_in = colptr[n] - base;
+  S.nnz_in = nnz_in;
+  for (int j = 0; j < n; ++j)
+    if (colptr[j + 1] < colptr[j]) return "colptr is not non-decreasing";
+  for (int64_t p = 0; p < nnz_in; ++p) {
+    int64_t i = rowval[p] - base;
+    if (i < 0 || i >= n) return "row index out of range";
+  }
+  S.pattern_hash = hash_pattern(n, colptr, rowval);
+
+  // ---- strictly-lower pattern of the input, symmetrised, de-duplicated -> graph for ordering
+  std::vector<int64_t> gp(n + 1, 0);
+  std::vector<int> gi;
+  {
+    std::vector<int64_t> cnt(n, 0);
+    int64_t nlow = 0;
+    for (int j = 0; j < n; ++j)
+      for (int64_t p = colptr[j] - base; p < colptr[j + 1] - base; ++p) {
+        int i = (int)(rowval[p] - base);
+        if (i >= j) ++nlow;
+        if (i > j) { ++cnt[i]; ++cnt[j]; }
+      }
+    S.nnz_lower = nlow;
+    for (int i = 0; i < n; ++i) gp[i + 1] = gp[i] + cnt[i];
+    gi.resize(gp[n]);
+    std::vector<int64_t> fill(gp.begin(), gp.end() - 1);
+    for (int j = 0; j < n; ++j)
+      for (int64_t p = colptr[j] - base; p < colptr[j + 1] - base; ++p) {
+        int i = (int)(rowval[p] - base);
+        if (i > j) { gi[fill[i]++] = j; gi[fill[j]++] = i; }
+      }
+    // sort + unique each list
+    std::vector<int64_t> np(n + 1, 0);
+    int64_t out = 0;
+    for (int i = 0; i < n; ++i) {
+      std::sort(gi.begin() + gp[i], gi.begin() + gp[i + 1]);
+      int64_t start = out;
+      for (int64_t p = gp[i]; p < gp[i + 1]; ++p) {
+        if (out > start && gi[out - 1] == gi[p]) { S.has_duplicates = true; continue; }
+        gi[out++] = gi[p];
+      }
+      np[i + 1] = out;
+    }
+    gi.resize(out);
+    gp.swap(np);
+  }
+  // duplicates on the diagonal
+  {
+    for (int j = 0; j < n && !S.has_duplicates; ++j) {
+      int ndiag = 0;
+      for (int64_t p = colptr[j] - base; p < colptr[j + 1] - base; ++p)
+        if (rowval[p] - base == j) ++ndiag;
+      if (ndiag > 1) S.has_duplicates = true;
+    }
+  }
+
+  // ---- ordering
+  std::vector<int> order;
+  if (opts.ordering == 0) {
+    amd_order(n, gp, gi, order);
+  } else if (opts.ordering == 1) {
+    order.resize(n);
+    std::iota(order.begin(), order.end(), 0);
+  } else if (opts.ordering == 2) {
+    if (!user_perm) return "ordering=user but no permutation was supplied";
+    order.resize(n);
+    std::vector<char> seen(n, 0);
+    for (int k = 0; k < n; ++k) {
+      int64_t v = user_perm[k];
+      if (v < 0 || v >= n || seen[v]) return "user permutation is not a permutation of 0..n-1";
+      seen[v] = 1;
+      order[k] = (int)v;
+    }
+  } else {
+    return "unknown ordering option";
+  }
+  if ((int)order.size() != n) return "internal error: ordering length";
+  {
+    std::vector<char> seen(n, 0);
+    for (int v : order) { if (v < 0 || v >= n || seen[v]) return "internal error: ordering is not a permutation"; seen[v] = 1; }
+  }
+
+  // ---- elimination tree + column counts in the pre-postorder numbering
+  std::vector<int> ip0(n);
+  for (int k = 0; k < n; ++k) ip0[order[k]] = k;
+  auto build_lower = [&](const std::vector<int>& ip, std::vector<int64_t>& rp, std::vector<int>& ri,
+                         std::vector<int64_t>* cp, std::vector<int>* ci) {
+    // row lists (cols < row) and optionally column lists (rows > col) of the permuted pattern
+    rp.assign(n + 1, 0);
+    for (int i = 0; i < n; ++i)
+      for (int64_t p = gp[i]; p < gp[i + 1]; ++p) {
+        int j = gi[p];
+        if (j < i) { int a = ip[i], b = ip[j]; ++rp[std::max(a, b) + 1]; }
+      }
+    for (int i = 0; i < n; ++i) rp[i + 1] += rp[i];
+    ri.resize(rp[n]);
+    std::vector<int64_t> fill(rp.begin(), rp.end() - 1);
+    for (int i = 0; i < n; ++i)
+      for (int64_t p = gp[i]; p < gp[i + 1]; ++p) {
+        int j = gi[p];
+        if (j < i) { int a = ip[i], b = ip[j]; ri[fill[std::max(a, b)]++] = std::min(a, b); }
+      }
+    if (cp) {
+      cp->assign(n + 1, 0);
+      for (int64_t p = 0; p < rp[n]; ++p) ++(*cp)[ri[p] + 1];
+      for (int i = 0; i < n; ++i) (*cp)[i + 1] += (*cp)[i];
+      ci->resize(rp[n]);
+      std::vector<int64_t> f2(cp->begin(), cp->end() - 1);
+      for (int r = 0; r < n; ++r)
+        for (int64_t p = rp[r]; p < rp[r + 1]; ++p) (*ci)[f2[ri[p]]++] = r;  // rows ascending per column
+    }
+  };
+  auto etree_and_counts = [&](const std::vector<int64_t>& rp, const std::vector<int>& ri,
+                              std::vector<int>& parent, std::vector<int>& count) {
+    parent.assign(n, -1);
+    std::vector<int> anc(n, -1);
+    for (int i = 0; i < n; ++i)
+      for (int64_t p = rp[i]; p < rp[i + 1]; ++p) {
+        int k = ri[p];
+        while (k != -1 && k < i) {  // climb with path compression
+          int nxt = anc[k];
+          anc[k] = i;
+          if (nxt == -1) { parent[k] = i; break; }
+          k = nxt;
+        }
+      }
+    count.assign(n, 1);
+    std::vector<int> mark(n, -1);
+    for (int i = 0; i < n; ++i) {
+      mark[i] = i;
+      for (int64_t p = rp[i]; p < rp[i + 1]; ++p)
+        for (int k = ri[p]; mark[k] != i; k = parent[k]) { ++count[k]; mark[k] = i; }
+    }
+  };
+  std::vector<int64_t> rp, cp;
+  std::vector<int> ri, ci;
+  std::vector<int> parent0, count0;
+  build_lower(ip0, rp, ri, nullptr, nullptr);
+  etree_and_counts(rp, ri, parent0, count0);
+
+  // ---- postorder, heaviest child last (it is the amalgamation candidate of its parent)
+  std::vector<int> post;
+  post.reserve(n);
+  {
+    std::vector<int64_t> chp(n + 1, 0);
+    for (int j = 0; j < n; ++j) if (parent0[j] >= 0) ++chp[parent0[j] + 1];
+    for (int j = 0; j < n; ++j) chp[j + 1] += chp[j];
+    std::vector<int> ch(chp[n]);
+    std::vector<int64_t> fill(chp.begin(), chp.end() - 1);
+    for (int j = 0; j < n; ++j) if (parent0[j] >= 0) ch[fill[parent0[j]]++] = j;
+    for (int j = 0; j < n; ++j)
+      std::stable_sort(ch.begin() + chp[j], ch.begin() + chp[j + 1],
+                       [&](int a, int b) { return count0[a] < count0[b]; });
+    std::vector<int> stack;
+    std::vector<int64_t> next_child(n);
+    for (int j = 0; j < n; ++j) next_child[j] = chp[j];
+    std::vector<int> roots;
+    for (int j = 0; j < n; ++j) if (parent0[j] < 0) roots.push_back(j);
+    std::stable_sort(roots.begin(), roots.end(), [&](int a, int b) { return count0[a] < count0[b]; });
+    for (int r : roots) {
+      stack.push_back(r);
+      while (!stack.empty()) {
+        int v = stack.back();
+        if (next_child[v] < chp[v + 1]) stack.push_back(ch[next_child[v]++]);
+        else { post.push_back(v); stack.pop_back(); }
+      }
+    }
+  }
+  S.perm.resize(n);
+  S.iperm.resize(n);
+  for (int k = 0; k < n; ++k) { S.perm[k] = order[post[k]]; S.iperm[S.perm[k]] = k; }
+  build_lower(S.iperm, rp, ri, &cp, &ci);
+  etree_and_counts(rp, ri, S.parent, S.colcount);
+  const std::vector<int>& parent = S.parent;
+  const std::vector<int>& cc = S.colcount;
+  for (int j = 0; j < n; ++j) { S.nnzL += cc[j]; S.flops_exact += (double)cc[j] * cc[j]; }
+
+  // ---- fundamental supernodes, then relaxed amalgamation of (last child -> parent) chains
+  std::vector<int> col0;  // first column of each supernode
+  col0.reserve(n + 1);
+  for (int j = 0; j < n; ++j) {
+    bool join = j > 0 && parent[j - 1] == j && cc[j - 1] == cc[j] + 1;
+    if (!join) col0.push_back(j);
+  }
+  col0.push_back(n);
+  {
+    int ns = (int)col0.size() - 1;
+    std::vector<int> start(ns), width(ns);
+    std::vector<int64_t> truennz(ns);
+    std::vector<char> alive(ns, 1);
+    for (int s = 0; s < ns; ++s) {
+      start[s] = col0[s];
+      width[s] = col0[s + 1] - col0[s];
+      int64_t t = 0;
+      for (int j = col0[s]; j < col0[s + 1]; ++j) t += cc[j];
+      truennz[s] = t;
+    }
+    for (int s = 0; s + 1 < ns; ++s) {
+      int last = col0[s + 1] - 1;
+      if (parent[last] != last + 1) continue;  // parent supernode is not the next one
+      int p = s + 1;
+      int64_t kc = width[s], kp = width[p];
+      int64_t fp = cc[col0[p]];  // front order of the parent: count of its first column
+      int64_t fm = kc + fp, km = kc + kp;
+      int64_t stored = trapezoid(fm, km);
+      int64_t tn = truennz[s] + truennz[p];
+      double z = stored > 0 ? (double)(stored - tn) / (double)stored : 0.0;
+      bool merge = km <= opts.relax_always || (km <= opts.relax_small && z < opts.relax_small_frac) ||
+                   (km <= opts.relax_mid && z < opts.relax_mid_frac) || z < opts.relax_any_frac;
+      if (!merge) continue;
+      alive[s] = 0;
+      start[p] = start[s];
+      width[p] = (int)km;
+      truennz[p] = tn;
+    }
+    std::vector<int> merged;
+    for (int s = 0; s < ns; ++s) if (alive[s]) merged.push_back(start[s]);
+    merged.push_back(n);
+    col0.swap(merged);
+  }
+  const int ns = (int)col0.size() - 1;
+  S.nsuper = ns;
+  S.sn_col0 = col0;
+  S.col2sn.resize(n);
+  for (int s = 0; s < ns; ++s)
+    for (int j = col0[s]; j < col0[s + 1]; ++j) S.col2sn[j] = s;
+  S.sn_parent.assign(ns, -1);
+  for (int s = 0; s < ns; ++s) {
+    int pj = parent[col0[s + 1] - 1];
+    S.sn_parent[s] = pj >= 0 ? S.col2sn[pj] : -1;
+  }
+  S.child_ptr.assign(ns + 1, 0);
+  for (int s = 0; s < ns; ++s) if (S.sn_parent[s] >= 0) ++S.child_ptr[S.sn_parent[s] + 1];
+  for (int s = 0; s < ns; ++s) S.child_ptr[s + 1] += S.child_ptr[s];
+  S.children.resize(S.child_ptr[ns]);
+  {
+    std::vector<int64_t> fill(S.child_ptr.begin(), S.child_ptr.end() - 1);
+    for (int s = 0; s < ns; ++s) if (S.sn_parent[s] >= 0) S.children[fill[S.sn_parent[s]]++] = s;
+  }
+
+  // ---- row structure of every front (sorted union of A's columns and the children's rows)
+  S.row_ptr.assign(ns + 1, 0);
+  S.rows.clear();
+  S.rows.reserve((size_t)S.nnzL / 2 + n);
+  {
+    std::vector<int> mark(n, -1);
+    std::vector<int> extra;
+    for (int s = 0; s < ns; ++s) {
+      const int c0 = col0[s], c1 = col0[s + 1], last = c1 - 1;
+      extra.clear();
+      for (int j = c0; j < c1; ++j)
+        for (int64_t p = cp[j]; p < cp[j + 1]; ++p) {
+          int i = ci[p];
+          if (i > last && mark[i] != s) { mark[i] = s; extra.push_back(i); }
+        }
+      for (int64_t q = S.child_ptr[s]; q < S.child_ptr[s + 1]; ++q) {
+        int c = S.children[q];
+        int kc = col0[c + 1] - col0[c];
+        for (int64_t p = S.row_ptr[c] + kc; p < S.row_ptr[c + 1]; ++p) {
+          int i = S.rows[p];
+          if (i > last && mark[i] != s) { mark[i] = s; extra.push_back(i); }
+        }
+      }
+      std::sort(extra.begin(), extra.end());
+      for (int j = c0; j < c1; ++j) S.rows.push_back(j);
+      S.rows.insert(S.rows.end(), extra.begin(), extra.end());
+      S.row_ptr[s + 1] = (int64_t)S.rows.size();
+      if ((int)extra.size() != cc[last] - 1) return "internal error: supernode row structure mismatch";
+    }
+  }
+
+  // ---- front layout, relative indices, solve workspaces, statistics
+  S.front_pos.assign(ns + 1, 0);
+  S.rel_ptr.assign(ns + 1, 0);
+  S.cv_pos.assign(ns + 1, 0);
+  for (int s = 0; s < ns; ++s) {
+    int64_t f = S.row_ptr[s + 1] - S.row_ptr[s];
+    int64_t k = col0[s + 1] - col0[s];
+    int64_t r = f - k;
+    int64_t sz = (f * f + 1) & ~(int64_t)1;  // keep every front 16-byte aligned
+    S.front_pos[s + 1] = S.front_pos[s] + sz;
+    S.rel_ptr[s + 1] = S.rel_ptr[s] + r;
+    S.cv_pos[s + 1] = S.cv_pos[s] + r;
+    S.nnzL_stored += trapezoid(f, k);
+    for (int64_t j = 0; j < k; ++j) S.flops_stored += (double)(f - j) * (double)(f - j);
+    S.max_front = std::max<int>(S.max_front, (int)f);
+    S.sum_r += r;
+  }
+  S.arena_doubles = S.front_pos[ns];
+  S.rel.resize(S.rel_ptr[ns]);
+  for (int s = 0; s < ns; ++s) {
+    int p = S.sn_parent[s];
+    if (p < 0) continue;
+    int k = col0[s + 1] - col0[s];
+    const int* mine = &S.rows[S.row_ptr[s] + k];
+    int64_t r = S.row_ptr[s + 1] - S.row_ptr[s] - k;
+    const int* theirs = &S.rows[S.row_ptr[p]];
+    int64_t fp = S.row_ptr[p + 1] - S.row_ptr[p];
+    int64_t q = 0;
+    for (int64_t i = 0; i < r; ++i) {
+      while (q < fp && theirs[q] < mine[i]) ++q;
+      if (q >= fp || theirs[q] != mine[i]) return "internal error: child row missing from parent front";
+      S.rel[S.rel_ptr[s] + i] = (int)q;
+    }
+  }
+
+  // ---- scatter maps from the caller's nzval into the front arena
+  S.amap.assign(nnz_in, -1);
+  S.diag_pos.assign(n, -1);
+  for (int j = 0; j < n; ++j) {
+    int c = S.iperm[j];
+    int s = S.col2sn[c];
+    int64_t f = S.row_ptr[s + 1] - S.row_ptr[s];
+    int64_t lc = c - col0[s];
+    S.diag_pos[j] = S.front_pos[s] + lc * f + lc;
+  }
+  {
+    std::vector<int64_t> cnt(ns + 1, 0);
+    for (int j = 0; j < n; ++j)
+      for (int64_t p = colptr[j] - base; p < colptr[j + 1] - base; ++p) {
+        int i = (int)(rowval[p] - base);
+        if (i < j) continue;  // upper-triangle entries are ignored (Symmetric(A,:L) in the reference)
+        int a = S.iperm[i], b = S.iperm[j];
+        int c = std::min(a, b), r = std::max(a, b);
+        int s = S.col2sn[c];
+        const int* rb = &S.rows[S.row_ptr[s]];
+        const int* re = &S.rows[S.row_ptr[s + 1]];
+        const int* it = std::lower_bound(rb, re, r);
+        if (it == re || *it != r) return "internal error: entry outside the symbolic structure";
+        int64_t f = re - rb;
+        int64_t off = (int64_t)(c - col0[s]) * f + (it - rb);
+        S.amap[p] = S.front_pos[s] + off;
+        ++cnt[s + 1];
+      }
+    S.aent_ptr.assign(ns + 1, 0);
+    for (int s = 0; s < ns; ++s) S.aent_ptr[s + 1] = S.aent_ptr[s] + cnt[s + 1];
+    S.aent_src.resize(S.aent_ptr[ns]);
+    S.aent_dst.resize(S.aent_ptr[ns]);
+    std::vector<int64_t> fill(S.aent_ptr.begin(), S.aent_ptr.end() - 1);
+    for (int64_t p = 0; p < nnz_in; ++p) {
+      int64_t off = S.amap[p];
+      if (off < 0) continue;
+      // locate the destination supernode from the arena offset
+      int s = (int)(std::upper_bound(S.front_pos.begin(), S.front_pos.end(), off) - S.front_pos.begin()) - 1;
+      int64_t q = fill[s]++;
+      S.aent_src[q] = p;
+      S.aent_dst[q] = (int)(off - S.front_pos[s]);
+    }
+    // inside a supernode keep the entries sorted by destination: the big-front assemble kernel
+    // locates the entries of a column block by binary search
+    std::vector<std::pair<int, int64_t>> tmp;
+    for (int s = 0; s < ns; ++s) {
+      const int64_t e0 = S.aent_ptr[s], e1 = S.aent_ptr[s + 1];
+      bool sorted = true;
+      for (int64_t e = e0 + 1; e < e1; ++e) if (S.aent_dst[e - 1] > S.aent_dst[e]) { sorted = false; break; }
+      if (sorted) continue;
+      tmp.clear();
+      for (int64_t e = e0; e < e1; ++e) tmp.emplace_back(S.aent_dst[e], S.aent_src[e]);
+      std::stable_sort(tmp.begin(), tmp.end());
+      for (int64_t e = e0; e < e1; ++e) { S.aent_dst[e] = tmp[e - e0].first; S.aent_src[e] = tmp[e - e0].second; }
+    }
+  }
+
+  // ---- level schedule (height above the leaves)
+  S.sn_level.assign(ns, 0);
+  for (int s = 0; s < ns; ++s) {
+    int p = S.sn_parent[s];
+    if (p >= 0) S.sn_level[p] = std::max(S.sn_level[p], S.sn_level[s] + 1);
+  }
+  S.nlevels = 0;
+  for (int s = 0; s < ns; ++s) S.nlevels = std::max(S.nlevels, S.sn_level[s] + 1);
+  S.level_ptr.assign(S.nlevels + 1, 0);
+  for (int s = 0; s < ns; ++s) ++S.level_ptr[S.sn_level[s] + 1];
+  for (int l = 0; l < S.nlevels; ++l) S.level_ptr[l + 1] += S.level_ptr[l];
+  S.level_sn.resize(ns);
+  {
+    std::vector<int> fill(S.level_ptr.begin(), S.level_ptr.end() - 1);
+    for (int s = 0; s < ns; ++s) S.level_sn[fill[S.sn_level[s]]++] = s;
+  }
+  return "";
+}
+
+}  // namespace okkt

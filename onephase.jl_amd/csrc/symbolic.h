@@ -1,0 +1,95 @@
+// Host-side symbolic analysis for the supernodal multifrontal LDL^T engine.
+//
+// What CHOLMOD's "analyze" step does for the reference on every ls_factor! call
+// (/root/reference/src/linear_system_solvers/julia.jl:34,52 -> cholesky/ldlt ->
+// cholmod_analyze: AMD ordering, elimination tree, postorder, column counts,
+// supernodes) is done here ONCE per sparsity pattern.  The result is a static plan
+// (front layout in HBM, scatter maps, extend-add index lists, level schedule) that the
+// HIP numeric kernels replay for every delta-shift refactorisation.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace okkt {
+
+void amd_order(int n, const std::vector<int64_t>& ap, const std::vector<int>& ai,
+               std::vector<int>& order);
+
+struct SymbolicOptions {
+  int ordering = 0;        // 0 = AMD, 1 = natural, 2 = user permutation
+  int relax_always = 8;    // merge a child into its parent when the merged width <= this
+  int relax_small = 32;    // ... or when width <= relax_small and zero fraction < relax_small_frac
+  double relax_small_frac = 0.5;
+  int relax_mid = 96;
+  double relax_mid_frac = 0.15;
+  double relax_any_frac = 0.03;
+  int small_front_max = 64;  // fronts of order <= this take the LDS-resident kernel
+  int panel_nb = 64;         // block-column width of the big-front kernels
+};
+
+// One supernode == one frontal matrix of order f = k + r:
+//   k pivot columns  [col0, col0+k)   (permuted numbering, contiguous)
+//   r off-diagonal rows (ancestors' columns), sorted ascending
+// The front is a dense column-major f x f buffer at front_pos (lower triangle used);
+// its first k columns become the L panel (unit diagonal implied, D on the diagonal),
+// its trailing r x r block is the contribution (update) block passed to the parent.
+struct Symbolic {
+  int64_t n = 0;          // matrix order
+  int64_t nnz_in = 0;     // entries in the caller's CSC (all, incl. ignored upper ones)
+  int64_t nnz_lower = 0;  // entries with row >= col (the ones that are used)
+  bool has_duplicates = false;
+
+  std::vector<int> perm;   // perm[new] = old
+  std::vector<int> iperm;  // iperm[old] = new
+  std::vector<int> parent; // column elimination tree (permuted numbering)
+  std::vector<int> colcount;  // nnz of each column of L incl. diagonal (before relaxation)
+
+  int nsuper = 0;
+  std::vector<int> sn_col0;     // [nsuper+1] first column of each supernode
+  std::vector<int> sn_parent;   // [nsuper] parent supernode or -1
+  std::vector<int> sn_level;    // [nsuper] height above the leaves
+  std::vector<int> col2sn;      // [n]
+  std::vector<int64_t> row_ptr; // [nsuper+1] into rows
+  std::vector<int> rows;        // front row lists (global permuted indices), first k are the columns
+  std::vector<int64_t> front_pos;  // [nsuper+1] offsets (in doubles) of the f x f buffers
+  std::vector<int64_t> child_ptr;  // [nsuper+1]
+  std::vector<int> children;       // child supernodes grouped by parent, ascending
+  std::vector<int64_t> rel_ptr;    // [nsuper+1] into rel (length r of each supernode)
+  std::vector<int> rel;            // position of each off-diagonal row inside the parent's front
+  std::vector<int64_t> cv_pos;     // [nsuper+1] offsets of the solve contribution vectors (length r)
+
+  // scatter of the caller's values into the fronts
+  std::vector<int64_t> amap;     // [nnz_in] destination offset in the front arena, -1 = ignored
+  std::vector<int64_t> diag_pos; // [n] arena offset of the diagonal entry of ORIGINAL index i
+  // the same, grouped by destination supernode (for the fused assemble-in-LDS kernel)
+  std::vector<int64_t> aent_ptr; // [nsuper+1]
+  std::vector<int64_t> aent_src; // source index into nzval
+  std::vector<int> aent_dst;     // local offset lrow + lcol * f inside the front
+
+  // level schedule: supernodes ordered by level
+  int nlevels = 0;
+  std::vector<int> level_ptr;    // [nlevels+1] into level_sn
+  std::vector<int> level_sn;
+
+  // statistics (algorithmic work)
+  int64_t nnzL = 0;          // sum_j colcount_j (exact structure, no relaxation zeros)
+  int64_t nnzL_stored = 0;   // sum_s (f*k - k(k-1)/2): panel entries incl. relaxation zeros
+  double flops_exact = 0;    // sum_j colcount_j^2
+  double flops_stored = 0;   // dense-front flops actually executed
+  int64_t arena_doubles = 0; // sum_s f^2
+  int64_t sum_r = 0;
+  int max_front = 0;
+  uint64_t pattern_hash = 0;
+};
+
+// colptr/rowval: CSC of a square matrix in either index base; only row >= col is used.
+// user_perm (size n, perm[new]=old, 0-based) is read when opts.ordering == 2.
+// Returns "" on success, otherwise an error message.
+std::string analyze_pattern(int64_t n, const int64_t* colptr, const int64_t* rowval,
+                            int index_base, const SymbolicOptions& opts,
+                            const int64_t* user_perm, Symbolic& S);
+
+uint64_t hash_pattern(int64_t n, const int64_t* colptr, const int64_t* rowval);
+
+}  // namespace okkt

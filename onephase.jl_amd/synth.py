@@ -1,0 +1,125 @@
+"""Seeded synthetic KKT inputs.
+
+The reference's real inputs (CUTEst SIF files, Netlib lpi_*.mat) are not in the repository and
+cannot be loaded here, so the path is exercised on generated (H, J, s, y) with the layouts the
+reference's iterate cache uses (/root/reference/src/utils/Class_iterate.jl:4-20): H is n x n,
+LOWER TRIANGLE ONLY (Class_cutest.jl:548), J is m x n, s, y > 0.
+
+Locality model: variable i couples to columns i + round(N(0, w)); a fraction p_far of the
+couplings is uniformly random, which controls fill.
+"""
+import numpy as np
+import scipy.sparse as sp
+
+CONFIGS = {
+    # name: n, m, J nnz/row, tril(H) nnz/col (incl. diagonal)
+    "S-metric": dict(n=40_000, m=60_000, j_per_row=24, h_per_col=10),
+    "S-C3": dict(n=10_000, m=20_000, j_per_row=20, h_per_col=8),
+    "S-small": dict(n=400, m=600, j_per_row=6, h_per_col=4),
+    "S-tiny": dict(n=40, m=60, j_per_row=4, h_per_col=3),
+}
+
+
+def _local_cols(rng, centers, per, ncols, w, p_far):
+    """`per` column indices for every center (may repeat; duplicates are merged later)."""
+    k = len(centers)
+    off = np.rint(rng.normal(0.0, w, size=(k, per))).astype(np.int64)
+    cols = centers[:, None] + off
+    far = rng.random((k, per)) < p_far
+    cols = np.where(far, rng.integers(0, ncols, size=(k, per)), cols)
+    return np.clip(cols, 0, ncols - 1)
+
+
+def make_problem(n, m, j_per_row=8, h_per_col=4, w=50.0, p_far=0.01, seed=0, convex=True,
+                 neg_shift=0.0, mu=1e-2):
+    """Returns dict(H=csc lower, J=csc, s, y, mu, n, m)."""
+    rng = np.random.default_rng(seed)
+    # J: row r is centred on column ~ r * n / m
+    centers = (np.arange(m, dtype=np.int64) * n) // max(m, 1)
+    jc = _local_cols(rng, centers, j_per_row, n, w, p_far)
+    jr = np.repeat(np.arange(m, dtype=np.int64), j_per_row)
+    jv = rng.normal(size=m * j_per_row)
+    J = sp.coo_matrix((jv, (jr, jc.ravel())), shape=(m, n)).tocsc()
+    J.sum_duplicates()
+    J.sort_indices()
+    # H: strictly lower couplings + diagonal
+    hp = max(h_per_col - 1, 0)
+    if hp > 0:
+        hc = np.repeat(np.arange(n, dtype=np.int64), hp)
+        hr = _local_cols(rng, np.arange(n, dtype=np.int64), hp, n, w, p_far).ravel()
+        lo = np.minimum(hr, hc)
+        hi = np.maximum(hr, hc)
+        keep = hi != lo
+        hv = rng.normal(size=keep.sum())
+        Hoff = sp.coo_matrix((hv, (hi[keep], lo[keep])), shape=(n, n)).tocsc()
+        Hoff.sum_duplicates()
+    else:
+        Hoff = sp.csc_matrix((n, n))
+    absrow = np.asarray(abs(Hoff).sum(axis=0)).ravel() + np.asarray(abs(Hoff).sum(axis=1)).ravel()
+    if convex:
+        d = absrow + 1.0 + rng.random(n)
+    else:
+        d = rng.normal(size=n)
+    d = d - neg_shift
+    H = (Hoff + sp.diags(d, format="csc")).tocsc()
+    H.sort_indices()
+    # s, y: log-uniform slack, complementarity products spread around mu (parameters.jl:97)
+    s = np.exp(rng.uniform(np.log(1e-4), np.log(1e2), size=m))
+    y = mu * np.exp(rng.uniform(np.log(1e-2), np.log(1e2), size=m)) / s
+    return dict(H=H, J=J, s=s, y=y, mu=mu, n=n, m=m)
+
+
+def make_config(name, seed=0, **over):
+    cfg = dict(CONFIGS[name])
+    cfg.update(over)
+    return make_problem(seed=seed, **cfg)
+
+
+def augmented_matrix(prob, delta=0.0, with_upper=True):
+    """K = [[H + delta I, J'], [J, -diag(s/y)]] as CSC (symmetric.jl:35-53).  H stays lower-only;
+    with_upper=True keeps the J' block exactly like the reference's hvcat (it is ignored by the
+    factorisation, Symmetric(K,:L))."""
+    H, J, s, y, n, m = prob["H"], prob["J"], prob["s"], prob["y"], prob["n"], prob["m"]
+    Hd = H + sp.diags(np.full(n, delta), format="csc") if delta != 0.0 else H
+    B = sp.diags(-s / y, format="csc")
+    top = sp.hstack([Hd, J.T if with_upper else sp.csc_matrix((n, m))], format="csc")
+    bot = sp.hstack([J, B], format="csc")
+    K = sp.vstack([top, bot], format="csc")
+    K.sort_indices()
+    return K
+
+
+def schur_matrix(prob, delta=0.0):
+    """Q = J' diag(y/s) J + H (+ delta I): full-symmetric J'SJ plus lower-only H (schur.jl:55)."""
+    H, J, s, y, n = prob["H"], prob["J"], prob["s"], prob["y"], prob["n"]
+    Q = (J.T @ sp.diags(y / s) @ J + H).tocsc()
+    if delta != 0.0:
+        Q = (Q + sp.diags(np.full(n, delta))).tocsc()
+    Q.sort_indices()
+    return Q
+
+
+def symmetrize_lower(A):
+    """Full symmetric matrix from the lower triangle of A (what Symmetric(A,:L) means)."""
+    L = sp.tril(A, format="csc")
+    return (L + sp.tril(A, -1, format="csc").T).tocsc()
+
+
+def block_angular(nblocks=8, n_b=5000, m_b=7500, n_link=200, seed=0, **kw):
+    """S-C5: independent diagonal blocks + linking columns that couple all blocks."""
+    rng = np.random.default_rng(seed + 1000)
+    Hs, Js, ss, ys = [], [], [], []
+    for b in range(nblocks):
+        p = make_problem(n_b, m_b, seed=seed * 100 + b, **kw)
+        Hs.append(p["H"]); Js.append(p["J"]); ss.append(p["s"]); ys.append(p["y"])
+    n = nblocks * n_b + n_link
+    m = nblocks * m_b
+    H = sp.block_diag(Hs + [sp.diags(1.0 + rng.random(n_link))], format="csc")
+    Jb = sp.block_diag(Js, format="csc")
+    # each linking column touches ~0.2% of the rows of every block
+    dens = 0.002
+    link = sp.random(m, n_link, density=dens, random_state=np.random.RandomState(seed + 7), format="csc",
+                     data_rvs=lambda k: rng.normal(size=k))
+    J = sp.hstack([Jb, link], format="csc")
+    J.sort_indices()
+    return dict(H=H.tocsc(), J=J, s=np.concatenate(ss), y=np.concatenate(ys), mu=1e-2, n=n, m=m)

@@ -1,0 +1,334 @@
+"""CPU ORACLE (test infrastructure): restatement of the reference's KKT-system layer with scipy.
+
+Follows, function by function:
+  /root/reference/src/kkt_system_solver/kkt_system_solver.jl:27-47,67-113,167-204,291-300
+  /root/reference/src/kkt_system_solver/schur.jl:47-182
+  /root/reference/src/kkt_system_solver/symmetric.jl:35-102
+  /root/reference/src/kkt_system_solver/system_rhs.jl:3-24,57-73
+  /root/reference/src/IPM/delta_strategy.jl:37-121
+  /root/reference/src/utils/eval.jl:53-63,85-108,136-142,221-234
+Linear algebra underneath = oracle.linear_solver_ORACLE (C up-looking LDL^T).
+"""
+import math
+from dataclasses import dataclass, field
+
+import numpy as np
+import scipy.sparse as sp
+
+from . import linear_solver_ORACLE
+
+
+@dataclass
+class Iterate:
+    """Class_iterate + Class_cache subset (Class_iterate.jl:4-20,40-84; Class_point.jl:1-12)."""
+    x: np.ndarray
+    y: np.ndarray
+    s: np.ndarray
+    mu: float
+    J: sp.csc_matrix            # m x n
+    H: sp.csc_matrix            # n x n, LOWER TRIANGLE ONLY (Class_cutest.jl:548)
+    grad: np.ndarray            # gradient of f
+    cons: np.ndarray            # a(x)
+    a_norm_penalty_par: float = 1e-4
+    delta: float = 0.0
+    primal_scale: float = 1.0
+
+    def dim(self):
+        return len(self.x)
+
+    def ncon(self):
+        return len(self.s)
+
+
+@dataclass
+class Class_reduction_factors:  # system_rhs.jl:3-13
+    P: float = math.nan
+    D: float = math.nan
+    mu: float = math.nan
+
+
+def Reduct_affine():  # system_rhs.jl:16-19
+    return Class_reduction_factors(0.0, 0.0, 0.0)
+
+
+def Reduct_stable():  # system_rhs.jl:21-24
+    return Class_reduction_factors(1.0, 0.0, 1.0)
+
+
+# ---- eval.jl subset
+def eval_jac_prod(it, x):  # eval.jl:102-104
+    return it.J @ x
+
+
+def eval_jac_T_prod(it, y):  # eval.jl:106-108
+    return it.J.T @ y
+
+
+def vector_product(Lmat, v):  # eval.jl:221-230
+    return Lmat @ v + Lmat.T @ v - Lmat.diagonal() * v
+
+
+def hess_product(it, v):  # eval.jl:232-234
+    return vector_product(it.H, v)
+
+
+def eval_grad_r(it):  # eval.jl:59-63
+    return it.a_norm_penalty_par * eval_jac_T_prod(it, np.ones(it.ncon()))
+
+
+def eval_grad_lag(it, mu, y=None):  # eval.jl:136-142
+    y = it.y if y is None else y
+    return it.grad - eval_jac_T_prod(it, y) + mu * eval_grad_r(it)
+
+
+def eval_J_T_J(it, diag_vals):  # eval.jl:85-87
+    return (it.J.T @ sp.diags(diag_vals) @ it.J).tocsc()
+
+
+def eval_diag_J_T_J(it, diag_vals):  # eval.jl:89-100
+    J2 = it.J.copy()
+    J2.data = J2.data ** 2
+    return np.asarray(J2.T @ diag_vals).ravel()
+
+
+def compute_schur_diag(it):  # kkt_system_solver.jl:296-300
+    return it.H.diagonal() + eval_diag_J_T_J(it, it.y / it.s)
+
+
+@dataclass
+class System_rhs:  # system_rhs.jl:34-73
+    dual_r: np.ndarray
+    primal_r: np.ndarray
+    comp_r: np.ndarray
+
+    @staticmethod
+    def build(it, reduct):
+        dual_target = -eval_grad_lag(it, it.mu * reduct.mu) * (1.0 - reduct.D)
+        primal_target = -(it.cons - it.s) * (1.0 - reduct.P)
+        mu_target = it.mu * reduct.mu
+        return System_rhs(dual_target, primal_target, mu_target - it.s * it.y)
+
+
+@dataclass
+class Class_kkt_error:  # kkt_system_solver.jl:49-65
+    error_D: float = 0.0
+    error_P: float = 0.0
+    error_mu: float = 0.0
+    overall: float = 0.0
+    rhs_norm: float = 0.0
+    ratio: float = 0.0
+
+
+@dataclass
+class Direction:  # Class_point as a direction
+    x: np.ndarray
+    y: np.ndarray
+    s: np.ndarray
+    mu: float = 0.0
+    primal_scale: float = 0.0
+
+
+@dataclass
+class KKTPars:
+    ItRefine_Num: int = 3          # parameters.jl:20
+    delta_start: float = 1e-6      # parameters.jl:147-158
+    delta_min: float = 1e-12
+    delta_max: float = 1e50
+    delta_inc: float = 8.0
+    delta_dec: float = 1.0 / math.pi
+    delta_zero: float = 0.0
+
+
+class _KKTBase:
+    def __init__(self, ls_solver, pars=None):
+        self.ls_solver = ls_solver
+        self.pars = pars or KKTPars()
+        self.ready = "not_ready"
+        self.kkt_err_norm = Class_kkt_error()
+        self.factor_it = None
+        self.dir = None
+        self.rhs = None
+        self.Q = None
+
+    # kkt_system_solver.jl:21-25
+    def initialize_b(self, it):
+        self.dir = Direction(np.zeros(it.dim()), np.zeros(it.ncon()), np.zeros(it.ncon()))
+
+    # kkt_system_solver.jl:109-113
+    def update_delta_b(self, delta_x, delta_s):
+        delta_x_vec = delta_x * np.ones(self.factor_it.dim())
+        delta_s_vec = delta_s * self.factor_it.s ** (-2.0)
+        self.update_delta_vecs_b(delta_x_vec, delta_s_vec)
+
+    # kkt_system_solver.jl:98-107,190-204
+    def factor_b(self, delta_x=None, delta_s=0.0):
+        if delta_x is not None:
+            self.update_delta_b(delta_x, delta_s)
+        if self.ready != "delta_updated":
+            raise RuntimeError(f"kkt solver not ready to factor kkt_solver.ready = {self.ready} != :delta_updated")
+        self.ready = "factored"
+        return self.factor_implementation_b()
+
+    # kkt_system_solver.jl:167-176
+    def kkt_associate_rhs_b(self, it, eta):
+        self.rhs = System_rhs.build(it, eta)
+        self.dir.mu = -(1.0 - eta.mu) * it.mu
+        self.dir.primal_scale = -(1.0 - eta.P) * it.primal_scale
+
+    # kkt_system_solver.jl:178-188
+    def compute_direction_b(self):
+        if self.ready != "factored":
+            raise RuntimeError("kkt solver not ready to compute direction!")
+        self.compute_direction_implementation_b()
+        for v in (self.dir.x, self.dir.y, self.dir.s):
+            if not np.all(np.isfinite(v)):
+                raise FloatingPointError("NaN in direction")  # check_for_nan, IPM_tools.jl:32-49
+
+    # kkt_system_solver.jl:27-47
+    def predicted_lag_change(self):
+        fi = self.factor_it
+        tmp1 = eval_jac_prod(fi, self.dir.x)
+        tmp2 = self.delta_s_vec * tmp1
+        tmp3 = eval_jac_T_prod(fi, tmp2)
+        delta_err = self.delta_x_vec * self.dir.x + tmp3
+        J_err = eval_jac_T_prod(fi, self.dir.y)
+        H_err = hess_product(fi, self.dir.x)
+        return delta_err + H_err - J_err
+
+    # kkt_system_solver.jl:67-96 (p = Inf)
+    def update_kkt_error_b(self):
+        fi, rhs, d = self.factor_it, self.rhs, self.dir
+        error_D = self.predicted_lag_change() - rhs.dual_r
+        error_P = eval_jac_prod(fi, d.x) - d.s - rhs.primal_r
+        error_mu = fi.s * d.y + fi.y * d.s - rhs.comp_r
+        inf = lambda v: float(np.max(np.abs(v))) if len(v) else 0.0
+        overall = max(inf(error_D), inf(error_P), inf(error_mu))
+        rhs_norm = max(inf(rhs.dual_r), inf(rhs.primal_r), inf(rhs.comp_r))
+        self.kkt_err_norm = Class_kkt_error(inf(error_D), inf(error_P), inf(error_mu), overall, rhs_norm,
+                                            overall / rhs_norm if rhs_norm != 0 else math.inf if overall > 0 else math.nan)
+
+    def diag_min(self):  # kkt_system_solver.jl:291-294
+        return float(np.min(self.schur_diag))
+
+
+class Schur_KKT_solver(_KKTBase):
+    """schur.jl:3-182"""
+
+    def form_system_b(self, it):  # schur.jl:47-62
+        self.Q = (eval_J_T_J(it, it.y / it.s) + it.H).tolil()
+        self.schur_diag = np.asarray(self.Q.diagonal()).copy()
+        self.factor_it = it
+        self.ready = "system_formed"
+
+    def update_delta_vecs_b(self, delta_x_vec, delta_s_vec):  # schur.jl:64-83
+        self.delta_x_vec, self.delta_s_vec = delta_x_vec, delta_s_vec
+        if np.sum(np.abs(delta_s_vec)) > 0.0:
+            raise NotImplementedError("Not implemented")
+        self.Q.setdiag(self.schur_diag + delta_x_vec)
+        self.ready = "delta_updated"
+
+    def factor_implementation_b(self):  # schur.jl:85-87
+        return self.ls_solver.ls_factor_b(self.Q.tocsc(), self.factor_it.dim(), 0)
+
+    def compute_direction_implementation_b(self):  # schur.jl:89-128
+        fi, rhs = self.factor_it, self.rhs
+        y_org, s_org = fi.y, fi.s
+        symmetric_primal_rhs = rhs.primal_r + rhs.comp_r / y_org
+        S_vec = y_org / s_org
+        y_ = rhs.primal_r * S_vec + rhs.comp_r / s_org
+        schur_rhs = rhs.dual_r + eval_jac_T_prod(fi, y_)
+        d = self.dir
+        d.x = self.solver_schur_rhs(schur_rhs)
+        d.y = -(eval_jac_prod(fi, d.x) - symmetric_primal_rhs) * S_vec
+        d.s = eval_jac_prod(fi, d.x) - rhs.primal_r
+        self.update_kkt_error_b()
+
+    def solver_schur_rhs(self, schur_rhs):  # schur.jl:131-182
+        fit = self.factor_it
+        S_vec = fit.y / fit.s
+        res_old = schur_rhs
+        dir_x = np.zeros(fit.dim())
+        for _ in range(self.pars.ItRefine_Num):
+            dir_x = dir_x + self.ls_solver.ls_solve(res_old)
+            jac_res = eval_jac_T_prod(fit, S_vec * eval_jac_prod(fit, dir_x))
+            hess_res = hess_product(fit, dir_x) + self.delta_x_vec * dir_x
+            res_old = schur_rhs - (jac_res + hess_res)
+        return dir_x
+
+
+class Symmetric_KKT_solver(_KKTBase):
+    """symmetric.jl:2-102"""
+
+    def form_system_b(self, it):  # symmetric.jl:35-53
+        B = sp.diags(-it.s / it.y)
+        M = sp.bmat([[it.H, it.J.T], [it.J, B]], format="lil")
+        self.Q = M
+        self.factor_it = it
+        self.schur_diag = compute_schur_diag(it)
+        self.true_x_diag = np.asarray(M.diagonal())[: it.dim()].copy()
+        self.ready = "system_formed"
+
+    def update_delta_vecs_b(self, delta_x_vec, delta_s_vec):  # symmetric.jl:85-102
+        self.delta_x_vec, self.delta_s_vec = delta_x_vec, delta_s_vec
+        if np.sum(np.abs(delta_s_vec)) > 0.0:
+            raise NotImplementedError("not implemented")
+        dg = np.asarray(self.Q.diagonal()).copy()
+        dg[: len(delta_x_vec)] = self.true_x_diag + delta_x_vec
+        self.Q.setdiag(dg)
+        self.ready = "delta_updated"
+
+    def factor_implementation_b(self):  # symmetric.jl:55-57
+        return self.ls_solver.ls_factor_b(self.Q.tocsc(), self.factor_it.dim(), self.factor_it.ncon())
+
+    def compute_direction_implementation_b(self):  # symmetric.jl:59-83
+        fi, rhs = self.factor_it, self.rhs
+        symmetric_rhs = np.concatenate([rhs.dual_r, rhs.primal_r + rhs.comp_r / fi.y])
+        sol = self.ls_solver.ls_solve(symmetric_rhs)
+        n = len(rhs.dual_r)
+        d = self.dir
+        d.x = sol[:n]
+        d.y = -sol[n:]
+        d.s = eval_jac_prod(fi, d.x) - rhs.primal_r
+        self.update_kkt_error_b()
+
+
+def ipopt_strategy_b(it, kkt_solver, pars=None):
+    """delta_strategy.jl:37-114.  Returns (status, num_fac, delta) and the list of deltas tried."""
+    pars = pars or kkt_solver.pars
+    MAX_IT = 500
+    num_fac = 0
+    tried = []
+    tau = 1.5 * kkt_solver.diag_min()
+    delta = pars.delta_zero
+    if tau > 0.0:
+        tau = 0.0
+        inertia = kkt_solver.factor_b(delta)
+        tried.append(delta)
+        num_fac += 1
+        if inertia == 1:
+            return "success", num_fac, delta, tried
+    for i in range(1, MAX_IT + 1):
+        if i == 1:
+            if it.delta != 0.0:
+                delta = max(pars.delta_min - tau, it.delta * pars.delta_dec)
+            else:
+                delta = pars.delta_start - tau
+        else:
+            delta = delta * pars.delta_inc
+        inertia = kkt_solver.factor_b(delta)
+        tried.append(delta)
+        num_fac += 1
+        if inertia == 1:
+            return "success", num_fac, delta, tried
+        if delta > pars.delta_max:
+            return "failure", num_fac, delta, tried
+    raise RuntimeError("max it")
+
+
+def pick_KKT_solver(kkt_solver_type, perm=None, pars=None):
+    """kkt_system_solver.jl:232-287 with linear_solver_type = :julia"""
+    if kkt_solver_type == "symmetric":
+        return Symmetric_KKT_solver(linear_solver_ORACLE("symmetric", perm=perm), pars)
+    if kkt_solver_type == "schur":
+        return Schur_KKT_solver(linear_solver_ORACLE("definite", perm=perm), pars)
+    raise ValueError("pick a solver!")

@@ -1,0 +1,170 @@
+"""Pins the CPU oracle: against the reference's own unit-test matrices and acceptance rules, against
+dense LAPACK known answers (tests/golden), and against dense numpy on seeded random sparse systems.
+CPU only."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import oracle
+from oracle import kkt_oracle as KO
+from conftest import iterate_from_record
+
+
+def full_sym(A):
+    A = sp.csc_matrix(A)
+    return (sp.tril(A) + sp.tril(A, -1).T).toarray()
+
+
+# ---- reference test/linear_system_solvers.jl:58-116
+def run_linear_solvers(A, b, n, m, inertia, x_expected):
+    tol = 1e-9
+    res = {}
+    for sym in ("symmetric", "definite"):
+        s = oracle.linear_solver_ORACLE(sym)
+        assert s.ls_factor_b(A, n, m) == inertia
+        r1 = np.zeros(len(b))
+        s.ls_solve_b(b, r1)
+        r2 = s.ls_solve(b)
+        assert np.array_equal(r1, r2)  # @test res1 == res2
+        res[sym] = r1
+    assert np.linalg.norm(res["symmetric"] - res["definite"]) < tol
+    assert np.linalg.norm(res["symmetric"] - x_expected) < tol
+    # A_2 = A + A' with the diagonal of A: upper entries must be ignored (:74-84)
+    A2 = sp.lil_matrix(A + A.T)
+    A2.setdiag(A.diagonal())
+    for sym in ("symmetric", "definite"):
+        s = oracle.linear_solver_ORACLE(sym)
+        assert s.ls_factor_b(A2.tocsc(), n, m) == inertia
+        assert np.linalg.norm(s.ls_solve(b) - res[sym]) < tol
+
+
+def test_linear_solvers_reference_matrices(golden):
+    for rec in golden["linear_solvers"]:
+        A = sp.csc_matrix(np.array(rec["A_lower"]))
+        run_linear_solvers(A, np.array(rec["b"]), rec["n"], rec["m"], rec["inertia"], np.array(rec["x"]))
+
+
+def test_inertia_rule():
+    # julia.jl:70-90 + linear_system_solvers.jl:48-91
+    A = sp.diags([2.0, -1.0, 3.0, -4.0]).tocsc()
+    s = oracle.linear_solver_ORACLE("symmetric")
+    assert s.ls_factor_b(A, 2, 2) == 1
+    assert s.inertia() == (2, 2, 0, 0)
+    assert s.ls_factor_b(A, 3, 1) == 0
+    assert oracle.linear_solver_ORACLE("definite").ls_factor_b(A, 4, 0) == 0
+    Z = sp.csc_matrix(np.array([[1.0, 0.0], [0.0, 0.0]]))
+    assert oracle.linear_solver_ORACLE("symmetric").ls_factor_b(Z, 1, 1) == 0  # zero pivot -> 0
+    tiny = sp.diags([1.0, 1e-21]).tocsc()
+    s = oracle.linear_solver_ORACLE("symmetric")
+    assert s.ls_factor_b(tiny, 2, 0) == 0 and s.inertia() == (1, 0, 1, 0)      # tol = 1e-20
+    assert oracle.linear_solver_ORACLE("definite").ls_factor_b(tiny, 2, 0) == 1
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+@pytest.mark.parametrize("n", [1, 7, 60, 200])
+def test_random_sparse_vs_dense(seed, n):
+    rng = np.random.default_rng(seed)
+    A = sp.random(n, n, density=min(1.0, 4.0 / n), random_state=np.random.RandomState(seed), format="csc")
+    A = sp.tril(A, -1) + sp.diags(rng.normal(size=n) + np.sign(rng.normal(size=n)) * 3.0)
+    A = sp.csc_matrix(A)
+    M = full_sym(A)
+    w = np.linalg.eigvalsh(M)
+    npos, nneg = int((w > 0).sum()), int((w < 0).sum())
+    b = rng.normal(size=n)
+    for perm in (None, rng.permutation(n)):
+        s = oracle.linear_solver_ORACLE("symmetric", perm=perm)
+        assert s.ls_factor_b(A, npos, nneg) == 1          # Sylvester: sign(D) = inertia
+        x = s.ls_solve(b)
+        assert np.linalg.norm(M @ x - b) <= 1e-9 * max(1.0, np.linalg.norm(b))
+        # L D L' reproduces P A P'
+        p = s.perm if s.perm is not None else np.arange(n)
+        Lm = s.L().toarray() + np.eye(n)
+        assert np.allclose(Lm @ np.diag(s.diag()) @ Lm.T, M[np.ix_(p, p)], atol=1e-9)
+
+
+# ---- known answers for the KKT layer
+def _perm_for(rec, kind):
+    # CHOLMOD's AMD is not reproducible here; natural order would pivot on the delta-sized (1,1)
+    # block first (element growth 1e8 on LPs).  Eliminating the -S/Y block first is the order a
+    # minimum-degree heuristic takes on these tiny problems and the one the Schur form implies.
+    n, m = rec["n"], rec["m"]
+    return np.concatenate([np.arange(n, n + m), np.arange(n)]) if kind == "symmetric" else None
+
+
+def _solve_kind(rec, kind):
+    it = iterate_from_record(rec, KO.Iterate)
+    k = KO.pick_KKT_solver(kind, perm=_perm_for(rec, kind))
+    k.initialize_b(it)
+    k.form_system_b(it)
+    inertia = k.factor_b(rec["delta"])
+    k.kkt_associate_rhs_b(it, KO.Reduct_affine())
+    k.compute_direction_b()
+    return inertia, k
+
+
+def test_rhs_matches_known_answers(golden):
+    for rec in golden["toy_lps"] + [golden["readme_toy"], golden["indef5"]]:
+        it = iterate_from_record(rec, KO.Iterate)
+        rhs = KO.System_rhs.build(it, KO.Reduct_affine())
+        assert np.allclose(rhs.dual_r, rec["rD"], rtol=0, atol=1e-14)
+        assert np.allclose(rhs.primal_r, rec["rP"], rtol=0, atol=1e-14)
+        assert np.allclose(rhs.comp_r, rec["rC"], rtol=0, atol=1e-14)
+
+
+def test_toy_lps_directions(golden):
+    # reference test/kkt_system_solvers.jl:91-181: schur vs symmetric agree to 1e-6; here both must
+    # also match the dense known answer
+    for rec in golden["toy_lps"]:
+        i1, ks = _solve_kind(rec, "schur")
+        i2, ky = _solve_kind(rec, "symmetric")
+        assert i1 == 1 and i2 == 1
+        for a in ("x", "y", "s"):
+            assert np.linalg.norm(getattr(ks.dir, a) - getattr(ky.dir, a)) < 1e-6
+            assert np.linalg.norm(getattr(ky.dir, a) - np.array(rec["d" + a])) < 1e-6, (rec["name"], a)
+            assert np.linalg.norm(getattr(ks.dir, a) - np.array(rec["d" + a])) < 1e-6, (rec["name"], a)
+        assert ks.kkt_err_norm.ratio < 1e-8 and ky.kkt_err_norm.ratio < 1e-6
+
+
+def test_readme_toy_known_answer(golden):
+    rec = golden["readme_toy"]
+    for kind in ("schur", "symmetric"):
+        inertia, k = _solve_kind(rec, kind)
+        assert inertia == 1
+        assert np.allclose(k.dir.x, rec["dx"], rtol=1e-12)
+        assert np.allclose(k.dir.y, rec["dy"], rtol=1e-11)
+        assert np.allclose(k.dir.s, rec["ds"], rtol=1e-12)
+        # K(0) has inertia (0,3,0): rejected
+        it = iterate_from_record(rec, KO.Iterate)
+        k2 = KO.pick_KKT_solver(kind, perm=_perm_for(rec, kind))
+        k2.initialize_b(it)
+        k2.form_system_b(it)
+        assert k2.factor_b(0.0) == 0
+
+
+@pytest.mark.parametrize("prob", ["readme_toy", "indef5", "posdiag_indef5"])
+def test_delta_loop_traces(golden, prob):
+    rec = golden[prob]
+    loops = rec.get("delta_loops") or {"schur_prev0.0": rec["delta_loop_schur"], "symmetric_prev0.0": rec["delta_loop_symmetric"]}
+    for key, exp in loops.items():
+        kind, prev = key.split("_prev")
+        it = iterate_from_record(rec, KO.Iterate)
+        it.delta = float(prev)
+        k = KO.pick_KKT_solver(kind, perm=_perm_for(rec, kind))
+        k.initialize_b(it)
+        k.form_system_b(it)
+        status, num_fac, delta, tried = KO.ipopt_strategy_b(it, k)
+        assert status == exp["status"] and num_fac == exp["num_fac"]
+        assert tried == exp["tried"]          # same arithmetic, bit for bit
+        assert delta == exp["delta"]
+
+
+def test_state_machine_errors(golden):
+    rec = golden["toy_lps"][1]
+    it = iterate_from_record(rec, KO.Iterate)
+    k = KO.pick_KKT_solver("schur")
+    k.initialize_b(it)
+    k.form_system_b(it)
+    with pytest.raises(RuntimeError):
+        k.factor_b()             # not :delta_updated (kkt_system_solver.jl:195-199)
+    with pytest.raises(RuntimeError):
+        k.compute_direction_b()  # not :factored (kkt_system_solver.jl:181-183)
