@@ -31,7 +31,7 @@ def _local_cols(rng, centers, per, ncols, w, p_far):
 
 
 def make_problem(n, m, j_per_row=8, h_per_col=4, w=50.0, p_far=0.01, seed=0, convex=True,
-                 neg_shift=0.0, mu=1e-2):
+                 neg_shift=0.0, mu=1e-2, well_scaled=False):
     """Returns dict(H=csc lower, J=csc, s, y, mu, n, m)."""
     rng = np.random.default_rng(seed)
     # J: row r is centred on column ~ r * n / m
@@ -64,8 +64,12 @@ def make_problem(n, m, j_per_row=8, h_per_col=4, w=50.0, p_far=0.01, seed=0, con
     H = (Hoff + sp.diags(d, format="csc")).tocsc()
     H.sort_indices()
     # s, y: log-uniform slack, complementarity products spread around mu (parameters.jl:97)
-    s = np.exp(rng.uniform(np.log(1e-4), np.log(1e2), size=m))
-    y = mu * np.exp(rng.uniform(np.log(1e-2), np.log(1e2), size=m)) / s
+    if well_scaled:  # s, y = O(1): condition number of K stays moderate
+        s = np.exp(rng.uniform(np.log(0.2), np.log(5.0), size=m))
+        y = np.exp(rng.uniform(np.log(0.2), np.log(5.0), size=m))
+    else:
+        s = np.exp(rng.uniform(np.log(1e-4), np.log(1e2), size=m))
+        y = mu * np.exp(rng.uniform(np.log(1e-2), np.log(1e2), size=m)) / s
     return dict(H=H, J=J, s=s, y=y, mu=mu, n=n, m=m)
 
 

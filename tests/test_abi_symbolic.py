@@ -1,0 +1,181 @@
+"""CPU-side checks of the C ABI library: it loads, exports every symbol include/okkt.h declares,
+refuses to compute without a GPU (no CPU fallback), and its host symbolic analysis agrees with the
+oracle's elimination tree / column counts for the permutation it chose."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import onephase_jl_amd as pk
+from onephase_jl_amd import _lib as L
+from onephase_jl_amd import synth
+from onephase_jl_amd.linear_system_solvers import OkktError, finalize_b, initialize_b, linear_solver_HIP
+import oracle
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "okkt.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(okkt_[a-z_0-9]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = L.load()
+    names = declared_symbols()
+    assert len(names) >= 30
+    for name in names:
+        assert hasattr(lib, name), f"{name} declared in include/okkt.h but not exported"
+        assert name in L.SIGNATURES, f"{name} has no ctypes signature"
+    assert L.MISSING == []
+    assert b"gfx950" in lib.okkt_version()
+
+
+def has_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+@pytest.mark.skipif(has_gpu(), reason="only meaningful on a box without a GPU")
+def test_no_cpu_fallback():
+    s = linear_solver_HIP("symmetric")
+    with pytest.raises(OkktError, match="no CPU fallback"):
+        initialize_b(s)
+    # a host-symbolic handle analyses but refuses to factor
+    s = linear_solver_HIP("symmetric", host_symbolic_only=1)
+    initialize_b(s)
+    A = sp.identity(4, format="csc")
+    s.analyze(A)
+    with pytest.raises(OkktError, match="host_symbolic_only"):
+        s.ls_factor_b(A, 4, 0)
+    finalize_b(s)
+
+
+def host_solver(**o):
+    s = linear_solver_HIP("symmetric", host_symbolic_only=1, **o)
+    initialize_b(s)
+    return s
+
+
+@pytest.mark.parametrize("name,seed", [("S-tiny", 0), ("S-tiny", 1), ("S-small", 0), ("S-small", 2)])
+@pytest.mark.parametrize("kind", ["augmented", "schur"])
+def test_symbolic_matches_oracle(name, seed, kind):
+    prob = synth.make_config(name, seed=seed)
+    A = synth.augmented_matrix(prob) if kind == "augmented" else synth.schur_matrix(prob)
+    s = host_solver()
+    s.analyze(A)
+    perm = s.perm()
+    n = A.shape[0]
+    assert sorted(perm.tolist()) == list(range(n))
+    ref = oracle.linear_solver_ORACLE("symmetric", perm=perm)
+    ref._analyze(A)
+    par, cnt = s.etree()
+    rpar, rcnt = ref.etree()
+    assert np.array_equal(par, rpar)
+    assert np.array_equal(cnt, rcnt)
+    st = s.stats()
+    assert st["nnzL"] == ref.lnz() + n
+    assert st["flops_exact"] == ref.flops()
+    assert st["nnzL_stored"] >= st["nnzL"]
+    assert st["nnz_lower"] == sp.tril(A).nnz
+    # etree is postordered: every parent has a larger index, subtrees are contiguous
+    assert all(p == -1 or p > j for j, p in enumerate(par))
+    finalize_b(s)
+
+
+def test_amd_reduces_fill():
+    prob = synth.make_config("S-small", seed=1)
+    A = synth.augmented_matrix(prob)
+    s0 = host_solver(ordering=1)
+    s0.analyze(A)
+    s1 = host_solver(ordering=0)
+    s1.analyze(A)
+    assert s1.stats()["nnzL"] < 0.6 * s0.stats()["nnzL"]
+
+
+def test_user_permutation_and_natural_order():
+    prob = synth.make_config("S-tiny", seed=5)
+    A = synth.augmented_matrix(prob)
+    n = A.shape[0]
+    s = host_solver(ordering=1)
+    s.analyze(A)
+    # natural order is only re-labelled by the etree postorder
+    ref = oracle.linear_solver_ORACLE("symmetric", perm=None)
+    ref._analyze(A)
+    assert s.stats()["nnzL"] == ref.lnz() + n
+    rng = np.random.default_rng(0)
+    p = rng.permutation(n)
+    s2 = host_solver(ordering=2)
+    s2.set_perm(p)
+    s2.analyze(A)
+    ref2 = oracle.linear_solver_ORACLE("symmetric", perm=p)
+    ref2._analyze(A)
+    assert s2.stats()["nnzL"] == ref2.lnz() + n
+    with pytest.raises(OkktError):
+        s3 = host_solver(ordering=2)
+        s3.set_perm(np.zeros(n, dtype=np.int64))
+        s3.analyze(A)
+
+
+def test_pattern_cache_and_upper_entries_ignored():
+    prob = synth.make_config("S-tiny", seed=2)
+    K_full = synth.augmented_matrix(prob, with_upper=True)
+    K_low = sp.tril(K_full, format="csc")
+    s = host_solver()
+    s.analyze(K_full)
+    s.analyze(K_full)
+    assert s.stats()["n_analyze_calls"] == 1           # same pattern -> cached
+    st_full = s.stats()
+    s.analyze(K_low)
+    assert s.stats()["n_analyze_calls"] == 2
+    assert s.stats()["nnzL"] == st_full["nnzL"]         # upper entries never mattered
+    assert np.array_equal(s.perm(), host_solver().__class__ and s.perm())
+
+
+def test_one_based_indices_and_errors():
+    A = sp.csc_matrix(np.array([[4.0, 0, 0], [1.0, 5.0, 0], [0, 2.0, 6.0]]))
+    s = host_solver()
+    s.analyze((3, A.indptr + 1, A.indices + 1, A.data, 1))
+    assert s.stats()["nnz_lower"] == 5
+    with pytest.raises(OkktError):
+        s.analyze((3, A.indptr, A.indices + 7, A.data, 0))
+    lib = L.load()
+    assert lib.okkt_analyze(None, 3, None, None, 0) == L.OKKT_ERR_INVALID
+    assert lib.okkt_destroy(None) == L.OKKT_ERR_INVALID
+
+
+def test_empty_and_diagonal_matrices():
+    s = host_solver()
+    s.analyze(sp.csc_matrix((0, 0)))
+    assert s.stats()["n"] == 0
+    s.analyze(sp.identity(7, format="csc"))
+    st = s.stats()
+    assert st["nnzL"] == 7 and st["nlevels"] == 1
+
+
+def test_block_angular_has_independent_subtrees():
+    prob = synth.block_angular(nblocks=4, n_b=60, m_b=90, n_link=6, seed=0, j_per_row=4, h_per_col=3, w=5.0, p_far=0.0)
+    K = synth.augmented_matrix(prob)
+    s = host_solver()
+    s.analyze(K)
+    par, _ = s.etree()
+    perm = s.perm()
+    n_b, m_b, nb = 60, 90, 4
+    def block_of(orig):
+        if orig < nb * n_b:
+            return orig // n_b
+        if orig < nb * n_b + 6:
+            return -1  # linking column
+        return (orig - nb * n_b - 6) // m_b
+    # a non-linking column's parent is either in the same block or a linking/ancestor column
+    blk = np.array([block_of(o) for o in perm])
+    for j, p in enumerate(par):
+        if p >= 0 and blk[j] >= 0 and blk[p] >= 0:
+            assert blk[j] == blk[p]
