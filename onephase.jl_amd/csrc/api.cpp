@@ -107,7 +107,7 @@ int okkt_default_opts(okkt_opts* o) {
   o->relax_any_frac = d.relax_any_frac;
   o->inertia_tol = 1e-20;
   o->small_front_max = 128;
-  o->panel_nb = 64;
+  o->panel_nb = 128;
   o->use_graph = 1;
   return OKKT_OK;
 }

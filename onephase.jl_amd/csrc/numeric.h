@@ -38,6 +38,15 @@ struct DevPlan {
   double* cv = nullptr;       // solve contribution vectors
   double* wbuf = nullptr;     // W = L21*D panels of the big fronts
   int64_t* wbuf_pos = nullptr;  // [nsuper] offset of each big front's W panel, -1 for small fronts
+  // big fronts only: per front-column inverted extend-add lists, inverse diagonal blocks, solve vectors
+  int64_t* bigcol_base = nullptr;  // [nsuper] first global big-column index of the front, -1 for small
+  int64_t* ea_ptr = nullptr;       // [n_bigcols + 1] contributions (child, jj) landing on a front column
+  int* ea_child = nullptr;
+  int* ea_jj = nullptr;
+  double* invl = nullptr;          // inverse of the unit-lower diagonal blocks, NB x NB each
+  double* invlt = nullptr;         // the same, transposed (backward solve reads it coalesced)
+  int64_t* invl_pos = nullptr;     // [nsuper]
+  double* bigw = nullptr;          // [n_bigcols] forward-solve work vectors of the big fronts
   unsigned long long* counters = nullptr;  // pos, neg, zero, nonfinite
 };
 

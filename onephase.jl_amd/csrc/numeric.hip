@@ -65,11 +65,11 @@ __device__ __forceinline__ void ldl_partial_lds(double* F, double* wcol, int ldf
   constexpr int G = TPB / 32;
   const int tid = threadIdx.x, lane = tid & 31, grp = tid >> 5;
   for (int j = 0; j < npiv; ++j) {
-    const double d = F[j + j * ldf];
+    const double rd = 1.0 / F[j + j * ldf];  // one division per pivot; l = w * (1/d)
     for (int i = j + 1 + tid; i < f; i += TPB) {
       const double w = F[i + j * ldf];
-      wcol[i] = w;            // w_i = l_ij * d_j
-      F[i + j * ldf] = w / d; // l_ij
+      wcol[i] = w;             // w_i = l_ij * d_j
+      F[i + j * ldf] = w * rd; // l_ij
     }
     __syncthreads();
     for (int c = j + 1 + grp; c < f; c += G) {
@@ -150,68 +150,101 @@ __global__ __launch_bounds__(TPB) void k_front_small(DevPlan P, const int* __res
 }
 
 // ------------------------------------------------------------------------------------------
-// big fronts
+// big fronts: blocked right-looking LDL^T, block-column width NB (<= 128)
+//   k_big_assemble : one wave per front column: zero, scatter A, extend-add via inverted lists
+//   k_big_diag     : NB x NB diagonal block in LDS (inner width 32), D + inertia, and its inverse
+//   k_big_trsm     : W = A21 * inv(L11)^T with FP64 MFMA, L21 = W * D^-1
+//   k_big_syrk     : trailing update C -= W * L^T with FP64 MFMA, 128 x 128 tile per workgroup
 // ------------------------------------------------------------------------------------------
-constexpr int kAsmCols = 16;  // columns of the parent owned by one assemble workgroup
-
 __device__ __forceinline__ int lower_bound_dev(const int* a, int n, int key) {
   int lo = 0, hi = n;
   while (lo < hi) { int mid = (lo + hi) >> 1; if (a[mid] < key) lo = mid + 1; else hi = mid; }
   return lo;
 }
 
+// Each front column is owned by exactly one wave, which applies the contributions in list order:
+// deterministic, no atomics, no workgroup barriers.
 __global__ __launch_bounds__(256) void k_big_assemble(DevPlan P, const int* __restrict__ list) {
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int s = list[blockIdx.y];
   const int col0 = P.sn_col0[s];
   const int k = P.sn_col0[s + 1] - col0;
   const int f = (int)(P.row_ptr[s + 1] - P.row_ptr[s]);
-  const int c0 = blockIdx.x * kAsmCols;
-  if (c0 >= f) return;
-  const int c1 = min(c0 + kAsmCols, f);
+  const int pc = blockIdx.x * 4 + wv;
+  if (pc >= f) return;
   double* F = P.arena + P.front_pos[s];
-  for (int c = c0 + wv; c < c1; c += 4) {
-    double* col = F + (size_t)c * f;
-    for (int i = c + lane; i < f; i += 64) col[i] = 0.0;
-  }
-  __syncthreads();
-  if (c0 < k) {
+  double* col = F + (size_t)pc * f;
+  for (int i = pc + lane; i < f; i += 64) col[i] = 0.0;
+  __threadfence_block();
+  if (pc < k) {
     const int64_t e0 = P.aent_ptr[s];
     const int ne = (int)(P.aent_ptr[s + 1] - e0);
     const int* dstv = P.aent_dst + e0;
-    const int lo = lower_bound_dev(dstv, ne, c0 * f);
-    const int hi = lower_bound_dev(dstv, ne, c1 * f);  // c1*f <= f*f fits: f <= 46340 checked on host
+    const int lo = lower_bound_dev(dstv, ne, pc * f);
+    const int hi = lower_bound_dev(dstv, ne, (pc + 1) * f);
     if (!P.has_dup) {
-      for (int e = lo + tid; e < hi; e += 256) F[dstv[e]] = P.vals[P.aent_src[e0 + e]];
-    } else if (tid == 0) {
+      for (int e = lo + lane; e < hi; e += 64) F[dstv[e]] = P.vals[P.aent_src[e0 + e]];
+    } else if (lane == 0) {
       for (int e = lo; e < hi; ++e) F[dstv[e]] += P.vals[P.aent_src[e0 + e]];
     }
-    __syncthreads();
-    for (int c = c0 + tid; c < min(c1, k); c += 256) F[c + (size_t)c * f] += P.diagadd[col0 + c];
+    __threadfence_block();
+    if (lane == 0) col[pc] += P.diagadd[col0 + pc];
+    __threadfence_block();
   }
-  __syncthreads();
-  for (int64_t q = P.child_ptr[s]; q < P.child_ptr[s + 1]; ++q) {
-    const int c = P.children[q];
+  const int64_t gc = P.bigcol_base[s] + pc;
+  for (int64_t q = P.ea_ptr[gc]; q < P.ea_ptr[gc + 1]; ++q) {
+    const int c = P.ea_child[q], jj = P.ea_jj[q];
     const int kc = P.sn_col0[c + 1] - P.sn_col0[c];
     const int fc = (int)(P.row_ptr[c + 1] - P.row_ptr[c]);
     const int rc = fc - kc;
-    const double* C = P.arena + P.front_pos[c];
     const int* rl = P.rel + P.rel_ptr[c];
-    const int j_lo = lower_bound_dev(rl, rc, c0);
-    const int j_hi = lower_bound_dev(rl, rc, c1);
-    for (int jj = j_lo + wv; jj < j_hi; jj += 4) {
-      double* pcol = F + (size_t)rl[jj] * f;
-      const double* Ccol = C + (size_t)(kc + jj) * fc + kc;
-      for (int ii = jj + lane; ii < rc; ii += 64) pcol[rl[ii]] += Ccol[ii];
-    }
-    __syncthreads();
+    const double* Ccol = P.arena + P.front_pos[c] + (size_t)(kc + jj) * fc + kc;
+    for (int ii = jj + lane; ii < rc; ii += 64) col[rl[ii]] += Ccol[ii];
+    __threadfence_block();
   }
 }
 
-// diagonal block of block-column `step`: LDL^T in LDS, D and inertia out
+__device__ __forceinline__ double readlane_f64(double v, int src_lane) {
+  // wave-uniform broadcast through SGPRs (v_readlane_b32 x 2); src_lane must be wave-uniform
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_readlane(lo, src_lane);
+  hi = __builtin_amdgcn_readlane(hi, src_lane);
+  return __hiloint2double(hi, lo);
+}
+
+// 32 x 32 (or smaller, w x w) LDL^T held in registers by lanes 0..31 of one wave; row i on lane i.
+__device__ __forceinline__ void diag32_wave(double* B, int ldb, int off, int w) {
+  const int lane = threadIdx.x & 63;
+  double a[32];
+#pragma unroll
+  for (int c = 0; c < 32; ++c)
+    a[c] = (lane < w && c < w && c <= lane) ? B[(off + lane) + (size_t)(off + c) * ldb] : (c == lane ? 1.0 : 0.0);
+#pragma unroll
+  for (int j = 0; j < 32; ++j) {
+    const double dj = readlane_f64(a[j], j);
+    const double wj = a[j];
+    const double l = wj * (1.0 / dj);
+#pragma unroll
+    for (int c = j + 1; c < 32; ++c) {
+      const double wc = readlane_f64(wj, c);
+      if (lane >= c) a[c] -= l * wc;
+    }
+    if (lane > j) a[j] = l;
+  }
+#pragma unroll
+  for (int c = 0; c < 32; ++c)
+    if (lane < w && c < w && c <= lane) B[(off + lane) + (size_t)(off + c) * ldb] = a[c];
+}
+
+constexpr int kIB = 32;  // inner block width of the diagonal-block kernel
+
+// NB x NB diagonal block of block-column `step`: LDL^T in LDS (inner width 32: register/readlane
+// 32 x 32 kernel on one wave, row-parallel solve below it, MFMA rank-32 update), D and inertia out,
+// then X = inv(L11) block by block (MFMA products) for the row-parallel k_big_trsm and the solves.
 __global__ __launch_bounds__(256) void k_big_diag(DevPlan P, const int* __restrict__ list, int step, int NB, double tol) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
-  const int tid = threadIdx.x, lane = tid & 31, grp = tid >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, l4 = lane >> 4;
   const int s = list[blockIdx.x];
   const int col0 = P.sn_col0[s];
   const int k = P.sn_col0[s + 1] - col0;
@@ -219,34 +252,160 @@ __global__ __launch_bounds__(256) void k_big_diag(DevPlan P, const int* __restri
   const int j0 = step * NB;
   if (j0 >= k) return;
   const int nb = min(NB, k - j0);
-  const int ldb = nb | 1;
-  double* B = sm;
-  double* wcol = sm + (size_t)ldb * nb;
+  const int ldb = NB;
+  const int RMAX = max(NB - kIB, kIB);       // most rows below an inner block (>= 32: also the T scratch)
+  double* B = sm;                            // NB x NB
+  double* Wb = sm + (size_t)NB * NB;         // RMAX x 32 scratch
+  double* rdv = Wb + (size_t)RMAX * kIB;     // reciprocal pivots
   double* F = P.arena + P.front_pos[s];
-  for (int c = grp; c < nb; c += 8) {
-    const double* src = F + (size_t)(j0 + c) * f + j0;
-    for (int i = c + lane; i < nb; i += 32) B[i + c * ldb] = src[i];
+  for (int idx = tid; idx < NB * NB; idx += 256) {
+    const int c = idx / NB, i = idx - c * NB;
+    B[idx] = (i < nb && c < nb && i >= c) ? F[(size_t)(j0 + c) * f + j0 + i] : 0.0;
   }
   __syncthreads();
-  ldl_partial_lds<256>(B, wcol, ldb, nb, nb);
-  for (int c = grp; c < nb; c += 8) {
-    double* dst = F + (size_t)(j0 + c) * f + j0;
-    for (int i = c + lane; i < nb; i += 32) dst[i] = B[i + c * ldb];
+  for (int off = 0; off < nb; off += kIB) {
+    const int w = min(kIB, nb - off);
+    if (wave == 0) diag32_wave(B, ldb, off, w);
+    __syncthreads();
+    if (tid < w) rdv[off + tid] = 1.0 / B[(off + tid) + (size_t)(off + tid) * ldb];
+    __syncthreads();
+    const int c0 = off + w;
+    const int R = nb - c0;
+    if (R > 0) {  // then w == 32
+      if (tid < R) {
+        const int r = c0 + tid;
+        double wr[kIB];
+#pragma unroll
+        for (int c = 0; c < kIB; ++c) {
+          double v = B[r + (size_t)(off + c) * ldb];
+#pragma unroll
+          for (int p = 0; p < c; ++p) v -= wr[p] * B[(off + c) + (size_t)(off + p) * ldb];
+          wr[c] = v;
+        }
+#pragma unroll
+        for (int c = 0; c < kIB; ++c) {
+          Wb[tid + c * RMAX] = wr[c];
+          B[r + (size_t)(off + c) * ldb] = wr[c] * rdv[off + c];
+        }
+      }
+      __syncthreads();
+      // rank-32 update of the trailing R x R lower triangle, 16 x 16 MFMA tiles spread over the waves
+      const int nt = (R + 15) >> 4;
+      for (int t = wave; t < nt * (nt + 1) / 2; t += 4) {
+        int ri = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+        while ((ri + 1) * (ri + 2) / 2 <= t) ++ri;
+        while (ri * (ri + 1) / 2 > t) --ri;
+        const int ci = t - ri * (ri + 1) / 2;
+        const int cb = c0 + ci * 16, rb = ri * 16;  // rb relative to c0
+        d4_t acc = (d4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int k0 = 0; k0 < kIB; k0 += 4) {
+          const double av = B[(cb + l15) + (size_t)(off + k0 + l4) * ldb];   // L[c][p]
+          const double bv = Wb[(rb + l15) + (k0 + l4) * RMAX];               // W[r][p]
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+        }
+        const int r = c0 + rb + l15;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int c = cb + l4 + 4 * reg;
+          if (r < nb && c < nb && r >= c) B[r + (size_t)c * ldb] -= acc[reg];
+        }
+      }
+      __syncthreads();
+    }
+  }
+  // L11, D, inertia
+  for (int idx = tid; idx < nb * nb; idx += 256) {
+    const int c = idx / nb, i = idx - c * nb;
+    if (i >= c) F[(size_t)(j0 + c) * f + j0 + i] = B[i + (size_t)c * ldb];
   }
   unsigned pos = 0, neg = 0, zer = 0, bad = 0;
   for (int j = tid; j < nb; j += 256) {
-    const double d = B[j + j * ldb];
+    const double d = B[j + (size_t)j * ldb];
     P.dvals[col0 + j0 + j] = d;
     classify_pivot(d, tol, pos, neg, zer, bad);
   }
   flush_counts(P.counters, pos, neg, zer, bad);
+  __syncthreads();
+  // ---- X = inv(L11), unit lower, blockwise; overwrites B
+  const int nblk = (nb + kIB - 1) / kIB;
+  {
+    // diagonal blocks: thread c owns column c of its block
+    double x[kIB];
+    const int c = tid, b = c / kIB, lc = c - b * kIB;
+    const int boff = b * kIB;
+    const int w = min(kIB, nb - boff);
+    if (c < nb) {
+#pragma unroll
+      for (int r = 0; r < kIB; ++r) {
+        double v = (r == lc) ? 1.0 : 0.0;
+#pragma unroll
+        for (int p = 0; p < r; ++p)
+          if (p >= lc && r < w) v -= B[(boff + r) + (size_t)(boff + p) * ldb] * x[p];
+        x[r] = (r >= lc && r < w) ? v : 0.0;
+      }
+    }
+    __syncthreads();
+    if (c < nb) {
+#pragma unroll
+      for (int r = 0; r < kIB; ++r)
+        if (r >= lc && r < w) B[(boff + r) + (size_t)c * ldb] = x[r];   // diagonal now holds 1
+    }
+    __syncthreads();
+  }
+  // off-diagonal blocks X_ij = -X_ii * (sum_{p=j}^{i-1} L_ip X_pj), by block distance d = i - j;
+  // every 32 x 32 product is 2 x 2 MFMA tiles, the tiles of a round are spread over the waves
+  double* T = Wb;  // up to 3 scratch blocks of 32 x 32
+  for (int d = 1; d < nblk; ++d) {
+    const int npairs = nblk - d;
+    for (int t = wave; t < npairs * 4; t += 4) {
+      const int bj = t >> 2, bi = bj + d, sub = t & 3;
+      const int ro = bi * kIB, co = bj * kIB;
+      const int rr0 = (sub & 1) * 16, cc0 = (sub >> 1) * 16;
+      d4_t acc = (d4_t){0.0, 0.0, 0.0, 0.0};
+      const int lrow = ro + rr0 + l15;
+      for (int p0 = co; p0 < ro; p0 += 4) {
+        // L comes from the front in HBM/L2 (written above): the LDS copy of a block (bi, bp) is
+        // replaced by X as soon as its distance bi - bp has been processed
+        const double av = lrow < nb ? F[(size_t)(j0 + p0 + l4) * f + j0 + lrow] : 0.0;   // L[ro+rr][p]
+        const double bv = B[(p0 + l4) + (size_t)(co + cc0 + l15) * ldb];          // X[p][co+cc]
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg)   // D[i = rr][j = cc]
+        T[bj * kIB * kIB + (rr0 + l4 + 4 * reg) + (cc0 + l15) * kIB] = acc[reg];
+    }
+    __syncthreads();
+    for (int t = wave; t < npairs * 4; t += 4) {
+      const int bj = t >> 2, bi = bj + d, sub = t & 3;
+      const int ro = bi * kIB, co = bj * kIB;
+      const int rr0 = (sub & 1) * 16, cc0 = (sub >> 1) * 16;
+      d4_t acc = (d4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int p0 = 0; p0 < kIB; p0 += 4) {
+        const double av = B[(ro + rr0 + l15) + (size_t)(ro + p0 + l4) * ldb];     // X_ii[rr][p]
+        const double bv = T[bj * kIB * kIB + (p0 + l4) + (cc0 + l15) * kIB];      // T[p][cc]
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg)
+        B[(ro + rr0 + l4 + 4 * reg) + (size_t)(co + cc0 + l15) * ldb] = -acc[reg];
+    }
+    __syncthreads();
+  }
+  double* X = P.invl + P.invl_pos[s] + (size_t)step * NB * NB;
+  double* XT = P.invlt + P.invl_pos[s] + (size_t)step * NB * NB;
+  for (int idx = tid; idx < NB * NB; idx += 256) {
+    const int c = idx / NB, i = idx - c * NB;
+    X[idx] = (i < nb && c < nb && i >= c) ? B[idx] : 0.0;
+    XT[idx] = (i < nb && c < nb && c >= i) ? B[c + (size_t)i * ldb] : 0.0;   // XT[i][c] = X[c][i]
+  }
 }
 
-// rows below the diagonal block: W = A21 * L11^-T (kept for the trailing update), L21 = W * D^-1
-constexpr int kTrsmRows = 64;
-__global__ __launch_bounds__(kTrsmRows) void k_big_trsm(DevPlan P, const int* __restrict__ list, int step, int NB) {
-  extern __shared__ __attribute__((aligned(16))) double sm[];
-  const int tid = threadIdx.x;
+// W = A21 * inv(L11)^T (MFMA), L21 = W * D^-1.  64 rows per workgroup; wave w owns panel columns
+// [32w, 32w + 32).  Computed transposed (D[c][r]) so that global accesses run along front rows.
+__global__ __launch_bounds__(256) void k_big_trsm(DevPlan P, const int* __restrict__ list, int step, int NB) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int s = list[blockIdx.y];
   const int col0 = P.sn_col0[s];
   const int k = P.sn_col0[s + 1] - col0;
@@ -254,41 +413,73 @@ __global__ __launch_bounds__(kTrsmRows) void k_big_trsm(DevPlan P, const int* __
   const int j0 = step * NB;
   if (j0 >= k) return;
   const int nb = min(NB, k - j0);
-  const int r0 = j0 + nb + blockIdx.x * kTrsmRows;
+  const int r0 = j0 + nb + blockIdx.x * 64;
   if (r0 >= f) return;
-  const int ldb = nb | 1;
-  double* L11 = sm;                         // nb x nb (lower, unit diagonal implied)
-  double* dd = sm + (size_t)ldb * nb;       // nb
-  double* wl = dd + nb;                     // nb x kTrsmRows, wl[c*64 + tid]
   double* F = P.arena + P.front_pos[s];
-  for (int idx = tid; idx < nb * nb; idx += kTrsmRows) {
-    const int c = idx / nb, i = idx - c * nb;
-    if (i >= c) L11[i + c * ldb] = F[(size_t)(j0 + c) * f + j0 + i];
+  double* Wb = P.wbuf + P.wbuf_pos[s];
+  const double* X = P.invl + P.invl_pos[s] + (size_t)step * NB * NB;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const int cs = wv * 32;  // column slice of this wave
+  d4_t acc[2][4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = (d4_t){0.0, 0.0, 0.0, 0.0};
+  if (cs < nb) {
+    const int pend = min(nb, cs + 32);  // inv(L11)[c][p] = 0 for p > c
+    for (int p0 = 0; p0 < pend; p0 += 4) {
+      const int p = p0 + l4;
+      const bool pv = p < nb;
+      double av[2], bv[4];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) av[a] = pv ? X[(cs + a * 16 + l15) + (size_t)p * NB] : 0.0;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int r = r0 + b * 16 + l15;
+        bv[b] = (pv && r < f) ? F[(size_t)(j0 + p) * f + r] : 0.0;
+      }
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a], bv[b], acc[a][b], 0, 0, 0);
+    }
   }
-  __syncthreads();
-  for (int j = tid; j < nb; j += kTrsmRows) dd[j] = L11[j + j * ldb];
-  __syncthreads();
-  const int i = r0 + tid;
-  if (i < f) {
-    double* Wb = P.wbuf + P.wbuf_pos[s];
-    for (int c = 0; c < nb; ++c) {
-      double v = F[(size_t)(j0 + c) * f + i];
-      for (int p = 0; p < c; ++p) v -= wl[p * kTrsmRows + tid] * L11[c + p * ldb];
-      wl[c * kTrsmRows + tid] = v;
-    }
-    for (int c = 0; c < nb; ++c) {
-      const double w = wl[c * kTrsmRows + tid];
-      Wb[(size_t)c * f + i] = w;
-      F[(size_t)(j0 + c) * f + i] = w / dd[c];
-    }
+  __syncthreads();  // every wave has finished reading the panel rows before anyone overwrites them
+  if (cs < nb) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int c = cs + a * 16 + l4 + 4 * reg;
+        if (c >= nb) continue;
+        const double rd = 1.0 / P.dvals[col0 + j0 + c];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const int r = r0 + b * 16 + l15;
+          if (r < f) {
+            const double wv_ = acc[a][b][reg];
+            Wb[(size_t)c * f + r] = wv_;
+            F[(size_t)(j0 + c) * f + r] = wv_ * rd;
+          }
+        }
+      }
   }
 }
 
-// trailing update with FP64 MFMA:  F[r, c] -= sum_p W[r, p] * L[c, p]   for r >= c >= j0 + nb
-// 64 x 64 tile per workgroup, 32 x 32 per wave, v_mfma_f64_16x16x4_f64.
-// The product is formed transposed (D[c][r]) so that the 16 lanes of an MFMA row group hold 16
-// consecutive front rows: loads and stores of F touch whole 128-byte segments.
-__global__ __launch_bounds__(256) void k_big_syrk(DevPlan P, const int* __restrict__ list, int step, int NB) {
+// trailing update  F[r, c] -= sum_p W[r, p] * L[c, p]  for r >= c >= j0 + nb  (the dominant kernel).
+// 128 x 128 tile per workgroup, 64 x 64 per wave = 4 x 4 accumulators of v_mfma_f64_16x16x4_f64.
+// The two operand panels are staged through LDS in chunks of kSyrkKC panel columns with 16-byte
+// coalesced global loads (one 1-KiB row per wave instruction), double buffered: the loads of chunk
+// i+1 are in flight while chunk i feeds the MFMAs.  LDS rows are padded to 144 doubles so that the
+// four k-slices of an operand fragment fall on disjoint banks.  The product is formed transposed
+// (D[c][r]) so that accumulator rows map to consecutive front rows: C is read and written in whole
+// 128-byte segments.  L is negated on its way into LDS, so the accumulators start from C.
+constexpr int kSyrkKC = 16;
+constexpr int kSyrkLd = 144;
+constexpr size_t kSyrkLds = (size_t)4 * kSyrkKC * kSyrkLd * sizeof(double);
+
+__global__ __launch_bounds__(256, 2) void k_big_syrk(DevPlan P, const int* __restrict__ list, int step, int NB) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int s = list[blockIdx.y];
   const int col0 = P.sn_col0[s];
@@ -298,45 +489,106 @@ __global__ __launch_bounds__(256) void k_big_syrk(DevPlan P, const int* __restri
   if (j0 >= k) return;
   const int nb = min(NB, k - j0);
   const int t0 = j0 + nb;
-  const int T = (f - t0 + 63) >> 6;
-  // tile pair (ti >= tj) from the flat index
-  const int idx = blockIdx.x;
-  if (idx >= T * (T + 1) / 2) return;
+  const int T = (f - t0 + 127) >> 7;
+  const int ntiles = T * (T + 1) / 2;
+  // XCD-aware order: workgroups b, b+8, b+16.. share an XCD (and its L2); give them consecutive
+  // tiles, which share the W row block
+  const int nx = (int)gridDim.x;
+  const int per = (nx + 7) >> 3;
+  const int idx = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+  if (idx >= ntiles) return;
   int ti = (int)((sqrtf(8.0f * (float)idx + 1.0f) - 1.0f) * 0.5f);
   while ((ti + 1) * (ti + 2) / 2 <= idx) ++ti;
   while (ti * (ti + 1) / 2 > idx) --ti;
   const int tj = idx - ti * (ti + 1) / 2;
-  const int rbase = t0 + ti * 64 + (wv & 1) * 32;  // front rows of this wave's 32 x 32 piece
-  const int cbase = t0 + tj * 64 + (wv >> 1) * 32; // front columns
-  if (rbase + 31 < cbase) return;                  // strictly above the diagonal
-  if (rbase >= f || cbase >= f) return;
+  const int rt0 = t0 + ti * 128, ct0 = t0 + tj * 128;   // tile origin
+  const int rbase = rt0 + (wv & 1) * 64;
+  const int cbase = ct0 + (wv >> 1) * 64;
+  const bool active = !(rbase + 63 < cbase) && rbase < f && cbase < f;
   double* F = P.arena + P.front_pos[s];
-  const double* Wb = P.wbuf + P.wbuf_pos[s];
+  const double* Wg = P.wbuf + P.wbuf_pos[s];
+  const double* Lg = F + (size_t)j0 * f;
+  double* smW = sm;                              // [2][KC][144]
+  double* smL = sm + 2 * kSyrkKC * kSyrkLd;      // [2][KC][144]
   const int l15 = lane & 15, l4 = lane >> 4;
-  d4_t acc[2][2];  // [column block][row block]
-  for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) acc[a][b] = (d4_t){0.0, 0.0, 0.0, 0.0};
-  const int cA0 = cbase + l15, cA1 = cbase + 16 + l15;
-  const int rB0 = rbase + l15, rB1 = rbase + 16 + l15;
-  for (int p0 = 0; p0 < nb; p0 += 4) {
-    const int p = p0 + l4;
-    const bool pv = p < nb;
-    // A operand: A[i = c][kk = p] = L[c, j0 + p];  B operand: B[kk = p][j = r] = W[r, p]
-    const double a0 = (pv && cA0 < f) ? F[(size_t)(j0 + p) * f + cA0] : 0.0;
-    const double a1 = (pv && cA1 < f) ? F[(size_t)(j0 + p) * f + cA1] : 0.0;
-    const double b0 = (pv && rB0 < f) ? Wb[(size_t)p * f + rB0] : 0.0;
-    const double b1 = (pv && rB1 < f) ? Wb[(size_t)p * f + rB1] : 0.0;
-    acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
-    acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
-    acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
-    acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
-  }
-  // D layout (f64 16x16x4): D[i = (lane>>4) + 4*reg][j = lane&15]  ->  i = column offset, j = row offset
-  for (int a = 0; a < 2; ++a)
-    for (int b = 0; b < 2; ++b) {
+
+  typedef double d2_t __attribute__((ext_vector_type(2)));
+  d2_t pw[4], pl[4];
+  const int nchunk = (nb + kSyrkKC - 1) / kSyrkKC;
+  auto gload = [&](int ch) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int p = ch * kSyrkKC + q * 4 + wv;
+      if (p < nb) {
+        const double* wsrc = Wg + (size_t)p * f + rt0 + lane * 2;
+        const double* lsrc = Lg + (size_t)p * f + ct0 + lane * 2;
+        __builtin_memcpy(&pw[q], wsrc, 16);
+        __builtin_memcpy(&pl[q], lsrc, 16);
+      } else {
+        pw[q] = (d2_t){0.0, 0.0};
+        pl[q] = (d2_t){0.0, 0.0};
+      }
+    }
+  };
+  auto sstore = [&](int buf) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int prow = q * 4 + wv;
+      *(d2_t*)(smW + ((size_t)buf * kSyrkKC + prow) * kSyrkLd + lane * 2) = pw[q];
+      *(d2_t*)(smL + ((size_t)buf * kSyrkKC + prow) * kSyrkLd + lane * 2) = -pl[q];
+    }
+  };
+
+  d4_t acc[4][4];  // [column block][row block]
+  gload(0);
+  // accumulators start from C (guarded; lanes outside the front or above the diagonal hold zeros)
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
       const int r = rbase + b * 16 + l15;
+#pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
         const int c = cbase + a * 16 + l4 + 4 * reg;
-        if (r < f && c < f && r >= c) F[(size_t)c * f + r] -= acc[a][b][reg];
+        acc[a][b][reg] = (active && r < f && c < f && r >= c) ? F[(size_t)c * f + r] : 0.0;
+      }
+    }
+  sstore(0);
+  __syncthreads();
+  for (int ch = 0; ch < nchunk; ++ch) {
+    const int buf = ch & 1;
+    if (ch + 1 < nchunk) gload(ch + 1);
+    if (active) {
+      const double* bw = smW + (size_t)buf * kSyrkKC * kSyrkLd + (wv & 1) * 64 + l15;
+      const double* bl = smL + (size_t)buf * kSyrkKC * kSyrkLd + (wv >> 1) * 64 + l15;
+#pragma unroll
+      for (int kk = 0; kk < kSyrkKC / 4; ++kk) {
+        double av[4], bv[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) av[a] = bl[(kk * 4 + l4) * kSyrkLd + a * 16];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) bv[b] = bw[(kk * 4 + l4) * kSyrkLd + b * 16];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a], bv[b], acc[a][b], 0, 0, 0);
+      }
+    }
+    if (ch + 1 < nchunk) sstore(buf ^ 1);
+    __syncthreads();
+  }
+  if (!active) return;
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int c = cbase + a * 16 + l4 + 4 * reg;
+      if (c >= f) continue;
+      double* colp = F + (size_t)c * f;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int r = rbase + b * 16 + l15;
+        if (r < f && r >= c) colp[r] = acc[a][b][reg];
       }
     }
 }
@@ -414,6 +666,110 @@ __global__ __launch_bounds__(TPB) void k_solve_bwd(DevPlan P, const int* __restr
   for (int j = tid; j < k; j += TPB) P.xwork[col0 + j] = xo[j];
 }
 
+// ---- big fronts: multi-workgroup blocked solves with the inverse diagonal blocks ----------------
+// forward assemble: w[pc] = rhs (pivot rows) + children's contribution vectors, via the inverted lists
+__global__ __launch_bounds__(256) void k_bigsolve_fwd_asm(DevPlan P, const int* __restrict__ list) {
+  const int s = list[blockIdx.y];
+  const int col0 = P.sn_col0[s];
+  const int k = P.sn_col0[s + 1] - col0;
+  const int f = (int)(P.row_ptr[s + 1] - P.row_ptr[s]);
+  const int pc = blockIdx.x * 256 + threadIdx.x;
+  if (pc >= f) return;
+  double w = pc < k ? P.xwork[col0 + pc] : 0.0;
+  const int64_t gc = P.bigcol_base[s] + pc;
+  for (int64_t q = P.ea_ptr[gc]; q < P.ea_ptr[gc + 1]; ++q) w += P.cv[P.cv_pos[P.ea_child[q]] + P.ea_jj[q]];
+  P.bigw[gc] = w;
+}
+
+// forward step J: y_J = inv(L_JJ) w_J (every workgroup, redundantly), z_J = y_J / d_J,
+// w[r] -= L[r, J] y_J for the rows below (row-parallel, no reduction)
+__global__ __launch_bounds__(256) void k_bigsolve_fwd_step(DevPlan P, const int* __restrict__ list, int step, int NB) {
+  __shared__ double wj[128], yj[128];
+  const int tid = threadIdx.x;
+  const int s = list[blockIdx.y];
+  const int col0 = P.sn_col0[s];
+  const int k = P.sn_col0[s + 1] - col0;
+  const int f = (int)(P.row_ptr[s + 1] - P.row_ptr[s]);
+  const int j0 = step * NB;
+  if (j0 >= k) return;
+  const int nb = min(NB, k - j0);
+  const int r = j0 + nb + blockIdx.x * 256 + tid;
+  if (blockIdx.x > 0 && j0 + nb + (int)blockIdx.x * 256 >= f) return;
+  double* w = P.bigw + P.bigcol_base[s];
+  const double* X = P.invl + P.invl_pos[s] + (size_t)step * NB * NB;
+  if (tid < nb) wj[tid] = w[j0 + tid];
+  __syncthreads();
+  if (tid < nb) {
+    double acc = 0.0;
+    for (int p = 0; p <= tid; ++p) acc += X[tid + (size_t)p * NB] * wj[p];
+    yj[tid] = acc;
+    if (blockIdx.x == 0) P.xwork[col0 + j0 + tid] = acc / P.dvals[col0 + j0 + tid];
+  }
+  __syncthreads();
+  if (r < f) {
+    const double* L = P.arena + P.front_pos[s] + (size_t)j0 * f + r;
+    double acc = w[r];
+#pragma unroll 4
+    for (int c = 0; c < nb; ++c) acc -= L[(size_t)c * f] * yj[c];
+    w[r] = acc;
+    if (j0 + nb >= k && r >= k) P.cv[P.cv_pos[s] + (r - k)] = acc;   // last step: contribution vector
+  }
+}
+
+// backward, rows below the pivot block: z[c] -= sum_{r >= k} L[r, c] x[rows[r]]   (wave per column)
+__global__ __launch_bounds__(256) void k_bigsolve_bwd_pre(DevPlan P, const int* __restrict__ list) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int s = list[blockIdx.y];
+  const int col0 = P.sn_col0[s];
+  const int k = P.sn_col0[s + 1] - col0;
+  const int f = (int)(P.row_ptr[s + 1] - P.row_ptr[s]);
+  const int c = blockIdx.x * 4 + wv;
+  if (c >= k || f == k) return;
+  const int* rows = P.rows + P.row_ptr[s];
+  const double* col = P.arena + P.front_pos[s] + (size_t)c * f;
+  double acc = 0.0;
+  for (int r = k + lane; r < f; r += 64) acc += col[r] * P.xwork[rows[r]];
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+  if (lane == 0) P.xwork[col0 + c] -= acc;
+}
+
+// backward step I (descending): x_I = inv(L_II)^T z_I (every workgroup, redundantly), then
+// z[c] -= sum_{r in I} L[r, c] x_I[r] for the columns c left of the block (wave per column)
+__global__ __launch_bounds__(256) void k_bigsolve_bwd_step(DevPlan P, const int* __restrict__ list, int step, int NB) {
+  __shared__ double zi[128], xi[128];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int s = list[blockIdx.y];
+  const int col0 = P.sn_col0[s];
+  const int k = P.sn_col0[s + 1] - col0;
+  const int f = (int)(P.row_ptr[s + 1] - P.row_ptr[s]);
+  const int j0 = step * NB;
+  if (j0 >= k) return;
+  const int nb = min(NB, k - j0);
+  if (blockIdx.x > 0 && (int)blockIdx.x * 64 >= j0) return;
+  const double* XT = P.invlt + P.invl_pos[s] + (size_t)step * NB * NB;
+  if (tid < nb) zi[tid] = P.xwork[col0 + j0 + tid];
+  __syncthreads();
+  if (tid < nb) {
+    double acc = 0.0;
+    for (int p = tid; p < nb; ++p) acc += XT[tid + (size_t)p * NB] * zi[p];   // X[p][tid]
+    xi[tid] = acc;
+  }
+  __syncthreads();
+  // columns [blockIdx.x*64, +64) of the part left of the block, 16 per wave
+  const double* Lrow = P.arena + P.front_pos[s] + j0;
+  for (int q = 0; q < 16; ++q) {
+    const int c = blockIdx.x * 64 + wv * 16 + q;
+    if (c >= j0) break;
+    const double* col = Lrow + (size_t)c * f;
+    double acc = 0.0;
+    for (int r = lane; r < nb; r += 64) acc += col[r] * xi[r];
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+    if (lane == 0) P.xwork[col0 + c] -= acc;
+  }
+  // the block's own solution is written last, by the first workgroup only: the others read z_I above
+  if (blockIdx.x == 0 && tid < nb) P.xwork[col0 + j0 + tid] = xi[tid];
+}
+
 __global__ void k_permute_in(int n, const int* __restrict__ perm, const double* __restrict__ rhs, double* __restrict__ x) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) x[i] = rhs[perm[i]];
@@ -462,7 +818,7 @@ size_t lds_small(int maxf) { return ((size_t)(maxf | 1) * maxf + maxf) * sizeof(
 
 std::string numeric_setup(const Symbolic& S, const SymbolicOptions& opts, hipStream_t stream, Numeric& N) {
   N.stream = stream;
-  N.nb = std::max(8, std::min(opts.panel_nb, 128));
+  N.nb = std::max(32, std::min((opts.panel_nb + 31) / 32 * 32, 128));
   N.small_max = std::max(32, std::min(opts.small_front_max, 136));
   N.nnz_in = S.nnz_in;
   if (S.max_front > 46000) return "front order exceeds the 32-bit local offset range";
@@ -522,19 +878,60 @@ std::string numeric_setup(const Symbolic& S, const SymbolicOptions& opts, hipStr
   }
   if (!(e = upload(N, sched, &d.sched)).empty()) return e;
   if (!(e = upload(N, wpos, &d.wbuf_pos)).empty()) return e;
-  if (!(e = dalloc(N, (size_t)S.arena_doubles, &d.arena, false)).empty()) return e;
+  // big fronts: inverted extend-add lists (per front column: which (child, jj) land on it),
+  // storage for the inverse diagonal blocks and the forward-solve work vectors
+  {
+    std::vector<int64_t> bigcol_base(ns, -1), invl_pos(ns, -1);
+    int64_t nbigcols = 0, invl_total = 0;
+    for (int s = 0; s < ns; ++s)
+      if (wpos[s] >= 0) {
+        const int64_t f = S.row_ptr[s + 1] - S.row_ptr[s];
+        const int64_t k = S.sn_col0[s + 1] - S.sn_col0[s];
+        bigcol_base[s] = nbigcols;
+        nbigcols += f;
+        invl_pos[s] = invl_total;
+        invl_total += ((k + N.nb - 1) / N.nb) * (int64_t)N.nb * N.nb;
+      }
+    std::vector<int64_t> ea_ptr(nbigcols + 1, 0);
+    for (int c = 0; c < ns; ++c) {
+      const int p = S.sn_parent[c];
+      if (p < 0 || wpos[p] < 0) continue;
+      for (int64_t q = S.rel_ptr[c]; q < S.rel_ptr[c + 1]; ++q) ++ea_ptr[bigcol_base[p] + S.rel[q] + 1];
+    }
+    for (int64_t i = 0; i < nbigcols; ++i) ea_ptr[i + 1] += ea_ptr[i];
+    std::vector<int> ea_child(ea_ptr[nbigcols]), ea_jj(ea_ptr[nbigcols]);
+    std::vector<int64_t> fill(ea_ptr.begin(), ea_ptr.end() - 1);
+    for (int c = 0; c < ns; ++c) {  // children in ascending order: the summation order is fixed
+      const int p = S.sn_parent[c];
+      if (p < 0 || wpos[p] < 0) continue;
+      for (int64_t q = S.rel_ptr[c]; q < S.rel_ptr[c + 1]; ++q) {
+        const int64_t slot = fill[bigcol_base[p] + S.rel[q]]++;
+        ea_child[slot] = c;
+        ea_jj[slot] = (int)(q - S.rel_ptr[c]);
+      }
+    }
+    if (!(e = upload(N, bigcol_base, &d.bigcol_base)).empty()) return e;
+    if (!(e = upload(N, invl_pos, &d.invl_pos)).empty()) return e;
+    if (!(e = upload(N, ea_ptr, &d.ea_ptr)).empty()) return e;
+    if (!(e = upload(N, ea_child, &d.ea_child)).empty()) return e;
+    if (!(e = upload(N, ea_jj, &d.ea_jj)).empty()) return e;
+    if (!(e = dalloc(N, (size_t)invl_total, &d.invl, false)).empty()) return e;
+    if (!(e = dalloc(N, (size_t)invl_total, &d.invlt, false)).empty()) return e;
+    if (!(e = dalloc(N, (size_t)nbigcols, &d.bigw, true)).empty()) return e;
+  }
+  if (!(e = dalloc(N, (size_t)S.arena_doubles + 512, &d.arena, false)).empty()) return e;
   if (!(e = dalloc(N, (size_t)S.n, &d.dvals, true)).empty()) return e;
   if (!(e = dalloc(N, (size_t)S.n, &d.diagadd, true)).empty()) return e;
   if (!(e = dalloc(N, (size_t)S.n, &d.xwork, true)).empty()) return e;
   if (!(e = dalloc(N, (size_t)S.sum_r, &d.cv, true)).empty()) return e;
-  if (!(e = dalloc(N, (size_t)wtotal, &d.wbuf, false)).empty()) return e;
+  if (!(e = dalloc(N, (size_t)wtotal + 512, &d.wbuf, true)).empty()) return e;
   if (!(e = dalloc(N, (size_t)4, &d.counters, true)).empty()) return e;
   if (!(e = dalloc(N, (size_t)S.nnz_in, &N.vals_owned, false)).empty()) return e;
   // kernels that may want more than 64 KiB of dynamic LDS
   const int big_lds = 160 * 1024;
   OKKT_HIP_TRY(hipFuncSetAttribute((const void*)k_front_small<256>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds));
   OKKT_HIP_TRY(hipFuncSetAttribute((const void*)k_big_diag, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds));
-  OKKT_HIP_TRY(hipFuncSetAttribute((const void*)k_big_trsm, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds));
+  OKKT_HIP_TRY(hipFuncSetAttribute((const void*)k_big_syrk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSyrkLds));
   return "";
 }
 
@@ -566,17 +963,16 @@ std::string numeric_factor_enqueue(Numeric& N, const double* d_vals, double tol)
     if (L.seg[3].cnt) {
       const Segment& g = L.seg[3];
       const int* list = P.sched + g.off;
-      hipLaunchKernelGGL(k_big_assemble, dim3((g.maxf + kAsmCols - 1) / kAsmCols, g.cnt), dim3(256), 0, st, P, list);
+      hipLaunchKernelGGL(k_big_assemble, dim3((g.maxf + 3) / 4, g.cnt), dim3(256), 0, st, P, list);
       const int nsteps = (g.maxk + NB - 1) / NB;
-      const size_t lds_diag = ((size_t)(NB | 1) * NB + NB) * sizeof(double);
-      const size_t lds_trsm = ((size_t)(NB | 1) * NB + NB + (size_t)NB * kTrsmRows) * sizeof(double);
+      const size_t lds_diag = ((size_t)NB * NB + (size_t)std::max(NB - kIB, kIB) * kIB + NB) * sizeof(double);
       for (int step = 0; step < nsteps; ++step) {
         hipLaunchKernelGGL(k_big_diag, dim3(g.cnt), dim3(256), lds_diag, st, P, list, step, NB, tol);
         const int rem = g.maxf - step * NB;  // upper bound on rows below the diagonal block
         if (rem <= 0) continue;
-        hipLaunchKernelGGL(k_big_trsm, dim3((rem + kTrsmRows - 1) / kTrsmRows, g.cnt), dim3(kTrsmRows), lds_trsm, st, P, list, step, NB);
-        const int T = (rem + 63) / 64;
-        hipLaunchKernelGGL(k_big_syrk, dim3(T * (T + 1) / 2, g.cnt), dim3(256), 0, st, P, list, step, NB);
+        hipLaunchKernelGGL(k_big_trsm, dim3((rem + 63) / 64, g.cnt), dim3(256), 0, st, P, list, step, NB);
+        const int T = (rem + 127) / 128;
+        hipLaunchKernelGGL(k_big_syrk, dim3((T * (T + 1) / 2 + 7) / 8 * 8, g.cnt), dim3(256), kSyrkLds, st, P, list, step, NB);
       }
     }
   }
@@ -588,26 +984,43 @@ std::string numeric_solve_enqueue(Numeric& N) {
   DevPlan P = N.d;
   hipStream_t st = N.stream;
   const int nl = (int)N.levels.size();
+  const int NB = N.nb;
   for (int l = 0; l < nl; ++l) {
     const LevelSchedule& L = N.levels[l];
-    for (int c = 0; c < kNumClasses; ++c) {
+    for (int c = 0; c < 3; ++c) {
       const Segment& g = L.seg[c];
       if (!g.cnt) continue;
       const size_t lds = (size_t)g.maxf * sizeof(double);
       if (c == 0) hipLaunchKernelGGL(k_solve_fwd<64>, dim3(g.cnt), dim3(64), lds, st, P, P.sched + g.off);
-      else if (c < 3) hipLaunchKernelGGL(k_solve_fwd<256>, dim3(g.cnt), dim3(256), lds, st, P, P.sched + g.off);
-      else hipLaunchKernelGGL(k_solve_fwd<1024>, dim3(g.cnt), dim3(1024), lds, st, P, P.sched + g.off);
+      else hipLaunchKernelGGL(k_solve_fwd<256>, dim3(g.cnt), dim3(256), lds, st, P, P.sched + g.off);
+    }
+    const Segment& g = L.seg[3];
+    if (g.cnt) {
+      const int* list = P.sched + g.off;
+      hipLaunchKernelGGL(k_bigsolve_fwd_asm, dim3((g.maxf + 255) / 256, g.cnt), dim3(256), 0, st, P, list);
+      const int nsteps = (g.maxk + NB - 1) / NB;
+      for (int step = 0; step < nsteps; ++step) {
+        const int rem = std::max(g.maxf - step * NB, 0);  // upper bound on the rows below block `step`
+        hipLaunchKernelGGL(k_bigsolve_fwd_step, dim3(std::max(1, (rem + 255) / 256), g.cnt), dim3(256), 0, st, P, list, step, NB);
+      }
     }
   }
   for (int l = nl - 1; l >= 0; --l) {
     const LevelSchedule& L = N.levels[l];
-    for (int c = 0; c < kNumClasses; ++c) {
+    const Segment& gb = L.seg[3];
+    if (gb.cnt) {
+      const int* list = P.sched + gb.off;
+      hipLaunchKernelGGL(k_bigsolve_bwd_pre, dim3((gb.maxk + 3) / 4, gb.cnt), dim3(256), 0, st, P, list);
+      const int nsteps = (gb.maxk + NB - 1) / NB;
+      for (int step = nsteps - 1; step >= 0; --step)
+        hipLaunchKernelGGL(k_bigsolve_bwd_step, dim3(std::max(1, (step * NB + 63) / 64), gb.cnt), dim3(256), 0, st, P, list, step, NB);
+    }
+    for (int c = 0; c < 3; ++c) {
       const Segment& g = L.seg[c];
       if (!g.cnt) continue;
       const size_t lds = (size_t)g.maxf * sizeof(double);
       if (c == 0) hipLaunchKernelGGL(k_solve_bwd<64>, dim3(g.cnt), dim3(64), lds, st, P, P.sched + g.off);
-      else if (c < 3) hipLaunchKernelGGL(k_solve_bwd<256>, dim3(g.cnt), dim3(256), lds, st, P, P.sched + g.off);
-      else hipLaunchKernelGGL(k_solve_bwd<1024>, dim3(g.cnt), dim3(1024), lds, st, P, P.sched + g.off);
+      else hipLaunchKernelGGL(k_solve_bwd<256>, dim3(g.cnt), dim3(256), lds, st, P, P.sched + g.off);
     }
   }
   OKKT_HIP_TRY(hipGetLastError());

@@ -25,7 +25,7 @@ struct SymbolicOptions {
   double relax_mid_frac = 0.15;
   double relax_any_frac = 0.03;
   int small_front_max = 64;  // fronts of order <= this take the LDS-resident kernel
-  int panel_nb = 64;         // block-column width of the big-front kernels
+  int panel_nb = 128;        // block-column width of the big-front kernels
 };
 
 // One supernode == one frontal matrix of order f = k + r:
