@@ -18,6 +18,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 
 namespace okkt {
 
@@ -241,7 +242,7 @@ constexpr int kIB = 32;  // inner block width of the diagonal-block kernel
 // NB x NB diagonal block of block-column `step`: LDL^T in LDS (inner width 32: register/readlane
 // 32 x 32 kernel on one wave, row-parallel solve below it, MFMA rank-32 update), D and inertia out,
 // then X = inv(L11) block by block (MFMA products) for the row-parallel k_big_trsm and the solves.
-__global__ __launch_bounds__(256) void k_big_diag(DevPlan P, const int* __restrict__ list, int step, int NB, double tol) {
+__global__ __launch_bounds__(256) void k_big_diag(DevPlan P, const int* __restrict__ list, int step, int NB, double tol, int dbg_stop) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, l4 = lane >> 4;
@@ -258,21 +259,33 @@ __global__ __launch_bounds__(256) void k_big_diag(DevPlan P, const int* __restri
   double* Wb = sm + (size_t)NB * NB;         // RMAX x 32 scratch
   double* rdv = Wb + (size_t)RMAX * kIB;     // reciprocal pivots
   double* F = P.arena + P.front_pos[s];
-  for (int idx = tid; idx < NB * NB; idx += 256) {
-    const int c = idx / NB, i = idx - c * NB;
-    B[idx] = (i < nb && c < nb && i >= c) ? F[(size_t)(j0 + c) * f + j0 + i] : 0.0;
+  for (int base = 0; base < NB * NB; base += 256 * 8) {
+    double v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {   // 8 loads in flight per thread
+      const int idx = base + q * 256 + tid;
+      const int c = idx / NB, i = idx - c * NB;
+      v[q] = (idx < NB * NB && i < nb && c < nb && i >= c) ? F[(size_t)(j0 + c) * f + j0 + i] : 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int idx = base + q * 256 + tid;
+      if (idx < NB * NB) B[idx] = v[q];
+    }
   }
   __syncthreads();
+  if (dbg_stop == 1) return;
   for (int off = 0; off < nb; off += kIB) {
     const int w = min(kIB, nb - off);
     if (wave == 0) diag32_wave(B, ldb, off, w);
     __syncthreads();
+    if (dbg_stop == 7) continue;
     if (tid < w) rdv[off + tid] = 1.0 / B[(off + tid) + (size_t)(off + tid) * ldb];
     __syncthreads();
     const int c0 = off + w;
     const int R = nb - c0;
     if (R > 0) {  // then w == 32
-      if (tid < R) {
+      if (dbg_stop != 8 && tid < R) {
         const int r = c0 + tid;
         double wr[kIB];
 #pragma unroll
@@ -314,7 +327,9 @@ __global__ __launch_bounds__(256) void k_big_diag(DevPlan P, const int* __restri
       __syncthreads();
     }
   }
+  if (dbg_stop == 2 || dbg_stop == 7 || dbg_stop == 8) return;
   // L11, D, inertia
+#pragma unroll 8
   for (int idx = tid; idx < nb * nb; idx += 256) {
     const int c = idx / nb, i = idx - c * nb;
     if (i >= c) F[(size_t)(j0 + c) * f + j0 + i] = B[i + (size_t)c * ldb];
@@ -327,6 +342,7 @@ __global__ __launch_bounds__(256) void k_big_diag(DevPlan P, const int* __restri
   }
   flush_counts(P.counters, pos, neg, zer, bad);
   __syncthreads();
+  if (dbg_stop == 3) return;
   // ---- X = inv(L11), unit lower, blockwise; overwrites B
   const int nblk = (nb + kIB - 1) / kIB;
   {
@@ -353,6 +369,7 @@ __global__ __launch_bounds__(256) void k_big_diag(DevPlan P, const int* __restri
     }
     __syncthreads();
   }
+  if (dbg_stop == 4) return;
   // off-diagonal blocks X_ij = -X_ii * (sum_{p=j}^{i-1} L_ip X_pj), by block distance d = i - j;
   // every 32 x 32 product is 2 x 2 MFMA tiles, the tiles of a round are spread over the waves
   double* T = Wb;  // up to 3 scratch blocks of 32 x 32
@@ -393,8 +410,10 @@ __global__ __launch_bounds__(256) void k_big_diag(DevPlan P, const int* __restri
     }
     __syncthreads();
   }
+  if (dbg_stop == 5) return;
   double* X = P.invl + P.invl_pos[s] + (size_t)step * NB * NB;
   double* XT = P.invlt + P.invl_pos[s] + (size_t)step * NB * NB;
+#pragma unroll 8
   for (int idx = tid; idx < NB * NB; idx += 256) {
     const int c = idx / NB, i = idx - c * NB;
     X[idx] = (i < nb && c < nb && i >= c) ? B[idx] : 0.0;
@@ -682,10 +701,11 @@ __global__ __launch_bounds__(256) void k_bigsolve_fwd_asm(DevPlan P, const int* 
 }
 
 // forward step J: y_J = inv(L_JJ) w_J (every workgroup, redundantly), z_J = y_J / d_J,
-// w[r] -= L[r, J] y_J for the rows below (row-parallel, no reduction)
+// w[r] -= L[r, J] y_J for the rows below (64 rows per workgroup, wave g takes a quarter of the
+// block's columns with all its loads in flight at once; partial sums meet in LDS)
 __global__ __launch_bounds__(256) void k_bigsolve_fwd_step(DevPlan P, const int* __restrict__ list, int step, int NB) {
-  __shared__ double wj[128], yj[128];
-  const int tid = threadIdx.x;
+  __shared__ double wj[128], yj[128], part[4][64];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int s = list[blockIdx.y];
   const int col0 = P.sn_col0[s];
   const int k = P.sn_col0[s + 1] - col0;
@@ -693,24 +713,58 @@ __global__ __launch_bounds__(256) void k_bigsolve_fwd_step(DevPlan P, const int*
   const int j0 = step * NB;
   if (j0 >= k) return;
   const int nb = min(NB, k - j0);
-  const int r = j0 + nb + blockIdx.x * 256 + tid;
-  if (blockIdx.x > 0 && j0 + nb + (int)blockIdx.x * 256 >= f) return;
+  if (blockIdx.x > 0 && j0 + nb + (int)blockIdx.x * 64 >= f) return;
   double* w = P.bigw + P.bigcol_base[s];
-  const double* X = P.invl + P.invl_pos[s] + (size_t)step * NB * NB;
+  const double* XT = P.invlt + P.invl_pos[s] + (size_t)step * NB * NB;
   if (tid < nb) wj[tid] = w[j0 + tid];
   __syncthreads();
-  if (tid < nb) {
-    double acc = 0.0;
-    for (int p = 0; p <= tid; ++p) acc += X[tid + (size_t)p * NB] * wj[p];
-    yj[tid] = acc;
-    if (blockIdx.x == 0) P.xwork[col0 + j0 + tid] = acc / P.dvals[col0 + j0 + tid];
+  // y[c] = sum_{p <= c} X[c][p] w[p]: one wave per row c (row c of X is contiguous in XT), 8 rows in flight
+  for (int c0 = wv * 8; c0 < nb; c0 += 32) {
+    double acc[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int c = c0 + q;
+      const double* xrow = XT + (size_t)c * NB;
+      double a = 0.0;
+      if (c < nb) {
+        if (lane <= c) a = xrow[lane] * wj[lane];
+        if (lane + 64 <= c) a += xrow[lane + 64] * wj[lane + 64];
+      }
+      acc[q] = a;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+      for (int q = 0; q < 8; ++q) acc[q] += __shfl_down(acc[q], o, 64);
+    if (lane == 0) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int c = c0 + q;
+        if (c < nb) {
+          yj[c] = acc[q];
+          if (blockIdx.x == 0) P.xwork[col0 + j0 + c] = acc[q] / P.dvals[col0 + j0 + c];
+        }
+      }
+    }
   }
   __syncthreads();
-  if (r < f) {
-    const double* L = P.arena + P.front_pos[s] + (size_t)j0 * f + r;
-    double acc = w[r];
-#pragma unroll 4
-    for (int c = 0; c < nb; ++c) acc -= L[(size_t)c * f] * yj[c];
+  const int r = j0 + nb + blockIdx.x * 64 + lane;
+  {
+    double a = 0.0;
+    if (r < f) {
+      const double* L = P.arena + P.front_pos[s] + (size_t)j0 * f + r;
+      const int cb = wv * 32;
+      double v[32];
+#pragma unroll
+      for (int q = 0; q < 32; ++q) v[q] = (cb + q < nb) ? L[(size_t)(cb + q) * f] : 0.0;
+#pragma unroll
+      for (int q = 0; q < 32; ++q) a += (cb + q < nb) ? v[q] * yj[(cb + q) & 127] : 0.0;   // yj beyond nb is uninitialised LDS
+    }
+    part[wv][lane] = a;
+  }
+  __syncthreads();
+  if (wv == 0 && r < f) {
+    const double acc = w[r] - ((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]));
     w[r] = acc;
     if (j0 + nb >= k && r >= k) P.cv[P.cv_pos[s] + (r - k)] = acc;   // last step: contribution vector
   }
@@ -746,25 +800,59 @@ __global__ __launch_bounds__(256) void k_bigsolve_bwd_step(DevPlan P, const int*
   if (j0 >= k) return;
   const int nb = min(NB, k - j0);
   if (blockIdx.x > 0 && (int)blockIdx.x * 64 >= j0) return;
-  const double* XT = P.invlt + P.invl_pos[s] + (size_t)step * NB * NB;
+  const double* X = P.invl + P.invl_pos[s] + (size_t)step * NB * NB;
   if (tid < nb) zi[tid] = P.xwork[col0 + j0 + tid];
   __syncthreads();
-  if (tid < nb) {
-    double acc = 0.0;
-    for (int p = tid; p < nb; ++p) acc += XT[tid + (size_t)p * NB] * zi[p];   // X[p][tid]
-    xi[tid] = acc;
+  // x[c] = sum_{p >= c} X[p][c] z[p]: one wave per c, lanes along p (column c of X is contiguous), 8 in flight
+  for (int c0 = wv * 8; c0 < nb; c0 += 32) {
+    double acc[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int c = c0 + q;
+      const double* xcol = X + (size_t)c * NB;
+      double a = 0.0;
+      if (c < nb) {
+        if (lane >= c && lane < nb) a = xcol[lane] * zi[lane];
+        if (lane + 64 >= c && lane + 64 < nb) a += xcol[lane + 64] * zi[lane + 64];
+      }
+      acc[q] = a;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+      for (int q = 0; q < 8; ++q) acc[q] += __shfl_down(acc[q], o, 64);
+    if (lane == 0) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) if (c0 + q < nb) xi[c0 + q] = acc[q];
+    }
   }
   __syncthreads();
-  // columns [blockIdx.x*64, +64) of the part left of the block, 16 per wave
+  // columns [blockIdx.x*64, +64) left of the block: 16 per wave, 8 at a time for memory parallelism
   const double* Lrow = P.arena + P.front_pos[s] + j0;
-  for (int q = 0; q < 16; ++q) {
-    const int c = blockIdx.x * 64 + wv * 16 + q;
-    if (c >= j0) break;
-    const double* col = Lrow + (size_t)c * f;
-    double acc = 0.0;
-    for (int r = lane; r < nb; r += 64) acc += col[r] * xi[r];
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
-    if (lane == 0) P.xwork[col0 + c] -= acc;
+  const double x0 = lane < nb ? xi[lane] : 0.0, x1 = lane + 64 < nb ? xi[lane + 64] : 0.0;
+  for (int q0 = 0; q0 < 16; q0 += 8) {
+    double acc[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int c = blockIdx.x * 64 + wv * 16 + q0 + q;
+      acc[q] = 0.0;
+      if (c < j0) {
+        const double* col = Lrow + (size_t)c * f;
+        if (lane < nb) acc[q] = col[lane] * x0;
+        if (lane + 64 < nb) acc[q] += col[lane + 64] * x1;
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+      for (int q = 0; q < 8; ++q) acc[q] += __shfl_down(acc[q], o, 64);
+    if (lane == 0) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int c = blockIdx.x * 64 + wv * 16 + q0 + q;
+        if (c < j0) P.xwork[col0 + c] -= acc[q];
+      }
+    }
   }
   // the block's own solution is written last, by the first workgroup only: the others read z_I above
   if (blockIdx.x == 0 && tid < nb) P.xwork[col0 + j0 + tid] = xi[tid];
@@ -949,6 +1037,7 @@ std::string numeric_factor_enqueue(Numeric& N, const double* d_vals, double tol)
   hipStream_t st = N.stream;
   OKKT_HIP_TRY(hipMemsetAsync(P.counters, 0, 4 * sizeof(unsigned long long), st));
   const int NB = N.nb;
+  static const int dbg_stop = getenv("OKKT_DEBUG_DIAG_STOP") ? atoi(getenv("OKKT_DEBUG_DIAG_STOP")) : 0;
   for (size_t l = 0; l < N.levels.size(); ++l) {
     const LevelSchedule& L = N.levels[l];
     if (L.seg[0].cnt) {
@@ -967,7 +1056,7 @@ std::string numeric_factor_enqueue(Numeric& N, const double* d_vals, double tol)
       const int nsteps = (g.maxk + NB - 1) / NB;
       const size_t lds_diag = ((size_t)NB * NB + (size_t)std::max(NB - kIB, kIB) * kIB + NB) * sizeof(double);
       for (int step = 0; step < nsteps; ++step) {
-        hipLaunchKernelGGL(k_big_diag, dim3(g.cnt), dim3(256), lds_diag, st, P, list, step, NB, tol);
+        hipLaunchKernelGGL(k_big_diag, dim3(g.cnt), dim3(256), lds_diag, st, P, list, step, NB, tol, dbg_stop);
         const int rem = g.maxf - step * NB;  // upper bound on rows below the diagonal block
         if (rem <= 0) continue;
         hipLaunchKernelGGL(k_big_trsm, dim3((rem + 63) / 64, g.cnt), dim3(256), 0, st, P, list, step, NB);
@@ -1001,7 +1090,7 @@ std::string numeric_solve_enqueue(Numeric& N) {
       const int nsteps = (g.maxk + NB - 1) / NB;
       for (int step = 0; step < nsteps; ++step) {
         const int rem = std::max(g.maxf - step * NB, 0);  // upper bound on the rows below block `step`
-        hipLaunchKernelGGL(k_bigsolve_fwd_step, dim3(std::max(1, (rem + 255) / 256), g.cnt), dim3(256), 0, st, P, list, step, NB);
+        hipLaunchKernelGGL(k_bigsolve_fwd_step, dim3(std::max(1, (rem + 63) / 64), g.cnt), dim3(256), 0, st, P, list, step, NB);
       }
     }
   }
