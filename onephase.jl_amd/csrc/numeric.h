@@ -48,6 +48,7 @@ struct DevPlan {
   int64_t* invl_pos = nullptr;     // [nsuper]
   double* bigw = nullptr;          // [n_bigcols] forward-solve work vectors of the big fronts
   unsigned long long* counters = nullptr;  // pos, neg, zero, nonfinite
+  double* zero_page = nullptr;  // 2 KiB of zeros (source of out-of-panel LDS-DMA rows)
 };
 
 // front classes by order f: 0: f<=32 (one wave), 1: f<=64, 2: f<=small_max (256 threads, LDS), 3: big

@@ -43,6 +43,12 @@ __device__ __forceinline__ void classify_pivot(double d, double tol, unsigned& p
   else ++zer;
 }
 
+// keep ? v : +0.0 as a bit mask.  A `cond ? load : 0` select lets hipcc sink the load under a branch
+// and wait vmcnt(0) for every element (serial memory round trips); the AND keeps the load unconditional.
+__device__ __forceinline__ double keep_f64(double v, bool keep) {
+  return __longlong_as_double(__double_as_longlong(v) & (keep ? -1ll : 0ll));
+}
+
 __device__ __forceinline__ unsigned wave_sum(unsigned v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
   return v;
@@ -449,13 +455,16 @@ __global__ __launch_bounds__(256) void k_big_trsm(DevPlan P, const int* __restri
     for (int p0 = 0; p0 < pend; p0 += 4) {
       const int p = p0 + l4;
       const bool pv = p < nb;
+      const int pc = pv ? p : 0;   // clamped: loads stay unconditional, the select follows
       double av[2], bv[4];
 #pragma unroll
-      for (int a = 0; a < 2; ++a) av[a] = pv ? X[(cs + a * 16 + l15) + (size_t)p * NB] : 0.0;
+      for (int a = 0; a < 2; ++a) {
+        av[a] = keep_f64(X[(cs + a * 16 + l15) + (size_t)pc * NB], pv);
+      }
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
         const int r = r0 + b * 16 + l15;
-        bv[b] = (pv && r < f) ? F[(size_t)(j0 + p) * f + r] : 0.0;
+        bv[b] = keep_f64(F[(size_t)(j0 + pc) * f + min(r, f - 1)], pv && r < f);
       }
 #pragma unroll
       for (int a = 0; a < 2; ++a)
@@ -486,18 +495,27 @@ __global__ __launch_bounds__(256) void k_big_trsm(DevPlan P, const int* __restri
 }
 
 // trailing update  F[r, c] -= sum_p W[r, p] * L[c, p]  for r >= c >= j0 + nb  (the dominant kernel).
-// 128 x 128 tile per workgroup, 64 x 64 per wave = 4 x 4 accumulators of v_mfma_f64_16x16x4_f64.
-// The two operand panels are staged through LDS in chunks of kSyrkKC panel columns with 16-byte
-// coalesced global loads (one 1-KiB row per wave instruction), double buffered: the loads of chunk
-// i+1 are in flight while chunk i feeds the MFMAs.  LDS rows are padded to 144 doubles so that the
-// four k-slices of an operand fragment fall on disjoint banks.  The product is formed transposed
-// (D[c][r]) so that accumulator rows map to consecutive front rows: C is read and written in whole
-// 128-byte segments.  L is negated on its way into LDS, so the accumulators start from C.
+//
+// 128 x 128 tile per workgroup (one workgroup per CU), 64 x 64 per wave.
+//  * MFMA shape: v_mfma_f64_4x4x4_4b_f64.  Measured on MI355X (scripts/mfma_f64_peak2.hip) it sustains
+//    68-76 TFLOP/s, the 16x16x4 form only 36-50.  Lane l of the instruction holds A[i = l&3][k = l>>4] and
+//    B[k = l>>4][j = l&3] of block (l>>2)&3 and receives D[i = l>>4][j = l&3] of that block (decoded with
+//    scripts/mfma_f64_4x4_decode.hip).  Feeding the same 4 panel columns c to all four A blocks (an LDS
+//    broadcast read) and 16 consecutive front rows r to B turns one instruction into a 16-row x 4-column
+//    strip of C: D lane l <-> row l&15, column l>>4, so C moves in whole 128-byte segments.
+//    A is negated by the instruction's neg modifier, so the accumulators simply start from C.
+//  * operands: both panels are staged by LDS-DMA (global_load_lds_dwordx4, one 1-KiB panel row per wave
+//    instruction, no staging registers) into a ring of three 16-column chunks; two chunks stay in flight
+//    across the (raw) barrier behind a counted s_waitcnt vmcnt.  LDS rows are padded to 144 doubles so the
+//    four k-slices of a B fragment fall on disjoint banks.
+//  * tile order: workgroups b, b+8, .. share an XCD; they get consecutive tiles (same W row block in L2).
 constexpr int kSyrkKC = 16;
 constexpr int kSyrkLd = 144;
-constexpr size_t kSyrkLds = (size_t)4 * kSyrkKC * kSyrkLd * sizeof(double);
+constexpr size_t syrk_lds_bytes(int stages) { return (size_t)stages * 2 * kSyrkKC * kSyrkLd * sizeof(double); }
+typedef __attribute__((address_space(3))) void lds_void_t;
 
-__global__ __launch_bounds__(256, 2) void k_big_syrk(DevPlan P, const int* __restrict__ list, int step, int NB) {
+template <int DBG, int STAGES>
+__global__ __launch_bounds__(256, STAGES == 2 ? 2 : 1) void k_big_syrk(DevPlan P, const int* __restrict__ list, int step, int NB) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int s = list[blockIdx.y];
@@ -510,8 +528,6 @@ __global__ __launch_bounds__(256, 2) void k_big_syrk(DevPlan P, const int* __res
   const int t0 = j0 + nb;
   const int T = (f - t0 + 127) >> 7;
   const int ntiles = T * (T + 1) / 2;
-  // XCD-aware order: workgroups b, b+8, b+16.. share an XCD (and its L2); give them consecutive
-  // tiles, which share the W row block
   const int nx = (int)gridDim.x;
   const int per = (nx + 7) >> 3;
   const int idx = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
@@ -525,91 +541,110 @@ __global__ __launch_bounds__(256, 2) void k_big_syrk(DevPlan P, const int* __res
   const int cbase = ct0 + (wv >> 1) * 64;
   const bool active = !(rbase + 63 < cbase) && rbase < f && cbase < f;
   double* F = P.arena + P.front_pos[s];
-  const double* Wg = P.wbuf + P.wbuf_pos[s];
-  const double* Lg = F + (size_t)j0 * f;
-  double* smW = sm;                              // [2][KC][144]
-  double* smL = sm + 2 * kSyrkKC * kSyrkLd;      // [2][KC][144]
+  const double* Wg = P.wbuf + P.wbuf_pos[s] + rt0 + lane * 2;
+  const double* Lg = F + (size_t)j0 * f + ct0 + lane * 2;
   const int l15 = lane & 15, l4 = lane >> 4;
-
-  typedef double d2_t __attribute__((ext_vector_type(2)));
-  d2_t pw[4], pl[4];
   const int nchunk = (nb + kSyrkKC - 1) / kSyrkKC;
-  auto gload = [&](int ch) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int p = ch * kSyrkKC + q * 4 + wv;
-      if (p < nb) {
-        const double* wsrc = Wg + (size_t)p * f + rt0 + lane * 2;
-        const double* lsrc = Lg + (size_t)p * f + ct0 + lane * 2;
-        __builtin_memcpy(&pw[q], wsrc, 16);
-        __builtin_memcpy(&pl[q], lsrc, 16);
-      } else {
-        pw[q] = (d2_t){0.0, 0.0};
-        pl[q] = (d2_t){0.0, 0.0};
-      }
-    }
-  };
-  auto sstore = [&](int buf) {
+
+  // stage `ch` -> ring slot ch % 3: wave wv moves panel rows q*4 + wv (q = 0..3) of both operands
+  auto issue = [&](int ch) {
+    double* slot = sm + (size_t)(ch % STAGES) * 2 * kSyrkKC * kSyrkLd;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int prow = q * 4 + wv;
-      *(d2_t*)(smW + ((size_t)buf * kSyrkKC + prow) * kSyrkLd + lane * 2) = pw[q];
-      *(d2_t*)(smL + ((size_t)buf * kSyrkKC + prow) * kSyrkLd + lane * 2) = -pl[q];
+      const int p = ch * kSyrkKC + prow;
+      // rows past the panel read a zero page instead (same instruction count on every path)
+      const double* wsrc = p < nb ? Wg + (size_t)p * f : P.zero_page + lane * 2;
+      const double* lsrc = p < nb ? Lg + (size_t)p * f : P.zero_page + lane * 2;
+      __builtin_amdgcn_global_load_lds(wsrc, (lds_void_t*)(slot + prow * kSyrkLd), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(lsrc, (lds_void_t*)(slot + (kSyrkKC + prow) * kSyrkLd), 16, 0, 0);
     }
   };
 
-  d4_t acc[4][4];  // [column block][row block]
-  gload(0);
+  double acc[16][4];  // [column group of 4][row block of 16]
   // accumulators start from C (guarded; lanes outside the front or above the diagonal hold zeros)
+  // Loads are unconditional on clamped (always valid) addresses and selected afterwards: a load under
+  // a per-element branch makes hipcc wait vmcnt(0) per element, i.e. 64 serial memory round trips.
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int cg = 0; cg < 16; ++cg) {
+    const int c = cbase + cg * 4 + l4;
+    const double* colp = F + (size_t)min(c, f - 1) * f;
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      const int r = rbase + b * 16 + l15;
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        const int c = cbase + a * 16 + l4 + 4 * reg;
-        acc[a][b][reg] = (active && r < f && c < f && r >= c) ? F[(size_t)c * f + r] : 0.0;
-      }
+    for (int rb = 0; rb < 4; ++rb) {
+      const int r = rbase + rb * 16 + l15;
+      if constexpr (DBG & 1) acc[cg][rb] = 0.0;
+      else acc[cg][rb] = keep_f64(colp[min(r, f - 1)], r < f && c < f && r >= c);
     }
-  sstore(0);
-  __syncthreads();
+  }
+  // the LDS-DMAs go out AFTER the C loads: with an LDS-DMA in flight hipcc waits vmcnt(0) after every
+  // ordinary load (64 serial round trips); in this order it issues all 64 back to back
+  asm volatile("" ::: "memory");
+  if constexpr (!(DBG & 8)) { issue(0); if (STAGES == 3 && nchunk > 1) issue(1); }
   for (int ch = 0; ch < nchunk; ++ch) {
-    const int buf = ch & 1;
-    if (ch + 1 < nchunk) gload(ch + 1);
-    if (active) {
-      const double* bw = smW + (size_t)buf * kSyrkKC * kSyrkLd + (wv & 1) * 64 + l15;
-      const double* bl = smL + (size_t)buf * kSyrkKC * kSyrkLd + (wv >> 1) * 64 + l15;
+    // STAGES == 3: chunk ch has landed once at most the 8 LDS-DMAs of chunk ch+1 are still outstanding;
+    // STAGES == 2: only chunk ch is in flight here
+    if (STAGES == 3 && ch + 1 < nchunk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    // the slot written next was last read STAGES - 1 iterations ago; everyone is past that barrier
+    if constexpr (!(DBG & 8)) { if (ch + STAGES - 1 < nchunk) issue(ch + STAGES - 1); }
+    if (active && !(DBG & 2)) {
+      const double* slot = sm + (size_t)(ch % STAGES) * 2 * kSyrkKC * kSyrkLd;
+      const double* bw = slot + (wv & 1) * 64 + l15;
+      const double* bl = slot + kSyrkKC * kSyrkLd + (wv >> 1) * 64 + (lane & 3);
+      if constexpr (STAGES == 3) {
+        // one wave per SIMD: nobody else hides the LDS latency, so all 80 operand fragments of the
+        // chunk are fetched up front and the latency is paid once per chunk
+        double bvv[kSyrkKC / 4][4], avv[kSyrkKC / 4][16];
 #pragma unroll
-      for (int kk = 0; kk < kSyrkKC / 4; ++kk) {
-        double av[4], bv[4];
+        for (int kk = 0; kk < kSyrkKC / 4; ++kk) {
 #pragma unroll
-        for (int a = 0; a < 4; ++a) av[a] = bl[(kk * 4 + l4) * kSyrkLd + a * 16];
+          for (int rb = 0; rb < 4; ++rb) bvv[kk][rb] = bw[(kk * 4 + l4) * kSyrkLd + rb * 16];
 #pragma unroll
-        for (int b = 0; b < 4; ++b) bv[b] = bw[(kk * 4 + l4) * kSyrkLd + b * 16];
+          for (int cg = 0; cg < 16; ++cg) avv[kk][cg] = bl[(kk * 4 + l4) * kSyrkLd + cg * 4];
+        }
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
+        for (int kk = 0; kk < kSyrkKC / 4; ++kk)
 #pragma unroll
-          for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a], bv[b], acc[a][b], 0, 0, 0);
+          for (int cg = 0; cg < 16; ++cg)
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb)
+              acc[cg][rb] = __builtin_amdgcn_mfma_f64_4x4x4f64(avv[kk][cg], bvv[kk][rb], acc[cg][rb], 0, 0, 1 /* neg A */);
+      } else {
+        // two workgroups per CU: the partner wave on the SIMD covers LDS latency; keep registers <= 256
+#pragma unroll
+        for (int kk = 0; kk < kSyrkKC / 4; ++kk) {
+          double bv[4];
+#pragma unroll
+          for (int rb = 0; rb < 4; ++rb) bv[rb] = bw[(kk * 4 + l4) * kSyrkLd + rb * 16];
+#pragma unroll
+          for (int half = 0; half < 4; ++half) {
+            double av[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) av[q] = bl[(kk * 4 + l4) * kSyrkLd + (half * 4 + q) * 4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+              for (int rb = 0; rb < 4; ++rb)
+                acc[half * 4 + q][rb] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[q], bv[rb], acc[half * 4 + q][rb], 0, 0, 1 /* neg A */);
+          }
+        }
       }
     }
-    if (ch + 1 < nchunk) sstore(buf ^ 1);
-    __syncthreads();
   }
   if (!active) return;
+  if constexpr (DBG & 4) { double t = 0; for (int a = 0; a < 16; ++a) for (int b = 0; b < 4; ++b) t += acc[a][b]; if (t == 1.2345e-300) F[0] = t; return; }
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int cg = 0; cg < 16; ++cg) {
+    const int c = cbase + cg * 4 + l4;
+    if (c >= f) continue;
+    double* colp = F + (size_t)c * f;
 #pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-      const int c = cbase + a * 16 + l4 + 4 * reg;
-      if (c >= f) continue;
-      double* colp = F + (size_t)c * f;
-#pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        const int r = rbase + b * 16 + l15;
-        if (r < f && r >= c) colp[r] = acc[a][b][reg];
-      }
+    for (int rb = 0; rb < 4; ++rb) {
+      const int r = rbase + rb * 16 + l15;
+      if (r < f && r >= c) colp[r] = acc[cg][rb];
     }
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1014,12 +1049,18 @@ std::string numeric_setup(const Symbolic& S, const SymbolicOptions& opts, hipStr
   if (!(e = dalloc(N, (size_t)S.sum_r, &d.cv, true)).empty()) return e;
   if (!(e = dalloc(N, (size_t)wtotal + 512, &d.wbuf, true)).empty()) return e;
   if (!(e = dalloc(N, (size_t)4, &d.counters, true)).empty()) return e;
+  if (!(e = dalloc(N, (size_t)256, &d.zero_page, true)).empty()) return e;
   if (!(e = dalloc(N, (size_t)S.nnz_in, &N.vals_owned, false)).empty()) return e;
   // kernels that may want more than 64 KiB of dynamic LDS
   const int big_lds = 160 * 1024;
   OKKT_HIP_TRY(hipFuncSetAttribute((const void*)k_front_small<256>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds));
   OKKT_HIP_TRY(hipFuncSetAttribute((const void*)k_big_diag, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds));
-  OKKT_HIP_TRY(hipFuncSetAttribute((const void*)k_big_syrk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSyrkLds));
+  for (const void* fn : {(const void*)k_big_syrk<0, 3>, (const void*)k_big_syrk<1, 3>, (const void*)k_big_syrk<2, 3>,
+                         (const void*)k_big_syrk<4, 3>, (const void*)k_big_syrk<13, 3>})
+    OKKT_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)syrk_lds_bytes(3)));
+  for (const void* fn : {(const void*)k_big_syrk<0, 2>, (const void*)k_big_syrk<1, 2>, (const void*)k_big_syrk<2, 2>,
+                         (const void*)k_big_syrk<13, 2>})
+    OKKT_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)syrk_lds_bytes(2)));
   return "";
 }
 
@@ -1037,6 +1078,7 @@ std::string numeric_factor_enqueue(Numeric& N, const double* d_vals, double tol)
   hipStream_t st = N.stream;
   OKKT_HIP_TRY(hipMemsetAsync(P.counters, 0, 4 * sizeof(unsigned long long), st));
   const int NB = N.nb;
+  static const int dbg_syrk = getenv("OKKT_DEBUG_SYRK") ? atoi(getenv("OKKT_DEBUG_SYRK")) : 0;
   static const int dbg_stop = getenv("OKKT_DEBUG_DIAG_STOP") ? atoi(getenv("OKKT_DEBUG_DIAG_STOP")) : 0;
   for (size_t l = 0; l < N.levels.size(); ++l) {
     const LevelSchedule& L = N.levels[l];
@@ -1061,7 +1103,22 @@ std::string numeric_factor_enqueue(Numeric& N, const double* d_vals, double tol)
         if (rem <= 0) continue;
         hipLaunchKernelGGL(k_big_trsm, dim3((rem + 63) / 64, g.cnt), dim3(256), 0, st, P, list, step, NB);
         const int T = (rem + 127) / 128;
-        hipLaunchKernelGGL(k_big_syrk, dim3((T * (T + 1) / 2 + 7) / 8 * 8, g.cnt), dim3(256), kSyrkLds, st, P, list, step, NB);
+        {
+          const dim3 grid((T * (T + 1) / 2 + 7) / 8 * 8, g.cnt);
+#define OKKT_SYRK(D, S) hipLaunchKernelGGL((k_big_syrk<D, S>), grid, dim3(256), syrk_lds_bytes(S), st, P, list, step, NB)
+          switch (dbg_syrk) {   // timing-only ablations (OKKT_DEBUG_SYRK): outputs are wrong for codes < 100
+            case 1: OKKT_SYRK(1, 3); break;
+            case 2: OKKT_SYRK(2, 3); break;
+            case 4: OKKT_SYRK(4, 3); break;
+            case 13: OKKT_SYRK(13, 3); break;
+            case 21: OKKT_SYRK(1, 2); break;
+            case 22: OKKT_SYRK(2, 2); break;
+            case 33: OKKT_SYRK(13, 2); break;
+            case 103: OKKT_SYRK(0, 3); break;   // correct variants
+            default: OKKT_SYRK(0, 2); break;
+          }
+#undef OKKT_SYRK
+        }
       }
     }
   }
