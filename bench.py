@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""bench.py -- KKT factor+solve/sec (fp64) on synthetic KKT systems, MI355X.
+
+A "step" is one pass of the hot path over one KKT system whose values are already resident in HBM:
+numeric multifrontal LDL^T (delta-shifted augmented matrix, symbolic analysis amortised -- it is done
+once per sparsity pattern) followed by one triangular solve.  Workload at N = 1: S-metric of SURVEY.md
+section 8d (n = 40 000, m = 60 000, nnz(tril K) ~ 1.8e6, locality model w = 50, p_far = 1 %).
+
+N > 1 (torchrun): every rank owns one GPU and factors+solves its own KKT system (different seed, same
+shape) -- replicas, weak scaling, no data-path collective; torch.distributed (RCCL) is used only for
+the barrier and the max-over-ranks of the elapsed time.
+
+One JSON line on rank 0 with `roofline` (dominant kernel = the FP64-MFMA trailing update k_big_syrk,
+timed live with HIP events on the library's stream) and `cpu_baseline` (the CPU oracle = scalar
+up-looking LDL^T restating CHOLMOD's simplicial ldlt, timed on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X FP64 matrix spec; measured ceilings: DESIGN.md
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="S-metric")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", default="S-C3")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the KKT path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    distributed = world > 1
+    if distributed:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from onephase_jl_amd import synth
+    from onephase_jl_amd.linear_system_solvers import finalize_b, initialize_b, linear_solver_HIP
+
+    prob = synth.make_config(args.config, seed=rank)
+    n, m = prob["n"], prob["m"]
+    K = synth.augmented_matrix(prob, delta=1e-8)
+    hip = linear_solver_HIP("symmetric", device=local_rank)
+    initialize_b(hip)
+    t0 = time.time()
+    hip.analyze(K)
+    t_analyze = time.time() - t0
+    d_vals = hip.dev_upload(K.data)
+    rhs = np.random.default_rng(1234 + rank).normal(size=n + m)
+    d_rhs = hip.dev_upload(rhs)
+    d_sol = hip.dev_alloc(8 * (n + m))
+
+    def step():
+        rc = hip.ls_factor_dev(d_vals, n, m)
+        hip.ls_solve_dev(d_rhs, d_sol)
+        return rc
+
+    for _ in range(args.warmup):
+        rc = step()
+    hip.profile_dominant(True)
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    t0 = time.perf_counter()
+    fac_ms = sol_ms = 0.0
+    for _ in range(args.steps):
+        rc = step()
+        st = hip.stats()
+        fac_ms += st["last_factor_ms"]
+        sol_ms += st["last_solve_ms"]
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    nlaunch, syrk_ms, syrk_flops = hip.get_profile()
+    hip.profile_dominant(False)
+
+    # correctness of what was timed: inertia flag and residual of the last solve
+    x = hip.dev_download(d_sol, (n + m,))
+    M = synth.symmetrize_lower(K)
+    resid = float(np.max(np.abs(M @ x - rhs)) / np.max(np.abs(rhs)))
+    st = hip.stats()
+    ok = (rc == 1) and hip.inertia == (n, m, 0, 0) and resid < 1e-5
+
+    if rank == 0:
+        value = world * args.steps / elapsed
+        achieved = syrk_flops / (syrk_ms * 1e-3) / 1e12 if syrk_ms > 0 else 0.0
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_syrk_pmc.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "KKT factor+solve/sec (fp64) at n+m~1e5, nnz~2e6",
+            "value": value,
+            "unit": "factor+solve/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{args.config}: augmented KKT [[H+dI, J'],[J, -S/Y]], n={n}, m={m}, nnz(tril K)={st['nnz_lower']}, "
+                            f"locality w=50, p_far=1%, delta=1e-8; per step: numeric LDL^T (symbolic amortised) + 1 solve",
+                "n": n, "m": m, "nnz_tril": st["nnz_lower"], "nnzL": st["nnzL"], "factor_flops": st["flops_exact"],
+                "multi_gpu": "replicas (one KKT system per rank)" if world > 1 else "single",
+                "factor_ms": fac_ms / args.steps, "solve_ms": sol_ms / args.steps, "analyze_s_once": t_analyze,
+                "inertia_ok": bool(ok), "residual_inf": resid,
+            },
+            "roofline": {
+                "kernel": "k_big_syrk (FP64 MFMA trailing update of the big fronts)",
+                "bound": "mfma",
+                "achieved": achieved,
+                "peak": FP64_MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
+                "traffic": traffic,
+                "launches": nlaunch,
+                "avg_launch_ms": syrk_ms / max(nlaunch, 1),
+                "algorithmic_flops_per_launch": syrk_flops / max(nlaunch, 1),
+                "share_of_factor_time": syrk_ms / max(fac_ms, 1e-9),
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_sample, st)
+        print(json.dumps(out))
+    hip.dev_free(d_vals); hip.dev_free(d_rhs); hip.dev_free(d_sol)
+    finalize_b(hip)
+    if distributed:
+        dist.destroy_process_group()
+    if not ok:
+        raise SystemExit(f"bench result failed its correctness check: rc={rc} inertia={hip.inertia} resid={resid}")
+
+
+def cpu_baseline(sample_cfg, st_metric):
+    """The oracle (scalar up-looking LDL^T, kind "port") on a bounded sample: one factor+solve of a smaller
+    instance of the same generator, scaled to the metric workload by the factor-flop ratio."""
+    import oracle
+    from onephase_jl_amd import synth
+    from onephase_jl_amd.linear_system_solvers import finalize_b, initialize_b, linear_solver_HIP
+    prob = synth.make_config(sample_cfg, seed=0)
+    n, m = prob["n"], prob["m"]
+    K = synth.augmented_matrix(prob, delta=1e-8)
+    h = linear_solver_HIP("symmetric")
+    initialize_b(h)
+    h.analyze(K)
+    perm = h.perm()          # same fill-reducing permutation as the GPU path
+    st = h.stats()
+    finalize_b(h)
+    ref = oracle.linear_solver_ORACLE("symmetric", perm=perm)
+    ref._analyze(K)          # symbolic amortised, like the GPU number
+    b = np.random.default_rng(0).normal(size=n + m)
+    t0 = time.perf_counter()
+    rc = ref.ls_factor_b(K, n, m)
+    x = ref.ls_solve(b)
+    dt = time.perf_counter() - t0
+    ratio = st_metric["flops_exact"] / st["flops_exact"]
+    return {
+        "value": 1.0 / (dt * ratio),
+        "unit": "factor+solve/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"one factor+solve of {sample_cfg} (n={n}, m={m}, {st['flops_exact']:.3g} factor flops) took {dt:.2f} s "
+                  f"on 1 core (rc={rc}); scaled by the factor-flop ratio {ratio:.1f} to the metric workload",
+        "sample_seconds": dt,
+        "sample_gflops": st["flops_exact"] / dt / 1e9,
+    }
+
+
+if __name__ == "__main__":
+    main()

@@ -137,6 +137,12 @@ int okkt_dev_upload(okkt_handle h, void* d_dst, const void* src, int64_t bytes);
 int okkt_dev_download(okkt_handle h, void* dst, const void* d_src, int64_t bytes);
 /* the handle's HIP stream (hipStream_t as void*), for callers that time with their own events */
 void* okkt_get_stream(okkt_handle h);
+/* per-launch timing of the dominant kernel (the FP64-MFMA trailing update k_big_syrk): HIP events are
+ * recorded around every launch on the handle's stream while enabled; okkt_get_profile returns the
+ * number of launches since enabling, their summed duration and their summed algorithmic flops
+ * (rem * (rem + 1) * nb per front and block column, DESIGN.md "Kernels") */
+int okkt_profile_dominant(okkt_handle h, int enable);
+int okkt_get_profile(okkt_handle h, int64_t* n_launches, double* total_ms, double* total_flops);
 
 /* ---- level 2: device-resident KKT system solver ----------------------------------------- */
 typedef struct {

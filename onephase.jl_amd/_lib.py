@@ -128,6 +128,8 @@ SIGNATURES = {
     "okkt_dev_upload": (C.c_int, [_vp, _vp, _vp, C.c_int64]),
     "okkt_dev_download": (C.c_int, [_vp, _vp, _vp, C.c_int64]),
     "okkt_get_stream": (_vp, [_vp]),
+    "okkt_profile_dominant": (C.c_int, [_vp, C.c_int]),
+    "okkt_get_profile": (C.c_int, [_vp, _i64p, _f64p, _f64p]),
     "okkt_kkt_default_pars": (C.c_int, [C.POINTER(OkktKktPars)]),
     "okkt_kkt_create": (C.c_int, [C.POINTER(_vp), C.POINTER(OkktOpts), C.c_int]),
     "okkt_kkt_destroy": (C.c_int, [_vp]),

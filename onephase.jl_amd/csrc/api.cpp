@@ -398,4 +398,35 @@ int okkt_dev_download(okkt_handle h, void* dst, const void* d_src, int64_t bytes
 }
 void* okkt_get_stream(okkt_handle h) { return h ? (void*)h->stream : nullptr; }
 
+int okkt_profile_dominant(okkt_handle h, int enable) {
+  if (!h) return OKKT_ERR_INVALID;
+  int rc = ensure_device(h);
+  if (rc != OKKT_OK) return rc;
+  (void)hipStreamSynchronize(h->stream);
+  h->N.profile = enable != 0;
+  h->N.prof_used = 0;
+  h->N.prof_flops.clear();
+  return OKKT_OK;
+}
+
+int okkt_get_profile(okkt_handle h, int64_t* n_launches, double* total_ms, double* total_flops) {
+  if (!h || !n_launches || !total_ms || !total_flops) return OKKT_ERR_INVALID;
+  int rc = ensure_device(h);
+  if (rc != OKKT_OK) return rc;
+  if (hipStreamSynchronize(h->stream) != hipSuccess) return solver_set_error(h, OKKT_ERR_HIP, "stream sync failed");
+  double ms = 0, fl = 0;
+  const size_t n = h->N.prof_used / 2;
+  for (size_t i = 0; i < n; ++i) {
+    float t = 0;
+    if (hipEventElapsedTime(&t, h->N.prof_events[2 * i], h->N.prof_events[2 * i + 1]) != hipSuccess)
+      return solver_set_error(h, OKKT_ERR_HIP, "hipEventElapsedTime failed");
+    ms += t;
+    fl += h->N.prof_flops[i];
+  }
+  *n_launches = (int64_t)n;
+  *total_ms = ms;
+  *total_flops = fl;
+  return OKKT_OK;
+}
+
 }  // extern "C"

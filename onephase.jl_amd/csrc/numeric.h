@@ -66,6 +66,14 @@ struct Numeric {
   hipStream_t stream = nullptr;
   double* vals_owned = nullptr;  // staging buffer for host-side nzval
   int64_t nnz_in = 0;
+  // optional per-launch timing of the dominant kernel (k_big_syrk) with HIP events on N.stream
+  bool profile = false;
+  std::vector<hipEvent_t> prof_events;   // pairs (start, stop)
+  size_t prof_used = 0;                  // events consumed since the last reset
+  std::vector<double> prof_flops;        // algorithmic flops of each profiled launch
+  std::vector<std::pair<int, int>> big_fk;  // (f, k) of sched entries (host copy, big fronts only need it)
+  std::vector<int> sched_host;
+  std::vector<int> sn_f, sn_k;           // per supernode
 };
 
 // returns "" or an error message

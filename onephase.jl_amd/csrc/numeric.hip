@@ -1001,6 +1001,10 @@ std::string numeric_setup(const Symbolic& S, const SymbolicOptions& opts, hipStr
   }
   if (!(e = upload(N, sched, &d.sched)).empty()) return e;
   if (!(e = upload(N, wpos, &d.wbuf_pos)).empty()) return e;
+  N.sched_host = sched;
+  N.sn_f.resize(ns);
+  N.sn_k.resize(ns);
+  for (int s = 0; s < ns; ++s) { N.sn_f[s] = (int)(S.row_ptr[s + 1] - S.row_ptr[s]); N.sn_k[s] = S.sn_col0[s + 1] - S.sn_col0[s]; }
   // big fronts: inverted extend-add lists (per front column: which (child, jj) land on it),
   // storage for the inverse diagonal blocks and the forward-solve work vectors
   {
@@ -1065,6 +1069,10 @@ std::string numeric_setup(const Symbolic& S, const SymbolicOptions& opts, hipStr
 }
 
 void numeric_release(Numeric& N) {
+  for (hipEvent_t ev : N.prof_events) (void)hipEventDestroy(ev);
+  N.prof_events.clear();
+  N.prof_used = 0;
+  N.prof_flops.clear();
   for (void* p : N.allocations) (void)hipFree(p);
   N.allocations.clear();
   N.levels.clear();
@@ -1105,6 +1113,23 @@ std::string numeric_factor_enqueue(Numeric& N, const double* d_vals, double tol)
         const int T = (rem + 127) / 128;
         {
           const dim3 grid((T * (T + 1) / 2 + 7) / 8 * 8, g.cnt);
+          if (N.profile) {
+            // algorithmic flops of this launch: sum over the level's fronts of rem * (rem + 1) * nb
+            double fl = 0;
+            for (int q = 0; q < g.cnt; ++q) {
+              const int s = N.sched_host[g.off + q];
+              const int j0 = step * NB;
+              if (j0 >= N.sn_k[s]) continue;
+              const double nbq = std::min(NB, N.sn_k[s] - j0);
+              const double remq = N.sn_f[s] - j0 - nbq;
+              fl += remq * (remq + 1.0) * nbq;
+            }
+            if (N.prof_used + 2 > N.prof_events.size()) {
+              for (int q = 0; q < 512; ++q) { hipEvent_t ev; OKKT_HIP_TRY(hipEventCreate(&ev)); N.prof_events.push_back(ev); }
+            }
+            N.prof_flops.push_back(fl);
+            OKKT_HIP_TRY(hipEventRecord(N.prof_events[N.prof_used++], st));
+          }
 #define OKKT_SYRK(D, S) hipLaunchKernelGGL((k_big_syrk<D, S>), grid, dim3(256), syrk_lds_bytes(S), st, P, list, step, NB)
           switch (dbg_syrk) {   // timing-only ablations (OKKT_DEBUG_SYRK): outputs are wrong for codes < 100
             case 1: OKKT_SYRK(1, 3); break;
@@ -1118,6 +1143,7 @@ std::string numeric_factor_enqueue(Numeric& N, const double* d_vals, double tol)
             default: OKKT_SYRK(0, 2); break;
           }
 #undef OKKT_SYRK
+          if (N.profile) OKKT_HIP_TRY(hipEventRecord(N.prof_events[N.prof_used++], st));
         }
       }
     }

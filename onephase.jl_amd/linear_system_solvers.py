@@ -154,6 +154,51 @@ class linear_solver_HIP(abstract_linear_system_solver):
                     "okkt_get_factor_csc")
         return sp.csc_matrix((val[: nnz.value], rowval[: nnz.value], colptr), shape=(self._dim, self._dim))
 
+    # -- device-resident variants: inputs already in HBM (bench.py, the KKT layer)
+    def dev_upload(self, arr):
+        """Copy a contiguous numpy array into a fresh HBM buffer; returns the device pointer (int)."""
+        self._need()
+        arr = np.ascontiguousarray(arr)
+        p = C.c_void_p()
+        self._check(self._lib.okkt_dev_alloc(self._h, arr.nbytes, C.byref(p)), "okkt_dev_alloc")
+        self._check(self._lib.okkt_dev_upload(self._h, p, arr.ctypes.data_as(C.c_void_p), arr.nbytes), "okkt_dev_upload")
+        return p.value
+
+    def dev_alloc(self, nbytes):
+        self._need()
+        p = C.c_void_p()
+        self._check(self._lib.okkt_dev_alloc(self._h, nbytes, C.byref(p)), "okkt_dev_alloc")
+        return p.value
+
+    def dev_download(self, ptr, shape, dtype=np.float64):
+        out = np.empty(shape, dtype=dtype)
+        self._check(self._lib.okkt_dev_download(self._h, out.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), out.nbytes), "okkt_dev_download")
+        return out
+
+    def dev_free(self, ptr):
+        self._check(self._lib.okkt_dev_free(self._h, C.c_void_p(ptr)), "okkt_dev_free")
+
+    def ls_factor_dev(self, d_nzval, n, m):
+        """ls_factor! with nzval resident in HBM (pattern analysed beforehand with analyze())."""
+        self._need()
+        inert = L.OkktInertia()
+        kind = L.OKKT_SYM_DEFINITE if self.sym == "definite" else L.OKKT_SYM_SYMMETRIC
+        rc = self._check(self._lib.okkt_factor_dev(self._h, C.c_void_p(d_nzval), n, m, kind, C.byref(inert)), "okkt_factor_dev")
+        self.inertia = inert.as_tuple()
+        return int(rc)
+
+    def ls_solve_dev(self, d_rhs, d_sol, nrhs=1):
+        self._need()
+        self._check(self._lib.okkt_solve_dev(self._h, C.c_void_p(d_rhs), C.c_void_p(d_sol), nrhs), "okkt_solve_dev")
+
+    def profile_dominant(self, enable):
+        self._check(self._lib.okkt_profile_dominant(self._h, 1 if enable else 0), "okkt_profile_dominant")
+
+    def get_profile(self):
+        n = C.c_int64(); ms = C.c_double(); fl = C.c_double()
+        self._check(self._lib.okkt_get_profile(self._h, C.byref(n), C.byref(ms), C.byref(fl)), "okkt_get_profile")
+        return n.value, ms.value, fl.value
+
     # -- the reference interface
     def ls_factor_b(self, SparseMatrix, n, m, timer=None):
         """ls_factor!(solver, A, n, m, timer) -> 1 if the inertia is (n, m, 0), else 0 (julia.jl:21-97)."""
