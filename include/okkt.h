@@ -176,6 +176,12 @@ int okkt_kkt_factor(okkt_kkt_handle k, double delta, okkt_inertia* inertia_out);
 /* ipopt_strategy!: returns 1 on :success, 0 on :failure (delta > delta_max), <0 on error */
 int okkt_kkt_ipopt_strategy(okkt_kkt_handle k, double delta_prev, const okkt_kkt_pars* pars,
                             int32_t* num_fac_out, double* delta_out);
+/* System_rhs(it, reduct) (system_rhs.jl:57-73): dual_r = -(grad - J'y + eta_mu*mu*pen*J'1)(1 - eta_D),
+ * primal_r = -(cons - s)(1 - eta_P), comp_r = eta_mu*mu - s.*y, at the CURRENT iterate.  J_nzval_cur = NULL
+ * uses the J values of the factorised iterate (form_system) */
+int okkt_kkt_system_rhs(okkt_kkt_handle k, const double* J_nzval_cur, const double* grad, const double* cons,
+                        const double* s, const double* y, double mu, double a_norm_penalty,
+                        double eta_P, double eta_D, double eta_mu, double* dual_r, double* primal_r, double* comp_r);
 /* compute_direction!: rhs triple (dual_r[n], primal_r[m], comp_r[m]) -> (dx[n], dy[m], ds[m]) + N err */
 int okkt_kkt_compute_direction(okkt_kkt_handle k, const double* dual_r, const double* primal_r,
                                const double* comp_r, int32_t ItRefine_Num,

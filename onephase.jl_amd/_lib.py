@@ -140,6 +140,7 @@ SIGNATURES = {
     "okkt_kkt_diag_min": (C.c_int, [_vp, _f64p]),
     "okkt_kkt_factor": (C.c_int, [_vp, C.c_double, C.POINTER(OkktInertia)]),
     "okkt_kkt_ipopt_strategy": (C.c_int, [_vp, C.c_double, C.POINTER(OkktKktPars), C.POINTER(C.c_int32), _f64p]),
+    "okkt_kkt_system_rhs": (C.c_int, [_vp, _f64p, _f64p, _f64p, _f64p, _f64p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _f64p, _f64p, _f64p]),
     "okkt_kkt_compute_direction": (C.c_int, [_vp, _f64p, _f64p, _f64p, C.c_int32, _f64p, _f64p, _f64p, C.POINTER(OkktKktError)]),
     "okkt_kkt_get_matrix": (C.c_int, [_vp, _i64p, _i64p, _i64p, _i64p, _f64p]),
     "okkt_kkt_get_schur_diag": (C.c_int, [_vp, _f64p]),

@@ -25,7 +25,7 @@ static int ensure_device(okkt_solver_s* h) {
   return solver_set_error(h, OKKT_ERR_NO_DEVICE, "no HIP device");
 }
 
-static int ensure_numeric(okkt_solver_s* h) {
+int solver_ensure_numeric(okkt_solver_s* h) {
   int rc = ensure_device(h);
   if (rc != OKKT_OK) return rc;
   if (!h->analyzed) return solver_set_error(h, OKKT_ERR_INVALID, "okkt_analyze has not been called");
@@ -38,7 +38,7 @@ static int ensure_numeric(okkt_solver_s* h) {
 
 int solver_factor_device(okkt_solver_s* h, const double* d_vals, int64_t n, int64_t m, int sym_kind,
                          okkt_inertia* out) {
-  int rc = ensure_numeric(h);
+  int rc = solver_ensure_numeric(h);
   if (rc != OKKT_OK) return rc;
   if (n < 0 || m < 0 || n + m != h->S.n) return solver_set_error(h, OKKT_ERR_INVALID, "n + m does not match the analysed dimension");
   if (sym_kind != OKKT_SYM_DEFINITE && sym_kind != OKKT_SYM_SYMMETRIC) return solver_set_error(h, OKKT_ERR_INVALID, "unknown sym_kind");
@@ -67,7 +67,7 @@ int solver_factor_device(okkt_solver_s* h, const double* d_vals, int64_t n, int6
 }
 
 int solver_solve_device(okkt_solver_s* h, const double* d_rhs, double* d_sol, int64_t nrhs) {
-  int rc = ensure_numeric(h);
+  int rc = solver_ensure_numeric(h);
   if (rc != OKKT_OK) return rc;
   if (!h->factored) return solver_set_error(h, OKKT_ERR_INVALID, "solve called before a factorisation");
   if (nrhs < 0) return solver_set_error(h, OKKT_ERR_INVALID, "nrhs < 0");
@@ -272,7 +272,7 @@ int okkt_factor_dev(okkt_handle h, const double* d_nzval, int64_t n, int64_t m, 
 int okkt_factor(okkt_handle h, const double* nzval, int64_t n, int64_t m, int sym_kind, okkt_inertia* out) {
   if (!h || (!nzval && h->S.nnz_in > 0)) return OKKT_ERR_INVALID;
   try {
-    int rc = ensure_numeric(h);
+    int rc = solver_ensure_numeric(h);
     if (rc != OKKT_OK) return rc;
     if (h->S.nnz_in > 0) {
       hipError_t he = hipMemcpyAsync(h->N.vals_owned, nzval, (size_t)h->S.nnz_in * sizeof(double), hipMemcpyHostToDevice, h->stream);
@@ -296,7 +296,7 @@ int okkt_solve_dev(okkt_handle h, const double* d_rhs, double* d_sol, int64_t nr
 int okkt_solve(okkt_handle h, const double* rhs, double* sol, int64_t nrhs) {
   if (!h || !rhs || !sol) return OKKT_ERR_INVALID;
   try {
-    int rc = ensure_numeric(h);
+    int rc = solver_ensure_numeric(h);
     if (rc != OKKT_OK) return rc;
     if (!h->factored) return solver_set_error(h, OKKT_ERR_INVALID, "solve called before a factorisation");
     const int64_t len = h->S.n * std::max<int64_t>(nrhs, 0);
@@ -323,7 +323,7 @@ int okkt_solve(okkt_handle h, const double* rhs, double* sol, int64_t nrhs) {
 
 int okkt_get_diag(okkt_handle h, double* d_out) {
   if (!h || !d_out) return OKKT_ERR_INVALID;
-  int rc = ensure_numeric(h);
+  int rc = solver_ensure_numeric(h);
   if (rc != OKKT_OK) return rc;
   if (!h->factored) return solver_set_error(h, OKKT_ERR_INVALID, "no factorisation");
   if (hipMemcpy(d_out, h->N.d.dvals, (size_t)h->S.n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
@@ -339,7 +339,7 @@ int okkt_get_factor_csc(okkt_handle h, int64_t* colptr_out, int64_t* rowval_out,
   if (nnz_out) *nnz_out = nnz;
   if (!colptr_out || !rowval_out || !val_out) return OKKT_OK;
   try {
-    int rc = ensure_numeric(h);
+    int rc = solver_ensure_numeric(h);
     if (rc != OKKT_OK) return rc;
     if (!h->factored) return solver_set_error(h, OKKT_ERR_INVALID, "no factorisation");
     std::vector<double> front;

@@ -1,0 +1,688 @@
+// C ABI, KKT-system level (include/okkt.h): device-resident counterpart of the reference's
+// Schur_KKT_solver / Symmetric_KKT_solver.
+//
+//   form_system!                       /root/reference/src/kkt_system_solver/schur.jl:47-62, symmetric.jl:35-53
+//   eval_J_T_J / eval_diag_J_T_J       src/utils/eval.jl:85-100          -> k_assemble_schur / k_schur_diag
+//   update_delta_vecs! + factor!       schur.jl:64-87, symmetric.jl:55-57,85-102, kkt_system_solver.jl:98-113,190-204
+//   System_rhs                         src/kkt_system_solver/system_rhs.jl:57-73
+//   compute_direction_implementation!  schur.jl:89-182, symmetric.jl:59-83
+//   update_kkt_error!                  kkt_system_solver.jl:27-47,67-96
+//   ipopt_strategy!                    src/IPM/delta_strategy.jl:37-114
+//   eval_jac_prod / eval_jac_T_prod / hess_product   eval.jl:102-108,221-234 -> k_spmv_* kernels
+//
+// All sums are owner-computes (one thread per output entry, fixed order): results are bitwise
+// reproducible from run to run; there are no floating-point atomics.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "solver.h"
+
+using namespace okkt;
+
+struct okkt_kkt_s {
+  okkt_handle ls = nullptr;
+  int kind = OKKT_KKT_SCHUR;
+  int64_t n = 0, m = 0, nnzH = 0, nnzJ = 0, nnzA = 0, dimA = 0;
+  bool structured = false, formed = false, factored = false;
+  double delta = 0.0;
+  std::string err;
+  std::vector<void*> allocs;
+  // assembled matrix pattern (host copy, 0-based CSC lower)
+  std::vector<int64_t> Ap, Ai;
+  // device: H (CSC lower + CSR view), J (CSC + CSR view), point
+  int64_t *Hp = nullptr, *Hrp = nullptr, *Hrmap = nullptr, *Jp = nullptr, *Jrp = nullptr, *Jrmap = nullptr;
+  int *Hi = nullptr, *Hrj = nullptr, *Ji = nullptr, *Jrj = nullptr;
+  double *Hx = nullptr, *Jx = nullptr, *s = nullptr, *y = nullptr, *sig = nullptr;
+  double* Avals = nullptr;
+  int64_t *mapH = nullptr, *mapJ = nullptr, *diagA = nullptr;   // symmetric: value slots in A
+  int64_t *qptr = nullptr, *qh = nullptr;                        // schur: contributions per Q entry
+  int *qa = nullptr, *qb = nullptr, *qi = nullptr;
+  double* schur_diag = nullptr;
+  // work vectors
+  double *rD = nullptr, *rP = nullptr, *rC = nullptr, *dx = nullptr, *dy = nullptr, *ds = nullptr;
+  double *vn1 = nullptr, *vn2 = nullptr, *vn3 = nullptr, *vm1 = nullptr, *vm2 = nullptr, *big1 = nullptr, *big2 = nullptr;
+  double* red = nullptr;  // reduction outputs
+};
+
+namespace {
+
+#define KK_TRY(k, expr)                                                                      \
+  do {                                                                                       \
+    hipError_t e__ = (expr);                                                                 \
+    if (e__ != hipSuccess) { (k)->err = std::string(#expr) + ": " + hipGetErrorString(e__); return OKKT_ERR_HIP; } \
+  } while (0)
+
+template <typename T>
+int kk_upload(okkt_kkt_s* k, const std::vector<T>& v, T** out) {
+  void* p = nullptr;
+  KK_TRY(k, hipMalloc(&p, std::max<size_t>(v.size(), 1) * sizeof(T)));
+  k->allocs.push_back(p);
+  if (!v.empty()) KK_TRY(k, hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  *out = (T*)p;
+  return OKKT_OK;
+}
+template <typename T>
+int kk_alloc(okkt_kkt_s* k, size_t count, T** out) {
+  void* p = nullptr;
+  KK_TRY(k, hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T)));
+  k->allocs.push_back(p);
+  KK_TRY(k, hipMemset(p, 0, std::max<size_t>(count, 1) * sizeof(T)));
+  *out = (T*)p;
+  return OKKT_OK;
+}
+
+inline dim3 grid1(int64_t n) { return dim3((unsigned)std::max<int64_t>(1, (n + 255) / 256)); }
+
+// ---- assembly ---------------------------------------------------------------------------------
+// K = [[H, J'],[J, -diag(s/y)]], lower triangle only: pure gather/scatter through precomputed slots
+__global__ void k_assemble_aug(int64_t nnzH, int64_t nnzJ, int64_t n, int64_t m, const double* __restrict__ Hx,
+                               const double* __restrict__ Jx, const double* __restrict__ s, const double* __restrict__ y,
+                               const int64_t* __restrict__ mapH, const int64_t* __restrict__ mapJ,
+                               const int64_t* __restrict__ diagA, double* __restrict__ A) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < nnzH) A[mapH[t]] = Hx[t];
+  else if (t < nnzH + nnzJ) A[mapJ[t - nnzH]] = Jx[t - nnzH];
+  else if (t < nnzH + nnzJ + m) { const int64_t i = t - nnzH - nnzJ; A[diagA[n + i]] = -s[i] / y[i]; }
+}
+
+// Q = J' diag(sig) J + H on the lower triangle: every entry sums its own contribution list
+// (row i ascending, like Gustavson's product in eval.jl:85-87), then adds H
+__global__ void k_assemble_schur(int64_t nnzQ, const int64_t* __restrict__ qptr, const int* __restrict__ qa,
+                                 const int* __restrict__ qb, const int* __restrict__ qi, const int64_t* __restrict__ qh,
+                                 const double* __restrict__ Jx, const double* __restrict__ sig,
+                                 const double* __restrict__ Hx, double* __restrict__ A) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= nnzQ) return;
+  double v = 0.0;
+  for (int64_t t = qptr[e]; t < qptr[e + 1]; ++t) v += (Jx[qa[t]] * sig[qi[t]]) * Jx[qb[t]];
+  if (qh[e] >= 0) v += Hx[qh[e]];
+  A[e] = v;
+}
+
+// schur_diag = diag(H) + sum_i J_ij^2 sig_i (kkt_system_solver.jl:296-300, eval.jl:89-100)
+__global__ void k_schur_diag(int64_t n, const int64_t* __restrict__ Jp, const int* __restrict__ Ji,
+                             const double* __restrict__ Jx, const double* __restrict__ sig,
+                             const int64_t* __restrict__ Hp, const int* __restrict__ Hi,
+                             const double* __restrict__ Hx, double* __restrict__ out) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  double di = 0.0;
+  for (int64_t p = Jp[j]; p < Jp[j + 1]; ++p) di += Jx[p] * Jx[p] * sig[Ji[p]];
+  double h = 0.0;
+  for (int64_t p = Hp[j]; p < Hp[j + 1]; ++p) if (Hi[p] == j) h += Hx[p];
+  out[j] = h + di;
+}
+__global__ void k_gather(int64_t n, const int64_t* __restrict__ idx, const double* __restrict__ src, double* __restrict__ dst) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[idx[i]];
+}
+__global__ void k_div(int64_t n, const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ o) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) o[i] = a[i] / b[i];
+}
+
+// ---- SpMV -------------------------------------------------------------------------------------
+// y = A x with A given by compressed rows over a value map (J x through the CSR view of the CSC J)
+__global__ void k_spmv_rows(int64_t nrows, const int64_t* __restrict__ rp, const int* __restrict__ cj,
+                            const int64_t* __restrict__ map, const double* __restrict__ vals,
+                            const double* __restrict__ x, double* __restrict__ y) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nrows) return;
+  double acc = 0.0;
+  for (int64_t p = rp[i]; p < rp[i + 1]; ++p) acc += vals[map[p]] * x[cj[p]];
+  y[i] = acc;
+}
+// y = A' v for a CSC matrix A: one thread per column (J' v)
+__global__ void k_spmv_cols(int64_t ncols, const int64_t* __restrict__ cp, const int* __restrict__ ri,
+                            const double* __restrict__ vals, const double* __restrict__ v, double* __restrict__ y) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= ncols) return;
+  double acc = 0.0;
+  for (int64_t p = cp[j]; p < cp[j + 1]; ++p) acc += vals[p] * v[ri[p]];
+  y[j] = acc;
+}
+// y = L x + L' x - diag(L) x for a lower-triangular CSC L (hess_product, eval.jl:221-234)
+__global__ void k_spmv_symlower(int64_t n, const int64_t* __restrict__ cp, const int* __restrict__ ri,
+                                const double* __restrict__ vals, const int64_t* __restrict__ rp,
+                                const int* __restrict__ rj, const int64_t* __restrict__ rmap,
+                                const double* __restrict__ x, double* __restrict__ y) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double v1 = 0.0, v2 = 0.0, dg = 0.0;
+  for (int64_t p = rp[i]; p < rp[i + 1]; ++p) {          // row i of L
+    v1 += vals[rmap[p]] * x[rj[p]];
+    if (rj[p] == i) dg += vals[rmap[p]];
+  }
+  for (int64_t p = cp[i]; p < cp[i + 1]; ++p) v2 += vals[p] * x[ri[p]];   // column i of L = row i of L'
+  y[i] = v1 + v2 - dg * x[i];
+}
+
+// ---- vector kernels -----------------------------------------------------------------------------
+__global__ void k_schur_t1(int64_t m, const double* rP, const double* rC, const double* sig, const double* s, double* o) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < m) o[i] = rP[i] * sig[i] + rC[i] / s[i];                 // schur.jl:103
+}
+__global__ void k_add(int64_t n, const double* a, const double* b, double* o) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) o[i] = a[i] + b[i];
+}
+__global__ void k_mul(int64_t n, const double* a, const double* b, double* o) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) o[i] = a[i] * b[i];
+}
+__global__ void k_refine_res(int64_t n, const double* rhs, const double* jac_res, const double* hx, const double* dx,
+                             double delta, double* res) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) res[i] = rhs[i] - (jac_res[i] + (hx[i] + delta * dx[i]));   // schur.jl:168-170
+}
+__global__ void k_schur_dyds(int64_t m, const double* Jdx, const double* rP, const double* rC, const double* y,
+                             const double* sig, double* dy, double* ds) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < m) {
+    dy[i] = -(Jdx[i] - (rP[i] + rC[i] / y[i])) * sig[i];            // schur.jl:113
+    ds[i] = Jdx[i] - rP[i];                                         // schur.jl:116
+  }
+}
+__global__ void k_sym_rhs(int64_t n, int64_t m, const double* rD, const double* rP, const double* rC, const double* y, double* o) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) o[i] = rD[i];
+  else if (i < n + m) o[i] = rP[i - n] + rC[i - n] / y[i - n];       // symmetric.jl:65
+}
+__global__ void k_sym_split(int64_t n, int64_t m, const double* sol, double* dx, double* dy) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dx[i] = sol[i];
+  else if (i < n + m) dy[i - n] = -sol[i];                           // symmetric.jl:72-73
+}
+__global__ void k_sub(int64_t n, const double* a, const double* b, double* o) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) o[i] = a[i] - b[i];
+}
+__global__ void k_errD(int64_t n, double delta, const double* dx, const double* hx, const double* jty, const double* rD, double* o) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) o[i] = ((delta * dx[i] + 0.0) + hx[i] - jty[i]) - rD[i];    // kkt_system_solver.jl:27-47,76
+}
+__global__ void k_errP(int64_t m, const double* Jdx, const double* ds, const double* rP, double* o) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < m) o[i] = Jdx[i] - ds[i] - rP[i];                          // :80
+}
+__global__ void k_errMu(int64_t m, const double* s, const double* dy, const double* y, const double* ds, const double* rC, double* o) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < m) o[i] = s[i] * dy[i] + y[i] * ds[i] - rC[i];             // :84
+}
+// system_rhs.jl:57-73 + eval.jl:59-63,136-142
+__global__ void k_rhs_dual(int64_t n, const double* grad, const double* jty, const double* jt1, double mu_pen, double one_minus_D, double* o) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) o[i] = -((grad[i] - jty[i]) + mu_pen * jt1[i]) * one_minus_D;
+}
+__global__ void k_rhs_pc(int64_t m, const double* cons, const double* s, const double* y, double one_minus_P, double mu_target, double* rP, double* rC) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < m) { rP[i] = -(cons[i] - s[i]) * one_minus_P; rC[i] = mu_target - s[i] * y[i]; }
+}
+__global__ void k_fill(int64_t n, double v, double* o) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) o[i] = v;
+}
+
+// single-block reductions (inputs are O(n+m) vectors; deterministic)
+__global__ __launch_bounds__(1024) void k_reduce(int64_t n, const double* __restrict__ v, int mode /*0 min, 1 max|.|*/, double* out) {
+  __shared__ double sh[1024];
+  double a = mode == 0 ? INFINITY : 0.0;
+  bool nan = false;
+  for (int64_t i = threadIdx.x; i < n; i += 1024) {
+    const double x = v[i];
+    if (x != x) nan = true;
+    if (mode == 0) a = fmin(a, x); else a = fmax(a, fabs(x));
+  }
+  sh[threadIdx.x] = nan ? NAN : a;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) {
+      const double p = sh[threadIdx.x], q = sh[threadIdx.x + o];
+      sh[threadIdx.x] = (p != p || q != q) ? NAN : (mode == 0 ? fmin(p, q) : fmax(p, q));
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *out = n > 0 ? sh[0] : (mode == 0 ? INFINITY : 0.0);
+}
+
+int kk_fail(okkt_kkt_s* k, int code, const std::string& msg) { k->err = msg; return code; }
+
+int kk_check_ls(okkt_kkt_s* k, int rc, const char* what) {
+  if (rc < 0) { k->err = std::string(what) + ": " + okkt_last_error(k->ls); }
+  return rc;
+}
+
+hipStream_t kk_stream(okkt_kkt_s* k) { return k->ls->stream; }
+
+int kk_reduce(okkt_kkt_s* k, int64_t n, const double* v, int mode, double* host_out) {
+  hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, kk_stream(k), n, v, mode, k->red);
+  KK_TRY(k, hipMemcpyAsync(host_out, k->red, sizeof(double), hipMemcpyDeviceToHost, kk_stream(k)));
+  KK_TRY(k, hipStreamSynchronize(kk_stream(k)));
+  return OKKT_OK;
+}
+
+// J x, J' v, H x on the handle's stream
+void spmv_J(okkt_kkt_s* k, const double* x, double* y) {
+  hipLaunchKernelGGL(k_spmv_rows, grid1(k->m), dim3(256), 0, kk_stream(k), k->m, k->Jrp, k->Jrj, k->Jrmap, k->Jx, x, y);
+}
+void spmv_JT(okkt_kkt_s* k, const double* Jx, const double* v, double* y) {
+  hipLaunchKernelGGL(k_spmv_cols, grid1(k->n), dim3(256), 0, kk_stream(k), k->n, k->Jp, k->Ji, Jx, v, y);
+}
+void spmv_H(okkt_kkt_s* k, const double* x, double* y) {
+  hipLaunchKernelGGL(k_spmv_symlower, grid1(k->n), dim3(256), 0, kk_stream(k), k->n, k->Hp, k->Hi, k->Hx, k->Hrp, k->Hrj, k->Hrmap, x, y);
+}
+
+}  // namespace
+
+extern "C" {
+
+int okkt_kkt_default_pars(okkt_kkt_pars* p) {
+  if (!p) return OKKT_ERR_INVALID;
+  p->delta_start = 1e-6;                 // parameters.jl:147-158
+  p->delta_min = 1e-12;
+  p->delta_max = 1e50;
+  p->delta_inc = 8.0;
+  p->delta_dec = 1.0 / M_PI;
+  p->delta_zero = 0.0;
+  p->ItRefine_Num = 3;                   // parameters.jl:20
+  p->max_it = 500;                       // delta_strategy.jl:40
+  return OKKT_OK;
+}
+
+int okkt_kkt_create(okkt_kkt_handle* out, const okkt_opts* opts, int kkt_kind) {
+  if (!out) return OKKT_ERR_INVALID;
+  *out = nullptr;
+  if (kkt_kind != OKKT_KKT_SCHUR && kkt_kind != OKKT_KKT_SYMMETRIC) return OKKT_ERR_INVALID;
+  okkt_kkt_s* k = new (std::nothrow) okkt_kkt_s();
+  if (!k) return OKKT_ERR_ALLOC;
+  k->kind = kkt_kind;
+  int rc = okkt_create(&k->ls, opts);
+  if (rc != OKKT_OK) { delete k; return rc; }
+  *out = k;
+  return OKKT_OK;
+}
+
+int okkt_kkt_destroy(okkt_kkt_handle k) {
+  if (!k) return OKKT_ERR_INVALID;
+  if (k->ls && k->ls->device_ready) { (void)hipSetDevice(k->ls->device); (void)hipStreamSynchronize(k->ls->stream); }
+  for (void* p : k->allocs) (void)hipFree(p);
+  if (k->ls) okkt_destroy(k->ls);
+  delete k;
+  return OKKT_OK;
+}
+
+const char* okkt_kkt_last_error(okkt_kkt_handle k) { return k ? k->err.c_str() : "null handle"; }
+okkt_handle okkt_kkt_linear_solver(okkt_kkt_handle k) { return k ? k->ls : nullptr; }
+
+int okkt_kkt_set_structure(okkt_kkt_handle k, int64_t n, int64_t m, const int64_t* H_colptr, const int64_t* H_rowval,
+                           const int64_t* J_colptr, const int64_t* J_rowval, int index_base) {
+  if (!k || !H_colptr || !J_colptr || n < 0 || m < 0) return OKKT_ERR_INVALID;
+  if (index_base != 0 && index_base != 1) return kk_fail(k, OKKT_ERR_INVALID, "index_base must be 0 or 1");
+  if (k->ls->opts.host_symbolic_only || !k->ls->device_ready) return kk_fail(k, OKKT_ERR_NO_DEVICE, "no HIP device");
+  if (k->structured) return kk_fail(k, OKKT_ERR_INVALID, "structure already set: create a new handle for a new pattern");
+  try {
+    const int64_t b = index_base;
+    const int64_t nnzH = H_colptr[n] - b, nnzJ = J_colptr[n] - b;
+    if (nnzH > 0 && !H_rowval) return OKKT_ERR_INVALID;
+    if (nnzJ > 0 && !J_rowval) return OKKT_ERR_INVALID;
+    k->n = n; k->m = m; k->nnzH = nnzH; k->nnzJ = nnzJ;
+    std::vector<int64_t> Hp(n + 1), Jp(n + 1);
+    std::vector<int> Hi(nnzH), Ji(nnzJ);
+    for (int64_t j = 0; j <= n; ++j) { Hp[j] = H_colptr[j] - b; Jp[j] = J_colptr[j] - b; }
+    for (int64_t j = 0; j < n; ++j) {
+      for (int64_t p = Hp[j]; p < Hp[j + 1]; ++p) {
+        const int64_t i = H_rowval[p] - b;
+        if (i < j || i >= n) return kk_fail(k, OKKT_ERR_INVALID, "H must hold the lower triangle only (Class_cutest.jl:548)");
+        Hi[p] = (int)i;
+      }
+      for (int64_t p = Jp[j]; p < Jp[j + 1]; ++p) {
+        const int64_t i = J_rowval[p] - b;
+        if (i < 0 || i >= m) return kk_fail(k, OKKT_ERR_INVALID, "J row index out of range");
+        Ji[p] = (int)i;
+      }
+    }
+    // CSR views
+    auto csr_view = [](int64_t nrows, int64_t ncols, const std::vector<int64_t>& cp, const std::vector<int>& ri,
+                       std::vector<int64_t>& rp, std::vector<int>& rj, std::vector<int64_t>& rmap) {
+      rp.assign(nrows + 1, 0);
+      for (size_t p = 0; p < ri.size(); ++p) ++rp[ri[p] + 1];
+      for (int64_t i = 0; i < nrows; ++i) rp[i + 1] += rp[i];
+      rj.resize(ri.size()); rmap.resize(ri.size());
+      std::vector<int64_t> fill(rp.begin(), rp.end() - 1);
+      for (int64_t j = 0; j < ncols; ++j)
+        for (int64_t p = cp[j]; p < cp[j + 1]; ++p) { const int64_t q = fill[ri[p]]++; rj[q] = (int)j; rmap[q] = p; }
+    };
+    std::vector<int64_t> Hrp, Hrmap, Jrp, Jrmap;
+    std::vector<int> Hrj, Jrj;
+    csr_view(n, n, Hp, Hi, Hrp, Hrj, Hrmap);
+    csr_view(m, n, Jp, Ji, Jrp, Jrj, Jrmap);
+    int rc;
+#define UPL(dst, vec) if ((rc = kk_upload(k, vec, &k->dst)) != OKKT_OK) return rc
+    UPL(Hp, Hp); UPL(Hi, Hi); UPL(Hrp, Hrp); UPL(Hrj, Hrj); UPL(Hrmap, Hrmap);
+    UPL(Jp, Jp); UPL(Ji, Ji); UPL(Jrp, Jrp); UPL(Jrj, Jrj); UPL(Jrmap, Jrmap);
+    // ---- pattern of the matrix that is factorised
+    if (k->kind == OKKT_KKT_SYMMETRIC) {
+      const int64_t dim = n + m;
+      k->dimA = dim;
+      std::vector<int64_t> Ap(dim + 1, 0), Ai, mapH(nnzH), mapJ(nnzJ), diagA(dim);
+      Ai.reserve(nnzH + nnzJ + dim);
+      for (int64_t j = 0; j < n; ++j) {
+        // column j: diagonal (always present: delta lands there), H below it, then the J rows
+        bool has_diag = false;
+        for (int64_t p = Hp[j]; p < Hp[j + 1]; ++p) has_diag |= Hi[p] == j;
+        diagA[j] = (int64_t)Ai.size();
+        if (!has_diag) Ai.push_back(j);
+        for (int64_t p = Hp[j]; p < Hp[j + 1]; ++p) {
+          if (Hi[p] == j) diagA[j] = (int64_t)Ai.size();
+          mapH[p] = (int64_t)Ai.size();
+          Ai.push_back(Hi[p]);
+        }
+        for (int64_t p = Jp[j]; p < Jp[j + 1]; ++p) { mapJ[p] = (int64_t)Ai.size(); Ai.push_back(n + Ji[p]); }
+        Ap[j + 1] = (int64_t)Ai.size();
+      }
+      for (int64_t i = 0; i < m; ++i) { diagA[n + i] = (int64_t)Ai.size(); Ai.push_back(n + i); Ap[n + i + 1] = (int64_t)Ai.size(); }
+      k->nnzA = (int64_t)Ai.size();
+      UPL(mapH, mapH); UPL(mapJ, mapJ); UPL(diagA, diagA);
+      k->Ap = Ap; k->Ai = Ai;
+    } else {
+      // lower triangle of J' S J + H: pairs (a >= b) of the columns present in each row of J
+      k->dimA = n;
+      std::vector<std::vector<int>> cols(n);   // per column b: rows a >= b
+      for (int64_t i = 0; i < m; ++i)
+        for (int64_t p = Jrp[i]; p < Jrp[i + 1]; ++p)
+          for (int64_t q = Jrp[i]; q < Jrp[i + 1]; ++q)
+            if (Jrj[p] >= Jrj[q]) cols[Jrj[q]].push_back(Jrj[p]);
+      for (int64_t j = 0; j < n; ++j) {
+        cols[j].push_back((int)j);  // diagonal always present (delta)
+        for (int64_t p = Hp[j]; p < Hp[j + 1]; ++p) cols[j].push_back(Hi[p]);
+        std::sort(cols[j].begin(), cols[j].end());
+        cols[j].erase(std::unique(cols[j].begin(), cols[j].end()), cols[j].end());
+      }
+      std::vector<int64_t> Ap(n + 1, 0), Ai, diagA(n);
+      for (int64_t j = 0; j < n; ++j) { Ap[j + 1] = Ap[j] + (int64_t)cols[j].size(); }
+      Ai.resize(Ap[n]);
+      for (int64_t j = 0; j < n; ++j) { std::copy(cols[j].begin(), cols[j].end(), Ai.begin() + Ap[j]); diagA[j] = Ap[j]; }
+      k->nnzA = Ap[n];
+      // contribution lists
+      std::vector<int64_t> qptr(k->nnzA + 1, 0), qh(k->nnzA, -1);
+      auto slot = [&](int a, int bcol) -> int64_t {
+        auto it = std::lower_bound(Ai.begin() + Ap[bcol], Ai.begin() + Ap[bcol + 1], (int64_t)a);
+        return it - Ai.begin();
+      };
+      for (int64_t i = 0; i < m; ++i)
+        for (int64_t p = Jrp[i]; p < Jrp[i + 1]; ++p)
+          for (int64_t q = Jrp[i]; q < Jrp[i + 1]; ++q)
+            if (Jrj[p] >= Jrj[q]) ++qptr[slot(Jrj[p], Jrj[q]) + 1];
+      for (int64_t e = 0; e < k->nnzA; ++e) qptr[e + 1] += qptr[e];
+      std::vector<int> qa(qptr[k->nnzA]), qb(qptr[k->nnzA]), qi(qptr[k->nnzA]);
+      std::vector<int64_t> fill(qptr.begin(), qptr.end() - 1);
+      for (int64_t i = 0; i < m; ++i)   // rows ascending: fixed summation order
+        for (int64_t p = Jrp[i]; p < Jrp[i + 1]; ++p)
+          for (int64_t q = Jrp[i]; q < Jrp[i + 1]; ++q)
+            if (Jrj[p] >= Jrj[q]) {
+              const int64_t t = fill[slot(Jrj[p], Jrj[q])]++;
+              // Q[a][b] = sum_i (J'[b... the reference forms (J_T * D) * J: entry (row a of J_T) -> J[i][a] * d_i * J[i][b]
+              qa[t] = (int)Jrmap[p]; qb[t] = (int)Jrmap[q]; qi[t] = (int)i;
+            }
+      for (int64_t j = 0; j < n; ++j)
+        for (int64_t p = Hp[j]; p < Hp[j + 1]; ++p) qh[slot(Hi[p], (int)j)] = p;
+      UPL(qptr, qptr); UPL(qh, qh); UPL(qa, qa); UPL(qb, qb); UPL(qi, qi); UPL(diagA, diagA);
+      k->Ap = Ap; k->Ai = Ai;
+    }
+#undef UPL
+    if ((rc = kk_alloc(k, (size_t)nnzH, &k->Hx)) || (rc = kk_alloc(k, (size_t)nnzJ, &k->Jx)) || (rc = kk_alloc(k, (size_t)m, &k->s)) ||
+        (rc = kk_alloc(k, (size_t)m, &k->y)) || (rc = kk_alloc(k, (size_t)m, &k->sig)) || (rc = kk_alloc(k, (size_t)k->nnzA, &k->Avals)) ||
+        (rc = kk_alloc(k, (size_t)n, &k->schur_diag)) || (rc = kk_alloc(k, (size_t)n, &k->rD)) || (rc = kk_alloc(k, (size_t)m, &k->rP)) ||
+        (rc = kk_alloc(k, (size_t)m, &k->rC)) || (rc = kk_alloc(k, (size_t)n, &k->dx)) || (rc = kk_alloc(k, (size_t)m, &k->dy)) ||
+        (rc = kk_alloc(k, (size_t)m, &k->ds)) || (rc = kk_alloc(k, (size_t)n, &k->vn1)) || (rc = kk_alloc(k, (size_t)n, &k->vn2)) ||
+        (rc = kk_alloc(k, (size_t)n, &k->vn3)) || (rc = kk_alloc(k, (size_t)m, &k->vm1)) || (rc = kk_alloc(k, (size_t)m, &k->vm2)) ||
+        (rc = kk_alloc(k, (size_t)(n + m), &k->big1)) || (rc = kk_alloc(k, (size_t)(n + m), &k->big2)) || (rc = kk_alloc(k, (size_t)8, &k->red)))
+      return rc;
+    rc = okkt_analyze(k->ls, k->dimA, k->Ap.data(), k->Ai.data(), 0);
+    if (rc != OKKT_OK) return kk_check_ls(k, rc, "okkt_analyze");
+    k->structured = true;
+    return OKKT_OK;
+  } catch (const std::bad_alloc&) {
+    return kk_fail(k, OKKT_ERR_ALLOC, "out of host memory in okkt_kkt_set_structure");
+  } catch (...) {
+    return kk_fail(k, OKKT_ERR_INTERNAL, "unexpected exception in okkt_kkt_set_structure");
+  }
+}
+
+int okkt_kkt_form_system(okkt_kkt_handle k, const double* H_nzval, const double* J_nzval, const double* s, const double* y) {
+  if (!k || !s || !y) return OKKT_ERR_INVALID;
+  if (!k->structured) return kk_fail(k, OKKT_ERR_INVALID, "okkt_kkt_set_structure has not been called");
+  if ((k->nnzH > 0 && !H_nzval) || (k->nnzJ > 0 && !J_nzval)) return OKKT_ERR_INVALID;
+  hipStream_t st = kk_stream(k);
+  KK_TRY(k, hipSetDevice(k->ls->device));
+  if (k->nnzH) KK_TRY(k, hipMemcpyAsync(k->Hx, H_nzval, (size_t)k->nnzH * 8, hipMemcpyHostToDevice, st));
+  if (k->nnzJ) KK_TRY(k, hipMemcpyAsync(k->Jx, J_nzval, (size_t)k->nnzJ * 8, hipMemcpyHostToDevice, st));
+  if (k->m) {
+    KK_TRY(k, hipMemcpyAsync(k->s, s, (size_t)k->m * 8, hipMemcpyHostToDevice, st));
+    KK_TRY(k, hipMemcpyAsync(k->y, y, (size_t)k->m * 8, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_div, grid1(k->m), dim3(256), 0, st, k->m, k->y, k->s, k->sig);   // y ./ s
+  }
+  if (k->kind == OKKT_KKT_SYMMETRIC) {
+    KK_TRY(k, hipMemsetAsync(k->Avals, 0, (size_t)std::max<int64_t>(k->nnzA, 1) * 8, st));
+    const int64_t tot = k->nnzH + k->nnzJ + k->m;
+    if (tot) hipLaunchKernelGGL(k_assemble_aug, grid1(tot), dim3(256), 0, st, k->nnzH, k->nnzJ, k->n, k->m, k->Hx, k->Jx, k->s, k->y, k->mapH, k->mapJ, k->diagA, k->Avals);
+    if (k->n) hipLaunchKernelGGL(k_schur_diag, grid1(k->n), dim3(256), 0, st, k->n, k->Jp, k->Ji, k->Jx, k->sig, k->Hp, k->Hi, k->Hx, k->schur_diag);
+  } else {
+    if (k->nnzA) hipLaunchKernelGGL(k_assemble_schur, grid1(k->nnzA), dim3(256), 0, st, k->nnzA, k->qptr, k->qa, k->qb, k->qi, k->qh, k->Jx, k->sig, k->Hx, k->Avals);
+    if (k->n) hipLaunchKernelGGL(k_gather, grid1(k->n), dim3(256), 0, st, k->n, k->diagA, k->Avals, k->schur_diag);   // schur_diag = diag(Q), schur.jl:56
+  }
+  KK_TRY(k, hipStreamSynchronize(st));
+  KK_TRY(k, hipGetLastError());
+  k->formed = true;
+  k->factored = false;
+  return OKKT_OK;
+}
+
+int okkt_kkt_diag_min(okkt_kkt_handle k, double* out) {
+  if (!k || !out) return OKKT_ERR_INVALID;
+  if (!k->formed) return kk_fail(k, OKKT_ERR_INVALID, "form_system has not been called");
+  return kk_reduce(k, k->n, k->schur_diag, 0, out);
+}
+
+int okkt_kkt_factor(okkt_kkt_handle k, double delta, okkt_inertia* inertia_out) {
+  if (!k) return OKKT_ERR_INVALID;
+  // factor!(kkt_solver, delta): update_delta! then factor! (kkt_system_solver.jl:98-113,190-204); the state
+  // machine of the reference (:system_formed -> :delta_updated -> :factored) collapses into this one call
+  if (!k->formed) return kk_fail(k, OKKT_ERR_INVALID, "kkt solver not ready to factor: form_system has not been called");
+  int rc = solver_ensure_numeric(k->ls);
+  if (rc != OKKT_OK) return kk_check_ls(k, rc, "device plan");
+  k->delta = delta;
+  // the first n diagonal entries move, the (2,2) block never does (symmetric.jl:85-102)
+  launch_set_shift(k->ls->N, delta, k->n);
+  if (k->kind == OKKT_KKT_SYMMETRIC) rc = solver_factor_device(k->ls, k->Avals, k->n, k->m, OKKT_SYM_SYMMETRIC, inertia_out);
+  else rc = solver_factor_device(k->ls, k->Avals, k->n, 0, OKKT_SYM_DEFINITE, inertia_out);
+  if (rc < 0) return kk_check_ls(k, rc, "factor");
+  k->factored = true;
+  return rc;
+}
+
+int okkt_kkt_ipopt_strategy(okkt_kkt_handle k, double delta_prev, const okkt_kkt_pars* pars, int32_t* num_fac_out, double* delta_out) {
+  if (!k || !num_fac_out || !delta_out) return OKKT_ERR_INVALID;
+  okkt_kkt_pars P;
+  okkt_kkt_default_pars(&P);
+  if (pars) P = *pars;
+  // delta_strategy.jl:37-114
+  int num_fac = 0;
+  double dmin = 0.0;
+  int rc = okkt_kkt_diag_min(k, &dmin);
+  if (rc != OKKT_OK) return rc;
+  double tau = 1.5 * dmin;
+  double delta = P.delta_zero;
+  *num_fac_out = 0;
+  *delta_out = delta;
+  if (tau > 0.0) {
+    tau = 0.0;
+    rc = okkt_kkt_factor(k, delta, nullptr);
+    if (rc < 0) return rc;
+    ++num_fac;
+    if (rc == 1) { *num_fac_out = num_fac; *delta_out = delta; return 1; }
+  }
+  for (int i = 1; i <= P.max_it; ++i) {
+    if (i == 1) {
+      if (delta_prev != 0.0) delta = std::max(P.delta_min - tau, delta_prev * P.delta_dec);
+      else delta = P.delta_start - tau;
+    } else {
+      delta = delta * P.delta_inc;
+    }
+    rc = okkt_kkt_factor(k, delta, nullptr);
+    if (rc < 0) return rc;
+    ++num_fac;
+    *num_fac_out = num_fac;
+    *delta_out = delta;
+    if (rc == 1) return 1;
+    if (delta > P.delta_max) return 0;   // :failure
+  }
+  return kk_fail(k, OKKT_ERR_INTERNAL, "max it");   // error("max it"), delta_strategy.jl:113
+}
+
+int okkt_kkt_system_rhs(okkt_kkt_handle k, const double* J_nzval_cur, const double* grad, const double* cons,
+                        const double* s, const double* y, double mu, double a_norm_penalty,
+                        double eta_P, double eta_D, double eta_mu, double* dual_r, double* primal_r, double* comp_r) {
+  if (!k || !grad || !cons || !s || !y || !dual_r || !primal_r || !comp_r) return OKKT_ERR_INVALID;
+  if (!k->structured) return kk_fail(k, OKKT_ERR_INVALID, "structure not set");
+  hipStream_t st = kk_stream(k);
+  const int64_t n = k->n, m = k->m;
+  // J of the CURRENT iterate (may differ from the factorised one in correction steps, one_phase.jl:262-279)
+  const double* Jx = k->Jx;
+  double* Jcur = nullptr;
+  if (J_nzval_cur && k->nnzJ) {
+    KK_TRY(k, hipMalloc((void**)&Jcur, (size_t)k->nnzJ * 8));
+    KK_TRY(k, hipMemcpyAsync(Jcur, J_nzval_cur, (size_t)k->nnzJ * 8, hipMemcpyHostToDevice, st));
+    Jx = Jcur;
+  }
+  if (n) KK_TRY(k, hipMemcpyAsync(k->vn1, grad, (size_t)n * 8, hipMemcpyHostToDevice, st));
+  if (m) {
+    KK_TRY(k, hipMemcpyAsync(k->vm1, cons, (size_t)m * 8, hipMemcpyHostToDevice, st));
+    KK_TRY(k, hipMemcpyAsync(k->big1, s, (size_t)m * 8, hipMemcpyHostToDevice, st));
+    KK_TRY(k, hipMemcpyAsync(k->big2, y, (size_t)m * 8, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_fill, grid1(m), dim3(256), 0, st, m, 1.0, k->vm2);
+  }
+  if (n) {
+    spmv_JT(k, Jx, k->big2, k->vn2);   // J' y
+    spmv_JT(k, Jx, k->vm2, k->vn3);    // J' 1
+    hipLaunchKernelGGL(k_rhs_dual, grid1(n), dim3(256), 0, st, n, k->vn1, k->vn2, k->vn3, (mu * eta_mu) * a_norm_penalty, 1.0 - eta_D, k->rD);
+    KK_TRY(k, hipMemcpyAsync(dual_r, k->rD, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+  }
+  if (m) {
+    hipLaunchKernelGGL(k_rhs_pc, grid1(m), dim3(256), 0, st, m, k->vm1, k->big1, k->big2, 1.0 - eta_P, mu * eta_mu, k->rP, k->rC);
+    KK_TRY(k, hipMemcpyAsync(primal_r, k->rP, (size_t)m * 8, hipMemcpyDeviceToHost, st));
+    KK_TRY(k, hipMemcpyAsync(comp_r, k->rC, (size_t)m * 8, hipMemcpyDeviceToHost, st));
+  }
+  KK_TRY(k, hipStreamSynchronize(st));
+  if (Jcur) (void)hipFree(Jcur);
+  return OKKT_OK;
+}
+
+int okkt_kkt_compute_direction(okkt_kkt_handle k, const double* dual_r, const double* primal_r, const double* comp_r,
+                               int32_t ItRefine_Num, double* dx, double* dy, double* ds, okkt_kkt_error* err_out) {
+  if (!k || !dual_r || !primal_r || !comp_r || !dx || !dy || !ds) return OKKT_ERR_INVALID;
+  if (!k->factored) return kk_fail(k, OKKT_ERR_INVALID, "kkt solver not ready to compute direction!");  // kkt_system_solver.jl:181-183
+  hipStream_t st = kk_stream(k);
+  const int64_t n = k->n, m = k->m;
+  int rc;
+  if (n) KK_TRY(k, hipMemcpyAsync(k->rD, dual_r, (size_t)n * 8, hipMemcpyHostToDevice, st));
+  if (m) {
+    KK_TRY(k, hipMemcpyAsync(k->rP, primal_r, (size_t)m * 8, hipMemcpyHostToDevice, st));
+    KK_TRY(k, hipMemcpyAsync(k->rC, comp_r, (size_t)m * 8, hipMemcpyHostToDevice, st));
+  }
+  if (k->kind == OKKT_KKT_SCHUR) {
+    // schur.jl:89-128 + solver_schur_rhs :131-182
+    if (m) hipLaunchKernelGGL(k_schur_t1, grid1(m), dim3(256), 0, st, m, k->rP, k->rC, k->sig, k->s, k->vm1);
+    if (n) {
+      spmv_JT(k, k->Jx, k->vm1, k->vn1);
+      hipLaunchKernelGGL(k_add, grid1(n), dim3(256), 0, st, n, k->rD, k->vn1, k->vn2);   // vn2 = schur_rhs
+      KK_TRY(k, hipMemsetAsync(k->dx, 0, (size_t)n * 8, st));
+      KK_TRY(k, hipMemcpyAsync(k->big1, k->vn2, (size_t)n * 8, hipMemcpyDeviceToDevice, st));   // res_old
+    }
+    for (int it = 0; it < ItRefine_Num; ++it) {
+      rc = solver_solve_device(k->ls, k->big1, k->big2, 1);
+      if (rc != OKKT_OK) return kk_check_ls(k, rc, "ls_solve");
+      if (n) hipLaunchKernelGGL(k_add, grid1(n), dim3(256), 0, st, n, k->dx, k->big2, k->dx);
+      if (m) { spmv_J(k, k->dx, k->vm1); hipLaunchKernelGGL(k_mul, grid1(m), dim3(256), 0, st, m, k->sig, k->vm1, k->vm2); }
+      if (n) {
+        spmv_JT(k, k->Jx, k->vm2, k->vn1);    // jac_res
+        spmv_H(k, k->dx, k->vn3);             // hess_product
+        hipLaunchKernelGGL(k_refine_res, grid1(n), dim3(256), 0, st, n, k->vn2, k->vn1, k->vn3, k->dx, k->delta, k->big1);
+      }
+    }
+    if (m) { spmv_J(k, k->dx, k->vm1); hipLaunchKernelGGL(k_schur_dyds, grid1(m), dim3(256), 0, st, m, k->vm1, k->rP, k->rC, k->y, k->sig, k->dy, k->ds); }
+  } else {
+    // symmetric.jl:59-83
+    if (n + m) hipLaunchKernelGGL(k_sym_rhs, grid1(n + m), dim3(256), 0, st, n, m, k->rD, k->rP, k->rC, k->y, k->big1);
+    rc = solver_solve_device(k->ls, k->big1, k->big2, 1);
+    if (rc != OKKT_OK) return kk_check_ls(k, rc, "ls_solve");
+    if (n + m) hipLaunchKernelGGL(k_sym_split, grid1(n + m), dim3(256), 0, st, n, m, k->big2, k->dx, k->dy);
+    if (m) { spmv_J(k, k->dx, k->vm1); hipLaunchKernelGGL(k_sub, grid1(m), dim3(256), 0, st, m, k->vm1, k->rP, k->ds); }
+  }
+  // update_kkt_error! (p = Inf), kkt_system_solver.jl:67-96
+  okkt_kkt_error E;
+  std::memset(&E, 0, sizeof(E));
+  double eD = 0, eP = 0, eMu = 0, nD = 0, nP = 0, nC = 0;
+  if (n) {
+    spmv_H(k, k->dx, k->vn1);
+    spmv_JT(k, k->Jx, k->dy, k->vn3);
+    hipLaunchKernelGGL(k_errD, grid1(n), dim3(256), 0, st, n, k->delta, k->dx, k->vn1, k->vn3, k->rD, k->big1);
+    if ((rc = kk_reduce(k, n, k->big1, 1, &eD))) return rc;
+    if ((rc = kk_reduce(k, n, k->rD, 1, &nD))) return rc;
+  }
+  if (m) {
+    spmv_J(k, k->dx, k->vm1);
+    hipLaunchKernelGGL(k_errP, grid1(m), dim3(256), 0, st, m, k->vm1, k->ds, k->rP, k->vm2);
+    if ((rc = kk_reduce(k, m, k->vm2, 1, &eP))) return rc;
+    hipLaunchKernelGGL(k_errMu, grid1(m), dim3(256), 0, st, m, k->s, k->dy, k->y, k->ds, k->rC, k->vm2);
+    if ((rc = kk_reduce(k, m, k->vm2, 1, &eMu))) return rc;
+    if ((rc = kk_reduce(k, m, k->rP, 1, &nP))) return rc;
+    if ((rc = kk_reduce(k, m, k->rC, 1, &nC))) return rc;
+  }
+  auto mx = [](double a, double b) { return (a != a || b != b) ? NAN : std::max(a, b); };
+  E.error_D = eD; E.error_P = eP; E.error_mu = eMu;
+  E.overall = mx(mx(eD, eP), eMu);
+  E.rhs_norm = mx(mx(nD, nP), nC);
+  E.ratio = E.overall / E.rhs_norm;
+  if (err_out) *err_out = E;
+  if (n) KK_TRY(k, hipMemcpyAsync(dx, k->dx, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+  if (m) {
+    KK_TRY(k, hipMemcpyAsync(dy, k->dy, (size_t)m * 8, hipMemcpyDeviceToHost, st));
+    KK_TRY(k, hipMemcpyAsync(ds, k->ds, (size_t)m * 8, hipMemcpyDeviceToHost, st));
+  }
+  KK_TRY(k, hipStreamSynchronize(st));
+  KK_TRY(k, hipGetLastError());
+  return OKKT_OK;
+}
+
+int okkt_kkt_get_matrix(okkt_kkt_handle k, int64_t* dim_out, int64_t* nnz_out, int64_t* colptr_out, int64_t* rowval_out, double* nzval_out) {
+  if (!k) return OKKT_ERR_INVALID;
+  if (!k->structured) return kk_fail(k, OKKT_ERR_INVALID, "structure not set");
+  if (dim_out) *dim_out = k->dimA;
+  if (nnz_out) *nnz_out = k->nnzA;
+  if (colptr_out) std::copy(k->Ap.begin(), k->Ap.end(), colptr_out);
+  if (rowval_out) std::copy(k->Ai.begin(), k->Ai.end(), rowval_out);
+  if (nzval_out) {
+    if (!k->formed) return kk_fail(k, OKKT_ERR_INVALID, "form_system has not been called");
+    KK_TRY(k, hipStreamSynchronize(kk_stream(k)));
+    if (k->nnzA) KK_TRY(k, hipMemcpy(nzval_out, k->Avals, (size_t)k->nnzA * 8, hipMemcpyDeviceToHost));
+  }
+  return OKKT_OK;
+}
+
+int okkt_kkt_get_schur_diag(okkt_kkt_handle k, double* out) {
+  if (!k || !out) return OKKT_ERR_INVALID;
+  if (!k->formed) return kk_fail(k, OKKT_ERR_INVALID, "form_system has not been called");
+  KK_TRY(k, hipStreamSynchronize(kk_stream(k)));
+  if (k->n) KK_TRY(k, hipMemcpy(out, k->schur_diag, (size_t)k->n * 8, hipMemcpyDeviceToHost));
+  return OKKT_OK;
+}
+
+}  // extern "C"

@@ -35,4 +35,5 @@ int solver_factor_device(okkt_solver_s* h, const double* d_vals, int64_t n, int6
                          okkt_inertia* out);
 int solver_solve_device(okkt_solver_s* h, const double* d_rhs, double* d_sol, int64_t nrhs);
 int solver_set_error(okkt_solver_s* h, int code, const std::string& msg);
+int solver_ensure_numeric(okkt_solver_s* h);
 }  // namespace okkt

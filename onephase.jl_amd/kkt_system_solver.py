@@ -1,0 +1,305 @@
+"""Host-side mirror of the reference's KKT-system-solver interface, bound to the HIP library.
+
+Mirrors /root/reference/src/kkt_system_solver/kkt_system_solver.jl (abstract_KKT_system_solver:
+initialize!, form_system!, factor!, kkt_associate_rhs!, compute_direction!, update_kkt_error!,
+pick_KKT_solver), schur.jl / symmetric.jl (the two solver kinds), system_rhs.jl and
+src/IPM/delta_strategy.jl (ipopt_strategy!).  `f!` becomes `f_b`.  Everything numeric happens in
+libonephase_kkt.so through the level-2 entry points of include/okkt.h; this file only keeps the
+reference's state machine (`ready`), field names (`dir`, `rhs`, `kkt_err_norm`, `schur_diag`,
+`delta_x_vec`, ...) and error behaviour.
+"""
+import ctypes as C
+import math
+from dataclasses import dataclass
+
+import numpy as np
+import scipy.sparse as sp
+
+from . import _lib as L
+from .linear_system_solvers import OkktError
+
+
+@dataclass
+class Class_iterate:
+    """Subset of Class_iterate + Class_cache the path reads (Class_iterate.jl:4-20,40-84)."""
+    x: np.ndarray
+    y: np.ndarray
+    s: np.ndarray
+    mu: float
+    J: sp.csc_matrix           # m x n
+    H: sp.csc_matrix           # n x n, lower triangle only (Class_cutest.jl:548)
+    grad: np.ndarray
+    cons: np.ndarray
+    a_norm_penalty_par: float = 1e-4
+    delta: float = 0.0
+    primal_scale: float = 1.0
+
+    def dim(self):
+        return len(self.x)
+
+    def ncon(self):
+        return len(self.s)
+
+
+@dataclass
+class Class_reduction_factors:  # system_rhs.jl:3-13
+    P: float = math.nan
+    D: float = math.nan
+    mu: float = math.nan
+
+
+def Reduct_affine():   # system_rhs.jl:16-19
+    return Class_reduction_factors(0.0, 0.0, 0.0)
+
+
+def Reduct_stable():   # system_rhs.jl:21-24
+    return Class_reduction_factors(1.0, 0.0, 1.0)
+
+
+@dataclass
+class System_rhs:      # system_rhs.jl:34-73
+    dual_r: np.ndarray
+    primal_r: np.ndarray
+    comp_r: np.ndarray
+
+
+@dataclass
+class Class_kkt_error:  # kkt_system_solver.jl:49-65
+    error_D: float = 0.0
+    error_P: float = 0.0
+    error_mu: float = 0.0
+    overall: float = 0.0
+    rhs_norm: float = 0.0
+    ratio: float = 0.0
+
+
+@dataclass
+class Class_point:      # Class_point.jl:1-12 (as a direction)
+    x: np.ndarray
+    y: np.ndarray
+    s: np.ndarray
+    mu: float = 0.0
+    primal_scale: float = 0.0
+
+
+@dataclass
+class Class_kkt_solver_options:   # parameters.jl:4-46 (the entries the path reads)
+    kkt_solver_type: str = "schur"
+    linear_solver_type: str = "HIP"
+    ItRefine_Num: int = 3
+
+
+@dataclass
+class Class_delta_parameters:     # parameters.jl:138-159
+    max: float = 1e50
+    start: float = 1e-6
+    zero: float = 0.0
+    min: float = 1e-12
+    inc: float = 8.0
+    dec: float = 1.0 / math.pi
+
+
+@dataclass
+class Class_parameters:
+    kkt: Class_kkt_solver_options = None
+    delta: Class_delta_parameters = None
+    output_level: int = 0
+
+    def __post_init__(self):
+        self.kkt = self.kkt or Class_kkt_solver_options()
+        self.delta = self.delta or Class_delta_parameters()
+
+
+def _csc(A):
+    A = sp.csc_matrix(A)
+    A.sort_indices()
+    return A
+
+
+class HIP_KKT_solver:
+    """abstract_KKT_system_solver backed by the device-resident KKT path (kind = 'schur' | 'symmetric')."""
+
+    def __init__(self, kind, pars=None, **opts):
+        if kind not in ("schur", "symmetric"):
+            raise OkktError("pick a solver!")          # kkt_system_solver.jl:280
+        self.kind = kind
+        self.pars = pars or Class_parameters()
+        self._opts = opts
+        self._lib = None
+        self._k = None
+        self.ready = "not_ready"
+        self.kkt_err_norm = Class_kkt_error()
+        self.factor_it = None
+        self.dir = None
+        self.rhs = None
+        self.schur_diag = None
+        self.delta_x_vec = None
+        self.delta_s_vec = None
+        self.inertia = None
+        self._pattern = None
+
+    # ---- initialize! (kkt_system_solver.jl:21-25)
+    def initialize_b(self, intial_it):
+        if self._k is None:
+            self._lib = L.load()
+            o = L.OkktOpts()
+            self._lib.okkt_default_opts(C.byref(o))
+            for key, v in self._opts.items():
+                setattr(o, key, v)
+            k = C.c_void_p()
+            rc = self._lib.okkt_kkt_create(C.byref(k), C.byref(o), L.OKKT_KKT_SCHUR if self.kind == "schur" else L.OKKT_KKT_SYMMETRIC)
+            if rc != L.OKKT_OK:
+                raise OkktError(f"okkt_kkt_create failed with code {rc}"
+                                + (" (no HIP device: the KKT path has no CPU fallback)" if rc == L.OKKT_ERR_NO_DEVICE else ""))
+            self._k = k
+        self.dir = Class_point(np.zeros(intial_it.dim()), np.zeros(intial_it.ncon()), np.zeros(intial_it.ncon()))
+
+    def finalize_b(self):
+        if self._k is not None:
+            self._lib.okkt_kkt_destroy(self._k)
+            self._k = None
+
+    def __del__(self):
+        try:
+            self.finalize_b()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc < 0:
+            msg = self._lib.okkt_kkt_last_error(self._k)
+            raise OkktError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+        return rc
+
+    # ---- form_system! (schur.jl:47-62, symmetric.jl:35-53)
+    def form_system_b(self, it, timer=None):
+        if self._k is None:
+            raise OkktError("initialize_b has not been called")
+        H, J = _csc(it.H), _csc(it.J)
+        n, m = it.dim(), it.ncon()
+        key = (n, m, H.indptr.tobytes(), H.indices.tobytes(), J.indptr.tobytes(), J.indices.tobytes())
+        if self._pattern is None:
+            Hp, Hi, Jp, Ji = L.i64(H.indptr), L.i64(H.indices), L.i64(J.indptr), L.i64(J.indices)
+            self._check(self._lib.okkt_kkt_set_structure(self._k, n, m, L.p_i64(Hp), L.p_i64(Hi), L.p_i64(Jp), L.p_i64(Ji), 0),
+                        "okkt_kkt_set_structure")
+            self._pattern = key
+        elif key != self._pattern:
+            raise OkktError("the sparsity pattern of H / J changed: create a new HIP_KKT_solver")
+        Hx, Jx, s, y = L.f64(H.data), L.f64(J.data), L.f64(it.s), L.f64(it.y)
+        self._check(self._lib.okkt_kkt_form_system(self._k, L.p_f64(Hx), L.p_f64(Jx), L.p_f64(s), L.p_f64(y)), "okkt_kkt_form_system")
+        sd = np.zeros(n)
+        self._check(self._lib.okkt_kkt_get_schur_diag(self._k, L.p_f64(sd)), "okkt_kkt_get_schur_diag")
+        self.schur_diag = sd
+        self.factor_it = it
+        self.ready = "system_formed"
+
+    def diag_min(self):   # kkt_system_solver.jl:291-294
+        out = C.c_double()
+        self._check(self._lib.okkt_kkt_diag_min(self._k, C.byref(out)), "okkt_kkt_diag_min")
+        return out.value
+
+    # ---- update_delta! / factor! (kkt_system_solver.jl:98-113,190-204)
+    def update_delta_b(self, delta_x, delta_s=0.0, timer=None):
+        self.delta_x_vec = delta_x * np.ones(self.factor_it.dim())
+        self.delta_s_vec = delta_s * self.factor_it.s ** (-2.0)
+        if np.sum(np.abs(self.delta_s_vec)) > 0.0:
+            raise OkktError("Not implemented")          # schur.jl:71, symmetric.jl:92
+        if self.ready == "not_ready":
+            raise OkktError("form_system! has not been called")
+        self._delta = float(delta_x)
+        self.ready = "delta_updated"
+
+    def factor_b(self, delta_x=None, delta_s=0.0, timer=None):
+        if delta_x is not None:
+            self.update_delta_b(delta_x, delta_s)
+        if self.ready != "delta_updated":
+            raise OkktError(f"kkt solver not ready to factor kkt_solver.ready = {self.ready} != :delta_updated")
+        self.ready = "factored"
+        inert = L.OkktInertia()
+        rc = self._check(self._lib.okkt_kkt_factor(self._k, self._delta, C.byref(inert)), "okkt_kkt_factor")
+        self.inertia = inert.as_tuple()
+        return int(rc)
+
+    # ---- kkt_associate_rhs! (kkt_system_solver.jl:167-176, schur.jl:34-45)
+    def kkt_associate_rhs_b(self, it, eta, timer=None):
+        n, m = it.dim(), it.ncon()
+        Jx = L.f64(_csc(it.J).data)
+        grad, cons, s, y = L.f64(it.grad), L.f64(it.cons), L.f64(it.s), L.f64(it.y)
+        rD, rP, rC = np.zeros(n), np.zeros(m), np.zeros(m)
+        self._check(self._lib.okkt_kkt_system_rhs(self._k, L.p_f64(Jx), L.p_f64(grad), L.p_f64(cons), L.p_f64(s), L.p_f64(y),
+                                                  it.mu, it.a_norm_penalty_par, eta.P, eta.D, eta.mu,
+                                                  L.p_f64(rD), L.p_f64(rP), L.p_f64(rC)), "okkt_kkt_system_rhs")
+        self.rhs = System_rhs(rD, rP, rC)
+        self.dir.mu = -(1.0 - eta.mu) * it.mu
+        self.dir.primal_scale = -(1.0 - eta.P) * it.primal_scale
+        self.reduct_factors = eta
+        self.current_it = it
+
+    # ---- compute_direction! (kkt_system_solver.jl:178-188)
+    def compute_direction_b(self, timer=None):
+        if self.ready != "factored":
+            raise OkktError("kkt solver not ready to compute direction!")
+        n, m = self.factor_it.dim(), self.factor_it.ncon()
+        dx, dy, ds = np.zeros(n), np.zeros(m), np.zeros(m)
+        err = L.OkktKktError()
+        rD, rP, rC = L.f64(self.rhs.dual_r), L.f64(self.rhs.primal_r), L.f64(self.rhs.comp_r)
+        self._check(self._lib.okkt_kkt_compute_direction(self._k, L.p_f64(rD), L.p_f64(rP), L.p_f64(rC), self.pars.kkt.ItRefine_Num,
+                                                         L.p_f64(dx), L.p_f64(dy), L.p_f64(ds), C.byref(err)),
+                    "okkt_kkt_compute_direction")
+        self.dir.x, self.dir.y, self.dir.s = dx, dy, ds
+        self.kkt_err_norm = Class_kkt_error(err.error_D, err.error_P, err.error_mu, err.overall, err.rhs_norm, err.ratio)
+        for name, v in (("x", dx), ("y", dy), ("s", ds)):       # check_for_nan, IPM_tools.jl:32-49
+            if not np.all(np.isfinite(v)):
+                raise OkktError(f"NaN in {name}")
+
+    # ---- ipopt_strategy! (delta_strategy.jl:37-114): the whole loop runs behind the C ABI
+    def ipopt_strategy_b(self, it, timer=None):
+        p = L.OkktKktPars()
+        self._lib.okkt_kkt_default_pars(C.byref(p))
+        d = self.pars.delta
+        p.delta_start, p.delta_min, p.delta_max, p.delta_inc, p.delta_dec, p.delta_zero = d.start, d.min, d.max, d.inc, d.dec, d.zero
+        nfac = C.c_int32()
+        delta = C.c_double()
+        rc = self._check(self._lib.okkt_kkt_ipopt_strategy(self._k, float(it.delta), C.byref(p), C.byref(nfac), C.byref(delta)),
+                         "okkt_kkt_ipopt_strategy")
+        self._delta = delta.value
+        self.delta_x_vec = delta.value * np.ones(it.dim())
+        self.delta_s_vec = np.zeros(it.ncon())
+        self.ready = "factored"
+        return ("success" if rc == 1 else "failure"), int(nfac.value), float(delta.value)
+
+    # ---- diagnostics
+    def matrix(self):
+        dim, nnz = C.c_int64(), C.c_int64()
+        self._check(self._lib.okkt_kkt_get_matrix(self._k, C.byref(dim), C.byref(nnz), None, None, None), "okkt_kkt_get_matrix")
+        colptr = np.zeros(dim.value + 1, dtype=np.int64)
+        rowval = np.zeros(max(nnz.value, 1), dtype=np.int64)
+        val = np.zeros(max(nnz.value, 1))
+        self._check(self._lib.okkt_kkt_get_matrix(self._k, C.byref(dim), C.byref(nnz), L.p_i64(colptr), L.p_i64(rowval), L.p_f64(val)),
+                    "okkt_kkt_get_matrix")
+        return sp.csc_matrix((val[: nnz.value], rowval[: nnz.value], colptr), shape=(dim.value, dim.value))
+
+    def linear_solver_stats(self):
+        st = L.OkktStats()
+        h = self._lib.okkt_kkt_linear_solver(self._k)
+        rc = self._lib.okkt_get_stats(C.c_void_p(h), C.byref(st))
+        if rc != 0:
+            raise OkktError("okkt_get_stats failed")
+        return st.as_dict()
+
+    def linear_solver_perm(self):
+        h = C.c_void_p(self._lib.okkt_kkt_linear_solver(self._k))
+        n = self.linear_solver_stats()["n"]
+        out = np.zeros(n, dtype=np.int64)
+        if self._lib.okkt_get_perm(h, L.p_i64(out)) != 0:
+            raise OkktError("okkt_get_perm failed")
+        return out
+
+
+def pick_KKT_solver(pars):
+    """kkt_system_solver.jl:232-287 with the `linear_solver_type == :HIP` branch."""
+    if pars.kkt.linear_solver_type != "HIP":
+        raise OkktError("pick a valid solver!")
+    if pars.kkt.kkt_solver_type in ("schur", "symmetric"):
+        return HIP_KKT_solver(pars.kkt.kkt_solver_type, pars)
+    raise OkktError("pick a solver!")

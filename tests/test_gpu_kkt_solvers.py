@@ -1,0 +1,184 @@
+"""GPU parity tests, KKT-system level.  Reads like the reference's test/kkt_system_solvers.jl:
+test_kkt_solver = initialize! -> form_system! -> factor!(kkt, 1e-8) -> kkt_associate_rhs!(Reduct_affine)
+-> compute_direction! -> dir, compared between solver kinds, with the oracle and with the golden answers."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from conftest import iterate_from_record
+from onephase_jl_amd import synth
+from onephase_jl_amd import kkt_system_solver as KS
+from onephase_jl_amd.linear_system_solvers import OkktError
+from oracle import kkt_oracle as KO
+
+pytestmark = pytest.mark.gpu
+
+
+def test_kkt_solver(rec_or_it, kind, delta=None, Iterate=KS.Class_iterate, **opts):
+    pars = KS.Class_parameters()
+    pars.kkt.kkt_solver_type = kind
+    it = iterate_from_record(rec_or_it, Iterate) if isinstance(rec_or_it, dict) else rec_or_it
+    kkt_solver = KS.pick_KKT_solver(pars) if not opts else KS.HIP_KKT_solver(kind, pars, **opts)
+    kkt_solver.initialize_b(it)
+    kkt_solver.form_system_b(it)
+    inertia = kkt_solver.factor_b(1e-8 if delta is None else delta)
+    kkt_solver.kkt_associate_rhs_b(it, KS.Reduct_affine())
+    kkt_solver.compute_direction_b()
+    return inertia, kkt_solver
+test_kkt_solver.__test__ = False
+
+
+def oracle_solver(rec_or_it, kind, delta, perm=None):
+    it = iterate_from_record(rec_or_it, KO.Iterate) if isinstance(rec_or_it, dict) else rec_or_it
+    k = KO.pick_KKT_solver(kind, perm=perm)
+    k.initialize_b(it)
+    k.form_system_b(it)
+    inertia = k.factor_b(delta)
+    k.kkt_associate_rhs_b(it, KO.Reduct_affine())
+    k.compute_direction_b()
+    return inertia, k
+
+
+def test_kkt_solvers_toy_lps(golden):
+    # test/kkt_system_solvers.jl:91-181: schur vs symmetric directions agree to 1e-6
+    for rec in golden["toy_lps"]:
+        i_s, ks = test_kkt_solver(rec, "schur")
+        i_y, ky = test_kkt_solver(rec, "symmetric")
+        assert i_s == 1 and i_y == 1, rec["name"]
+        for a in ("x", "y", "s"):
+            assert np.linalg.norm(getattr(ks.dir, a) - getattr(ky.dir, a)) < 1e-6, (rec["name"], a)
+            assert np.linalg.norm(getattr(ks.dir, a) - np.array(rec["d" + a])) < 1e-6, (rec["name"], a)
+            assert np.linalg.norm(getattr(ky.dir, a) - np.array(rec["d" + a])) < 1e-6, (rec["name"], a)
+        assert ks.kkt_err_norm.ratio < 1e-8
+        assert np.allclose(ks.rhs.dual_r, rec["rD"], atol=1e-14) and np.allclose(ks.rhs.primal_r, rec["rP"], atol=1e-14)
+        assert np.allclose(ks.rhs.comp_r, rec["rC"], atol=1e-14)
+
+
+def test_readme_toy(golden):
+    rec = golden["readme_toy"]
+    for kind in ("schur", "symmetric"):
+        inertia, k = test_kkt_solver(rec, kind, delta=rec["delta"])
+        assert inertia == 1
+        assert np.allclose(k.dir.x, rec["dx"], rtol=1e-12)
+        assert np.allclose(k.dir.y, rec["dy"], rtol=1e-11)
+        assert np.allclose(k.dir.s, rec["ds"], rtol=1e-12)
+        i0, _ = None, None
+        it = iterate_from_record(rec, KS.Class_iterate)
+        k2 = KS.HIP_KKT_solver(kind)
+        k2.initialize_b(it)
+        k2.form_system_b(it)
+        assert k2.factor_b(0.0) == 0              # K(0) has inertia (0, 3, 0)
+        status, num_fac, delta = k2.ipopt_strategy_b(it)
+        exp = rec["delta_loop_" + kind]
+        assert (status, num_fac, delta) == (exp["status"], exp["num_fac"], exp["delta"])
+
+
+@pytest.mark.parametrize("prob", ["indef5", "posdiag_indef5"])
+def test_delta_loop_traces(golden, prob):
+    rec = golden[prob]
+    for key, exp in rec["delta_loops"].items():
+        kind, prev = key.split("_prev")
+        it = iterate_from_record(rec, KS.Class_iterate)
+        it.delta = float(prev)
+        k = KS.HIP_KKT_solver(kind)
+        k.initialize_b(it)
+        k.form_system_b(it)
+        status, num_fac, delta = k.ipopt_strategy_b(it)
+        assert status == exp["status"] and num_fac == exp["num_fac"]     # '#fac' column
+        assert delta == exp["delta"]                                     # same scalar arithmetic, bit for bit
+        k.kkt_associate_rhs_b(it, KS.Reduct_affine())
+        k.compute_direction_b()
+        if abs(delta - rec["delta"]) < 1e-12:
+            assert np.allclose(k.dir.x, rec["dx"], rtol=1e-8, atol=1e-10)
+
+
+def test_state_machine_errors(golden):
+    rec = golden["toy_lps"][1]
+    it = iterate_from_record(rec, KS.Class_iterate)
+    k = KS.HIP_KKT_solver("schur")
+    k.initialize_b(it)
+    k.form_system_b(it)
+    with pytest.raises(OkktError):
+        k.factor_b()                 # not :delta_updated
+    with pytest.raises(OkktError):
+        k.compute_direction_b()      # not :factored
+    with pytest.raises(OkktError):
+        k.factor_b(1e-8, 1.0)        # delta_s != 0: "Not implemented"
+    with pytest.raises(OkktError):
+        KS.HIP_KKT_solver("clever")
+
+
+def synth_iterate(prob, Iterate, seed=0):
+    rng = np.random.default_rng(seed)
+    n, m = prob["n"], prob["m"]
+    return Iterate(x=rng.normal(size=n), y=prob["y"].copy(), s=prob["s"].copy(), mu=prob["mu"], J=prob["J"], H=prob["H"],
+                   grad=rng.normal(size=n), cons=prob["s"] + 0.1 * rng.normal(size=m), a_norm_penalty_par=1e-4)
+
+
+@pytest.mark.parametrize("name,seed", [("S-tiny", 0), ("S-small", 0), ("S-small", 3)])
+@pytest.mark.parametrize("kind", ["schur", "symmetric"])
+def test_synthetic_directions_vs_oracle(name, seed, kind):
+    prob = synth.make_config(name, seed=seed, well_scaled=True)
+    inertia, k = test_kkt_solver(synth_iterate(prob, KS.Class_iterate, seed), kind, delta=1e-6)
+    io, ko = oracle_solver(synth_iterate(prob, KO.Iterate, seed), kind, 1e-6, perm=k.linear_solver_perm())
+    assert inertia == io == 1
+    # assembled matrix: lower triangle equals the reference-shaped scipy assembly
+    A = k.matrix()
+    Aref = sp.tril(sp.csc_matrix(ko.Q)).tolil()          # the oracle's copy carries delta on the x-diagonal
+    nn = prob["n"]
+    dg = Aref.diagonal()
+    dg[:nn] -= 1e-6
+    Aref.setdiag(dg)
+    Aref = Aref.tocsc()
+    assert abs(A - Aref).max() <= 1e-12 * max(1.0, abs(Aref).max())
+    assert np.allclose(k.schur_diag, ko.schur_diag, rtol=1e-13)
+    assert np.allclose(k.rhs.dual_r, ko.rhs.dual_r, rtol=1e-12, atol=1e-13)
+    for a in ("x", "y", "s"):
+        da, db = getattr(k.dir, a), getattr(ko.dir, a)
+        assert np.max(np.abs(da - db)) <= 1e-9 * max(1.0, np.max(np.abs(db))), (a, np.max(np.abs(da - db)))
+    assert k.kkt_err_norm.ratio < 1e-8 and ko.kkt_err_norm.ratio < 1e-8
+    assert abs(k.kkt_err_norm.rhs_norm - ko.kkt_err_norm.rhs_norm) <= 1e-12 * ko.kkt_err_norm.rhs_norm
+    k.finalize_b()
+
+
+def test_nonconvex_delta_loop_matches_oracle():
+    prob = synth.make_config("S-small", seed=5, convex=False, well_scaled=True)
+    for kind in ("schur", "symmetric"):
+        it = synth_iterate(prob, KS.Class_iterate)
+        k = KS.HIP_KKT_solver(kind)
+        k.initialize_b(it)
+        k.form_system_b(it)
+        status, num_fac, delta = k.ipopt_strategy_b(it)
+        ito = synth_iterate(prob, KO.Iterate)
+        ko = KO.pick_KKT_solver(kind, perm=k.linear_solver_perm())
+        ko.initialize_b(ito)
+        ko.form_system_b(ito)
+        so, nfo, do, tried = KO.ipopt_strategy_b(ito, ko)
+        assert (status, num_fac) == (so, nfo) and num_fac >= 1
+        assert abs(delta - do) <= 1e-12 * abs(do)
+        assert k.linear_solver_stats()["n_analyze_calls"] == 1       # refactor never re-analyses
+        k.finalize_b()
+
+
+def test_second_form_system_same_pattern_new_values():
+    prob = synth.make_config("S-small", seed=7, well_scaled=True)
+    it = synth_iterate(prob, KS.Class_iterate)
+    k = KS.HIP_KKT_solver("symmetric")
+    k.initialize_b(it)
+    k.form_system_b(it)
+    assert k.factor_b(1e-6) == 1
+    it2 = synth_iterate(prob, KS.Class_iterate, seed=9)
+    it2.s = it2.s * 1.7
+    it2.H = it2.H * 0.5
+    k.form_system_b(it2)
+    assert k.factor_b(1e-6) == 1
+    k.kkt_associate_rhs_b(it2, KS.Reduct_stable())
+    k.compute_direction_b()
+    ito = synth_iterate(prob, KO.Iterate, seed=9)
+    ito.s = ito.s * 1.7
+    ito.H = ito.H * 0.5
+    ko = KO.pick_KKT_solver("symmetric", perm=k.linear_solver_perm())
+    ko.initialize_b(ito); ko.form_system_b(ito); ko.factor_b(1e-6)
+    ko.kkt_associate_rhs_b(ito, KO.Reduct_stable()); ko.compute_direction_b()
+    assert np.max(np.abs(k.dir.x - ko.dir.x)) <= 1e-9 * np.max(np.abs(ko.dir.x))
+    assert k.linear_solver_stats()["n_analyze_calls"] == 1
