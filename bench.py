@@ -109,7 +109,7 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "r01_syrk_pmc.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch_raw")
             except Exception:
                 traffic = None
         out = {
