@@ -738,8 +738,10 @@ __global__ __launch_bounds__(256) void k_bigsolve_fwd_asm(DevPlan P, const int* 
 // forward step J: y_J = inv(L_JJ) w_J (every workgroup, redundantly), z_J = y_J / d_J,
 // w[r] -= L[r, J] y_J for the rows below (64 rows per workgroup, wave g takes a quarter of the
 // block's columns with all its loads in flight at once; partial sums meet in LDS)
-__global__ __launch_bounds__(256) void k_bigsolve_fwd_step(DevPlan P, const int* __restrict__ list, int step, int NB) {
+template <int NB>
+__global__ __launch_bounds__(256) void k_bigsolve_fwd_step(DevPlan P, const int* __restrict__ list, int step) {
   __shared__ double wj[128], yj[128], part[4][64];
+  constexpr int HALF = NB / 2;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int s = list[blockIdx.y];
   const int col0 = P.sn_col0[s];
@@ -751,35 +753,26 @@ __global__ __launch_bounds__(256) void k_bigsolve_fwd_step(DevPlan P, const int*
   if (blockIdx.x > 0 && j0 + nb + (int)blockIdx.x * 64 >= f) return;
   double* w = P.bigw + P.bigcol_base[s];
   const double* XT = P.invlt + P.invl_pos[s] + (size_t)step * NB * NB;
-  if (tid < nb) wj[tid] = w[j0 + tid];
+  if (tid < 128) wj[tid] = tid < nb ? w[j0 + tid] : 0.0;
   __syncthreads();
-  // y[c] = sum_{p <= c} X[c][p] w[p]: one wave per row c (row c of X is contiguous in XT), 8 rows in flight
-  for (int c0 = wv * 8; c0 < nb; c0 += 32) {
-    double acc[8];
+  // y[c] = sum_{p <= c} X[c][p] w[p]: two threads per row c (row c of X is contiguous in XT), each with
+  // its 64 loads in flight at once -- one memory round trip for the whole 128 x 128 triangle
+  {
+    const int c = tid >> 1, h = tid & 1;
+    double a = 0.0;
+    if (c < nb) {
+      const double* xrow = XT + (size_t)c * NB + h * HALF;
+      // the stored block is zero above the diagonal and beyond nb, wj is zero-padded: no predicates
+      double v[HALF];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int c = c0 + q;
-      const double* xrow = XT + (size_t)c * NB;
-      double a = 0.0;
-      if (c < nb) {
-        if (lane <= c) a = xrow[lane] * wj[lane];
-        if (lane + 64 <= c) a += xrow[lane + 64] * wj[lane + 64];
-      }
-      acc[q] = a;
+      for (int q = 0; q < HALF; ++q) v[q] = xrow[q];
+#pragma unroll
+      for (int q = 0; q < HALF; ++q) a += v[q] * wj[h * HALF + q];
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1)
-#pragma unroll
-      for (int q = 0; q < 8; ++q) acc[q] += __shfl_down(acc[q], o, 64);
-    if (lane == 0) {
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int c = c0 + q;
-        if (c < nb) {
-          yj[c] = acc[q];
-          if (blockIdx.x == 0) P.xwork[col0 + j0 + c] = acc[q] / P.dvals[col0 + j0 + c];
-        }
-      }
+    a += __shfl_xor(a, 1, 64);
+    if (c < nb && h == 0) {
+      yj[c] = a;
+      if (blockIdx.x == 0) P.xwork[col0 + j0 + c] = a / P.dvals[col0 + j0 + c];
     }
   }
   __syncthreads();
@@ -824,8 +817,10 @@ __global__ __launch_bounds__(256) void k_bigsolve_bwd_pre(DevPlan P, const int* 
 
 // backward step I (descending): x_I = inv(L_II)^T z_I (every workgroup, redundantly), then
 // z[c] -= sum_{r in I} L[r, c] x_I[r] for the columns c left of the block (wave per column)
-__global__ __launch_bounds__(256) void k_bigsolve_bwd_step(DevPlan P, const int* __restrict__ list, int step, int NB) {
+template <int NB>
+__global__ __launch_bounds__(256) void k_bigsolve_bwd_step(DevPlan P, const int* __restrict__ list, int step) {
   __shared__ double zi[128], xi[128];
+  constexpr int HALF = NB / 2;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int s = list[blockIdx.y];
   const int col0 = P.sn_col0[s];
@@ -836,58 +831,42 @@ __global__ __launch_bounds__(256) void k_bigsolve_bwd_step(DevPlan P, const int*
   const int nb = min(NB, k - j0);
   if (blockIdx.x > 0 && (int)blockIdx.x * 64 >= j0) return;
   const double* X = P.invl + P.invl_pos[s] + (size_t)step * NB * NB;
-  if (tid < nb) zi[tid] = P.xwork[col0 + j0 + tid];
+  if (tid < 128) zi[tid] = tid < nb ? P.xwork[col0 + j0 + tid] : 0.0;
   __syncthreads();
-  // x[c] = sum_{p >= c} X[p][c] z[p]: one wave per c, lanes along p (column c of X is contiguous), 8 in flight
-  for (int c0 = wv * 8; c0 < nb; c0 += 32) {
-    double acc[8];
+  // x[c] = sum_{p >= c} X[p][c] z[p]: two threads per c (column c of X is contiguous), 64 loads in flight each
+  {
+    const int c = tid >> 1, h = tid & 1;
+    double a = 0.0;
+    if (c < nb) {
+      const double* xcol = X + (size_t)c * NB + h * HALF;
+      double v[HALF];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int c = c0 + q;
-      const double* xcol = X + (size_t)c * NB;
-      double a = 0.0;
-      if (c < nb) {
-        if (lane >= c && lane < nb) a = xcol[lane] * zi[lane];
-        if (lane + 64 >= c && lane + 64 < nb) a += xcol[lane + 64] * zi[lane + 64];
-      }
-      acc[q] = a;
+      for (int q = 0; q < HALF; ++q) v[q] = xcol[q];
+#pragma unroll
+      for (int q = 0; q < HALF; ++q) a += v[q] * zi[h * HALF + q];
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1)
-#pragma unroll
-      for (int q = 0; q < 8; ++q) acc[q] += __shfl_down(acc[q], o, 64);
-    if (lane == 0) {
-#pragma unroll
-      for (int q = 0; q < 8; ++q) if (c0 + q < nb) xi[c0 + q] = acc[q];
-    }
+    a += __shfl_xor(a, 1, 64);
+    if (c < nb && h == 0) xi[c] = a;
   }
   __syncthreads();
-  // columns [blockIdx.x*64, +64) left of the block: 16 per wave, 8 at a time for memory parallelism
+  // columns [blockIdx.x*64, +64) left of the block, 16 per wave in two passes of 8: lane = (column
+  // lane>>3, row phase lane&7); every lane has its 16 loads in flight, then three shuffle steps per pass
   const double* Lrow = P.arena + P.front_pos[s] + j0;
-  const double x0 = lane < nb ? xi[lane] : 0.0, x1 = lane + 64 < nb ? xi[lane + 64] : 0.0;
-  for (int q0 = 0; q0 < 16; q0 += 8) {
-    double acc[8];
+  const int rl = lane & 7;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int c = blockIdx.x * 64 + wv * 16 + q0 + q;
-      acc[q] = 0.0;
-      if (c < j0) {
-        const double* col = Lrow + (size_t)c * f;
-        if (lane < nb) acc[q] = col[lane] * x0;
-        if (lane + 64 < nb) acc[q] += col[lane + 64] * x1;
-      }
-    }
+  for (int pass = 0; pass < 2; ++pass) {
+    const int c = blockIdx.x * 64 + wv * 16 + pass * 8 + (lane >> 3);
+    const double* col = Lrow + (size_t)min(c, max(j0 - 1, 0)) * f;
+    double v[NB / 8];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1)
+    for (int it = 0; it < NB / 8; ++it) v[it] = col[min(rl + 8 * it, nb - 1)];
+    double acc = 0.0;
 #pragma unroll
-      for (int q = 0; q < 8; ++q) acc[q] += __shfl_down(acc[q], o, 64);
-    if (lane == 0) {
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int c = blockIdx.x * 64 + wv * 16 + q0 + q;
-        if (c < j0) P.xwork[col0 + c] -= acc[q];
-      }
-    }
+    for (int it = 0; it < NB / 8; ++it) acc += (rl + 8 * it < nb) ? v[it] * xi[rl + 8 * it] : 0.0;
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    acc += __shfl_xor(acc, 4, 64);
+    if (rl == 0 && c < j0) P.xwork[col0 + c] -= acc;
   }
   // the block's own solution is written last, by the first workgroup only: the others read z_I above
   if (blockIdx.x == 0 && tid < nb) P.xwork[col0 + j0 + tid] = xi[tid];
@@ -1173,7 +1152,13 @@ std::string numeric_solve_enqueue(Numeric& N) {
       const int nsteps = (g.maxk + NB - 1) / NB;
       for (int step = 0; step < nsteps; ++step) {
         const int rem = std::max(g.maxf - step * NB, 0);  // upper bound on the rows below block `step`
-        hipLaunchKernelGGL(k_bigsolve_fwd_step, dim3(std::max(1, (rem + 63) / 64), g.cnt), dim3(256), 0, st, P, list, step, NB);
+        const dim3 gr(std::max(1, (rem + 63) / 64), g.cnt);
+        switch (NB) {
+          case 32: hipLaunchKernelGGL(k_bigsolve_fwd_step<32>, gr, dim3(256), 0, st, P, list, step); break;
+          case 64: hipLaunchKernelGGL(k_bigsolve_fwd_step<64>, gr, dim3(256), 0, st, P, list, step); break;
+          case 96: hipLaunchKernelGGL(k_bigsolve_fwd_step<96>, gr, dim3(256), 0, st, P, list, step); break;
+          default: hipLaunchKernelGGL(k_bigsolve_fwd_step<128>, gr, dim3(256), 0, st, P, list, step); break;
+        }
       }
     }
   }
@@ -1184,8 +1169,15 @@ std::string numeric_solve_enqueue(Numeric& N) {
       const int* list = P.sched + gb.off;
       hipLaunchKernelGGL(k_bigsolve_bwd_pre, dim3((gb.maxk + 3) / 4, gb.cnt), dim3(256), 0, st, P, list);
       const int nsteps = (gb.maxk + NB - 1) / NB;
-      for (int step = nsteps - 1; step >= 0; --step)
-        hipLaunchKernelGGL(k_bigsolve_bwd_step, dim3(std::max(1, (step * NB + 63) / 64), gb.cnt), dim3(256), 0, st, P, list, step, NB);
+      for (int step = nsteps - 1; step >= 0; --step) {
+        const dim3 gr(std::max(1, (step * NB + 63) / 64), gb.cnt);
+        switch (NB) {
+          case 32: hipLaunchKernelGGL(k_bigsolve_bwd_step<32>, gr, dim3(256), 0, st, P, list, step); break;
+          case 64: hipLaunchKernelGGL(k_bigsolve_bwd_step<64>, gr, dim3(256), 0, st, P, list, step); break;
+          case 96: hipLaunchKernelGGL(k_bigsolve_bwd_step<96>, gr, dim3(256), 0, st, P, list, step); break;
+          default: hipLaunchKernelGGL(k_bigsolve_bwd_step<128>, gr, dim3(256), 0, st, P, list, step); break;
+        }
+      }
     }
     for (int c = 0; c < 3; ++c) {
       const Segment& g = L.seg[c];
