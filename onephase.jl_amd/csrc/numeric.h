@@ -44,7 +44,6 @@ struct DevPlan {
   int* ea_child = nullptr;
   int* ea_jj = nullptr;
   double* invl = nullptr;          // inverse of the unit-lower diagonal blocks, NB x NB each
-  double* invlt = nullptr;         // the same, transposed (backward solve reads it coalesced)
   int64_t* invl_pos = nullptr;     // [nsuper]
   double* bigw = nullptr;          // [n_bigcols] forward-solve work vectors of the big fronts
   unsigned long long* counters = nullptr;  // pos, neg, zero, nonfinite
@@ -61,6 +60,7 @@ struct Numeric {
   std::vector<LevelSchedule> levels;
   std::vector<void*> allocations;
   int nb = 64;
+  int group = 2;   // block columns per super-step: the trailing update runs with K = group * nb
   int small_max = 128;
   int64_t n_small = 0, n_big = 0;
   hipStream_t stream = nullptr;

@@ -211,6 +211,14 @@ __global__ __launch_bounds__(256) void k_big_assemble(DevPlan P, const int* __re
   }
 }
 
+// 1/d from v_rcp_f64 and two Newton steps (about 1 ulp); d = 0 gives inf/NaN like the division would
+__device__ __forceinline__ double fast_rcp_f64(double d) {
+  double r = __builtin_amdgcn_rcp(d);
+  r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+  r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+  return r;
+}
+
 __device__ __forceinline__ double readlane_f64(double v, int src_lane) {
   // wave-uniform broadcast through SGPRs (v_readlane_b32 x 2); src_lane must be wave-uniform
   int lo = __double2loint(v), hi = __double2hiint(v);
@@ -230,7 +238,7 @@ __device__ __forceinline__ void diag32_wave(double* B, int ldb, int off, int w) 
   for (int j = 0; j < 32; ++j) {
     const double dj = readlane_f64(a[j], j);
     const double wj = a[j];
-    const double l = wj * (1.0 / dj);
+    const double l = wj * fast_rcp_f64(dj);
 #pragma unroll
     for (int c = j + 1; c < 32; ++c) {
       const double wc = readlane_f64(wj, c);
@@ -290,6 +298,31 @@ __global__ __launch_bounds__(256) void k_big_diag(DevPlan P, const int* __restri
     __syncthreads();
     const int c0 = off + w;
     const int R = nb - c0;
+    if (wave == 3) {
+      // X_ii = inv(L_ii) (unit lower) on the otherwise idle wave 3, beside the row solve below (waves 0-1).
+      // Row r on lane r, like diag32_wave: X[r][:] -= L[r][p] * X[p][:] for p < r, rows broadcast by
+      // v_readlane.  It goes straight to HBM (the LDS copy of L_ii is still needed) and is read back for
+      // the off-diagonal blocks.
+      double x[kIB], lr[kIB];
+#pragma unroll
+      for (int p = 0; p < kIB; ++p)
+        lr[p] = (lane < w && p < lane) ? B[(off + min(lane, kIB - 1)) + (size_t)(off + p) * ldb] : 0.0;
+#pragma unroll
+      for (int c = 0; c < kIB; ++c) x[c] = (c == lane && lane < w) ? 1.0 : 0.0;
+#pragma unroll
+      for (int p = 0; p < kIB - 1; ++p) {
+#pragma unroll
+        for (int c = 0; c <= p; ++c) {
+          const double xp = readlane_f64(x[c], p);
+          x[c] -= lr[p] * xp;     // lr[p] = 0 on lanes <= p
+        }
+      }
+      double* Xg = P.invl + P.invl_pos[s] + (size_t)step * NB * NB;
+      if (lane < kIB) {
+#pragma unroll
+        for (int c = 0; c < kIB; ++c) Xg[(off + lane) + (size_t)(off + c) * NB] = x[c];
+      }
+    }
     if (R > 0) {  // then w == 32
       if (dbg_stop != 8 && tid < R) {
         const int r = c0 + tid;
@@ -349,32 +382,16 @@ __global__ __launch_bounds__(256) void k_big_diag(DevPlan P, const int* __restri
   flush_counts(P.counters, pos, neg, zer, bad);
   __syncthreads();
   if (dbg_stop == 3) return;
-  // ---- X = inv(L11), unit lower, blockwise; overwrites B
+  // ---- X = inv(L11), unit lower, blockwise; overwrites B.  The diagonal blocks X_ii were computed beside
+  // the factorisation (wave 3) and are read back from HBM into the places of L_ii
   const int nblk = (nb + kIB - 1) / kIB;
-  {
-    // diagonal blocks: thread c owns column c of its block
-    double x[kIB];
-    const int c = tid, b = c / kIB, lc = c - b * kIB;
-    const int boff = b * kIB;
-    const int w = min(kIB, nb - boff);
-    if (c < nb) {
-#pragma unroll
-      for (int r = 0; r < kIB; ++r) {
-        double v = (r == lc) ? 1.0 : 0.0;
-#pragma unroll
-        for (int p = 0; p < r; ++p)
-          if (p >= lc && r < w) v -= B[(boff + r) + (size_t)(boff + p) * ldb] * x[p];
-        x[r] = (r >= lc && r < w) ? v : 0.0;
-      }
-    }
-    __syncthreads();
-    if (c < nb) {
-#pragma unroll
-      for (int r = 0; r < kIB; ++r)
-        if (r >= lc && r < w) B[(boff + r) + (size_t)c * ldb] = x[r];   // diagonal now holds 1
-    }
-    __syncthreads();
+  double* X = P.invl + P.invl_pos[s] + (size_t)step * NB * NB;
+  for (int idx = tid; idx < nblk * kIB * kIB; idx += 256) {
+    const int b = idx / (kIB * kIB), e = idx - b * kIB * kIB;
+    const int cc = e / kIB, rr = e - cc * kIB;
+    B[(b * kIB + rr) + (size_t)(b * kIB + cc) * ldb] = X[(b * kIB + rr) + (size_t)(b * kIB + cc) * NB];
   }
+  __syncthreads();
   if (dbg_stop == 4) return;
   // off-diagonal blocks X_ij = -X_ii * (sum_{p=j}^{i-1} L_ip X_pj), by block distance d = i - j;
   // every 32 x 32 product is 2 x 2 MFMA tiles, the tiles of a round are spread over the waves
@@ -387,12 +404,23 @@ __global__ __launch_bounds__(256) void k_big_diag(DevPlan P, const int* __restri
       const int rr0 = (sub & 1) * 16, cc0 = (sub >> 1) * 16;
       d4_t acc = (d4_t){0.0, 0.0, 0.0, 0.0};
       const int lrow = ro + rr0 + l15;
-      for (int p0 = co; p0 < ro; p0 += 4) {
-        // L comes from the front in HBM/L2 (written above): the LDS copy of a block (bi, bp) is
-        // replaced by X as soon as its distance bi - bp has been processed
-        const double av = lrow < nb ? F[(size_t)(j0 + p0 + l4) * f + j0 + lrow] : 0.0;   // L[ro+rr][p]
-        const double bv = B[(p0 + l4) + (size_t)(co + cc0 + l15) * ldb];          // X[p][co+cc]
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+      // L comes from the front in HBM/L2 (written above): the LDS copy of a block (bi, bp) is replaced by X
+      // as soon as its distance bi - bp has been processed.  All (up to 24) operand loads are issued up
+      // front, unconditionally on clamped addresses, and masked afterwards: one memory round trip per tile.
+      double avv[24];
+      const int lrc = min(lrow, nb - 1);
+#pragma unroll
+      for (int q = 0; q < 24; ++q) {
+        const int p = min(co + 4 * q + l4, nb - 1);
+        avv[q] = keep_f64(F[(size_t)(j0 + p) * f + j0 + lrc], lrow < nb && co + 4 * q < ro);
+      }
+#pragma unroll
+      for (int q = 0; q < 24; ++q) {
+        const int p0 = co + 4 * q;
+        if (p0 < ro) {
+          const double bv = B[(p0 + l4) + (size_t)(co + cc0 + l15) * ldb];          // X[p][co+cc]
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(avv[q], bv, acc, 0, 0, 0);
+        }
       }
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg)   // D[i = rr][j = cc]
@@ -417,19 +445,17 @@ __global__ __launch_bounds__(256) void k_big_diag(DevPlan P, const int* __restri
     __syncthreads();
   }
   if (dbg_stop == 5) return;
-  double* X = P.invl + P.invl_pos[s] + (size_t)step * NB * NB;
-  double* XT = P.invlt + P.invl_pos[s] + (size_t)step * NB * NB;
-#pragma unroll 8
+  // strictly-lower blocks of X go out; the diagonal blocks are already there, the blocks above stay zero
   for (int idx = tid; idx < NB * NB; idx += 256) {
     const int c = idx / NB, i = idx - c * NB;
-    X[idx] = (i < nb && c < nb && i >= c) ? B[idx] : 0.0;
-    XT[idx] = (i < nb && c < nb && c >= i) ? B[c + (size_t)i * ldb] : 0.0;   // XT[i][c] = X[c][i]
+    const int bi = i / kIB, bc = c / kIB;
+    if (bi != bc) X[idx] = (i < nb && c < nb && bi > bc) ? B[idx] : 0.0;
   }
 }
 
 // W = A21 * inv(L11)^T (MFMA), L21 = W * D^-1.  64 rows per workgroup; wave w owns panel columns
 // [32w, 32w + 32).  Computed transposed (D[c][r]) so that global accesses run along front rows.
-__global__ __launch_bounds__(256) void k_big_trsm(DevPlan P, const int* __restrict__ list, int step, int NB) {
+__global__ __launch_bounds__(256) void k_big_trsm(DevPlan P, const int* __restrict__ list, int step, int NB, int wcol0) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int s = list[blockIdx.y];
   const int col0 = P.sn_col0[s];
@@ -441,7 +467,7 @@ __global__ __launch_bounds__(256) void k_big_trsm(DevPlan P, const int* __restri
   const int r0 = j0 + nb + blockIdx.x * 64;
   if (r0 >= f) return;
   double* F = P.arena + P.front_pos[s];
-  double* Wb = P.wbuf + P.wbuf_pos[s];
+  double* Wb = P.wbuf + P.wbuf_pos[s] + (size_t)wcol0 * f;   // this panel's slot inside the super-step's W
   const double* X = P.invl + P.invl_pos[s] + (size_t)step * NB * NB;
   const int l15 = lane & 15, l4 = lane >> 4;
   const int cs = wv * 32;  // column slice of this wave
@@ -515,31 +541,42 @@ constexpr size_t syrk_lds_bytes(int stages) { return (size_t)stages * 2 * kSyrkK
 typedef __attribute__((address_space(3))) void lds_void_t;
 
 template <int DBG, int STAGES>
-__global__ __launch_bounds__(256, STAGES == 2 ? 2 : 1) void k_big_syrk(DevPlan P, const int* __restrict__ list, int step, int NB) {
+__global__ __launch_bounds__(256, STAGES == 2 ? 2 : 1) void k_big_syrk(DevPlan P, const int* __restrict__ list, int stepA, int npan,
+                                                                       int tstep, int head, int NB) {
+  // Applies the panels [stepA, stepA + npan) (K = up to npan * NB columns, W panels side by side in wbuf)
+  // to the region that starts at block column tstep.  head = 0: the whole trailing lower triangle
+  // (super-step update, K = GS * NB halves the C traffic per flop for GS = 2); head = 1: only the next
+  // panel's own columns [t0, min(t0 + NB, k)) -- what that panel needs before it can be factored.
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int s = list[blockIdx.y];
   const int col0 = P.sn_col0[s];
   const int k = P.sn_col0[s + 1] - col0;
   const int f = (int)(P.row_ptr[s + 1] - P.row_ptr[s]);
-  const int j0 = step * NB;
+  const int j0 = stepA * NB;
   if (j0 >= k) return;
-  const int nb = min(NB, k - j0);
-  const int t0 = j0 + nb;
+  const int nb = min(npan * NB, k - j0);          // K of this update
+  if (head && tstep * NB >= k) return;            // there is no next panel in this front
+  const int t0 = min(tstep * NB, k);
+  const int climit = head ? min(t0 + NB, k) : f;  // columns this launch may write
   const int T = (f - t0 + 127) >> 7;
-  const int ntiles = T * (T + 1) / 2;
+  const int ntiles = head ? T : T * (T + 1) / 2;
   const int nx = (int)gridDim.x;
   const int per = (nx + 7) >> 3;
   const int idx = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
   if (idx >= ntiles) return;
-  int ti = (int)((sqrtf(8.0f * (float)idx + 1.0f) - 1.0f) * 0.5f);
-  while ((ti + 1) * (ti + 2) / 2 <= idx) ++ti;
-  while (ti * (ti + 1) / 2 > idx) --ti;
-  const int tj = idx - ti * (ti + 1) / 2;
+  int ti, tj;
+  if (head) { ti = idx; tj = 0; }
+  else {
+    ti = (int)((sqrtf(8.0f * (float)idx + 1.0f) - 1.0f) * 0.5f);
+    while ((ti + 1) * (ti + 2) / 2 <= idx) ++ti;
+    while (ti * (ti + 1) / 2 > idx) --ti;
+    tj = idx - ti * (ti + 1) / 2;
+  }
   const int rt0 = t0 + ti * 128, ct0 = t0 + tj * 128;   // tile origin
   const int rbase = rt0 + (wv & 1) * 64;
   const int cbase = ct0 + (wv >> 1) * 64;
-  const bool active = !(rbase + 63 < cbase) && rbase < f && cbase < f;
+  const bool active = !(rbase + 63 < cbase) && rbase < f && cbase < climit;
   double* F = P.arena + P.front_pos[s];
   const double* Wg = P.wbuf + P.wbuf_pos[s] + rt0 + lane * 2;
   const double* Lg = F + (size_t)j0 * f + ct0 + lane * 2;
@@ -573,7 +610,7 @@ __global__ __launch_bounds__(256, STAGES == 2 ? 2 : 1) void k_big_syrk(DevPlan P
     for (int rb = 0; rb < 4; ++rb) {
       const int r = rbase + rb * 16 + l15;
       if constexpr (DBG & 1) acc[cg][rb] = 0.0;
-      else acc[cg][rb] = keep_f64(colp[min(r, f - 1)], r < f && c < f && r >= c);
+      else acc[cg][rb] = keep_f64(colp[min(r, f - 1)], r < f && c < climit && r >= c);
     }
   }
   // the LDS-DMAs go out AFTER the C loads: with an LDS-DMA in flight hipcc waits vmcnt(0) after every
@@ -637,7 +674,7 @@ __global__ __launch_bounds__(256, STAGES == 2 ? 2 : 1) void k_big_syrk(DevPlan P
 #pragma unroll
   for (int cg = 0; cg < 16; ++cg) {
     const int c = cbase + cg * 4 + l4;
-    if (c >= f) continue;
+    if (c >= climit) continue;
     double* colp = F + (size_t)c * f;
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb) {
@@ -752,7 +789,7 @@ __global__ __launch_bounds__(256) void k_bigsolve_fwd_step(DevPlan P, const int*
   const int nb = min(NB, k - j0);
   if (blockIdx.x > 0 && j0 + nb + (int)blockIdx.x * 64 >= f) return;
   double* w = P.bigw + P.bigcol_base[s];
-  const double* XT = P.invlt + P.invl_pos[s] + (size_t)step * NB * NB;
+  const double* X = P.invl + P.invl_pos[s] + (size_t)step * NB * NB;
   if (tid < 128) wj[tid] = tid < nb ? w[j0 + tid] : 0.0;
   __syncthreads();
   // y[c] = sum_{p <= c} X[c][p] w[p]: two threads per row c (row c of X is contiguous in XT), each with
@@ -761,11 +798,12 @@ __global__ __launch_bounds__(256) void k_bigsolve_fwd_step(DevPlan P, const int*
     const int c = tid >> 1, h = tid & 1;
     double a = 0.0;
     if (c < nb) {
-      const double* xrow = XT + (size_t)c * NB + h * HALF;
-      // the stored block is zero above the diagonal and beyond nb, wj is zero-padded: no predicates
+      // X[c][p] sits at X[c + p * NB]: for a fixed p consecutive threads read consecutive addresses.  The
+      // stored block is zero above the diagonal and beyond nb, wj is zero-padded: no predicates
+      const double* xrow = X + c + (size_t)(h * HALF) * NB;
       double v[HALF];
 #pragma unroll
-      for (int q = 0; q < HALF; ++q) v[q] = xrow[q];
+      for (int q = 0; q < HALF; ++q) v[q] = xrow[(size_t)q * NB];
 #pragma unroll
       for (int q = 0; q < HALF; ++q) a += v[q] * wj[h * HALF + q];
     }
@@ -922,6 +960,7 @@ std::string numeric_setup(const Symbolic& S, const SymbolicOptions& opts, hipStr
   N.stream = stream;
   N.nb = std::max(32, std::min((opts.panel_nb + 31) / 32 * 32, 128));
   N.small_max = std::max(32, std::min(opts.small_front_max, 136));
+  N.group = getenv("OKKT_GROUP") ? std::max(1, std::min(atoi(getenv("OKKT_GROUP")), 4)) : 2;
   N.nnz_in = S.nnz_in;
   if (S.max_front > 46000) return "front order exceeds the 32-bit local offset range";
   const int ns = S.nsuper;
@@ -974,7 +1013,7 @@ std::string numeric_setup(const Symbolic& S, const SymbolicOptions& opts, hipStr
         g.maxf = std::max(g.maxf, f);
         g.maxk = std::max(g.maxk, k);
         sched.push_back(s);
-        if (c == 3) { wpos[s] = wtotal; wtotal += (int64_t)f * N.nb; ++N.n_big; } else ++N.n_small;
+        if (c == 3) { wpos[s] = wtotal; wtotal += (int64_t)f * N.nb * N.group; ++N.n_big; } else ++N.n_small;
       }
     }
   }
@@ -1022,7 +1061,6 @@ std::string numeric_setup(const Symbolic& S, const SymbolicOptions& opts, hipStr
     if (!(e = upload(N, ea_child, &d.ea_child)).empty()) return e;
     if (!(e = upload(N, ea_jj, &d.ea_jj)).empty()) return e;
     if (!(e = dalloc(N, (size_t)invl_total, &d.invl, false)).empty()) return e;
-    if (!(e = dalloc(N, (size_t)invl_total, &d.invlt, false)).empty()) return e;
     if (!(e = dalloc(N, (size_t)nbigcols, &d.bigw, true)).empty()) return e;
   }
   if (!(e = dalloc(N, (size_t)S.arena_doubles + 512, &d.arena, false)).empty()) return e;
@@ -1084,46 +1122,60 @@ std::string numeric_factor_enqueue(Numeric& N, const double* d_vals, double tol)
       hipLaunchKernelGGL(k_big_assemble, dim3((g.maxf + 3) / 4, g.cnt), dim3(256), 0, st, P, list);
       const int nsteps = (g.maxk + NB - 1) / NB;
       const size_t lds_diag = ((size_t)NB * NB + (size_t)std::max(NB - kIB, kIB) * kIB + NB) * sizeof(double);
-      for (int step = 0; step < nsteps; ++step) {
-        hipLaunchKernelGGL(k_big_diag, dim3(g.cnt), dim3(256), lds_diag, st, P, list, step, NB, tol, dbg_stop);
-        const int rem = g.maxf - step * NB;  // upper bound on rows below the diagonal block
-        if (rem <= 0) continue;
-        hipLaunchKernelGGL(k_big_trsm, dim3((rem + 63) / 64, g.cnt), dim3(256), 0, st, P, list, step, NB);
+      const int GS = N.group;
+      auto launch_syrk = [&](int stepA, int npan, int tstep, int head) -> std::string {
+        // upper bound on the rows of the target region: a front whose pivot block ends inside the group
+        // starts its trailing region at k < tstep * NB
+        const int rem = g.maxf - (head ? tstep : stepA) * NB;
+        if (rem <= 0) return "";
         const int T = (rem + 127) / 128;
-        {
-          const dim3 grid((T * (T + 1) / 2 + 7) / 8 * 8, g.cnt);
-          if (N.profile) {
-            // algorithmic flops of this launch: sum over the level's fronts of rem * (rem + 1) * nb
-            double fl = 0;
-            for (int q = 0; q < g.cnt; ++q) {
-              const int s = N.sched_host[g.off + q];
-              const int j0 = step * NB;
-              if (j0 >= N.sn_k[s]) continue;
-              const double nbq = std::min(NB, N.sn_k[s] - j0);
-              const double remq = N.sn_f[s] - j0 - nbq;
-              fl += remq * (remq + 1.0) * nbq;
-            }
-            if (N.prof_used + 2 > N.prof_events.size()) {
-              for (int q = 0; q < 512; ++q) { hipEvent_t ev; OKKT_HIP_TRY(hipEventCreate(&ev)); N.prof_events.push_back(ev); }
-            }
-            N.prof_flops.push_back(fl);
-            OKKT_HIP_TRY(hipEventRecord(N.prof_events[N.prof_used++], st));
+        const dim3 grid(((head ? T : T * (T + 1) / 2) + 7) / 8 * 8, g.cnt);
+        if (N.profile) {
+          // algorithmic flops of this launch: 2 * K * (lower-triangle entries it updates), summed over fronts
+          double fl = 0;
+          for (int q = 0; q < g.cnt; ++q) {
+            const int s = N.sched_host[g.off + q];
+            const int kk = N.sn_k[s], ff = N.sn_f[s];
+            const int j0 = stepA * NB;
+            if (j0 >= kk) continue;
+            if (head && tstep * NB >= kk) continue;
+            const double K = std::min(npan * NB, kk - j0);
+            const double t0 = std::min(tstep * NB, kk);
+            const double remq = ff - t0;
+            if (head) { const double w = std::min<double>(t0 + NB, kk) - t0; fl += 2.0 * K * (w * remq - w * (w - 1.0) / 2.0); }
+            else fl += K * remq * (remq + 1.0);
           }
-#define OKKT_SYRK(D, S) hipLaunchKernelGGL((k_big_syrk<D, S>), grid, dim3(256), syrk_lds_bytes(S), st, P, list, step, NB)
-          switch (dbg_syrk) {   // timing-only ablations (OKKT_DEBUG_SYRK): outputs are wrong for codes < 100
-            case 1: OKKT_SYRK(1, 3); break;
-            case 2: OKKT_SYRK(2, 3); break;
-            case 4: OKKT_SYRK(4, 3); break;
-            case 13: OKKT_SYRK(13, 3); break;
-            case 21: OKKT_SYRK(1, 2); break;
-            case 22: OKKT_SYRK(2, 2); break;
-            case 33: OKKT_SYRK(13, 2); break;
-            case 103: OKKT_SYRK(0, 3); break;   // correct variants
-            default: OKKT_SYRK(0, 2); break;
-          }
-#undef OKKT_SYRK
-          if (N.profile) OKKT_HIP_TRY(hipEventRecord(N.prof_events[N.prof_used++], st));
+          if (N.prof_used + 2 > N.prof_events.size())
+            for (int q = 0; q < 512; ++q) { hipEvent_t ev; OKKT_HIP_TRY(hipEventCreate(&ev)); N.prof_events.push_back(ev); }
+          N.prof_flops.push_back(fl);
+          OKKT_HIP_TRY(hipEventRecord(N.prof_events[N.prof_used++], st));
         }
+#define OKKT_SYRK(D, S) hipLaunchKernelGGL((k_big_syrk<D, S>), grid, dim3(256), syrk_lds_bytes(S), st, P, list, stepA, npan, tstep, head, NB)
+        switch (dbg_syrk) {   // timing-only ablations (OKKT_DEBUG_SYRK): outputs are wrong for codes < 100
+          case 1: OKKT_SYRK(1, 3); break;
+          case 2: OKKT_SYRK(2, 3); break;
+          case 4: OKKT_SYRK(4, 3); break;
+          case 13: OKKT_SYRK(13, 3); break;
+          case 21: OKKT_SYRK(1, 2); break;
+          case 22: OKKT_SYRK(2, 2); break;
+          case 33: OKKT_SYRK(13, 2); break;
+          case 103: OKKT_SYRK(0, 3); break;   // correct variants
+          default: OKKT_SYRK(0, 2); break;
+        }
+#undef OKKT_SYRK
+        if (N.profile) OKKT_HIP_TRY(hipEventRecord(N.prof_events[N.prof_used++], st));
+        return "";
+      };
+      for (int stepA = 0; stepA < nsteps; stepA += GS) {
+        for (int i = 0; i < GS && stepA + i < nsteps; ++i) {
+          const int step = stepA + i;
+          if (i > 0) { std::string e = launch_syrk(stepA, i, step, 1); if (!e.empty()) return e; }   // bring this panel up to date
+          hipLaunchKernelGGL(k_big_diag, dim3(g.cnt), dim3(256), lds_diag, st, P, list, step, NB, tol, dbg_stop);
+          const int rem = g.maxf - step * NB;  // upper bound on rows below the diagonal block
+          if (rem > 0) hipLaunchKernelGGL(k_big_trsm, dim3((rem + 63) / 64, g.cnt), dim3(256), 0, st, P, list, step, NB, i * NB);
+        }
+        std::string e = launch_syrk(stepA, GS, stepA + GS, 0);
+        if (!e.empty()) return e;
       }
     }
   }
