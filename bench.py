@@ -28,6 +28,22 @@ sys.path.insert(0, ROOT)
 FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X FP64 matrix spec; measured ceilings: DESIGN.md
 
 
+def max_over_ranks(elapsed, distributed, device="cuda"):
+    """MAX over ranks of the timed region (the slowest rank defines the step time)."""
+    if not distributed:
+        return elapsed
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def units_for_rank(rank, world):
+    """Replicas: every rank factors and solves its own KKT system (generator seed = rank)."""
+    return {"seed": rank, "systems_per_step": 1}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -53,7 +69,7 @@ def main():
     from onephase_jl_amd import synth
     from onephase_jl_amd.linear_system_solvers import finalize_b, initialize_b, linear_solver_HIP
 
-    prob = synth.make_config(args.config, seed=rank)
+    prob = synth.make_config(args.config, seed=units_for_rank(rank, world)["seed"])
     n, m = prob["n"], prob["m"]
     K = synth.augmented_matrix(prob, delta=1e-8)
     hip = linear_solver_HIP("symmetric", device=local_rank)
@@ -88,10 +104,7 @@ def main():
     if distributed:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = max_over_ranks(elapsed, distributed)
     nlaunch, syrk_ms, syrk_flops = hip.get_profile()
     hip.profile_dominant(False)
 

@@ -144,6 +144,32 @@ void* okkt_get_stream(okkt_handle h);
 int okkt_profile_dominant(okkt_handle h, int enable);
 int okkt_get_profile(okkt_handle h, int64_t* n_launches, double* total_ms, double* total_flops);
 
+/* ---- multi-GPU: subtree-to-GPU sharding of ONE factorisation (one process per GPU) -------------------
+ * No reference counterpart (the reference is single-process).  Every rank analyses the same
+ * pattern and calls okkt_dist_set_partition(nparts, its part id): disjoint elimination-tree subtrees are
+ * assigned to the parts (flop-balanced, deterministic), the ancestors of the cut ("top") to part 0.  The
+ * caller moves three flat device buffers between ranks with its own collective (RCCL reduce / broadcast):
+ *   factor: okkt_dist_factor_local -> okkt_dist_cb(buf, 0) [reduce(sum) to part 0] okkt_dist_cb(buf, 1) ->
+ *           okkt_dist_factor_top (part 0) -> okkt_dist_counts [all-reduce(sum)] -> okkt_dist_finish -> 1/0
+ *   solve : okkt_dist_solve_begin(rhs) -> okkt_dist_cv(buf, 0) [reduce(sum) to part 0] okkt_dist_cv(buf, 1) ->
+ *           okkt_dist_solve_top (part 0) -> okkt_dist_x(buf, 0) on part 0 [broadcast] okkt_dist_x(buf, 1) ->
+ *           okkt_dist_solve_end -> okkt_dist_x(sol, 2) [reduce(sum)]: the solution in original order.
+ * Buffers must be zero before the pack calls (every slot has exactly one writer, the sum is exact). */
+int okkt_dist_set_partition(okkt_handle h, int nparts, int part_id);
+int okkt_dist_info(okkt_handle h, int64_t* cb_doubles, int64_t* cv_doubles, int64_t* n_boundary,
+                   double* part_flops_out /* [nparts] or NULL */, double* top_flops_out);
+int okkt_dist_get_owner(okkt_handle h, int64_t* sn_owner_out, int64_t* col_owner_out, int64_t* sn_parent_out);
+int okkt_dist_factor_local(okkt_handle h, const double* d_nzval, int64_t n, int64_t m, int sym_kind);
+int okkt_dist_cb(okkt_handle h, double* d_buf, int unpack);
+int okkt_dist_factor_top(okkt_handle h);
+int okkt_dist_counts(okkt_handle h, int64_t out[4]);
+int okkt_dist_finish(okkt_handle h, const int64_t total[4]);
+int okkt_dist_solve_begin(okkt_handle h, const double* d_rhs);
+int okkt_dist_cv(okkt_handle h, double* d_buf, int unpack);
+int okkt_dist_solve_top(okkt_handle h);
+int okkt_dist_x(okkt_handle h, double* d_buf, int mode);
+int okkt_dist_solve_end(okkt_handle h);
+
 /* ---- level 2: device-resident KKT system solver ----------------------------------------- */
 typedef struct {
   double delta_start, delta_min, delta_max, delta_inc, delta_dec, delta_zero; /* parameters.jl:147-158 */

@@ -130,6 +130,19 @@ SIGNATURES = {
     "okkt_get_stream": (_vp, [_vp]),
     "okkt_profile_dominant": (C.c_int, [_vp, C.c_int]),
     "okkt_get_profile": (C.c_int, [_vp, _i64p, _f64p, _f64p]),
+    "okkt_dist_set_partition": (C.c_int, [_vp, C.c_int, C.c_int]),
+    "okkt_dist_info": (C.c_int, [_vp, _i64p, _i64p, _i64p, _f64p, _f64p]),
+    "okkt_dist_get_owner": (C.c_int, [_vp, _i64p, _i64p, _i64p]),
+    "okkt_dist_factor_local": (C.c_int, [_vp, _vp, C.c_int64, C.c_int64, C.c_int]),
+    "okkt_dist_cb": (C.c_int, [_vp, _vp, C.c_int]),
+    "okkt_dist_factor_top": (C.c_int, [_vp]),
+    "okkt_dist_counts": (C.c_int, [_vp, _i64p]),
+    "okkt_dist_finish": (C.c_int, [_vp, _i64p]),
+    "okkt_dist_solve_begin": (C.c_int, [_vp, _vp]),
+    "okkt_dist_cv": (C.c_int, [_vp, _vp, C.c_int]),
+    "okkt_dist_solve_top": (C.c_int, [_vp]),
+    "okkt_dist_x": (C.c_int, [_vp, _vp, C.c_int]),
+    "okkt_dist_solve_end": (C.c_int, [_vp]),
     "okkt_kkt_default_pars": (C.c_int, [C.POINTER(OkktKktPars)]),
     "okkt_kkt_create": (C.c_int, [C.POINTER(_vp), C.POINTER(OkktOpts), C.c_int]),
     "okkt_kkt_destroy": (C.c_int, [_vp]),

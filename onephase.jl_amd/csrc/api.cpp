@@ -30,6 +30,7 @@ int solver_ensure_numeric(okkt_solver_s* h) {
   if (rc != OKKT_OK) return rc;
   if (!h->analyzed) return solver_set_error(h, OKKT_ERR_INVALID, "okkt_analyze has not been called");
   if (h->numeric_ready) return OKKT_OK;
+  h->N.part_id = h->part_id;
   std::string e = numeric_setup(h->S, h->sopts, h->stream, h->N);
   if (!e.empty()) { numeric_release(h->N); return solver_set_error(h, OKKT_ERR_HIP, e); }
   h->numeric_ready = true;

@@ -46,6 +46,11 @@ struct DevPlan {
   double* invl = nullptr;          // inverse of the unit-lower diagonal blocks, NB x NB each
   int64_t* invl_pos = nullptr;     // [nsuper]
   double* bigw = nullptr;          // [n_bigcols] forward-solve work vectors of the big fronts
+  int* sn_owner = nullptr;     // multi-GPU partition: owner part of each supernode (-1 = top)
+  int* col_owner = nullptr;    // the same per permuted column
+  int* bnd = nullptr;          // boundary fronts (subtree roots under a top node)
+  int64_t* bnd_cb = nullptr;   // their offsets in the contribution-block exchange buffer
+  int64_t* bnd_cv = nullptr;   // ... and in the contribution-vector exchange buffer
   unsigned long long* counters = nullptr;  // pos, neg, zero, nonfinite
   double* zero_page = nullptr;  // 2 KiB of zeros (source of out-of-panel LDS-DMA rows)
 };
@@ -57,7 +62,10 @@ struct LevelSchedule { Segment seg[kNumClasses]; };
 
 struct Numeric {
   DevPlan d;
-  std::vector<LevelSchedule> levels;
+  std::vector<LevelSchedule> levels;      // subtrees owned by this part (everything when unpartitioned)
+  std::vector<LevelSchedule> levels_top;  // top of the tree (part 0 of a partitioned plan only)
+  int part_id = 0;
+  int n_boundary = 0;
   std::vector<void*> allocations;
   int nb = 64;
   int group = 2;   // block columns per super-step: the trailing update runs with K = group * nb
@@ -81,7 +89,14 @@ std::string numeric_setup(const Symbolic& S, const SymbolicOptions& opts, hipStr
 void numeric_release(Numeric& N);
 
 // enqueue the whole numeric factorisation on N.stream (no sync); values read from d_vals
-std::string numeric_factor_enqueue(Numeric& N, const double* d_vals, double tol);
+// which = 0: the local schedule, 1: the top-of-tree schedule
+std::string numeric_factor_enqueue(Numeric& N, const double* d_vals, double tol, int which = 0, bool reset_counters = true);
+std::string numeric_solve_fwd_enqueue(Numeric& N, int which);
+std::string numeric_solve_bwd_enqueue(Numeric& N, int which);
+// what = 0 contribution blocks, 1 contribution vectors; unpack = 0: mine -> buffer, 1: buffer -> the others' slots
+std::string numeric_dist_pack(Numeric& N, int what, int unpack, double* d_buf);
+// mode 0: xwork -> buf; 1: buf -> xwork on top columns; 2: owned part of the solution, original order -> buf
+std::string numeric_dist_x(Numeric& N, int mode, double* d_buf);
 // enqueue forward/diagonal/backward solves for the rhs already stored (permuted) in d.xwork
 std::string numeric_solve_enqueue(Numeric& N);
 // permute helpers: xwork[k] = rhs[perm[k]]  /  sol[perm[k]] = xwork[k]

@@ -984,42 +984,64 @@ std::string numeric_setup(const Symbolic& S, const SymbolicOptions& opts, hipStr
   UP(aent_dst, S.aent_dst);
   UP(perm, S.perm);
 #undef UP
-  // schedule: per level, fronts grouped by class, larger fronts first inside a class
+  // schedule: per level, fronts grouped by class, larger fronts first inside a class.  With a multi-GPU
+  // partition there are two schedules: the subtrees this part owns and (part 0 only) the top of the tree.
   std::vector<int> sched;
   sched.reserve(ns);
   std::vector<int64_t> wpos(ns, -1);
   int64_t wtotal = 0;
-  N.levels.assign(S.nlevels, LevelSchedule());
   N.n_small = N.n_big = 0;
-  for (int l = 0; l < S.nlevels; ++l) {
-    std::vector<int> cls[kNumClasses];
-    for (int q = S.level_ptr[l]; q < S.level_ptr[l + 1]; ++q) {
-      int s = S.level_sn[q];
-      int f = (int)(S.row_ptr[s + 1] - S.row_ptr[s]);
-      int c = f <= 32 ? 0 : (f <= 64 ? 1 : (f <= N.small_max ? 2 : 3));
-      cls[c].push_back(s);
-    }
-    for (int c = 0; c < kNumClasses; ++c) {
-      auto& v = cls[c];
-      std::stable_sort(v.begin(), v.end(), [&](int a, int b) {
-        return (S.row_ptr[a + 1] - S.row_ptr[a]) > (S.row_ptr[b + 1] - S.row_ptr[b]);
-      });
-      Segment& g = N.levels[l].seg[c];
-      g.off = (int)sched.size();
-      g.cnt = (int)v.size();
-      for (int s : v) {
+  const bool parted = S.nparts > 1 && (int)S.sn_owner.size() == ns;
+  auto build = [&](std::vector<LevelSchedule>& levels, int want_owner) {
+    levels.assign(S.nlevels, LevelSchedule());
+    for (int l = 0; l < S.nlevels; ++l) {
+      std::vector<int> cls[kNumClasses];
+      for (int q = S.level_ptr[l]; q < S.level_ptr[l + 1]; ++q) {
+        int s = S.level_sn[q];
+        if (parted && S.sn_owner[s] != want_owner) continue;
+        if (!parted && want_owner == -1) continue;
         int f = (int)(S.row_ptr[s + 1] - S.row_ptr[s]);
-        int k = S.sn_col0[s + 1] - S.sn_col0[s];
-        g.maxf = std::max(g.maxf, f);
-        g.maxk = std::max(g.maxk, k);
-        sched.push_back(s);
-        if (c == 3) { wpos[s] = wtotal; wtotal += (int64_t)f * N.nb * N.group; ++N.n_big; } else ++N.n_small;
+        int c = f <= 32 ? 0 : (f <= 64 ? 1 : (f <= N.small_max ? 2 : 3));
+        cls[c].push_back(s);
+      }
+      for (int c = 0; c < kNumClasses; ++c) {
+        auto& v = cls[c];
+        std::stable_sort(v.begin(), v.end(), [&](int a, int b) {
+          return (S.row_ptr[a + 1] - S.row_ptr[a]) > (S.row_ptr[b + 1] - S.row_ptr[b]);
+        });
+        Segment& g = levels[l].seg[c];
+        g.off = (int)sched.size();
+        g.cnt = (int)v.size();
+        for (int s : v) {
+          int f = (int)(S.row_ptr[s + 1] - S.row_ptr[s]);
+          int k = S.sn_col0[s + 1] - S.sn_col0[s];
+          g.maxf = std::max(g.maxf, f);
+          g.maxk = std::max(g.maxk, k);
+          sched.push_back(s);
+          if (c == 3) { wpos[s] = wtotal; wtotal += (int64_t)f * N.nb * N.group; ++N.n_big; } else ++N.n_small;
+        }
       }
     }
-  }
+  };
+  build(N.levels, parted ? N.part_id : 0);
+  if (parted && N.part_id == 0) build(N.levels_top, -1); else N.levels_top.clear();
   if (!(e = upload(N, sched, &d.sched)).empty()) return e;
   if (!(e = upload(N, wpos, &d.wbuf_pos)).empty()) return e;
   N.sched_host = sched;
+  {
+    std::vector<int> owner(ns, 0), col_owner((size_t)S.n, 0);
+    if (parted) owner = S.sn_owner;
+    for (int sn = 0; sn < ns; ++sn)
+      for (int j = S.sn_col0[sn]; j < S.sn_col0[sn + 1]; ++j) col_owner[j] = owner[sn];
+    if (!(e = upload(N, owner, &d.sn_owner)).empty()) return e;
+    if (!(e = upload(N, col_owner, &d.col_owner)).empty()) return e;
+    N.n_boundary = parted ? (int)S.boundary.size() : 0;
+    if (parted) {
+      if (!(e = upload(N, S.boundary, &d.bnd)).empty()) return e;
+      if (!(e = upload(N, S.boundary_cb, &d.bnd_cb)).empty()) return e;
+      if (!(e = upload(N, S.boundary_cv, &d.bnd_cv)).empty()) return e;
+    }
+  }
   N.sn_f.resize(ns);
   N.sn_k.resize(ns);
   for (int s = 0; s < ns; ++s) { N.sn_f[s] = (int)(S.row_ptr[s + 1] - S.row_ptr[s]); N.sn_k[s] = S.sn_col0[s + 1] - S.sn_col0[s]; }
@@ -1097,16 +1119,17 @@ void numeric_release(Numeric& N) {
   N.vals_owned = nullptr;
 }
 
-std::string numeric_factor_enqueue(Numeric& N, const double* d_vals, double tol) {
+std::string numeric_factor_enqueue(Numeric& N, const double* d_vals, double tol, int which, bool reset_counters) {
   DevPlan P = N.d;
   P.vals = d_vals;
   hipStream_t st = N.stream;
-  OKKT_HIP_TRY(hipMemsetAsync(P.counters, 0, 4 * sizeof(unsigned long long), st));
+  const std::vector<LevelSchedule>& levels = which == 0 ? N.levels : N.levels_top;
+  if (reset_counters) OKKT_HIP_TRY(hipMemsetAsync(P.counters, 0, 4 * sizeof(unsigned long long), st));
   const int NB = N.nb;
   static const int dbg_syrk = getenv("OKKT_DEBUG_SYRK") ? atoi(getenv("OKKT_DEBUG_SYRK")) : 0;
   static const int dbg_stop = getenv("OKKT_DEBUG_DIAG_STOP") ? atoi(getenv("OKKT_DEBUG_DIAG_STOP")) : 0;
-  for (size_t l = 0; l < N.levels.size(); ++l) {
-    const LevelSchedule& L = N.levels[l];
+  for (size_t l = 0; l < levels.size(); ++l) {
+    const LevelSchedule& L = levels[l];
     if (L.seg[0].cnt) {
       const Segment& g = L.seg[0];
       hipLaunchKernelGGL(k_front_small<64>, dim3(g.cnt), dim3(64), lds_small(g.maxf), st, P, P.sched + g.off, tol);
@@ -1183,13 +1206,32 @@ std::string numeric_factor_enqueue(Numeric& N, const double* d_vals, double tol)
   return "";
 }
 
-std::string numeric_solve_enqueue(Numeric& N) {
+static void launch_fwd_step(hipStream_t st, const DevPlan& P, const int* list, const dim3& gr, int NB, int step) {
+  switch (NB) {
+    case 32: hipLaunchKernelGGL(k_bigsolve_fwd_step<32>, gr, dim3(256), 0, st, P, list, step); break;
+    case 64: hipLaunchKernelGGL(k_bigsolve_fwd_step<64>, gr, dim3(256), 0, st, P, list, step); break;
+    case 96: hipLaunchKernelGGL(k_bigsolve_fwd_step<96>, gr, dim3(256), 0, st, P, list, step); break;
+    default: hipLaunchKernelGGL(k_bigsolve_fwd_step<128>, gr, dim3(256), 0, st, P, list, step); break;
+  }
+}
+static void launch_bwd_step(hipStream_t st, const DevPlan& P, const int* list, const dim3& gr, int NB, int step) {
+  switch (NB) {
+    case 32: hipLaunchKernelGGL(k_bigsolve_bwd_step<32>, gr, dim3(256), 0, st, P, list, step); break;
+    case 64: hipLaunchKernelGGL(k_bigsolve_bwd_step<64>, gr, dim3(256), 0, st, P, list, step); break;
+    case 96: hipLaunchKernelGGL(k_bigsolve_bwd_step<96>, gr, dim3(256), 0, st, P, list, step); break;
+    default: hipLaunchKernelGGL(k_bigsolve_bwd_step<128>, gr, dim3(256), 0, st, P, list, step); break;
+  }
+}
+
+// forward (L, then D^-1 fused) sweep over one schedule: which = 0 local subtrees, 1 top of the tree
+std::string numeric_solve_fwd_enqueue(Numeric& N, int which) {
   DevPlan P = N.d;
   hipStream_t st = N.stream;
-  const int nl = (int)N.levels.size();
+  const std::vector<LevelSchedule>& levels = which == 0 ? N.levels : N.levels_top;
+  const int nl = (int)levels.size();
   const int NB = N.nb;
   for (int l = 0; l < nl; ++l) {
-    const LevelSchedule& L = N.levels[l];
+    const LevelSchedule& L = levels[l];
     for (int c = 0; c < 3; ++c) {
       const Segment& g = L.seg[c];
       if (!g.cnt) continue;
@@ -1204,32 +1246,29 @@ std::string numeric_solve_enqueue(Numeric& N) {
       const int nsteps = (g.maxk + NB - 1) / NB;
       for (int step = 0; step < nsteps; ++step) {
         const int rem = std::max(g.maxf - step * NB, 0);  // upper bound on the rows below block `step`
-        const dim3 gr(std::max(1, (rem + 63) / 64), g.cnt);
-        switch (NB) {
-          case 32: hipLaunchKernelGGL(k_bigsolve_fwd_step<32>, gr, dim3(256), 0, st, P, list, step); break;
-          case 64: hipLaunchKernelGGL(k_bigsolve_fwd_step<64>, gr, dim3(256), 0, st, P, list, step); break;
-          case 96: hipLaunchKernelGGL(k_bigsolve_fwd_step<96>, gr, dim3(256), 0, st, P, list, step); break;
-          default: hipLaunchKernelGGL(k_bigsolve_fwd_step<128>, gr, dim3(256), 0, st, P, list, step); break;
-        }
+        launch_fwd_step(st, P, list, dim3(std::max(1, (rem + 63) / 64), g.cnt), NB, step);
       }
     }
   }
+  OKKT_HIP_TRY(hipGetLastError());
+  return "";
+}
+
+std::string numeric_solve_bwd_enqueue(Numeric& N, int which) {
+  DevPlan P = N.d;
+  hipStream_t st = N.stream;
+  const std::vector<LevelSchedule>& levels = which == 0 ? N.levels : N.levels_top;
+  const int nl = (int)levels.size();
+  const int NB = N.nb;
   for (int l = nl - 1; l >= 0; --l) {
-    const LevelSchedule& L = N.levels[l];
+    const LevelSchedule& L = levels[l];
     const Segment& gb = L.seg[3];
     if (gb.cnt) {
       const int* list = P.sched + gb.off;
       hipLaunchKernelGGL(k_bigsolve_bwd_pre, dim3((gb.maxk + 3) / 4, gb.cnt), dim3(256), 0, st, P, list);
       const int nsteps = (gb.maxk + NB - 1) / NB;
-      for (int step = nsteps - 1; step >= 0; --step) {
-        const dim3 gr(std::max(1, (step * NB + 63) / 64), gb.cnt);
-        switch (NB) {
-          case 32: hipLaunchKernelGGL(k_bigsolve_bwd_step<32>, gr, dim3(256), 0, st, P, list, step); break;
-          case 64: hipLaunchKernelGGL(k_bigsolve_bwd_step<64>, gr, dim3(256), 0, st, P, list, step); break;
-          case 96: hipLaunchKernelGGL(k_bigsolve_bwd_step<96>, gr, dim3(256), 0, st, P, list, step); break;
-          default: hipLaunchKernelGGL(k_bigsolve_bwd_step<128>, gr, dim3(256), 0, st, P, list, step); break;
-        }
-      }
+      for (int step = nsteps - 1; step >= 0; --step)
+        launch_bwd_step(st, P, list, dim3(std::max(1, (step * NB + 63) / 64), gb.cnt), NB, step);
     }
     for (int c = 0; c < 3; ++c) {
       const Segment& g = L.seg[c];
@@ -1239,6 +1278,67 @@ std::string numeric_solve_enqueue(Numeric& N) {
       else hipLaunchKernelGGL(k_solve_bwd<256>, dim3(g.cnt), dim3(256), lds, st, P, P.sched + g.off);
     }
   }
+  OKKT_HIP_TRY(hipGetLastError());
+  return "";
+}
+
+std::string numeric_solve_enqueue(Numeric& N) {
+  std::string e;
+  if (!(e = numeric_solve_fwd_enqueue(N, 0)).empty()) return e;
+  if (!(e = numeric_solve_fwd_enqueue(N, 1)).empty()) return e;
+  if (!(e = numeric_solve_bwd_enqueue(N, 1)).empty()) return e;
+  return numeric_solve_bwd_enqueue(N, 0);
+}
+
+// ---- multi-GPU exchange helpers (contribution blocks / vectors of the cut, solution pieces) -------------
+__global__ void k_pack_cb(DevPlan P, const int* __restrict__ bnd, const int64_t* __restrict__ off, const int* __restrict__ owner,
+                          int part, int unpack, double* __restrict__ buf) {
+  // one workgroup per boundary front: its r x r contribution block <-> a dense r x r slot of the buffer
+  const int s = bnd[blockIdx.x];
+  const bool mine = owner[s] == part;
+  if (unpack ? mine : !mine) return;
+  const int k = P.sn_col0[s + 1] - P.sn_col0[s];
+  const int f = (int)(P.row_ptr[s + 1] - P.row_ptr[s]);
+  const int r = f - k;
+  double* F = P.arena + P.front_pos[s] + (size_t)k * f + k;
+  double* B = buf + off[blockIdx.x];
+  for (int64_t idx = threadIdx.x; idx < (int64_t)r * r; idx += blockDim.x) {
+    const int j = (int)(idx / r), i = (int)(idx - (int64_t)j * r);
+    if (i < j) continue;
+    if (unpack) F[(size_t)j * f + i] = B[idx]; else B[idx] = F[(size_t)j * f + i];
+  }
+}
+__global__ void k_pack_cv(DevPlan P, const int* __restrict__ bnd, const int64_t* __restrict__ off, const int* __restrict__ owner,
+                          int part, int unpack, double* __restrict__ buf) {
+  const int s = bnd[blockIdx.x];
+  const bool mine = owner[s] == part;
+  if (unpack ? mine : !mine) return;
+  const int r = (int)(P.rel_ptr[s + 1] - P.rel_ptr[s]);
+  double* cv = P.cv + P.cv_pos[s];
+  double* B = buf + off[blockIdx.x];
+  for (int i = threadIdx.x; i < r; i += blockDim.x) { if (unpack) cv[i] = B[i]; else B[i] = cv[i]; }
+}
+// mode 0: buf[col] = xwork[col] (all);  1: xwork[col] = buf[col] for top columns only;
+// mode 2: sol[perm[col]] = owned(col) ? xwork[col] : 0  (owned: my part, or top when I am part 0)
+__global__ void k_exchange_x(int n, const int* __restrict__ col_owner, const int* __restrict__ perm, int part, int mode,
+                             double* __restrict__ xwork, double* __restrict__ buf) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n) return;
+  if (mode == 0) buf[c] = xwork[c];
+  else if (mode == 1) { if (col_owner[c] == -1) xwork[c] = buf[c]; }
+  else { const int o = col_owner[c]; buf[perm[c]] = (o == part || (o == -1 && part == 0)) ? xwork[c] : 0.0; }
+}
+
+std::string numeric_dist_pack(Numeric& N, int what, int unpack, double* d_buf) {
+  if (!N.d.bnd || N.n_boundary == 0) return "";
+  if (what == 0) hipLaunchKernelGGL(k_pack_cb, dim3(N.n_boundary), dim3(256), 0, N.stream, N.d, N.d.bnd, N.d.bnd_cb, N.d.sn_owner, N.part_id, unpack, d_buf);
+  else hipLaunchKernelGGL(k_pack_cv, dim3(N.n_boundary), dim3(256), 0, N.stream, N.d, N.d.bnd, N.d.bnd_cv, N.d.sn_owner, N.part_id, unpack, d_buf);
+  OKKT_HIP_TRY(hipGetLastError());
+  return "";
+}
+std::string numeric_dist_x(Numeric& N, int mode, double* d_buf) {
+  const int n = N.d.n;
+  if (n) hipLaunchKernelGGL(k_exchange_x, dim3((n + 255) / 256), dim3(256), 0, N.stream, n, N.d.col_owner, N.d.perm, N.part_id, mode, N.d.xwork, d_buf);
   OKKT_HIP_TRY(hipGetLastError());
   return "";
 }

@@ -25,6 +25,11 @@ struct okkt_solver_s {
   std::string err;
   double analyze_seconds = 0, last_factor_ms = 0, last_solve_ms = 0;
   int64_t n_analyze_calls = 0;
+  int part_id = 0;                 // multi-GPU part of this handle (okkt_dist_set_partition)
+  const double* dist_vals = nullptr;
+  int64_t dist_n = 0, dist_m = 0;
+  int dist_kind = 0;
+  double dist_tol = 0;
   double* d_rhs_stage = nullptr;  // staging for host-side rhs/sol
   int64_t rhs_stage_len = 0;
 };

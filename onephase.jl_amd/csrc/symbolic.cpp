@@ -4,6 +4,7 @@
 #include "symbolic.h"
 
 #include <algorithm>
+#include <functional>
 #include <cstring>
 #include <numeric>
 
@@ -419,6 +420,101 @@ std::string analyze_pattern(int64_t n64, const int64_t* colptr, const int64_t* r
     for (int s = 0; s < ns; ++s) S.level_sn[fill[S.sn_level[s]]++] = s;
   }
   return "";
+}
+
+
+void partition_tree(Symbolic& S, int nparts) {
+  const int ns = S.nsuper;
+  S.nparts = std::max(1, nparts);
+  S.sn_owner.assign(ns, 0);
+  S.boundary.clear();
+  S.boundary_cb.assign(1, 0);
+  S.boundary_cv.assign(1, 0);
+  S.part_flops.assign(S.nparts, 0.0);
+  S.top_flops = 0;
+  std::vector<double> own(ns, 0.0), sub(ns, 0.0);
+  for (int s = 0; s < ns; ++s) {
+    const double f = (double)(S.row_ptr[s + 1] - S.row_ptr[s]);
+    const int k = S.sn_col0[s + 1] - S.sn_col0[s];
+    for (int j = 0; j < k; ++j) own[s] += (f - j) * (f - j);
+  }
+  for (int s = 0; s < ns; ++s) {   // children precede parents
+    sub[s] += own[s];
+    if (S.sn_parent[s] >= 0) sub[S.sn_parent[s]] += sub[s];
+  }
+  if (S.nparts == 1) {
+    for (int s = 0; s < ns; ++s) S.part_flops[0] += own[s];
+    return;
+  }
+  // candidates = current subtree roots; top = nodes that were split.  Greedy on the estimated parallel
+  // time  T = (flops of the top, serial on part 0) + (heaviest bin of an LPT packing of the candidates):
+  // the heaviest candidate is split into its children while that lowers T.
+  std::vector<char> is_top(ns, 0);
+  std::vector<int> cand;
+  for (int s = 0; s < ns; ++s) if (S.sn_parent[s] < 0) cand.push_back(s);
+  auto lpt_max = [&](const std::vector<int>& cs) {
+    std::vector<double> w;
+    w.reserve(cs.size());
+    for (int s : cs) w.push_back(sub[s]);
+    std::sort(w.begin(), w.end(), std::greater<double>());
+    std::vector<double> bins(S.nparts, 0.0);
+    for (double x : w) *std::min_element(bins.begin(), bins.end()) += x;
+    return *std::max_element(bins.begin(), bins.end());
+  };
+  double top = 0.0;
+  double best_T = top + lpt_max(cand);
+  int stall = 0;
+  for (int iter = 0; iter < ns && stall < 8; ++iter) {
+    int best = -1;
+    for (size_t q = 0; q < cand.size(); ++q) {
+      const bool hc = S.child_ptr[cand[q] + 1] > S.child_ptr[cand[q]];
+      if (!hc) continue;
+      if (best < 0 || sub[cand[q]] > sub[cand[best]] || (sub[cand[q]] == sub[cand[best]] && cand[q] < cand[best])) best = (int)q;
+    }
+    if (best < 0) break;
+    const int s = cand[best];
+    std::vector<int> trial = cand;
+    trial[best] = trial.back();
+    trial.pop_back();
+    for (int64_t q = S.child_ptr[s]; q < S.child_ptr[s + 1]; ++q) trial.push_back(S.children[q]);
+    const double T = top + own[s] + lpt_max(trial);
+    // accept improving splits; tolerate a few non-improving ones (a chain of single-child fronts has to be
+    // crossed before the tree widens), then stop
+    if (T < best_T * (1.0 - 1e-12)) { best_T = T; stall = 0; } else ++stall;
+    if (stall >= 8) break;
+    is_top[s] = 1;
+    top += own[s];
+    cand.swap(trial);
+    if (stall > 0) continue;
+  }
+  // splits taken during a final stall did not pay off: that is harmless for correctness, only the estimate
+  // of T is slightly worse than the best seen
+  S.top_flops = top;
+  // LPT bin packing of the candidate subtrees
+  std::sort(cand.begin(), cand.end(), [&](int a, int b) { return sub[a] > sub[b] || (sub[a] == sub[b] && a < b); });
+  std::vector<int> root_owner(ns, -2);
+  for (int s : cand) {
+    int p = 0;
+    for (int q = 1; q < S.nparts; ++q) if (S.part_flops[q] < S.part_flops[p]) p = q;
+    root_owner[s] = p;
+    S.part_flops[p] += sub[s];
+  }
+  // propagate ownership down the subtrees (parents have larger indices: walk downwards)
+  for (int s = ns - 1; s >= 0; --s) {
+    if (is_top[s]) { S.sn_owner[s] = -1; continue; }
+    if (root_owner[s] >= 0) { S.sn_owner[s] = root_owner[s]; continue; }
+    S.sn_owner[s] = S.sn_owner[S.sn_parent[s]];
+  }
+  for (int s = 0; s < ns; ++s) {
+    const int p = S.sn_parent[s];
+    if (S.sn_owner[s] >= 0 && p >= 0 && S.sn_owner[p] == -1) {
+      const int64_t k = S.sn_col0[s + 1] - S.sn_col0[s];
+      const int64_t r = S.row_ptr[s + 1] - S.row_ptr[s] - k;
+      S.boundary.push_back(s);
+      S.boundary_cb.push_back(S.boundary_cb.back() + r * r);
+      S.boundary_cv.push_back(S.boundary_cv.back() + r);
+    }
+  }
 }
 
 }  // namespace okkt

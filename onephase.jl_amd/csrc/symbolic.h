@@ -81,7 +81,21 @@ struct Symbolic {
   int64_t sum_r = 0;
   int max_front = 0;
   uint64_t pattern_hash = 0;
+
+  // subtree-to-GPU partition (multi-GPU row of SURVEY 8e): owner part of every supernode, -1 = "top"
+  // (ancestors of the cut, factored by part 0 after the contribution blocks of the cut have arrived)
+  int nparts = 1;
+  std::vector<int> sn_owner;          // [nsuper]
+  std::vector<int> boundary;          // subtree roots whose parent is a top node, ascending
+  std::vector<int64_t> boundary_cb;   // [nboundary+1] offsets (doubles) of their r x r blocks in the exchange buffer
+  std::vector<int64_t> boundary_cv;   // [nboundary+1] offsets of their length-r vectors
+  std::vector<double> part_flops;     // [nparts] dense-front flops of the subtrees of each part
+  double top_flops = 0;
 };
+
+// assigns disjoint elimination-tree subtrees to nparts parts (greedy: split the heaviest subtree until the
+// pieces are small enough to balance, then longest-processing-time bin packing); deterministic
+void partition_tree(Symbolic& S, int nparts);
 
 // colptr/rowval: CSC of a square matrix in either index base; only row >= col is used.
 // user_perm (size n, perm[new]=old, 0-based) is read when opts.ordering == 2.

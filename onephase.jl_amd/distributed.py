@@ -1,0 +1,209 @@
+"""Multi-GPU orchestration of ONE KKT factorisation + solve: elimination-tree subtrees sharded over ranks
+(SURVEY.md section 8e).  The numeric work and the pack/unpack kernels live behind the C ABI
+(include/okkt.h, okkt_dist_*); this module only sequences the phases and moves three flat buffers
+(contribution blocks of the cut, contribution vectors of the cut, solution pieces) between ranks.
+
+Two communicators:
+  * TorchComm  -- one process per GPU, torch.distributed ("nccl" = RCCL over xGMI on the GPU box, "gloo"
+                  in the CPU tests): reduce(sum) to part 0, broadcast from part 0, all-reduce of 4 integers.
+  * LocalComm  -- several parts driven from ONE process (virtual ranks); used by the single-GPU parity test
+                  to run the exact sharded code path and compare it with the unsharded factorisation.
+There is no reference counterpart: the reference is single-process.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+from .linear_system_solvers import OkktError, csc_arrays, finalize_b, initialize_b, linear_solver_HIP
+
+
+class LocalComm:
+    """nparts virtual ranks in one process; buffers live in HBM of the solver's device, collectives go
+    through the host (numpy) -- a test vehicle, not a performance path."""
+
+    def __init__(self, nparts):
+        self.world = nparts
+        self.ranks = list(range(nparts))
+
+    def alloc(self, solver, ndoubles):
+        return _DevBuf(solver, ndoubles)
+
+    def reduce_sum(self, bufs, dst=0):
+        tot = sum(b.download() for b in bufs)
+        bufs[dst].upload(tot)
+
+    def broadcast(self, bufs, src=0):
+        v = bufs[src].download()
+        for i, b in enumerate(bufs):
+            if i != src:
+                b.upload(v)
+
+    def allreduce_counts(self, counts):
+        tot = np.sum(np.stack(counts), axis=0)
+        return [tot.copy() for _ in counts]
+
+
+class _DevBuf:
+    def __init__(self, solver, n):
+        self.solver, self.n = solver, max(int(n), 1)
+        self.ptr = solver.dev_alloc(8 * self.n)
+        self.zero()
+
+    def zero(self):
+        self.upload(np.zeros(self.n))
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr, dtype=np.float64)
+        self.solver._check(self.solver._lib.okkt_dev_upload(self.solver._h, C.c_void_p(self.ptr), arr.ctypes.data_as(C.c_void_p), arr.nbytes), "upload")
+
+    def download(self):
+        return self.solver.dev_download(self.ptr, (self.n,))
+
+    def free(self):
+        self.solver.dev_free(self.ptr)
+
+
+class TorchComm:
+    """One process per GPU.  Buffers are torch tensors (their data_ptr() is what the C ABI receives)."""
+
+    def __init__(self, device=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.world = dist.get_world_size()
+        self.ranks = [dist.get_rank()]
+        self.device = device
+
+    def alloc(self, solver, ndoubles):
+        return _TorchBuf(self.torch, max(int(ndoubles), 1), self.device)
+
+    def reduce_sum(self, bufs, dst=0):
+        self.dist.reduce(bufs[0].t, dst=dst, op=self.dist.ReduceOp.SUM)
+
+    def broadcast(self, bufs, src=0):
+        self.dist.broadcast(bufs[0].t, src=src)
+
+    def allreduce_counts(self, counts):
+        t = self.torch.tensor(np.asarray(counts[0], dtype=np.int64), device=self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return [t.cpu().numpy()]
+
+
+class _TorchBuf:
+    def __init__(self, torch, n, device):
+        self.t = torch.zeros(n, dtype=torch.float64, device=device)
+        self.ptr = self.t.data_ptr()
+        self.n = n
+
+    def zero(self):
+        self.t.zero_()
+
+    def download(self):
+        return self.t.cpu().numpy()
+
+    def free(self):
+        pass
+
+
+class ShardedLinearSolver:
+    """ls_factor! / ls_solve of ONE matrix with its elimination tree sharded over `comm.world` parts."""
+
+    def __init__(self, comm, sym="symmetric", **opts):
+        self.comm = comm
+        self.sym = sym
+        self.solvers = []
+        for r in comm.ranks:
+            s = linear_solver_HIP(sym, **opts)
+            initialize_b(s)
+            self.solvers.append(s)
+        self._bufs = None
+        self.inertia = None
+
+    def _call(self, s, fn, *args):
+        return s._check(getattr(s._lib, fn)(s._h, *args), fn)
+
+    def analyze(self, A):
+        self.dim, colptr, rowval, self._nzval, base = csc_arrays(A)
+        for s, r in zip(self.solvers, self.comm.ranks):
+            s._check(s._lib.okkt_analyze(s._h, self.dim, L.p_i64(colptr), L.p_i64(rowval), base), "okkt_analyze")
+            s._dim = self.dim
+            self._call(s, "okkt_dist_set_partition", self.comm.world, r)
+        s0 = self.solvers[0]
+        cb, cv, nb = C.c_int64(), C.c_int64(), C.c_int64()
+        pf = np.zeros(self.comm.world)
+        tf = C.c_double()
+        self._call(s0, "okkt_dist_info", C.byref(cb), C.byref(cv), C.byref(nb), L.p_f64(pf), C.byref(tf))
+        self.info = dict(cb_doubles=cb.value, cv_doubles=cv.value, n_boundary=nb.value, part_flops=pf.tolist(), top_flops=tf.value)
+        if self._bufs:
+            for group in self._bufs.values():
+                for b in group:
+                    b.free()
+        mk = lambda n: [self.comm.alloc(s, n) for s in self.solvers]
+        self._bufs = dict(cb=mk(cb.value), cv=mk(cv.value), x=mk(self.dim), sol=mk(self.dim))
+        return self.info
+
+    def owners(self):
+        s = self.solvers[0]
+        st = s.stats()
+        sn = np.zeros(st["nsuper"], dtype=np.int64)
+        col = np.zeros(self.dim, dtype=np.int64)
+        par = np.zeros(st["nsuper"], dtype=np.int64)
+        self._call(s, "okkt_dist_get_owner", L.p_i64(sn), L.p_i64(col), L.p_i64(par))
+        return sn, col, par
+
+    def factor(self, d_vals_per_rank, n, m):
+        """d_vals_per_rank: device pointers of nzval, one per local rank.  Returns the 1/0 inertia flag."""
+        kind = L.OKKT_SYM_DEFINITE if self.sym == "definite" else L.OKKT_SYM_SYMMETRIC
+        cbs = self._bufs["cb"]
+        for b in cbs:
+            b.zero()
+        for s, dv in zip(self.solvers, d_vals_per_rank):
+            self._call(s, "okkt_dist_factor_local", C.c_void_p(dv), n, m, kind)
+        for s, b in zip(self.solvers, cbs):
+            self._call(s, "okkt_dist_cb", C.c_void_p(b.ptr), 0)
+        self.comm.reduce_sum(cbs, dst=0)                      # RCCL reduce of the parent-front contribution blocks
+        for s, b, r in zip(self.solvers, cbs, self.comm.ranks):
+            if r == 0:
+                self._call(s, "okkt_dist_cb", C.c_void_p(b.ptr), 1)
+                self._call(s, "okkt_dist_factor_top")
+        counts = []
+        for s in self.solvers:
+            c = np.zeros(4, dtype=np.int64)
+            self._call(s, "okkt_dist_counts", L.p_i64(c))
+            counts.append(c)
+        totals = self.comm.allreduce_counts(counts)
+        flag = None
+        for s, t in zip(self.solvers, totals):
+            t = np.ascontiguousarray(t, dtype=np.int64)
+            flag = self._call(s, "okkt_dist_finish", L.p_i64(t))
+            self.inertia = tuple(int(v) for v in t)
+        return int(flag)
+
+    def solve(self, d_rhs_per_rank):
+        """Returns the solution (original ordering) as a numpy array on every rank that owns buffer 0."""
+        cvs, xs, sols = self._bufs["cv"], self._bufs["x"], self._bufs["sol"]
+        for b in cvs:
+            b.zero()
+        for s, dr in zip(self.solvers, d_rhs_per_rank):
+            self._call(s, "okkt_dist_solve_begin", C.c_void_p(dr))
+        for s, b in zip(self.solvers, cvs):
+            self._call(s, "okkt_dist_cv", C.c_void_p(b.ptr), 0)
+        self.comm.reduce_sum(cvs, dst=0)
+        for s, b, xb, r in zip(self.solvers, cvs, xs, self.comm.ranks):
+            if r == 0:
+                self._call(s, "okkt_dist_cv", C.c_void_p(b.ptr), 1)
+                self._call(s, "okkt_dist_solve_top")
+                self._call(s, "okkt_dist_x", C.c_void_p(xb.ptr), 0)
+        self.comm.broadcast(xs, src=0)                        # separator solution to every part
+        for s, xb, sb in zip(self.solvers, xs, sols):
+            self._call(s, "okkt_dist_x", C.c_void_p(xb.ptr), 1)
+            self._call(s, "okkt_dist_solve_end")
+            self._call(s, "okkt_dist_x", C.c_void_p(sb.ptr), 2)
+        self.comm.reduce_sum(sols, dst=0)
+        return sols[0].download()
+
+    def finalize(self):
+        for s in self.solvers:
+            finalize_b(s)
+        self.solvers = []

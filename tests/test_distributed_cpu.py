@@ -1,0 +1,113 @@
+"""CPU tests of the N > 1 path: the tree partition (host symbolic only) and the collective layer with two
+gloo processes (127.0.0.1)."""
+import ctypes as C
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from onephase_jl_amd import _lib as L
+from onephase_jl_amd import synth
+from onephase_jl_amd.linear_system_solvers import initialize_b, linear_solver_HIP
+
+
+def host_partition(K, nparts):
+    s = linear_solver_HIP("symmetric", host_symbolic_only=1)
+    initialize_b(s)
+    s.analyze(K)
+    lib = s._lib
+    assert lib.okkt_dist_set_partition(s._h, nparts, 0) == 0
+    st = s.stats()
+    sn = np.zeros(st["nsuper"], dtype=np.int64)
+    col = np.zeros(st["n"], dtype=np.int64)
+    par = np.zeros(st["nsuper"], dtype=np.int64)
+    assert lib.okkt_dist_get_owner(s._h, L.p_i64(sn), L.p_i64(col), L.p_i64(par)) == 0
+    cb, cv, nb = C.c_int64(), C.c_int64(), C.c_int64()
+    pf = np.zeros(nparts)
+    tf = C.c_double()
+    assert lib.okkt_dist_info(s._h, C.byref(cb), C.byref(cv), C.byref(nb), L.p_f64(pf), C.byref(tf)) == 0
+    return s, sn, col, par, pf, tf.value, nb.value
+
+
+@pytest.mark.parametrize("nparts", [1, 2, 4, 8])
+def test_partition_is_a_valid_cut(nparts):
+    prob = synth.block_angular(nblocks=8, n_b=60, m_b=90, n_link=6, seed=0, j_per_row=4, h_per_col=3, w=5.0, p_far=0.0)
+    K = synth.augmented_matrix(prob)
+    s, sn, col, par, pf, tf, nb = host_partition(K, nparts)
+    assert set(np.unique(sn)).issubset(set(range(-1, nparts)))
+    for c, p in enumerate(par):
+        if p < 0:
+            continue
+        if sn[p] >= 0:
+            assert sn[c] == sn[p]          # below an owned node everything has the same owner: whole subtrees
+        # a top node (-1) may have children of any owner; a top node's parent is a top node
+        if sn[c] == -1:
+            assert sn[p] == -1
+    st = s.stats()
+    assert abs(pf.sum() + tf - st["flops_stored"]) <= 1e-6 * st["flops_stored"]
+    if nparts == 8:
+        assert (pf > 0).all() and pf.max() <= 1.6 * pf.mean()
+    if nparts == 1:
+        assert nb == 0 and (sn == 0).all()
+
+
+def test_partition_deterministic_across_ranks():
+    prob = synth.make_config("S-small", seed=3)
+    K = synth.augmented_matrix(prob)
+    a = host_partition(K, 4)
+    b = host_partition(K, 4)
+    assert np.array_equal(a[1], b[1]) and np.array_equal(a[4], b[4])
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+    from onephase_jl_amd.distributed import TorchComm
+    import bench
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    comm = TorchComm(device="cpu")
+    buf = comm.alloc(None, 6)
+    buf.t[:] = torch.arange(6, dtype=torch.float64) * (rank + 1) if rank else 0.0
+    if rank == 1:
+        buf.t[:] = torch.tensor([0, 0, 3.0, 4.0, 0, 0], dtype=torch.float64)     # every slot has one writer
+    else:
+        buf.t[:] = torch.tensor([1.0, 2.0, 0, 0, 5.0, 6.0], dtype=torch.float64)
+    comm.reduce_sum([buf], dst=0)
+    red = buf.download().copy()
+    x = comm.alloc(None, 3)
+    if rank == 0:
+        x.t[:] = torch.tensor([7.0, 8.0, 9.0], dtype=torch.float64)
+    comm.broadcast([x], src=0)
+    tot = comm.allreduce_counts([np.array([rank + 1, 10, 0, 0])])[0]
+    elapsed = bench.max_over_ranks(0.5 + rank, distributed=True, device="cpu")
+    units = bench.units_for_rank(rank, world)
+    q.put((rank, red.tolist(), x.download().tolist(), tot.tolist(), elapsed, units))
+    dist.destroy_process_group()
+
+
+def test_collective_layer_gloo_world2():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (r0, red0, x0, tot0, e0, u0), (r1, red1, x1, tot1, e1, u1) = out
+    assert red0 == [1.0, 2.0, 3.0, 4.0, 5.0, 6.0]            # reduce(sum) to part 0
+    assert x0 == x1 == [7.0, 8.0, 9.0]                        # broadcast from part 0
+    assert tot0 == tot1 == [3, 20, 0, 0]                      # all-reduce of the pivot counts
+    assert e0 == e1 == 1.5                                    # max over ranks of the elapsed time
+    assert u0 != u1                                           # replicas: every rank its own KKT system (seed)
