@@ -74,6 +74,8 @@ def make_problem(n, m, j_per_row=8, h_per_col=4, w=50.0, p_far=0.01, seed=0, con
 
 
 def make_config(name, seed=0, **over):
+    if name == "S-C5":   # block-angular: 8 independent blocks + 200 linking columns (wide elimination tree)
+        return block_angular(seed=seed, **over)
     cfg = dict(CONFIGS[name])
     cfg.update(over)
     return make_problem(seed=seed, **cfg)
