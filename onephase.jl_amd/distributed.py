@@ -78,11 +78,19 @@ class TorchComm:
     def alloc(self, solver, ndoubles):
         return _TorchBuf(self.torch, max(int(ndoubles), 1), self.device)
 
+    def _fence(self):
+        # the library works on its own HIP stream and is synchronous at every C-ABI call; RCCL collectives
+        # are only enqueued on torch's stream -- wait for them before the library touches the buffer
+        if self.device is not None and str(self.device) != "cpu":
+            self.torch.cuda.synchronize()
+
     def reduce_sum(self, bufs, dst=0):
         self.dist.reduce(bufs[0].t, dst=dst, op=self.dist.ReduceOp.SUM)
+        self._fence()
 
     def broadcast(self, bufs, src=0):
         self.dist.broadcast(bufs[0].t, src=src)
+        self._fence()
 
     def allreduce_counts(self, counts):
         t = self.torch.tensor(np.asarray(counts[0], dtype=np.int64), device=self.device)
