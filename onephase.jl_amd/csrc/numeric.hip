@@ -206,7 +206,20 @@ __global__ __launch_bounds__(256) void k_big_assemble(DevPlan P, const int* __re
     const int rc = fc - kc;
     const int* rl = P.rel + P.rel_ptr[c];
     const double* Ccol = P.arena + P.front_pos[c] + (size_t)(kc + jj) * fc + kc;
-    for (int ii = jj + lane; ii < rc; ii += 64) col[rl[ii]] += Ccol[ii];
+    // within one item the destinations rl[ii] are distinct: 4 chunks of 64 rows are fetched together
+    // (index, source and destination loads all in flight) before the adds and stores
+    int ii = jj + lane;
+    for (; ii + 192 < rc; ii += 256) {
+      int d[4];
+      double v[4], o[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) d[u] = rl[ii + 64 * u];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { v[u] = Ccol[ii + 64 * u]; o[u] = col[d[u]]; }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) col[d[u]] = o[u] + v[u];
+    }
+    for (; ii < rc; ii += 64) col[rl[ii]] += Ccol[ii];
     __threadfence_block();
   }
 }
@@ -252,6 +265,7 @@ __device__ __forceinline__ void diag32_wave(double* B, int ldb, int off, int w) 
 }
 
 constexpr int kIB = 32;  // inner block width of the diagonal-block kernel
+constexpr int kTld = 33; // leading dimension of the 32 x 32 scratch blocks (odd: conflict-free column access)
 
 // NB x NB diagonal block of block-column `step`: LDL^T in LDS (inner width 32: register/readlane
 // 32 x 32 kernel on one wave, row-parallel solve below it, MFMA rank-32 update), D and inertia out,
@@ -267,24 +281,26 @@ __global__ __launch_bounds__(256) void k_big_diag(DevPlan P, const int* __restri
   const int j0 = step * NB;
   if (j0 >= k) return;
   const int nb = min(NB, k - j0);
-  const int ldb = NB;
+  const int ldb = NB + 2;                    // padded: column stride = 4 banks, MFMA fragment reads stay conflict-free
   const int RMAX = max(NB - kIB, kIB);       // most rows below an inner block (>= 32: also the T scratch)
-  double* B = sm;                            // NB x NB
-  double* Wb = sm + (size_t)NB * NB;         // RMAX x 32 scratch
-  double* rdv = Wb + (size_t)RMAX * kIB;     // reciprocal pivots
+  double* B = sm;                            // NB columns of ldb
+  double* Wb = sm + (size_t)ldb * NB;        // RMAX x 32 scratch (+ slack for the padded T blocks)
+  double* rdv = Wb + (size_t)RMAX * kIB + 3 * kIB;   // reciprocal pivots
   double* F = P.arena + P.front_pos[s];
-  for (int base = 0; base < NB * NB; base += 256 * 8) {
-    double v[8];
+  // one block column per wave instruction: lane l moves rows 2l, 2l+1 (16 bytes); 8 columns in flight
+  for (int cb = wave * 8; cb < NB; cb += 32) {
+    double v0[8], v1[8];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {   // 8 loads in flight per thread
-      const int idx = base + q * 256 + tid;
-      const int c = idx / NB, i = idx - c * NB;
-      v[q] = (idx < NB * NB && i < nb && c < nb && i >= c) ? F[(size_t)(j0 + c) * f + j0 + i] : 0.0;
+    for (int q = 0; q < 8; ++q) {
+      const int c = cb + q, i0 = 2 * lane;
+      const double* src = F + (size_t)(j0 + min(c, nb - 1)) * f + j0;
+      v0[q] = keep_f64(src[min(i0, nb - 1)], c < nb && i0 < nb && i0 >= c && i0 < NB);
+      v1[q] = keep_f64(src[min(i0 + 1, nb - 1)], c < nb && i0 + 1 < nb && i0 + 1 >= c && i0 + 1 < NB);
     }
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-      const int idx = base + q * 256 + tid;
-      if (idx < NB * NB) B[idx] = v[q];
+      const int c = cb + q, i0 = 2 * lane;
+      if (c < NB && i0 < NB) { B[i0 + (size_t)c * ldb] = v0[q]; B[i0 + 1 + (size_t)c * ldb] = v1[q]; }
     }
   }
   __syncthreads();
@@ -367,11 +383,12 @@ __global__ __launch_bounds__(256) void k_big_diag(DevPlan P, const int* __restri
     }
   }
   if (dbg_stop == 2 || dbg_stop == 7 || dbg_stop == 8) return;
-  // L11, D, inertia
-#pragma unroll 8
-  for (int idx = tid; idx < nb * nb; idx += 256) {
-    const int c = idx / nb, i = idx - c * nb;
-    if (i >= c) F[(size_t)(j0 + c) * f + j0 + i] = B[i + (size_t)c * ldb];
+  // L11, D, inertia (one block column per wave instruction)
+  for (int c = wave; c < nb; c += 4) {
+    double* dst = F + (size_t)(j0 + c) * f + j0;
+    const int i0 = 2 * lane;
+    if (i0 >= c && i0 < nb) dst[i0] = B[i0 + (size_t)c * ldb];
+    if (i0 + 1 >= c && i0 + 1 < nb) dst[i0 + 1] = B[i0 + 1 + (size_t)c * ldb];
   }
   unsigned pos = 0, neg = 0, zer = 0, bad = 0;
   for (int j = tid; j < nb; j += 256) {
@@ -386,10 +403,18 @@ __global__ __launch_bounds__(256) void k_big_diag(DevPlan P, const int* __restri
   // the factorisation (wave 3) and are read back from HBM into the places of L_ii
   const int nblk = (nb + kIB - 1) / kIB;
   double* X = P.invl + P.invl_pos[s] + (size_t)step * NB * NB;
-  for (int idx = tid; idx < nblk * kIB * kIB; idx += 256) {
-    const int b = idx / (kIB * kIB), e = idx - b * kIB * kIB;
-    const int cc = e / kIB, rr = e - cc * kIB;
-    B[(b * kIB + rr) + (size_t)(b * kIB + cc) * ldb] = X[(b * kIB + rr) + (size_t)(b * kIB + cc) * NB];
+  {
+    // 4 x (32 x 32): thread = (block b, column cc, half h) moves 16 rows; 16 loads in flight each
+    const int b = tid >> 6, cc = (tid >> 1) & 31, h = tid & 1;
+    if (b < nblk) {
+      const size_t o = (size_t)(b * kIB + h * 16) + (size_t)(b * kIB + cc);
+      double v[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) v[q] = X[(b * kIB + h * 16 + q) + (size_t)(b * kIB + cc) * NB];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) B[(b * kIB + h * 16 + q) + (size_t)(b * kIB + cc) * ldb] = v[q];
+      (void)o;
+    }
   }
   __syncthreads();
   if (dbg_stop == 4) return;
@@ -424,7 +449,7 @@ __global__ __launch_bounds__(256) void k_big_diag(DevPlan P, const int* __restri
       }
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg)   // D[i = rr][j = cc]
-        T[bj * kIB * kIB + (rr0 + l4 + 4 * reg) + (cc0 + l15) * kIB] = acc[reg];
+        T[bj * kTld * kIB + (rr0 + l4 + 4 * reg) + (cc0 + l15) * kTld] = acc[reg];
     }
     __syncthreads();
     for (int t = wave; t < npairs * 4; t += 4) {
@@ -435,7 +460,7 @@ __global__ __launch_bounds__(256) void k_big_diag(DevPlan P, const int* __restri
 #pragma unroll
       for (int p0 = 0; p0 < kIB; p0 += 4) {
         const double av = B[(ro + rr0 + l15) + (size_t)(ro + p0 + l4) * ldb];     // X_ii[rr][p]
-        const double bv = T[bj * kIB * kIB + (p0 + l4) + (cc0 + l15) * kIB];      // T[p][cc]
+        const double bv = T[bj * kTld * kIB + (p0 + l4) + (cc0 + l15) * kTld];    // T[p][cc]
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
       }
 #pragma unroll
@@ -446,10 +471,13 @@ __global__ __launch_bounds__(256) void k_big_diag(DevPlan P, const int* __restri
   }
   if (dbg_stop == 5) return;
   // strictly-lower blocks of X go out; the diagonal blocks are already there, the blocks above stay zero
-  for (int idx = tid; idx < NB * NB; idx += 256) {
-    const int c = idx / NB, i = idx - c * NB;
-    const int bi = i / kIB, bc = c / kIB;
-    if (bi != bc) X[idx] = (i < nb && c < nb && bi > bc) ? B[idx] : 0.0;
+  for (int c = wave; c < NB; c += 4) {
+    const int bc = c / kIB;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int i = 2 * lane + u;
+      if (i < NB && i / kIB != bc) X[i + (size_t)c * NB] = (i < nb && c < nb && i / kIB > bc) ? B[i + (size_t)c * ldb] : 0.0;
+    }
   }
 }
 
@@ -1144,7 +1172,7 @@ std::string numeric_factor_enqueue(Numeric& N, const double* d_vals, double tol,
       const int* list = P.sched + g.off;
       hipLaunchKernelGGL(k_big_assemble, dim3((g.maxf + 3) / 4, g.cnt), dim3(256), 0, st, P, list);
       const int nsteps = (g.maxk + NB - 1) / NB;
-      const size_t lds_diag = ((size_t)NB * NB + (size_t)std::max(NB - kIB, kIB) * kIB + NB) * sizeof(double);
+      const size_t lds_diag = ((size_t)(NB + 2) * NB + (size_t)std::max(NB - kIB, kIB) * kIB + 3 * kIB + NB) * sizeof(double);
       const int GS = N.group;
       auto launch_syrk = [&](int stepA, int npan, int tstep, int head) -> std::string {
         // upper bound on the rows of the target region: a front whose pivot block ends inside the group
