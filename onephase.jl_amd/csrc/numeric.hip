@@ -630,15 +630,23 @@ __global__ __launch_bounds__(256, STAGES == 2 ? 2 : 1) void k_big_syrk(DevPlan P
   // accumulators start from C (guarded; lanes outside the front or above the diagonal hold zeros)
   // Loads are unconditional on clamped (always valid) addresses and selected afterwards: a load under
   // a per-element branch makes hipcc wait vmcnt(0) per element, i.e. 64 serial memory round trips.
+  // Row map of an accumulator: (l15, rb) <-> row 2*l15 + (rb & 1) + 32*(rb >> 1) of the wave's 64 rows, so
+  // that a lane's (rb, rb+1) pair is 16 contiguous bytes of C: 16-byte loads/stores, 256-byte segments.
+  typedef double d2_t __attribute__((ext_vector_type(2)));
 #pragma unroll
   for (int cg = 0; cg < 16; ++cg) {
     const int c = cbase + cg * 4 + l4;
     const double* colp = F + (size_t)min(c, f - 1) * f;
 #pragma unroll
-    for (int rb = 0; rb < 4; ++rb) {
-      const int r = rbase + rb * 16 + l15;
-      if constexpr (DBG & 1) acc[cg][rb] = 0.0;
-      else acc[cg][rb] = keep_f64(colp[min(r, f - 1)], r < f && c < climit && r >= c);
+    for (int h = 0; h < 2; ++h) {
+      const int r = rbase + 2 * l15 + 32 * h;
+      const int rcl = min(r, f - 2);            // clamped pair start: always in bounds, no branch
+      const int shift = r - rcl;                // 0 in the interior, 1 when r is the last row, >= 2 outside
+      d2_t v = (d2_t){0.0, 0.0};
+      if constexpr (!(DBG & 1)) __builtin_memcpy(&v, colp + rcl, 16);
+      const double e0 = shift == 0 ? v[0] : v[1];
+      acc[cg][2 * h] = keep_f64(e0, shift <= 1 && c < climit && r >= c);
+      acc[cg][2 * h + 1] = keep_f64(v[1], shift == 0 && c < climit && r + 1 >= c);
     }
   }
   // the LDS-DMAs go out AFTER the C loads: with an LDS-DMA in flight hipcc waits vmcnt(0) after every
@@ -655,7 +663,7 @@ __global__ __launch_bounds__(256, STAGES == 2 ? 2 : 1) void k_big_syrk(DevPlan P
     if constexpr (!(DBG & 8)) { if (ch + STAGES - 1 < nchunk) issue(ch + STAGES - 1); }
     if (active && !(DBG & 2)) {
       const double* slot = sm + (size_t)(ch % STAGES) * 2 * kSyrkKC * kSyrkLd;
-      const double* bw = slot + (wv & 1) * 64 + l15;
+      const double* bw = slot + (wv & 1) * 64 + 2 * l15;
       const double* bl = slot + kSyrkKC * kSyrkLd + (wv >> 1) * 64 + (lane & 3);
       if constexpr (STAGES == 3) {
         // one wave per SIMD: nobody else hides the LDS latency, so all 80 operand fragments of the
@@ -664,7 +672,7 @@ __global__ __launch_bounds__(256, STAGES == 2 ? 2 : 1) void k_big_syrk(DevPlan P
 #pragma unroll
         for (int kk = 0; kk < kSyrkKC / 4; ++kk) {
 #pragma unroll
-          for (int rb = 0; rb < 4; ++rb) bvv[kk][rb] = bw[(kk * 4 + l4) * kSyrkLd + rb * 16];
+          for (int rb = 0; rb < 4; ++rb) bvv[kk][rb] = bw[(kk * 4 + l4) * kSyrkLd + (rb & 1) + 32 * (rb >> 1)];
 #pragma unroll
           for (int cg = 0; cg < 16; ++cg) avv[kk][cg] = bl[(kk * 4 + l4) * kSyrkLd + cg * 4];
         }
@@ -681,7 +689,7 @@ __global__ __launch_bounds__(256, STAGES == 2 ? 2 : 1) void k_big_syrk(DevPlan P
         for (int kk = 0; kk < kSyrkKC / 4; ++kk) {
           double bv[4];
 #pragma unroll
-          for (int rb = 0; rb < 4; ++rb) bv[rb] = bw[(kk * 4 + l4) * kSyrkLd + rb * 16];
+          for (int rb = 0; rb < 4; ++rb) bv[rb] = bw[(kk * 4 + l4) * kSyrkLd + (rb & 1) + 32 * (rb >> 1)];
 #pragma unroll
           for (int half = 0; half < 4; ++half) {
             double av[4];
@@ -705,9 +713,15 @@ __global__ __launch_bounds__(256, STAGES == 2 ? 2 : 1) void k_big_syrk(DevPlan P
     if (c >= climit) continue;
     double* colp = F + (size_t)c * f;
 #pragma unroll
-    for (int rb = 0; rb < 4; ++rb) {
-      const int r = rbase + rb * 16 + l15;
-      if (r < f && r >= c) colp[r] = acc[cg][rb];
+    for (int h = 0; h < 2; ++h) {
+      const int r = rbase + 2 * l15 + 32 * h;
+      if (r + 1 < f && r >= c) {
+        const d2_t v = (d2_t){acc[cg][2 * h], acc[cg][2 * h + 1]};
+        __builtin_memcpy(colp + r, &v, 16);
+      } else {
+        if (r < f && r >= c) colp[r] = acc[cg][2 * h];
+        if (r + 1 < f && r + 1 >= c) colp[r + 1] = acc[cg][2 * h + 1];
+      }
     }
   }
 }
