@@ -398,29 +398,41 @@ __global__ __launch_bounds__(256) void k_big_diag(DevPlan P, const int* __restri
   }
   flush_counts(P.counters, pos, neg, zer, bad);
   __syncthreads();
-  if (dbg_stop == 3) return;
-  // ---- X = inv(L11), unit lower, blockwise; overwrites B.  The diagonal blocks X_ii were computed beside
-  // the factorisation (wave 3) and are read back from HBM into the places of L_ii
+}
+
+// Deferred full inverse X = inv(L11) of every NB x NB diagonal block of the big fronts of a level (one
+// workgroup per block, all blocks in parallel, off the critical path of the factorisation: k_big_trsm
+// only needs the 32 x 32 diagonal inverses X_ii that k_big_diag leaves in `invl`).  The blocked solves read X.
+// Off-diagonal blocks X_ij = -X_ii * (sum_{p=j}^{i-1} L_ip X_pj) by block distance, 32 x 32 MFMA products.
+__global__ __launch_bounds__(256) void k_big_invert(DevPlan P, const int* __restrict__ list, int NB) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const int s = list[blockIdx.y];
+  const int step = blockIdx.x;
+  const int col0 = P.sn_col0[s];
+  const int k = P.sn_col0[s + 1] - col0;
+  const int f = (int)(P.row_ptr[s + 1] - P.row_ptr[s]);
+  const int j0 = step * NB;
+  if (j0 >= k) return;
+  const int nb = min(NB, k - j0);
+  const int ldb = NB + 2;
+  double* B = sm;
+  double* T = sm + (size_t)ldb * NB;   // 3 scratch blocks, leading dimension kTld
+  const double* F = P.arena + P.front_pos[s];
   const int nblk = (nb + kIB - 1) / kIB;
   double* X = P.invl + P.invl_pos[s] + (size_t)step * NB * NB;
   {
-    // 4 x (32 x 32): thread = (block b, column cc, half h) moves 16 rows; 16 loads in flight each
     const int b = tid >> 6, cc = (tid >> 1) & 31, h = tid & 1;
     if (b < nblk) {
-      const size_t o = (size_t)(b * kIB + h * 16) + (size_t)(b * kIB + cc);
       double v[16];
 #pragma unroll
       for (int q = 0; q < 16; ++q) v[q] = X[(b * kIB + h * 16 + q) + (size_t)(b * kIB + cc) * NB];
 #pragma unroll
       for (int q = 0; q < 16; ++q) B[(b * kIB + h * 16 + q) + (size_t)(b * kIB + cc) * ldb] = v[q];
-      (void)o;
     }
   }
   __syncthreads();
-  if (dbg_stop == 4) return;
-  // off-diagonal blocks X_ij = -X_ii * (sum_{p=j}^{i-1} L_ip X_pj), by block distance d = i - j;
-  // every 32 x 32 product is 2 x 2 MFMA tiles, the tiles of a round are spread over the waves
-  double* T = Wb;  // up to 3 scratch blocks of 32 x 32
   for (int d = 1; d < nblk; ++d) {
     const int npairs = nblk - d;
     for (int t = wave; t < npairs * 4; t += 4) {
@@ -429,9 +441,6 @@ __global__ __launch_bounds__(256) void k_big_diag(DevPlan P, const int* __restri
       const int rr0 = (sub & 1) * 16, cc0 = (sub >> 1) * 16;
       d4_t acc = (d4_t){0.0, 0.0, 0.0, 0.0};
       const int lrow = ro + rr0 + l15;
-      // L comes from the front in HBM/L2 (written above): the LDS copy of a block (bi, bp) is replaced by X
-      // as soon as its distance bi - bp has been processed.  All (up to 24) operand loads are issued up
-      // front, unconditionally on clamped addresses, and masked afterwards: one memory round trip per tile.
       double avv[24];
       const int lrc = min(lrow, nb - 1);
 #pragma unroll
@@ -443,12 +452,12 @@ __global__ __launch_bounds__(256) void k_big_diag(DevPlan P, const int* __restri
       for (int q = 0; q < 24; ++q) {
         const int p0 = co + 4 * q;
         if (p0 < ro) {
-          const double bv = B[(p0 + l4) + (size_t)(co + cc0 + l15) * ldb];          // X[p][co+cc]
+          const double bv = B[(p0 + l4) + (size_t)(co + cc0 + l15) * ldb];
           acc = __builtin_amdgcn_mfma_f64_16x16x4f64(avv[q], bv, acc, 0, 0, 0);
         }
       }
 #pragma unroll
-      for (int reg = 0; reg < 4; ++reg)   // D[i = rr][j = cc]
+      for (int reg = 0; reg < 4; ++reg)
         T[bj * kTld * kIB + (rr0 + l4 + 4 * reg) + (cc0 + l15) * kTld] = acc[reg];
     }
     __syncthreads();
@@ -459,8 +468,8 @@ __global__ __launch_bounds__(256) void k_big_diag(DevPlan P, const int* __restri
       d4_t acc = (d4_t){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
       for (int p0 = 0; p0 < kIB; p0 += 4) {
-        const double av = B[(ro + rr0 + l15) + (size_t)(ro + p0 + l4) * ldb];     // X_ii[rr][p]
-        const double bv = T[bj * kTld * kIB + (p0 + l4) + (cc0 + l15) * kTld];    // T[p][cc]
+        const double av = B[(ro + rr0 + l15) + (size_t)(ro + p0 + l4) * ldb];
+        const double bv = T[bj * kTld * kIB + (p0 + l4) + (cc0 + l15) * kTld];
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
       }
 #pragma unroll
@@ -469,8 +478,6 @@ __global__ __launch_bounds__(256) void k_big_diag(DevPlan P, const int* __restri
     }
     __syncthreads();
   }
-  if (dbg_stop == 5) return;
-  // strictly-lower blocks of X go out; the diagonal blocks are already there, the blocks above stay zero
   for (int c = wave; c < NB; c += 4) {
     const int bc = c / kIB;
 #pragma unroll
@@ -481,9 +488,18 @@ __global__ __launch_bounds__(256) void k_big_diag(DevPlan P, const int* __restri
   }
 }
 
-// W = A21 * inv(L11)^T (MFMA), L21 = W * D^-1.  64 rows per workgroup; wave w owns panel columns
-// [32w, 32w + 32).  Computed transposed (D[c][r]) so that global accesses run along front rows.
-__global__ __launch_bounds__(256) void k_big_trsm(DevPlan P, const int* __restrict__ list, int step, int NB, int wcol0) {
+// Rows below the diagonal block: W = A21 * L11^-T by blocked forward substitution over the four 32-column
+// blocks, W_i = (A_i - sum_{p<i} W_p L_ip^T) X_ii^T, with only the 32 x 32 inverses X_ii (k_big_diag) -- the full
+// 128 x 128 inverse is not needed on the critical path.  One wave owns 16 front rows and all 128 columns, so
+// there is no cross-wave dependency.  FP64 MFMA 4x4x4: an accumulator register holds a 4-column x 16-row strip
+// (lane <-> column l>>4, row l&15) and is, unchanged, the B operand of the k-step over those 4 columns: W_p
+// feeds the later products straight from registers.  L blocks and X_ii are staged once per workgroup in LDS
+// and read as broadcast A operands.  L21 = W * D^-1.
+template <int NBLK>
+__global__ __launch_bounds__(256) void k_big_trsm(DevPlan P, const int* __restrict__ list, int step, int wcol0) {
+  constexpr int NB = NBLK * kIB;
+  constexpr int NPAIR = NBLK * (NBLK + 1) / 2;
+  extern __shared__ __attribute__((aligned(16))) double sm[];   // NPAIR blocks of 32 x 32, then NB reciprocals
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int s = list[blockIdx.y];
   const int col0 = P.sn_col0[s];
@@ -497,54 +513,71 @@ __global__ __launch_bounds__(256) void k_big_trsm(DevPlan P, const int* __restri
   double* F = P.arena + P.front_pos[s];
   double* Wb = P.wbuf + P.wbuf_pos[s] + (size_t)wcol0 * f;   // this panel's slot inside the super-step's W
   const double* X = P.invl + P.invl_pos[s] + (size_t)step * NB * NB;
-  const int l15 = lane & 15, l4 = lane >> 4;
-  const int cs = wv * 32;  // column slice of this wave
-  d4_t acc[2][4];
+  double* rdv = sm + NPAIR * kIB * kIB;
+  // stage block (bi, bp), bp <= bi, at index bi(bi+1)/2 + bp: L_{bi,bp} below the diagonal, X_ii on it
+  {
+    const int e = tid * 4;                 // 4 consecutive rows of one column per thread and block
+    const int cc = e / kIB, rr = e - cc * kIB;
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+    for (int bi = 0; bi < NBLK; ++bi)
 #pragma unroll
-    for (int b = 0; b < 4; ++b) acc[a][b] = (d4_t){0.0, 0.0, 0.0, 0.0};
-  if (cs < nb) {
-    const int pend = min(nb, cs + 32);  // inv(L11)[c][p] = 0 for p > c
-    for (int p0 = 0; p0 < pend; p0 += 4) {
-      const int p = p0 + l4;
-      const bool pv = p < nb;
-      const int pc = pv ? p : 0;   // clamped: loads stay unconditional, the select follows
-      double av[2], bv[4];
+      for (int bp = 0; bp <= bi; ++bp) {
+        double v[4];
+        const int gr = bi * kIB + rr, gc = bp * kIB + cc;
 #pragma unroll
-      for (int a = 0; a < 2; ++a) {
-        av[a] = keep_f64(X[(cs + a * 16 + l15) + (size_t)pc * NB], pv);
-      }
-#pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        const int r = r0 + b * 16 + l15;
-        bv[b] = keep_f64(F[(size_t)(j0 + pc) * f + min(r, f - 1)], pv && r < f);
-      }
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a], bv[b], acc[a][b], 0, 0, 0);
-    }
-  }
-  __syncthreads();  // every wave has finished reading the panel rows before anyone overwrites them
-  if (cs < nb) {
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        const int c = cs + a * 16 + l4 + 4 * reg;
-        if (c >= nb) continue;
-        const double rd = 1.0 / P.dvals[col0 + j0 + c];
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-          const int r = r0 + b * 16 + l15;
-          if (r < f) {
-            const double wv_ = acc[a][b][reg];
-            Wb[(size_t)c * f + r] = wv_;
-            F[(size_t)(j0 + c) * f + r] = wv_ * rd;
-          }
+        for (int u = 0; u < 4; ++u) {
+          const double* src = bp == bi ? X + (gr + u) + (size_t)gc * NB
+                                       : F + (size_t)(j0 + min(gc, nb - 1)) * f + j0 + min(gr + u, nb - 1);
+          v[u] = keep_f64(*src, gr + u < nb && gc < nb);
         }
+        double* dst = sm + (bi * (bi + 1) / 2 + bp) * kIB * kIB + e;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) dst[u] = v[u];
       }
+    if (tid < NB) rdv[tid] = tid < nb ? 1.0 / P.dvals[col0 + j0 + tid] : 0.0;
+  }
+  __syncthreads();
+  const int row = r0 + wv * 16 + (lane & 15);
+  const int rowc = min(row, f - 1);
+  const int lk = lane >> 4, li = lane & 3;
+  double t[NBLK * 8];
+#pragma unroll
+  for (int q = 0; q < NBLK * 8; ++q) {
+    const int c = 4 * q + lk;
+    t[q] = keep_f64(F[(size_t)(j0 + min(c, nb - 1)) * f + rowc], c < nb && row < f);
+  }
+#pragma unroll
+  for (int bi = 0; bi < NBLK; ++bi) {
+#pragma unroll
+    for (int bp = 0; bp < bi; ++bp) {
+      const double* Lb = sm + (bi * (bi + 1) / 2 + bp) * kIB * kIB;
+#pragma unroll
+      for (int gp = 0; gp < 8; ++gp)
+#pragma unroll
+        for (int g = 0; g < 8; ++g)
+          t[bi * 8 + gp] = __builtin_amdgcn_mfma_f64_4x4x4f64(Lb[(gp * 4 + li) + (g * 4 + lk) * kIB], t[bp * 8 + g], t[bi * 8 + gp], 0, 0, 1 /* neg A */);
+    }
+    const double* Xb = sm + (bi * (bi + 1) / 2 + bi) * kIB * kIB;
+    double wt[8];
+#pragma unroll
+    for (int gp = 0; gp < 8; ++gp) {
+      wt[gp] = 0.0;
+#pragma unroll
+      for (int g = 0; g <= gp; ++g)   // X_ii is lower triangular
+        wt[gp] = __builtin_amdgcn_mfma_f64_4x4x4f64(Xb[(gp * 4 + li) + (g * 4 + lk) * kIB], t[bi * 8 + g], wt[gp], 0, 0, 0);
+    }
+#pragma unroll
+    for (int gp = 0; gp < 8; ++gp) t[bi * 8 + gp] = wt[gp];
+  }
+  if (row < f) {
+#pragma unroll
+    for (int q = 0; q < NBLK * 8; ++q) {
+      const int c = 4 * q + lk;
+      if (c < nb) {
+        Wb[(size_t)c * f + row] = t[q];
+        F[(size_t)(j0 + c) * f + row] = t[q] * rdv[c];
+      }
+    }
   }
 }
 
@@ -1140,6 +1173,9 @@ std::string numeric_setup(const Symbolic& S, const SymbolicOptions& opts, hipStr
   const int big_lds = 160 * 1024;
   OKKT_HIP_TRY(hipFuncSetAttribute((const void*)k_front_small<256>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds));
   OKKT_HIP_TRY(hipFuncSetAttribute((const void*)k_big_diag, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds));
+  OKKT_HIP_TRY(hipFuncSetAttribute((const void*)k_big_invert, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds));
+  OKKT_HIP_TRY(hipFuncSetAttribute((const void*)k_big_trsm<3>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds));
+  OKKT_HIP_TRY(hipFuncSetAttribute((const void*)k_big_trsm<4>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds));
   for (const void* fn : {(const void*)k_big_syrk<0, 3>, (const void*)k_big_syrk<1, 3>, (const void*)k_big_syrk<2, 3>,
                          (const void*)k_big_syrk<4, 3>, (const void*)k_big_syrk<13, 3>})
     OKKT_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)syrk_lds_bytes(3)));
@@ -1237,10 +1273,25 @@ std::string numeric_factor_enqueue(Numeric& N, const double* d_vals, double tol,
           if (i > 0) { std::string e = launch_syrk(stepA, i, step, 1); if (!e.empty()) return e; }   // bring this panel up to date
           hipLaunchKernelGGL(k_big_diag, dim3(g.cnt), dim3(256), lds_diag, st, P, list, step, NB, tol, dbg_stop);
           const int rem = g.maxf - step * NB;  // upper bound on rows below the diagonal block
-          if (rem > 0) hipLaunchKernelGGL(k_big_trsm, dim3((rem + 63) / 64, g.cnt), dim3(256), 0, st, P, list, step, NB, i * NB);
+          if (rem > 0) {
+            const dim3 gr((rem + 63) / 64, g.cnt);
+            const int nbl = NB / kIB;
+            const size_t lds_trsm = ((size_t)nbl * (nbl + 1) / 2 * kIB * kIB + NB) * sizeof(double);
+            switch (nbl) {
+              case 1: hipLaunchKernelGGL(k_big_trsm<1>, gr, dim3(256), lds_trsm, st, P, list, step, i * NB); break;
+              case 2: hipLaunchKernelGGL(k_big_trsm<2>, gr, dim3(256), lds_trsm, st, P, list, step, i * NB); break;
+              case 3: hipLaunchKernelGGL(k_big_trsm<3>, gr, dim3(256), lds_trsm, st, P, list, step, i * NB); break;
+              default: hipLaunchKernelGGL(k_big_trsm<4>, gr, dim3(256), lds_trsm, st, P, list, step, i * NB); break;
+            }
+          }
         }
         std::string e = launch_syrk(stepA, GS, stepA + GS, 0);
         if (!e.empty()) return e;
+      }
+      // full inverses of the diagonal blocks (for the solves), all blocks of the level in one launch
+      {
+        const size_t lds_inv = ((size_t)(NB + 2) * NB + 3 * kTld * kIB) * sizeof(double);
+        hipLaunchKernelGGL(k_big_invert, dim3(nsteps, g.cnt), dim3(256), lds_inv, st, P, list, NB);
       }
     }
   }
