@@ -252,10 +252,17 @@ __device__ __forceinline__ void diag32_wave(double* B, int ldb, int off, int w) 
     const double dj = readlane_f64(a[j], j);
     const double wj = a[j];
     const double l = wj * fast_rcp_f64(dj);
+    // broadcasts in batches of 8 into distinct SGPR pairs, then the 8 FMAs: one SGPR-hazard wait per batch
 #pragma unroll
-    for (int c = j + 1; c < 32; ++c) {
-      const double wc = readlane_f64(wj, c);
-      if (lane >= c) a[c] -= l * wc;
+    for (int c0 = j + 1; c0 < 32; c0 += 8) {
+      double wc[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) wc[q] = (c0 + q < 32) ? readlane_f64(wj, (c0 + q) & 31) : 0.0;
+      // no predicate: an update of a[c] on a lane < c only touches the unused upper triangle of that row
+      // (it is never read back: lane c broadcasts a[j] only for j < c, the write-back stores c <= lane)
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+        if (c0 + q < 32) a[c0 + q] = __builtin_fma(-l, wc[q], a[c0 + q]);
     }
     if (lane > j) a[j] = l;
   }
@@ -328,9 +335,13 @@ __global__ __launch_bounds__(256) void k_big_diag(DevPlan P, const int* __restri
 #pragma unroll
       for (int p = 0; p < kIB - 1; ++p) {
 #pragma unroll
-        for (int c = 0; c <= p; ++c) {
-          const double xp = readlane_f64(x[c], p);
-          x[c] -= lr[p] * xp;     // lr[p] = 0 on lanes <= p
+        for (int c0 = 0; c0 <= p; c0 += 8) {
+          double xp[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) xp[q] = (c0 + q <= p) ? readlane_f64(x[(c0 + q) & 31], p) : 0.0;
+#pragma unroll
+          for (int q = 0; q < 8; ++q)
+            if (c0 + q <= p) x[c0 + q] = __builtin_fma(-lr[p], xp[q], x[c0 + q]);     // lr[p] = 0 on lanes <= p
         }
       }
       double* Xg = P.invl + P.invl_pos[s] + (size_t)step * NB * NB;
