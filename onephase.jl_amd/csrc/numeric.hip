@@ -612,13 +612,17 @@ constexpr int kSyrkLd = 144;
 constexpr size_t syrk_lds_bytes(int stages) { return (size_t)stages * 2 * kSyrkKC * kSyrkLd * sizeof(double); }
 typedef __attribute__((address_space(3))) void lds_void_t;
 
-template <int DBG, int STAGES>
-__global__ __launch_bounds__(256, STAGES == 2 ? 2 : 1) void k_big_syrk(DevPlan P, const int* __restrict__ list, int stepA, int npan,
+template <int DBG, int STAGES, int NW>
+__global__ __launch_bounds__(NW * 64, STAGES == 2 ? NW / 2 : 1) void k_big_syrk(DevPlan P, const int* __restrict__ list, int stepA, int npan,
                                                                        int tstep, int head, int NB) {
   // Applies the panels [stepA, stepA + npan) (K = up to npan * NB columns, W panels side by side in wbuf)
   // to the region that starts at block column tstep.  head = 0: the whole trailing lower triangle
   // (super-step update, K = GS * NB halves the C traffic per flop for GS = 2); head = 1: only the next
   // panel's own columns [t0, min(t0 + NB, k)) -- what that panel needs before it can be factored.
+  // NW = 4: 2 x 2 waves of 64 x 64; NW = 8: 2 x 4 waves of 64 rows x 32 columns (four waves per SIMD with two
+  // workgroups per CU: a wave's C-tile load/store hides behind three other waves' MFMAs)
+  constexpr int WCW = 128 / (NW / 2);   // columns per wave
+  constexpr int NCG = WCW / 4;          // 4-column groups per wave
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int s = list[blockIdx.y];
@@ -647,7 +651,7 @@ __global__ __launch_bounds__(256, STAGES == 2 ? 2 : 1) void k_big_syrk(DevPlan P
   }
   const int rt0 = t0 + ti * 128, ct0 = t0 + tj * 128;   // tile origin
   const int rbase = rt0 + (wv & 1) * 64;
-  const int cbase = ct0 + (wv >> 1) * 64;
+  const int cbase = ct0 + (wv >> 1) * WCW;
   const bool active = !(rbase + 63 < cbase) && rbase < f && cbase < climit;
   double* F = P.arena + P.front_pos[s];
   const double* Wg = P.wbuf + P.wbuf_pos[s] + rt0 + lane * 2;
@@ -659,8 +663,8 @@ __global__ __launch_bounds__(256, STAGES == 2 ? 2 : 1) void k_big_syrk(DevPlan P
   auto issue = [&](int ch) {
     double* slot = sm + (size_t)(ch % STAGES) * 2 * kSyrkKC * kSyrkLd;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int prow = q * 4 + wv;
+    for (int q = 0; q < kSyrkKC / NW; ++q) {
+      const int prow = q * NW + wv;
       const int p = ch * kSyrkKC + prow;
       // rows past the panel read a zero page instead (same instruction count on every path)
       const double* wsrc = p < nb ? Wg + (size_t)p * f : P.zero_page + lane * 2;
@@ -670,7 +674,7 @@ __global__ __launch_bounds__(256, STAGES == 2 ? 2 : 1) void k_big_syrk(DevPlan P
     }
   };
 
-  double acc[16][4];  // [column group of 4][row block of 16]
+  double acc[NCG][4];  // [column group of 4][row block of 16]
   // accumulators start from C (guarded; lanes outside the front or above the diagonal hold zeros)
   // Loads are unconditional on clamped (always valid) addresses and selected afterwards: a load under
   // a per-element branch makes hipcc wait vmcnt(0) per element, i.e. 64 serial memory round trips.
@@ -678,7 +682,7 @@ __global__ __launch_bounds__(256, STAGES == 2 ? 2 : 1) void k_big_syrk(DevPlan P
   // that a lane's (rb, rb+1) pair is 16 contiguous bytes of C: 16-byte loads/stores, 256-byte segments.
   typedef double d2_t __attribute__((ext_vector_type(2)));
 #pragma unroll
-  for (int cg = 0; cg < 16; ++cg) {
+  for (int cg = 0; cg < NCG; ++cg) {
     const int c = cbase + cg * 4 + l4;
     const double* colp = F + (size_t)min(c, f - 1) * f;
 #pragma unroll
@@ -700,7 +704,7 @@ __global__ __launch_bounds__(256, STAGES == 2 ? 2 : 1) void k_big_syrk(DevPlan P
   for (int ch = 0; ch < nchunk; ++ch) {
     // STAGES == 3: chunk ch has landed once at most the 8 LDS-DMAs of chunk ch+1 are still outstanding;
     // STAGES == 2: only chunk ch is in flight here
-    if (STAGES == 3 && ch + 1 < nchunk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    if (STAGES == 3 && ch + 1 < nchunk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // STAGES == 3 only with NW == 4
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     // the slot written next was last read STAGES - 1 iterations ago; everyone is past that barrier
@@ -708,22 +712,22 @@ __global__ __launch_bounds__(256, STAGES == 2 ? 2 : 1) void k_big_syrk(DevPlan P
     if (active && !(DBG & 2)) {
       const double* slot = sm + (size_t)(ch % STAGES) * 2 * kSyrkKC * kSyrkLd;
       const double* bw = slot + (wv & 1) * 64 + 2 * l15;
-      const double* bl = slot + kSyrkKC * kSyrkLd + (wv >> 1) * 64 + (lane & 3);
+      const double* bl = slot + kSyrkKC * kSyrkLd + (wv >> 1) * WCW + (lane & 3);
       if constexpr (STAGES == 3) {
         // one wave per SIMD: nobody else hides the LDS latency, so all 80 operand fragments of the
         // chunk are fetched up front and the latency is paid once per chunk
-        double bvv[kSyrkKC / 4][4], avv[kSyrkKC / 4][16];
+        double bvv[kSyrkKC / 4][4], avv[kSyrkKC / 4][NCG];
 #pragma unroll
         for (int kk = 0; kk < kSyrkKC / 4; ++kk) {
 #pragma unroll
           for (int rb = 0; rb < 4; ++rb) bvv[kk][rb] = bw[(kk * 4 + l4) * kSyrkLd + (rb & 1) + 32 * (rb >> 1)];
 #pragma unroll
-          for (int cg = 0; cg < 16; ++cg) avv[kk][cg] = bl[(kk * 4 + l4) * kSyrkLd + cg * 4];
+          for (int cg = 0; cg < NCG; ++cg) avv[kk][cg] = bl[(kk * 4 + l4) * kSyrkLd + cg * 4];
         }
 #pragma unroll
         for (int kk = 0; kk < kSyrkKC / 4; ++kk)
 #pragma unroll
-          for (int cg = 0; cg < 16; ++cg)
+          for (int cg = 0; cg < NCG; ++cg)
 #pragma unroll
             for (int rb = 0; rb < 4; ++rb)
               acc[cg][rb] = __builtin_amdgcn_mfma_f64_4x4x4f64(avv[kk][cg], bvv[kk][rb], acc[cg][rb], 0, 0, 1 /* neg A */);
@@ -735,7 +739,7 @@ __global__ __launch_bounds__(256, STAGES == 2 ? 2 : 1) void k_big_syrk(DevPlan P
 #pragma unroll
           for (int rb = 0; rb < 4; ++rb) bv[rb] = bw[(kk * 4 + l4) * kSyrkLd + (rb & 1) + 32 * (rb >> 1)];
 #pragma unroll
-          for (int half = 0; half < 4; ++half) {
+          for (int half = 0; half < NCG / 4; ++half) {
             double av[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) av[q] = bl[(kk * 4 + l4) * kSyrkLd + (half * 4 + q) * 4];
@@ -752,7 +756,7 @@ __global__ __launch_bounds__(256, STAGES == 2 ? 2 : 1) void k_big_syrk(DevPlan P
   if (!active) return;
   if constexpr (DBG & 4) { double t = 0; for (int a = 0; a < 16; ++a) for (int b = 0; b < 4; ++b) t += acc[a][b]; if (t == 1.2345e-300) F[0] = t; return; }
 #pragma unroll
-  for (int cg = 0; cg < 16; ++cg) {
+  for (int cg = 0; cg < NCG; ++cg) {
     const int c = cbase + cg * 4 + l4;
     if (c >= climit) continue;
     double* colp = F + (size_t)c * f;
@@ -1187,11 +1191,12 @@ std::string numeric_setup(const Symbolic& S, const SymbolicOptions& opts, hipStr
   OKKT_HIP_TRY(hipFuncSetAttribute((const void*)k_big_invert, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds));
   OKKT_HIP_TRY(hipFuncSetAttribute((const void*)k_big_trsm<3>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds));
   OKKT_HIP_TRY(hipFuncSetAttribute((const void*)k_big_trsm<4>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds));
-  for (const void* fn : {(const void*)k_big_syrk<0, 3>, (const void*)k_big_syrk<1, 3>, (const void*)k_big_syrk<2, 3>,
-                         (const void*)k_big_syrk<4, 3>, (const void*)k_big_syrk<13, 3>})
+  for (const void* fn : {(const void*)k_big_syrk<0, 3, 4>, (const void*)k_big_syrk<1, 3, 4>, (const void*)k_big_syrk<2, 3, 4>,
+                         (const void*)k_big_syrk<4, 3, 4>, (const void*)k_big_syrk<13, 3, 4>})
     OKKT_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)syrk_lds_bytes(3)));
-  for (const void* fn : {(const void*)k_big_syrk<0, 2>, (const void*)k_big_syrk<1, 2>, (const void*)k_big_syrk<2, 2>,
-                         (const void*)k_big_syrk<13, 2>})
+  for (const void* fn : {(const void*)k_big_syrk<0, 2, 4>, (const void*)k_big_syrk<1, 2, 4>, (const void*)k_big_syrk<2, 2, 4>,
+                         (const void*)k_big_syrk<13, 2, 4>, (const void*)k_big_syrk<0, 2, 8>, (const void*)k_big_syrk<1, 2, 8>,
+                         (const void*)k_big_syrk<2, 2, 8>, (const void*)k_big_syrk<13, 2, 8>})
     OKKT_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)syrk_lds_bytes(2)));
   return "";
 }
@@ -1262,7 +1267,8 @@ std::string numeric_factor_enqueue(Numeric& N, const double* d_vals, double tol,
           N.prof_flops.push_back(fl);
           OKKT_HIP_TRY(hipEventRecord(N.prof_events[N.prof_used++], st));
         }
-#define OKKT_SYRK(D, S) hipLaunchKernelGGL((k_big_syrk<D, S>), grid, dim3(256), syrk_lds_bytes(S), st, P, list, stepA, npan, tstep, head, NB)
+#define OKKT_SYRK(D, S) hipLaunchKernelGGL((k_big_syrk<D, S, 4>), grid, dim3(256), syrk_lds_bytes(S), st, P, list, stepA, npan, tstep, head, NB)
+#define OKKT_SYRK8(D) hipLaunchKernelGGL((k_big_syrk<D, 2, 8>), grid, dim3(512), syrk_lds_bytes(2), st, P, list, stepA, npan, tstep, head, NB)
         switch (dbg_syrk) {   // timing-only ablations (OKKT_DEBUG_SYRK): outputs are wrong for codes < 100
           case 1: OKKT_SYRK(1, 3); break;
           case 2: OKKT_SYRK(2, 3); break;
@@ -1272,9 +1278,14 @@ std::string numeric_factor_enqueue(Numeric& N, const double* d_vals, double tol,
           case 22: OKKT_SYRK(2, 2); break;
           case 33: OKKT_SYRK(13, 2); break;
           case 103: OKKT_SYRK(0, 3); break;   // correct variants
-          default: OKKT_SYRK(0, 2); break;
+          case 104: OKKT_SYRK(0, 2); break;
+          case 81: OKKT_SYRK8(1); break;
+          case 82: OKKT_SYRK8(2); break;
+          case 93: OKKT_SYRK8(13); break;
+          default: OKKT_SYRK8(0); break;   // 8 waves x (64 x 32), two workgroups per CU
         }
 #undef OKKT_SYRK
+#undef OKKT_SYRK8
         if (N.profile) OKKT_HIP_TRY(hipEventRecord(N.prof_events[N.prof_used++], st));
         return "";
       };
