@@ -2,6 +2,7 @@
 // `linear_solver_HIP <: abstract_linear_system_solver` binds in place of linear_solver_JULIA
 // (/root/reference/src/linear_system_solvers/julia.jl).  No exception leaves this file.
 #include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -32,6 +33,8 @@ int solver_ensure_numeric(okkt_solver_s* h) {
   if (h->numeric_ready) return OKKT_OK;
   h->N.part_id = h->part_id;
   std::string e = numeric_setup(h->S, h->sopts, h->stream, h->N);
+  h->N.stream_panel = h->stream_panel;
+  if (const char* mt = getenv("OKKT_LA_MIN_TILES")) h->N.la_min_tiles = atoi(mt);
   if (!e.empty()) { numeric_release(h->N); return solver_set_error(h, OKKT_ERR_HIP, e); }
   h->numeric_ready = true;
   return OKKT_OK;
@@ -147,7 +150,31 @@ int okkt_create(okkt_handle* out, const okkt_opts* opts) {
     if (dev < 0) { if (hipGetDevice(&dev) != hipSuccess) dev = 0; }
     if (dev >= count || hipSetDevice(dev) != hipSuccess) { delete h; return OKKT_ERR_NO_DEVICE; }
     h->device = dev;
-    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return OKKT_ERR_HIP; }
+    // Look-ahead needs a CU that the trailing update never occupies (k_big_diag wants a whole CU's LDS): the main
+    // stream gets a CU mask without the first `reserved` CUs (mask bit b = CU b / 8 of XCD b % 8 on gfx950, probed
+    // with scripts/cumask_probe.hip), the panel stream is unmasked and high priority.
+    const char* ela = getenv("OKKT_LOOKAHEAD");
+    const char* ercu = getenv("OKKT_RESERVED_CUS");
+    const int la = ela ? atoi(ela) : 1;
+    int reserved = ercu ? atoi(ercu) : 8;   // one per XCD: a lone workgroup always lands on XCD 0, several fronts spread
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) { delete h; return OKKT_ERR_HIP; }
+    const int ncu = prop.multiProcessorCount;
+    if (reserved < 1) reserved = 1;
+    if (reserved > ncu / 2) reserved = ncu / 2;
+    if (la) {
+      std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
+      for (int b = reserved; b < ncu; ++b) mask[(size_t)b >> 5] |= 1u << (b & 31);
+      int lo = 0, hi = 0;
+      if (hipExtStreamCreateWithCUMask(&h->stream, (uint32_t)mask.size(), mask.data()) != hipSuccess ||
+          hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess ||
+          hipStreamCreateWithPriority(&h->stream_panel, hipStreamNonBlocking, hi) != hipSuccess) {
+        (void)hipGetLastError();
+        if (h->stream) { (void)hipStreamDestroy(h->stream); h->stream = nullptr; }
+        h->stream_panel = nullptr;
+      }
+    }
+    if (!h->stream && hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return OKKT_ERR_HIP; }
     if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) { delete h; return OKKT_ERR_HIP; }
     h->device_ready = true;
   }
@@ -164,6 +191,7 @@ int okkt_destroy(okkt_handle h) {
     if (h->d_rhs_stage) (void)hipFree(h->d_rhs_stage);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->stream_panel) (void)hipStreamDestroy(h->stream_panel);
     if (h->stream) (void)hipStreamDestroy(h->stream);
   }
   delete h;

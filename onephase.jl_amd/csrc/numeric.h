@@ -72,6 +72,12 @@ struct Numeric {
   int small_max = 128;
   int64_t n_small = 0, n_big = 0;
   hipStream_t stream = nullptr;
+  // look-ahead: panels of the next super-step are factored on stream_panel while the trailing update runs
+  hipStream_t stream_panel = nullptr;
+  int lookahead = 1;
+  int la_min_tiles = 256;                // rest triangle must hold at least this many 128 x 128 tiles
+  std::vector<hipEvent_t> la_events;
+  size_t la_used = 0;
   double* vals_owned = nullptr;  // staging buffer for host-side nzval
   int64_t nnz_in = 0;
   // optional per-launch timing of the dominant kernel (k_big_syrk) with HIP events on N.stream

@@ -277,7 +277,7 @@ constexpr int kTld = 33; // leading dimension of the 32 x 32 scratch blocks (odd
 // NB x NB diagonal block of block-column `step`: LDL^T in LDS (inner width 32: register/readlane
 // 32 x 32 kernel on one wave, row-parallel solve below it, MFMA rank-32 update), D and inertia out,
 // then X = inv(L11) block by block (MFMA products) for the row-parallel k_big_trsm and the solves.
-__global__ __launch_bounds__(256) void k_big_diag(DevPlan P, const int* __restrict__ list, int step, int NB, double tol, int dbg_stop) {
+__global__ __launch_bounds__(256) void k_big_diag_v1(DevPlan P, const int* __restrict__ list, int step, int NB, double tol, int dbg_stop) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, l4 = lane >> 4;
@@ -409,6 +409,189 @@ __global__ __launch_bounds__(256) void k_big_diag(DevPlan P, const int* __restri
   }
   flush_counts(P.counters, pos, neg, zer, bad);
   __syncthreads();
+}
+
+// k_big_diag (v2): LDL^T of the NB x NB diagonal block held in MFMA ACCUMULATORS.
+//   The block is viewed as 8 x 8 tiles of 16 x 16 (identity-padded past nb); the 36 lower tiles are dealt
+//   cyclically to the four waves (9 accumulator quads per lane).  A micro-step factors 8 columns:
+//     (1) the waves that own the tile column copy the 8 columns out of their accumulators into LDS (Praw),
+//     (2) threads 0..127 (one per row) each redo the 8 x 8 diagonal LDL^T in registers (broadcast LDS reads, no
+//         communication: the 8 dependent reciprocals are the irreducible latency) and solve their own row,
+//         write the final L entries to HBM (and the 32 x 32 diagonal blocks to LDS for the inverse) and the
+//         operand panels -L, W = L D to LDS,
+//     (3) every live tile gets its rank-8 update as two v_mfma_f64_16x16x4 straight into the accumulators.
+//   16 micro-steps x 2 barriers replace the 128 pivot round trips of v1 (about 80 us -> 42 us per block).
+//   Tile entry held by lane (l15, l4), register v of tile (ti, tj):  row 16 ti + l15, column 16 tj + 4 v + l4
+//   (rows on l15: the initial load reads 128-byte row segments of the column-major front).
+//   Entries above the diagonal and columns already factored are dead: the updates may write garbage there.
+//   Finally wave b inverts the unit-lower 32 x 32 diagonal block b: one COLUMN of X per lane, forward
+//   substitution with broadcast LDS reads of L (no cross-lane traffic at all).
+constexpr int kMW = 8;        // micro-panel width
+constexpr int kPLD = 144;     // leading dimension of the LDS panels: 16-lane groups of an MFMA fragment hit disjoint banks
+constexpr int kXld = 33;
+
+__global__ __launch_bounds__(256) void k_big_diag(DevPlan P, const int* __restrict__ list, int step, int NB, double tol, int dbg_stop) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const int s = list[blockIdx.x];
+  const int col0 = P.sn_col0[s];
+  const int k = P.sn_col0[s + 1] - col0;
+  const int f = (int)(P.row_ptr[s + 1] - P.row_ptr[s]);
+  const int j0 = step * NB;
+  if (j0 >= k) return;
+  const int nb = min(NB, k - j0);
+  double* Praw = sm;                         // 8 x kPLD: raw micro-panel (columns as rows of the array)
+  double* Lp = Praw + kMW * kPLD;            // -L of the micro-panel
+  double* Wp = Lp + kMW * kPLD;              // W = L * D
+  double* Ld = Wp + kMW * kPLD;              // 4 diagonal 32 x 32 blocks of L, leading dimension 33
+  double* Xs = Ld + 4 * 32 * kXld;           // their inverses
+  double* F = P.arena + P.front_pos[s];
+
+  // tiles of this wave: t = 4 s + wave in column-major order of the lower triangle of the 8 x 8 tile grid
+  int ti_s[9], tj_s[9];
+#pragma unroll
+  for (int q = 0; q < 9; ++q) {
+    const int t = 4 * q + wave;
+    const int tj = (t >= 8) + (t >= 15) + (t >= 21) + (t >= 26) + (t >= 30) + (t >= 33) + (t >= 35);
+    const int start = tj * 8 - tj * (tj - 1) / 2;
+    tj_s[q] = tj;
+    ti_s[q] = tj + (t - start);
+  }
+  d4_t acc[9];
+  {
+    // all loads first (clamped addresses, no branches), then the selects
+    double raw[9][4];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+      const int r = 16 * ti_s[q] + l15;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int c = 16 * tj_s[q] + 4 * v + l4;
+        raw[q][v] = F[(size_t)(j0 + min(c, nb - 1)) * f + j0 + min(r, nb - 1)];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+      const int r = 16 * ti_s[q] + l15;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int c = 16 * tj_s[q] + 4 * v + l4;
+        const double pad = r == c ? 1.0 : 0.0;
+        acc[q][v] = (r < nb && c < nb && r >= c) ? raw[q][v] : pad;
+      }
+    }
+  }
+  if (dbg_stop == 1) return;
+  unsigned pos = 0, neg = 0, zer = 0, bad = 0;
+  const int npair = (nb + 15) >> 4;
+  for (int pp = 0; pp < npair; ++pp) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int p8 = pp * 16 + h * 8;        // first column of the micro-panel
+      if (p8 >= nb) continue;                // uniform
+      // (1) copy columns [p8, p8 + 8) out of the accumulators
+#pragma unroll
+      for (int q = 0; q < 9; ++q)
+        if (tj_s[q] == pp) {
+          const int r = 16 * ti_s[q] + l15;
+          Praw[l4 * kPLD + r] = acc[q][2 * h];
+          Praw[(4 + l4) * kPLD + r] = acc[q][2 * h + 1];
+        }
+      __syncthreads();
+      // (2) one thread per row
+      if (tid < 128 && tid >= p8) {
+        const int r = tid;
+        double A[kMW][kMW], a[kMW], rd[kMW], w[kMW], lr[kMW];
+#pragma unroll
+        for (int c = 0; c < kMW; ++c) {
+          a[c] = Praw[c * kPLD + r];
+#pragma unroll
+          for (int i = c; i < kMW; ++i) A[i][c] = Praw[c * kPLD + p8 + i];
+        }
+#pragma unroll
+        for (int c = 0; c < kMW; ++c) {
+          rd[c] = fast_rcp_f64(A[c][c]);
+          w[c] = a[c];
+          lr[c] = w[c] * rd[c];
+#pragma unroll
+          for (int i = c + 1; i < kMW; ++i) {
+            const double lic = A[i][c] * rd[c];
+#pragma unroll
+            for (int j = c + 1; j <= i; ++j) A[i][j] = __builtin_fma(-lic, A[j][c], A[i][j]);
+          }
+#pragma unroll
+          for (int j = c + 1; j < kMW; ++j) a[j] = __builtin_fma(-lr[c], A[j][c], a[j]);
+        }
+        const int i = r - p8;                // >= 0; < 8: a row of the diagonal block
+        double* Fr = F + (size_t)(j0 + p8) * f + j0 + r;
+#pragma unroll
+        for (int c = 0; c < kMW; ++c) {
+          Lp[c * kPLD + r] = -lr[c];
+          Wp[c * kPLD + r] = w[c];
+          // final entry (r, p8 + c): L below the diagonal, D on it, nothing above
+          const double val = i == c ? w[c] : lr[c];
+          if (i >= c && r < nb && p8 + c < nb) {
+            Fr[(size_t)c * f] = val;
+            if ((r >> 5) == ((p8 + c) >> 5)) Ld[(r >> 5) * 32 * kXld + (r & 31) + ((p8 + c) & 31) * kXld] = val;
+          }
+        }
+        if (i < kMW && r < nb) {
+          double d = w[0];
+#pragma unroll
+          for (int c = 1; c < kMW; ++c) d = i == c ? w[c] : d;
+          P.dvals[col0 + j0 + r] = d;
+          classify_pivot(d, tol, pos, neg, zer, bad);
+        }
+      }
+      __syncthreads();
+      // (3) rank-8 update of every tile that still has live columns (to the right of the micro-panel)
+#pragma unroll
+      for (int q = 0; q < 9; ++q)
+        if (tj_s[q] * 16 + 15 >= p8 + kMW) {
+          const int rr = 16 * ti_s[q] + l15, cc = 16 * tj_s[q] + l15;
+          const double a0 = Wp[l4 * kPLD + cc], a1 = Wp[(4 + l4) * kPLD + cc];
+          const double b0 = Lp[l4 * kPLD + rr], b1 = Lp[(4 + l4) * kPLD + rr];
+          acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[q], 0, 0, 0);
+          acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[q], 0, 0, 0);
+        }
+    }
+  }
+  flush_counts(P.counters, pos, neg, zer, bad);
+  __syncthreads();
+  if (dbg_stop == 2) return;
+  // X_bb = inv(L_bb): wave b, one column per lane
+  const int off = wave * 32;
+  if (off < nb) {
+    const int w = min(32, nb - off);
+    const double* Lb = Ld + wave * 32 * kXld;
+    double* Xb = Xs + wave * 32 * kXld;
+    if (lane < 32) {
+      const int c = lane;
+      double x[32];
+#pragma unroll
+      for (int r = 0; r < 32; ++r) {
+        double v = (r == c) ? 1.0 : 0.0;
+        if (r < w) {
+#pragma unroll
+          for (int p = 0; p < r; ++p) v = __builtin_fma(-Lb[r + p * kXld], x[p], v);
+        }
+        x[r] = (r < w && c < w && r >= c) ? v : 0.0;
+      }
+#pragma unroll
+      for (int r = 0; r < 32; ++r) Xb[r + c * kXld] = x[r];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the wave's own LDS writes have landed
+    __builtin_amdgcn_wave_barrier();
+    double* Xg = P.invl + P.invl_pos[s] + (size_t)step * NB * NB;
+    const int r = lane & 31;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int c = (lane >> 5) + 2 * q;
+      Xg[(off + r) + (size_t)(off + c) * NB] = Xb[r + c * kXld];
+    }
+  }
 }
 
 // Deferred full inverse X = inv(L11) of every NB x NB diagonal block of the big fronts of a level (one
@@ -614,11 +797,13 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 
 template <int DBG, int STAGES, int NW>
 __global__ __launch_bounds__(NW * 64, STAGES == 2 ? NW / 2 : 1) void k_big_syrk(DevPlan P, const int* __restrict__ list, int stepA, int npan,
-                                                                       int tstep, int head, int NB) {
+                                                                       int tstep, int head, int NB, int wofs, int csplit) {
   // Applies the panels [stepA, stepA + npan) (K = up to npan * NB columns, W panels side by side in wbuf)
   // to the region that starts at block column tstep.  head = 0: the whole trailing lower triangle
   // (super-step update, K = GS * NB halves the C traffic per flop for GS = 2); head = 1: only the next
   // panel's own columns [t0, min(t0 + NB, k)) -- what that panel needs before it can be factored.
+  // Look-ahead split of the head = 0 update: head = 2 covers only the first `csplit` tile columns of the region
+  // (all the next super-step's panels need), head = 3 the remaining tile columns; wofs = first W column in wbuf.
   // NW = 4: 2 x 2 waves of 64 x 64; NW = 8: 2 x 4 waves of 64 rows x 32 columns (four waves per SIMD with two
   // workgroups per CU: a wave's C-tile load/store hides behind three other waves' MFMAs)
   constexpr int WCW = 128 / (NW / 2);   // columns per wave
@@ -632,29 +817,39 @@ __global__ __launch_bounds__(NW * 64, STAGES == 2 ? NW / 2 : 1) void k_big_syrk(
   const int j0 = stepA * NB;
   if (j0 >= k) return;
   const int nb = min(npan * NB, k - j0);          // K of this update
-  if (head && tstep * NB >= k) return;            // there is no next panel in this front
+  if (head == 1 && tstep * NB >= k) return;       // there is no next panel in this front
   const int t0 = min(tstep * NB, k);
-  const int climit = head ? min(t0 + NB, k) : f;  // columns this launch may write
+  const int climit = head == 1 ? min(t0 + NB, k) : f;  // columns this launch may write
   const int T = (f - t0 + 127) >> 7;
-  const int ntiles = head ? T : T * (T + 1) / 2;
+  const int Tr = max(T - csplit, 0);              // head = 3: triangle that is left after csplit tile columns
+  int ntiles;
+  if (head == 0) ntiles = T * (T + 1) / 2;
+  else if (head == 1) ntiles = T;
+  else if (head == 2) { ntiles = 0; for (int c = 0; c < csplit && c < T; ++c) ntiles += T - c; }
+  else ntiles = Tr * (Tr + 1) / 2;
   const int nx = (int)gridDim.x;
   const int per = (nx + 7) >> 3;
   const int idx = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
   if (idx >= ntiles) return;
   int ti, tj;
-  if (head) { ti = idx; tj = 0; }
-  else {
+  if (head == 1) { ti = idx; tj = 0; }
+  else if (head == 2) {
+    int rest = idx; tj = 0;
+    while (rest >= T - tj) { rest -= T - tj; ++tj; }
+    ti = tj + rest;
+  } else {
     ti = (int)((sqrtf(8.0f * (float)idx + 1.0f) - 1.0f) * 0.5f);
     while ((ti + 1) * (ti + 2) / 2 <= idx) ++ti;
     while (ti * (ti + 1) / 2 > idx) --ti;
     tj = idx - ti * (ti + 1) / 2;
+    if (head == 3) { ti += csplit; tj += csplit; }
   }
   const int rt0 = t0 + ti * 128, ct0 = t0 + tj * 128;   // tile origin
   const int rbase = rt0 + (wv & 1) * 64;
   const int cbase = ct0 + (wv >> 1) * WCW;
   const bool active = !(rbase + 63 < cbase) && rbase < f && cbase < climit;
   double* F = P.arena + P.front_pos[s];
-  const double* Wg = P.wbuf + P.wbuf_pos[s] + rt0 + lane * 2;
+  const double* Wg = P.wbuf + P.wbuf_pos[s] + (size_t)wofs * f + rt0 + lane * 2;
   const double* Lg = F + (size_t)j0 * f + ct0 + lane * 2;
   const int l15 = lane & 15, l4 = lane >> 4;
   const int nchunk = (nb + kSyrkKC - 1) / kSyrkKC;
@@ -754,7 +949,7 @@ __global__ __launch_bounds__(NW * 64, STAGES == 2 ? NW / 2 : 1) void k_big_syrk(
     }
   }
   if (!active) return;
-  if constexpr (DBG & 4) { double t = 0; for (int a = 0; a < 16; ++a) for (int b = 0; b < 4; ++b) t += acc[a][b]; if (t == 1.2345e-300) F[0] = t; return; }
+  if constexpr (DBG & 4) { double t = 0; for (int a = 0; a < NCG; ++a) for (int b = 0; b < 4; ++b) t += acc[a][b]; if (t == 1.2345e-300) F[0] = t; return; }
 #pragma unroll
   for (int cg = 0; cg < NCG; ++cg) {
     const int c = cbase + cg * 4 + l4;
@@ -1108,7 +1303,7 @@ std::string numeric_setup(const Symbolic& S, const SymbolicOptions& opts, hipStr
           g.maxf = std::max(g.maxf, f);
           g.maxk = std::max(g.maxk, k);
           sched.push_back(s);
-          if (c == 3) { wpos[s] = wtotal; wtotal += (int64_t)f * N.nb * N.group; ++N.n_big; } else ++N.n_small;
+          if (c == 3) { wpos[s] = wtotal; wtotal += (int64_t)f * N.nb * N.group * 2; ++N.n_big;   /* two super-steps of W: look-ahead double buffer */ } else ++N.n_small;
         }
       }
     }
@@ -1188,6 +1383,7 @@ std::string numeric_setup(const Symbolic& S, const SymbolicOptions& opts, hipStr
   const int big_lds = 160 * 1024;
   OKKT_HIP_TRY(hipFuncSetAttribute((const void*)k_front_small<256>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds));
   OKKT_HIP_TRY(hipFuncSetAttribute((const void*)k_big_diag, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds));
+  OKKT_HIP_TRY(hipFuncSetAttribute((const void*)k_big_diag_v1, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds));
   OKKT_HIP_TRY(hipFuncSetAttribute((const void*)k_big_invert, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds));
   OKKT_HIP_TRY(hipFuncSetAttribute((const void*)k_big_trsm<3>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds));
   OKKT_HIP_TRY(hipFuncSetAttribute((const void*)k_big_trsm<4>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds));
@@ -1206,6 +1402,9 @@ void numeric_release(Numeric& N) {
   N.prof_events.clear();
   N.prof_used = 0;
   N.prof_flops.clear();
+  for (hipEvent_t ev : N.la_events) (void)hipEventDestroy(ev);
+  N.la_events.clear();
+  N.la_used = 0;
   for (void* p : N.allocations) (void)hipFree(p);
   N.allocations.clear();
   N.levels.clear();
@@ -1219,6 +1418,7 @@ std::string numeric_factor_enqueue(Numeric& N, const double* d_vals, double tol,
   hipStream_t st = N.stream;
   const std::vector<LevelSchedule>& levels = which == 0 ? N.levels : N.levels_top;
   if (reset_counters) OKKT_HIP_TRY(hipMemsetAsync(P.counters, 0, 4 * sizeof(unsigned long long), st));
+  N.la_used = 0;
   const int NB = N.nb;
   static const int dbg_syrk = getenv("OKKT_DEBUG_SYRK") ? atoi(getenv("OKKT_DEBUG_SYRK")) : 0;
   static const int dbg_stop = getenv("OKKT_DEBUG_DIAG_STOP") ? atoi(getenv("OKKT_DEBUG_DIAG_STOP")) : 0;
@@ -1238,16 +1438,28 @@ std::string numeric_factor_enqueue(Numeric& N, const double* d_vals, double tol,
       const int* list = P.sched + g.off;
       hipLaunchKernelGGL(k_big_assemble, dim3((g.maxf + 3) / 4, g.cnt), dim3(256), 0, st, P, list);
       const int nsteps = (g.maxk + NB - 1) / NB;
-      const size_t lds_diag = ((size_t)(NB + 2) * NB + (size_t)std::max(NB - kIB, kIB) * kIB + 3 * kIB + NB) * sizeof(double);
+      const size_t lds_diag_v1 = ((size_t)(NB + 2) * NB + (size_t)std::max(NB - kIB, kIB) * kIB + 3 * kIB + NB) * sizeof(double);
+      const size_t lds_diag = ((size_t)3 * kMW * kPLD + (size_t)2 * 4 * 32 * kXld) * sizeof(double);
+      static const int diag_v1 = getenv("OKKT_DIAG_V1") ? atoi(getenv("OKKT_DIAG_V1")) : 0;
       const int GS = N.group;
-      auto launch_syrk = [&](int stepA, int npan, int tstep, int head) -> std::string {
+      // W of super-step q lives in wbuf columns [(q & 1) * GS * NB, ...): the look-ahead factors the panels of
+      // super-step q + 1 while the trailing update of super-step q still reads its W
+      auto launch_syrk = [&](hipStream_t sst, int stepA, int npan, int tstep, int head) -> std::string {
         // upper bound on the rows of the target region: a front whose pivot block ends inside the group
         // starts its trailing region at k < tstep * NB
-        const int rem = g.maxf - (head ? tstep : stepA) * NB;
+        const int rem = g.maxf - (head == 1 ? tstep : stepA) * NB;
         if (rem <= 0) return "";
         const int T = (rem + 127) / 128;
-        const dim3 grid(((head ? T : T * (T + 1) / 2) + 7) / 8 * 8, g.cnt);
-        if (N.profile) {
+        const int Tr = std::max(T - GS, 0);
+        int ntile = T * (T + 1) / 2;
+        if (head == 1) ntile = T;
+        else if (head == 2) { ntile = 0; for (int c = 0; c < GS && c < T; ++c) ntile += T - c; }
+        else if (head == 3) ntile = Tr * (Tr + 1) / 2;
+        if (ntile == 0) return "";
+        const dim3 grid((ntile + 7) / 8 * 8, g.cnt);
+        const int wofs = ((stepA / GS) & 1) * GS * NB;
+        const bool prof = N.profile;
+        if (prof) {
           // algorithmic flops of this launch: 2 * K * (lower-triangle entries it updates), summed over fronts
           double fl = 0;
           for (int q = 0; q < g.cnt; ++q) {
@@ -1255,20 +1467,24 @@ std::string numeric_factor_enqueue(Numeric& N, const double* d_vals, double tol,
             const int kk = N.sn_k[s], ff = N.sn_f[s];
             const int j0 = stepA * NB;
             if (j0 >= kk) continue;
-            if (head && tstep * NB >= kk) continue;
+            if (head == 1 && tstep * NB >= kk) continue;
             const double K = std::min(npan * NB, kk - j0);
             const double t0 = std::min(tstep * NB, kk);
             const double remq = ff - t0;
-            if (head) { const double w = std::min<double>(t0 + NB, kk) - t0; fl += 2.0 * K * (w * remq - w * (w - 1.0) / 2.0); }
+            const double w2 = std::min<double>(GS * 128, remq);          // columns of the look-ahead head
+            const double remr = remq - w2;
+            if (head == 1) { const double w = std::min<double>(t0 + NB, kk) - t0; fl += 2.0 * K * (w * remq - w * (w - 1.0) / 2.0); }
+            else if (head == 2) fl += 2.0 * K * (w2 * remq - w2 * (w2 - 1.0) / 2.0);
+            else if (head == 3) fl += K * remr * (remr + 1.0);
             else fl += K * remq * (remq + 1.0);
           }
           if (N.prof_used + 2 > N.prof_events.size())
             for (int q = 0; q < 512; ++q) { hipEvent_t ev; OKKT_HIP_TRY(hipEventCreate(&ev)); N.prof_events.push_back(ev); }
           N.prof_flops.push_back(fl);
-          OKKT_HIP_TRY(hipEventRecord(N.prof_events[N.prof_used++], st));
+          OKKT_HIP_TRY(hipEventRecord(N.prof_events[N.prof_used++], sst));
         }
-#define OKKT_SYRK(D, S) hipLaunchKernelGGL((k_big_syrk<D, S, 4>), grid, dim3(256), syrk_lds_bytes(S), st, P, list, stepA, npan, tstep, head, NB)
-#define OKKT_SYRK8(D) hipLaunchKernelGGL((k_big_syrk<D, 2, 8>), grid, dim3(512), syrk_lds_bytes(2), st, P, list, stepA, npan, tstep, head, NB)
+#define OKKT_SYRK(D, S) hipLaunchKernelGGL((k_big_syrk<D, S, 4>), grid, dim3(256), syrk_lds_bytes(S), sst, P, list, stepA, npan, tstep, head, NB, wofs, GS)
+#define OKKT_SYRK8(D) hipLaunchKernelGGL((k_big_syrk<D, 2, 8>), grid, dim3(512), syrk_lds_bytes(2), sst, P, list, stepA, npan, tstep, head, NB, wofs, GS)
         switch (dbg_syrk) {   // timing-only ablations (OKKT_DEBUG_SYRK): outputs are wrong for codes < 100
           case 1: OKKT_SYRK(1, 3); break;
           case 2: OKKT_SYRK(2, 3); break;
@@ -1281,34 +1497,76 @@ std::string numeric_factor_enqueue(Numeric& N, const double* d_vals, double tol,
           case 104: OKKT_SYRK(0, 2); break;
           case 81: OKKT_SYRK8(1); break;
           case 82: OKKT_SYRK8(2); break;
+          case 85: OKKT_SYRK8(5); break;
           case 93: OKKT_SYRK8(13); break;
           default: OKKT_SYRK8(0); break;   // 8 waves x (64 x 32), two workgroups per CU
         }
 #undef OKKT_SYRK
 #undef OKKT_SYRK8
-        if (N.profile) OKKT_HIP_TRY(hipEventRecord(N.prof_events[N.prof_used++], st));
+        if (prof) OKKT_HIP_TRY(hipEventRecord(N.prof_events[N.prof_used++], sst));
         return "";
       };
-      for (int stepA = 0; stepA < nsteps; stepA += GS) {
+      // the panels of super-step q (block columns [q * GS, (q + 1) * GS)): diag -> trsm, with the in-group
+      // "head" update that brings each later panel of the group up to date first
+      auto launch_panels = [&](hipStream_t pst, int stepA) -> std::string {
+        const int par = (stepA / GS) & 1;
         for (int i = 0; i < GS && stepA + i < nsteps; ++i) {
           const int step = stepA + i;
-          if (i > 0) { std::string e = launch_syrk(stepA, i, step, 1); if (!e.empty()) return e; }   // bring this panel up to date
-          hipLaunchKernelGGL(k_big_diag, dim3(g.cnt), dim3(256), lds_diag, st, P, list, step, NB, tol, dbg_stop);
+          if (i > 0) { std::string e = launch_syrk(pst, stepA, i, step, 1); if (!e.empty()) return e; }
+          if (diag_v1) hipLaunchKernelGGL(k_big_diag_v1, dim3(g.cnt), dim3(256), lds_diag_v1, pst, P, list, step, NB, tol, dbg_stop);
+          else hipLaunchKernelGGL(k_big_diag, dim3(g.cnt), dim3(256), lds_diag, pst, P, list, step, NB, tol, dbg_stop);
           const int rem = g.maxf - step * NB;  // upper bound on rows below the diagonal block
           if (rem > 0) {
             const dim3 gr((rem + 63) / 64, g.cnt);
             const int nbl = NB / kIB;
             const size_t lds_trsm = ((size_t)nbl * (nbl + 1) / 2 * kIB * kIB + NB) * sizeof(double);
+            const int wc = (par * GS + i) * NB;
             switch (nbl) {
-              case 1: hipLaunchKernelGGL(k_big_trsm<1>, gr, dim3(256), lds_trsm, st, P, list, step, i * NB); break;
-              case 2: hipLaunchKernelGGL(k_big_trsm<2>, gr, dim3(256), lds_trsm, st, P, list, step, i * NB); break;
-              case 3: hipLaunchKernelGGL(k_big_trsm<3>, gr, dim3(256), lds_trsm, st, P, list, step, i * NB); break;
-              default: hipLaunchKernelGGL(k_big_trsm<4>, gr, dim3(256), lds_trsm, st, P, list, step, i * NB); break;
+              case 1: hipLaunchKernelGGL(k_big_trsm<1>, gr, dim3(256), lds_trsm, pst, P, list, step, wc); break;
+              case 2: hipLaunchKernelGGL(k_big_trsm<2>, gr, dim3(256), lds_trsm, pst, P, list, step, wc); break;
+              case 3: hipLaunchKernelGGL(k_big_trsm<3>, gr, dim3(256), lds_trsm, pst, P, list, step, wc); break;
+              default: hipLaunchKernelGGL(k_big_trsm<4>, gr, dim3(256), lds_trsm, pst, P, list, step, wc); break;
             }
           }
         }
-        std::string e = launch_syrk(stepA, GS, stepA + GS, 0);
-        if (!e.empty()) return e;
+        return "";
+      };
+      auto next_event = [&](hipEvent_t* ev) -> std::string {
+        if (N.la_used >= N.la_events.size())
+          for (int q = 0; q < 64; ++q) { hipEvent_t e2; OKKT_HIP_TRY(hipEventCreateWithFlags(&e2, hipEventDisableTiming)); N.la_events.push_back(e2); }
+        *ev = N.la_events[N.la_used++];
+        return "";
+      };
+      // Look-ahead: the trailing update of super-step q is split into the tile columns of super-step q + 1
+      // (head = 2) and the rest (head = 3).  head2(q) and rest(q) both need Panel(q) and rest(q - 1) and are
+      // independent of each other; Panel(q + 1) needs head2(q).  So the panel stream (which finds the CUs the
+      // main stream's CU mask leaves free: k_big_diag is a lone, latency-bound workgroup) runs
+      // head2(q) -> Panel(q + 1)  while the main stream runs rest(q) back to back with rest(q - 1).
+      // Used only while the rest is large enough; afterwards everything runs in order on the main stream.
+      std::string e = launch_panels(st, 0);
+      if (!e.empty()) return e;
+      hipEvent_t ev_panel = nullptr;   // set while the panels of the current super-step are on the panel stream
+      for (int stepA = 0; stepA < nsteps; stepA += GS) {
+        const int remr = g.maxf - (stepA + 2 * GS) * NB;           // rows of the rest triangle (upper bound)
+        const int Trr = remr > 0 ? (remr + 127) / 128 : 0;
+        const bool more = stepA + GS < nsteps;
+        const bool la = more && N.stream_panel != nullptr && N.lookahead && (int64_t)Trr * (Trr + 1) / 2 * g.cnt >= N.la_min_tiles;
+        if (la) {
+          hipEvent_t eva, evp;
+          if (!(e = next_event(&eva)).empty() || !(e = next_event(&evp)).empty()) return e;
+          OKKT_HIP_TRY(hipEventRecord(eva, st));                     // rest(q - 1) (and Panel(0)) are behind this
+          OKKT_HIP_TRY(hipStreamWaitEvent(N.stream_panel, eva, 0));
+          if (!(e = launch_syrk(N.stream_panel, stepA, GS, stepA + GS, 2)).empty()) return e;
+          if (!(e = launch_panels(N.stream_panel, stepA + GS)).empty()) return e;
+          OKKT_HIP_TRY(hipEventRecord(evp, N.stream_panel));
+          if (ev_panel) OKKT_HIP_TRY(hipStreamWaitEvent(st, ev_panel, 0));
+          if (!(e = launch_syrk(st, stepA, GS, stepA + GS, 3)).empty()) return e;
+          ev_panel = evp;
+        } else {
+          if (ev_panel) { OKKT_HIP_TRY(hipStreamWaitEvent(st, ev_panel, 0)); ev_panel = nullptr; }
+          if (!(e = launch_syrk(st, stepA, GS, stepA + GS, 0)).empty()) return e;
+          if (more && !(e = launch_panels(st, stepA + GS)).empty()) return e;
+        }
       }
       // full inverses of the diagonal blocks (for the solves), all blocks of the level in one launch
       {

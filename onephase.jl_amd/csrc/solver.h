@@ -19,7 +19,8 @@ struct okkt_solver_s {
   bool device_ready = false;  // HIP device selected and stream created
   bool numeric_ready = false; // device plan uploaded for the current pattern
   int device = 0;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;        // main stream (CU-masked when look-ahead is on)
+  hipStream_t stream_panel = nullptr;  // look-ahead panel stream (high priority, all CUs)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::vector<int64_t> user_perm;
   std::string err;
