@@ -152,7 +152,7 @@ def main():
                 "inertia_ok": bool(ok), "residual_inf": resid,
             },
             "roofline": {
-                "kernel": "k_big_syrk (FP64 MFMA trailing update of the big fronts)",
+                "kernel": "k_big_syrk<0, 0> (kSyrkTrail: FP64 MFMA trailing update of the big fronts, main stream)",
                 "bound": "mfma",
                 "achieved": achieved,
                 "peak": FP64_MFMA_PEAK_TFLOPS,

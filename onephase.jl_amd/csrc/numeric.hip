@@ -426,7 +426,10 @@ __global__ __launch_bounds__(256) void k_big_diag_v1(DevPlan P, const int* __res
 //   Entries above the diagonal and columns already factored are dead: the updates may write garbage there.
 //   Finally wave b inverts the unit-lower 32 x 32 diagonal block b: one COLUMN of X per lane, forward
 //   substitution with broadcast LDS reads of L (no cross-lane traffic at all).
-constexpr int kMW = 8;        // micro-panel width
+#ifndef OKKT_DIAG_MW
+#define OKKT_DIAG_MW 8
+#endif
+constexpr int kMW = OKKT_DIAG_MW;   // micro-panel width (4 or 8)
 constexpr int kPLD = 144;     // leading dimension of the LDS panels: 16-lane groups of an MFMA fragment hit disjoint banks
 constexpr int kXld = 33;
 
@@ -459,6 +462,7 @@ __global__ __launch_bounds__(256) void k_big_diag(DevPlan P, const int* __restri
     tj_s[q] = tj;
     ti_s[q] = tj + (t - start);
   }
+  long long tdbg0 = dbg_stop == 9 ? wall_clock64() : 0, tA = 0, tB = 0, tC = 0, tL = 0;
   d4_t acc[9];
   {
     // all loads first (clamped addresses, no branches), then the selects
@@ -484,24 +488,30 @@ __global__ __launch_bounds__(256) void k_big_diag(DevPlan P, const int* __restri
     }
   }
   if (dbg_stop == 1) return;
-  unsigned pos = 0, neg = 0, zer = 0, bad = 0;
+  if (dbg_stop == 9) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); tL = wall_clock64() - tdbg0; }
+  double my_d = 1.0;
   const int npair = (nb + 15) >> 4;
   for (int pp = 0; pp < npair; ++pp) {
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int p8 = pp * 16 + h * 8;        // first column of the micro-panel
+    for (int h = 0; h < 16 / kMW; ++h) {
+      const int p8 = pp * 16 + h * kMW;      // first column of the micro-panel
       if (p8 >= nb) continue;                // uniform
+      long long tq = dbg_stop == 9 ? wall_clock64() : 0;
       // (1) copy columns [p8, p8 + 8) out of the accumulators
 #pragma unroll
       for (int q = 0; q < 9; ++q)
         if (tj_s[q] == pp) {
           const int r = 16 * ti_s[q] + l15;
-          Praw[l4 * kPLD + r] = acc[q][2 * h];
-          Praw[(4 + l4) * kPLD + r] = acc[q][2 * h + 1];
+#pragma unroll
+          for (int e = 0; e < kMW / 4; ++e) Praw[(4 * e + l4) * kPLD + r] = acc[q][h * (kMW / 4) + e];
         }
-      __syncthreads();
+      // LDS-only barrier: __syncthreads() would also wait for the global stores of L (an HBM round trip per micro-step)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (dbg_stop == 9) { const long long tn = wall_clock64(); tA += tn - tq; tq = tn; }
       // (2) one thread per row
-      if (tid < 128 && tid >= p8) {
+      if (tid < 128 && tid >= p8 && dbg_stop != 3) {
         const int r = tid;
         double A[kMW][kMW], a[kMW], rd[kMW], w[kMW], lr[kMW];
 #pragma unroll
@@ -537,29 +547,45 @@ __global__ __launch_bounds__(256) void k_big_diag(DevPlan P, const int* __restri
             if ((r >> 5) == ((p8 + c) >> 5)) Ld[(r >> 5) * 32 * kXld + (r & 31) + ((p8 + c) & 31) * kXld] = val;
           }
         }
-        if (i < kMW && r < nb) {
-          double d = w[0];
+        if (i < kMW) {   // each row is a pivot row in exactly one micro-step: classified once, after the loop
 #pragma unroll
-          for (int c = 1; c < kMW; ++c) d = i == c ? w[c] : d;
-          P.dvals[col0 + j0 + r] = d;
-          classify_pivot(d, tol, pos, neg, zer, bad);
+          for (int c = 0; c < kMW; ++c) my_d = i == c ? w[c] : my_d;
         }
       }
-      __syncthreads();
+      // LDS-only barrier: __syncthreads() would also wait for the global stores of L (an HBM round trip per micro-step)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (dbg_stop == 9) { const long long tn = wall_clock64(); tB += tn - tq; tq = tn; }
       // (3) rank-8 update of every tile that still has live columns (to the right of the micro-panel)
 #pragma unroll
       for (int q = 0; q < 9; ++q)
-        if (tj_s[q] * 16 + 15 >= p8 + kMW) {
+        if (tj_s[q] * 16 + 15 >= p8 + kMW && dbg_stop != 4) {
           const int rr = 16 * ti_s[q] + l15, cc = 16 * tj_s[q] + l15;
-          const double a0 = Wp[l4 * kPLD + cc], a1 = Wp[(4 + l4) * kPLD + cc];
-          const double b0 = Lp[l4 * kPLD + rr], b1 = Lp[(4 + l4) * kPLD + rr];
-          acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[q], 0, 0, 0);
-          acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[q], 0, 0, 0);
+          double av[kMW / 4], bv[kMW / 4];
+#pragma unroll
+          for (int e = 0; e < kMW / 4; ++e) { av[e] = Wp[(4 * e + l4) * kPLD + cc]; bv[e] = Lp[(4 * e + l4) * kPLD + rr]; }
+#pragma unroll
+          for (int e = 0; e < kMW / 4; ++e) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[e], bv[e], acc[q], 0, 0, 0);
         }
+      if (dbg_stop == 9) { tC += wall_clock64() - tq; }
     }
   }
-  flush_counts(P.counters, pos, neg, zer, bad);
-  __syncthreads();
+  {
+    unsigned pos = 0, neg = 0, zer = 0, bad = 0;
+    if (tid < nb) {
+      P.dvals[col0 + j0 + tid] = my_d;
+      classify_pivot(my_d, tol, pos, neg, zer, bad);
+    }
+    if (dbg_stop != 9) flush_counts(P.counters, pos, neg, zer, bad);
+    else if (tid == 0) {   // debug: phase times (wall-clock ticks x 1000) instead of pivot counts
+      atomicAdd(&P.counters[0], (unsigned long long)tL * 1000ull); atomicAdd(&P.counters[1], (unsigned long long)tA * 1000ull);
+      atomicAdd(&P.counters[2], (unsigned long long)tB * 1000ull); atomicAdd(&P.counters[3], (unsigned long long)tC * 1000ull);
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
   if (dbg_stop == 2) return;
   // X_bb = inv(L_bb): wave b, one column per lane
   const int off = wave * 32;
@@ -795,17 +821,23 @@ constexpr int kSyrkLd = 144;
 constexpr size_t syrk_lds_bytes(int stages) { return (size_t)stages * 2 * kSyrkKC * kSyrkLd * sizeof(double); }
 typedef __attribute__((address_space(3))) void lds_void_t;
 
-template <int DBG, int STAGES, int NW>
-__global__ __launch_bounds__(NW * 64, STAGES == 2 ? NW / 2 : 1) void k_big_syrk(DevPlan P, const int* __restrict__ list, int stepA, int npan,
-                                                                       int tstep, int head, int NB, int wofs, int csplit) {
-  // Applies the panels [stepA, stepA + npan) (K = up to npan * NB columns, W panels side by side in wbuf)
-  // to the region that starts at block column tstep.  head = 0: the whole trailing lower triangle
-  // (super-step update, K = GS * NB halves the C traffic per flop for GS = 2); head = 1: only the next
-  // panel's own columns [t0, min(t0 + NB, k)) -- what that panel needs before it can be factored.
-  // Look-ahead split of the head = 0 update: head = 2 covers only the first `csplit` tile columns of the region
-  // (all the next super-step's panels need), head = 3 the remaining tile columns; wofs = first W column in wbuf.
-  // NW = 4: 2 x 2 waves of 64 x 64; NW = 8: 2 x 4 waves of 64 rows x 32 columns (four waves per SIMD with two
-  // workgroups per CU: a wave's C-tile load/store hides behind three other waves' MFMAs)
+// HEAD selects which tiles of the region that starts at block column tstep a launch updates:
+//   kSyrkTrail (the dominant kernel): the lower triangle without its first `csplit` tile columns
+//                (csplit = 0: the whole super-step update; csplit = GS: what is left beside the look-ahead columns)
+//   kSyrkPanel : only the next panel's own columns [t0, min(t0 + NB, k)) -- what that panel needs before it
+//                can be factored (in-group update, K = NB)
+//   kSyrkAhead : the first `csplit` tile columns -- all that the next super-step's panels need (look-ahead)
+// DBG != 0 are timing-only ablations (wrong results): bit0 no C load, bit1 no MFMA, bit2 no store, bit3 no LDS-DMA.
+enum { kSyrkTrail = 0, kSyrkPanel = 1, kSyrkAhead = 2 };
+constexpr int kSyrkNW = 8;   // 2 x 4 waves of 64 rows x 32 columns: four waves per SIMD with two workgroups per CU,
+                             // so a wave's C-tile load/store hides behind three other waves' MFMAs
+
+template <int DBG, int HEAD>
+__global__ __launch_bounds__(kSyrkNW * 64, kSyrkNW / 2) void k_big_syrk(DevPlan P, const int* __restrict__ list, int stepA, int npan,
+                                                                        int tstep, int NB, int wofs, int csplit) {
+  // Applies the panels [stepA, stepA + npan) (K = up to npan * NB columns, W panels side by side in wbuf from
+  // column wofs) to the region that starts at block column tstep; K = GS * NB halves the C traffic per flop.
+  constexpr int NW = kSyrkNW, STAGES = 2;
   constexpr int WCW = 128 / (NW / 2);   // columns per wave
   constexpr int NCG = WCW / 4;          // 4-column groups per wave
   extern __shared__ __attribute__((aligned(16))) double sm[];
@@ -817,23 +849,22 @@ __global__ __launch_bounds__(NW * 64, STAGES == 2 ? NW / 2 : 1) void k_big_syrk(
   const int j0 = stepA * NB;
   if (j0 >= k) return;
   const int nb = min(npan * NB, k - j0);          // K of this update
-  if (head == 1 && tstep * NB >= k) return;       // there is no next panel in this front
+  if (HEAD == kSyrkPanel && tstep * NB >= k) return;   // there is no next panel in this front
   const int t0 = min(tstep * NB, k);
-  const int climit = head == 1 ? min(t0 + NB, k) : f;  // columns this launch may write
+  const int climit = HEAD == kSyrkPanel ? min(t0 + NB, k) : f;  // columns this launch may write
   const int T = (f - t0 + 127) >> 7;
-  const int Tr = max(T - csplit, 0);              // head = 3: triangle that is left after csplit tile columns
   int ntiles;
-  if (head == 0) ntiles = T * (T + 1) / 2;
-  else if (head == 1) ntiles = T;
-  else if (head == 2) { ntiles = 0; for (int c = 0; c < csplit && c < T; ++c) ntiles += T - c; }
-  else ntiles = Tr * (Tr + 1) / 2;
+  if (HEAD == kSyrkTrail) { const int Tr = max(T - csplit, 0); ntiles = Tr * (Tr + 1) / 2; }
+  else if (HEAD == kSyrkPanel) ntiles = T;
+  else { ntiles = 0; for (int c = 0; c < csplit && c < T; ++c) ntiles += T - c; }
+  // XCD-aware order: consecutive tile indices (which share operand panels) stay on one XCD and its L2
   const int nx = (int)gridDim.x;
   const int per = (nx + 7) >> 3;
   const int idx = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
   if (idx >= ntiles) return;
   int ti, tj;
-  if (head == 1) { ti = idx; tj = 0; }
-  else if (head == 2) {
+  if (HEAD == kSyrkPanel) { ti = idx; tj = 0; }
+  else if (HEAD == kSyrkAhead) {
     int rest = idx; tj = 0;
     while (rest >= T - tj) { rest -= T - tj; ++tj; }
     ti = tj + rest;
@@ -842,7 +873,7 @@ __global__ __launch_bounds__(NW * 64, STAGES == 2 ? NW / 2 : 1) void k_big_syrk(
     while ((ti + 1) * (ti + 2) / 2 <= idx) ++ti;
     while (ti * (ti + 1) / 2 > idx) --ti;
     tj = idx - ti * (ti + 1) / 2;
-    if (head == 3) { ti += csplit; tj += csplit; }
+    ti += csplit; tj += csplit;
   }
   const int rt0 = t0 + ti * 128, ct0 = t0 + tj * 128;   // tile origin
   const int rbase = rt0 + (wv & 1) * 64;
@@ -854,7 +885,7 @@ __global__ __launch_bounds__(NW * 64, STAGES == 2 ? NW / 2 : 1) void k_big_syrk(
   const int l15 = lane & 15, l4 = lane >> 4;
   const int nchunk = (nb + kSyrkKC - 1) / kSyrkKC;
 
-  // stage `ch` -> ring slot ch % 3: wave wv moves panel rows q*4 + wv (q = 0..3) of both operands
+  // stage `ch` -> ring slot ch % 2: wave wv moves panel rows q * 8 + wv (q = 0, 1) of both operands by LDS-DMA
   auto issue = [&](int ch) {
     double* slot = sm + (size_t)(ch % STAGES) * 2 * kSyrkKC * kSyrkLd;
 #pragma unroll
@@ -895,55 +926,32 @@ __global__ __launch_bounds__(NW * 64, STAGES == 2 ? NW / 2 : 1) void k_big_syrk(
   // the LDS-DMAs go out AFTER the C loads: with an LDS-DMA in flight hipcc waits vmcnt(0) after every
   // ordinary load (64 serial round trips); in this order it issues all 64 back to back
   asm volatile("" ::: "memory");
-  if constexpr (!(DBG & 8)) { issue(0); if (STAGES == 3 && nchunk > 1) issue(1); }
+  if constexpr (!(DBG & 8)) issue(0);
   for (int ch = 0; ch < nchunk; ++ch) {
-    // STAGES == 3: chunk ch has landed once at most the 8 LDS-DMAs of chunk ch+1 are still outstanding;
-    // STAGES == 2: only chunk ch is in flight here
-    if (STAGES == 3 && ch + 1 < nchunk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // STAGES == 3 only with NW == 4
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // only chunk ch is in flight here
     __builtin_amdgcn_s_barrier();
-    // the slot written next was last read STAGES - 1 iterations ago; everyone is past that barrier
-    if constexpr (!(DBG & 8)) { if (ch + STAGES - 1 < nchunk) issue(ch + STAGES - 1); }
+    // the slot written next was last read one iteration ago; everyone is past that barrier
+    if constexpr (!(DBG & 8)) { if (ch + 1 < nchunk) issue(ch + 1); }
     if (active && !(DBG & 2)) {
       const double* slot = sm + (size_t)(ch % STAGES) * 2 * kSyrkKC * kSyrkLd;
       const double* bw = slot + (wv & 1) * 64 + 2 * l15;
       const double* bl = slot + kSyrkKC * kSyrkLd + (wv >> 1) * WCW + (lane & 3);
-      if constexpr (STAGES == 3) {
-        // one wave per SIMD: nobody else hides the LDS latency, so all 80 operand fragments of the
-        // chunk are fetched up front and the latency is paid once per chunk
-        double bvv[kSyrkKC / 4][4], avv[kSyrkKC / 4][NCG];
+      // the partner waves on the SIMD cover LDS latency; fragments are fetched per k-step to stay <= 128 VGPRs
 #pragma unroll
-        for (int kk = 0; kk < kSyrkKC / 4; ++kk) {
+      for (int kk = 0; kk < kSyrkKC / 4; ++kk) {
+        double bv[4];
 #pragma unroll
-          for (int rb = 0; rb < 4; ++rb) bvv[kk][rb] = bw[(kk * 4 + l4) * kSyrkLd + (rb & 1) + 32 * (rb >> 1)];
+        for (int rb = 0; rb < 4; ++rb) bv[rb] = bw[(kk * 4 + l4) * kSyrkLd + (rb & 1) + 32 * (rb >> 1)];
 #pragma unroll
-          for (int cg = 0; cg < NCG; ++cg) avv[kk][cg] = bl[(kk * 4 + l4) * kSyrkLd + cg * 4];
-        }
+        for (int half = 0; half < NCG / 4; ++half) {
+          double av[4];
 #pragma unroll
-        for (int kk = 0; kk < kSyrkKC / 4; ++kk)
+          for (int q = 0; q < 4; ++q) av[q] = bl[(kk * 4 + l4) * kSyrkLd + (half * 4 + q) * 4];
 #pragma unroll
-          for (int cg = 0; cg < NCG; ++cg)
+          for (int q = 0; q < 4; ++q)
 #pragma unroll
             for (int rb = 0; rb < 4; ++rb)
-              acc[cg][rb] = __builtin_amdgcn_mfma_f64_4x4x4f64(avv[kk][cg], bvv[kk][rb], acc[cg][rb], 0, 0, 1 /* neg A */);
-      } else {
-        // two workgroups per CU: the partner wave on the SIMD covers LDS latency; keep registers <= 256
-#pragma unroll
-        for (int kk = 0; kk < kSyrkKC / 4; ++kk) {
-          double bv[4];
-#pragma unroll
-          for (int rb = 0; rb < 4; ++rb) bv[rb] = bw[(kk * 4 + l4) * kSyrkLd + (rb & 1) + 32 * (rb >> 1)];
-#pragma unroll
-          for (int half = 0; half < NCG / 4; ++half) {
-            double av[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) av[q] = bl[(kk * 4 + l4) * kSyrkLd + (half * 4 + q) * 4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-              for (int rb = 0; rb < 4; ++rb)
-                acc[half * 4 + q][rb] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[q], bv[rb], acc[half * 4 + q][rb], 0, 0, 1 /* neg A */);
-          }
+              acc[half * 4 + q][rb] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[q], bv[rb], acc[half * 4 + q][rb], 0, 0, 1 /* neg A */);
         }
       }
     }
@@ -1387,12 +1395,9 @@ std::string numeric_setup(const Symbolic& S, const SymbolicOptions& opts, hipStr
   OKKT_HIP_TRY(hipFuncSetAttribute((const void*)k_big_invert, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds));
   OKKT_HIP_TRY(hipFuncSetAttribute((const void*)k_big_trsm<3>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds));
   OKKT_HIP_TRY(hipFuncSetAttribute((const void*)k_big_trsm<4>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds));
-  for (const void* fn : {(const void*)k_big_syrk<0, 3, 4>, (const void*)k_big_syrk<1, 3, 4>, (const void*)k_big_syrk<2, 3, 4>,
-                         (const void*)k_big_syrk<4, 3, 4>, (const void*)k_big_syrk<13, 3, 4>})
-    OKKT_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)syrk_lds_bytes(3)));
-  for (const void* fn : {(const void*)k_big_syrk<0, 2, 4>, (const void*)k_big_syrk<1, 2, 4>, (const void*)k_big_syrk<2, 2, 4>,
-                         (const void*)k_big_syrk<13, 2, 4>, (const void*)k_big_syrk<0, 2, 8>, (const void*)k_big_syrk<1, 2, 8>,
-                         (const void*)k_big_syrk<2, 2, 8>, (const void*)k_big_syrk<13, 2, 8>})
+  for (const void* fn : {(const void*)k_big_syrk<0, kSyrkTrail>, (const void*)k_big_syrk<0, kSyrkPanel>, (const void*)k_big_syrk<0, kSyrkAhead>,
+                         (const void*)k_big_syrk<1, kSyrkTrail>, (const void*)k_big_syrk<2, kSyrkTrail>, (const void*)k_big_syrk<5, kSyrkTrail>,
+                         (const void*)k_big_syrk<13, kSyrkTrail>})
     OKKT_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)syrk_lds_bytes(2)));
   return "";
 }
@@ -1458,7 +1463,7 @@ std::string numeric_factor_enqueue(Numeric& N, const double* d_vals, double tol,
         if (ntile == 0) return "";
         const dim3 grid((ntile + 7) / 8 * 8, g.cnt);
         const int wofs = ((stepA / GS) & 1) * GS * NB;
-        const bool prof = N.profile;
+        const bool prof = N.profile && (head == 0 || head == 3);   // the dominant kernel: k_big_syrk<0, kSyrkTrail>
         if (prof) {
           // algorithmic flops of this launch: 2 * K * (lower-triangle entries it updates), summed over fronts
           double fl = 0;
@@ -1483,26 +1488,18 @@ std::string numeric_factor_enqueue(Numeric& N, const double* d_vals, double tol,
           N.prof_flops.push_back(fl);
           OKKT_HIP_TRY(hipEventRecord(N.prof_events[N.prof_used++], sst));
         }
-#define OKKT_SYRK(D, S) hipLaunchKernelGGL((k_big_syrk<D, S, 4>), grid, dim3(256), syrk_lds_bytes(S), sst, P, list, stepA, npan, tstep, head, NB, wofs, GS)
-#define OKKT_SYRK8(D) hipLaunchKernelGGL((k_big_syrk<D, 2, 8>), grid, dim3(512), syrk_lds_bytes(2), sst, P, list, stepA, npan, tstep, head, NB, wofs, GS)
-        switch (dbg_syrk) {   // timing-only ablations (OKKT_DEBUG_SYRK): outputs are wrong for codes < 100
-          case 1: OKKT_SYRK(1, 3); break;
-          case 2: OKKT_SYRK(2, 3); break;
-          case 4: OKKT_SYRK(4, 3); break;
-          case 13: OKKT_SYRK(13, 3); break;
-          case 21: OKKT_SYRK(1, 2); break;
-          case 22: OKKT_SYRK(2, 2); break;
-          case 33: OKKT_SYRK(13, 2); break;
-          case 103: OKKT_SYRK(0, 3); break;   // correct variants
-          case 104: OKKT_SYRK(0, 2); break;
-          case 81: OKKT_SYRK8(1); break;
-          case 82: OKKT_SYRK8(2); break;
-          case 85: OKKT_SYRK8(5); break;
-          case 93: OKKT_SYRK8(13); break;
-          default: OKKT_SYRK8(0); break;   // 8 waves x (64 x 32), two workgroups per CU
+#define OKKT_SYRK(D, H) hipLaunchKernelGGL((k_big_syrk<D, H>), grid, dim3(kSyrkNW * 64), syrk_lds_bytes(2), sst, P, list, stepA, npan, tstep, NB, wofs, csplit)
+        const int csplit = head == 0 ? 0 : GS;
+        if (head == 1) OKKT_SYRK(0, kSyrkPanel);
+        else if (head == 2) OKKT_SYRK(0, kSyrkAhead);
+        else switch (dbg_syrk) {   // timing-only ablations of the trailing update (OKKT_DEBUG_SYRK): wrong outputs
+          case 81: OKKT_SYRK(1, kSyrkTrail); break;    // no C load
+          case 82: OKKT_SYRK(2, kSyrkTrail); break;    // no MFMA
+          case 85: OKKT_SYRK(5, kSyrkTrail); break;    // no C load, no store
+          case 93: OKKT_SYRK(13, kSyrkTrail); break;   // MFMA + LDS reads only
+          default: OKKT_SYRK(0, kSyrkTrail); break;
         }
 #undef OKKT_SYRK
-#undef OKKT_SYRK8
         if (prof) OKKT_HIP_TRY(hipEventRecord(N.prof_events[N.prof_used++], sst));
         return "";
       };
