@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libonephase_kkt.so")
+LIB_PATH = os.environ.get("OKKT_LIB_PATH", os.path.join(_HERE, "libonephase_kkt.so"))   # override: A/B builds
 
 OKKT_SYM_DEFINITE = 0
 OKKT_SYM_SYMMETRIC = 1

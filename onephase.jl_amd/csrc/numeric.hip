@@ -816,7 +816,14 @@ __global__ __launch_bounds__(256) void k_big_trsm(DevPlan P, const int* __restri
 //    across the (raw) barrier behind a counted s_waitcnt vmcnt.  LDS rows are padded to 144 doubles so the
 //    four k-slices of a B fragment fall on disjoint banks.
 //  * tile order: workgroups b, b+8, .. share an XCD; they get consecutive tiles (same W row block in L2).
-constexpr int kSyrkKC = 16;
+#ifndef OKKT_SYRK_KC
+#define OKKT_SYRK_KC 16
+#endif
+#ifndef OKKT_SYRK_STAGES
+#define OKKT_SYRK_STAGES 2
+#endif
+constexpr int kSyrkKC = OKKT_SYRK_KC;          // k-columns per ring slot
+constexpr int kSyrkStages = OKKT_SYRK_STAGES;  // ring slots (KC * stages = 32 keeps two workgroups per CU)
 constexpr int kSyrkLd = 144;
 constexpr size_t syrk_lds_bytes(int stages) { return (size_t)stages * 2 * kSyrkKC * kSyrkLd * sizeof(double); }
 typedef __attribute__((address_space(3))) void lds_void_t;
@@ -837,7 +844,8 @@ __global__ __launch_bounds__(kSyrkNW * 64, kSyrkNW / 2) void k_big_syrk(DevPlan 
                                                                         int tstep, int NB, int wofs, int csplit) {
   // Applies the panels [stepA, stepA + npan) (K = up to npan * NB columns, W panels side by side in wbuf from
   // column wofs) to the region that starts at block column tstep; K = GS * NB halves the C traffic per flop.
-  constexpr int NW = kSyrkNW, STAGES = 2;
+  constexpr int NW = kSyrkNW, STAGES = kSyrkStages;
+  constexpr int DMA = 2 * (kSyrkKC / NW);   // LDS-DMA instructions per wave and chunk
   constexpr int WCW = 128 / (NW / 2);   // columns per wave
   constexpr int NCG = WCW / 4;          // 4-column groups per wave
   extern __shared__ __attribute__((aligned(16))) double sm[];
@@ -926,12 +934,22 @@ __global__ __launch_bounds__(kSyrkNW * 64, kSyrkNW / 2) void k_big_syrk(DevPlan 
   // the LDS-DMAs go out AFTER the C loads: with an LDS-DMA in flight hipcc waits vmcnt(0) after every
   // ordinary load (64 serial round trips); in this order it issues all 64 back to back
   asm volatile("" ::: "memory");
-  if constexpr (!(DBG & 8)) issue(0);
+  if constexpr (!(DBG & 8)) {
+#pragma unroll
+    for (int q = 0; q < STAGES - 1; ++q) if (q < nchunk) issue(q);
+  }
   for (int ch = 0; ch < nchunk; ++ch) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // only chunk ch is in flight here
+    // chunk ch has landed once only the chunks issued after it (at most STAGES - 2) are still outstanding
+    if constexpr (STAGES == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else {
+      const int later = min(STAGES - 2, nchunk - 1 - ch);
+      if (later >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DMA) : "memory");
+      else if (later == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();
     // the slot written next was last read one iteration ago; everyone is past that barrier
-    if constexpr (!(DBG & 8)) { if (ch + 1 < nchunk) issue(ch + 1); }
+    if constexpr (!(DBG & 8)) { if (ch + STAGES - 1 < nchunk) issue(ch + STAGES - 1); }
     if (active && !(DBG & 2)) {
       const double* slot = sm + (size_t)(ch % STAGES) * 2 * kSyrkKC * kSyrkLd;
       const double* bw = slot + (wv & 1) * 64 + 2 * l15;
@@ -1398,7 +1416,7 @@ std::string numeric_setup(const Symbolic& S, const SymbolicOptions& opts, hipStr
   for (const void* fn : {(const void*)k_big_syrk<0, kSyrkTrail>, (const void*)k_big_syrk<0, kSyrkPanel>, (const void*)k_big_syrk<0, kSyrkAhead>,
                          (const void*)k_big_syrk<1, kSyrkTrail>, (const void*)k_big_syrk<2, kSyrkTrail>, (const void*)k_big_syrk<5, kSyrkTrail>,
                          (const void*)k_big_syrk<13, kSyrkTrail>})
-    OKKT_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)syrk_lds_bytes(2)));
+    OKKT_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)syrk_lds_bytes(kSyrkStages)));
   return "";
 }
 
@@ -1488,7 +1506,7 @@ std::string numeric_factor_enqueue(Numeric& N, const double* d_vals, double tol,
           N.prof_flops.push_back(fl);
           OKKT_HIP_TRY(hipEventRecord(N.prof_events[N.prof_used++], sst));
         }
-#define OKKT_SYRK(D, H) hipLaunchKernelGGL((k_big_syrk<D, H>), grid, dim3(kSyrkNW * 64), syrk_lds_bytes(2), sst, P, list, stepA, npan, tstep, NB, wofs, csplit)
+#define OKKT_SYRK(D, H) hipLaunchKernelGGL((k_big_syrk<D, H>), grid, dim3(kSyrkNW * 64), syrk_lds_bytes(kSyrkStages), sst, P, list, stepA, npan, tstep, NB, wofs, csplit)
         const int csplit = head == 0 ? 0 : GS;
         if (head == 1) OKKT_SYRK(0, kSyrkPanel);
         else if (head == 2) OKKT_SYRK(0, kSyrkAhead);
