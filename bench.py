@@ -52,6 +52,7 @@ def main():
     ap.add_argument("--config", default="S-metric")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", default="S-C3")
+    ap.add_argument("--no-kkt-level", action="store_true", help="skip the (untimed-region) KKT-level breakdown in config.kkt_level")
     ap.add_argument("--mode", default="replicas", choices=["replicas", "sharded"],
                     help="N > 1: replicas = one KKT system per rank (weak scaling, default); sharded = ONE system, elimination-tree "
                          "subtrees over the ranks with RCCL reduce of the contribution blocks (strong scaling; use --config S-C5)")
@@ -165,6 +166,8 @@ def main():
                 "share_of_factor_time": syrk_ms / max(fac_ms, 1e-9),
             },
         }
+        if world == 1 and not args.no_kkt_level:
+            out["config"]["kkt_level"] = kkt_level_breakdown(prob, local_rank)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, st)
         print(json.dumps(out))
@@ -219,6 +222,37 @@ def bench_sharded(args, rank, world, local_rank):
     dist.destroy_process_group()
 
 
+def kkt_level_breakdown(prob, device):
+    """Outside the timed region: wall-clock of the four reference methods of the device-resident KKT solver
+    (form_system! -> factor! -> kkt_associate_rhs! -> compute_direction!, kkt_system_solver.jl:13-17) on the same
+    workload, for both system shapes.  Host buffers cross PCIe in form_system (H, J, s, y) and in the rhs/direction
+    vectors, so these are PCIe-inclusive figures; they are reported beside `value`, never as it."""
+    from onephase_jl_amd import kkt_system_solver as KS
+    n, m = prob["n"], prob["m"]
+    rng = np.random.default_rng(1)
+    it = KS.Class_iterate(x=rng.normal(size=n), y=prob["y"], s=prob["s"], mu=float(prob["mu"]), J=prob["J"], H=prob["H"],
+                          grad=rng.normal(size=n), cons=prob["s"] + 1e-3 * rng.normal(size=m))
+    out = {}
+    for kind in ("symmetric", "schur"):
+        pars = KS.Class_parameters()
+        pars.kkt.kkt_solver_type = kind
+        k = KS.HIP_KKT_solver(kind, pars, device=device)
+        k.initialize_b(it)
+        k.form_system_b(it)                      # first call: symbolic analysis of this shape
+        tm = {}
+        for _ in range(2):
+            t = time.perf_counter(); k.form_system_b(it); tm["form_system_ms"] = 1e3 * (time.perf_counter() - t)
+            t = time.perf_counter(); inertia = k.factor_b(1e-8); tm["factor_ms"] = 1e3 * (time.perf_counter() - t)
+            t = time.perf_counter(); k.kkt_associate_rhs_b(it, KS.Reduct_affine()); tm["rhs_ms"] = 1e3 * (time.perf_counter() - t)
+            t = time.perf_counter(); k.compute_direction_b(); tm["direction_ms"] = 1e3 * (time.perf_counter() - t)
+        tm["inertia_flag"] = int(inertia)
+        tm["N_err"] = float(k.kkt_err_norm.ratio)
+        tm["refinement_solves"] = 3 if kind == "schur" else 1
+        out[kind] = tm
+        k.finalize_b()
+    return out
+
+
 def cpu_baseline(sample_cfg, st_metric):
     """The oracle (scalar up-looking LDL^T, kind "port") on a bounded sample: one factor+solve of a smaller
     instance of the same generator, scaled to the metric workload by the factor-flop ratio."""
@@ -242,6 +276,19 @@ def cpu_baseline(sample_cfg, st_metric):
     x = ref.ls_solve(b)
     dt = time.perf_counter() - t0
     ratio = st_metric["flops_exact"] / st["flops_exact"]
+    # independent datapoint: SuperLU through scipy on the same sample, its own ordering, analysis included
+    indep = None
+    try:
+        import scipy.sparse.linalg as spla
+        M = synth.symmetrize_lower(K).tocsc()
+        t1 = time.perf_counter()
+        lu = spla.splu(M, permc_spec="MMD_AT_PLUS_A", diag_pivot_thresh=0.0, options=dict(SymmetricMode=True))
+        xs = lu.solve(b)
+        indep = {"what": "scipy.sparse.linalg.splu (SuperLU, MMD_AT_PLUS_A, symmetric mode), ordering + factor + solve",
+                 "sample_seconds": time.perf_counter() - t1,
+                 "agrees_with_port": bool(np.max(np.abs(xs - x)) <= 1e-6 * max(1.0, float(np.max(np.abs(x)))))}
+    except Exception as exc:   # scipy is optional on the box
+        indep = {"what": "scipy splu unavailable", "error": str(exc)[:80]}
     return {
         "value": 1.0 / (dt * ratio),
         "unit": "factor+solve/s",
@@ -251,6 +298,7 @@ def cpu_baseline(sample_cfg, st_metric):
                   f"on 1 core (rc={rc}); scaled by the factor-flop ratio {ratio:.1f} to the metric workload",
         "sample_seconds": dt,
         "sample_gflops": st["flops_exact"] / dt / 1e9,
+        "independent": indep,
     }
 
 
