@@ -292,6 +292,205 @@ class Symmetric_KKT_solver(_KKTBase):
         self.update_kkt_error_b()
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# Clever_Symmetric_KKT_solver (clever_symmetric.jl): parallel rows of J are merged before the LDL^T.
+# Index work (integer outputs pinned by the reference's test_compute_indicies / test_compare_columns,
+# test/kkt_system_solvers.jl:5-58) is restated literally; indices are 0-based here, the tests add 1.
+# ---------------------------------------------------------------------------------------------------------------
+def _cols_of(A):
+    """Columns of a CSC matrix as (sorted index array, value array) pairs, explicit zeros dropped like Julia's
+    sparse() constructor does for the test matrices."""
+    A = sp.csc_matrix(A)
+    A.sort_indices()
+    out = []
+    for j in range(A.shape[1]):
+        idx = A.indices[A.indptr[j]:A.indptr[j + 1]]
+        val = A.data[A.indptr[j]:A.indptr[j + 1]]
+        out.append((np.array(idx, dtype=np.int64), np.array(val, dtype=float)))
+    return out
+
+
+def rescale_cols(cols):  # clever_symmetric.jl:90-105: every column divided by its first stored value
+    return [(idx, val / val[0] if len(val) else val) for idx, val in cols]
+
+
+def compare_columns(cols, i, j):  # clever_symmetric.jl:107-155: the strict order "column i before column j"
+    ai, vi = cols[i]
+    aj, vj = cols[j]
+    if len(aj) == 0:
+        return False
+    if len(ai) == 0:
+        return True
+    if ai[0] != aj[0]:
+        return bool(aj[0] < ai[0])            # the LARGER first row index sorts first
+    if len(ai) != len(aj):
+        return len(ai) < len(aj)
+    for a, b in zip(ai, aj):
+        if a != b:
+            return bool(a < b)
+    for a, b in zip(vi, vj):
+        if a < b:
+            return True
+        if a > b:
+            return False
+    return i < j
+
+
+def sorted_col_list(cols):  # clever_symmetric.jl:157-166
+    import functools
+    rc = rescale_cols(cols)
+    order = list(range(len(cols)))
+    order.sort(key=functools.cmp_to_key(lambda i, j: -1 if compare_columns(rc, i, j) else (1 if compare_columns(rc, j, i) else 0)))
+    return order
+
+
+def columns_are_same(cols, i, j):  # clever_symmetric.jl:63-88 (on the UNscaled matrix, tolerance 1e-16 in the 2-norm)
+    ai, vi = cols[i]
+    aj, vj = cols[j]
+    if len(ai) != len(aj) or not np.array_equal(ai, aj):
+        return False
+    if len(vi) == 0:
+        return True
+    ratio = vi[0] / vj[0]
+    return bool(np.sqrt(np.sum((vi - vj * ratio) ** 2)) < 1e-16)
+
+
+def compute_breakpoints(cols, sorted_cols):  # clever_symmetric.jl:168-198
+    bps = []
+    for bp in range(len(sorted_cols)):
+        if bp == 0 or not columns_are_same(cols, sorted_cols[bp - 1], sorted_cols[bp]):
+            bps.append(bp)
+    return bps
+
+
+@dataclass
+class Parallel_row:   # clever_symmetric.jl:4-13
+    ind: int
+    ratio: float
+    u: float = math.nan
+    g: float = math.nan
+
+
+@dataclass
+class Parallel_row_group:   # clever_symmetric.jl:15-19
+    ls: list
+    first: int
+    u: float = math.nan
+
+
+def compute_indicies(J, diag_vals=None):  # clever_symmetric.jl:200-260
+    cols = _cols_of(sp.csc_matrix(J).T)          # columns of J' = rows of J
+    sorted_cols = sorted_col_list(cols)
+    bps = compute_breakpoints(cols, sorted_cols)
+    no_para = sorted(sorted_cols[b] for b in bps)
+    groups = []
+    for k, bp in enumerate(bps):
+        end = bps[k + 1] if k + 1 < len(bps) else len(sorted_cols)
+        ind_ls = sorted_cols[bp:end]
+        ls = []
+        for i in ind_ls:
+            if i == ind_ls[0]:
+                ratio = 1.0
+            else:
+                ratio = cols[i][1][0] / cols[ind_ls[0]][1][0] if len(cols[i][1]) else 1.0
+                if ratio == 0.0 or not math.isfinite(ratio):
+                    raise ArithmeticError(f"clever_symmetric.jl: ratio = {ratio}")
+            ls.append(Parallel_row(i, ratio))
+        groups.append(Parallel_row_group(ls, ind_ls[0]))
+    groups.sort(key=lambda g: g.first)
+    if diag_vals is not None:
+        update_indicies(groups, diag_vals)
+    return no_para, groups
+
+
+def update_indicies(groups, diag_vals):  # clever_symmetric.jl:262-287
+    for grp in groups:
+        u_inv = 0.0
+        for row in grp.ls:
+            row.u = float(diag_vals[row.ind])
+            u_inv += row.ratio ** 2 * row.u ** (-1.0)
+        if not u_inv > 0.0:
+            raise ArithmeticError(f"clever_symmetric.jl: u_inf = {u_inv} !> 0.0")
+        grp.u = 1.0 / u_inv
+        for row in grp.ls:
+            row.g = grp.u * row.ratio * row.u ** (-1.0)
+
+
+class Clever_Symmetric_KKT_solver(_KKTBase):
+    """clever_symmetric.jl:25-519.  kkt_system_rescale in {"none", "u_only", "u_and_x"} (parameters.jl:24-28)."""
+
+    def __init__(self, ls_solver, pars=None, kkt_system_rescale="none"):
+        super().__init__(ls_solver, pars)
+        self.kkt_system_rescale = kkt_system_rescale
+
+    def initialize_b(self, it):  # clever_symmetric.jl:53-61
+        super().initialize_b(it)
+        self.first_para_indicies, self.para_row_info = compute_indicies(it.J)
+
+    def form_system_b(self, it):  # clever_symmetric.jl:341-393
+        u = it.s / it.y
+        assert np.all(u > 0.0)
+        update_indicies(self.para_row_info, u)
+        J_new = sp.csr_matrix(it.J)[self.first_para_indicies, :]
+        u_new = np.array([g.u for g in self.para_row_info])
+        n = it.dim()
+        M = sp.bmat([[it.H, None], [J_new, -sp.diags(u_new)]], format="csc") if len(u_new) else sp.csc_matrix(it.H)
+        self.factor_it = it
+        if self.kkt_system_rescale == "none":
+            self.diag_rescale = np.ones(n + len(u_new))
+        elif self.kkt_system_rescale == "u_only":
+            self.diag_rescale = np.concatenate([np.ones(n), it.mu / np.sqrt(u_new)])
+        else:
+            self.diag_rescale = np.concatenate([np.ones(n) / math.sqrt(1.0 + float(np.max(np.abs(it.x)))), it.mu / np.sqrt(u_new)])
+        D = sp.diags(self.diag_rescale)
+        self.Q = (D @ M @ D).tolil()
+        self.schur_diag = compute_schur_diag(it)
+        self.true_x_diag = np.asarray(M.diagonal())[:n].copy()
+        self.ready = "system_formed"
+
+    def update_delta_vecs_b(self, delta_x_vec, delta_s_vec):  # clever_symmetric.jl:494-519
+        self.delta_x_vec, self.delta_s_vec = delta_x_vec, delta_s_vec
+        if np.sum(np.abs(delta_s_vec)) > 0.0:
+            raise NotImplementedError("not implemented")
+        if np.sum(np.abs(delta_x_vec)) > 0.0:
+            dg = np.asarray(self.Q.diagonal()).copy()
+            dg[: len(delta_x_vec)] = self.true_x_diag + delta_x_vec   # the UNscaled diagonal, as the reference does
+            self.Q.setdiag(dg)
+        self.ready = "delta_updated"
+
+    def factor_implementation_b(self):  # clever_symmetric.jl:395-400
+        n = self.factor_it.dim()
+        return self.ls_solver.ls_factor_b(self.Q.tocsc(), n, len(self.para_row_info))
+
+    def compute_direction_implementation_b(self):  # clever_symmetric.jl:417-492
+        fi, rhs = self.factor_it, self.rhs
+        symmetric_primal_rhs = rhs.primal_r + rhs.comp_r / fi.y
+        m = len(self.para_row_info)
+        crhs = np.zeros(m)
+        for i, grp in enumerate(self.para_row_info):
+            for row in grp.ls:
+                crhs[i] += row.g * symmetric_primal_rhs[row.ind]
+        my_rhs = np.concatenate([rhs.dual_r, crhs]) * self.diag_rescale
+        Qc = sp.csc_matrix(self.Q)
+        sol = np.zeros(len(my_rhs))
+        for i in range(self.pars.ItRefine_Num):                     # ls_solve with refinement, clever_symmetric.jl:402-415
+            err = my_rhs.copy() if i == 0 else my_rhs - vector_product(Qc, sol)
+            sol = sol + self.ls_solver.ls_solve(err)
+        dir_x_and_y = sol * self.diag_rescale
+        n = len(rhs.dual_r)
+        d = self.dir
+        d.x = dir_x_and_y[:n]
+        v = dir_x_and_y[n:]
+        y = (fi.s / fi.y) ** (-1.0) * symmetric_primal_rhs
+        for i, grp in enumerate(self.para_row_info):
+            tmp = -(crhs[i] + grp.u * v[i])
+            for row in grp.ls:
+                y[row.ind] += row.u ** (-1.0) * row.ratio * tmp
+        d.y = y
+        d.s = eval_jac_prod(fi, d.x) - rhs.primal_r
+        self.update_kkt_error_b()
+
+
 def ipopt_strategy_b(it, kkt_solver, pars=None):
     """delta_strategy.jl:37-114.  Returns (status, num_fac, delta) and the list of deltas tried."""
     pars = pars or kkt_solver.pars
@@ -331,4 +530,6 @@ def pick_KKT_solver(kkt_solver_type, perm=None, pars=None):
         return Symmetric_KKT_solver(linear_solver_ORACLE("symmetric", perm=perm), pars)
     if kkt_solver_type == "schur":
         return Schur_KKT_solver(linear_solver_ORACLE("definite", perm=perm), pars)
+    if kkt_solver_type == "clever_symmetric":
+        return Clever_Symmetric_KKT_solver(linear_solver_ORACLE("symmetric", perm=perm), pars)
     raise ValueError("pick a solver!")

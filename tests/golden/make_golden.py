@@ -208,6 +208,18 @@ def main():
     rec = problem_record("posdiag_indef5", Hl, J, grad, cons, xx, s, y, 0.1, loops["symmetric_prev0.0"]["delta"])
     rec["delta_loops"] = loops
     out["posdiag_indef5"] = rec
+    # --- Clever_Symmetric index work: the data and the integer answers of the reference's own unit tests
+    # (test/kkt_system_solvers.jl:5-41 test_compute_indicies, :49-58 test_compare_columns), 1-based as written there
+    out["compute_indicies"] = {
+        "J": [[1.0, 1.0, 1.0], [-1.0, -1.0, -1.0], [1.0, 0.0, 0.0], [0.0, 4.0, 3.0], [0.0, 2.0, 1.5], [3.0, 2.0, 1.0], [-2.0, -2.0, -2.0]],
+        "sorted_cols": [4, 5, 3, 6, 1, 2, 7],
+        "break_points": [1, 3, 4, 5],
+        "no_para_indicies": [1, 3, 4, 6],
+        "group_members": {"1": [[2, 2, -1.0], [3, 7, -2.0]], "3": [[2, 5, 0.5]]},   # group -> [position in ls, ind, ratio]
+        "singletons": [2, 4],                                                       # groups with u == u[first], g == 1
+        "compare_columns_A_rows": [[0.0, 10.0, 0.0], [1.0, 0.0, 1.0], [1.0, 0.0, 0.0], [2.0, 0.0, 0.0]],   # A = sparse(rows')'
+        "compare_columns": [[1, 2, True], [2, 1, False], [2, 3, False], [3, 2, True], [3, 1, False], [1, 3, True]],
+    }
     with open(os.path.join(HERE, "kkt_known_answers.json"), "w") as f:
         json.dump(out, f, indent=1)
     print("wrote", os.path.join(HERE, "kkt_known_answers.json"))

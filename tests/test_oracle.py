@@ -168,3 +168,60 @@ def test_state_machine_errors(golden):
         k.factor_b()             # not :delta_updated (kkt_system_solver.jl:195-199)
     with pytest.raises(RuntimeError):
         k.compute_direction_b()  # not :factored (kkt_system_solver.jl:181-183)
+
+
+# ---- Clever_Symmetric (clever_symmetric.jl): index work pinned on the reference's own unit-test data
+def test_compute_indicies_reference_goldens(golden):
+    g = golden["compute_indicies"]
+    J = sp.csc_matrix(np.array(g["J"]))
+    cols = KO._cols_of(J.T)
+    sorted_cols = KO.sorted_col_list(cols)
+    assert [c + 1 for c in sorted_cols] == g["sorted_cols"]                       # test/kkt_system_solvers.jl:17-18
+    assert [b + 1 for b in KO.compute_breakpoints(cols, sorted_cols)] == g["break_points"]   # :19-20
+    u = 1.0 / np.arange(1, J.shape[0] + 1)
+    no_para, info = KO.compute_indicies(J, u)
+    assert [i + 1 for i in no_para] == g["no_para_indicies"]                      # :24
+    assert [grp.first + 1 for grp in info] == g["no_para_indicies"]               # :25-27
+    for grp_no, members in g["group_members"].items():                            # :28-33 (exact float equality, as there)
+        for pos, ind, ratio in members:
+            row = info[int(grp_no) - 1].ls[pos - 1]
+            assert row.ind + 1 == ind and row.ratio == ratio
+    for grp_no in g["singletons"]:                                                # :36-39
+        grp = info[grp_no - 1]
+        assert grp.u == u[grp.first] and grp.ls[0].g == 1.0
+
+
+def test_compare_columns_reference_goldens(golden):
+    g = golden["compute_indicies"]
+    cols = KO._cols_of(sp.csc_matrix(np.array(g["compare_columns_A_rows"]).T))
+    for i, j, expect in g["compare_columns"]:                                     # test/kkt_system_solvers.jl:49-58
+        assert KO.compare_columns(cols, i - 1, j - 1) is expect
+
+
+def _oracle_direction(rec, kind, delta=1e-8, **kw):
+    it = iterate_from_record(rec, KO.Iterate)
+    k = KO.pick_KKT_solver(kind)
+    for a, b in kw.items():
+        setattr(k, a, b)
+    k.initialize_b(it)
+    k.form_system_b(it)
+    inertia = k.factor_b(delta)
+    k.kkt_associate_rhs_b(it, KO.Reduct_affine())
+    k.compute_direction_b()
+    return inertia, k
+
+
+@pytest.mark.parametrize("rescale", ["none", "u_only", "u_and_x"])
+def test_clever_symmetric_toy_lps(golden, rescale):
+    # test/kkt_system_solvers.jl:141-150: clever_symmetric directions agree with schur to 1e-6 on toy_lp0-8
+    merged = 0
+    for rec in golden["toy_lps"]:
+        i_c, kc = _oracle_direction(rec, "clever_symmetric", kkt_system_rescale=rescale)
+        i_s, ks = _oracle_direction(rec, "schur")
+        assert i_c == 1 and i_s == 1, rec["name"]
+        merged += rec["m"] - len(kc.para_row_info)
+        for a in ("x", "y", "s"):
+            assert np.linalg.norm(getattr(kc.dir, a) - getattr(ks.dir, a)) < 1e-6, (rec["name"], a)
+            assert np.linalg.norm(getattr(kc.dir, a) - np.array(rec["d" + a])) < 1e-6, (rec["name"], a)
+        assert kc.kkt_err_norm.ratio < 1e-8
+    assert merged > 0      # the toy LPs do contain parallel rows (two-sided constraints / duplicated bounds)
