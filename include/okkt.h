@@ -58,6 +58,12 @@ typedef enum {
 /* kkt_kind: pars.kkt.kkt_solver_type (parameters.jl:30) */
 #define OKKT_KKT_SCHUR 0      /* Q = H + J' diag(y/s) J       (n x n),     Cholesky semantics */
 #define OKKT_KKT_SYMMETRIC 1  /* K = [[H J'];[J -diag(s/y)]]  (n+m square), LDL^T inertia (n,m,0) */
+#define OKKT_KKT_CLEVER_SYMMETRIC 2  /* parallel rows of J merged first: M = [[H 0];[J_new -U_new]] (n+m_new square),
+                                      * inertia (n, m_new, 0); Clever_Symmetric_KKT_solver, clever_symmetric.jl:25-519 */
+/* kkt_system_rescale of the clever-symmetric system (parameters.jl:24-28, clever_symmetric.jl:307-325) */
+#define OKKT_RESCALE_NONE 0
+#define OKKT_RESCALE_U_ONLY 1
+#define OKKT_RESCALE_U_AND_X 2
 
 typedef struct {
   int32_t device;             /* HIP device ordinal; -1 = current device */
@@ -216,6 +222,22 @@ int okkt_kkt_compute_direction(okkt_kkt_handle k, const double* dual_r, const do
 int okkt_kkt_get_matrix(okkt_kkt_handle k, int64_t* dim_out, int64_t* nnz_out,
                         int64_t* colptr_out, int64_t* rowval_out, double* nzval_out);
 int okkt_kkt_get_schur_diag(okkt_kkt_handle k, double* out /* [n] */);
+
+/* ---- Clever_Symmetric only -------------------------------------------------------
+ * initialize!(::Clever_Symmetric_KKT_solver, it) = compute_indicies(get_jac(it)) (clever_symmetric.jl:53-61,
+ * 200-246): rows of J that are exact multiples of each other (same pattern, ||a_i - a_j * ratio||_2 < 1e-16)
+ * are grouped on the host with the reference's ordering rule (compare_columns, :107-155); the reduced matrix
+ * is analysed here.  Call once after okkt_kkt_set_structure and before the first okkt_kkt_form_system; the
+ * grouping is kept for the life of the handle, as in the reference. */
+int okkt_kkt_compute_indicies(okkt_kkt_handle k, const double* J_nzval, int64_t* m_new_out);
+/* the grouping, 0-based: first_para_indicies [m_new] (sorted first rows = para_row_info[g].first),
+ * group_ptr [m_new + 1], and per member in ls order: ind, ratio; after a form_system also u, g and the
+ * group's combined u (update_indicies!, clever_symmetric.jl:262-287).  Any pointer may be NULL. */
+int okkt_kkt_get_indicies(okkt_kkt_handle k, int64_t* first_para_indicies, int64_t* group_ptr, int64_t* member_ind,
+                          double* member_ratio, double* member_u, double* member_g, double* group_u);
+/* diag_rescale used by the next okkt_kkt_form_system: mode OKKT_RESCALE_*, mu = iter.point.mu,
+ * x_norm_inf = norm(iter.point.x, Inf) (create_diag_rescale_*, clever_symmetric.jl:307-319); default NONE */
+int okkt_kkt_set_rescale(okkt_kkt_handle k, int mode, double mu, double x_norm_inf);
 
 #ifdef __cplusplus
 }

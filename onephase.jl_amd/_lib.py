@@ -17,6 +17,8 @@ OKKT_SYM_DEFINITE = 0
 OKKT_SYM_SYMMETRIC = 1
 OKKT_KKT_SCHUR = 0
 OKKT_KKT_SYMMETRIC = 1
+OKKT_KKT_CLEVER_SYMMETRIC = 2
+OKKT_RESCALE = {"none": 0, "u_only": 1, "u_and_x": 2}
 
 OKKT_OK = 0
 OKKT_ERR_INVALID = -1
@@ -157,6 +159,9 @@ SIGNATURES = {
     "okkt_kkt_compute_direction": (C.c_int, [_vp, _f64p, _f64p, _f64p, C.c_int32, _f64p, _f64p, _f64p, C.POINTER(OkktKktError)]),
     "okkt_kkt_get_matrix": (C.c_int, [_vp, _i64p, _i64p, _i64p, _i64p, _f64p]),
     "okkt_kkt_get_schur_diag": (C.c_int, [_vp, _f64p]),
+    "okkt_kkt_compute_indicies": (C.c_int, [_vp, _f64p, C.POINTER(C.c_int64)]),
+    "okkt_kkt_get_indicies": (C.c_int, [_vp, _i64p, _i64p, _i64p, _f64p, _f64p, _f64p, _f64p]),
+    "okkt_kkt_set_rescale": (C.c_int, [_vp, C.c_int, C.c_double, C.c_double]),
 }
 
 _lib = None

@@ -49,6 +49,21 @@ struct okkt_kkt_s {
   double *rD = nullptr, *rP = nullptr, *rC = nullptr, *dx = nullptr, *dy = nullptr, *ds = nullptr;
   double *vn1 = nullptr, *vn2 = nullptr, *vn3 = nullptr, *vm1 = nullptr, *vm2 = nullptr, *big1 = nullptr, *big2 = nullptr;
   double* red = nullptr;  // reduction outputs
+  // ---- clever symmetric (clever_symmetric.jl): parallel-row groups and the reduced system
+  bool indexed = false;
+  int64_t m_new = 0;
+  int rescale_mode = OKKT_RESCALE_NONE;
+  double rescale_mu = 0.0, rescale_xinf = 0.0;
+  std::vector<int64_t> h_Jrp, h_Jrmap;           // host CSR view of J (kept for compute_indicies)
+  std::vector<int> h_Jrj;
+  std::vector<int64_t> h_Hp, h_Jp;               // host copies of the column pointers / row indices
+  std::vector<int> h_Hi, h_Ji;
+  std::vector<int64_t> h_first, h_gptr, h_mind;  // groups: first row, member ranges, member rows (ls order)
+  std::vector<double> h_mratio;
+  int64_t *gptr = nullptr, *mapJc = nullptr, *Arp = nullptr, *Armap = nullptr, *dAp = nullptr;
+  int *mind = nullptr, *row_grp = nullptr, *dAi = nullptr, *Arj = nullptr, *Hcol = nullptr, *Jcol = nullptr;
+  double *mratio = nullptr, *row_ratio = nullptr, *gU = nullptr, *rowg = nullptr, *Dres = nullptr, *true_x_diag = nullptr;
+  double *crhs = nullptr, *big3 = nullptr, *big4 = nullptr;
 };
 
 namespace {
@@ -252,6 +267,96 @@ __global__ __launch_bounds__(1024) void k_reduce(int64_t n, const double* __rest
   if (threadIdx.x == 0) *out = n > 0 ? sh[0] : (mode == 0 ? INFINITY : 0.0);
 }
 
+
+// ---- clever symmetric ------------------------------------------------------------------------------------
+// update_indicies! (clever_symmetric.jl:262-287): one thread per group, members in ls order
+__global__ void k_clever_groups(int64_t m_new, const int64_t* __restrict__ gptr, const int* __restrict__ mind,
+                                const double* __restrict__ mratio, const double* __restrict__ s, const double* __restrict__ y,
+                                double* __restrict__ gU, double* __restrict__ rowg) {
+  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= m_new) return;
+  double u_inv = 0.0;
+  for (int64_t t = gptr[g]; t < gptr[g + 1]; ++t) { const int j = mind[t]; const double u = s[j] / y[j]; u_inv += (mratio[t] * mratio[t]) * (1.0 / u); }
+  const double U = 1.0 / u_inv;
+  gU[g] = U;
+  for (int64_t t = gptr[g]; t < gptr[g + 1]; ++t) { const int j = mind[t]; const double u = s[j] / y[j]; rowg[j] = U * mratio[t] * (1.0 / u); }
+}
+// diag_rescale (clever_symmetric.jl:307-319)
+__global__ void k_clever_rescale(int64_t n, int64_t m_new, int mode, double mu, double xscale, const double* __restrict__ gU, double* __restrict__ D) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n + m_new) return;
+  if (i < n) D[i] = mode == OKKT_RESCALE_U_AND_X ? xscale : 1.0;
+  else D[i] = mode == OKKT_RESCALE_NONE ? 1.0 : mu / sqrt(gU[i - n]);
+}
+// Q = D M D, M = [[H 0];[J_new -U_new]] (lower): gather through precomputed slots, then the (2,2) diagonal
+__global__ void k_clever_assemble(int64_t nnzH, int64_t nnzJ, int64_t n, int64_t m_new, const double* __restrict__ Hx,
+                                  const double* __restrict__ Jx, const int64_t* __restrict__ mapH, const int64_t* __restrict__ mapJc,
+                                  const int* __restrict__ Hcol, const int* __restrict__ Jcol,
+                                  const int* __restrict__ Ai, const int64_t* __restrict__ diagA, const double* __restrict__ gU,
+                                  const double* __restrict__ D, double* __restrict__ A) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < nnzH) { const int64_t e = mapH[t]; A[e] = (D[Ai[e]] * Hx[t]) * D[Hcol[t]]; }
+  else if (t < nnzH + nnzJ) {
+    const int64_t p = t - nnzH, e = mapJc[p];
+    if (e >= 0) A[e] = (D[Ai[e]] * Jx[p]) * D[Jcol[p]];
+  } else if (t < nnzH + nnzJ + m_new) {
+    const int64_t g = t - nnzH - nnzJ;
+    A[diagA[n + g]] = (D[n + g] * -gU[g]) * D[n + g];
+  }
+}
+// true_x_diag = diag(M)[1:n] (unscaled H diagonal)
+__global__ void k_clever_true_diag(int64_t n, const int64_t* __restrict__ Hp, const int* __restrict__ Hi, const double* __restrict__ Hx, double* __restrict__ o) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  double v = 0.0;
+  for (int64_t p = Hp[j]; p < Hp[j + 1]; ++p) if (Hi[p] == j) v += Hx[p];
+  o[j] = v;
+}
+// update_delta_vecs! (clever_symmetric.jl:494-519): with delta > 0 the x diagonal becomes the UNscaled
+// true_x_diag (+ delta, added by the factorisation's shift), with delta == 0 it stays D^2 * true_x_diag
+__global__ void k_clever_xdiag(int64_t n, int delta_pos, const double* __restrict__ D, const double* __restrict__ tx, const int64_t* __restrict__ diagA, double* __restrict__ A) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < n) A[diagA[j]] = delta_pos ? tx[j] : (D[j] * tx[j]) * D[j];
+}
+__global__ void k_clever_symrhs(int64_t m, const double* rP, const double* rC, const double* y, double* o) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < m) o[i] = rP[i] + rC[i] / y[i];
+}
+__global__ void k_clever_crhs(int64_t m_new, const int64_t* __restrict__ gptr, const int* __restrict__ mind, const double* __restrict__ rowg,
+                              const double* __restrict__ symrhs, double* __restrict__ crhs) {
+  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= m_new) return;
+  double v = 0.0;
+  for (int64_t t = gptr[g]; t < gptr[g + 1]; ++t) { const int j = mind[t]; v += rowg[j] * symrhs[j]; }
+  crhs[g] = v;
+}
+__global__ void k_clever_rhs(int64_t n, int64_t m_new, const double* rD, const double* crhs, const double* D, double* o) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) o[i] = rD[i] * D[i];
+  else if (i < n + m_new) o[i] = crhs[i - n] * D[i];
+}
+// err = rhs - (Q sol), Q carrying delta on its first n diagonal entries
+__global__ void k_clever_res(int64_t dim, int64_t n, double delta, const double* rhs, const double* qx, const double* sol, double* err) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < dim) err[i] = rhs[i] - (qx[i] + (i < n ? delta * sol[i] : 0.0));
+}
+__global__ void k_clever_unscale(int64_t n, int64_t m_new, const double* sol, const double* D, double* dx, double* v) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dx[i] = sol[i] * D[i];
+  else if (i < n + m_new) v[i - n] = sol[i] * D[i];
+}
+// dir.y (clever_symmetric.jl:457-474): y_j = u_j^-1 symrhs_j + u_j^-1 ratio_j * (-(crhs_g + U_g v_g)), g = group of row j
+__global__ void k_clever_y(int64_t m, const int* __restrict__ row_grp, const double* __restrict__ row_ratio, const double* __restrict__ s,
+                           const double* __restrict__ y, const double* __restrict__ symrhs, const double* __restrict__ crhs,
+                           const double* __restrict__ gU, const double* __restrict__ v, double* __restrict__ dy) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= m) return;
+  const double uinv = 1.0 / (s[j] / y[j]);
+  const int g = row_grp[j];
+  const double tmp = -(crhs[g] + gU[g] * v[g]);
+  dy[j] = uinv * symrhs[j] + (uinv * row_ratio[j]) * tmp;
+}
+
 int kk_fail(okkt_kkt_s* k, int code, const std::string& msg) { k->err = msg; return code; }
 
 int kk_check_ls(okkt_kkt_s* k, int rc, const char* what) {
@@ -299,7 +404,7 @@ int okkt_kkt_default_pars(okkt_kkt_pars* p) {
 int okkt_kkt_create(okkt_kkt_handle* out, const okkt_opts* opts, int kkt_kind) {
   if (!out) return OKKT_ERR_INVALID;
   *out = nullptr;
-  if (kkt_kind != OKKT_KKT_SCHUR && kkt_kind != OKKT_KKT_SYMMETRIC) return OKKT_ERR_INVALID;
+  if (kkt_kind != OKKT_KKT_SCHUR && kkt_kind != OKKT_KKT_SYMMETRIC && kkt_kind != OKKT_KKT_CLEVER_SYMMETRIC) return OKKT_ERR_INVALID;
   okkt_kkt_s* k = new (std::nothrow) okkt_kkt_s();
   if (!k) return OKKT_ERR_ALLOC;
   k->kind = kkt_kind;
@@ -368,7 +473,17 @@ int okkt_kkt_set_structure(okkt_kkt_handle k, int64_t n, int64_t m, const int64_
     UPL(Hp, Hp); UPL(Hi, Hi); UPL(Hrp, Hrp); UPL(Hrj, Hrj); UPL(Hrmap, Hrmap);
     UPL(Jp, Jp); UPL(Ji, Ji); UPL(Jrp, Jrp); UPL(Jrj, Jrj); UPL(Jrmap, Jrmap);
     // ---- pattern of the matrix that is factorised
-    if (k->kind == OKKT_KKT_SYMMETRIC) {
+    if (k->kind == OKKT_KKT_CLEVER_SYMMETRIC) {
+      // the reduced pattern depends on the values of J (parallel rows): built by okkt_kkt_compute_indicies
+      k->h_Hp = Hp; k->h_Hi = Hi; k->h_Jp = Jp; k->h_Ji = Ji; k->h_Jrp = Jrp; k->h_Jrj = Jrj; k->h_Jrmap = Jrmap;
+      std::vector<int> Hcol(nnzH), Jcol(nnzJ);
+      for (int64_t j = 0; j < n; ++j) {
+        for (int64_t p = Hp[j]; p < Hp[j + 1]; ++p) Hcol[p] = (int)j;
+        for (int64_t p = Jp[j]; p < Jp[j + 1]; ++p) Jcol[p] = (int)j;
+      }
+      UPL(Hcol, Hcol); UPL(Jcol, Jcol);
+      k->dimA = 0; k->nnzA = 0;
+    } else if (k->kind == OKKT_KKT_SYMMETRIC) {
       const int64_t dim = n + m;
       k->dimA = dim;
       std::vector<int64_t> Ap(dim + 1, 0), Ai, mapH(nnzH), mapJ(nnzJ), diagA(dim);
@@ -445,6 +560,14 @@ int okkt_kkt_set_structure(okkt_kkt_handle k, int64_t n, int64_t m, const int64_
         (rc = kk_alloc(k, (size_t)n, &k->vn3)) || (rc = kk_alloc(k, (size_t)m, &k->vm1)) || (rc = kk_alloc(k, (size_t)m, &k->vm2)) ||
         (rc = kk_alloc(k, (size_t)(n + m), &k->big1)) || (rc = kk_alloc(k, (size_t)(n + m), &k->big2)) || (rc = kk_alloc(k, (size_t)8, &k->red)))
       return rc;
+    if (k->kind == OKKT_KKT_CLEVER_SYMMETRIC) {
+      if ((rc = kk_alloc(k, (size_t)m, &k->rowg)) || (rc = kk_alloc(k, (size_t)n, &k->true_x_diag)) ||
+          (rc = kk_alloc(k, (size_t)(n + m), &k->big3)) || (rc = kk_alloc(k, (size_t)(n + m), &k->big4)) ||
+          (rc = kk_alloc(k, (size_t)(n + m), &k->Dres)) || (rc = kk_alloc(k, (size_t)m, &k->crhs)) || (rc = kk_alloc(k, (size_t)m, &k->gU)))
+        return rc;
+      k->structured = true;
+      return OKKT_OK;
+    }
     rc = okkt_analyze(k->ls, k->dimA, k->Ap.data(), k->Ai.data(), 0);
     if (rc != OKKT_OK) return kk_check_ls(k, rc, "okkt_analyze");
     k->structured = true;
@@ -459,6 +582,7 @@ int okkt_kkt_set_structure(okkt_kkt_handle k, int64_t n, int64_t m, const int64_
 int okkt_kkt_form_system(okkt_kkt_handle k, const double* H_nzval, const double* J_nzval, const double* s, const double* y) {
   if (!k || !s || !y) return OKKT_ERR_INVALID;
   if (!k->structured) return kk_fail(k, OKKT_ERR_INVALID, "okkt_kkt_set_structure has not been called");
+  if (k->kind == OKKT_KKT_CLEVER_SYMMETRIC && !k->indexed) return kk_fail(k, OKKT_ERR_INVALID, "okkt_kkt_compute_indicies has not been called (initialize!, clever_symmetric.jl:53-61)");
   if ((k->nnzH > 0 && !H_nzval) || (k->nnzJ > 0 && !J_nzval)) return OKKT_ERR_INVALID;
   hipStream_t st = kk_stream(k);
   KK_TRY(k, hipSetDevice(k->ls->device));
@@ -469,7 +593,21 @@ int okkt_kkt_form_system(okkt_kkt_handle k, const double* H_nzval, const double*
     KK_TRY(k, hipMemcpyAsync(k->y, y, (size_t)k->m * 8, hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(k_div, grid1(k->m), dim3(256), 0, st, k->m, k->y, k->s, k->sig);   // y ./ s
   }
-  if (k->kind == OKKT_KKT_SYMMETRIC) {
+  if (k->kind == OKKT_KKT_CLEVER_SYMMETRIC) {
+    // form_system!(::Clever_Symmetric_KKT_solver), clever_symmetric.jl:341-393
+    KK_TRY(k, hipMemsetAsync(k->Avals, 0, (size_t)std::max<int64_t>(k->nnzA, 1) * 8, st));
+    const int64_t mn = k->m_new;
+    if (mn) hipLaunchKernelGGL(k_clever_groups, grid1(mn), dim3(256), 0, st, mn, k->gptr, k->mind, k->mratio, k->s, k->y, k->gU, k->rowg);
+    const double xscale = 1.0 / std::sqrt(1.0 + k->rescale_xinf);
+    if (k->n + mn) hipLaunchKernelGGL(k_clever_rescale, grid1(k->n + mn), dim3(256), 0, st, k->n, mn, k->rescale_mode, k->rescale_mu, xscale, k->gU, k->Dres);
+    const int64_t tot = k->nnzH + k->nnzJ + mn;
+    if (tot) hipLaunchKernelGGL(k_clever_assemble, grid1(tot), dim3(256), 0, st, k->nnzH, k->nnzJ, k->n, mn, k->Hx, k->Jx, k->mapH, k->mapJc,
+                                k->Hcol, k->Jcol, k->dAi, k->diagA, k->gU, k->Dres, k->Avals);
+    if (k->n) {
+      hipLaunchKernelGGL(k_clever_true_diag, grid1(k->n), dim3(256), 0, st, k->n, k->Hp, k->Hi, k->Hx, k->true_x_diag);
+      hipLaunchKernelGGL(k_schur_diag, grid1(k->n), dim3(256), 0, st, k->n, k->Jp, k->Ji, k->Jx, k->sig, k->Hp, k->Hi, k->Hx, k->schur_diag);
+    }
+  } else if (k->kind == OKKT_KKT_SYMMETRIC) {
     KK_TRY(k, hipMemsetAsync(k->Avals, 0, (size_t)std::max<int64_t>(k->nnzA, 1) * 8, st));
     const int64_t tot = k->nnzH + k->nnzJ + k->m;
     if (tot) hipLaunchKernelGGL(k_assemble_aug, grid1(tot), dim3(256), 0, st, k->nnzH, k->nnzJ, k->n, k->m, k->Hx, k->Jx, k->s, k->y, k->mapH, k->mapJ, k->diagA, k->Avals);
@@ -501,7 +639,10 @@ int okkt_kkt_factor(okkt_kkt_handle k, double delta, okkt_inertia* inertia_out) 
   k->delta = delta;
   // the first n diagonal entries move, the (2,2) block never does (symmetric.jl:85-102)
   launch_set_shift(k->ls->N, delta, k->n);
-  if (k->kind == OKKT_KKT_SYMMETRIC) rc = solver_factor_device(k->ls, k->Avals, k->n, k->m, OKKT_SYM_SYMMETRIC, inertia_out);
+  if (k->kind == OKKT_KKT_CLEVER_SYMMETRIC) {
+    if (k->n) hipLaunchKernelGGL(k_clever_xdiag, grid1(k->n), dim3(256), 0, kk_stream(k), k->n, delta > 0.0 ? 1 : 0, k->Dres, k->true_x_diag, k->diagA, k->Avals);
+    rc = solver_factor_device(k->ls, k->Avals, k->n, k->m_new, OKKT_SYM_SYMMETRIC, inertia_out);   // clever_symmetric.jl:395-400
+  } else if (k->kind == OKKT_KKT_SYMMETRIC) rc = solver_factor_device(k->ls, k->Avals, k->n, k->m, OKKT_SYM_SYMMETRIC, inertia_out);
   else rc = solver_factor_device(k->ls, k->Avals, k->n, 0, OKKT_SYM_DEFINITE, inertia_out);
   if (rc < 0) return kk_check_ls(k, rc, "factor");
   k->factored = true;
@@ -618,6 +759,31 @@ int okkt_kkt_compute_direction(okkt_kkt_handle k, const double* dual_r, const do
       }
     }
     if (m) { spmv_J(k, k->dx, k->vm1); hipLaunchKernelGGL(k_schur_dyds, grid1(m), dim3(256), 0, st, m, k->vm1, k->rP, k->rC, k->y, k->sig, k->dy, k->ds); }
+  } else if (k->kind == OKKT_KKT_CLEVER_SYMMETRIC) {
+    // compute_direction_implementation!(::Clever_Symmetric_KKT_solver), clever_symmetric.jl:417-492
+    const int64_t mn = k->m_new, dim = n + mn;
+    if (m) hipLaunchKernelGGL(k_clever_symrhs, grid1(m), dim3(256), 0, st, m, k->rP, k->rC, k->y, k->vm1);
+    if (mn) hipLaunchKernelGGL(k_clever_crhs, grid1(mn), dim3(256), 0, st, mn, k->gptr, k->mind, k->rowg, k->vm1, k->crhs);
+    if (dim) {
+      hipLaunchKernelGGL(k_clever_rhs, grid1(dim), dim3(256), 0, st, n, mn, k->rD, k->crhs, k->Dres, k->big1);   // rescaled rhs
+      KK_TRY(k, hipMemsetAsync(k->big2, 0, (size_t)dim * 8, st));                                                  // sol
+    }
+    for (int it = 0; it < ItRefine_Num; ++it) {       // ls_solve with refinement, clever_symmetric.jl:402-415
+      if (it == 0) { if (dim) KK_TRY(k, hipMemcpyAsync(k->big3, k->big1, (size_t)dim * 8, hipMemcpyDeviceToDevice, st)); }
+      else if (dim) {
+        hipLaunchKernelGGL(k_spmv_symlower, grid1(dim), dim3(256), 0, st, dim, k->dAp, k->dAi, k->Avals, k->Arp, k->Arj, k->Armap, k->big2, k->big4);
+        hipLaunchKernelGGL(k_clever_res, grid1(dim), dim3(256), 0, st, dim, n, k->delta, k->big1, k->big4, k->big2, k->big3);
+      }
+      rc = solver_solve_device(k->ls, k->big3, k->big4, 1);
+      if (rc != OKKT_OK) return kk_check_ls(k, rc, "ls_solve");
+      if (dim) hipLaunchKernelGGL(k_add, grid1(dim), dim3(256), 0, st, dim, k->big2, k->big4, k->big2);
+    }
+    if (dim) hipLaunchKernelGGL(k_clever_unscale, grid1(dim), dim3(256), 0, st, n, mn, k->big2, k->Dres, k->dx, k->big4);   // big4 = v
+    if (m) {
+      hipLaunchKernelGGL(k_clever_y, grid1(m), dim3(256), 0, st, m, k->row_grp, k->row_ratio, k->s, k->y, k->vm1, k->crhs, k->gU, k->big4, k->dy);
+      spmv_J(k, k->dx, k->vm2);
+      hipLaunchKernelGGL(k_sub, grid1(m), dim3(256), 0, st, m, k->vm2, k->rP, k->ds);
+    }
   } else {
     // symmetric.jl:59-83
     if (n + m) hipLaunchKernelGGL(k_sym_rhs, grid1(n + m), dim3(256), 0, st, n, m, k->rD, k->rP, k->rC, k->y, k->big1);
@@ -659,6 +825,165 @@ int okkt_kkt_compute_direction(okkt_kkt_handle k, const double* dual_r, const do
   }
   KK_TRY(k, hipStreamSynchronize(st));
   KK_TRY(k, hipGetLastError());
+  return OKKT_OK;
+}
+
+int okkt_kkt_set_rescale(okkt_kkt_handle k, int mode, double mu, double x_norm_inf) {
+  if (!k) return OKKT_ERR_INVALID;
+  if (k->kind != OKKT_KKT_CLEVER_SYMMETRIC) return kk_fail(k, OKKT_ERR_INVALID, "kkt_system_rescale applies to the clever-symmetric solver only");
+  if (mode != OKKT_RESCALE_NONE && mode != OKKT_RESCALE_U_ONLY && mode != OKKT_RESCALE_U_AND_X) return kk_fail(k, OKKT_ERR_INVALID, "unknown rescale mode");
+  k->rescale_mode = mode; k->rescale_mu = mu; k->rescale_xinf = x_norm_inf;
+  return OKKT_OK;
+}
+
+int okkt_kkt_compute_indicies(okkt_kkt_handle k, const double* J_nzval, int64_t* m_new_out) {
+  if (!k) return OKKT_ERR_INVALID;
+  if (k->kind != OKKT_KKT_CLEVER_SYMMETRIC) return kk_fail(k, OKKT_ERR_INVALID, "compute_indicies applies to the clever-symmetric solver only");
+  if (!k->structured) return kk_fail(k, OKKT_ERR_INVALID, "okkt_kkt_set_structure has not been called");
+  if (k->indexed) return kk_fail(k, OKKT_ERR_INVALID, "the parallel-row grouping is computed once per handle (clever_symmetric.jl:53-61)");
+  if (k->nnzJ > 0 && !J_nzval) return OKKT_ERR_INVALID;
+  try {
+    const int64_t n = k->n, m = k->m;
+    const std::vector<int64_t>& rp = k->h_Jrp;
+    const std::vector<int>& rj = k->h_Jrj;
+    // rows of J = columns of J_T: indices ascending, values in stored order; rescaled = divided by the first value
+    std::vector<double> val(k->nnzJ), sc(k->nnzJ);
+    for (int64_t i = 0; i < m; ++i)
+      for (int64_t q = rp[i]; q < rp[i + 1]; ++q) { val[q] = J_nzval[k->h_Jrmap[q]]; sc[q] = val[q] / val[rp[i]]; }
+    auto len = [&](int64_t i) { return rp[i + 1] - rp[i]; };
+    // compare_columns on the rescaled matrix (clever_symmetric.jl:107-155): strict order "i before j"
+    auto before = [&](int64_t i, int64_t j) -> bool {
+      if (len(j) == 0) return false;
+      if (len(i) == 0) return true;
+      if (rj[rp[i]] != rj[rp[j]]) return rj[rp[j]] < rj[rp[i]];     // larger first index sorts first
+      if (len(i) != len(j)) return len(i) < len(j);
+      for (int64_t t = 0; t < len(i); ++t) if (rj[rp[i] + t] != rj[rp[j] + t]) return rj[rp[i] + t] < rj[rp[j] + t];
+      for (int64_t t = 0; t < len(i); ++t) {
+        if (sc[rp[i] + t] < sc[rp[j] + t]) return true;
+        if (sc[rp[i] + t] > sc[rp[j] + t]) return false;
+      }
+      return i < j;
+    };
+    std::vector<int64_t> sorted_cols(m);
+    std::iota(sorted_cols.begin(), sorted_cols.end(), (int64_t)0);
+    std::sort(sorted_cols.begin(), sorted_cols.end(), before);
+    // columns_are_same on the UNscaled matrix (clever_symmetric.jl:63-88)
+    auto same = [&](int64_t i, int64_t j) -> bool {
+      if (len(i) != len(j)) return false;
+      for (int64_t t = 0; t < len(i); ++t) if (rj[rp[i] + t] != rj[rp[j] + t]) return false;
+      if (len(i) == 0) return true;
+      const double ratio = val[rp[i]] / val[rp[j]];
+      double ss = 0.0;
+      for (int64_t t = 0; t < len(i); ++t) { const double d = val[rp[i] + t] - val[rp[j] + t] * ratio; ss += d * d; }
+      return std::sqrt(ss) < 1e-16;
+    };
+    struct Grp { int64_t first; std::vector<int64_t> ind; std::vector<double> ratio; };
+    std::vector<Grp> groups;
+    for (int64_t bp = 0; bp < m; ++bp) {
+      const int64_t cur = sorted_cols[bp];
+      if (bp == 0 || !same(sorted_cols[bp - 1], cur)) { groups.push_back(Grp{cur, {}, {}}); }
+      Grp& g = groups.back();
+      double ratio = 1.0;
+      if (cur != g.first) {
+        ratio = len(cur) > 0 ? val[rp[cur]] / val[rp[g.first]] : 1.0;
+        if (ratio == 0.0 || !std::isfinite(ratio)) return kk_fail(k, OKKT_ERR_INVALID, "clever_symmetric.jl: ratio = 0, NaN or Inf between parallel rows");
+      }
+      g.ind.push_back(cur);
+      g.ratio.push_back(ratio);
+    }
+    std::sort(groups.begin(), groups.end(), [](const Grp& a, const Grp& b) { return a.first < b.first; });
+    const int64_t mn = (int64_t)groups.size();
+    k->m_new = mn;
+    k->h_first.resize(mn); k->h_gptr.assign(mn + 1, 0); k->h_mind.clear(); k->h_mratio.clear();
+    std::vector<int> mind, row_grp(m, 0), grp_of_first_row(m, -1);
+    std::vector<double> row_ratio(m, 1.0);
+    for (int64_t g = 0; g < mn; ++g) {
+      k->h_first[g] = groups[g].first;
+      grp_of_first_row[groups[g].first] = (int)g;
+      for (size_t t = 0; t < groups[g].ind.size(); ++t) {
+        k->h_mind.push_back(groups[g].ind[t]); k->h_mratio.push_back(groups[g].ratio[t]);
+        mind.push_back((int)groups[g].ind[t]);
+        row_grp[groups[g].ind[t]] = (int)g; row_ratio[groups[g].ind[t]] = groups[g].ratio[t];
+      }
+      k->h_gptr[g + 1] = (int64_t)k->h_mind.size();
+    }
+    // ---- pattern of M = [[H 0];[J_new -U_new]] (lower), J_new = J[first rows, :] (clever_symmetric.jl:357-367)
+    const int64_t dim = n + mn;
+    k->dimA = dim;
+    std::vector<int64_t> Ap(dim + 1, 0), Ai, mapH(k->nnzH), mapJc(k->nnzJ, -1), diagA(dim);
+    for (int64_t j = 0; j < n; ++j) {
+      bool has_diag = false;
+      for (int64_t p = k->h_Hp[j]; p < k->h_Hp[j + 1]; ++p) has_diag |= k->h_Hi[p] == j;
+      diagA[j] = (int64_t)Ai.size();
+      if (!has_diag) Ai.push_back(j);
+      for (int64_t p = k->h_Hp[j]; p < k->h_Hp[j + 1]; ++p) {
+        if (k->h_Hi[p] == j) diagA[j] = (int64_t)Ai.size();
+        mapH[p] = (int64_t)Ai.size();
+        Ai.push_back(k->h_Hi[p]);
+      }
+      // rows of J that lead a group, in increasing group order (= increasing row order: groups are sorted by first)
+      for (int64_t p = k->h_Jp[j]; p < k->h_Jp[j + 1]; ++p) {
+        const int g = grp_of_first_row[k->h_Ji[p]];
+        if (g >= 0) { mapJc[p] = (int64_t)Ai.size(); Ai.push_back(n + g); }
+      }
+      Ap[j + 1] = (int64_t)Ai.size();
+    }
+    for (int64_t g = 0; g < mn; ++g) { diagA[n + g] = (int64_t)Ai.size(); Ai.push_back(n + g); Ap[n + g + 1] = (int64_t)Ai.size(); }
+    k->nnzA = (int64_t)Ai.size();
+    k->Ap = Ap; k->Ai = Ai;
+    // CSR view of the lower pattern for the symmetric product of the refinement (vector_product, eval.jl:221-230)
+    std::vector<int64_t> Arp(dim + 1, 0), Armap(k->nnzA);
+    std::vector<int> Arj(k->nnzA), dAi(k->nnzA);
+    for (int64_t e = 0; e < k->nnzA; ++e) { dAi[e] = (int)Ai[e]; ++Arp[Ai[e] + 1]; }
+    for (int64_t i = 0; i < dim; ++i) Arp[i + 1] += Arp[i];
+    {
+      std::vector<int64_t> fill(Arp.begin(), Arp.end() - 1);
+      for (int64_t j = 0; j < dim; ++j)
+        for (int64_t e = Ap[j]; e < Ap[j + 1]; ++e) { const int64_t q = fill[Ai[e]]++; Arj[q] = (int)j; Armap[q] = e; }
+    }
+    int rc;
+#define UPL(dst, vec) if ((rc = kk_upload(k, vec, &k->dst)) != OKKT_OK) return rc
+    UPL(gptr, k->h_gptr); UPL(mind, mind); UPL(mratio, k->h_mratio); UPL(row_grp, row_grp); UPL(row_ratio, row_ratio);
+    UPL(mapH, mapH); UPL(mapJc, mapJc); UPL(diagA, diagA); UPL(dAp, Ap); UPL(dAi, dAi); UPL(Arp, Arp); UPL(Arj, Arj); UPL(Armap, Armap);
+#undef UPL
+    if ((rc = kk_alloc(k, (size_t)k->nnzA, &k->Avals))) return rc;
+    rc = okkt_analyze(k->ls, k->dimA, k->Ap.data(), k->Ai.data(), 0);
+    if (rc != OKKT_OK) return kk_check_ls(k, rc, "okkt_analyze");
+    k->indexed = true;
+    if (m_new_out) *m_new_out = mn;
+    return OKKT_OK;
+  } catch (const std::bad_alloc&) {
+    return kk_fail(k, OKKT_ERR_ALLOC, "out of host memory in okkt_kkt_compute_indicies");
+  } catch (...) {
+    return kk_fail(k, OKKT_ERR_INTERNAL, "unexpected exception in okkt_kkt_compute_indicies");
+  }
+}
+
+int okkt_kkt_get_indicies(okkt_kkt_handle k, int64_t* first_para_indicies, int64_t* group_ptr, int64_t* member_ind,
+                          double* member_ratio, double* member_u, double* member_g, double* group_u) {
+  if (!k) return OKKT_ERR_INVALID;
+  if (!k->indexed) return kk_fail(k, OKKT_ERR_INVALID, "okkt_kkt_compute_indicies has not been called");
+  if (first_para_indicies) std::copy(k->h_first.begin(), k->h_first.end(), first_para_indicies);
+  if (group_ptr) std::copy(k->h_gptr.begin(), k->h_gptr.end(), group_ptr);
+  if (member_ind) std::copy(k->h_mind.begin(), k->h_mind.end(), member_ind);
+  if (member_ratio) std::copy(k->h_mratio.begin(), k->h_mratio.end(), member_ratio);
+  if (member_u || member_g || group_u) {
+    if (!k->formed) return kk_fail(k, OKKT_ERR_INVALID, "u and g exist after form_system (update_indicies!)");
+    KK_TRY(k, hipStreamSynchronize(kk_stream(k)));
+    const int64_t m = k->m;
+    std::vector<double> s(m), y(m), rowg(m);
+    if (m) {
+      KK_TRY(k, hipMemcpy(s.data(), k->s, (size_t)m * 8, hipMemcpyDeviceToHost));
+      KK_TRY(k, hipMemcpy(y.data(), k->y, (size_t)m * 8, hipMemcpyDeviceToHost));
+      KK_TRY(k, hipMemcpy(rowg.data(), k->rowg, (size_t)m * 8, hipMemcpyDeviceToHost));
+    }
+    for (size_t t = 0; t < k->h_mind.size(); ++t) {
+      const int64_t j = k->h_mind[t];
+      if (member_u) member_u[t] = s[j] / y[j];
+      if (member_g) member_g[t] = rowg[j];
+    }
+    if (group_u && k->m_new) KK_TRY(k, hipMemcpy(group_u, k->gU, (size_t)k->m_new * 8, hipMemcpyDeviceToHost));
+  }
   return OKKT_OK;
 }
 

@@ -87,6 +87,7 @@ class Class_kkt_solver_options:   # parameters.jl:4-46 (the entries the path rea
     kkt_solver_type: str = "schur"
     linear_solver_type: str = "HIP"
     ItRefine_Num: int = 3
+    kkt_system_rescale: str = "none"    # parameters.jl:24 (:none | :u_only | :u_and_x), clever_symmetric only
 
 
 @dataclass
@@ -117,10 +118,13 @@ def _csc(A):
 
 
 class HIP_KKT_solver:
-    """abstract_KKT_system_solver backed by the device-resident KKT path (kind = 'schur' | 'symmetric')."""
+    """abstract_KKT_system_solver backed by the device-resident KKT path
+    (kind = 'schur' | 'symmetric' | 'clever_symmetric')."""
+
+    _KINDS = {"schur": L.OKKT_KKT_SCHUR, "symmetric": L.OKKT_KKT_SYMMETRIC, "clever_symmetric": L.OKKT_KKT_CLEVER_SYMMETRIC}
 
     def __init__(self, kind, pars=None, **opts):
-        if kind not in ("schur", "symmetric"):
+        if kind not in self._KINDS:
             raise OkktError("pick a solver!")          # kkt_system_solver.jl:280
         self.kind = kind
         self.pars = pars or Class_parameters()
@@ -147,12 +151,50 @@ class HIP_KKT_solver:
             for key, v in self._opts.items():
                 setattr(o, key, v)
             k = C.c_void_p()
-            rc = self._lib.okkt_kkt_create(C.byref(k), C.byref(o), L.OKKT_KKT_SCHUR if self.kind == "schur" else L.OKKT_KKT_SYMMETRIC)
+            rc = self._lib.okkt_kkt_create(C.byref(k), C.byref(o), self._KINDS[self.kind])
             if rc != L.OKKT_OK:
                 raise OkktError(f"okkt_kkt_create failed with code {rc}"
                                 + (" (no HIP device: the KKT path has no CPU fallback)" if rc == L.OKKT_ERR_NO_DEVICE else ""))
             self._k = k
         self.dir = Class_point(np.zeros(intial_it.dim()), np.zeros(intial_it.ncon()), np.zeros(intial_it.ncon()))
+        if self.kind == "clever_symmetric" and self._pattern is None:
+            # initialize!(::Clever_Symmetric_KKT_solver, it): compute_indicies(get_jac(it)), clever_symmetric.jl:53-61
+            self._set_structure(intial_it)
+            J = _csc(intial_it.J)
+            Jx = L.f64(J.data)
+            m_new = C.c_int64()
+            self._check(self._lib.okkt_kkt_compute_indicies(self._k, L.p_f64(Jx), C.byref(m_new)), "okkt_kkt_compute_indicies")
+            self.m_new = m_new.value
+            self.first_para_indicies, self.para_row_info = self.get_indicies()
+
+    def _set_structure(self, it):
+        H, J = _csc(it.H), _csc(it.J)
+        n, m = it.dim(), it.ncon()
+        key = (n, m, H.indptr.tobytes(), H.indices.tobytes(), J.indptr.tobytes(), J.indices.tobytes())
+        if self._pattern is None:
+            Hp, Hi, Jp, Ji = L.i64(H.indptr), L.i64(H.indices), L.i64(J.indptr), L.i64(J.indices)
+            self._check(self._lib.okkt_kkt_set_structure(self._k, n, m, L.p_i64(Hp), L.p_i64(Hi), L.p_i64(Jp), L.p_i64(Ji), 0),
+                        "okkt_kkt_set_structure")
+            self._pattern = key
+            self._m = m
+        elif key != self._pattern:
+            raise OkktError("the sparsity pattern of H / J changed: create a new HIP_KKT_solver")
+        return H, J, n, m
+
+    def get_indicies(self, with_values=False):
+        """(first_para_indicies, para_row_info) of the clever-symmetric solver, 0-based; para_row_info[g] =
+        dict(first, u, ls=[dict(ind, ratio, u, g)]) like Parallel_row_group / Parallel_row (clever_symmetric.jl:4-19)."""
+        m = self._m
+        mn = self.m_new
+        first, gptr, ind = np.zeros(mn, np.int64), np.zeros(mn + 1, np.int64), np.zeros(m, np.int64)
+        ratio, mu, mg, gu = np.zeros(m), np.full(m, np.nan), np.full(m, np.nan), np.full(mn, np.nan)
+        self._check(self._lib.okkt_kkt_get_indicies(self._k, L.p_i64(first), L.p_i64(gptr), L.p_i64(ind), L.p_f64(ratio),
+                                                    L.p_f64(mu) if with_values else None, L.p_f64(mg) if with_values else None,
+                                                    L.p_f64(gu) if with_values else None), "okkt_kkt_get_indicies")
+        info = [dict(first=int(first[g]), u=float(gu[g]),
+                     ls=[dict(ind=int(ind[t]), ratio=float(ratio[t]), u=float(mu[t]), g=float(mg[t])) for t in range(gptr[g], gptr[g + 1])])
+                for g in range(mn)]
+        return [int(v) for v in first], info
 
     def finalize_b(self):
         if self._k is not None:
@@ -175,16 +217,12 @@ class HIP_KKT_solver:
     def form_system_b(self, it, timer=None):
         if self._k is None:
             raise OkktError("initialize_b has not been called")
-        H, J = _csc(it.H), _csc(it.J)
-        n, m = it.dim(), it.ncon()
-        key = (n, m, H.indptr.tobytes(), H.indices.tobytes(), J.indptr.tobytes(), J.indices.tobytes())
-        if self._pattern is None:
-            Hp, Hi, Jp, Ji = L.i64(H.indptr), L.i64(H.indices), L.i64(J.indptr), L.i64(J.indices)
-            self._check(self._lib.okkt_kkt_set_structure(self._k, n, m, L.p_i64(Hp), L.p_i64(Hi), L.p_i64(Jp), L.p_i64(Ji), 0),
-                        "okkt_kkt_set_structure")
-            self._pattern = key
-        elif key != self._pattern:
-            raise OkktError("the sparsity pattern of H / J changed: create a new HIP_KKT_solver")
+        H, J, n, m = self._set_structure(it)
+        if self.kind == "clever_symmetric":
+            if not np.all(it.s / it.y > 0.0):
+                raise OkktError("assert all(u .> 0.0)")          # clever_symmetric.jl:352
+            mode = L.OKKT_RESCALE[self.pars.kkt.kkt_system_rescale]
+            self._check(self._lib.okkt_kkt_set_rescale(self._k, mode, float(it.mu), float(np.max(np.abs(it.x))) if n else 0.0), "okkt_kkt_set_rescale")
         Hx, Jx, s, y = L.f64(H.data), L.f64(J.data), L.f64(it.s), L.f64(it.y)
         self._check(self._lib.okkt_kkt_form_system(self._k, L.p_f64(Hx), L.p_f64(Jx), L.p_f64(s), L.p_f64(y)), "okkt_kkt_form_system")
         sd = np.zeros(n)
@@ -300,6 +338,6 @@ def pick_KKT_solver(pars):
     """kkt_system_solver.jl:232-287 with the `linear_solver_type == :HIP` branch."""
     if pars.kkt.linear_solver_type != "HIP":
         raise OkktError("pick a valid solver!")
-    if pars.kkt.kkt_solver_type in ("schur", "symmetric"):
+    if pars.kkt.kkt_solver_type in ("schur", "symmetric", "clever_symmetric"):
         return HIP_KKT_solver(pars.kkt.kkt_solver_type, pars)
     raise OkktError("pick a solver!")

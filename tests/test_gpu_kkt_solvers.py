@@ -182,3 +182,104 @@ def test_second_form_system_same_pattern_new_values():
     ko.kkt_associate_rhs_b(ito, KO.Reduct_stable()); ko.compute_direction_b()
     assert np.max(np.abs(k.dir.x - ko.dir.x)) <= 1e-9 * np.max(np.abs(ko.dir.x))
     assert k.linear_solver_stats()["n_analyze_calls"] == 1
+
+
+# ---- Clever_Symmetric (clever_symmetric.jl) -----------------------------------------------
+def _clever(rec_or_it, rescale="none", delta=None):
+    pars = KS.Class_parameters()
+    pars.kkt.kkt_solver_type = "clever_symmetric"
+    pars.kkt.kkt_system_rescale = rescale
+    it = iterate_from_record(rec_or_it, KS.Class_iterate) if isinstance(rec_or_it, dict) else rec_or_it
+    k = KS.pick_KKT_solver(pars)
+    k.initialize_b(it)
+    k.form_system_b(it)
+    inertia = k.factor_b(1e-8 if delta is None else delta)
+    k.kkt_associate_rhs_b(it, KS.Reduct_affine())
+    k.compute_direction_b()
+    return inertia, k
+
+
+def test_compute_indicies_reference_goldens(golden):
+    # test/kkt_system_solvers.jl:5-41: the integer answers of the reference's own unit test, through the C ABI
+    g = golden["compute_indicies"]
+    J = sp.csc_matrix(np.array(g["J"]))
+    m, n = J.shape
+    u = 1.0 / np.arange(1, m + 1)
+    it = KS.Class_iterate(x=np.zeros(n), y=np.ones(m), s=u.copy(), mu=0.1, J=J, H=sp.csc_matrix((n, n)), grad=np.zeros(n), cons=np.zeros(m))
+    pars = KS.Class_parameters(); pars.kkt.kkt_solver_type = "clever_symmetric"
+    k = KS.pick_KKT_solver(pars)
+    k.initialize_b(it)
+    assert [i + 1 for i in k.first_para_indicies] == g["no_para_indicies"]
+    assert [grp["first"] + 1 for grp in k.para_row_info] == g["no_para_indicies"]
+    for grp_no, members in g["group_members"].items():
+        for pos, ind, ratio in members:
+            row = k.para_row_info[int(grp_no) - 1]["ls"][pos - 1]
+            assert row["ind"] + 1 == ind and row["ratio"] == ratio
+    k.form_system_b(it)
+    _, info = k.get_indicies(with_values=True)
+    for grp_no in g["singletons"]:
+        grp = info[grp_no - 1]
+        assert grp["u"] == u[grp["first"]] and grp["ls"][0]["g"] == 1.0
+    # and everything equals the oracle's restatement
+    no_para, oinfo = KO.compute_indicies(J, u)
+    assert no_para == k.first_para_indicies
+    for a, b in zip(info, oinfo):
+        assert a["first"] == b.first and abs(a["u"] - b.u) <= 1e-15 * abs(b.u)
+        assert [(r["ind"], r["ratio"]) for r in a["ls"]] == [(r.ind, r.ratio) for r in b.ls]
+        assert np.allclose([r["g"] for r in a["ls"]], [r.g for r in b.ls], rtol=1e-15, atol=0)
+    k.finalize_b()
+
+
+@pytest.mark.parametrize("rescale", ["none", "u_only", "u_and_x"])
+def test_clever_symmetric_toy_lps(golden, rescale):
+    # test/kkt_system_solvers.jl:141-150: clever_symmetric agrees with schur to 1e-6 on toy_lp0-8
+    for rec in golden["toy_lps"]:
+        i_c, kc = _clever(rec, rescale)
+        i_s, ks = test_kkt_solver(rec, "schur")
+        assert i_c == 1 and i_s == 1, rec["name"]
+        _, ko = oracle_solver(rec, "clever_symmetric", 1e-8)
+        for a in ("x", "y", "s"):
+            assert np.linalg.norm(getattr(kc.dir, a) - getattr(ks.dir, a)) < 1e-6, (rec["name"], a)
+            assert np.linalg.norm(getattr(kc.dir, a) - np.array(rec["d" + a])) < 1e-6, (rec["name"], a)
+        assert kc.kkt_err_norm.ratio < 1e-8
+        assert kc.m_new == len(ko.para_row_info)
+        assert kc.first_para_indicies == ko.first_para_indicies
+        kc.finalize_b(); ks.finalize_b()
+
+
+def test_clever_symmetric_synthetic_with_duplicated_rows():
+    # a well-scaled synthetic KKT whose J carries exact multiples of existing rows (two-sided constraints):
+    # grouping, reduced matrix, inertia (n, m_new, 0) and directions against the oracle and the plain symmetric solver
+    prob = synth.make_problem(n=300, m=200, seed=5, well_scaled=True)
+    rng = np.random.default_rng(7)
+    J0 = sp.csr_matrix(prob["J"])
+    dup = rng.choice(200, size=60, replace=False)
+    scale = rng.choice([-1.0, 2.0, -0.5, 4.0], size=60)
+    J = sp.vstack([J0, sp.diags(scale) @ J0[dup, :]]).tocsc()
+    m = J.shape[0]
+    s = np.concatenate([prob["s"], rng.uniform(0.5, 2.0, 60)]); y = np.concatenate([prob["y"], rng.uniform(0.5, 2.0, 60)])
+    n = 300
+    it = KS.Class_iterate(x=rng.normal(size=n), y=y, s=s, mu=float(prob["mu"]), J=J, H=prob["H"], grad=rng.normal(size=n),
+                          cons=s + 1e-3 * rng.normal(size=m))
+    ito = KO.Iterate(x=it.x, y=y, s=s, mu=it.mu, J=J, H=prob["H"], grad=it.grad, cons=it.cons)
+    for rescale in ("none", "u_only"):
+        i_c, kc = _clever(it, rescale, delta=1e-6)
+        assert i_c == 1 and kc.m_new == 200
+        ko = KO.pick_KKT_solver("clever_symmetric", perm=kc.linear_solver_perm())
+        ko.kkt_system_rescale = rescale
+        ko.initialize_b(ito); ko.form_system_b(ito)
+        assert ko.factor_b(1e-6) == 1
+        ko.kkt_associate_rhs_b(ito, KO.Reduct_affine()); ko.compute_direction_b()
+        assert kc.first_para_indicies == ko.first_para_indicies
+        A = kc.matrix()                                   # Q without delta (the factorisation adds it as a shift)
+        Qo = sp.csc_matrix(sp.tril(sp.csc_matrix(ko.Q)))
+        Qo.setdiag(Qo.diagonal() - np.concatenate([1e-6 * np.ones(n), np.zeros(kc.m_new)]))
+        assert abs(A - Qo).max() < 1e-12 * abs(Qo).max()
+        for a in ("x", "y", "s"):
+            ref = getattr(ko.dir, a)
+            assert np.max(np.abs(getattr(kc.dir, a) - ref)) <= 1e-9 * max(1.0, np.max(np.abs(ref))), (rescale, a)
+        assert kc.kkt_err_norm.ratio < 1e-9
+        i_y, ky = test_kkt_solver(it, "symmetric", delta=1e-6)
+        for a in ("x", "y", "s"):
+            assert np.linalg.norm(getattr(kc.dir, a) - getattr(ky.dir, a)) < 1e-6 * max(1.0, np.linalg.norm(getattr(ky.dir, a)))
+        kc.finalize_b(); ky.finalize_b()
