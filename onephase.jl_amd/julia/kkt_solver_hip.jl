@@ -17,13 +17,13 @@ mutable struct HIP_KKT_solver <: abstract_KKT_system_solver
     ready::Symbol
     Q::SparseMatrixCSC{Float64,Int64}           # left empty: the assembled matrix lives in HBM
     handle::Ptr{Cvoid}
-    kind::Cint                                   # 0 = :schur, 1 = :symmetric
+    kind::Cint                                   # 0 = :schur, 1 = :symmetric, 2 = :clever_symmetric
     pattern_set::Bool
 
     function HIP_KKT_solver(kind::Symbol)
         this = new()
         this.ready = :not_ready
-        this.kind = kind == :schur ? 0 : 1
+        this.kind = kind == :schur ? 0 : (kind == :symmetric ? 1 : 2)
         this.pattern_set = false
         h = Ref{Ptr{Cvoid}}(C_NULL)
         rc = ccall((:okkt_kkt_create, OKKT_LIB), Cint, (Ref{Ptr{Cvoid}}, Ptr{Cvoid}, Cint), h, C_NULL, this.kind)
@@ -39,10 +39,31 @@ function kkt_hip_check(k::HIP_KKT_solver, what::String, rc)
     return rc
 end
 
+# initialize!(::Clever_Symmetric_KKT_solver, it) (clever_symmetric.jl:53-61): the parallel-row grouping is computed
+# once, from the Jacobian of the initial iterate
+function initialize!(k::HIP_KKT_solver, intial_it::Class_iterate)
+    k.dir = zero_point(dim(intial_it), ncon(intial_it))
+    if k.kind == 2
+        H = get_lag_hess(intial_it); J = get_jac(intial_it)
+        kkt_hip_check(k, "okkt_kkt_set_structure", ccall((:okkt_kkt_set_structure, OKKT_LIB), Cint,
+            (Ptr{Cvoid}, Int64, Int64, Ptr{Int64}, Ptr{Int64}, Ptr{Int64}, Ptr{Int64}, Cint),
+            k.handle, dim(intial_it), ncon(intial_it), H.colptr, H.rowval, J.colptr, J.rowval, 1))
+        k.pattern_set = true
+        m_new = Ref{Int64}(0)
+        kkt_hip_check(k, "okkt_kkt_compute_indicies", ccall((:okkt_kkt_compute_indicies, OKKT_LIB), Cint,
+            (Ptr{Cvoid}, Ptr{Float64}, Ref{Int64}), k.handle, J.nzval, m_new))
+    end
+end
+
 function form_system!(k::HIP_KKT_solver, iter::Class_iterate, timer::class_advanced_timer)
     start_advanced_timer(timer, "HIP/form_system")
     H = get_lag_hess(iter); J = get_jac(iter)
     n = dim(iter); m = ncon(iter)
+    if k.kind == 2     # kkt_system_rescale, clever_symmetric.jl:377-385
+        mode = Dict(:none => 0, :u_only => 1, :u_and_x => 2)[k.pars.kkt.kkt_system_rescale]
+        kkt_hip_check(k, "okkt_kkt_set_rescale", ccall((:okkt_kkt_set_rescale, OKKT_LIB), Cint,
+            (Ptr{Cvoid}, Cint, Float64, Float64), k.handle, mode, iter.point.mu, LinearAlgebra.norm(iter.point.x, Inf)))
+    end
     if !k.pattern_set
         kkt_hip_check(k, "okkt_kkt_set_structure", ccall((:okkt_kkt_set_structure, OKKT_LIB), Cint,
             (Ptr{Cvoid}, Int64, Int64, Ptr{Int64}, Ptr{Int64}, Ptr{Int64}, Ptr{Int64}, Cint),
