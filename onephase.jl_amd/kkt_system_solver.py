@@ -334,6 +334,44 @@ class HIP_KKT_solver:
         return out
 
 
+    def ls_solve(self, rhs):
+        """ls_solve(kkt_solver.ls_solver, rhs, timer) with the factor this KKT solver holds (julia.jl:105-113)."""
+        if self.ready != "factored":
+            raise OkktError("kkt solver not ready: factor! first")
+        h = C.c_void_p(self._lib.okkt_kkt_linear_solver(self._k))
+        b = L.f64(np.asarray(rhs, dtype=float))
+        x = np.zeros_like(b)
+        rc = self._lib.okkt_solve(h, L.p_f64(b), L.p_f64(x), 1)
+        if rc != 0:
+            raise OkktError(f"okkt_solve failed ({rc})")
+        return x
+
+
+def estimate_y_tilde(J, g, pars=None, **opts):
+    """Initialisation-time Cholesky routed through the same handle (guess-vars.jl:128-169):
+    M = cholesky(lambda I + J^T J), dx = M^-1 (-g), y = -J dx with lambda = 1e-4.  J'J + lambda I is assembled on the
+    device by the Schur kernel (Sigma = I, H = lambda I) and factored with Cholesky semantics; like the reference,
+    any failure returns ones(m)."""
+    J = _csc(J)
+    m, n = J.shape
+    lam = 1e-4
+    it = Class_iterate(x=np.zeros(n), y=np.ones(m), s=np.ones(m), mu=1.0, J=J, H=sp.identity(n, format="csc") * lam,
+                       grad=np.asarray(g, dtype=float), cons=np.zeros(m))
+    p = pars or Class_parameters()
+    k = HIP_KKT_solver("schur", p, **opts)
+    try:
+        k.initialize_b(it)
+        k.form_system_b(it)
+        if k.factor_b(0.0) != 1:
+            return np.ones(m)
+        dx = k.ls_solve(-it.grad)
+        return -(J @ dx)
+    except OkktError:
+        return np.ones(m)
+    finally:
+        k.finalize_b()
+
+
 def pick_KKT_solver(pars):
     """kkt_system_solver.jl:232-287 with the `linear_solver_type == :HIP` branch."""
     if pars.kkt.linear_solver_type != "HIP":

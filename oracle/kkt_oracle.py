@@ -491,6 +491,15 @@ class Clever_Symmetric_KKT_solver(_KKTBase):
         self.update_kkt_error_b()
 
 
+def estimate_y_tilde(J, g):  # guess-vars.jl:128-169 (cholesky branch), dense restatement
+    J = sp.csc_matrix(J)
+    n = J.shape[1]
+    Hd = 1e-4 * np.eye(n) + (J.T @ J).toarray()
+    Lc = np.linalg.cholesky(Hd)
+    dx = np.linalg.solve(Lc.T, np.linalg.solve(Lc, -np.asarray(g, dtype=float)))
+    return -(J @ dx)
+
+
 def ipopt_strategy_b(it, kkt_solver, pars=None):
     """delta_strategy.jl:37-114.  Returns (status, num_fac, delta) and the list of deltas tried."""
     pars = pars or kkt_solver.pars

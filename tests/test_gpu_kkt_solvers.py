@@ -283,3 +283,13 @@ def test_clever_symmetric_synthetic_with_duplicated_rows():
         for a in ("x", "y", "s"):
             assert np.linalg.norm(getattr(kc.dir, a) - getattr(ky.dir, a)) < 1e-6 * max(1.0, np.linalg.norm(getattr(ky.dir, a)))
         kc.finalize_b(); ky.finalize_b()
+
+
+def test_estimate_y_tilde_through_the_handle():
+    # guess-vars.jl:128-169, cholesky(lambda I + J'J) \ -g routed through the HIP handle
+    for seed, (n, m) in enumerate([(40, 25), (300, 420)]):
+        prob = synth.make_problem(n=n, m=m, seed=seed, well_scaled=True)
+        g = np.random.default_rng(seed).normal(size=n)
+        y_hip = KS.estimate_y_tilde(prob["J"], g)
+        y_ref = KO.estimate_y_tilde(prob["J"], g)
+        assert np.max(np.abs(y_hip - y_ref)) <= 1e-9 * max(1.0, np.max(np.abs(y_ref)))
