@@ -1329,6 +1329,7 @@ std::string numeric_setup(const Symbolic& S, const SymbolicOptions& opts, hipStr
           g.maxf = std::max(g.maxf, f);
           g.maxk = std::max(g.maxk, k);
           sched.push_back(s);
+          if (c == 3 && getenv("OKKT_DEBUG_FRONTS")) fprintf(stderr, "okkt: big front level %d  f %d  k %d\n", (int)l, f, k);
           if (c == 3) { wpos[s] = wtotal; wtotal += (int64_t)f * N.nb * N.group * 2; ++N.n_big;   /* two super-steps of W: look-ahead double buffer */ } else ++N.n_small;
         }
       }

@@ -215,3 +215,78 @@ class ShardedLinearSolver:
         for s in self.solvers:
             finalize_b(s)
         self.solvers = []
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Speculative delta loop: replicas of ONE KKT system, every rank factors a different candidate of
+# ipopt_strategy!'s delta sequence at the same time.  The candidates, their order and the returned
+# (status, num_fac, delta) are exactly those of the serial loop (delta_strategy.jl:37-114): a round of W ranks costs
+# the wall time of one factorisation instead of W.
+# ---------------------------------------------------------------------------------------------------------------
+def delta_candidates(tau, delta_prev, pars, max_it=500):
+    """The deltas ipopt_strategy! would try, in order, generated lazily with the reference's own arithmetic
+    (delta = delta * inc, not inc ** k).  The sequence ends after the first delta > delta.max (the serial loop
+    returns :failure right after trying it) or after max_it entries of the for-loop."""
+    d = pars.delta
+    if tau > 0.0:
+        tau = 0.0
+        yield d.zero
+    delta = None
+    for i in range(1, max_it + 1):
+        if i == 1:
+            delta = max(d.min - tau, delta_prev * d.dec) if delta_prev != 0.0 else d.start - tau
+        else:
+            delta = delta * d.inc
+        yield delta
+        if delta > d.max:
+            return
+
+
+def _allgather_flags(comm, local_flags):
+    """Inertia flags of all ranks in rank order.  LocalComm: the list is already global."""
+    if isinstance(comm, LocalComm):
+        return list(local_flags)
+    t = comm.torch.tensor([int(local_flags[0])], dtype=comm.torch.int64, device=comm.device)
+    out = [comm.torch.zeros_like(t) for _ in range(comm.world)]
+    comm.dist.all_gather(out, t)
+    return [int(v.item()) for v in out]
+
+
+def speculative_ipopt_strategy(comm, kkt_solvers, it, sync_factor=True):
+    """kkt_solvers: one formed KKT solver per LOCAL rank (comm.ranks), all holding the same system.
+    Returns (status, num_fac, delta, owner_rank) identical on every rank; the owner's solver holds the successful
+    factor, the others refactor with the chosen delta when sync_factor is set (in parallel: one more factorisation
+    of wall time), so that every rank can go on to compute_direction!."""
+    W = comm.world
+    pars = kkt_solvers[0].pars
+    tau = 1.5 * kkt_solvers[0].diag_min()
+    gen = delta_candidates(tau, float(it.delta), pars)
+    tried = 0
+    while True:
+        cands = []
+        for _ in range(W):
+            try:
+                cands.append(next(gen))
+            except StopIteration:
+                break
+        if not cands:
+            raise OkktError("max it")                       # error("max it"), delta_strategy.jl:113
+        local = []
+        for k, r in zip(kkt_solvers, comm.ranks):
+            local.append(k.factor_b(cands[r]) if r < len(cands) else -1)
+        flags = _allgather_flags(comm, local)
+        for j, d in enumerate(cands):
+            if flags[j] == 1:
+                status, num_fac, delta, owner = "success", tried + j + 1, d, j
+                break
+            if d > pars.delta.max:
+                status, num_fac, delta, owner = "failure", tried + j + 1, d, j
+                break
+        else:
+            tried += len(cands)
+            continue
+        if sync_factor:
+            for k, r in zip(kkt_solvers, comm.ranks):
+                if r != owner:
+                    k.factor_b(delta)
+        return status, num_fac, delta, owner

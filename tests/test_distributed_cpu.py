@@ -66,6 +66,38 @@ def _free_port():
         return s.getsockname()[1]
 
 
+class _FakeIt:
+    def __init__(self, delta):
+        self.delta = delta
+
+
+class _FakeKKT:
+    """Stand-in with the interface speculative_ipopt_strategy uses: factor_b(delta) -> 1 iff delta >= need."""
+
+    def __init__(self, need, dmin):
+        from onephase_jl_amd import kkt_system_solver as KS
+        self.pars = KS.Class_parameters()
+        self.need, self.dmin, self.calls = need, dmin, []
+
+    def diag_min(self):
+        return self.dmin
+
+    def factor_b(self, delta):
+        self.calls.append(delta)
+        return 1 if delta >= self.need else 0
+
+
+def _serial_fake(need, dmin, delta_prev):
+    """The serial loop (delta_strategy.jl:37-114) on the stand-in."""
+    from onephase_jl_amd.distributed import delta_candidates
+    k = _FakeKKT(need, dmin)
+    for i, d in enumerate(delta_candidates(1.5 * dmin, delta_prev, k.pars)):
+        if k.factor_b(d) == 1:
+            return "success", i + 1, d
+        if d > k.pars.delta.max:
+            return "failure", i + 1, d
+
+
 def _worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import torch
@@ -89,7 +121,11 @@ def _worker(rank, world, port, q):
     tot = comm.allreduce_counts([np.array([rank + 1, 10, 0, 0])])[0]
     elapsed = bench.max_over_ranks(0.5 + rank, distributed=True, device="cpu")
     units = bench.units_for_rank(rank, world)
-    q.put((rank, red.tolist(), x.download().tolist(), tot.tolist(), elapsed, units))
+    # speculative delta loop over the real collective layer, with a stand-in solver (inertia OK iff delta >= 3e-4)
+    from onephase_jl_amd.distributed import speculative_ipopt_strategy
+    spec = speculative_ipopt_strategy(comm, [_FakeKKT(3e-4, -0.2)], _FakeIt(0.0))
+    spec2 = speculative_ipopt_strategy(comm, [_FakeKKT(0.0, 0.5)], _FakeIt(2.0))      # tau > 0: delta = 0 is tried first
+    q.put((rank, red.tolist(), x.download().tolist(), tot.tolist(), elapsed, units, spec, spec2))
     dist.destroy_process_group()
 
 
@@ -105,7 +141,11 @@ def test_collective_layer_gloo_world2():
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    (r0, red0, x0, tot0, e0, u0), (r1, red1, x1, tot1, e1, u1) = out
+    (r0, red0, x0, tot0, e0, u0, sp0, spb0), (r1, red1, x1, tot1, e1, u1, sp1, spb1) = out
+    # speculative delta loop: both ranks agree, and with the serial loop, on (status, num_fac, delta); owner = rank
+    # that held the successful candidate
+    assert sp0 == sp1 and tuple(sp0[:3]) == _serial_fake(3e-4, -0.2, 0.0) and sp0[3] == (sp0[1] - 1) % 2
+    assert spb0 == spb1 and tuple(spb0[:3]) == _serial_fake(0.0, 0.5, 2.0) == ("success", 1, 0.0)
     assert red0 == [1.0, 2.0, 3.0, 4.0, 5.0, 6.0]            # reduce(sum) to part 0
     assert x0 == x1 == [7.0, 8.0, 9.0]                        # broadcast from part 0
     assert tot0 == tot1 == [3, 20, 0, 0]                      # all-reduce of the pivot counts

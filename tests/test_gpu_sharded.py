@@ -53,3 +53,37 @@ def test_block_angular_subtrees_are_balanced():
     assert pf.min() > 0 and pf.max() <= 1.6 * pf.mean()        # 8 independent blocks -> 8 busy parts
     assert info["top_flops"] < 1.0 * pf.sum()
     sh.finalize()
+
+
+# ---- speculative delta loop: W virtual ranks on one GPU must reproduce the serial ipopt_strategy! exactly
+@pytest.mark.parametrize("world", [1, 2, 3, 5])
+def test_speculative_delta_loop_matches_serial(golden, world):
+    from conftest import iterate_from_record
+    from onephase_jl_amd import kkt_system_solver as KS
+    from onephase_jl_amd.distributed import LocalComm, speculative_ipopt_strategy
+    for prob in ("indef5", "posdiag_indef5"):
+        rec = golden[prob]
+        for key, want in rec["delta_loops"].items():
+            kind, dprev = key.split("_prev")
+            dprev = float(dprev)
+            if True:
+                it = iterate_from_record(rec, KS.Class_iterate)
+                it.delta = dprev
+                pars = KS.Class_parameters(); pars.kkt.kkt_solver_type = kind
+                ks = []
+                for _ in range(world):
+                    k = KS.pick_KKT_solver(pars); k.initialize_b(it); k.form_system_b(it); ks.append(k)
+                status, num_fac, delta, owner = speculative_ipopt_strategy(LocalComm(world), ks, it)
+                serial = KS.pick_KKT_solver(pars); serial.initialize_b(it); serial.form_system_b(it)
+                s_status, s_fac, s_delta = serial.ipopt_strategy_b(it)
+                assert (status, num_fac, delta) == (s_status, s_fac, s_delta)              # bit-for-bit the serial loop
+                assert num_fac == want["num_fac"] and delta == want["delta"]               # and the golden trace
+                assert owner == (num_fac - 1) % world
+                # every replica ends up with the chosen factor: same direction everywhere
+                dirs = []
+                for k in ks:
+                    k.kkt_associate_rhs_b(it, KS.Reduct_affine()); k.compute_direction_b(); dirs.append(k.dir.x.copy())
+                for d in dirs[1:]:
+                    assert np.max(np.abs(d - dirs[0])) <= 1e-12 * max(1.0, np.max(np.abs(dirs[0])))
+                for k in ks + [serial]:
+                    k.finalize_b()
