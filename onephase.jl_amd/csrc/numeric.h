@@ -43,6 +43,9 @@ struct DevPlan {
   int64_t* ea_ptr = nullptr;       // [n_bigcols + 1] contributions (child, jj) landing on a front column
   int* ea_child = nullptr;
   int* ea_jj = nullptr;
+  int* ea_rc = nullptr;          // per item: rows of the child's contribution block
+  int64_t* ea_src = nullptr;     // per item: arena offset of the child's contribution-block column
+  int64_t* ea_rel = nullptr;     // per item: start of the child's rel list
   double* invl = nullptr;          // inverse of the unit-lower diagonal blocks, NB x NB each
   int64_t* invl_pos = nullptr;     // [nsuper]
   double* bigw = nullptr;          // [n_bigcols] forward-solve work vectors of the big fronts

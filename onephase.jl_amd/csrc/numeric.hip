@@ -171,17 +171,13 @@ __device__ __forceinline__ int lower_bound_dev(const int* a, int n, int key) {
 
 // Each front column is owned by exactly one wave, which applies the contributions in list order:
 // deterministic, no atomics, no workgroup barriers.
-__global__ __launch_bounds__(256) void k_big_assemble(DevPlan P, const int* __restrict__ list) {
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int s = list[blockIdx.y];
-  const int col0 = P.sn_col0[s];
-  const int k = P.sn_col0[s + 1] - col0;
-  const int f = (int)(P.row_ptr[s + 1] - P.row_ptr[s]);
-  const int pc = blockIdx.x * 4 + wv;
-  if (pc >= f) return;
-  double* F = P.arena + P.front_pos[s];
-  double* col = F + (size_t)pc * f;
-  for (int i = pc + lane; i < f; i += 64) col[i] = 0.0;
+// column pc of front s accumulated in `buf` (buf[0] = row pc): zero, A entries, delta, children's contributions in
+// their fixed order.  LDS = true: buf is the wave's LDS column; false: the HBM column itself.
+template <bool LDS, bool BATCH>
+__device__ __forceinline__ void assemble_column(const DevPlan& P, int s, int pc, int f, int k, int col0, double* __restrict__ buf) {
+  const int lane = threadIdx.x & 63;
+  const int nrow = f - pc;
+  for (int i = lane; i < nrow; i += 64) buf[i] = 0.0;
   __threadfence_block();
   if (pc < k) {
     const int64_t e0 = P.aent_ptr[s];
@@ -189,38 +185,113 @@ __global__ __launch_bounds__(256) void k_big_assemble(DevPlan P, const int* __re
     const int* dstv = P.aent_dst + e0;
     const int lo = lower_bound_dev(dstv, ne, pc * f);
     const int hi = lower_bound_dev(dstv, ne, (pc + 1) * f);
+    const int base = pc * f + pc;     // dstv holds offsets in the front; entry (row, pc) sits at pc * f + row
     if (!P.has_dup) {
-      for (int e = lo + lane; e < hi; e += 64) F[dstv[e]] = P.vals[P.aent_src[e0 + e]];
+      for (int e = lo + lane; e < hi; e += 64) buf[dstv[e] - base] = P.vals[P.aent_src[e0 + e]];
     } else if (lane == 0) {
-      for (int e = lo; e < hi; ++e) F[dstv[e]] += P.vals[P.aent_src[e0 + e]];
+      for (int e = lo; e < hi; ++e) buf[dstv[e] - base] += P.vals[P.aent_src[e0 + e]];
     }
     __threadfence_block();
-    if (lane == 0) col[pc] += P.diagadd[col0 + pc];
+    if (lane == 0) buf[0] += P.diagadd[col0 + pc];
     __threadfence_block();
   }
   const int64_t gc = P.bigcol_base[s] + pc;
-  for (int64_t q = P.ea_ptr[gc]; q < P.ea_ptr[gc + 1]; ++q) {
-    const int c = P.ea_child[q], jj = P.ea_jj[q];
-    const int kc = P.sn_col0[c + 1] - P.sn_col0[c];
-    const int fc = (int)(P.row_ptr[c + 1] - P.row_ptr[c]);
-    const int rc = fc - kc;
-    const int* rl = P.rel + P.rel_ptr[c];
-    const double* Ccol = P.arena + P.front_pos[c] + (size_t)(kc + jj) * fc + kc;
-    // within one item the destinations rl[ii] are distinct: 4 chunks of 64 rows are fetched together
-    // (index, source and destination loads all in flight) before the adds and stores
-    int ii = jj + lane;
-    for (; ii + 192 < rc; ii += 256) {
-      int d[4];
-      double v[4], o[4];
+  // one precomputed record per item (source column in the arena, rel list, lengths): the per-child metadata
+  // would cost two more dependent memory round trips per item; the next record is fetched while the current
+  // item is applied
+  const int64_t q0 = P.ea_ptr[gc], q1 = P.ea_ptr[gc + 1];
+  // Items are applied strictly in order (same destination column), but their loads need not wait for each other:
+  // four items at a time have their records, and then the first 64 rows of their index and source columns, in
+  // flight together (clamped addresses, no branches); most items of the lower levels are no longer than that.
+  constexpr int NB4 = 4;
+  if constexpr (!BATCH) {
+    // long columns (upper levels, bandwidth-bound): one item after the other, the next record fetched meanwhile
+    int64_t src_n = 0, rel_n = 0;
+    int rc_n = 0, jj_n = 0;
+    if (q0 < q1) { src_n = P.ea_src[q0]; rel_n = P.ea_rel[q0]; rc_n = P.ea_rc[q0]; jj_n = P.ea_jj[q0]; }
+    for (int64_t q = q0; q < q1; ++q) {
+      const int rc = rc_n, jj = jj_n;
+      const int* rl = P.rel + rel_n;
+      const double* Ccol = P.arena + src_n;
+      if (q + 1 < q1) { src_n = P.ea_src[q + 1]; rel_n = P.ea_rel[q + 1]; rc_n = P.ea_rc[q + 1]; jj_n = P.ea_jj[q + 1]; }
+      int ii = jj + lane;
+      for (; ii + 192 < rc; ii += 256) {
+        int d[4];
+        double v[4], o[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) d[u] = rl[ii + 64 * u];
+        for (int u = 0; u < 4; ++u) d[u] = rl[ii + 64 * u] - pc;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) { v[u] = Ccol[ii + 64 * u]; o[u] = col[d[u]]; }
+        for (int u = 0; u < 4; ++u) { v[u] = Ccol[ii + 64 * u]; o[u] = buf[d[u]]; }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) col[d[u]] = o[u] + v[u];
+        for (int u = 0; u < 4; ++u) buf[d[u]] = o[u] + v[u];
+      }
+      for (; ii < rc; ii += 64) buf[rl[ii] - pc] += Ccol[ii];
+      __threadfence_block();
     }
-    for (; ii < rc; ii += 64) col[rl[ii]] += Ccol[ii];
-    __threadfence_block();
+    return;
+  }
+  for (int64_t q = q0; q < q1; q += NB4) {
+    int64_t src[NB4], rel[NB4];
+    int rc[NB4], jj[NB4];
+#pragma unroll
+    for (int u = 0; u < NB4; ++u) {
+      const int64_t qq = min(q + u, q1 - 1);
+      src[u] = P.ea_src[qq]; rel[u] = P.ea_rel[qq]; rc[u] = P.ea_rc[qq]; jj[u] = P.ea_jj[qq];
+    }
+    int d[NB4];
+    double v[NB4];
+#pragma unroll
+    for (int u = 0; u < NB4; ++u) {
+      const int ii = min(jj[u] + lane, rc[u] - 1);
+      d[u] = P.rel[rel[u] + ii] - pc;
+      v[u] = P.arena[src[u] + ii];
+    }
+#pragma unroll
+    for (int u = 0; u < NB4; ++u) {
+      if (q + u < q1) {       // wave-uniform
+        if (jj[u] + lane < rc[u]) buf[d[u]] += v[u];
+        const int* rl = P.rel + rel[u];
+        const double* Ccol = P.arena + src[u];
+        int ii = jj[u] + 64 + lane;
+        for (; ii + 192 < rc[u]; ii += 256) {
+          int dd[4];
+          double vv[4], oo[4];
+#pragma unroll
+          for (int w = 0; w < 4; ++w) dd[w] = rl[ii + 64 * w] - pc;
+#pragma unroll
+          for (int w = 0; w < 4; ++w) { vv[w] = Ccol[ii + 64 * w]; oo[w] = buf[dd[w]]; }
+#pragma unroll
+          for (int w = 0; w < 4; ++w) buf[dd[w]] = oo[w] + vv[w];
+        }
+        for (; ii < rc[u]; ii += 64) buf[rl[ii] - pc] += Ccol[ii];
+        __threadfence_block();
+      }
+    }
+  }
+}
+
+template <bool BATCH>
+__global__ __launch_bounds__(256) void k_big_assemble(DevPlan P, const int* __restrict__ list, int lcol) {
+  // One wave per front column.  Columns of at most `lcol` rows are accumulated in LDS and written to HBM once:
+  // the read-modify-write chain of the extend-add then runs at LDS latency instead of an HBM round trip per
+  // item, and the zero-fill and the read-back of the column never reach HBM.  Longer columns take the same steps
+  // directly in HBM.  The summation order is the same on both paths (bitwise identical results).
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int s = list[blockIdx.y];
+  const int col0 = P.sn_col0[s];
+  const int k = P.sn_col0[s + 1] - col0;
+  const int f = (int)(P.row_ptr[s + 1] - P.row_ptr[s]);
+  const int pc = blockIdx.x * 4 + wv;
+  if (pc >= f) return;
+  double* col = P.arena + P.front_pos[s] + (size_t)pc * f + pc;   // first row of the lower triangle: (pc, pc)
+  const int nrow = f - pc;
+  if (nrow <= lcol) {
+    double* buf = sm + (size_t)wv * lcol;
+    assemble_column<true, BATCH>(P, s, pc, f, k, col0, buf);
+    for (int i = lane; i < nrow; i += 64) col[i] = buf[i];
+  } else {
+    assemble_column<false, BATCH>(P, s, pc, f, k, col0, col);
   }
 }
 
@@ -1378,7 +1449,8 @@ std::string numeric_setup(const Symbolic& S, const SymbolicOptions& opts, hipStr
       for (int64_t q = S.rel_ptr[c]; q < S.rel_ptr[c + 1]; ++q) ++ea_ptr[bigcol_base[p] + S.rel[q] + 1];
     }
     for (int64_t i = 0; i < nbigcols; ++i) ea_ptr[i + 1] += ea_ptr[i];
-    std::vector<int> ea_child(ea_ptr[nbigcols]), ea_jj(ea_ptr[nbigcols]);
+    std::vector<int> ea_child(ea_ptr[nbigcols]), ea_jj(ea_ptr[nbigcols]), ea_rc(ea_ptr[nbigcols]);
+    std::vector<int64_t> ea_src(ea_ptr[nbigcols]), ea_rel(ea_ptr[nbigcols]);
     std::vector<int64_t> fill(ea_ptr.begin(), ea_ptr.end() - 1);
     for (int c = 0; c < ns; ++c) {  // children in ascending order: the summation order is fixed
       const int p = S.sn_parent[c];
@@ -1387,6 +1459,12 @@ std::string numeric_setup(const Symbolic& S, const SymbolicOptions& opts, hipStr
         const int64_t slot = fill[bigcol_base[p] + S.rel[q]]++;
         ea_child[slot] = c;
         ea_jj[slot] = (int)(q - S.rel_ptr[c]);
+        {
+          const int64_t kc = S.sn_col0[c + 1] - S.sn_col0[c], fc = S.row_ptr[c + 1] - S.row_ptr[c];
+          ea_rc[slot] = (int)(fc - kc);
+          ea_rel[slot] = S.rel_ptr[c];
+          ea_src[slot] = S.front_pos[c] + (kc + ea_jj[slot]) * fc + kc;   // arena offset of the child's CB column, row 0 of the CB
+        }
       }
     }
     if (!(e = upload(N, bigcol_base, &d.bigcol_base)).empty()) return e;
@@ -1394,6 +1472,9 @@ std::string numeric_setup(const Symbolic& S, const SymbolicOptions& opts, hipStr
     if (!(e = upload(N, ea_ptr, &d.ea_ptr)).empty()) return e;
     if (!(e = upload(N, ea_child, &d.ea_child)).empty()) return e;
     if (!(e = upload(N, ea_jj, &d.ea_jj)).empty()) return e;
+    if (!(e = upload(N, ea_rc, &d.ea_rc)).empty()) return e;
+    if (!(e = upload(N, ea_src, &d.ea_src)).empty()) return e;
+    if (!(e = upload(N, ea_rel, &d.ea_rel)).empty()) return e;
     if (!(e = dalloc(N, (size_t)invl_total, &d.invl, false)).empty()) return e;
     if (!(e = dalloc(N, (size_t)nbigcols, &d.bigw, true)).empty()) return e;
   }
@@ -1460,7 +1541,16 @@ std::string numeric_factor_enqueue(Numeric& N, const double* d_vals, double tol,
     if (L.seg[3].cnt) {
       const Segment& g = L.seg[3];
       const int* list = P.sched + g.off;
-      hipLaunchKernelGGL(k_big_assemble, dim3((g.maxf + 3) / 4, g.cnt), dim3(256), 0, st, P, list);
+      {
+        // LDS-resident columns up to 2048 rows (16 KiB per wave); smaller fronts take less LDS for more waves per CU
+        static const int lcol_max = getenv("OKKT_ASM_LCOL") ? atoi(getenv("OKKT_ASM_LCOL")) : 2048;
+        int lcol = 256;
+        while (lcol < g.maxf && lcol < lcol_max) lcol *= 2;
+        if (lcol_max <= 0) lcol = 0;
+        // lower levels (many fronts, short items): loads of four items batched; upper levels: item after item
+        if (g.maxf <= 2048) hipLaunchKernelGGL(k_big_assemble<true>, dim3((g.maxf + 3) / 4, g.cnt), dim3(256), (size_t)4 * lcol * sizeof(double), st, P, list, lcol);
+        else hipLaunchKernelGGL(k_big_assemble<false>, dim3((g.maxf + 3) / 4, g.cnt), dim3(256), (size_t)4 * lcol * sizeof(double), st, P, list, lcol);
+      }
       const int nsteps = (g.maxk + NB - 1) / NB;
       const size_t lds_diag_v1 = ((size_t)(NB + 2) * NB + (size_t)std::max(NB - kIB, kIB) * kIB + 3 * kIB + NB) * sizeof(double);
       const size_t lds_diag = ((size_t)3 * kMW * kPLD + (size_t)2 * 4 * 32 * kXld) * sizeof(double);
