@@ -46,6 +46,9 @@ struct DevPlan {
   int* ea_rc = nullptr;          // per item: rows of the child's contribution block
   int64_t* ea_src = nullptr;     // per item: arena offset of the child's contribution-block column
   int64_t* ea_rel = nullptr;     // per item: start of the child's rel list
+  int64_t* ea_cut = nullptr;     // per item: start of the child's chunk-boundary table in cutv
+  int* cutv = nullptr;           // per child of a big front: positions of the parent's 1024-row boundaries in its rel list
+  int64_t* acol_lo = nullptr;    // [n_bigcols + 1] first A entry of each big-front column
   double* invl = nullptr;          // inverse of the unit-lower diagonal blocks, NB x NB each
   int64_t* invl_pos = nullptr;     // [nsuper]
   double* bigw = nullptr;          // [n_bigcols] forward-solve work vectors of the big fronts

@@ -183,8 +183,10 @@ __device__ __forceinline__ void assemble_column(const DevPlan& P, int s, int pc,
     const int64_t e0 = P.aent_ptr[s];
     const int ne = (int)(P.aent_ptr[s + 1] - e0);
     const int* dstv = P.aent_dst + e0;
-    const int lo = lower_bound_dev(dstv, ne, pc * f);
-    const int hi = lower_bound_dev(dstv, ne, (pc + 1) * f);
+    // range of this column's entries: precomputed on the host (two binary searches = ~25 dependent loads otherwise)
+    const int64_t gcol = P.bigcol_base[s] + pc;
+    const int lo = (int)(P.acol_lo[gcol] - e0);
+    const int hi = pc + 1 < f ? (int)(P.acol_lo[gcol + 1] - e0) : ne;
     const int base = pc * f + pc;     // dstv holds offsets in the front; entry (row, pc) sits at pc * f + row
     if (!P.has_dup) {
       for (int e = lo + lane; e < hi; e += 64) buf[dstv[e] - base] = P.vals[P.aent_src[e0 + e]];
@@ -293,6 +295,78 @@ __global__ __launch_bounds__(256) void k_big_assemble(DevPlan P, const int* __re
   } else {
     assemble_column<false, BATCH>(P, s, pc, f, k, col0, col);
   }
+}
+
+// Upper levels (fronts with more than 2048 rows): the column is cut into row chunks of kAsmChunk rows and each
+// (column, chunk) is a wave with its chunk in LDS -- every front entry is written to HBM exactly once and every
+// child entry read once (the in-HBM path zero-fills, then reads and writes the column once per contributing item).
+// Per child a small table gives the position in its rel list where each chunk boundary falls (the list is sorted),
+// and per front column the range of its A entries is precomputed: no searches on the device.
+constexpr int kAsmChunk = 1024;
+__global__ __launch_bounds__(256) void k_big_assemble_chunked(DevPlan P, const int* __restrict__ list) {
+  __shared__ double sm[4 * kAsmChunk];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int s = list[blockIdx.y];
+  const int col0 = P.sn_col0[s];
+  const int k = P.sn_col0[s + 1] - col0;
+  const int f = (int)(P.row_ptr[s + 1] - P.row_ptr[s]);
+  const int pc = blockIdx.x * 4 + wv;
+  if (pc >= f) return;
+  const int t = blockIdx.z;
+  const int r0 = max(pc, t * kAsmChunk), r1 = min(f, (t + 1) * kAsmChunk);
+  if (r0 >= r1) return;
+  double* buf = sm + wv * kAsmChunk - r0;      // buf[row] for row in [r0, r1): LDS array (static, so the bias is harmless)
+  double* base = sm + wv * kAsmChunk;
+  const int n = r1 - r0;
+  for (int i = lane; i < n; i += 64) base[i] = 0.0;
+  __threadfence_block();
+  const int64_t gc = P.bigcol_base[s] + pc;
+  if (pc < k) {
+    const int64_t lo = P.acol_lo[gc], hi = pc + 1 < f ? P.acol_lo[gc + 1] : P.aent_ptr[s + 1];
+    const int cbase = pc * f;
+    if (!P.has_dup) {
+      for (int64_t e = lo + lane; e < hi; e += 64) {
+        const int row = P.aent_dst[e] - cbase;
+        if (row >= r0 && row < r1) base[row - r0] = P.vals[P.aent_src[e]];
+      }
+    } else if (lane == 0) {
+      for (int64_t e = lo; e < hi; ++e) {
+        const int row = P.aent_dst[e] - cbase;
+        if (row >= r0 && row < r1) base[row - r0] += P.vals[P.aent_src[e]];
+      }
+    }
+    __threadfence_block();
+    if (lane == 0 && pc >= r0 && pc < r1) base[pc - r0] += P.diagadd[col0 + pc];
+    __threadfence_block();
+  }
+  (void)buf;
+  const int64_t q0 = P.ea_ptr[gc], q1 = P.ea_ptr[gc + 1];
+  int64_t src_n = 0, rel_n = 0, cut_n = 0;
+  int rc_n = 0, jj_n = 0;
+  if (q0 < q1) { src_n = P.ea_src[q0]; rel_n = P.ea_rel[q0]; rc_n = P.ea_rc[q0]; jj_n = P.ea_jj[q0]; cut_n = P.ea_cut[q0]; }
+  for (int64_t q = q0; q < q1; ++q) {
+    const int rc = rc_n, jj = jj_n;
+    const int* rl = P.rel + rel_n;
+    const double* Ccol = P.arena + src_n;
+    const int* cut = P.cutv + cut_n;
+    if (q + 1 < q1) { src_n = P.ea_src[q + 1]; rel_n = P.ea_rel[q + 1]; rc_n = P.ea_rc[q + 1]; jj_n = P.ea_jj[q + 1]; cut_n = P.ea_cut[q + 1]; }
+    const int lo = max(jj, cut[t]), hi = min(rc, cut[t + 1]);     // rows of this item that fall into the chunk
+    int ii = lo + lane;
+    for (; ii + 192 < hi; ii += 256) {
+      int d[4];
+      double v[4], o[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) d[u] = rl[ii + 64 * u] - r0;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { v[u] = Ccol[ii + 64 * u]; o[u] = base[d[u]]; }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) base[d[u]] = o[u] + v[u];
+    }
+    for (; ii < hi; ii += 64) base[rl[ii] - r0] += Ccol[ii];
+    __threadfence_block();
+  }
+  double* col = P.arena + P.front_pos[s] + (size_t)pc * f + r0;
+  for (int i = lane; i < n; i += 64) col[i] = base[i];
 }
 
 // 1/d from v_rcp_f64 and two Newton steps (about 1 ulp); d = 0 gives inf/NaN like the division would
@@ -1450,7 +1524,32 @@ std::string numeric_setup(const Symbolic& S, const SymbolicOptions& opts, hipStr
     }
     for (int64_t i = 0; i < nbigcols; ++i) ea_ptr[i + 1] += ea_ptr[i];
     std::vector<int> ea_child(ea_ptr[nbigcols]), ea_jj(ea_ptr[nbigcols]), ea_rc(ea_ptr[nbigcols]);
-    std::vector<int64_t> ea_src(ea_ptr[nbigcols]), ea_rel(ea_ptr[nbigcols]);
+    std::vector<int64_t> ea_src(ea_ptr[nbigcols]), ea_rel(ea_ptr[nbigcols]), ea_cut(ea_ptr[nbigcols]);
+    // per child of a big front: where each kAsmChunk-row boundary of the parent falls in its (sorted) rel list
+    std::vector<int64_t> cut_pos(ns, -1);
+    std::vector<int> cutv;
+    for (int c = 0; c < ns; ++c) {
+      const int p = S.sn_parent[c];
+      if (p < 0 || wpos[p] < 0) continue;
+      const int64_t fp = S.row_ptr[p + 1] - S.row_ptr[p];
+      const int* rb = S.rel.data() + S.rel_ptr[c];
+      const int* re = S.rel.data() + S.rel_ptr[c + 1];
+      cut_pos[c] = (int64_t)cutv.size();
+      const int nchunks = (int)((fp + kAsmChunk - 1) / kAsmChunk);
+      for (int t = 0; t <= nchunks; ++t) cutv.push_back((int)(std::lower_bound(rb, re, t * kAsmChunk) - rb));
+    }
+    // per big-front column: first A entry of the column (entries are sorted by destination)
+    std::vector<int64_t> acol_lo(nbigcols + 1, 0);
+    for (int s = 0; s < ns; ++s)
+      if (wpos[s] >= 0) {
+        const int64_t f = S.row_ptr[s + 1] - S.row_ptr[s];
+        const int64_t e0 = S.aent_ptr[s], e1 = S.aent_ptr[s + 1];
+        int64_t e = e0;
+        for (int64_t pc = 0; pc < f; ++pc) {
+          while (e < e1 && (int64_t)S.aent_dst[e] < pc * f) ++e;
+          acol_lo[bigcol_base[s] + pc] = e;
+        }
+      }
     std::vector<int64_t> fill(ea_ptr.begin(), ea_ptr.end() - 1);
     for (int c = 0; c < ns; ++c) {  // children in ascending order: the summation order is fixed
       const int p = S.sn_parent[c];
@@ -1463,6 +1562,7 @@ std::string numeric_setup(const Symbolic& S, const SymbolicOptions& opts, hipStr
           const int64_t kc = S.sn_col0[c + 1] - S.sn_col0[c], fc = S.row_ptr[c + 1] - S.row_ptr[c];
           ea_rc[slot] = (int)(fc - kc);
           ea_rel[slot] = S.rel_ptr[c];
+          ea_cut[slot] = cut_pos[c];
           ea_src[slot] = S.front_pos[c] + (kc + ea_jj[slot]) * fc + kc;   // arena offset of the child's CB column, row 0 of the CB
         }
       }
@@ -1475,6 +1575,9 @@ std::string numeric_setup(const Symbolic& S, const SymbolicOptions& opts, hipStr
     if (!(e = upload(N, ea_rc, &d.ea_rc)).empty()) return e;
     if (!(e = upload(N, ea_src, &d.ea_src)).empty()) return e;
     if (!(e = upload(N, ea_rel, &d.ea_rel)).empty()) return e;
+    if (!(e = upload(N, ea_cut, &d.ea_cut)).empty()) return e;
+    if (!(e = upload(N, cutv, &d.cutv)).empty()) return e;
+    if (!(e = upload(N, acol_lo, &d.acol_lo)).empty()) return e;
     if (!(e = dalloc(N, (size_t)invl_total, &d.invl, false)).empty()) return e;
     if (!(e = dalloc(N, (size_t)nbigcols, &d.bigw, true)).empty()) return e;
   }
@@ -1548,7 +1651,10 @@ std::string numeric_factor_enqueue(Numeric& N, const double* d_vals, double tol,
         while (lcol < g.maxf && lcol < lcol_max) lcol *= 2;
         if (lcol_max <= 0) lcol = 0;
         // lower levels (many fronts, short items): loads of four items batched; upper levels: item after item
-        if (g.maxf <= 2048) hipLaunchKernelGGL(k_big_assemble<true>, dim3((g.maxf + 3) / 4, g.cnt), dim3(256), (size_t)4 * lcol * sizeof(double), st, P, list, lcol);
+        static const int chunked = getenv("OKKT_ASM_CHUNKED") ? atoi(getenv("OKKT_ASM_CHUNKED")) : 1;
+        static const int chunk_min = getenv("OKKT_ASM_CHUNK_MIN") ? atoi(getenv("OKKT_ASM_CHUNK_MIN")) : 2048;
+        if (g.maxf > chunk_min && chunked) hipLaunchKernelGGL(k_big_assemble_chunked, dim3((g.maxf + 3) / 4, g.cnt, (g.maxf + kAsmChunk - 1) / kAsmChunk), dim3(256), 0, st, P, list);
+        else if (g.maxf <= 2048) hipLaunchKernelGGL(k_big_assemble<true>, dim3((g.maxf + 3) / 4, g.cnt), dim3(256), (size_t)4 * lcol * sizeof(double), st, P, list, lcol);
         else hipLaunchKernelGGL(k_big_assemble<false>, dim3((g.maxf + 3) / 4, g.cnt), dim3(256), (size_t)4 * lcol * sizeof(double), st, P, list, lcol);
       }
       const int nsteps = (g.maxk + NB - 1) / NB;
