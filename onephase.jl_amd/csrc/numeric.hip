@@ -1246,6 +1246,18 @@ __global__ __launch_bounds__(256) void k_bigsolve_fwd_step(DevPlan P, const int*
   if (blockIdx.x > 0 && j0 + nb + (int)blockIdx.x * 64 >= f) return;
   double* w = P.bigw + P.bigcol_base[s];
   const double* X = P.invl + P.invl_pos[s] + (size_t)step * NB * NB;
+  // the panel entries of this thread's row and its right-hand-side entry do not depend on y: they are requested
+  // first, so that their round trip overlaps the one of the X block (the step is pure latency: 4 -> 2 round trips)
+  const int r = j0 + nb + blockIdx.x * 64 + lane;
+  const int rcl = min(r, f - 1);
+  double lv[32];
+  {
+    const double* L = P.arena + P.front_pos[s] + (size_t)j0 * f + rcl;
+    const int cb = wv * 32;
+#pragma unroll
+    for (int q = 0; q < 32; ++q) lv[q] = L[(size_t)min(cb + q, nb - 1) * f];
+  }
+  const double wr = w[rcl];
   if (tid < 128) wj[tid] = tid < nb ? w[j0 + tid] : 0.0;
   __syncthreads();
   // y[c] = sum_{p <= c} X[c][p] w[p]: two threads per row c (row c of X is contiguous in XT), each with
@@ -1270,23 +1282,16 @@ __global__ __launch_bounds__(256) void k_bigsolve_fwd_step(DevPlan P, const int*
     }
   }
   __syncthreads();
-  const int r = j0 + nb + blockIdx.x * 64 + lane;
   {
     double a = 0.0;
-    if (r < f) {
-      const double* L = P.arena + P.front_pos[s] + (size_t)j0 * f + r;
-      const int cb = wv * 32;
-      double v[32];
+    const int cb = wv * 32;
 #pragma unroll
-      for (int q = 0; q < 32; ++q) v[q] = (cb + q < nb) ? L[(size_t)(cb + q) * f] : 0.0;
-#pragma unroll
-      for (int q = 0; q < 32; ++q) a += (cb + q < nb) ? v[q] * yj[(cb + q) & 127] : 0.0;   // yj beyond nb is uninitialised LDS
-    }
+    for (int q = 0; q < 32; ++q) a += (cb + q < nb) ? lv[q] * yj[(cb + q) & 127] : 0.0;   // yj beyond nb is uninitialised LDS
     part[wv][lane] = a;
   }
   __syncthreads();
   if (wv == 0 && r < f) {
-    const double acc = w[r] - ((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]));
+    const double acc = wr - ((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]));
     w[r] = acc;
     if (j0 + nb >= k && r >= k) P.cv[P.cv_pos[s] + (r - k)] = acc;   // last step: contribution vector
   }
@@ -1325,6 +1330,19 @@ __global__ __launch_bounds__(256) void k_bigsolve_bwd_step(DevPlan P, const int*
   const int nb = min(NB, k - j0);
   if (blockIdx.x > 0 && (int)blockIdx.x * 64 >= j0) return;
   const double* X = P.invl + P.invl_pos[s] + (size_t)step * NB * NB;
+  // as in the forward step: the panel entries and the entries of x they update are requested before x_I is known
+  const double* Lrow = P.arena + P.front_pos[s] + j0;
+  const int rl = lane & 7;
+  double lv[2][NB / 8], xold[2];
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const int c = blockIdx.x * 64 + wv * 16 + pass * 8 + (lane >> 3);
+    const int cc = min(c, max(j0 - 1, 0));
+    const double* col = Lrow + (size_t)cc * f;
+#pragma unroll
+    for (int it = 0; it < NB / 8; ++it) lv[pass][it] = col[min(rl + 8 * it, nb - 1)];
+    xold[pass] = P.xwork[col0 + cc];
+  }
   if (tid < 128) zi[tid] = tid < nb ? P.xwork[col0 + j0 + tid] : 0.0;
   __syncthreads();
   // x[c] = sum_{p >= c} X[p][c] z[p]: two threads per c (column c of X is contiguous), 64 loads in flight each
@@ -1345,22 +1363,16 @@ __global__ __launch_bounds__(256) void k_bigsolve_bwd_step(DevPlan P, const int*
   __syncthreads();
   // columns [blockIdx.x*64, +64) left of the block, 16 per wave in two passes of 8: lane = (column
   // lane>>3, row phase lane&7); every lane has its 16 loads in flight, then three shuffle steps per pass
-  const double* Lrow = P.arena + P.front_pos[s] + j0;
-  const int rl = lane & 7;
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
     const int c = blockIdx.x * 64 + wv * 16 + pass * 8 + (lane >> 3);
-    const double* col = Lrow + (size_t)min(c, max(j0 - 1, 0)) * f;
-    double v[NB / 8];
-#pragma unroll
-    for (int it = 0; it < NB / 8; ++it) v[it] = col[min(rl + 8 * it, nb - 1)];
     double acc = 0.0;
 #pragma unroll
-    for (int it = 0; it < NB / 8; ++it) acc += (rl + 8 * it < nb) ? v[it] * xi[rl + 8 * it] : 0.0;
+    for (int it = 0; it < NB / 8; ++it) acc += (rl + 8 * it < nb) ? lv[pass][it] * xi[rl + 8 * it] : 0.0;
     acc += __shfl_xor(acc, 1, 64);
     acc += __shfl_xor(acc, 2, 64);
     acc += __shfl_xor(acc, 4, 64);
-    if (rl == 0 && c < j0) P.xwork[col0 + c] -= acc;
+    if (rl == 0 && c < j0) P.xwork[col0 + c] = xold[pass] - acc;
   }
   // the block's own solution is written last, by the first workgroup only: the others read z_I above
   if (blockIdx.x == 0 && tid < nb) P.xwork[col0 + j0 + tid] = xi[tid];
