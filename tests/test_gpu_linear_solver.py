@@ -235,3 +235,35 @@ def test_sc3_size_properties():
     st = h.stats()
     print("S-C3 stats:", {k: st[k] for k in ("nnzL", "flops_exact", "nsuper", "nlevels", "max_front", "last_factor_ms", "last_solve_ms", "analyze_seconds")})
     finalize_b(h)
+
+
+def test_long_columns_chunked_assembly_with_duplicates():
+    # one dense front of 2300 rows: its columns are assembled in 1024-row LDS chunks (k_big_assemble_chunked), three
+    # panel super-steps with look-ahead; a raw CSC with duplicated entries exercises the serial has_dup scatter
+    n = 2300
+    rng = np.random.default_rng(23)
+    B = rng.normal(size=(n, n))
+    M = B + B.T + np.diag(np.where(rng.random(n) < 0.5, 1.0, -1.0) * (3.0 * np.sqrt(n)))
+    A = sp.csc_matrix(np.tril(M))
+    w = np.linalg.eigvalsh(M)
+    compare_with_oracle(A, int((w > 0).sum()), int((w < 0).sum()), tol=1e-9)
+    # duplicates: split 200 random lower entries (some on chunk boundaries and on the diagonal) into two halves
+    A.sort_indices()
+    colptr, rowval, nzval = [A.indptr.astype(np.int64)], A.indices.astype(np.int64), A.data.copy()
+    cols = np.repeat(np.arange(n), np.diff(A.indptr))
+    pick = np.concatenate([rng.choice(len(nzval), size=196, replace=False),
+                           [A.indptr[0], A.indptr[5] + 1019, A.indptr[5] + 1020, A.indptr[1030]]]).astype(np.int64)
+    pick = np.unique(pick)
+    keep = np.ones(len(nzval), dtype=bool)
+    extra_r, extra_c, extra_v = rowval[pick], cols[pick], 0.25 * nzval[pick]
+    nz2 = nzval.copy(); nz2[pick] *= 0.75
+    rr = np.concatenate([rowval, extra_r]); cc = np.concatenate([cols, extra_c]); vv = np.concatenate([nz2, extra_v])
+    order = np.lexsort((rr, cc))
+    rr, cc, vv = rr[order], cc[order], vv[order]
+    cp = np.zeros(n + 1, dtype=np.int64); np.add.at(cp, cc + 1, 1); cp = np.cumsum(cp)
+    h = hip_solver("symmetric")
+    assert h.ls_factor_b((n, cp, rr, vv, 0), int((w > 0).sum()), int((w < 0).sum())) == 1
+    b = rng.normal(size=n)
+    x = h.ls_solve(b)
+    assert np.max(np.abs(M @ x - b)) <= 1e-9 * np.max(np.abs(b)) * np.sqrt(n)
+    finalize_b(h)
