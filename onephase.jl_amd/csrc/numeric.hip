@@ -1011,8 +1011,10 @@ __global__ __launch_bounds__(kSyrkNW * 64, kSyrkNW / 2) void k_big_syrk(DevPlan 
   else if (HEAD == kSyrkPanel) ntiles = T;
   else { ntiles = 0; for (int c = 0; c < csplit && c < T; ++c) ntiles += T - c; }
   // XCD-aware order: consecutive tile indices (which share operand panels) stay on one XCD and its L2
-  const int nx = (int)gridDim.x;
-  const int per = (nx + 7) >> 3;
+  // `per` from THIS front's tile count, not from the grid (which is sized for the largest front of the level):
+  // otherwise a smaller front of a batched launch runs on the first one or two XCDs only
+  const int per = (ntiles + 7) >> 3;
+  if ((int)(blockIdx.x >> 3) >= per) return;
   const int idx = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
   if (idx >= ntiles) return;
   int ti, tj;
