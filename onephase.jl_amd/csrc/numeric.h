@@ -63,7 +63,7 @@ struct DevPlan {
 
 // front classes by order f: 0: f<=32 (one wave), 1: f<=64, 2: f<=small_max (256 threads, LDS), 3: big
 constexpr int kNumClasses = 4;
-struct Segment { int off = 0, cnt = 0, maxf = 0, maxk = 0; };
+struct Segment { int off = 0, cnt = 0, maxf = 0, maxk = 0, minf = 1 << 30; };
 struct LevelSchedule { Segment seg[kNumClasses]; };
 
 struct Numeric {
@@ -75,6 +75,7 @@ struct Numeric {
   std::vector<void*> allocations;
   int nb = 64;
   int group = 2;   // block columns per super-step: the trailing update runs with K = group * nb
+  int group_big = 4, group_big_minf = 8192;   // ... and for fronts of at least group_big_minf rows
   int small_max = 128;
   int64_t n_small = 0, n_big = 0;
   hipStream_t stream = nullptr;

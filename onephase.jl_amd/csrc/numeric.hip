@@ -1430,7 +1430,13 @@ std::string numeric_setup(const Symbolic& S, const SymbolicOptions& opts, hipStr
   N.stream = stream;
   N.nb = std::max(32, std::min((opts.panel_nb + 31) / 32 * 32, 128));
   N.small_max = std::max(32, std::min(opts.small_front_max, 136));
-  N.group = getenv("OKKT_GROUP") ? std::max(1, std::min(atoi(getenv("OKKT_GROUP")), 4)) : 2;
+  // block columns per super-step (K = group * NB of the trailing update): 2 by default; fronts of at least
+  // group_big_minf rows use group_big (more flops per byte of C traffic; the longer panel chain only pays off when the
+  // trailing update is large).  OKKT_GROUP fixes one value for every front.
+  N.group = 2;
+  N.group_big = getenv("OKKT_GROUP_BIG") ? std::max(1, std::min(atoi(getenv("OKKT_GROUP_BIG")), 4)) : 4;
+  N.group_big_minf = getenv("OKKT_GROUP_BIG_MINF") ? atoi(getenv("OKKT_GROUP_BIG_MINF")) : 8192;
+  if (getenv("OKKT_GROUP")) { N.group = N.group_big = std::max(1, std::min(atoi(getenv("OKKT_GROUP")), 4)); }
   N.nnz_in = S.nnz_in;
   if (S.max_front > 46000) return "front order exceeds the 32-bit local offset range";
   const int ns = S.nsuper;
@@ -1486,10 +1492,11 @@ std::string numeric_setup(const Symbolic& S, const SymbolicOptions& opts, hipStr
           int f = (int)(S.row_ptr[s + 1] - S.row_ptr[s]);
           int k = S.sn_col0[s + 1] - S.sn_col0[s];
           g.maxf = std::max(g.maxf, f);
+          g.minf = std::min(g.minf, f);
           g.maxk = std::max(g.maxk, k);
           sched.push_back(s);
           if (c == 3 && getenv("OKKT_DEBUG_FRONTS")) fprintf(stderr, "okkt: big front level %d  f %d  k %d\n", (int)l, f, k);
-          if (c == 3) { wpos[s] = wtotal; wtotal += (int64_t)f * N.nb * N.group * 2; ++N.n_big;   /* two super-steps of W: look-ahead double buffer */ } else ++N.n_small;
+          if (c == 3) { wpos[s] = wtotal; wtotal += (int64_t)f * N.nb * (f >= N.group_big_minf ? std::max(N.group, N.group_big) : N.group) * 2; ++N.n_big;   /* two super-steps of W: look-ahead double buffer */ } else ++N.n_small;
         }
       }
     }
@@ -1675,7 +1682,8 @@ std::string numeric_factor_enqueue(Numeric& N, const double* d_vals, double tol,
       const size_t lds_diag_v1 = ((size_t)(NB + 2) * NB + (size_t)std::max(NB - kIB, kIB) * kIB + 3 * kIB + NB) * sizeof(double);
       const size_t lds_diag = ((size_t)3 * kMW * kPLD + (size_t)2 * 4 * 32 * kXld) * sizeof(double);
       static const int diag_v1 = getenv("OKKT_DIAG_V1") ? atoi(getenv("OKKT_DIAG_V1")) : 0;
-      const int GS = N.group;
+      // every front of the segment must own a W buffer for this group size: decided on the smallest front
+      const int GS = g.minf >= N.group_big_minf ? N.group_big : N.group;
       // W of super-step q lives in wbuf columns [(q & 1) * GS * NB, ...): the look-ahead factors the panels of
       // super-step q + 1 while the trailing update of super-step q still reads its W
       auto launch_syrk = [&](hipStream_t sst, int stepA, int npan, int tstep, int head) -> std::string {
