@@ -34,6 +34,8 @@ int solver_ensure_numeric(okkt_solver_s* h) {
   h->N.part_id = h->part_id;
   std::string e = numeric_setup(h->S, h->sopts, h->stream, h->N);
   h->N.stream_panel = h->stream_panel;
+  h->N.stream_aux = h->stream_aux;
+  if (const char* sh = getenv("OKKT_SPLIT_HEAD")) h->N.split_head = atoi(sh);
   if (const char* mt = getenv("OKKT_LA_MIN_TILES")) h->N.la_min_tiles = atoi(mt);
   if (!e.empty()) { numeric_release(h->N); return solver_set_error(h, OKKT_ERR_HIP, e); }
   h->numeric_ready = true;
@@ -168,10 +170,13 @@ int okkt_create(okkt_handle* out, const okkt_opts* opts) {
       int lo = 0, hi = 0;
       if (hipExtStreamCreateWithCUMask(&h->stream, (uint32_t)mask.size(), mask.data()) != hipSuccess ||
           hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess ||
-          hipStreamCreateWithPriority(&h->stream_panel, hipStreamNonBlocking, hi) != hipSuccess) {
+          hipStreamCreateWithPriority(&h->stream_panel, hipStreamNonBlocking, hi) != hipSuccess ||
+          hipStreamCreateWithPriority(&h->stream_aux, hipStreamNonBlocking, hi) != hipSuccess) {
         (void)hipGetLastError();
         if (h->stream) { (void)hipStreamDestroy(h->stream); h->stream = nullptr; }
+        if (h->stream_panel) { (void)hipStreamDestroy(h->stream_panel); }
         h->stream_panel = nullptr;
+        h->stream_aux = nullptr;
       }
     }
     if (!h->stream && hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return OKKT_ERR_HIP; }
@@ -191,6 +196,7 @@ int okkt_destroy(okkt_handle h) {
     if (h->d_rhs_stage) (void)hipFree(h->d_rhs_stage);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->stream_aux) (void)hipStreamDestroy(h->stream_aux);
     if (h->stream_panel) (void)hipStreamDestroy(h->stream_panel);
     if (h->stream) (void)hipStreamDestroy(h->stream);
   }

@@ -81,6 +81,8 @@ struct Numeric {
   hipStream_t stream = nullptr;
   // look-ahead: panels of the next super-step are factored on stream_panel while the trailing update runs
   hipStream_t stream_panel = nullptr;
+  hipStream_t stream_aux = nullptr;     // off-critical-path part of the in-group panel updates
+  int split_head = 1;
   int lookahead = 1;
   int la_min_tiles = 256;                // rest triangle must hold at least this many 128 x 128 tiles
   std::vector<hipEvent_t> la_events;

@@ -1008,7 +1008,7 @@ __global__ __launch_bounds__(kSyrkNW * 64, kSyrkNW / 2) void k_big_syrk(DevPlan 
   const int T = (f - t0 + 127) >> 7;
   int ntiles;
   if (HEAD == kSyrkTrail) { const int Tr = max(T - csplit, 0); ntiles = Tr * (Tr + 1) / 2; }
-  else if (HEAD == kSyrkPanel) ntiles = T;
+  else if (HEAD == kSyrkPanel) ntiles = csplit == 1 ? min(T, 1) : (csplit == 2 ? max(T - 1, 0) : T);   // all / diagonal tile / the rest
   else { ntiles = 0; for (int c = 0; c < csplit && c < T; ++c) ntiles += T - c; }
   // XCD-aware order: consecutive tile indices (which share operand panels) stay on one XCD and its L2
   // `per` from THIS front's tile count, not from the grid (which is sized for the largest front of the level):
@@ -1018,7 +1018,7 @@ __global__ __launch_bounds__(kSyrkNW * 64, kSyrkNW / 2) void k_big_syrk(DevPlan 
   const int idx = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
   if (idx >= ntiles) return;
   int ti, tj;
-  if (HEAD == kSyrkPanel) { ti = idx; tj = 0; }
+  if (HEAD == kSyrkPanel) { ti = idx + (csplit == 2 ? 1 : 0); tj = 0; }
   else if (HEAD == kSyrkAhead) {
     int rest = idx; tj = 0;
     while (rest >= T - tj) { rest -= T - tj; ++tj; }
@@ -1434,7 +1434,7 @@ std::string numeric_setup(const Symbolic& S, const SymbolicOptions& opts, hipStr
   // group_big_minf rows use group_big (more flops per byte of C traffic; the longer panel chain only pays off when the
   // trailing update is large).  OKKT_GROUP fixes one value for every front.
   N.group = 2;
-  N.group_big = getenv("OKKT_GROUP_BIG") ? std::max(1, std::min(atoi(getenv("OKKT_GROUP_BIG")), 4)) : 4;
+  N.group_big = getenv("OKKT_GROUP_BIG") ? std::max(1, std::min(atoi(getenv("OKKT_GROUP_BIG")), 8)) : 4;
   N.group_big_minf = getenv("OKKT_GROUP_BIG_MINF") ? atoi(getenv("OKKT_GROUP_BIG_MINF")) : 8192;
   if (getenv("OKKT_GROUP")) { N.group = N.group_big = std::max(1, std::min(atoi(getenv("OKKT_GROUP")), 4)); }
   N.nnz_in = S.nnz_in;
@@ -1686,7 +1686,7 @@ std::string numeric_factor_enqueue(Numeric& N, const double* d_vals, double tol,
       const int GS = g.minf >= N.group_big_minf ? N.group_big : N.group;
       // W of super-step q lives in wbuf columns [(q & 1) * GS * NB, ...): the look-ahead factors the panels of
       // super-step q + 1 while the trailing update of super-step q still reads its W
-      auto launch_syrk = [&](hipStream_t sst, int stepA, int npan, int tstep, int head) -> std::string {
+      auto launch_syrk = [&](hipStream_t sst, int stepA, int npan, int tstep, int head, int sub = 0) -> std::string {
         // upper bound on the rows of the target region: a front whose pivot block ends inside the group
         // starts its trailing region at k < tstep * NB
         const int rem = g.maxf - (head == 1 ? tstep : stepA) * NB;
@@ -1694,7 +1694,7 @@ std::string numeric_factor_enqueue(Numeric& N, const double* d_vals, double tol,
         const int T = (rem + 127) / 128;
         const int Tr = std::max(T - GS, 0);
         int ntile = T * (T + 1) / 2;
-        if (head == 1) ntile = T;
+        if (head == 1) ntile = sub == 1 ? 1 : (sub == 2 ? T - 1 : T);
         else if (head == 2) { ntile = 0; for (int c = 0; c < GS && c < T; ++c) ntile += T - c; }
         else if (head == 3) ntile = Tr * (Tr + 1) / 2;
         if (ntile == 0) return "";
@@ -1726,7 +1726,7 @@ std::string numeric_factor_enqueue(Numeric& N, const double* d_vals, double tol,
           OKKT_HIP_TRY(hipEventRecord(N.prof_events[N.prof_used++], sst));
         }
 #define OKKT_SYRK(D, H) hipLaunchKernelGGL((k_big_syrk<D, H>), grid, dim3(kSyrkNW * 64), syrk_lds_bytes(kSyrkStages), sst, P, list, stepA, npan, tstep, NB, wofs, csplit)
-        const int csplit = head == 0 ? 0 : GS;
+        const int csplit = head == 1 ? sub : (head == 0 ? 0 : GS);
         if (head == 1) OKKT_SYRK(0, kSyrkPanel);
         else if (head == 2) OKKT_SYRK(0, kSyrkAhead);
         else switch (dbg_syrk) {   // timing-only ablations of the trailing update (OKKT_DEBUG_SYRK): wrong outputs
@@ -1740,15 +1740,41 @@ std::string numeric_factor_enqueue(Numeric& N, const double* d_vals, double tol,
         if (prof) OKKT_HIP_TRY(hipEventRecord(N.prof_events[N.prof_used++], sst));
         return "";
       };
+      auto next_event = [&](hipEvent_t* ev) -> std::string {
+        if (N.la_used >= N.la_events.size())
+          for (int q = 0; q < 64; ++q) { hipEvent_t e2; OKKT_HIP_TRY(hipEventCreateWithFlags(&e2, hipEventDisableTiming)); N.la_events.push_back(e2); }
+        *ev = N.la_events[N.la_used++];
+        return "";
+      };
+      auto rem_rows = [&](int step) { return g.maxf - step * NB; };
       // the panels of super-step q (block columns [q * GS, (q + 1) * GS)): diag -> trsm, with the in-group
       // "head" update that brings each later panel of the group up to date first
       auto launch_panels = [&](hipStream_t pst, int stepA) -> std::string {
         const int par = (stepA / GS) & 1;
         for (int i = 0; i < GS && stepA + i < nsteps; ++i) {
           const int step = stepA + i;
-          if (i > 0) { std::string e = launch_syrk(pst, stepA, i, step, 1); if (!e.empty()) return e; }
+          // in-group update of panel i: only its diagonal tile is on the critical path (k_big_diag needs it); the
+          // other tiles run on the auxiliary stream beside k_big_diag and are joined before k_big_trsm
+          hipEvent_t ev_rest = nullptr;
+          if (i > 0) {
+            const bool split = N.stream_aux != nullptr && N.split_head && rem_rows(step) > 3000;   // the two extra stream hops cost more than they hide on small fronts
+            if (split) {
+              hipEvent_t ev_t;
+              std::string e = next_event(&ev_t);
+              if (!e.empty() || !(e = next_event(&ev_rest)).empty()) return e;
+              OKKT_HIP_TRY(hipEventRecord(ev_t, pst));                         // trsm of panel i - 1 is behind this
+              OKKT_HIP_TRY(hipStreamWaitEvent(N.stream_aux, ev_t, 0));
+              if (!(e = launch_syrk(N.stream_aux, stepA, i, step, 1, 2)).empty()) return e;
+              OKKT_HIP_TRY(hipEventRecord(ev_rest, N.stream_aux));
+              if (!(e = launch_syrk(pst, stepA, i, step, 1, 1)).empty()) return e;
+            } else {
+              std::string e = launch_syrk(pst, stepA, i, step, 1);
+              if (!e.empty()) return e;
+            }
+          }
           if (diag_v1) hipLaunchKernelGGL(k_big_diag_v1, dim3(g.cnt), dim3(256), lds_diag_v1, pst, P, list, step, NB, tol, dbg_stop);
           else hipLaunchKernelGGL(k_big_diag, dim3(g.cnt), dim3(256), lds_diag, pst, P, list, step, NB, tol, dbg_stop);
+          if (ev_rest) OKKT_HIP_TRY(hipStreamWaitEvent(pst, ev_rest, 0));
           const int rem = g.maxf - step * NB;  // upper bound on rows below the diagonal block
           if (rem > 0) {
             const dim3 gr((rem + 63) / 64, g.cnt);
@@ -1763,12 +1789,6 @@ std::string numeric_factor_enqueue(Numeric& N, const double* d_vals, double tol,
             }
           }
         }
-        return "";
-      };
-      auto next_event = [&](hipEvent_t* ev) -> std::string {
-        if (N.la_used >= N.la_events.size())
-          for (int q = 0; q < 64; ++q) { hipEvent_t e2; OKKT_HIP_TRY(hipEventCreateWithFlags(&e2, hipEventDisableTiming)); N.la_events.push_back(e2); }
-        *ev = N.la_events[N.la_used++];
         return "";
       };
       // Look-ahead: the trailing update of super-step q is split into the tile columns of super-step q + 1
