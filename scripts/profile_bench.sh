@@ -4,11 +4,11 @@ export TMPDIR=/tmp
 R=${1:-r01}
 OUT=gpurun_out/profiles_new
 mkdir -p $OUT gpurun_out/pb_stats gpurun_out/pb_fetch gpurun_out/pb_write
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/pb_stats -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline > $OUT/${R}_bench_under_rocprof.json 2> /dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/pb_stats -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-kkt-level > $OUT/${R}_bench_under_rocprof.json 2> /dev/null
 cp gpurun_out/pb_stats/*/*kernel_stats.csv $OUT/${R}_bench_kernel_stats.csv
 # HBM traffic of the dominant kernel: separate PMC passes (FETCH_SIZE and WRITE_SIZE do not fit one pass)
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pb_fetch -- python3 bench.py --steps 2 --warmup 0 --no-cpu-baseline > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pb_write -- python3 bench.py --steps 2 --warmup 0 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pb_fetch -- python3 bench.py --steps 2 --warmup 0 --no-cpu-baseline --no-kkt-level > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pb_write -- python3 bench.py --steps 2 --warmup 0 --no-cpu-baseline --no-kkt-level > /dev/null 2>&1
 python3 - "$R" <<'PY'
 import csv, glob, json, sys
 R = sys.argv[1]
