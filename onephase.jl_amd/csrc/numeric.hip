@@ -385,36 +385,6 @@ __device__ __forceinline__ double readlane_f64(double v, int src_lane) {
   return __hiloint2double(hi, lo);
 }
 
-// 32 x 32 (or smaller, w x w) LDL^T held in registers by lanes 0..31 of one wave; row i on lane i.
-__device__ __forceinline__ void diag32_wave(double* B, int ldb, int off, int w) {
-  const int lane = threadIdx.x & 63;
-  double a[32];
-#pragma unroll
-  for (int c = 0; c < 32; ++c)
-    a[c] = (lane < w && c < w && c <= lane) ? B[(off + lane) + (size_t)(off + c) * ldb] : (c == lane ? 1.0 : 0.0);
-#pragma unroll
-  for (int j = 0; j < 32; ++j) {
-    const double dj = readlane_f64(a[j], j);
-    const double wj = a[j];
-    const double l = wj * fast_rcp_f64(dj);
-    // broadcasts in batches of 8 into distinct SGPR pairs, then the 8 FMAs: one SGPR-hazard wait per batch
-#pragma unroll
-    for (int c0 = j + 1; c0 < 32; c0 += 8) {
-      double wc[8];
-#pragma unroll
-      for (int q = 0; q < 8; ++q) wc[q] = (c0 + q < 32) ? readlane_f64(wj, (c0 + q) & 31) : 0.0;
-      // no predicate: an update of a[c] on a lane < c only touches the unused upper triangle of that row
-      // (it is never read back: lane c broadcasts a[j] only for j < c, the write-back stores c <= lane)
-#pragma unroll
-      for (int q = 0; q < 8; ++q)
-        if (c0 + q < 32) a[c0 + q] = __builtin_fma(-l, wc[q], a[c0 + q]);
-    }
-    if (lane > j) a[j] = l;
-  }
-#pragma unroll
-  for (int c = 0; c < 32; ++c)
-    if (lane < w && c < w && c <= lane) B[(off + lane) + (size_t)(off + c) * ldb] = a[c];
-}
 
 constexpr int kIB = 32;  // inner block width of the diagonal-block kernel
 constexpr int kTld = 33; // leading dimension of the 32 x 32 scratch blocks (odd: conflict-free column access)
@@ -422,141 +392,8 @@ constexpr int kTld = 33; // leading dimension of the 32 x 32 scratch blocks (odd
 // NB x NB diagonal block of block-column `step`: LDL^T in LDS (inner width 32: register/readlane
 // 32 x 32 kernel on one wave, row-parallel solve below it, MFMA rank-32 update), D and inertia out,
 // then X = inv(L11) block by block (MFMA products) for the row-parallel k_big_trsm and the solves.
-__global__ __launch_bounds__(256) void k_big_diag_v1(DevPlan P, const int* __restrict__ list, int step, int NB, double tol, int dbg_stop) {
-  extern __shared__ __attribute__((aligned(16))) double sm[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int l15 = lane & 15, l4 = lane >> 4;
-  const int s = list[blockIdx.x];
-  const int col0 = P.sn_col0[s];
-  const int k = P.sn_col0[s + 1] - col0;
-  const int f = (int)(P.row_ptr[s + 1] - P.row_ptr[s]);
-  const int j0 = step * NB;
-  if (j0 >= k) return;
-  const int nb = min(NB, k - j0);
-  const int ldb = NB + 2;                    // padded: column stride = 4 banks, MFMA fragment reads stay conflict-free
-  const int RMAX = max(NB - kIB, kIB);       // most rows below an inner block (>= 32: also the T scratch)
-  double* B = sm;                            // NB columns of ldb
-  double* Wb = sm + (size_t)ldb * NB;        // RMAX x 32 scratch (+ slack for the padded T blocks)
-  double* rdv = Wb + (size_t)RMAX * kIB + 3 * kIB;   // reciprocal pivots
-  double* F = P.arena + P.front_pos[s];
-  // one block column per wave instruction: lane l moves rows 2l, 2l+1 (16 bytes); 8 columns in flight
-  for (int cb = wave * 8; cb < NB; cb += 32) {
-    double v0[8], v1[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int c = cb + q, i0 = 2 * lane;
-      const double* src = F + (size_t)(j0 + min(c, nb - 1)) * f + j0;
-      v0[q] = keep_f64(src[min(i0, nb - 1)], c < nb && i0 < nb && i0 >= c && i0 < NB);
-      v1[q] = keep_f64(src[min(i0 + 1, nb - 1)], c < nb && i0 + 1 < nb && i0 + 1 >= c && i0 + 1 < NB);
-    }
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int c = cb + q, i0 = 2 * lane;
-      if (c < NB && i0 < NB) { B[i0 + (size_t)c * ldb] = v0[q]; B[i0 + 1 + (size_t)c * ldb] = v1[q]; }
-    }
-  }
-  __syncthreads();
-  if (dbg_stop == 1) return;
-  for (int off = 0; off < nb; off += kIB) {
-    const int w = min(kIB, nb - off);
-    if (wave == 0) diag32_wave(B, ldb, off, w);
-    __syncthreads();
-    if (dbg_stop == 7) continue;
-    if (tid < w) rdv[off + tid] = 1.0 / B[(off + tid) + (size_t)(off + tid) * ldb];
-    __syncthreads();
-    const int c0 = off + w;
-    const int R = nb - c0;
-    if (wave == 3) {
-      // X_ii = inv(L_ii) (unit lower) on the otherwise idle wave 3, beside the row solve below (waves 0-1).
-      // Row r on lane r, like diag32_wave: X[r][:] -= L[r][p] * X[p][:] for p < r, rows broadcast by
-      // v_readlane.  It goes straight to HBM (the LDS copy of L_ii is still needed) and is read back for
-      // the off-diagonal blocks.
-      double x[kIB], lr[kIB];
-#pragma unroll
-      for (int p = 0; p < kIB; ++p)
-        lr[p] = (lane < w && p < lane) ? B[(off + min(lane, kIB - 1)) + (size_t)(off + p) * ldb] : 0.0;
-#pragma unroll
-      for (int c = 0; c < kIB; ++c) x[c] = (c == lane && lane < w) ? 1.0 : 0.0;
-#pragma unroll
-      for (int p = 0; p < kIB - 1; ++p) {
-#pragma unroll
-        for (int c0 = 0; c0 <= p; c0 += 8) {
-          double xp[8];
-#pragma unroll
-          for (int q = 0; q < 8; ++q) xp[q] = (c0 + q <= p) ? readlane_f64(x[(c0 + q) & 31], p) : 0.0;
-#pragma unroll
-          for (int q = 0; q < 8; ++q)
-            if (c0 + q <= p) x[c0 + q] = __builtin_fma(-lr[p], xp[q], x[c0 + q]);     // lr[p] = 0 on lanes <= p
-        }
-      }
-      double* Xg = P.invl + P.invl_pos[s] + (size_t)step * NB * NB;
-      if (lane < kIB) {
-#pragma unroll
-        for (int c = 0; c < kIB; ++c) Xg[(off + lane) + (size_t)(off + c) * NB] = x[c];
-      }
-    }
-    if (R > 0) {  // then w == 32
-      if (dbg_stop != 8 && tid < R) {
-        const int r = c0 + tid;
-        double wr[kIB];
-#pragma unroll
-        for (int c = 0; c < kIB; ++c) {
-          double v = B[r + (size_t)(off + c) * ldb];
-#pragma unroll
-          for (int p = 0; p < c; ++p) v -= wr[p] * B[(off + c) + (size_t)(off + p) * ldb];
-          wr[c] = v;
-        }
-#pragma unroll
-        for (int c = 0; c < kIB; ++c) {
-          Wb[tid + c * RMAX] = wr[c];
-          B[r + (size_t)(off + c) * ldb] = wr[c] * rdv[off + c];
-        }
-      }
-      __syncthreads();
-      // rank-32 update of the trailing R x R lower triangle, 16 x 16 MFMA tiles spread over the waves
-      const int nt = (R + 15) >> 4;
-      for (int t = wave; t < nt * (nt + 1) / 2; t += 4) {
-        int ri = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
-        while ((ri + 1) * (ri + 2) / 2 <= t) ++ri;
-        while (ri * (ri + 1) / 2 > t) --ri;
-        const int ci = t - ri * (ri + 1) / 2;
-        const int cb = c0 + ci * 16, rb = ri * 16;  // rb relative to c0
-        d4_t acc = (d4_t){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int k0 = 0; k0 < kIB; k0 += 4) {
-          const double av = B[(cb + l15) + (size_t)(off + k0 + l4) * ldb];   // L[c][p]
-          const double bv = Wb[(rb + l15) + (k0 + l4) * RMAX];               // W[r][p]
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
-        }
-        const int r = c0 + rb + l15;
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-          const int c = cb + l4 + 4 * reg;
-          if (r < nb && c < nb && r >= c) B[r + (size_t)c * ldb] -= acc[reg];
-        }
-      }
-      __syncthreads();
-    }
-  }
-  if (dbg_stop == 2 || dbg_stop == 7 || dbg_stop == 8) return;
-  // L11, D, inertia (one block column per wave instruction)
-  for (int c = wave; c < nb; c += 4) {
-    double* dst = F + (size_t)(j0 + c) * f + j0;
-    const int i0 = 2 * lane;
-    if (i0 >= c && i0 < nb) dst[i0] = B[i0 + (size_t)c * ldb];
-    if (i0 + 1 >= c && i0 + 1 < nb) dst[i0 + 1] = B[i0 + 1 + (size_t)c * ldb];
-  }
-  unsigned pos = 0, neg = 0, zer = 0, bad = 0;
-  for (int j = tid; j < nb; j += 256) {
-    const double d = B[j + (size_t)j * ldb];
-    P.dvals[col0 + j0 + j] = d;
-    classify_pivot(d, tol, pos, neg, zer, bad);
-  }
-  flush_counts(P.counters, pos, neg, zer, bad);
-  __syncthreads();
-}
 
-// k_big_diag (v2): LDL^T of the NB x NB diagonal block held in MFMA ACCUMULATORS.
+// k_big_diag: LDL^T of the NB x NB diagonal block held in MFMA ACCUMULATORS.
 //   The block is viewed as 8 x 8 tiles of 16 x 16 (identity-padded past nb); the 36 lower tiles are dealt
 //   cyclically to the four waves (9 accumulator quads per lane).  A micro-step factors 8 columns:
 //     (1) the waves that own the tile column copy the 8 columns out of their accumulators into LDS (Praw),
@@ -565,7 +402,7 @@ __global__ __launch_bounds__(256) void k_big_diag_v1(DevPlan P, const int* __res
 //         write the final L entries to HBM (and the 32 x 32 diagonal blocks to LDS for the inverse) and the
 //         operand panels -L, W = L D to LDS,
 //     (3) every live tile gets its rank-8 update as two v_mfma_f64_16x16x4 straight into the accumulators.
-//   16 micro-steps x 2 barriers replace the 128 pivot round trips of v1 (about 80 us -> 42 us per block).
+//   16 micro-steps x 2 barriers replace the 128 pivot round trips of a row-on-lane LDS version (80 us -> 42 us per block).
 //   Tile entry held by lane (l15, l4), register v of tile (ti, tj):  row 16 ti + l15, column 16 tj + 4 v + l4
 //   (rows on l15: the initial load reads 128-byte row segments of the column-major front).
 //   Entries above the diagonal and columns already factored are dead: the updates may write garbage there.
@@ -1615,7 +1452,6 @@ std::string numeric_setup(const Symbolic& S, const SymbolicOptions& opts, hipStr
   const int big_lds = 160 * 1024;
   OKKT_HIP_TRY(hipFuncSetAttribute((const void*)k_front_small<256>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds));
   OKKT_HIP_TRY(hipFuncSetAttribute((const void*)k_big_diag, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds));
-  OKKT_HIP_TRY(hipFuncSetAttribute((const void*)k_big_diag_v1, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds));
   OKKT_HIP_TRY(hipFuncSetAttribute((const void*)k_big_invert, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds));
   OKKT_HIP_TRY(hipFuncSetAttribute((const void*)k_big_trsm<3>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds));
   OKKT_HIP_TRY(hipFuncSetAttribute((const void*)k_big_trsm<4>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds));
@@ -1679,9 +1515,7 @@ std::string numeric_factor_enqueue(Numeric& N, const double* d_vals, double tol,
         else hipLaunchKernelGGL(k_big_assemble<false>, dim3((g.maxf + 3) / 4, g.cnt), dim3(256), (size_t)4 * lcol * sizeof(double), st, P, list, lcol);
       }
       const int nsteps = (g.maxk + NB - 1) / NB;
-      const size_t lds_diag_v1 = ((size_t)(NB + 2) * NB + (size_t)std::max(NB - kIB, kIB) * kIB + 3 * kIB + NB) * sizeof(double);
       const size_t lds_diag = ((size_t)3 * kMW * kPLD + (size_t)2 * 4 * 32 * kXld) * sizeof(double);
-      static const int diag_v1 = getenv("OKKT_DIAG_V1") ? atoi(getenv("OKKT_DIAG_V1")) : 0;
       // every front of the segment must own a W buffer for this group size: decided on the smallest front
       const int GS = g.minf >= N.group_big_minf ? N.group_big : N.group;
       // W of super-step q lives in wbuf columns [(q & 1) * GS * NB, ...): the look-ahead factors the panels of
@@ -1772,8 +1606,7 @@ std::string numeric_factor_enqueue(Numeric& N, const double* d_vals, double tol,
               if (!e.empty()) return e;
             }
           }
-          if (diag_v1) hipLaunchKernelGGL(k_big_diag_v1, dim3(g.cnt), dim3(256), lds_diag_v1, pst, P, list, step, NB, tol, dbg_stop);
-          else hipLaunchKernelGGL(k_big_diag, dim3(g.cnt), dim3(256), lds_diag, pst, P, list, step, NB, tol, dbg_stop);
+          hipLaunchKernelGGL(k_big_diag, dim3(g.cnt), dim3(256), lds_diag, pst, P, list, step, NB, tol, dbg_stop);
           if (ev_rest) OKKT_HIP_TRY(hipStreamWaitEvent(pst, ev_rest, 0));
           const int rem = g.maxf - step * NB;  // upper bound on rows below the diagonal block
           if (rem > 0) {
