@@ -49,6 +49,10 @@ struct DevPlan {
   int64_t* ea_cut = nullptr;     // per item: start of the child's chunk-boundary table in cutv
   int* cutv = nullptr;           // per child of a big front: positions of the parent's 1024-row boundaries in its rel list
   int64_t* acol_lo = nullptr;    // [n_bigcols + 1] first A entry of each big-front column
+  double* xsb = nullptr;         // explicit inverses of the 1024-column diagonal blocks (super-block solves)
+  int64_t* xsb_pos = nullptr;    // [nsuper] offset into xsb, -1 if the front takes the 128-column steps
+  double* ysb = nullptr;         // block product work vector
+  int64_t* ysb_pos = nullptr;
   double* invl = nullptr;          // inverse of the unit-lower diagonal blocks, NB x NB each
   int64_t* invl_pos = nullptr;     // [nsuper]
   double* bigw = nullptr;          // [n_bigcols] forward-solve work vectors of the big fronts
@@ -63,7 +67,7 @@ struct DevPlan {
 
 // front classes by order f: 0: f<=32 (one wave), 1: f<=64, 2: f<=small_max (256 threads, LDS), 3: big
 constexpr int kNumClasses = 4;
-struct Segment { int off = 0, cnt = 0, maxf = 0, maxk = 0, minf = 1 << 30; };
+struct Segment { int off = 0, cnt = 0, maxf = 0, maxk = 0, minf = 1 << 30, mink = 1 << 30; };
 struct LevelSchedule { Segment seg[kNumClasses]; };
 
 struct Numeric {
@@ -84,6 +88,12 @@ struct Numeric {
   hipStream_t stream_aux = nullptr;     // off-critical-path part of the in-group panel updates
   int split_head = 1;
   int lookahead = 1;
+  int use_sb = 1;                        // super-block solves for fronts with >= 2048 pivot columns 
+  bool sb_ready = false;                 // inverses of the current factorisation are in place
+  int solves_since_factor = 0;
+  int sb_lazy = 0;                       // solves with the 128-column steps before the inverses are prepared
+  void* blas = nullptr;                  // rocblas_handle (TRSM for the super-block inverses)
+  std::vector<int64_t> xsb_pos_host, front_pos_host;
   int la_min_tiles = 256;                // rest triangle must hold at least this many 128 x 128 tiles
   std::vector<hipEvent_t> la_events;
   size_t la_used = 0;

@@ -13,6 +13,8 @@
 //     (k_big_trsm) and an FP64-MFMA trailing update C -= W * L^T (k_big_syrk).
 // Extend-add is deterministic: every destination entry is owned by exactly one workgroup that
 // adds the children's contribution blocks in a fixed order -- no floating-point atomics.
+#include <rocblas/rocblas.h>
+
 #include "numeric.h"
 
 #include <algorithm>
@@ -303,6 +305,13 @@ __global__ __launch_bounds__(256) void k_big_assemble(DevPlan P, const int* __re
 // Per child a small table gives the position in its rel list where each chunk boundary falls (the list is sorted),
 // and per front column the range of its A entries is precomputed: no searches on the device.
 constexpr int kAsmChunk = 1024;
+constexpr int kSolveSB = 1024;   // super-block width of the solves of fronts with many pivot columns (see k_sb_*)
+__global__ void k_sb_identity(double* __restrict__ X, int sb, int64_t total) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int64_t e = i % ((int64_t)sb * sb);
+  X[i] = (e / sb == e % sb) ? 1.0 : 0.0;
+}
 __global__ __launch_bounds__(256) void k_big_assemble_chunked(DevPlan P, const int* __restrict__ list) {
   __shared__ double sm[4 * kAsmChunk];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -1148,7 +1157,18 @@ __global__ __launch_bounds__(256) void k_bigsolve_bwd_pre(DevPlan P, const int* 
   const int* rows = P.rows + P.row_ptr[s];
   const double* col = P.arena + P.front_pos[s] + (size_t)c * f;
   double acc = 0.0;
-  for (int r = k + lane; r < f; r += 64) acc += col[r] * P.xwork[rows[r]];
+  int r = k + lane;
+  for (; r + 7 * 64 < f; r += 8 * 64) {       // eight index / value / x loads in flight per lane
+    int ri[8];
+    double lv[8], xv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { ri[u] = rows[r + 64 * u]; lv[u] = col[r + 64 * u]; }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) xv[u] = P.xwork[ri[u]];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc += lv[u] * xv[u];
+  }
+  for (; r < f; r += 64) acc += col[r] * P.xwork[rows[r]];
   for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
   if (lane == 0) P.xwork[col0 + c] -= acc;
 }
@@ -1331,6 +1351,7 @@ std::string numeric_setup(const Symbolic& S, const SymbolicOptions& opts, hipStr
           g.maxf = std::max(g.maxf, f);
           g.minf = std::min(g.minf, f);
           g.maxk = std::max(g.maxk, k);
+          g.mink = std::min(g.mink, k);
           sched.push_back(s);
           if (c == 3 && getenv("OKKT_DEBUG_FRONTS")) fprintf(stderr, "okkt: big front level %d  f %d  k %d\n", (int)l, f, k);
           if (c == 3) { wpos[s] = wtotal; wtotal += (int64_t)f * N.nb * (f >= N.group_big_minf ? std::max(N.group, N.group_big) : N.group) * 2; ++N.n_big;   /* two super-steps of W: look-ahead double buffer */ } else ++N.n_small;
@@ -1358,6 +1379,7 @@ std::string numeric_setup(const Symbolic& S, const SymbolicOptions& opts, hipStr
     }
   }
   N.sn_f.resize(ns);
+  N.front_pos_host.assign(S.front_pos.begin(), S.front_pos.end());
   N.sn_k.resize(ns);
   for (int s = 0; s < ns; ++s) { N.sn_f[s] = (int)(S.row_ptr[s + 1] - S.row_ptr[s]); N.sn_k[s] = S.sn_col0[s + 1] - S.sn_col0[s]; }
   // big fronts: inverted extend-add lists (per front column: which (child, jj) land on it),
@@ -1437,6 +1459,30 @@ std::string numeric_setup(const Symbolic& S, const SymbolicOptions& opts, hipStr
     if (!(e = upload(N, cutv, &d.cutv)).empty()) return e;
     if (!(e = upload(N, acol_lo, &d.acol_lo)).empty()) return e;
     if (!(e = dalloc(N, (size_t)invl_total, &d.invl, false)).empty()) return e;
+    // explicit inverses of the kSolveSB-column diagonal blocks of fronts with many pivot columns (super-block solves)
+    {
+      std::vector<int64_t> xsb_pos(ns, -1), ysb_pos(ns, -1);
+      int64_t xtot = 0, ytot = 0;
+      N.use_sb = getenv("OKKT_SOLVE_SB") ? atoi(getenv("OKKT_SOLVE_SB")) : 1;
+      N.sb_lazy = getenv("OKKT_SOLVE_SB_LAZY") ? atoi(getenv("OKKT_SOLVE_SB_LAZY")) : -1;   // -1: by size, see below
+      int64_t max_sb_k = 0;
+      for (int s2 = 0; s2 < ns; ++s2)
+        if (wpos[s2] >= 0 && N.use_sb) {
+          const int64_t k2 = S.sn_col0[s2 + 1] - S.sn_col0[s2];
+          if (k2 < 2 * kSolveSB) continue;
+          xsb_pos[s2] = xtot; xtot += ((k2 + kSolveSB - 1) / kSolveSB) * (int64_t)kSolveSB * kSolveSB;
+          ysb_pos[s2] = ytot; ytot += 4 * kSolveSB;     // four partial vectors of a block product
+          max_sb_k = std::max(max_sb_k, k2);
+        }
+      // the inversion pays for itself on the first solve only when the front is large (S-metric root: 16 641 columns);
+      // medium fronts take the 128-column steps once and prepare the inverses when a second solve arrives
+      if (N.sb_lazy < 0) N.sb_lazy = max_sb_k >= 8 * kSolveSB ? 0 : 1;
+      N.xsb_pos_host = xsb_pos;
+      if (!(e = upload(N, xsb_pos, &d.xsb_pos)).empty()) return e;
+      if (!(e = upload(N, ysb_pos, &d.ysb_pos)).empty()) return e;
+      if (!(e = dalloc(N, (size_t)xtot, &d.xsb, false)).empty()) return e;
+      if (!(e = dalloc(N, (size_t)ytot, &d.ysb, true)).empty()) return e;
+    }
     if (!(e = dalloc(N, (size_t)nbigcols, &d.bigw, true)).empty()) return e;
   }
   if (!(e = dalloc(N, (size_t)S.arena_doubles + 512, &d.arena, false)).empty()) return e;
@@ -1467,9 +1513,12 @@ void numeric_release(Numeric& N) {
   N.prof_events.clear();
   N.prof_used = 0;
   N.prof_flops.clear();
+  if (N.blas) { (void)rocblas_destroy_handle((rocblas_handle)N.blas); N.blas = nullptr; }
   for (hipEvent_t ev : N.la_events) (void)hipEventDestroy(ev);
   N.la_events.clear();
   N.la_used = 0;
+  N.sb_ready = false;
+  N.solves_since_factor = 0;
   for (void* p : N.allocations) (void)hipFree(p);
   N.allocations.clear();
   N.levels.clear();
@@ -1484,6 +1533,8 @@ std::string numeric_factor_enqueue(Numeric& N, const double* d_vals, double tol,
   const std::vector<LevelSchedule>& levels = which == 0 ? N.levels : N.levels_top;
   if (reset_counters) OKKT_HIP_TRY(hipMemsetAsync(P.counters, 0, 4 * sizeof(unsigned long long), st));
   N.la_used = 0;
+  N.sb_ready = false;            // the super-block inverses belong to the previous factorisation
+  N.solves_since_factor = 0;
   const int NB = N.nb;
   static const int dbg_syrk = getenv("OKKT_DEBUG_SYRK") ? atoi(getenv("OKKT_DEBUG_SYRK")) : 0;
   static const int dbg_stop = getenv("OKKT_DEBUG_DIAG_STOP") ? atoi(getenv("OKKT_DEBUG_DIAG_STOP")) : 0;
@@ -1666,6 +1717,183 @@ std::string numeric_factor_enqueue(Numeric& N, const double* d_vals, double tol,
   return "";
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Super-block solves for fronts with many pivot columns (the dense root): the 128-column step kernels are pure
+// launch latency there (130 dependent launches of ~10-15 us per sweep).  After the factorisation the unit-lower
+// diagonal blocks of kSolveSB columns are inverted explicitly (X = L_bb^-1, a plain library TRSM on the identity:
+// rocblas_dtrsm_strided_batched); a sweep then takes two launches per kSolveSB columns: a block product with X
+// and one tall GEMV with the panel below (forward) / the row block to the left (backward).
+
+// forward, block b: partial products of y = X_b * w_b.  Workgroup (rb, cq): rows [rb * 64, +64), columns
+// [cq * 256, +256) (wave wv: 64 of them, two batches of 32 loads in flight); the four partial vectors are summed by
+// the consumer (k_sb_fwd_upd), which also stores z = y / d.  64 workgroups instead of 16: the product is pure latency.
+__global__ __launch_bounds__(256) void k_sb_fwd_y(DevPlan P, const int* __restrict__ list, int b) {
+  __shared__ double wj[256], part[4][64];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int s = list[blockIdx.y];
+  const int col0 = P.sn_col0[s];
+  const int k = P.sn_col0[s + 1] - col0;
+  const int c0 = b * kSolveSB;
+  if (c0 >= k) return;
+  const int kb = min(kSolveSB, k - c0);
+  const int i = blockIdx.x * 64 + lane, cq = blockIdx.z;
+  if ((int)blockIdx.x * 64 >= kb) return;
+  double* yp = P.ysb + P.ysb_pos[s] + (size_t)cq * kSolveSB;
+  // X is lower triangular (zero above the diagonal, 1 on it): no row of this workgroup reaches beyond its last row
+  const int pend = min(kb, (int)blockIdx.x * 64 + 64);
+  if (cq * 256 >= pend) { if (wv == 0 && i < kb) yp[i] = 0.0; return; }
+  const double* w = P.bigw + P.bigcol_base[s] + c0 + cq * 256;
+  const double* X = P.xsb + P.xsb_pos[s] + (size_t)b * kSolveSB * kSolveSB + (size_t)cq * 256 * kSolveSB;
+  const int kq = min(256, kb - cq * 256);          // columns of this quarter
+  const int ic = min(i, kb - 1);
+  double v[2][32];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int q = 0; q < 32; ++q) v[h][q] = X[(size_t)min(wv * 64 + h * 32 + q, kq - 1) * kSolveSB + ic];
+  wj[tid] = tid < kq ? w[tid] : 0.0;
+  __syncthreads();
+  double a = 0.0;
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int q = 0; q < 32; ++q) a += (wv * 64 + h * 32 + q < kq) ? v[h][q] * wj[wv * 64 + h * 32 + q] : 0.0;
+  part[wv][lane] = a;
+  __syncthreads();
+  if (wv == 0 && i < kb) yp[i] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+}
+// forward, block b: y = sum of the four partials, z = y / d (first workgroup), then the rows below the block:
+// w[r] -= sum_p L[r][c0 + p] y[p]   (and the contribution vector on the last block)
+__global__ __launch_bounds__(256) void k_sb_fwd_upd(DevPlan P, const int* __restrict__ list, int b) {
+  __shared__ double yj[kSolveSB], part[4][64];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int s = list[blockIdx.y];
+  const int col0 = P.sn_col0[s];
+  const int k = P.sn_col0[s + 1] - col0;
+  const int f = (int)(P.row_ptr[s + 1] - P.row_ptr[s]);
+  const int c0 = b * kSolveSB;
+  if (c0 >= k) return;
+  const int kb = min(kSolveSB, k - c0);
+  const int r = c0 + kb + blockIdx.x * 64 + lane;
+  if (blockIdx.x > 0 && c0 + kb + (int)blockIdx.x * 64 >= f) return;
+  double* w = P.bigw + P.bigcol_base[s];
+  const double* yp = P.ysb + P.ysb_pos[s];
+  const int rc = min(r, f - 1);
+  const double wr = w[rc];
+  for (int p = tid; p < kSolveSB; p += 256) {
+    const int pc = min(p, kb - 1);
+    const double y = (yp[pc] + yp[kSolveSB + pc]) + (yp[2 * kSolveSB + pc] + yp[3 * kSolveSB + pc]);
+    yj[p] = p < kb ? y : 0.0;
+    if (blockIdx.x == 0 && p < kb) P.xwork[col0 + c0 + p] = y / P.dvals[col0 + c0 + p];
+  }
+  __syncthreads();
+  if (c0 + kb + (int)blockIdx.x * 64 >= f) return;
+  const double* L = P.arena + P.front_pos[s] + (size_t)c0 * f + rc;
+  double a = 0.0;
+  for (int p0 = wv * 256; p0 < min(kb, wv * 256 + 256); p0 += 64) {
+    double v[64];       // 64 loads per lane in flight: the panel is streamed from HBM, four round trips per wave
+#pragma unroll
+    for (int q = 0; q < 64; ++q) v[q] = L[(size_t)min(p0 + q, kb - 1) * f];
+#pragma unroll
+    for (int q = 0; q < 64; ++q) a += (p0 + q < kb) ? v[q] * yj[p0 + q] : 0.0;
+  }
+  part[wv][lane] = a;
+  __syncthreads();
+  if (wv == 0 && r < f) {
+    const double acc = wr - ((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]));
+    w[r] = acc;
+    if (c0 + kb >= k && r >= k) P.cv[P.cv_pos[s] + (r - k)] = acc;
+  }
+}
+// backward, block b: partial products of x = X_b' z.  Workgroup (cb, rq): columns [cb * 64, +64), rows
+// [rq * 256, +256); wave: 16 columns, lanes along the rows (4 loads each), shuffle reduction
+__global__ __launch_bounds__(256) void k_sb_bwd_x(DevPlan P, const int* __restrict__ list, int b) {
+  __shared__ double zj[256];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int s = list[blockIdx.y];
+  const int col0 = P.sn_col0[s];
+  const int k = P.sn_col0[s + 1] - col0;
+  const int c0 = b * kSolveSB;
+  if (c0 >= k) return;
+  const int kb = min(kSolveSB, k - c0);
+  const int rq = blockIdx.z;
+  if ((int)blockIdx.x * 64 >= kb) return;
+  double* xp = P.ysb + P.ysb_pos[s] + (size_t)rq * kSolveSB;
+  const int i0 = blockIdx.x * 64 + wv * 16;
+  // column i of X is zero above row i: a row chunk that ends above the first column of this workgroup contributes nothing
+  if (rq * 256 >= kb || rq * 256 + 255 < (int)blockIdx.x * 64) {
+    if (lane < 16 && i0 + lane < kb) xp[i0 + lane] = 0.0;
+    return;
+  }
+  const double* X = P.xsb + P.xsb_pos[s] + (size_t)b * kSolveSB * kSolveSB + rq * 256;
+  const int kq = min(256, kb - rq * 256);
+  double v[16][4];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const double* xc = X + (size_t)min(i0 + q, kb - 1) * kSolveSB;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) v[q][t] = xc[min(lane + 64 * t, kq - 1)];
+  }
+  zj[tid] = tid < kq ? P.xwork[col0 + c0 + rq * 256 + tid] : 0.0;
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    double a = 0.0;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) a += (lane + 64 * t < kq) ? v[q][t] * zj[lane + 64 * t] : 0.0;
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_down(a, o, 64);
+    if (lane == 0 && i0 + q < kb) xp[i0 + q] = a;
+  }
+}
+// backward, block b: x_b = sum of the four partials; columns c < c0:  x[c] -= sum_p L[c0 + p][c] x_b[p];
+// one extra workgroup stores x_b itself
+__global__ __launch_bounds__(256) void k_sb_bwd_upd(DevPlan P, const int* __restrict__ list, int b) {
+  __shared__ double xj[kSolveSB];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int s = list[blockIdx.y];
+  const int col0 = P.sn_col0[s];
+  const int k = P.sn_col0[s + 1] - col0;
+  const int f = (int)(P.row_ptr[s + 1] - P.row_ptr[s]);
+  const int c0 = b * kSolveSB;
+  if (c0 >= k) return;
+  const int kb = min(kSolveSB, k - c0);
+  const double* xp = P.ysb + P.ysb_pos[s];
+  const int nupd = (c0 + 63) / 64;                 // workgroups that update columns; the next one copies x_b
+  if ((int)blockIdx.x > nupd) return;
+  for (int p = tid; p < kSolveSB; p += 256) {
+    const int pc = min(p, kb - 1);
+    const double x = (xp[pc] + xp[kSolveSB + pc]) + (xp[2 * kSolveSB + pc] + xp[3 * kSolveSB + pc]);
+    xj[p] = p < kb ? x : 0.0;
+  }
+  __syncthreads();
+  if ((int)blockIdx.x == nupd) {
+    for (int p = tid; p < kb; p += 256) P.xwork[col0 + c0 + p] = xj[p];
+    return;
+  }
+  const double* Lrow = P.arena + P.front_pos[s] + c0;
+#pragma unroll 1
+  for (int q0 = 0; q0 < 16; q0 += 4) {
+    const int cb = blockIdx.x * 64 + wv * 16 + q0;
+    if (cb >= c0) break;
+    double v[4][kSolveSB / 64];       // four columns = 64 loads per lane in flight
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const double* col = Lrow + (size_t)min(cb + q, c0 - 1) * f;
+#pragma unroll
+      for (int t = 0; t < kSolveSB / 64; ++t) v[q][t] = col[min(lane + 64 * t, kb - 1)];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      double a = 0.0;
+#pragma unroll
+      for (int t = 0; t < kSolveSB / 64; ++t) a += (lane + 64 * t < kb) ? v[q][t] * xj[lane + 64 * t] : 0.0;
+      for (int o = 32; o > 0; o >>= 1) a += __shfl_down(a, o, 64);
+      if (lane == 0 && cb + q < c0) P.xwork[col0 + cb + q] -= a;
+    }
+  }
+}
+
 static void launch_fwd_step(hipStream_t st, const DevPlan& P, const int* list, const dim3& gr, int NB, int step) {
   switch (NB) {
     case 32: hipLaunchKernelGGL(k_bigsolve_fwd_step<32>, gr, dim3(256), 0, st, P, list, step); break;
@@ -1683,6 +1911,55 @@ static void launch_bwd_step(hipStream_t st, const DevPlan& P, const int* list, c
   }
 }
 
+
+// Explicit inverses of the kSolveSB-column diagonal blocks of the fronts that take the super-block solves: a plain
+// library TRSM on the identity (rocblas_dtrsm_strided_batched over the full blocks of a front).  It costs about one
+// millisecond at the S-metric root and saves 1.4 ms per solve (4.3 -> 3.0 ms), so it already pays for itself on the
+// first solve after a factorisation (an IPM iteration solves 5-10 times per factorisation).  It runs on demand, before
+// the first solve (OKKT_SOLVE_SB_LAZY=n: only after n solves with the 128-column steps), never inside the factorisation.
+static std::string numeric_sb_prepare(Numeric& N, int which) {
+  DevPlan P = N.d;
+  hipStream_t st = N.stream;
+  if (!N.blas) {
+    rocblas_handle h2 = nullptr;
+    if (rocblas_create_handle(&h2) != rocblas_status_success) return "rocblas_create_handle failed";
+    N.blas = h2;
+  }
+  rocblas_handle hb = (rocblas_handle)N.blas;
+  if (rocblas_set_stream(hb, st) != rocblas_status_success) return "rocblas_set_stream failed";
+  const double one = 1.0;
+  for (int pass = 0; pass < 2; ++pass) {
+    const std::vector<LevelSchedule>& levels = pass == 0 ? N.levels : N.levels_top;
+    (void)which;
+    for (const LevelSchedule& L : levels) {
+      const Segment& g = L.seg[3];
+      if (!g.cnt || g.mink < 2 * kSolveSB) continue;
+      for (int q = 0; q < g.cnt; ++q) {
+        const int s2 = N.sched_host[g.off + q];
+        const int64_t kk = N.sn_k[s2], ff = N.sn_f[s2];
+        const int nfull = (int)(kk / kSolveSB), klast = (int)(kk - (int64_t)nfull * kSolveSB);
+        const int nblk = nfull + (klast ? 1 : 0);
+        double* X = P.xsb + N.xsb_pos_host[s2];
+        const double* Lf = P.arena + N.front_pos_host[s2];
+        const int64_t tot = (int64_t)nblk * kSolveSB * kSolveSB;
+        hipLaunchKernelGGL(k_sb_identity, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, X, kSolveSB, tot);
+        if (nfull &&
+            rocblas_dtrsm_strided_batched(hb, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_unit,
+                                          kSolveSB, kSolveSB, &one, Lf, (rocblas_int)ff, (rocblas_stride)kSolveSB * (ff + 1), X,
+                                          kSolveSB, (rocblas_stride)kSolveSB * kSolveSB, nfull) != rocblas_status_success)
+          return "rocblas_dtrsm_strided_batched failed";
+        if (klast &&
+            rocblas_dtrsm(hb, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_unit, klast, klast, &one,
+                          Lf + (size_t)nfull * kSolveSB * (ff + 1), (rocblas_int)ff, X + (size_t)nfull * kSolveSB * kSolveSB,
+                          kSolveSB) != rocblas_status_success)
+          return "rocblas_dtrsm failed";
+      }
+    }
+  }
+  N.sb_ready = true;
+  return "";
+}
+
 // forward (L, then D^-1 fused) sweep over one schedule: which = 0 local subtrees, 1 top of the tree
 std::string numeric_solve_fwd_enqueue(Numeric& N, int which) {
   DevPlan P = N.d;
@@ -1690,6 +1967,13 @@ std::string numeric_solve_fwd_enqueue(Numeric& N, int which) {
   const std::vector<LevelSchedule>& levels = which == 0 ? N.levels : N.levels_top;
   const int nl = (int)levels.size();
   const int NB = N.nb;
+  if (which == 0 && N.use_sb && !N.sb_ready && (N.solves_since_factor >= N.sb_lazy)) {
+    std::string e = numeric_sb_prepare(N, which);
+    if (!e.empty()) return e;
+  }
+  if (getenv("OKKT_DEBUG_SB")) fprintf(stderr, "okkt: solve fwd which=%d solves_since_factor=%d sb_ready=%d use_sb=%d\n", which, N.solves_since_factor, (int)N.sb_ready, N.use_sb);
+  if (which == 0) ++N.solves_since_factor;
+  const bool sb = N.use_sb && N.sb_ready;
   for (int l = 0; l < nl; ++l) {
     const LevelSchedule& L = levels[l];
     for (int c = 0; c < 3; ++c) {
@@ -1703,6 +1987,15 @@ std::string numeric_solve_fwd_enqueue(Numeric& N, int which) {
     if (g.cnt) {
       const int* list = P.sched + g.off;
       hipLaunchKernelGGL(k_bigsolve_fwd_asm, dim3((g.maxf + 255) / 256, g.cnt), dim3(256), 0, st, P, list);
+      if (sb && g.mink >= 2 * kSolveSB) {
+        const int nblk = (g.maxk + kSolveSB - 1) / kSolveSB;
+        for (int b = 0; b < nblk; ++b) {
+          hipLaunchKernelGGL(k_sb_fwd_y, dim3(kSolveSB / 64, g.cnt, 4), dim3(256), 0, st, P, list, b);
+          const int rem = std::max(g.maxf - b * kSolveSB, 0);      // upper bound on the rows below block b
+          hipLaunchKernelGGL(k_sb_fwd_upd, dim3(std::max(1, (rem + 63) / 64), g.cnt), dim3(256), 0, st, P, list, b);
+        }
+        continue;
+      }
       const int nsteps = (g.maxk + NB - 1) / NB;
       for (int step = 0; step < nsteps; ++step) {
         const int rem = std::max(g.maxf - step * NB, 0);  // upper bound on the rows below block `step`
@@ -1726,9 +2019,17 @@ std::string numeric_solve_bwd_enqueue(Numeric& N, int which) {
     if (gb.cnt) {
       const int* list = P.sched + gb.off;
       hipLaunchKernelGGL(k_bigsolve_bwd_pre, dim3((gb.maxk + 3) / 4, gb.cnt), dim3(256), 0, st, P, list);
+      if (N.use_sb && N.sb_ready && gb.mink >= 2 * kSolveSB) {
+        const int nblk = (gb.maxk + kSolveSB - 1) / kSolveSB;
+        for (int b = nblk - 1; b >= 0; --b) {
+          hipLaunchKernelGGL(k_sb_bwd_x, dim3(kSolveSB / 64, gb.cnt, 4), dim3(256), 0, st, P, list, b);
+          hipLaunchKernelGGL(k_sb_bwd_upd, dim3((b * kSolveSB + 63) / 64 + 1, gb.cnt), dim3(256), 0, st, P, list, b);
+        }
+      } else {
       const int nsteps = (gb.maxk + NB - 1) / NB;
       for (int step = nsteps - 1; step >= 0; --step)
         launch_bwd_step(st, P, list, dim3(std::max(1, (step * NB + 63) / 64), gb.cnt), NB, step);
+      }
     }
     for (int c = 0; c < 3; ++c) {
       const Segment& g = L.seg[c];

@@ -267,3 +267,27 @@ def test_long_columns_chunked_assembly_with_duplicates():
     x = h.ls_solve(b)
     assert np.max(np.abs(M @ x - b)) <= 1e-9 * np.max(np.abs(b)) * np.sqrt(n)
     finalize_b(h)
+
+
+def test_super_block_solves_follow_the_factorisation():
+    # fronts with >= 2048 pivot columns switch to the super-block solves (explicit 1024-column inverses, prepared lazily):
+    # the first solve after a factorisation takes the 128-column steps, the second prepares the inverses, the later ones
+    # use them -- and a NEW factorisation must invalidate them
+    n = 2300
+    rng = np.random.default_rng(5)
+    h = hip_solver("symmetric")
+    for trial in range(2):
+        B = rng.normal(size=(n, n))
+        M = B + B.T + np.diag(np.where(rng.random(n) < 0.5, 1.0, -1.0) * (3.0 * np.sqrt(n)))
+        w = np.linalg.eigvalsh(M)
+        assert h.ls_factor_b(sp.csc_matrix(np.tril(M)), int((w > 0).sum()), int((w < 0).sum())) == 1
+        xs = []
+        for i in range(4):
+            b = rng.normal(size=n) if i < 3 else bs
+            bs = b
+            x = h.ls_solve(b)
+            assert np.max(np.abs(M @ x - b)) <= 1e-9 * np.max(np.abs(b)) * np.sqrt(n), (trial, i)
+            xs.append(x)
+        # the same right-hand side through the prepared inverses twice: identical bits (deterministic kernels)
+        assert np.array_equal(xs[2], xs[3])
+    finalize_b(h)
