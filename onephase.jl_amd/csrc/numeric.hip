@@ -1917,9 +1917,8 @@ static void launch_bwd_step(hipStream_t st, const DevPlan& P, const int* list, c
 // millisecond at the S-metric root and saves 1.4 ms per solve (4.3 -> 3.0 ms), so it already pays for itself on the
 // first solve after a factorisation (an IPM iteration solves 5-10 times per factorisation).  It runs on demand, before
 // the first solve (OKKT_SOLVE_SB_LAZY=n: only after n solves with the 128-column steps), never inside the factorisation.
-static std::string numeric_sb_prepare(Numeric& N, int which) {
+static std::string numeric_sb_prepare(Numeric& N, hipStream_t st) {
   DevPlan P = N.d;
-  hipStream_t st = N.stream;
   if (!N.blas) {
     rocblas_handle h2 = nullptr;
     if (rocblas_create_handle(&h2) != rocblas_status_success) return "rocblas_create_handle failed";
@@ -1930,7 +1929,6 @@ static std::string numeric_sb_prepare(Numeric& N, int which) {
   const double one = 1.0;
   for (int pass = 0; pass < 2; ++pass) {
     const std::vector<LevelSchedule>& levels = pass == 0 ? N.levels : N.levels_top;
-    (void)which;
     for (const LevelSchedule& L : levels) {
       const Segment& g = L.seg[3];
       if (!g.cnt || g.mink < 2 * kSolveSB) continue;
@@ -1967,9 +1965,20 @@ std::string numeric_solve_fwd_enqueue(Numeric& N, int which) {
   const std::vector<LevelSchedule>& levels = which == 0 ? N.levels : N.levels_top;
   const int nl = (int)levels.size();
   const int NB = N.nb;
+  hipEvent_t ev_sb = nullptr;      // set while the inversion runs on the auxiliary stream, beside the lower levels' sweeps
   if (which == 0 && N.use_sb && !N.sb_ready && (N.solves_since_factor >= N.sb_lazy)) {
-    std::string e = numeric_sb_prepare(N, which);
+    hipStream_t ps = N.stream_aux ? N.stream_aux : st;
+    if (ps != st) {
+      if (N.la_used + 2 > N.la_events.size())
+        for (int q = 0; q < 64; ++q) { hipEvent_t e2; OKKT_HIP_TRY(hipEventCreateWithFlags(&e2, hipEventDisableTiming)); N.la_events.push_back(e2); }
+      hipEvent_t ev0 = N.la_events[N.la_used++];
+      ev_sb = N.la_events[N.la_used++];
+      OKKT_HIP_TRY(hipEventRecord(ev0, st));
+      OKKT_HIP_TRY(hipStreamWaitEvent(ps, ev0, 0));
+    }
+    std::string e = numeric_sb_prepare(N, ps);
     if (!e.empty()) return e;
+    if (ev_sb) OKKT_HIP_TRY(hipEventRecord(ev_sb, ps));
   }
   if (getenv("OKKT_DEBUG_SB")) fprintf(stderr, "okkt: solve fwd which=%d solves_since_factor=%d sb_ready=%d use_sb=%d\n", which, N.solves_since_factor, (int)N.sb_ready, N.use_sb);
   if (which == 0) ++N.solves_since_factor;
@@ -1988,6 +1997,7 @@ std::string numeric_solve_fwd_enqueue(Numeric& N, int which) {
       const int* list = P.sched + g.off;
       hipLaunchKernelGGL(k_bigsolve_fwd_asm, dim3((g.maxf + 255) / 256, g.cnt), dim3(256), 0, st, P, list);
       if (sb && g.mink >= 2 * kSolveSB) {
+        if (ev_sb) { OKKT_HIP_TRY(hipStreamWaitEvent(st, ev_sb, 0)); ev_sb = nullptr; }
         const int nblk = (g.maxk + kSolveSB - 1) / kSolveSB;
         for (int b = 0; b < nblk; ++b) {
           hipLaunchKernelGGL(k_sb_fwd_y, dim3(kSolveSB / 64, g.cnt, 4), dim3(256), 0, st, P, list, b);
@@ -2003,6 +2013,7 @@ std::string numeric_solve_fwd_enqueue(Numeric& N, int which) {
       }
     }
   }
+  if (ev_sb) OKKT_HIP_TRY(hipStreamWaitEvent(st, ev_sb, 0));
   OKKT_HIP_TRY(hipGetLastError());
   return "";
 }
