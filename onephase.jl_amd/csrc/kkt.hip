@@ -49,6 +49,7 @@ struct okkt_kkt_s {
   double *rD = nullptr, *rP = nullptr, *rC = nullptr, *dx = nullptr, *dy = nullptr, *ds = nullptr;
   double *vn1 = nullptr, *vn2 = nullptr, *vn3 = nullptr, *vm1 = nullptr, *vm2 = nullptr, *big1 = nullptr, *big2 = nullptr;
   double* red = nullptr;  // reduction outputs
+  double* Jcur = nullptr; // Jacobian values of a current iterate that differs from the factorised one
   // ---- clever symmetric (clever_symmetric.jl): parallel-row groups and the reduced system
   bool indexed = false;
   int64_t m_new = 0;
@@ -697,11 +698,10 @@ int okkt_kkt_system_rhs(okkt_kkt_handle k, const double* J_nzval_cur, const doub
   const int64_t n = k->n, m = k->m;
   // J of the CURRENT iterate (may differ from the factorised one in correction steps, one_phase.jl:262-279)
   const double* Jx = k->Jx;
-  double* Jcur = nullptr;
   if (J_nzval_cur && k->nnzJ) {
-    KK_TRY(k, hipMalloc((void**)&Jcur, (size_t)k->nnzJ * 8));
-    KK_TRY(k, hipMemcpyAsync(Jcur, J_nzval_cur, (size_t)k->nnzJ * 8, hipMemcpyHostToDevice, st));
-    Jx = Jcur;
+    if (!k->Jcur) { int rc2 = kk_alloc(k, (size_t)k->nnzJ, &k->Jcur); if (rc2 != OKKT_OK) return rc2; }   // kept for the life of the handle
+    KK_TRY(k, hipMemcpyAsync(k->Jcur, J_nzval_cur, (size_t)k->nnzJ * 8, hipMemcpyHostToDevice, st));
+    Jx = k->Jcur;
   }
   if (n) KK_TRY(k, hipMemcpyAsync(k->vn1, grad, (size_t)n * 8, hipMemcpyHostToDevice, st));
   if (m) {
@@ -722,7 +722,6 @@ int okkt_kkt_system_rhs(okkt_kkt_handle k, const double* J_nzval_cur, const doub
     KK_TRY(k, hipMemcpyAsync(comp_r, k->rC, (size_t)m * 8, hipMemcpyDeviceToHost, st));
   }
   KK_TRY(k, hipStreamSynchronize(st));
-  if (Jcur) (void)hipFree(Jcur);
   return OKKT_OK;
 }
 

@@ -261,10 +261,12 @@ class HIP_KKT_solver:
     # ---- kkt_associate_rhs! (kkt_system_solver.jl:167-176, schur.jl:34-45)
     def kkt_associate_rhs_b(self, it, eta, timer=None):
         n, m = it.dim(), it.ncon()
-        Jx = L.f64(_csc(it.J).data)
+        # J of the iterate the system was formed at is already resident: NULL = use it (no 11 MB upload at S-metric);
+        # a different iterate (correction steps, one_phase.jl:262-279) sends its own Jacobian values
+        Jx = None if it is self.factor_it else L.f64(_csc(it.J).data)
         grad, cons, s, y = L.f64(it.grad), L.f64(it.cons), L.f64(it.s), L.f64(it.y)
         rD, rP, rC = np.zeros(n), np.zeros(m), np.zeros(m)
-        self._check(self._lib.okkt_kkt_system_rhs(self._k, L.p_f64(Jx), L.p_f64(grad), L.p_f64(cons), L.p_f64(s), L.p_f64(y),
+        self._check(self._lib.okkt_kkt_system_rhs(self._k, L.p_f64(Jx) if Jx is not None else None, L.p_f64(grad), L.p_f64(cons), L.p_f64(s), L.p_f64(y),
                                                   it.mu, it.a_norm_penalty_par, eta.P, eta.D, eta.mu,
                                                   L.p_f64(rD), L.p_f64(rP), L.p_f64(rC)), "okkt_kkt_system_rhs")
         self.rhs = System_rhs(rD, rP, rC)
