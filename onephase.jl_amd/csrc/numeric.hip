@@ -1482,6 +1482,25 @@ std::string numeric_setup(const Symbolic& S, const SymbolicOptions& opts, hipStr
       if (!(e = upload(N, ysb_pos, &d.ysb_pos)).empty()) return e;
       if (!(e = dalloc(N, (size_t)xtot, &d.xsb, false)).empty()) return e;
       if (!(e = dalloc(N, (size_t)ytot, &d.ysb, true)).empty()) return e;
+      // the library's one-time initialisation (handle + kernel load, ~1.4 s) belongs to the analysis, not to the first
+      // solve that needs the inverses: a warm-up TRSM of the shape used later, on identity blocks of the X buffer
+      if (xtot >= 2 * (int64_t)kSolveSB * kSolveSB) {
+        if (!N.blas) {
+          rocblas_handle h2 = nullptr;
+          if (rocblas_create_handle(&h2) != rocblas_status_success) return "rocblas_create_handle failed";
+          N.blas = h2;
+        }
+        rocblas_handle hb = (rocblas_handle)N.blas;
+        if (rocblas_set_stream(hb, stream) != rocblas_status_success) return "rocblas_set_stream failed";
+        const int64_t tot = 2 * (int64_t)kSolveSB * kSolveSB;
+        hipLaunchKernelGGL(k_sb_identity, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream, d.xsb, kSolveSB, tot);
+        const double one = 1.0;
+        if (rocblas_dtrsm_strided_batched(hb, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_unit, kSolveSB,
+                                          kSolveSB, &one, d.xsb, kSolveSB, 0, d.xsb + (size_t)kSolveSB * kSolveSB, kSolveSB, 0, 1) !=
+            rocblas_status_success)
+          return "rocblas warm-up failed";
+        OKKT_HIP_TRY(hipStreamSynchronize(stream));
+      }
     }
     if (!(e = dalloc(N, (size_t)nbigcols, &d.bigw, true)).empty()) return e;
   }
