@@ -250,6 +250,29 @@ def kkt_level_breakdown(prob, device):
         tm["refinement_solves"] = 3 if kind == "schur" else 1
         out[kind] = tm
         k.finalize_b()
+    # the delta-loop variant: a nonconvex instance of the same generator (H shifted by -5), the whole
+    # ipopt_strategy! (delta_strategy.jl:37-114) + one direction = what one outer IPM iteration costs on the path
+    from onephase_jl_amd import synth
+    cfg = dict(synth.CONFIGS["S-metric"]) if n + m == 100000 else None
+    if cfg is not None:
+        cfg.update(convex=False, neg_shift=5.0)
+        pnc = synth.make_problem(seed=0, **cfg)
+        itn = KS.Class_iterate(x=it.x, y=pnc["y"], s=pnc["s"], mu=float(pnc["mu"]), J=pnc["J"], H=pnc["H"], grad=it.grad,
+                               cons=pnc["s"] + 1e-3 * rng.normal(size=m))
+        pars = KS.Class_parameters()
+        pars.kkt.kkt_solver_type = "symmetric"
+        k = KS.HIP_KKT_solver("symmetric", pars, device=device)
+        k.initialize_b(itn)
+        k.form_system_b(itn)
+        k.ipopt_strategy_b(itn)                                   # warm-up incl. the symbolic analysis
+        k.form_system_b(itn)
+        t = time.perf_counter(); status, nfac, delta = k.ipopt_strategy_b(itn); t_loop = 1e3 * (time.perf_counter() - t)
+        k.kkt_associate_rhs_b(itn, KS.Reduct_affine())
+        t = time.perf_counter(); k.compute_direction_b(); t_dir = 1e3 * (time.perf_counter() - t)
+        out["delta_loop"] = {"workload": "S-metric generator, nonconvex (neg_shift = 5), symmetric KKT", "status": status, "num_fac": int(nfac),
+                             "delta": float(delta), "loop_ms": t_loop, "ms_per_factorisation": t_loop / max(nfac, 1),
+                             "direction_ms": t_dir, "N_err": float(k.kkt_err_norm.ratio)}
+        k.finalize_b()
     return out
 
 
