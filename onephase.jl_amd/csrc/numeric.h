@@ -80,6 +80,7 @@ struct Numeric {
   int nb = 64;
   int group = 2;   // block columns per super-step: the trailing update runs with K = group * nb
   int group_big = 4, group_big_minf = 8192;   // ... and for fronts of at least group_big_minf rows
+  int group_switch_rows = 9000;               // ... until fewer rows than this are left below the super-step
   int small_max = 128;
   int64_t n_small = 0, n_big = 0;
   hipStream_t stream = nullptr;

@@ -1294,6 +1294,7 @@ std::string numeric_setup(const Symbolic& S, const SymbolicOptions& opts, hipStr
   N.group_big = getenv("OKKT_GROUP_BIG") ? std::max(1, std::min(atoi(getenv("OKKT_GROUP_BIG")), 8)) : 4;
   N.group_big_minf = getenv("OKKT_GROUP_BIG_MINF") ? atoi(getenv("OKKT_GROUP_BIG_MINF")) : 8192;
   if (getenv("OKKT_GROUP")) { N.group = N.group_big = std::max(1, std::min(atoi(getenv("OKKT_GROUP")), 4)); }
+  N.group_switch_rows = getenv("OKKT_GROUP_SWITCH_ROWS") ? atoi(getenv("OKKT_GROUP_SWITCH_ROWS")) : 9000;
   N.nnz_in = S.nnz_in;
   if (S.max_front > 46000) return "front order exceeds the 32-bit local offset range";
   const int ns = S.nsuper;
@@ -1587,23 +1588,32 @@ std::string numeric_factor_enqueue(Numeric& N, const double* d_vals, double tol,
       const int nsteps = (g.maxk + NB - 1) / NB;
       const size_t lds_diag = ((size_t)3 * kMW * kPLD + (size_t)2 * 4 * 32 * kXld) * sizeof(double);
       // every front of the segment must own a W buffer for this group size: decided on the smallest front
-      const int GS = g.minf >= N.group_big_minf ? N.group_big : N.group;
-      // W of super-step q lives in wbuf columns [(q & 1) * GS * NB, ...): the look-ahead factors the panels of
-      // super-step q + 1 while the trailing update of super-step q still reads its W
-      auto launch_syrk = [&](hipStream_t sst, int stepA, int npan, int tstep, int head, int sub = 0) -> std::string {
+      const int GS = g.minf >= N.group_big_minf ? N.group_big : N.group;     // widest super-step of this segment (sizes wbuf)
+      // Super-step widths adapt: GS block columns while the trailing update is long enough to hide the panel chain,
+      // N.group (2) once the chain is the critical path -- there the in-group diagonal-tile updates with K up to
+      // (GS - 1) * NB (33-75 us each for a lone tile) cost more than the extra C traffic of K = 256 updates.
+      auto gs_at = [&](int stepA) {
+        const int rows_after = g.maxf - (stepA + GS) * NB;
+        return (GS > N.group && rows_after < N.group_switch_rows) ? N.group : GS;
+      };
+      // W of the super-step with parity `par` lives in wbuf columns [par * GS * NB, ...): the look-ahead factors the
+      // panels of the next super-step while the trailing update of the current one still reads its W
+      // npan panels [stepA, stepA + npan) (their W at parity par) applied to the region from block column tstep; cs = block
+      // columns of the NEXT super-step (look-ahead split of the region)
+      auto launch_syrk = [&](hipStream_t sst, int stepA, int npan, int tstep, int head, int par, int cs, int sub = 0) -> std::string {
         // upper bound on the rows of the target region: a front whose pivot block ends inside the group
         // starts its trailing region at k < tstep * NB
         const int rem = g.maxf - (head == 1 ? tstep : stepA) * NB;
         if (rem <= 0) return "";
         const int T = (rem + 127) / 128;
-        const int Tr = std::max(T - GS, 0);
+        const int Tr = std::max(T - cs, 0);
         int ntile = T * (T + 1) / 2;
         if (head == 1) ntile = sub == 1 ? 1 : (sub == 2 ? T - 1 : T);
-        else if (head == 2) { ntile = 0; for (int c = 0; c < GS && c < T; ++c) ntile += T - c; }
+        else if (head == 2) { ntile = 0; for (int c = 0; c < cs && c < T; ++c) ntile += T - c; }
         else if (head == 3) ntile = Tr * (Tr + 1) / 2;
         if (ntile == 0) return "";
         const dim3 grid((ntile + 7) / 8 * 8, g.cnt);
-        const int wofs = ((stepA / GS) & 1) * GS * NB;
+        const int wofs = par * GS * NB;
         const bool prof = N.profile && (head == 0 || head == 3);   // the dominant kernel: k_big_syrk<0, kSyrkTrail>
         if (prof) {
           // algorithmic flops of this launch: 2 * K * (lower-triangle entries it updates), summed over fronts
@@ -1617,7 +1627,7 @@ std::string numeric_factor_enqueue(Numeric& N, const double* d_vals, double tol,
             const double K = std::min(npan * NB, kk - j0);
             const double t0 = std::min(tstep * NB, kk);
             const double remq = ff - t0;
-            const double w2 = std::min<double>(GS * 128, remq);          // columns of the look-ahead head
+            const double w2 = std::min<double>(cs * 128, remq);          // columns of the look-ahead head
             const double remr = remq - w2;
             if (head == 1) { const double w = std::min<double>(t0 + NB, kk) - t0; fl += 2.0 * K * (w * remq - w * (w - 1.0) / 2.0); }
             else if (head == 2) fl += 2.0 * K * (w2 * remq - w2 * (w2 - 1.0) / 2.0);
@@ -1630,7 +1640,7 @@ std::string numeric_factor_enqueue(Numeric& N, const double* d_vals, double tol,
           OKKT_HIP_TRY(hipEventRecord(N.prof_events[N.prof_used++], sst));
         }
 #define OKKT_SYRK(D, H) hipLaunchKernelGGL((k_big_syrk<D, H>), grid, dim3(kSyrkNW * 64), syrk_lds_bytes(kSyrkStages), sst, P, list, stepA, npan, tstep, NB, wofs, csplit)
-        const int csplit = head == 1 ? sub : (head == 0 ? 0 : GS);
+        const int csplit = head == 1 ? sub : (head == 0 ? 0 : cs);
         if (head == 1) OKKT_SYRK(0, kSyrkPanel);
         else if (head == 2) OKKT_SYRK(0, kSyrkAhead);
         else switch (dbg_syrk) {   // timing-only ablations of the trailing update (OKKT_DEBUG_SYRK): wrong outputs
@@ -1653,9 +1663,8 @@ std::string numeric_factor_enqueue(Numeric& N, const double* d_vals, double tol,
       auto rem_rows = [&](int step) { return g.maxf - step * NB; };
       // the panels of super-step q (block columns [q * GS, (q + 1) * GS)): diag -> trsm, with the in-group
       // "head" update that brings each later panel of the group up to date first
-      auto launch_panels = [&](hipStream_t pst, int stepA) -> std::string {
-        const int par = (stepA / GS) & 1;
-        for (int i = 0; i < GS && stepA + i < nsteps; ++i) {
+      auto launch_panels = [&](hipStream_t pst, int stepA, int gs, int par) -> std::string {
+        for (int i = 0; i < gs && stepA + i < nsteps; ++i) {
           const int step = stepA + i;
           // in-group update of panel i: only its diagonal tile is on the critical path (k_big_diag needs it); the
           // other tiles run on the auxiliary stream beside k_big_diag and are joined before k_big_trsm
@@ -1668,11 +1677,11 @@ std::string numeric_factor_enqueue(Numeric& N, const double* d_vals, double tol,
               if (!e.empty() || !(e = next_event(&ev_rest)).empty()) return e;
               OKKT_HIP_TRY(hipEventRecord(ev_t, pst));                         // trsm of panel i - 1 is behind this
               OKKT_HIP_TRY(hipStreamWaitEvent(N.stream_aux, ev_t, 0));
-              if (!(e = launch_syrk(N.stream_aux, stepA, i, step, 1, 2)).empty()) return e;
+              if (!(e = launch_syrk(N.stream_aux, stepA, i, step, 1, par, 0, 2)).empty()) return e;
               OKKT_HIP_TRY(hipEventRecord(ev_rest, N.stream_aux));
-              if (!(e = launch_syrk(pst, stepA, i, step, 1, 1)).empty()) return e;
+              if (!(e = launch_syrk(pst, stepA, i, step, 1, par, 0, 1)).empty()) return e;
             } else {
-              std::string e = launch_syrk(pst, stepA, i, step, 1);
+              std::string e = launch_syrk(pst, stepA, i, step, 1, par, 0);
               if (!e.empty()) return e;
             }
           }
@@ -1700,30 +1709,34 @@ std::string numeric_factor_enqueue(Numeric& N, const double* d_vals, double tol,
       // main stream's CU mask leaves free: k_big_diag is a lone, latency-bound workgroup) runs
       // head2(q) -> Panel(q + 1)  while the main stream runs rest(q) back to back with rest(q - 1).
       // Used only while the rest is large enough; afterwards everything runs in order on the main stream.
-      std::string e = launch_panels(st, 0);
+      int gs_cur = gs_at(0), par = 0;
+      std::string e = launch_panels(st, 0, gs_cur, par);
       if (!e.empty()) return e;
       hipEvent_t ev_panel = nullptr;   // set while the panels of the current super-step are on the panel stream
-      for (int stepA = 0; stepA < nsteps; stepA += GS) {
-        const int remr = g.maxf - (stepA + 2 * GS) * NB;           // rows of the rest triangle (upper bound)
+      for (int stepA = 0; stepA < nsteps;) {
+        const int stepB = stepA + gs_cur;                          // first block column of the next super-step
+        const bool more = stepB < nsteps;
+        const int gs_next = more ? gs_at(stepB) : gs_cur;
+        const int remr = g.maxf - (stepB + gs_next) * NB;          // rows of the rest triangle (upper bound)
         const int Trr = remr > 0 ? (remr + 127) / 128 : 0;
-        const bool more = stepA + GS < nsteps;
         const bool la = more && N.stream_panel != nullptr && N.lookahead && (int64_t)Trr * (Trr + 1) / 2 * g.cnt >= N.la_min_tiles;
         if (la) {
           hipEvent_t eva, evp;
           if (!(e = next_event(&eva)).empty() || !(e = next_event(&evp)).empty()) return e;
           OKKT_HIP_TRY(hipEventRecord(eva, st));                     // rest(q - 1) (and Panel(0)) are behind this
           OKKT_HIP_TRY(hipStreamWaitEvent(N.stream_panel, eva, 0));
-          if (!(e = launch_syrk(N.stream_panel, stepA, GS, stepA + GS, 2)).empty()) return e;
-          if (!(e = launch_panels(N.stream_panel, stepA + GS)).empty()) return e;
+          if (!(e = launch_syrk(N.stream_panel, stepA, gs_cur, stepB, 2, par, gs_next)).empty()) return e;
+          if (!(e = launch_panels(N.stream_panel, stepB, gs_next, par ^ 1)).empty()) return e;
           OKKT_HIP_TRY(hipEventRecord(evp, N.stream_panel));
           if (ev_panel) OKKT_HIP_TRY(hipStreamWaitEvent(st, ev_panel, 0));
-          if (!(e = launch_syrk(st, stepA, GS, stepA + GS, 3)).empty()) return e;
+          if (!(e = launch_syrk(st, stepA, gs_cur, stepB, 3, par, gs_next)).empty()) return e;
           ev_panel = evp;
         } else {
           if (ev_panel) { OKKT_HIP_TRY(hipStreamWaitEvent(st, ev_panel, 0)); ev_panel = nullptr; }
-          if (!(e = launch_syrk(st, stepA, GS, stepA + GS, 0)).empty()) return e;
-          if (more && !(e = launch_panels(st, stepA + GS)).empty()) return e;
+          if (!(e = launch_syrk(st, stepA, gs_cur, stepB, 0, par, 0)).empty()) return e;
+          if (more && !(e = launch_panels(st, stepB, gs_next, par ^ 1)).empty()) return e;
         }
+        stepA = stepB; gs_cur = gs_next; par ^= 1;
       }
       // full inverses of the diagonal blocks (for the solves), all blocks of the level in one launch
       {
