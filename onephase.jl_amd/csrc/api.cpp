@@ -33,6 +33,7 @@ int solver_ensure_numeric(okkt_solver_s* h) {
   if (h->numeric_ready) return OKKT_OK;
   h->N.part_id = h->part_id;
   std::string e = numeric_setup(h->S, h->sopts, h->stream, h->N);
+  h->N.stream_masked = h->stream_masked;
   h->N.stream_panel = h->stream_panel;
   h->N.stream_aux = h->stream_aux;
   if (const char* sh = getenv("OKKT_SPLIT_HEAD")) h->N.split_head = atoi(sh);
@@ -152,9 +153,10 @@ int okkt_create(okkt_handle* out, const okkt_opts* opts) {
     if (dev < 0) { if (hipGetDevice(&dev) != hipSuccess) dev = 0; }
     if (dev >= count || hipSetDevice(dev) != hipSuccess) { delete h; return OKKT_ERR_NO_DEVICE; }
     h->device = dev;
-    // Look-ahead needs a CU that the trailing update never occupies (k_big_diag wants a whole CU's LDS): the main
-    // stream gets a CU mask without the first `reserved` CUs (mask bit b = CU b / 8 of XCD b % 8 on gfx950, probed
-    // with scripts/cumask_probe.hip), the panel stream is unmasked and high priority.
+    // Look-ahead needs a CU that the trailing update never occupies (k_big_diag wants a whole CU's LDS): levels that
+    // use it run on a twin of the handle's stream whose CU mask leaves out the first `reserved` CUs (mask bit b =
+    // CU b / 8 of XCD b % 8 on gfx950, probed with scripts/cumask_probe.hip); the panel streams are unmasked and high
+    // priority.  Everything else (small fronts, levels without look-ahead, the solves) keeps all CUs.
     const char* ela = getenv("OKKT_LOOKAHEAD");
     const char* ercu = getenv("OKKT_RESERVED_CUS");
     const int la = ela ? atoi(ela) : 1;
@@ -168,18 +170,18 @@ int okkt_create(okkt_handle* out, const okkt_opts* opts) {
       std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
       for (int b = reserved; b < ncu; ++b) mask[(size_t)b >> 5] |= 1u << (b & 31);
       int lo = 0, hi = 0;
-      if (hipExtStreamCreateWithCUMask(&h->stream, (uint32_t)mask.size(), mask.data()) != hipSuccess ||
+      if (hipExtStreamCreateWithCUMask(&h->stream_masked, (uint32_t)mask.size(), mask.data()) != hipSuccess ||
           hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess ||
           hipStreamCreateWithPriority(&h->stream_panel, hipStreamNonBlocking, hi) != hipSuccess ||
           hipStreamCreateWithPriority(&h->stream_aux, hipStreamNonBlocking, hi) != hipSuccess) {
         (void)hipGetLastError();
-        if (h->stream) { (void)hipStreamDestroy(h->stream); h->stream = nullptr; }
+        if (h->stream_masked) { (void)hipStreamDestroy(h->stream_masked); h->stream_masked = nullptr; }
         if (h->stream_panel) { (void)hipStreamDestroy(h->stream_panel); }
         h->stream_panel = nullptr;
         h->stream_aux = nullptr;
       }
     }
-    if (!h->stream && hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return OKKT_ERR_HIP; }
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return OKKT_ERR_HIP; }
     if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) { delete h; return OKKT_ERR_HIP; }
     h->device_ready = true;
   }
@@ -198,6 +200,7 @@ int okkt_destroy(okkt_handle h) {
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->stream_aux) (void)hipStreamDestroy(h->stream_aux);
     if (h->stream_panel) (void)hipStreamDestroy(h->stream_panel);
+    if (h->stream_masked) (void)hipStreamDestroy(h->stream_masked);
     if (h->stream) (void)hipStreamDestroy(h->stream);
   }
   delete h;

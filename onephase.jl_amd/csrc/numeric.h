@@ -81,10 +81,12 @@ struct Numeric {
   int group = 2;   // block columns per super-step: the trailing update runs with K = group * nb
   int group_big = 4, group_big_minf = 8192;   // ... and for fronts of at least group_big_minf rows
   int group_switch_rows = 9000;               // ... until fewer rows than this are left below the super-step
+  int group_one_rows = 4000;                  // single block columns once fewer rows than this are left
   int small_max = 128;
   int64_t n_small = 0, n_big = 0;
   hipStream_t stream = nullptr;
   // look-ahead: panels of the next super-step are factored on stream_panel while the trailing update runs
+  hipStream_t stream_masked = nullptr;  // CU-masked twin of `stream`: levels that use the look-ahead fork onto it and join back
   hipStream_t stream_panel = nullptr;
   hipStream_t stream_aux = nullptr;     // off-critical-path part of the in-group panel updates
   int split_head = 1;
@@ -95,7 +97,7 @@ struct Numeric {
   int sb_lazy = 0;                       // solves with the 128-column steps before the inverses are prepared
   void* blas = nullptr;                  // rocblas_handle (TRSM for the super-block inverses)
   std::vector<int64_t> xsb_pos_host, front_pos_host;
-  int la_min_tiles = 256;                // rest triangle must hold at least this many 128 x 128 tiles
+  int la_min_tiles = 600;                // rest triangle must hold at least this many 128 x 128 tiles
   std::vector<hipEvent_t> la_events;
   size_t la_used = 0;
   double* vals_owned = nullptr;  // staging buffer for host-side nzval

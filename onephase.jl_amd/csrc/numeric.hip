@@ -1295,6 +1295,7 @@ std::string numeric_setup(const Symbolic& S, const SymbolicOptions& opts, hipStr
   N.group_big_minf = getenv("OKKT_GROUP_BIG_MINF") ? atoi(getenv("OKKT_GROUP_BIG_MINF")) : 8192;
   if (getenv("OKKT_GROUP")) { N.group = N.group_big = std::max(1, std::min(atoi(getenv("OKKT_GROUP")), 4)); }
   N.group_switch_rows = getenv("OKKT_GROUP_SWITCH_ROWS") ? atoi(getenv("OKKT_GROUP_SWITCH_ROWS")) : 9000;
+  N.group_one_rows = getenv("OKKT_GROUP_ONE_ROWS") ? atoi(getenv("OKKT_GROUP_ONE_ROWS")) : 4000;
   N.nnz_in = S.nnz_in;
   if (S.max_front > 46000) return "front order exceeds the 32-bit local offset range";
   const int ns = S.nsuper;
@@ -1557,6 +1558,7 @@ std::string numeric_factor_enqueue(Numeric& N, const double* d_vals, double tol,
   N.solves_since_factor = 0;
   const int NB = N.nb;
   static const int dbg_syrk = getenv("OKKT_DEBUG_SYRK") ? atoi(getenv("OKKT_DEBUG_SYRK")) : 0;
+  static const int split_min_rows = getenv("OKKT_SPLIT_MIN_ROWS") ? atoi(getenv("OKKT_SPLIT_MIN_ROWS")) : 5000;
   static const int dbg_stop = getenv("OKKT_DEBUG_DIAG_STOP") ? atoi(getenv("OKKT_DEBUG_DIAG_STOP")) : 0;
   for (size_t l = 0; l < levels.size(); ++l) {
     const LevelSchedule& L = levels[l];
@@ -1572,6 +1574,44 @@ std::string numeric_factor_enqueue(Numeric& N, const double* d_vals, double tol,
     if (L.seg[3].cnt) {
       const Segment& g = L.seg[3];
       const int* list = P.sched + g.off;
+      const int nsteps = (g.maxk + NB - 1) / NB;
+      const size_t lds_diag = ((size_t)3 * kMW * kPLD + (size_t)2 * 4 * 32 * kXld) * sizeof(double);
+      // every front of the segment must own a W buffer for this group size: decided on the smallest front
+      const int GS = g.minf >= N.group_big_minf ? N.group_big : N.group;     // widest super-step of this segment (sizes wbuf)
+      // Super-step widths adapt: GS block columns while the trailing update is long enough to hide the panel chain,
+      // N.group (2) once the chain is the critical path -- there the in-group diagonal-tile updates with K up to
+      // (GS - 1) * NB (33-75 us each for a lone tile) cost more than the extra C traffic of K = 256 updates.
+      auto gs_at = [&](int stepA) {
+        const int rows_after = g.maxf - (stepA + GS) * NB;
+        if (rows_after < N.group_one_rows) return 1;
+        return (GS > N.group && rows_after < N.group_switch_rows) ? N.group : GS;
+      };
+      auto next_event = [&](hipEvent_t* ev) -> std::string {
+        if (N.la_used >= N.la_events.size())
+          for (int q = 0; q < 64; ++q) { hipEvent_t e2; OKKT_HIP_TRY(hipEventCreateWithFlags(&e2, hipEventDisableTiming)); N.la_events.push_back(e2); }
+        *ev = N.la_events[N.la_used++];
+        return "";
+      };
+      // look-ahead for the trailing update of the super-step that starts at block column stepA (gs_cur wide)?
+      auto la_at = [&](int stepA, int gs_cur) {
+        const int stepB = stepA + gs_cur;
+        if (stepB >= nsteps || !N.lookahead || N.stream_panel == nullptr || N.stream_masked == nullptr) return false;
+        const int remr = g.maxf - (stepB + gs_at(stepB)) * NB;     // rows of the rest triangle (upper bound)
+        const int Trr = remr > 0 ? (remr + 127) / 128 : 0;
+        return (int64_t)Trr * (Trr + 1) / 2 * g.cnt >= N.la_min_tiles;
+      };
+      // A level that uses the look-ahead runs on the CU-masked twin of the handle's stream (the reserved CUs belong
+      // to the panel streams); every other level keeps all CUs
+      const bool seg_la = la_at(0, gs_at(0));
+      hipStream_t st = N.stream;
+      if (seg_la) {
+        hipEvent_t evf;
+        std::string e = next_event(&evf);
+        if (!e.empty()) return e;
+        OKKT_HIP_TRY(hipEventRecord(evf, N.stream));
+        OKKT_HIP_TRY(hipStreamWaitEvent(N.stream_masked, evf, 0));
+        st = N.stream_masked;
+      }
       {
         // LDS-resident columns up to 2048 rows (16 KiB per wave); smaller fronts take less LDS for more waves per CU
         static const int lcol_max = getenv("OKKT_ASM_LCOL") ? atoi(getenv("OKKT_ASM_LCOL")) : 2048;
@@ -1585,17 +1625,6 @@ std::string numeric_factor_enqueue(Numeric& N, const double* d_vals, double tol,
         else if (g.maxf <= 2048) hipLaunchKernelGGL(k_big_assemble<true>, dim3((g.maxf + 3) / 4, g.cnt), dim3(256), (size_t)4 * lcol * sizeof(double), st, P, list, lcol);
         else hipLaunchKernelGGL(k_big_assemble<false>, dim3((g.maxf + 3) / 4, g.cnt), dim3(256), (size_t)4 * lcol * sizeof(double), st, P, list, lcol);
       }
-      const int nsteps = (g.maxk + NB - 1) / NB;
-      const size_t lds_diag = ((size_t)3 * kMW * kPLD + (size_t)2 * 4 * 32 * kXld) * sizeof(double);
-      // every front of the segment must own a W buffer for this group size: decided on the smallest front
-      const int GS = g.minf >= N.group_big_minf ? N.group_big : N.group;     // widest super-step of this segment (sizes wbuf)
-      // Super-step widths adapt: GS block columns while the trailing update is long enough to hide the panel chain,
-      // N.group (2) once the chain is the critical path -- there the in-group diagonal-tile updates with K up to
-      // (GS - 1) * NB (33-75 us each for a lone tile) cost more than the extra C traffic of K = 256 updates.
-      auto gs_at = [&](int stepA) {
-        const int rows_after = g.maxf - (stepA + GS) * NB;
-        return (GS > N.group && rows_after < N.group_switch_rows) ? N.group : GS;
-      };
       // W of the super-step with parity `par` lives in wbuf columns [par * GS * NB, ...): the look-ahead factors the
       // panels of the next super-step while the trailing update of the current one still reads its W
       // npan panels [stepA, stepA + npan) (their W at parity par) applied to the region from block column tstep; cs = block
@@ -1654,12 +1683,6 @@ std::string numeric_factor_enqueue(Numeric& N, const double* d_vals, double tol,
         if (prof) OKKT_HIP_TRY(hipEventRecord(N.prof_events[N.prof_used++], sst));
         return "";
       };
-      auto next_event = [&](hipEvent_t* ev) -> std::string {
-        if (N.la_used >= N.la_events.size())
-          for (int q = 0; q < 64; ++q) { hipEvent_t e2; OKKT_HIP_TRY(hipEventCreateWithFlags(&e2, hipEventDisableTiming)); N.la_events.push_back(e2); }
-        *ev = N.la_events[N.la_used++];
-        return "";
-      };
       auto rem_rows = [&](int step) { return g.maxf - step * NB; };
       // the panels of super-step q (block columns [q * GS, (q + 1) * GS)): diag -> trsm, with the in-group
       // "head" update that brings each later panel of the group up to date first
@@ -1670,7 +1693,7 @@ std::string numeric_factor_enqueue(Numeric& N, const double* d_vals, double tol,
           // other tiles run on the auxiliary stream beside k_big_diag and are joined before k_big_trsm
           hipEvent_t ev_rest = nullptr;
           if (i > 0) {
-            const bool split = N.stream_aux != nullptr && N.split_head && rem_rows(step) > 3000;   // the two extra stream hops cost more than they hide on small fronts
+            const bool split = N.stream_aux != nullptr && N.split_head && rem_rows(step) > split_min_rows;   // the two extra stream hops cost more than they hide on small fronts
             if (split) {
               hipEvent_t ev_t;
               std::string e = next_event(&ev_t);
@@ -1717,9 +1740,7 @@ std::string numeric_factor_enqueue(Numeric& N, const double* d_vals, double tol,
         const int stepB = stepA + gs_cur;                          // first block column of the next super-step
         const bool more = stepB < nsteps;
         const int gs_next = more ? gs_at(stepB) : gs_cur;
-        const int remr = g.maxf - (stepB + gs_next) * NB;          // rows of the rest triangle (upper bound)
-        const int Trr = remr > 0 ? (remr + 127) / 128 : 0;
-        const bool la = more && N.stream_panel != nullptr && N.lookahead && (int64_t)Trr * (Trr + 1) / 2 * g.cnt >= N.la_min_tiles;
+        const bool la = seg_la && la_at(stepA, gs_cur);
         if (la) {
           hipEvent_t eva, evp;
           if (!(e = next_event(&eva)).empty() || !(e = next_event(&evp)).empty()) return e;
@@ -1742,6 +1763,12 @@ std::string numeric_factor_enqueue(Numeric& N, const double* d_vals, double tol,
       {
         const size_t lds_inv = ((size_t)(NB + 2) * NB + 3 * kTld * kIB) * sizeof(double);
         hipLaunchKernelGGL(k_big_invert, dim3(nsteps, g.cnt), dim3(256), lds_inv, st, P, list, NB);
+      }
+      if (seg_la) {   // join the handle's stream
+        hipEvent_t evj;
+        if (!(e = next_event(&evj)).empty()) return e;
+        OKKT_HIP_TRY(hipEventRecord(evj, st));
+        OKKT_HIP_TRY(hipStreamWaitEvent(N.stream, evj, 0));
       }
     }
   }

@@ -20,6 +20,7 @@ struct okkt_solver_s {
   bool numeric_ready = false; // device plan uploaded for the current pattern
   int device = 0;
   hipStream_t stream = nullptr;        // main stream (CU-masked when look-ahead is on)
+  hipStream_t stream_masked = nullptr; // look-ahead main stream: CU mask without the reserved CUs (segments that use the look-ahead run here)
   hipStream_t stream_panel = nullptr;  // look-ahead panel stream (high priority, all CUs)
   hipStream_t stream_aux = nullptr;    // second panel stream: the part of the in-group updates that k_big_diag does not wait for
   hipEvent_t ev0 = nullptr, ev1 = nullptr;

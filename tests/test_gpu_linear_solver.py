@@ -237,6 +237,36 @@ def test_sc3_size_properties():
     finalize_b(h)
 
 
+def test_smetric_size_properties_and_reproducibility():
+    # BASELINE's metric configuration (n = 4e4, m = 6e4; 16641-column root front): the look-ahead streams, the
+    # adaptive super-step width and the super-block solves all engage only at this size.  Properties checked:
+    # inertia (n, m, 0), residual, linearity, and -- because every tile is updated in a fixed order whatever the
+    # streams' relative timing -- bit-identical D and solutions from a second factorisation of the same values.
+    prob = synth.make_config("S-metric", seed=0)
+    n, m = prob["n"], prob["m"]
+    K = synth.augmented_matrix(prob, delta=1e-8)
+    h = hip_solver("symmetric")
+    assert h.ls_factor_b(K, n, m) == 1
+    assert h.inertia == (n, m, 0, 0)
+    M = full_sym(K)
+    rng = np.random.default_rng(2)
+    b1, b2 = rng.normal(size=n + m), rng.normal(size=n + m)
+    d_first = h.diag().copy()
+    # solve 1 takes the 128-column steps, solve 2 prepares the super-block inverses, 3+ use them
+    x1, x2, x12, x1_again = h.ls_solve(b1), h.ls_solve(b2), h.ls_solve(b1 + 2.0 * b2), h.ls_solve(b1)
+    for b, x in ((b1, x1), (b2, x2), (b1, x1_again)):
+        r = M @ x - b
+        assert np.max(np.abs(r)) <= 1e-7 * np.max(np.abs(b)) * max(1.0, np.max(np.abs(x)))
+    assert np.max(np.abs(x12 - (x1 + 2.0 * x2))) <= 1e-7 * np.max(np.abs(x12))
+    assert np.max(np.abs(x1_again - x1)) <= 1e-7 * np.max(np.abs(x1))
+    assert h.ls_factor_b(K, n, m) == 1
+    assert np.array_equal(h.diag(), d_first)
+    assert np.array_equal(h.ls_solve(b1), x1)
+    st = h.stats()
+    print("S-metric stats:", {k: st[k] for k in ("nnzL", "flops_exact", "max_front", "last_factor_ms", "last_solve_ms")})
+    finalize_b(h)
+
+
 def test_long_columns_chunked_assembly_with_duplicates():
     # one dense front of 2300 rows: its columns are assembled in 1024-row LDS chunks (k_big_assemble_chunked), three
     # panel super-steps with look-ahead; a raw CSC with duplicated entries exercises the serial has_dup scatter
