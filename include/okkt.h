@@ -239,6 +239,39 @@ int okkt_kkt_get_indicies(okkt_kkt_handle k, int64_t* first_para_indicies, int64
  * x_norm_inf = norm(iter.point.x, Inf) (create_diag_rescale_*, clever_symmetric.jl:307-319); default NONE */
 int okkt_kkt_set_rescale(okkt_kkt_handle k, int mode, double mu, double x_norm_inf);
 
+/* ---- step-side vector kernels ---------------------------------------------------
+ * The reductions and SpMVs simple_ls runs either side of a step (line_search.jl:36-199), on the state the
+ * handle already holds: "iter" = the point (s, y) and J, H of the last okkt_kkt_form_system, "dir" = the
+ * direction left on the device by the last okkt_kkt_compute_direction (an error if there is none).  Vector
+ * arguments are host pointers of the stated length; min / max reductions propagate NaN as Julia's do and are
+ * bit-exact, sums are taken in a fixed order (reproducible, not Julia's order). */
+/* replace the resident direction (scale_direction of line_search.jl:10-19, corrections, tests): dx [n], dy, ds [m] */
+int okkt_kkt_set_direction(okkt_kkt_handle k, const double* dx, const double* dy, const double* ds);
+/* simple_max_step(iter.point.s, dir.s, lb_s_predict(iter, dir, pars)) (frac_boundary.jl:3-15,31-35;
+ * line_search.jl:40-41); ex = pars.ls.fraction_to_boundary_predict_exp; also returns norm(dir.x, Inf) */
+int okkt_kkt_max_step_primal(okkt_kkt_handle k, const double* frac_bd_predict /* [m] */, double ex,
+                             double* step_size_P, double* dx_norm_inf);
+/* all(s_new .>= lb_s(iter, dir, pars)) of move_primal (move.jl:15-17; frac_boundary.jl:22-28): 1 / 0 */
+int okkt_kkt_s_bound_ok(okkt_kkt_handle k, const double* s_new /* [m] */, const double* frac_bd /* [m] */, double ex,
+                        int32_t* ok);
+/* lb, ub = dual_bounds(candidate, candidate.point.y, dir.y, comp_feas); ub = min(ub, simple_max_step(
+ * candidate.point.y, dir.y, lb_y(iter, dir, pars))) (move.jl:28-80; frac_boundary.jl:17-20;
+ * line_search.jl:84-86), with the sequential semantics of the reference's loop */
+int okkt_kkt_dual_step_range(okkt_kkt_handle k, const double* s_cand /* [m] */, const double* y_cand /* [m] */,
+                             double mu_cand, double comp_feas, const double* frac_bd /* [m] */, double* lb, double* ub);
+/* out = { phi_predicted_reduction_primal_dual, norm(comp(iter), Inf), norm(comp_predicted(iter, dir, step), Inf),
+ * merit_function_predicted_reduction } (eval.jl:11-13,117-120,236-273); grad = get_grad(iter) [n], mu =
+ * iter.point.mu, dmu = dir.mu, a_norm_penalty = iter.a_norm_penalty_par */
+int okkt_kkt_predicted_reduction(okkt_kkt_handle k, const double* grad, double mu, double dmu, double a_norm_penalty,
+                                 double step_size, double out[4]);
+/* step_size_D of move_dual (move.jl:82-118) for move_primal_seperate_to_dual: dual_ls 1 / 3 = the least-squares
+ * step on [scale_D * dual residual; -scale_mu * comp] clamped to [max(lb, min(ub, step_size_P)), ub], any other
+ * dual_ls = ub.  The candidate: J_nzval_cand (pattern of okkt_kkt_set_structure; NULL = the J of form_system),
+ * grad_cand [n], s_cand, y_cand [m] (y not yet moved), mu_cand */
+int okkt_kkt_dual_step(okkt_kkt_handle k, const double* J_nzval_cand, const double* grad_cand, const double* s_cand,
+                       const double* y_cand, double mu_cand, double a_norm_penalty, double step_size_P, double lb,
+                       double ub, int dual_ls, double scale_D, double scale_mu, double* step_size_D);
+
 #ifdef __cplusplus
 }
 #endif

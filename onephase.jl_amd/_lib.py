@@ -162,6 +162,13 @@ SIGNATURES = {
     "okkt_kkt_compute_indicies": (C.c_int, [_vp, _f64p, C.POINTER(C.c_int64)]),
     "okkt_kkt_get_indicies": (C.c_int, [_vp, _i64p, _i64p, _i64p, _f64p, _f64p, _f64p, _f64p]),
     "okkt_kkt_set_rescale": (C.c_int, [_vp, C.c_int, C.c_double, C.c_double]),
+    "okkt_kkt_set_direction": (C.c_int, [_vp, _f64p, _f64p, _f64p]),
+    "okkt_kkt_max_step_primal": (C.c_int, [_vp, _f64p, C.c_double, _f64p, _f64p]),
+    "okkt_kkt_s_bound_ok": (C.c_int, [_vp, _f64p, _f64p, C.c_double, C.POINTER(C.c_int32)]),
+    "okkt_kkt_dual_step_range": (C.c_int, [_vp, _f64p, _f64p, C.c_double, C.c_double, _f64p, _f64p, _f64p]),
+    "okkt_kkt_predicted_reduction": (C.c_int, [_vp, _f64p, C.c_double, C.c_double, C.c_double, C.c_double, _f64p]),
+    "okkt_kkt_dual_step": (C.c_int, [_vp, _f64p, _f64p, _f64p, _f64p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
+                                     C.c_int, C.c_double, C.c_double, _f64p]),
 }
 
 _lib = None

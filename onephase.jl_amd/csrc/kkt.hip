@@ -22,58 +22,11 @@
 #include <string>
 #include <vector>
 
-#include "solver.h"
+#include "kkt_state.h"
 
 using namespace okkt;
 
-struct okkt_kkt_s {
-  okkt_handle ls = nullptr;
-  int kind = OKKT_KKT_SCHUR;
-  int64_t n = 0, m = 0, nnzH = 0, nnzJ = 0, nnzA = 0, dimA = 0;
-  bool structured = false, formed = false, factored = false;
-  double delta = 0.0;
-  std::string err;
-  std::vector<void*> allocs;
-  // assembled matrix pattern (host copy, 0-based CSC lower)
-  std::vector<int64_t> Ap, Ai;
-  // device: H (CSC lower + CSR view), J (CSC + CSR view), point
-  int64_t *Hp = nullptr, *Hrp = nullptr, *Hrmap = nullptr, *Jp = nullptr, *Jrp = nullptr, *Jrmap = nullptr;
-  int *Hi = nullptr, *Hrj = nullptr, *Ji = nullptr, *Jrj = nullptr;
-  double *Hx = nullptr, *Jx = nullptr, *s = nullptr, *y = nullptr, *sig = nullptr;
-  double* Avals = nullptr;
-  int64_t *mapH = nullptr, *mapJ = nullptr, *diagA = nullptr;   // symmetric: value slots in A
-  int64_t *qptr = nullptr, *qh = nullptr;                        // schur: contributions per Q entry
-  int *qa = nullptr, *qb = nullptr, *qi = nullptr;
-  double* schur_diag = nullptr;
-  // work vectors
-  double *rD = nullptr, *rP = nullptr, *rC = nullptr, *dx = nullptr, *dy = nullptr, *ds = nullptr;
-  double *vn1 = nullptr, *vn2 = nullptr, *vn3 = nullptr, *vm1 = nullptr, *vm2 = nullptr, *big1 = nullptr, *big2 = nullptr;
-  double* red = nullptr;  // reduction outputs
-  double* Jcur = nullptr; // Jacobian values of a current iterate that differs from the factorised one
-  // ---- clever symmetric (clever_symmetric.jl): parallel-row groups and the reduced system
-  bool indexed = false;
-  int64_t m_new = 0;
-  int rescale_mode = OKKT_RESCALE_NONE;
-  double rescale_mu = 0.0, rescale_xinf = 0.0;
-  std::vector<int64_t> h_Jrp, h_Jrmap;           // host CSR view of J (kept for compute_indicies)
-  std::vector<int> h_Jrj;
-  std::vector<int64_t> h_Hp, h_Jp;               // host copies of the column pointers / row indices
-  std::vector<int> h_Hi, h_Ji;
-  std::vector<int64_t> h_first, h_gptr, h_mind;  // groups: first row, member ranges, member rows (ls order)
-  std::vector<double> h_mratio;
-  int64_t *gptr = nullptr, *mapJc = nullptr, *Arp = nullptr, *Armap = nullptr, *dAp = nullptr;
-  int *mind = nullptr, *row_grp = nullptr, *dAi = nullptr, *Arj = nullptr, *Hcol = nullptr, *Jcol = nullptr;
-  double *mratio = nullptr, *row_ratio = nullptr, *gU = nullptr, *rowg = nullptr, *Dres = nullptr, *true_x_diag = nullptr;
-  double *crhs = nullptr, *big3 = nullptr, *big4 = nullptr;
-};
-
 namespace {
-
-#define KK_TRY(k, expr)                                                                      \
-  do {                                                                                       \
-    hipError_t e__ = (expr);                                                                 \
-    if (e__ != hipSuccess) { (k)->err = std::string(#expr) + ": " + hipGetErrorString(e__); return OKKT_ERR_HIP; } \
-  } while (0)
 
 template <typename T>
 int kk_upload(okkt_kkt_s* k, const std::vector<T>& v, T** out) {
@@ -365,7 +318,6 @@ int kk_check_ls(okkt_kkt_s* k, int rc, const char* what) {
   return rc;
 }
 
-hipStream_t kk_stream(okkt_kkt_s* k) { return k->ls->stream; }
 
 int kk_reduce(okkt_kkt_s* k, int64_t n, const double* v, int mode, double* host_out) {
   hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, kk_stream(k), n, v, mode, k->red);
@@ -386,6 +338,12 @@ void spmv_H(okkt_kkt_s* k, const double* x, double* y) {
 }
 
 }  // namespace
+
+namespace okkt {
+void kk_spmv_J(okkt_kkt_s* k, const double* x, double* y) { spmv_J(k, x, y); }
+void kk_spmv_JT(okkt_kkt_s* k, const double* Jx, const double* v, double* y) { spmv_JT(k, Jx, v, y); }
+void kk_spmv_H(okkt_kkt_s* k, const double* x, double* y) { spmv_H(k, x, y); }
+}  // namespace okkt
 
 extern "C" {
 
@@ -585,6 +543,7 @@ int okkt_kkt_form_system(okkt_kkt_handle k, const double* H_nzval, const double*
   if (!k->structured) return kk_fail(k, OKKT_ERR_INVALID, "okkt_kkt_set_structure has not been called");
   if (k->kind == OKKT_KKT_CLEVER_SYMMETRIC && !k->indexed) return kk_fail(k, OKKT_ERR_INVALID, "okkt_kkt_compute_indicies has not been called (initialize!, clever_symmetric.jl:53-61)");
   if ((k->nnzH > 0 && !H_nzval) || (k->nnzJ > 0 && !J_nzval)) return OKKT_ERR_INVALID;
+  k->have_dir = false;
   hipStream_t st = kk_stream(k);
   KK_TRY(k, hipSetDevice(k->ls->device));
   if (k->nnzH) KK_TRY(k, hipMemcpyAsync(k->Hx, H_nzval, (size_t)k->nnzH * 8, hipMemcpyHostToDevice, st));
@@ -824,6 +783,7 @@ int okkt_kkt_compute_direction(okkt_kkt_handle k, const double* dual_r, const do
   }
   KK_TRY(k, hipStreamSynchronize(st));
   KK_TRY(k, hipGetLastError());
+  k->have_dir = true;
   return OKKT_OK;
 }
 

@@ -1,0 +1,68 @@
+// State of a KKT-system handle (include/okkt.h, level 2), shared by kkt.hip (system, factor, direction) and
+// linesearch.hip (step-side vector kernels).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "solver.h"
+
+struct okkt_kkt_s {
+  okkt_handle ls = nullptr;
+  int kind = OKKT_KKT_SCHUR;
+  int64_t n = 0, m = 0, nnzH = 0, nnzJ = 0, nnzA = 0, dimA = 0;
+  bool structured = false, formed = false, factored = false;
+  bool have_dir = false;   // dx, dy, ds hold the direction of the last okkt_kkt_compute_direction for the current (s, y)
+  double delta = 0.0;
+  std::string err;
+  std::vector<void*> allocs;
+  // assembled matrix pattern (host copy, 0-based CSC lower)
+  std::vector<int64_t> Ap, Ai;
+  // device: H (CSC lower + CSR view), J (CSC + CSR view), point
+  int64_t *Hp = nullptr, *Hrp = nullptr, *Hrmap = nullptr, *Jp = nullptr, *Jrp = nullptr, *Jrmap = nullptr;
+  int *Hi = nullptr, *Hrj = nullptr, *Ji = nullptr, *Jrj = nullptr;
+  double *Hx = nullptr, *Jx = nullptr, *s = nullptr, *y = nullptr, *sig = nullptr;
+  double* Avals = nullptr;
+  int64_t *mapH = nullptr, *mapJ = nullptr, *diagA = nullptr;   // symmetric: value slots in A
+  int64_t *qptr = nullptr, *qh = nullptr;                        // schur: contributions per Q entry
+  int *qa = nullptr, *qb = nullptr, *qi = nullptr;
+  double* schur_diag = nullptr;
+  // work vectors
+  double *rD = nullptr, *rP = nullptr, *rC = nullptr, *dx = nullptr, *dy = nullptr, *ds = nullptr;
+  double *vn1 = nullptr, *vn2 = nullptr, *vn3 = nullptr, *vm1 = nullptr, *vm2 = nullptr, *big1 = nullptr, *big2 = nullptr;
+  double* red = nullptr;  // reduction outputs
+  // step-side kernels (linesearch.hip): staged host vectors and reduction partials, allocated on first use
+  double *ls_m[4] = {nullptr, nullptr, nullptr, nullptr}, *ls_n[2] = {nullptr, nullptr}, *ls_part = nullptr, *ls_out = nullptr;
+  double* Jcur = nullptr; // Jacobian values of a current iterate that differs from the factorised one
+  // ---- clever symmetric (clever_symmetric.jl): parallel-row groups and the reduced system
+  bool indexed = false;
+  int64_t m_new = 0;
+  int rescale_mode = OKKT_RESCALE_NONE;
+  double rescale_mu = 0.0, rescale_xinf = 0.0;
+  std::vector<int64_t> h_Jrp, h_Jrmap;           // host CSR view of J (kept for compute_indicies)
+  std::vector<int> h_Jrj;
+  std::vector<int64_t> h_Hp, h_Jp;               // host copies of the column pointers / row indices
+  std::vector<int> h_Hi, h_Ji;
+  std::vector<int64_t> h_first, h_gptr, h_mind;  // groups: first row, member ranges, member rows (ls order)
+  std::vector<double> h_mratio;
+  int64_t *gptr = nullptr, *mapJc = nullptr, *Arp = nullptr, *Armap = nullptr, *dAp = nullptr;
+  int *mind = nullptr, *row_grp = nullptr, *dAi = nullptr, *Arj = nullptr, *Hcol = nullptr, *Jcol = nullptr;
+  double *mratio = nullptr, *row_ratio = nullptr, *gU = nullptr, *rowg = nullptr, *Dres = nullptr, *true_x_diag = nullptr;
+  double *crhs = nullptr, *big3 = nullptr, *big4 = nullptr;
+};
+
+#define KK_TRY(k, expr)                                                                      \
+  do {                                                                                       \
+    hipError_t e__ = (expr);                                                                 \
+    if (e__ != hipSuccess) { (k)->err = std::string(#expr) + ": " + hipGetErrorString(e__); return OKKT_ERR_HIP; } \
+  } while (0)
+
+namespace okkt {
+// y = J x (m), y = J' v with the Jacobian values Jx (n), y = H x with the lower-stored H (n): on the handle's stream
+void kk_spmv_J(okkt_kkt_s* k, const double* x, double* y);
+void kk_spmv_JT(okkt_kkt_s* k, const double* Jx, const double* v, double* y);
+void kk_spmv_H(okkt_kkt_s* k, const double* x, double* y);
+inline hipStream_t kk_stream(okkt_kkt_s* k) { return k->ls->stream; }
+}  // namespace okkt

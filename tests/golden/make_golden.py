@@ -109,6 +109,78 @@ def problem_record(name, Hl, J, grad, cons, x, s, y, mu, delta, a_norm_penalty=1
                 inertia_K=inertia_dense(K), inertia_Q=inertia_dense(Q))
 
 
+def jl_max(a, b):
+    return math.nan if (a != a or b != b) else max(a, b)
+
+
+def jl_min(a, b):
+    return math.nan if (a != a or b != b) else min(a, b)
+
+
+def line_search_record(rec, frac_bd_predict=0.2, frac_bd=0.1, ex=0.5, comp_feas=0.01, scale_D=0.7, scale_mu=1.3):
+    """Known answers for the step-side functions (frac_boundary.jl:3-35, move.jl:15-17,28-118, line_search.jl:84-86,
+    eval.jl:236-273), written out entry by entry with Python floats from the record's dense direction; affine
+    direction, so dir.mu = -mu.  The candidate is the half step to the boundary."""
+    n, m = rec["n"], rec["m"]
+    Hl, J = np.array(rec["H_lower"], float).reshape(n, n), np.array(rec["J"], float).reshape(m, n)
+    s, y, mu, pen = rec["s"], rec["y"], rec["mu"], rec["a_norm_penalty"]
+    dx, dy, ds, grad = rec["dx"], rec["dy"], rec["ds"], rec["grad"]
+    dmu = -mu
+    nx = max(abs(v) for v in dx)
+    thr = nx * nx ** ex
+    ratio = 1.0
+    for i in range(m):
+        ratio = jl_max(ratio, -ds[i] / (s[i] - frac_bd_predict * min(s[i], thr)))
+    step_P = 1.0 / ratio
+    alpha = 0.5 * step_P
+    s_c = [s[i] + alpha * ds[i] for i in range(m)]
+    mu_c = mu + alpha * dmu
+    s_ok = all(s_c[i] >= frac_bd * min(s[i], thr) for i in range(m))
+    s_bad = list(s_c)
+    if m:
+        s_bad[m - 1] = 0.5 * frac_bd * min(s[m - 1], thr)
+    lb, ub = 0.0, 1.0
+    for i in range(m):
+        if dy[i] == 0.0:
+            continue   # no entry of these fixtures has dy == 0 (asserted below)
+        ub_i = mu_c / (comp_feas * s_c[i] * dy[i]) - y[i] / dy[i]
+        lb_i = mu_c * comp_feas / (s_c[i] * dy[i]) - y[i] / dy[i]
+        if dy[i] > 0.0:
+            lb, ub = jl_max(lb_i * 1.001 + 0.0, lb), jl_min(ub_i / 1.001 - 0.0, ub)
+        else:
+            lb, ub = jl_max(ub_i * 1.001 + 0.0, lb), jl_min(lb_i / 1.001 - 0.0, ub)
+    assert all(v != 0.0 for v in dy)
+    ratio_y = 1.0
+    for i in range(m):
+        ratio_y = jl_max(ratio_y, -dy[i] / (y[i] - frac_bd * y[i] * min(1.0, nx)))
+    ub = jl_min(ub, 1.0 / ratio_y)
+    # predicted reductions at step 1 (long double accumulation: the expected values are the exact sums, rounded once)
+    ld = np.longdouble
+    H = sym_from_lower(Hl).astype(ld)
+    Jl, dxl = J.astype(ld), np.array(dx, ld)
+    v = Jl @ dxl
+    J_gain = sum(v[i] * v[i] * (ld(y[i]) / ld(s[i])) for i in range(m))
+    w = np.array([ld(mu) / ld(s[i]) - ld(mu) * ld(pen) for i in range(m)], ld)
+    gphi = np.array(grad, ld) - (Jl.T @ w if m else 0)
+    step = 1.0
+    phi_red = step * float(dxl @ gphi) + step * step * 0.5 * float(dxl @ (H @ dxl) + J_gain)
+    C_k = max([abs(s[i] * y[i] - mu) for i in range(m)], default=0.0)
+    P_k = max([abs(s[i] * y[i] + dy[i] * s[i] * step + ds[i] * y[i] * step - (mu + dmu * step)) for i in range(m)], default=0.0)
+    merit = phi_red + ((P_k ** 3 - C_k ** 3) / mu ** 2 if m else 0.0)
+    # move_dual's least-squares step on the candidate (same J and grad: the toys are linear or evaluated at iter)
+    dyl = np.array(dy, ld)
+    q = np.concatenate([ld(scale_D) * (Jl.T @ dyl), np.array([ld(scale_mu) * ld(s_c[i]) * dyl[i] for i in range(m)], ld)])
+    dres = np.array(grad, ld) - Jl.T @ (np.array(y, ld) - ld(mu_c) * ld(pen))
+    res = np.concatenate([ld(scale_D) * dres, np.array([-ld(scale_mu) * (ld(s_c[i]) * ld(y[i]) - ld(mu_c)) for i in range(m)], ld)])
+    sd = float((res @ q) / (q @ q))
+    small = max(lb, min(ub, alpha))
+    step_D = jl_max(jl_min(sd, ub), small)
+    return dict(name=rec["name"], frac_bd_predict=frac_bd_predict, frac_bd=frac_bd, ex=ex, comp_feas=comp_feas, scale_D=scale_D,
+                scale_mu=scale_mu, dir_mu=dmu, dx_norm_inf=nx, step_size_P=step_P, alpha=alpha, s_cand=s_c, mu_cand=mu_c,
+                s_bound_ok=bool(s_ok), s_bad=s_bad, dual_lb=lb, dual_ub=ub, phi_red=phi_red, C_k=C_k, P_k=P_k, merit_red=merit,
+                ls_step_unclamped=sd, step_size_D=step_D)
+
+
 def delta_loop_dense(Hl, J, s, y, delta_prev, kind):
     """delta_strategy.jl:37-114 with dense inertia; kind = 'schur' or 'symmetric'."""
     n, m = Hl.shape[0], J.shape[0]
@@ -220,6 +292,12 @@ def main():
         "compare_columns_A_rows": [[0.0, 10.0, 0.0], [1.0, 0.0, 1.0], [1.0, 0.0, 0.0], [2.0, 0.0, 0.0]],   # A = sparse(rows')'
         "compare_columns": [[1, 2, True], [2, 1, False], [2, 3, False], [3, 2, True], [3, 1, False], [1, 3, True]],
     }
+    # --- step-side functions (line search), known answers on the records above
+    out["line_search"] = [line_search_record(r) for r in [out["readme_toy"], out["indef5"], out["posdiag_indef5"]] + out["toy_lps"]]
+    # a tight complementarity window (comp_feas = 0.5, 0.9): positive lower bounds and empty ranges (lb >= ub)
+    for cf in (0.5, 0.9):
+        out["line_search"] += [line_search_record(r, frac_bd_predict=0.05, frac_bd=0.3, ex=1.0, comp_feas=cf, scale_D=1.0, scale_mu=1.0)
+                               for r in (out["indef5"], out["toy_lps"][3], out["toy_lps"][8])]
     with open(os.path.join(HERE, "kkt_known_answers.json"), "w") as f:
         json.dump(out, f, indent=1)
     print("wrote", os.path.join(HERE, "kkt_known_answers.json"))
