@@ -170,6 +170,8 @@ def main():
             out["config"]["kkt_level"] = kkt_level_breakdown(prob, local_rank)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, st)
+            if not args.no_kkt_level:
+                out["cpu_baseline"]["step_side_port"] = step_side_port(prob)
         print(json.dumps(out))
     hip.dev_free(d_vals); hip.dev_free(d_rhs); hip.dev_free(d_sol)
     finalize_b(hip)
@@ -249,6 +251,8 @@ def kkt_level_breakdown(prob, device):
         tm["N_err"] = float(k.kkt_err_norm.ratio)
         tm["refinement_solves"] = 3 if kind == "schur" else 1
         out[kind] = tm
+        if kind == "symmetric":
+            out["step_side"] = step_side_breakdown(k, it)
         k.finalize_b()
     # the delta-loop variant: a nonconvex instance of the same generator (H shifted by -5), the whole
     # ipopt_strategy! (delta_strategy.jl:37-114) + one direction = what one outer IPM iteration costs on the path
@@ -273,6 +277,64 @@ def kkt_level_breakdown(prob, device):
                              "delta": float(delta), "loop_ms": t_loop, "ms_per_factorisation": t_loop / max(nfac, 1),
                              "direction_ms": t_dir, "N_err": float(k.kkt_err_norm.ratio)}
         k.finalize_b()
+    return out
+
+
+def step_side_breakdown(k, it):
+    """SURVEY.md 8f rank 4: wall-clock of the step-side functions (line_search.jl:40-41,84-86; move.jl:15-17,82-118;
+    eval.jl:236-273) against the direction that compute_direction_b left on the device.  Host vectors (frac_bd, the
+    candidate's s, y, grad) cross PCIe inside each call; `stream_bytes` = the length-m / length-n vectors and the
+    J, H entries a call reads on the device (8 B values + 4 B indices), for the HBM figure."""
+    from onephase_jl_amd import line_search as LS
+    n, m = it.dim(), it.ncon()
+    nnzJ, nnzH = it.J.nnz, it.H.nnz
+    rng = np.random.default_rng(2)
+    fp, fb = np.full(m, 0.2), np.full(m, 0.1)
+    pars = LS.Class_ls_parameters()
+    out = {"workload": f"n = {n}, m = {m}, nnz(J) = {nnzJ}, nnz(tril H) = {nnzH}; direction resident"}
+    step_P, _ = LS.max_step_primal(k, fp, pars)
+    alpha = 0.5 * step_P
+    d = k.dir
+    import copy
+    cand = copy.copy(it)
+    cand.s, cand.mu, cand.grad = it.s + alpha * d.s, it.mu + alpha * d.mu, it.grad + 1e-3 * rng.normal(size=n)
+    lb, ub = LS.dual_step_range(k, cand, fb, pars)
+    calls = {
+        "max_step_primal": (lambda: LS.max_step_primal(k, fp, pars), 8 * (n + 4 * m)),
+        "s_bound_ok": (lambda: LS.s_bound_ok(k, cand.s, fb, pars), 8 * (n + 3 * m)),
+        "dual_step_range": (lambda: LS.dual_step_range(k, cand, fb, pars), 8 * (n + 5 * m)),
+        "predicted_reduction": (lambda: LS.predicted_reduction_terms(k, 1.0), 12 * (2 * nnzJ + 2 * nnzH) + 8 * (8 * m + 7 * n)),
+        "dual_step": (lambda: LS.move_dual_step(k, cand, alpha, lb, ub, 1.0, 1.0, pars), 12 * 2 * nnzJ + 8 * (6 * m + 6 * n)),
+    }
+    for name, (fn, nbytes) in calls.items():
+        fn()
+        t = time.perf_counter()
+        for _ in range(5):
+            fn()
+        ms = 1e3 * (time.perf_counter() - t) / 5
+        out[name] = {"ms": ms, "stream_bytes": int(nbytes)}
+    out["step_size_P"], out["dual_range"] = float(step_P), [float(lb), float(ub)]
+    return out
+
+
+def step_side_port(prob):
+    """cpu_baseline leg: the oracle's numpy / Python restatement of the same step-side functions on the same sizes."""
+    from oracle import kkt_oracle as KO
+    from oracle import line_search_oracle as LO
+    n, m = prob["n"], prob["m"]
+    rng = np.random.default_rng(1)
+    it = KO.Iterate(x=rng.normal(size=n), y=prob["y"], s=prob["s"], mu=float(prob["mu"]), J=prob["J"], H=prob["H"],
+                    grad=rng.normal(size=n), cons=prob["s"].copy())
+    d = KO.Direction(rng.normal(size=n), 0.1 * rng.normal(size=m) * prob["y"], 0.1 * rng.normal(size=m) * prob["s"], mu=-0.5 * it.mu)
+    fp, fb = np.full(m, 0.2), np.full(m, 0.1)
+    out = {}
+    t = time.perf_counter(); step_P = LO.simple_max_step(it.s, d.s, LO.lb_s_predict(it, d, fp, 0.5)); out["max_step_primal_ms"] = 1e3 * (time.perf_counter() - t)
+    s_c = it.s + 0.5 * step_P * d.s
+    t = time.perf_counter(); lb, ub = LO.dual_step_range(it, d, s_c, it.y, 0.75 * it.mu, 0.01, fb); out["dual_step_range_ms"] = 1e3 * (time.perf_counter() - t)
+    t = time.perf_counter(); LO.predicted_reduction_terms(it, d, 1.0); out["predicted_reduction_ms"] = 1e3 * (time.perf_counter() - t)
+    cand = KO.Iterate(x=it.x, y=it.y, s=s_c, mu=0.75 * it.mu, J=it.J, H=it.H, grad=it.grad, cons=it.cons)
+    t = time.perf_counter(); LO.move_dual_step(cand, d, 0.5 * step_P, lb, ub, 1, 1.0, 1.0); out["dual_step_ms"] = 1e3 * (time.perf_counter() - t)
+    out["note"] = "numpy, 1 thread; dual_bounds is the reference's scalar loop in Python"
     return out
 
 

@@ -43,6 +43,7 @@ int kk_alloc(okkt_kkt_s* k, size_t count, T** out) {
   KK_TRY(k, hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T)));
   k->allocs.push_back(p);
   KK_TRY(k, hipMemset(p, 0, std::max<size_t>(count, 1) * sizeof(T)));
+  KK_TRY(k, hipStreamSynchronize(nullptr));   // the fill runs on the null stream; the handle's streams do not wait for it
   *out = (T*)p;
   return OKKT_OK;
 }

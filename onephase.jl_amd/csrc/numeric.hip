@@ -1274,7 +1274,12 @@ std::string dalloc(Numeric& N, size_t count, T** out, bool zero) {
   void* p = nullptr;
   OKKT_HIP_TRY(hipMalloc(&p, bytes));
   N.allocations.push_back(p);
-  if (zero) OKKT_HIP_TRY(hipMemset(p, 0, bytes));
+  if (zero) {
+    // hipMemset on device memory returns before the fill has run (null stream), and the handle's streams are
+    // non-blocking: without this wait the first factorisation can race with the zero fill of its own buffers
+    OKKT_HIP_TRY(hipMemset(p, 0, bytes));
+    OKKT_HIP_TRY(hipStreamSynchronize(nullptr));
+  }
   *out = (T*)p;
   return "";
 }
