@@ -166,6 +166,11 @@ def main():
                 "share_of_factor_time": syrk_ms / max(fac_ms, 1e-9),
             },
         }
+    # the handle goes back before the KKT-level handles are created: they reuse its pooled stream set (api.cpp)
+    hip.dev_free(d_vals); hip.dev_free(d_rhs); hip.dev_free(d_sol)
+    inertia_final = hip.inertia
+    finalize_b(hip)
+    if rank == 0:
         if world == 1 and not args.no_kkt_level:
             out["config"]["kkt_level"] = kkt_level_breakdown(prob, local_rank)
         if world == 1 and not args.no_cpu_baseline:
@@ -173,12 +178,10 @@ def main():
             if not args.no_kkt_level:
                 out["cpu_baseline"]["step_side_port"] = step_side_port(prob)
         print(json.dumps(out))
-    hip.dev_free(d_vals); hip.dev_free(d_rhs); hip.dev_free(d_sol)
-    finalize_b(hip)
     if distributed:
         dist.destroy_process_group()
     if not ok:
-        raise SystemExit(f"bench result failed its correctness check: rc={rc} inertia={hip.inertia} resid={resid}")
+        raise SystemExit(f"bench result failed its correctness check: rc={rc} inertia={inertia_final} resid={resid}")
 
 
 def bench_sharded(args, rank, world, local_rank):

@@ -21,6 +21,7 @@ struct okkt_solver_s {
   int device = 0;
   hipStream_t stream = nullptr;        // main stream (CU-masked when look-ahead is on)
   hipStream_t stream_masked = nullptr; // look-ahead main stream: CU mask without the reserved CUs (segments that use the look-ahead run here)
+  int stream_la = 0, stream_reserved = 0;   // key of the pooled stream set (api.cpp)
   hipStream_t stream_panel = nullptr;  // look-ahead panel stream (high priority, all CUs)
   hipStream_t stream_aux = nullptr;    // second panel stream: the part of the in-group updates that k_big_diag does not wait for
   hipEvent_t ev0 = nullptr, ev1 = nullptr;

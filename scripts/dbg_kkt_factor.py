@@ -7,7 +7,7 @@ n, m = prob["n"], prob["m"]
 rng = np.random.default_rng(1)
 it = KS.Class_iterate(x=rng.normal(size=n), y=prob["y"], s=prob["s"], mu=float(prob["mu"]), J=prob["J"], H=prob["H"],
                       grad=rng.normal(size=n), cons=prob["s"] + 1e-3 * rng.normal(size=m))
-for kind in ("symmetric", "schur"):
+for kind in (sys.argv[2].split(",") if len(sys.argv) > 2 else ("symmetric", "schur")):
     k = KS.HIP_KKT_solver(kind)
     k.initialize_b(it)
     k.form_system_b(it)
@@ -16,4 +16,6 @@ for kind in ("symmetric", "schur"):
             print(kind, r, "inertia flag", k.factor_b(1e-8), k.linear_solver_stats()["last_factor_ms"])
         except Exception as e:
             print(kind, r, "FAILED", e)
+    st = k.linear_solver_stats()
+    print({q: st[q] for q in ("nnz_lower", "nnzL", "flops_exact", "flops_stored", "max_front", "n_big_fronts", "nlevels")})
     k.finalize_b()

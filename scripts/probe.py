@@ -13,8 +13,12 @@ for a in sys.argv[3:]:
     opts[k] = float(v) if "." in v else int(v)
 prob = synth.make_config(name, seed=0)
 n, m = prob["n"], prob["m"]
-K = synth.augmented_matrix(prob, delta=1e-8)
-h = linear_solver_HIP("symmetric", **opts); initialize_b(h)
+schur = opts.pop("schur", 0)
+if schur:
+    K = synth.schur_matrix(prob, delta=1e-8); n, m = n, 0
+else:
+    K = synth.augmented_matrix(prob, delta=1e-8)
+h = linear_solver_HIP("definite" if schur else "symmetric", **opts); initialize_b(h)
 t = time.time(); rc = h.ls_factor_b(K, n, m); t1 = time.time() - t
 st = h.stats()
 print(name, "rc", rc, "inertia", h.inertia, "first call s", round(t1, 3), "analyze s", round(st["analyze_seconds"], 3))
