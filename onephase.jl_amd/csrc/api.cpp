@@ -128,22 +128,47 @@ struct StreamSet {
   int device = -1, la = 0, reserved = 0;
   hipStream_t stream = nullptr, masked = nullptr, panel = nullptr, aux = nullptr;
 };
-static std::mutex g_pool_mutex;
-static std::vector<StreamSet> g_pool;
+// heap objects that are never destructed: no static-destruction order to get wrong at process exit
+static std::mutex& pool_mutex() { static std::mutex* m = new std::mutex; return *m; }
+static std::vector<StreamSet>& pool_free() { static std::vector<StreamSet>* v = new std::vector<StreamSet>; return *v; }
+static std::vector<StreamSet>& pool_all() { static std::vector<StreamSet>* v = new std::vector<StreamSet>; return *v; }
+static bool g_pool_closed = false;
+
+// At exit every stream of the pool is destroyed (in use or not): CU-masked and priority streams that are still alive
+// when rocprofv3's tool library tears down crash it (exit code 139 after the traces were written); the handler is
+// registered at the first okkt_create, i.e. after HIP's and the profiler's own, so it runs before them.
+static void pool_close() {
+  std::lock_guard<std::mutex> lock(pool_mutex());
+  g_pool_closed = true;
+  for (const StreamSet& set : pool_all()) {
+    if (hipSetDevice(set.device) != hipSuccess) continue;
+    for (hipStream_t q : {set.aux, set.panel, set.masked, set.stream})
+      if (q) { (void)hipStreamSynchronize(q); (void)hipStreamDestroy(q); }
+  }
+  pool_all().clear();
+  pool_free().clear();
+}
 
 static bool take_stream_set(int device, int la, int reserved, StreamSet* out) {
-  std::lock_guard<std::mutex> lock(g_pool_mutex);
-  for (size_t q = 0; q < g_pool.size(); ++q)
-    if (g_pool[q].device == device && g_pool[q].la == la && g_pool[q].reserved == reserved) {
-      *out = g_pool[q];
-      g_pool.erase(g_pool.begin() + (long)q);
+  std::lock_guard<std::mutex> lock(pool_mutex());
+  std::vector<StreamSet>& fr = pool_free();
+  for (size_t q = 0; q < fr.size(); ++q)
+    if (fr[q].device == device && fr[q].la == la && fr[q].reserved == reserved) {
+      *out = fr[q];
+      fr.erase(fr.begin() + (long)q);
       return true;
     }
   return false;
 }
+static void register_stream_set(const StreamSet& set) {
+  std::lock_guard<std::mutex> lock(pool_mutex());
+  static bool registered = false;
+  if (!registered) { registered = true; (void)atexit(pool_close); }
+  pool_all().push_back(set);
+}
 static void give_stream_set(const StreamSet& set) {
-  std::lock_guard<std::mutex> lock(g_pool_mutex);
-  g_pool.push_back(set);
+  std::lock_guard<std::mutex> lock(pool_mutex());
+  if (!g_pool_closed) pool_free().push_back(set);
 }
 
 int okkt_create(okkt_handle* out, const okkt_opts* opts) {
@@ -214,6 +239,11 @@ int okkt_create(okkt_handle* out, const okkt_opts* opts) {
     if (!h->stream && hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return OKKT_ERR_HIP; }
     h->stream_la = la ? 1 : 0;
     h->stream_reserved = reserved;
+    if (set.device < 0) {   // a new set: the pool owns its streams from now on
+      set.device = dev; set.la = h->stream_la; set.reserved = reserved;
+      set.stream = h->stream; set.masked = h->stream_masked; set.panel = h->stream_panel; set.aux = h->stream_aux;
+      register_stream_set(set);
+    }
     if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) { delete h; return OKKT_ERR_HIP; }
     h->device_ready = true;
   }
