@@ -93,6 +93,9 @@ struct Numeric {
   int lookahead = 1;
   int use_sb = 1;                        // super-block solves for fronts with >= 2048 pivot columns 
   bool sb_ready = false;                 // inverses of the current factorisation are in place
+  hipEvent_t sb_event = nullptr;         // recorded behind an inversion that the factorisation started on the auxiliary stream
+  bool sb_wait = false;                  // ... which the next solve has to wait for
+  int sb_tail_rows = 4000;               // the inversion of the finished blocks starts once fewer rows than this remain
   int solves_since_factor = 0;
   int sb_lazy = 0;                       // solves with the 128-column steps before the inverses are prepared
   void* blas = nullptr;                  // rocblas_handle (TRSM for the super-block inverses)

@@ -1300,6 +1300,7 @@ std::string numeric_setup(const Symbolic& S, const SymbolicOptions& opts, hipStr
   N.group_big_minf = getenv("OKKT_GROUP_BIG_MINF") ? atoi(getenv("OKKT_GROUP_BIG_MINF")) : 8192;
   if (getenv("OKKT_GROUP")) { N.group = N.group_big = std::max(1, std::min(atoi(getenv("OKKT_GROUP")), 4)); }
   N.group_switch_rows = getenv("OKKT_GROUP_SWITCH_ROWS") ? atoi(getenv("OKKT_GROUP_SWITCH_ROWS")) : 9000;
+  if (getenv("OKKT_SB_TAIL_ROWS")) N.sb_tail_rows = atoi(getenv("OKKT_SB_TAIL_ROWS"));   // -1: at the end of the factorisation only
   N.group_one_rows = getenv("OKKT_GROUP_ONE_ROWS") ? atoi(getenv("OKKT_GROUP_ONE_ROWS")) : 4000;
   N.nnz_in = S.nnz_in;
   if (S.max_front > 46000) return "front order exceeds the 32-bit local offset range";
@@ -1540,6 +1541,7 @@ void numeric_release(Numeric& N) {
   N.prof_used = 0;
   N.prof_flops.clear();
   if (N.blas) { (void)rocblas_destroy_handle((rocblas_handle)N.blas); N.blas = nullptr; }
+  if (N.sb_event) { (void)hipEventDestroy(N.sb_event); N.sb_event = nullptr; }
   for (hipEvent_t ev : N.la_events) (void)hipEventDestroy(ev);
   N.la_events.clear();
   N.la_used = 0;
@@ -1552,6 +1554,66 @@ void numeric_release(Numeric& N) {
   N.vals_owned = nullptr;
 }
 
+// Explicit inverses of the kSolveSB-column diagonal blocks of the fronts that take the super-block solves: a plain
+// library TRSM on the identity (rocblas_dtrsm_strided_batched over the full blocks of a front).  It costs about one
+// millisecond at the S-metric root (some 120 small library kernels) and saves 1.4 ms per solve (4.3 -> 3.0 ms).
+// Fronts of at least 8 * kSolveSB columns (sb_lazy == 0) start it inside the factorisation, on the auxiliary stream:
+// the blocks that are final when the front enters its chain-bound tail (fewer than sb_tail_rows rows left, idle CUs),
+// the rest behind the last panel; the first solve waits for sb_event.  Smaller fronts prepare on demand, before the
+// (sb_lazy + 1)-th solve (numeric_sb_prepare).
+static std::string sb_blas(Numeric& N, hipStream_t st, rocblas_handle* out) {
+  if (!N.blas) {
+    rocblas_handle h2 = nullptr;
+    if (rocblas_create_handle(&h2) != rocblas_status_success) return "rocblas_create_handle failed";
+    N.blas = h2;
+  }
+  *out = (rocblas_handle)N.blas;
+  if (rocblas_set_stream(*out, st) != rocblas_status_success) return "rocblas_set_stream failed";
+  return "";
+}
+// blocks [b_lo, b_hi) of front s2 (b_hi is clipped to the front's block count)
+static std::string sb_prepare_front(Numeric& N, rocblas_handle hb, hipStream_t st, int s2, int b_lo, int b_hi) {
+  DevPlan P = N.d;
+  const double one = 1.0;
+  const int64_t kk = N.sn_k[s2], ff = N.sn_f[s2];
+  const int nfull = (int)(kk / kSolveSB), klast = (int)(kk - (int64_t)nfull * kSolveSB);
+  const int nblk = nfull + (klast ? 1 : 0);
+  b_hi = std::min(b_hi, nblk);
+  if (b_lo >= b_hi) return "";
+  double* X = P.xsb + N.xsb_pos_host[s2] + (size_t)b_lo * kSolveSB * kSolveSB;
+  const double* Lf = P.arena + N.front_pos_host[s2] + (size_t)b_lo * kSolveSB * (ff + 1);
+  const int64_t tot = (int64_t)(b_hi - b_lo) * kSolveSB * kSolveSB;
+  hipLaunchKernelGGL(k_sb_identity, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, X, kSolveSB, tot);
+  const int full_hi = std::min(b_hi, nfull);
+  if (full_hi > b_lo &&
+      rocblas_dtrsm_strided_batched(hb, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_unit,
+                                    kSolveSB, kSolveSB, &one, Lf, (rocblas_int)ff, (rocblas_stride)kSolveSB * (ff + 1), X,
+                                    kSolveSB, (rocblas_stride)kSolveSB * kSolveSB, full_hi - b_lo) != rocblas_status_success)
+    return "rocblas_dtrsm_strided_batched failed";
+  if (klast && b_hi == nblk &&
+      rocblas_dtrsm(hb, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_unit, klast, klast, &one,
+                    Lf + (size_t)(nfull - b_lo) * kSolveSB * (ff + 1), (rocblas_int)ff, X + (size_t)(nfull - b_lo) * kSolveSB * kSolveSB,
+                    kSolveSB) != rocblas_status_success)
+    return "rocblas_dtrsm failed";
+  return "";
+}
+static std::string numeric_sb_prepare(Numeric& N, hipStream_t st) {
+  rocblas_handle hb = nullptr;
+  std::string e = sb_blas(N, st, &hb);
+  if (!e.empty()) return e;
+  for (int pass = 0; pass < 2; ++pass) {
+    const std::vector<LevelSchedule>& levels = pass == 0 ? N.levels : N.levels_top;
+    for (const LevelSchedule& L : levels) {
+      const Segment& g = L.seg[3];
+      if (!g.cnt || g.mink < 2 * kSolveSB) continue;
+      for (int q = 0; q < g.cnt; ++q)
+        if (!(e = sb_prepare_front(N, hb, st, N.sched_host[g.off + q], 0, 1 << 30)).empty()) return e;
+    }
+  }
+  N.sb_ready = true;
+  return "";
+}
+
 std::string numeric_factor_enqueue(Numeric& N, const double* d_vals, double tol, int which, bool reset_counters) {
   DevPlan P = N.d;
   P.vals = d_vals;
@@ -1560,6 +1622,7 @@ std::string numeric_factor_enqueue(Numeric& N, const double* d_vals, double tol,
   if (reset_counters) OKKT_HIP_TRY(hipMemsetAsync(P.counters, 0, 4 * sizeof(unsigned long long), st));
   N.la_used = 0;
   N.sb_ready = false;            // the super-block inverses belong to the previous factorisation
+  N.sb_wait = false;
   N.solves_since_factor = 0;
   const int NB = N.nb;
   static const int dbg_syrk = getenv("OKKT_DEBUG_SYRK") ? atoi(getenv("OKKT_DEBUG_SYRK")) : 0;
@@ -1737,6 +1800,30 @@ std::string numeric_factor_enqueue(Numeric& N, const double* d_vals, double tol,
       // main stream's CU mask leaves free: k_big_diag is a lone, latency-bound workgroup) runs
       // head2(q) -> Panel(q + 1)  while the main stream runs rest(q) back to back with rest(q - 1).
       // Used only while the rest is large enough; afterwards everything runs in order on the main stream.
+      // super-block inverses started inside the factorisation (see sb_prepare_front)
+      const bool sb_eager = which == 0 && N.levels_top.empty() && N.use_sb && N.sb_lazy == 0 && N.stream_aux != nullptr && g.mink >= 2 * kSolveSB;
+      int sb_done = 0;       // pivot columns (a multiple of kSolveSB, or all) whose blocks are already being inverted
+      auto sb_range = [&](int cols_final, bool last) -> std::string {
+        const int upto = last ? (1 << 30) : cols_final / kSolveSB;   // blocks [sb_done / kSolveSB, upto)
+        if (!last && upto * kSolveSB <= sb_done) return "";
+        hipEvent_t evs;
+        std::string e2 = next_event(&evs);
+        if (!e2.empty()) return e2;
+        OKKT_HIP_TRY(hipEventRecord(evs, st));
+        OKKT_HIP_TRY(hipStreamWaitEvent(N.stream_aux, evs, 0));
+        rocblas_handle hb = nullptr;
+        if (!(e2 = sb_blas(N, N.stream_aux, &hb)).empty()) return e2;
+        for (int q = 0; q < g.cnt; ++q)
+          if (!(e2 = sb_prepare_front(N, hb, N.stream_aux, N.sched_host[g.off + q], sb_done / kSolveSB, upto)).empty()) return e2;
+        sb_done = last ? (1 << 30) : upto * kSolveSB;
+        if (last) {
+          if (!N.sb_event) OKKT_HIP_TRY(hipEventCreateWithFlags(&N.sb_event, hipEventDisableTiming));
+          OKKT_HIP_TRY(hipEventRecord(N.sb_event, N.stream_aux));
+          N.sb_ready = true;
+          N.sb_wait = true;
+        }
+        return "";
+      };
       int gs_cur = gs_at(0), par = 0;
       std::string e = launch_panels(st, 0, gs_cur, par);
       if (!e.empty()) return e;
@@ -1759,6 +1846,9 @@ std::string numeric_factor_enqueue(Numeric& N, const double* d_vals, double tol,
           ev_panel = evp;
         } else {
           if (ev_panel) { OKKT_HIP_TRY(hipStreamWaitEvent(st, ev_panel, 0)); ev_panel = nullptr; }
+          // columns below stepB * NB are final behind this point of `st`: once the front is in its chain-bound tail, the
+          // inversion of the finished super-blocks starts on the auxiliary stream
+          if (sb_eager && sb_done == 0 && rem_rows(stepB) < N.sb_tail_rows && !(e = sb_range(stepB * NB, false)).empty()) return e;
           if (!(e = launch_syrk(st, stepA, gs_cur, stepB, 0, par, 0)).empty()) return e;
           if (more && !(e = launch_panels(st, stepB, gs_next, par ^ 1)).empty()) return e;
         }
@@ -1769,6 +1859,7 @@ std::string numeric_factor_enqueue(Numeric& N, const double* d_vals, double tol,
         const size_t lds_inv = ((size_t)(NB + 2) * NB + 3 * kTld * kIB) * sizeof(double);
         hipLaunchKernelGGL(k_big_invert, dim3(nsteps, g.cnt), dim3(256), lds_inv, st, P, list, NB);
       }
+      if (sb_eager && !(e = sb_range(0, true)).empty()) return e;
       if (seg_la) {   // join the handle's stream
         hipEvent_t evj;
         if (!(e = next_event(&evj)).empty()) return e;
@@ -1976,52 +2067,6 @@ static void launch_bwd_step(hipStream_t st, const DevPlan& P, const int* list, c
 }
 
 
-// Explicit inverses of the kSolveSB-column diagonal blocks of the fronts that take the super-block solves: a plain
-// library TRSM on the identity (rocblas_dtrsm_strided_batched over the full blocks of a front).  It costs about one
-// millisecond at the S-metric root and saves 1.4 ms per solve (4.3 -> 3.0 ms), so it already pays for itself on the
-// first solve after a factorisation (an IPM iteration solves 5-10 times per factorisation).  It runs on demand, before
-// the first solve (OKKT_SOLVE_SB_LAZY=n: only after n solves with the 128-column steps), never inside the factorisation.
-static std::string numeric_sb_prepare(Numeric& N, hipStream_t st) {
-  DevPlan P = N.d;
-  if (!N.blas) {
-    rocblas_handle h2 = nullptr;
-    if (rocblas_create_handle(&h2) != rocblas_status_success) return "rocblas_create_handle failed";
-    N.blas = h2;
-  }
-  rocblas_handle hb = (rocblas_handle)N.blas;
-  if (rocblas_set_stream(hb, st) != rocblas_status_success) return "rocblas_set_stream failed";
-  const double one = 1.0;
-  for (int pass = 0; pass < 2; ++pass) {
-    const std::vector<LevelSchedule>& levels = pass == 0 ? N.levels : N.levels_top;
-    for (const LevelSchedule& L : levels) {
-      const Segment& g = L.seg[3];
-      if (!g.cnt || g.mink < 2 * kSolveSB) continue;
-      for (int q = 0; q < g.cnt; ++q) {
-        const int s2 = N.sched_host[g.off + q];
-        const int64_t kk = N.sn_k[s2], ff = N.sn_f[s2];
-        const int nfull = (int)(kk / kSolveSB), klast = (int)(kk - (int64_t)nfull * kSolveSB);
-        const int nblk = nfull + (klast ? 1 : 0);
-        double* X = P.xsb + N.xsb_pos_host[s2];
-        const double* Lf = P.arena + N.front_pos_host[s2];
-        const int64_t tot = (int64_t)nblk * kSolveSB * kSolveSB;
-        hipLaunchKernelGGL(k_sb_identity, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, X, kSolveSB, tot);
-        if (nfull &&
-            rocblas_dtrsm_strided_batched(hb, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_unit,
-                                          kSolveSB, kSolveSB, &one, Lf, (rocblas_int)ff, (rocblas_stride)kSolveSB * (ff + 1), X,
-                                          kSolveSB, (rocblas_stride)kSolveSB * kSolveSB, nfull) != rocblas_status_success)
-          return "rocblas_dtrsm_strided_batched failed";
-        if (klast &&
-            rocblas_dtrsm(hb, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_unit, klast, klast, &one,
-                          Lf + (size_t)nfull * kSolveSB * (ff + 1), (rocblas_int)ff, X + (size_t)nfull * kSolveSB * kSolveSB,
-                          kSolveSB) != rocblas_status_success)
-          return "rocblas_dtrsm failed";
-      }
-    }
-  }
-  N.sb_ready = true;
-  return "";
-}
-
 // forward (L, then D^-1 fused) sweep over one schedule: which = 0 local subtrees, 1 top of the tree
 std::string numeric_solve_fwd_enqueue(Numeric& N, int which) {
   DevPlan P = N.d;
@@ -2047,6 +2092,7 @@ std::string numeric_solve_fwd_enqueue(Numeric& N, int which) {
   if (getenv("OKKT_DEBUG_SB")) fprintf(stderr, "okkt: solve fwd which=%d solves_since_factor=%d sb_ready=%d use_sb=%d\n", which, N.solves_since_factor, (int)N.sb_ready, N.use_sb);
   if (which == 0) ++N.solves_since_factor;
   const bool sb = N.use_sb && N.sb_ready;
+  if (sb && N.sb_wait) { OKKT_HIP_TRY(hipStreamWaitEvent(st, N.sb_event, 0)); N.sb_wait = false; }   // inversion started by the factorisation
   for (int l = 0; l < nl; ++l) {
     const LevelSchedule& L = levels[l];
     for (int c = 0; c < 3; ++c) {
