@@ -1,0 +1,34 @@
+"""GPU tests: every schedule the tuning switches of DESIGN.md section 9 can select gives the same answers
+(look-ahead on / off / everywhere, super-step widths, split in-group updates, super-block solves on / off)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+VARIANTS = [
+    {},
+    {"OKKT_LOOKAHEAD": "0"},
+    {"OKKT_LA_MIN_TILES": "1"},                                   # look-ahead on every big front, masked twin stream everywhere
+    {"OKKT_LA_MIN_TILES": "1", "OKKT_SPLIT_MIN_ROWS": "0", "OKKT_GROUP": "4", "OKKT_GROUP_ONE_ROWS": "0"},
+    {"OKKT_GROUP": "1"},
+    {"OKKT_GROUP_BIG": "4", "OKKT_GROUP_BIG_MINF": "0", "OKKT_GROUP_SWITCH_ROWS": "0", "OKKT_GROUP_ONE_ROWS": "0"},
+    {"OKKT_GROUP_ONE_ROWS": "100000"},
+    {"OKKT_RESERVED_CUS": "32", "OKKT_LA_MIN_TILES": "64"},
+    {"OKKT_SOLVE_SB": "0"},
+    {"OKKT_SOLVE_SB_LAZY": "0", "OKKT_SB_TAIL_ROWS": "1500"},    # in-factorisation inversion of the dense case's blocks
+    {"OKKT_SOLVE_SB_LAZY": "0", "OKKT_SB_TAIL_ROWS": "-1"},
+    {"OKKT_ASM_CHUNKED": "0"},
+    {"OKKT_ASM_LCOL": "0"},
+]
+
+
+@pytest.mark.parametrize("env", VARIANTS, ids=lambda e: ",".join(f"{k[5:]}={v}" for k, v in e.items()) or "default")
+def test_schedule_variant(env):
+    e = dict(os.environ)
+    e.update(env)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "env_variant_case.py")], cwd=ROOT, env=e, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "VARIANT_OK" in r.stdout, (env, r.stdout[-400:], r.stderr[-1200:])
