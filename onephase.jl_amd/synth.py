@@ -129,3 +129,76 @@ def block_angular(nblocks=8, n_b=5000, m_b=7500, n_link=200, seed=0, **kw):
     J = sp.hstack([Jb, link], format="csc")
     J.sort_indices()
     return dict(H=H.tocsc(), J=J, s=np.concatenate(ss), y=np.concatenate(ys), mu=1e-2, n=n, m=m)
+
+
+def hanging_chain(N_h=400, seed=0):
+    """S-C2, stand-in for CUTEst CHAIN (BASELINE config 2; CUTEst is not in the repo): the hanging chain
+        min  int_0^1 x sqrt(1 + u^2) dt   s.t.  x' = u,  int_0^1 sqrt(1 + u^2) dt = L,  x(0) = a, x(1) = b
+    on N_h trapezoidal intervals, variables z = [x_0..x_N, u_0..u_N] (n = 2 N_h + 2).  Rows of a(z) >= 0 in the
+    order the reference's adapter builds them (Class_cutest.jl:454-459): [cons >= l ; -cons <= u] for the N_h
+    dynamics rows, the length row and the two end conditions (every equality is a row pair).  J is banded except
+    for the two length rows (dense in u), H = Hessian of the Lagrangian at a seeded point: 2 x 2 blocks coupling
+    x_i and u_i with a zero (x, x) diagonal -- indefinite, the delta loop has work to do.  Small fronts throughout:
+    the HBM-bound assembly case."""
+    rng = np.random.default_rng(seed + 2000)
+    N = N_h
+    h = 1.0 / N
+    t = np.linspace(0.0, 1.0, N + 1)
+    x = 1.0 + 3.0 * (t - 0.5) ** 2 + 0.01 * rng.normal(size=N + 1)
+    u = 6.0 * (t - 0.5) + 0.01 * rng.normal(size=N + 1)
+    n = 2 * N + 2
+    ix, iu = np.arange(N + 1), N + 1 + np.arange(N + 1)
+    wq = np.full(N + 1, h); wq[0] = wq[-1] = h / 2            # trapezoid weights
+    r1 = np.sqrt(1.0 + u * u)
+    # equality rows c(z) = 0: dynamics (N), length (1), ends (2)
+    rows, cols, vals = [], [], []
+    for i in range(N):
+        rows += [i, i, i, i]; cols += [ix[i + 1], ix[i], iu[i], iu[i + 1]]; vals += [1.0, -1.0, -h / 2, -h / 2]
+    rows += [N] * (N + 1); cols += list(iu); vals += list(wq * u / r1)
+    rows += [N + 1, N + 2]; cols += [ix[0], ix[N]]; vals += [1.0, 1.0]
+    C = sp.coo_matrix((vals, (rows, cols)), shape=(N + 3, n)).tocsc()
+    J = sp.vstack([C, -C], format="csc")
+    J.sort_indices()
+    m = J.shape[0]
+    # Lagrangian Hessian: objective sum w x sqrt(1 + u^2), minus lam * length constraint (lam seeded)
+    lam = 0.3 + 0.1 * rng.random()
+    duu = wq * (x - lam) / r1 ** 3
+    dxu = wq * u / r1
+    H = sp.coo_matrix((np.concatenate([duu, dxu]), (np.concatenate([iu, iu]), np.concatenate([iu, ix]))), shape=(n, n)).tocsc()
+    H.sort_indices()
+    s = np.exp(rng.uniform(np.log(1e-3), np.log(1e1), size=m))
+    mu = 1e-2
+    y = mu * np.exp(rng.uniform(np.log(1e-1), np.log(1e1), size=m)) / s
+    return dict(H=H, J=J, s=s, y=y, mu=mu, n=n, m=m)
+
+
+def infeasible_lp(rows=600, cols=900, per_col=5, frac_bounded=0.7, n_dependent=6, seed=0):
+    """S-C4, stand-in for the Netlib-infeasible LPs (BASELINE config 4; the lpi_*.mat files are not in the repo):
+    a random sparse LP  l_c <= A x <= u_c, bounds on a fraction of the variables, made infeasible by a contradictory
+    row pair (the last row repeats the first with an incompatible range -- for the KKT matrix: two parallel rows).
+    H = 0, and `n_dependent` free columns repeat other free columns, so J'SJ is singular: factor!(delta = 0) has the
+    wrong inertia and ipopt_strategy! must shift."""
+    rng = np.random.default_rng(seed + 4000)
+    A = sp.random(rows, cols, density=per_col / rows, random_state=np.random.RandomState(seed + 11), format="lil",
+                  data_rvs=lambda k: rng.normal(size=k))
+    A = A.tocsc()
+    empty = np.flatnonzero(np.diff(A.indptr) == 0)              # a real LP has no empty columns
+    A = A.tolil()
+    for c in empty:
+        A[int(rng.integers(rows)), c] = 1.0
+    bounded = rng.random(cols) < frac_bounded
+    free = np.flatnonzero(~bounded)
+    for q in range(min(n_dependent, len(free) // 2)):
+        A[:, free[2 * q + 1]] = A[:, free[2 * q]]                # linearly dependent free columns
+    A = A.tocsr()
+    A = sp.vstack([A, A[0]], format="csr")                        # the contradictory twin of row 0
+    lo_b = np.flatnonzero(bounded)
+    up_b = lo_b[rng.random(len(lo_b)) < 0.5]
+    I = sp.identity(cols, format="csr")
+    J = sp.vstack([A, -A, I[lo_b], -I[up_b]], format="csc")       # [cons >= l ; -cons <= u ; I_l ; -I_u]
+    J.sort_indices()
+    n, m = cols, J.shape[0]
+    s = np.exp(rng.uniform(np.log(1e-3), np.log(1e1), size=m))
+    mu = 1e-2
+    y = mu * np.exp(rng.uniform(np.log(1e-1), np.log(1e1), size=m)) / s
+    return dict(H=sp.csc_matrix((n, n)), J=J, s=s, y=y, mu=mu, n=n, m=m)
