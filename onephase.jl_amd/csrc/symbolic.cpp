@@ -3,6 +3,9 @@
 // See symbolic.h for the role of this step relative to the reference.
 #include "symbolic.h"
 
+#include <cstdlib>
+#include <cstdio>
+#include <chrono>
 #include <algorithm>
 #include <functional>
 #include <cstring>
@@ -50,6 +53,15 @@ std::string analyze_pattern(int64_t n64, const int64_t* colptr, const int64_t* r
   }
   S.pattern_hash = hash_pattern(n, colptr, rowval);
 
+  // OKKT_DEBUG_ANALYZE: seconds per phase on stderr
+  const bool dbg_time = getenv("OKKT_DEBUG_ANALYZE") != nullptr;
+  auto t_last = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (!dbg_time) return;
+    auto t = std::chrono::steady_clock::now();
+    fprintf(stderr, "okkt: analyze %-28s %.3f s\n", what, std::chrono::duration<double>(t - t_last).count());
+    t_last = t;
+  };
   // ---- strictly-lower pattern of the input, symmetrised, de-duplicated -> graph for ordering
   std::vector<int64_t> gp(n + 1, 0);
   std::vector<int> gi;
@@ -96,6 +108,7 @@ std::string analyze_pattern(int64_t n64, const int64_t* colptr, const int64_t* r
     }
   }
 
+  lap("graph");
   // ---- ordering
   std::vector<int> order;
   if (opts.ordering == 0) {
@@ -122,6 +135,7 @@ std::string analyze_pattern(int64_t n64, const int64_t* colptr, const int64_t* r
     for (int v : order) { if (v < 0 || v >= n || seen[v]) return "internal error: ordering is not a permutation"; seen[v] = 1; }
   }
 
+  lap("ordering");
   // ---- elimination tree + column counts in the pre-postorder numbering
   std::vector<int> ip0(n);
   for (int k = 0; k < n; ++k) ip0[order[k]] = k;
@@ -152,8 +166,7 @@ std::string analyze_pattern(int64_t n64, const int64_t* colptr, const int64_t* r
         for (int64_t p = rp[r]; p < rp[r + 1]; ++p) (*ci)[f2[ri[p]]++] = r;  // rows ascending per column
     }
   };
-  auto etree_and_counts = [&](const std::vector<int64_t>& rp, const std::vector<int>& ri,
-                              std::vector<int>& parent, std::vector<int>& count) {
+  auto etree_of = [&](const std::vector<int64_t>& rp, const std::vector<int>& ri, std::vector<int>& parent) {
     parent.assign(n, -1);
     std::vector<int> anc(n, -1);
     for (int i = 0; i < n; ++i)
@@ -166,20 +179,77 @@ std::string analyze_pattern(int64_t n64, const int64_t* colptr, const int64_t* r
           k = nxt;
         }
       }
-    count.assign(n, 1);
-    std::vector<int> mark(n, -1);
-    for (int i = 0; i < n; ++i) {
-      mark[i] = i;
-      for (int64_t p = rp[i]; p < rp[i + 1]; ++p)
-        for (int k = ri[p]; mark[k] != i; k = parent[k]) { ++count[k]; mark[k] = i; }
+  };
+  // Column counts of L from the skeleton of A (Gilbert, Ng & Peyton 1994, as in Davis' cs_counts): every entry
+  // A(i, j), i > j, is looked at once and decides with the first-descendant test whether j is a leaf of row i's
+  // subtree; overlaps are subtracted at least common ancestors (disjoint-set forest).  O(nnz(A) alpha(n)) instead
+  // of the O(nnz(L)) row-subtree walk (187 M steps at S-metric).  `post` must be a postorder of `parent`;
+  // cp/ci = the strictly-lower column lists.
+  auto column_counts = [&](const std::vector<int>& parent, const std::vector<int>& post, const std::vector<int64_t>& cp,
+                           const std::vector<int>& ci, std::vector<int>& count) {
+    std::vector<int> first(n, -1), maxfirst(n, -1), prevleaf(n, -1), ancestor(n);
+    std::vector<int64_t> delta(n, 0);
+    for (int k = 0; k < n; ++k) {
+      int j = post[k];
+      delta[j] = first[j] == -1 ? 1 : 0;                       // j is a leaf of the etree
+      for (; j != -1 && first[j] == -1; j = parent[j]) first[j] = k;
+    }
+    for (int i = 0; i < n; ++i) ancestor[i] = i;
+    for (int k = 0; k < n; ++k) {
+      const int j = post[k];
+      if (parent[j] != -1) --delta[parent[j]];                 // j is not a root
+      for (int64_t p = cp[j]; p < cp[j + 1]; ++p) {
+        const int i = ci[p];
+        if (i <= j || first[j] <= maxfirst[i]) continue;       // j is not a leaf of the row subtree of i
+        maxfirst[i] = first[j];
+        const int jprev = prevleaf[i];
+        prevleaf[i] = j;
+        ++delta[j];                                            // A(i, j) is in the skeleton
+        if (jprev != -1) {                                     // a later leaf: subtract the overlap at the lca
+          int q = jprev;
+          while (q != ancestor[q]) q = ancestor[q];
+          for (int t = jprev; t != q;) { const int nxt = ancestor[t]; ancestor[t] = q; t = nxt; }
+          --delta[q];
+        }
+      }
+      if (parent[j] != -1) ancestor[j] = parent[j];
+    }
+    for (int k = 0; k < n; ++k) {                              // sum up the subtrees, children before parents
+      const int j = post[k];
+      if (parent[j] != -1) delta[parent[j]] += delta[j];
+    }
+    count.resize(n);
+    for (int j = 0; j < n; ++j) count[j] = (int)delta[j];
+  };
+  auto plain_postorder = [&](const std::vector<int>& parent, std::vector<int>& post) {
+    std::vector<int> head(n, -1), nxt(n, -1), stack;
+    for (int j = n - 1; j >= 0; --j)
+      if (parent[j] >= 0) { nxt[j] = head[parent[j]]; head[parent[j]] = j; }
+    post.clear();
+    post.reserve(n);
+    for (int r = 0; r < n; ++r) {
+      if (parent[r] >= 0) continue;
+      stack.push_back(r);
+      while (!stack.empty()) {
+        const int v = stack.back();
+        const int c = head[v];
+        if (c >= 0) { head[v] = nxt[c]; stack.push_back(c); }
+        else { post.push_back(v); stack.pop_back(); }
+      }
     }
   };
   std::vector<int64_t> rp, cp;
   std::vector<int> ri, ci;
   std::vector<int> parent0, count0;
-  build_lower(ip0, rp, ri, nullptr, nullptr);
-  etree_and_counts(rp, ri, parent0, count0);
+  build_lower(ip0, rp, ri, &cp, &ci);
+  etree_of(rp, ri, parent0);
+  {
+    std::vector<int> post1;
+    plain_postorder(parent0, post1);
+    column_counts(parent0, post1, cp, ci, count0);
+  }
 
+  lap("etree + colcounts");
   // ---- postorder, heaviest child last (it is the amalgamation candidate of its parent)
   std::vector<int> post;
   post.reserve(n);
@@ -212,11 +282,17 @@ std::string analyze_pattern(int64_t n64, const int64_t* colptr, const int64_t* r
   S.iperm.resize(n);
   for (int k = 0; k < n; ++k) { S.perm[k] = order[post[k]]; S.iperm[S.perm[k]] = k; }
   build_lower(S.iperm, rp, ri, &cp, &ci);
-  etree_and_counts(rp, ri, S.parent, S.colcount);
+  etree_of(rp, ri, S.parent);
+  {
+    std::vector<int> ident(n);                                 // the new numbering is a postorder of its own tree
+    std::iota(ident.begin(), ident.end(), 0);
+    column_counts(S.parent, ident, cp, ci, S.colcount);
+  }
   const std::vector<int>& parent = S.parent;
   const std::vector<int>& cc = S.colcount;
   for (int j = 0; j < n; ++j) { S.nnzL += cc[j]; S.flops_exact += (double)cc[j] * cc[j]; }
 
+  lap("postorder");
   // ---- fundamental supernodes, then relaxed amalgamation of (last child -> parent) chains
   std::vector<int> col0;  // first column of each supernode
   col0.reserve(n + 1);
@@ -280,6 +356,7 @@ std::string analyze_pattern(int64_t n64, const int64_t* colptr, const int64_t* r
     for (int s = 0; s < ns; ++s) if (S.sn_parent[s] >= 0) S.children[fill[S.sn_parent[s]]++] = s;
   }
 
+  lap("supernodes");
   // ---- row structure of every front (sorted union of A's columns and the children's rows)
   S.row_ptr.assign(ns + 1, 0);
   S.rows.clear();
@@ -311,6 +388,7 @@ std::string analyze_pattern(int64_t n64, const int64_t* colptr, const int64_t* r
     }
   }
 
+  lap("row structure");
   // ---- front layout, relative indices, solve workspaces, statistics
   S.front_pos.assign(ns + 1, 0);
   S.rel_ptr.assign(ns + 1, 0);
@@ -346,6 +424,7 @@ std::string analyze_pattern(int64_t n64, const int64_t* colptr, const int64_t* r
     }
   }
 
+  lap("layout");
   // ---- scatter maps from the caller's nzval into the front arena
   S.amap.assign(nnz_in, -1);
   S.diag_pos.assign(n, -1);
@@ -403,6 +482,7 @@ std::string analyze_pattern(int64_t n64, const int64_t* colptr, const int64_t* r
     }
   }
 
+  lap("scatter maps");
   // ---- level schedule (height above the leaves)
   S.sn_level.assign(ns, 0);
   for (int s = 0; s < ns; ++s) {
