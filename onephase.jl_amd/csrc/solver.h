@@ -19,13 +19,14 @@ struct okkt_solver_s {
   bool device_ready = false;  // HIP device selected and stream created
   bool numeric_ready = false; // device plan uploaded for the current pattern
   int device = 0;
-  hipStream_t stream = nullptr;        // main stream (CU-masked when look-ahead is on)
+  hipStream_t stream = nullptr;        // the handle's stream (all CUs)
   hipStream_t stream_masked = nullptr; // look-ahead main stream: CU mask without the reserved CUs (segments that use the look-ahead run here)
   int stream_la = 0, stream_reserved = 0;   // key of the pooled stream set (api.cpp)
   hipStream_t stream_panel = nullptr;  // look-ahead panel stream (high priority, all CUs)
   hipStream_t stream_aux = nullptr;    // second panel stream: the part of the in-group updates that k_big_diag does not wait for
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::vector<int64_t> user_perm;
+  std::vector<int64_t> pat_colptr, pat_rowval;   // the analysed pattern as the caller passed it (exact re-use test in okkt_analyze)
   std::string err;
   double analyze_seconds = 0, last_factor_ms = 0, last_solve_ms = 0;
   int64_t n_analyze_calls = 0;
