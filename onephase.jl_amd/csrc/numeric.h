@@ -28,7 +28,8 @@ struct DevPlan {
   int64_t* aent_src = nullptr;
   int* aent_dst = nullptr;
   int* perm = nullptr;
-  int* sched = nullptr;  // supernode ids grouped by (level, class)
+  int* sched = nullptr;  // supernode ids grouped by (level, class); for the small classes: the ROOT of a task
+  int* task_lo = nullptr;  // [supernode] first supernode of the task rooted there (small fronts): the workgroup runs task_lo[s] .. s in order
   // numeric state
   double* arena = nullptr;    // all fronts, f x f column-major each
   const double* vals = nullptr;  // caller's nzval in HBM
@@ -84,6 +85,8 @@ struct Numeric {
   int group_one_rows = 4000;                  // single block columns once fewer rows than this are left
   int small_max = 128;
   int64_t n_small = 0, n_big = 0;
+  int64_t n_tasks = 0;     // workgroup tasks of small fronts (subtrees run by one workgroup)
+  int max_task_len = 0;
   hipStream_t stream = nullptr;
   // look-ahead: panels of the next super-step are factored on stream_panel while the trailing update runs
   hipStream_t stream_masked = nullptr;  // CU-masked twin of `stream`: levels that use the look-ahead fork onto it and join back

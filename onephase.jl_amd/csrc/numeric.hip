@@ -97,7 +97,11 @@ __global__ __launch_bounds__(TPB) void k_front_small(DevPlan P, const int* __res
   extern __shared__ __attribute__((aligned(16))) double sm[];
   constexpr int G = TPB / 32;
   const int tid = threadIdx.x, lane = tid & 31, grp = tid >> 5;
-  const int s = list[blockIdx.x];
+  const int s_root = list[blockIdx.x];
+  unsigned pos = 0, neg = 0, zer = 0, bad = 0;
+  // the task: the fronts task_lo[root] .. root in postorder, children's contribution blocks pass through HBM (the
+  // barrier at the end of an iteration makes the workgroup's stores visible to its own later loads)
+  for (int s = P.task_lo[s_root]; s <= s_root; ++s) {
   const int col0 = P.sn_col0[s];
   const int k = P.sn_col0[s + 1] - col0;
   const int f = (int)(P.row_ptr[s + 1] - P.row_ptr[s]);
@@ -149,11 +153,13 @@ __global__ __launch_bounds__(TPB) void k_front_small(DevPlan P, const int* __res
     double* dst = front + (size_t)c * f;
     for (int i = c + lane; i < f; i += 32) dst[i] = F[i + c * ldf];
   }
-  unsigned pos = 0, neg = 0, zer = 0, bad = 0;
   for (int j = tid; j < k; j += TPB) {
     const double d = F[j + j * ldf];
     P.dvals[col0 + j] = d;
     classify_pivot(d, tol, pos, neg, zer, bad);
+  }
+  __threadfence_block();
+  __syncthreads();
   }
   flush_counts(P.counters, pos, neg, zer, bad);
 }
@@ -995,7 +1001,8 @@ template <int TPB>
 __global__ __launch_bounds__(TPB) void k_solve_fwd(DevPlan P, const int* __restrict__ list) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int tid = threadIdx.x;
-  const int s = list[blockIdx.x];
+  const int s_root = list[blockIdx.x];
+  for (int s = P.task_lo[s_root]; s <= s_root; ++s) {      // the task's fronts, children first
   const int col0 = P.sn_col0[s];
   const int k = P.sn_col0[s + 1] - col0;
   const int f = (int)(P.row_ptr[s + 1] - P.row_ptr[s]);
@@ -1027,6 +1034,9 @@ __global__ __launch_bounds__(TPB) void k_solve_fwd(DevPlan P, const int* __restr
   }
   // z = D^-1 y
   for (int j = tid; j < k; j += TPB) P.xwork[col0 + j] = w[j] / P.dvals[col0 + j];
+  __threadfence_block();
+  __syncthreads();
+  }
 }
 
 template <int TPB>
@@ -1034,7 +1044,8 @@ __global__ __launch_bounds__(TPB) void k_solve_bwd(DevPlan P, const int* __restr
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   constexpr int NW = TPB / 64;
-  const int s = list[blockIdx.x];
+  const int s_root = list[blockIdx.x];
+  for (int s = s_root; s >= P.task_lo[s_root]; --s) {      // the task's fronts, parents first
   const int col0 = P.sn_col0[s];
   const int k = P.sn_col0[s + 1] - col0;
   const int f = (int)(P.row_ptr[s + 1] - P.row_ptr[s]);
@@ -1059,6 +1070,9 @@ __global__ __launch_bounds__(TPB) void k_solve_bwd(DevPlan P, const int* __restr
     __syncthreads();
   }
   for (int j = tid; j < k; j += TPB) P.xwork[col0 + j] = xo[j];
+  __threadfence_block();
+  __syncthreads();
+  }
 }
 
 // ---- big fronts: multi-workgroup blocked solves with the inverse diagonal blocks ----------------
@@ -1333,36 +1347,98 @@ std::string numeric_setup(const Symbolic& S, const SymbolicOptions& opts, hipStr
   int64_t wtotal = 0;
   N.n_small = N.n_big = 0;
   const bool parted = S.nparts > 1 && (int)S.sn_owner.size() == ns;
+  // Tasks: a workgroup runs a whole subtree of small fronts, children before parents (the supernodes are numbered
+  // in postorder, so a subtree is the index range [first descendant, root]); one launch per LEVEL OF TASKS instead of
+  // one per level of fronts.  A banded KKT (the hanging chain of BASELINE config 2) has an elimination tree that is
+  // one long path: 6668 levels of one 16-row front each = 6668 dependent launches (99 ms) without tasks, one launch
+  // with them.  A subtree becomes one task when it is all small fronts and either little work (cost <= task_abs front
+  // units) or without parallelism to lose (total cost <= task_ratio x its critical path); otherwise its root is a
+  // task of its own and the rule is applied to the children.  Big fronts are units of their own.
+  const bool use_tasks = !parted && !(getenv("OKKT_TASKS") && atoi(getenv("OKKT_TASKS")) == 0);
+  const double task_abs = getenv("OKKT_TASK_ABS") ? atof(getenv("OKKT_TASK_ABS")) : 48.0;
+  const double task_ratio = getenv("OKKT_TASK_RATIO") ? atof(getenv("OKKT_TASK_RATIO")) : 1.5;
+  std::vector<int> task_lo(ns), unit_root(ns), ulevel(ns, 0);
+  {
+    auto fof = [&](int s2) { return (int)(S.row_ptr[s2 + 1] - S.row_ptr[s2]); };
+    std::vector<char> allsmall(ns), assigned(ns, 0);
+    std::vector<int> first(ns);
+    std::vector<double> ctot(ns), cpath(ns), cmaxchild(ns, 0.0);
+    for (int s2 = 0; s2 < ns; ++s2) {
+      const int f = fof(s2), k = S.sn_col0[s2 + 1] - S.sn_col0[s2];
+      allsmall[s2] = f <= N.small_max;
+      first[s2] = s2;
+      ctot[s2] = 1.0 + (double)f * f * k / 8192.0;
+      cpath[s2] = ctot[s2];
+    }
+    for (int s2 = 0; s2 < ns; ++s2) {           // children before parents
+      cpath[s2] += cmaxchild[s2];
+      const int p2 = S.sn_parent[s2];
+      if (p2 < 0) continue;
+      if (!allsmall[s2]) allsmall[p2] = 0;
+      first[p2] = std::min(first[p2], first[s2]);
+      ctot[p2] += ctot[s2];
+      cmaxchild[p2] = std::max(cmaxchild[p2], cpath[s2]);
+    }
+    for (int s2 = ns - 1; s2 >= 0; --s2) {      // parents before children: the largest admissible subtrees win
+      if (assigned[s2]) continue;
+      task_lo[s2] = s2;
+      unit_root[s2] = s2;
+      assigned[s2] = 1;
+      if (!use_tasks || !allsmall[s2] || !(ctot[s2] <= task_abs || ctot[s2] <= task_ratio * cpath[s2])) continue;
+      task_lo[s2] = first[s2];
+      for (int t = first[s2]; t < s2; ++t) { assigned[t] = 1; unit_root[t] = s2; task_lo[t] = t; }
+    }
+    for (int s2 = 0; s2 < ns; ++s2) {           // level of a unit = height in the tree of units
+      const int p2 = S.sn_parent[s2];
+      if (p2 < 0 || unit_root[p2] == unit_root[s2]) continue;
+      ulevel[unit_root[p2]] = std::max(ulevel[unit_root[p2]], ulevel[unit_root[s2]] + 1);
+    }
+  }
+  int nulev = 0;
+  for (int s2 = 0; s2 < ns; ++s2) if (unit_root[s2] == s2) nulev = std::max(nulev, ulevel[s2] + 1);
+  std::vector<std::vector<int>> units_at(nulev);
+  for (int s2 = 0; s2 < ns; ++s2) if (unit_root[s2] == s2) units_at[ulevel[s2]].push_back(s2);
+  N.n_tasks = 0;
+  N.max_task_len = 0;
   auto build = [&](std::vector<LevelSchedule>& levels, int want_owner) {
-    levels.assign(S.nlevels, LevelSchedule());
-    for (int l = 0; l < S.nlevels; ++l) {
+    levels.assign(nulev, LevelSchedule());
+    for (int l = 0; l < nulev; ++l) {
       std::vector<int> cls[kNumClasses];
-      for (int q = S.level_ptr[l]; q < S.level_ptr[l + 1]; ++q) {
-        int s = S.level_sn[q];
+      for (int s : units_at[l]) {
         if (parted && S.sn_owner[s] != want_owner) continue;
         if (!parted && want_owner == -1) continue;
-        int f = (int)(S.row_ptr[s + 1] - S.row_ptr[s]);
+        int f = 0;                                            // largest front of the unit decides the class
+        for (int t = task_lo[s]; t <= s; ++t) f = std::max(f, (int)(S.row_ptr[t + 1] - S.row_ptr[t]));
         int c = f <= 32 ? 0 : (f <= 64 ? 1 : (f <= N.small_max ? 2 : 3));
         cls[c].push_back(s);
       }
       for (int c = 0; c < kNumClasses; ++c) {
         auto& v = cls[c];
+        // longest tasks first (they finish last), then larger fronts first
         std::stable_sort(v.begin(), v.end(), [&](int a, int b) {
+          const int la = a - task_lo[a], lb = b - task_lo[b];
+          if (la != lb) return la > lb;
           return (S.row_ptr[a + 1] - S.row_ptr[a]) > (S.row_ptr[b + 1] - S.row_ptr[b]);
         });
         Segment& g = levels[l].seg[c];
         g.off = (int)sched.size();
         g.cnt = (int)v.size();
         for (int s : v) {
-          int f = (int)(S.row_ptr[s + 1] - S.row_ptr[s]);
-          int k = S.sn_col0[s + 1] - S.sn_col0[s];
-          g.maxf = std::max(g.maxf, f);
-          g.minf = std::min(g.minf, f);
-          g.maxk = std::max(g.maxk, k);
-          g.mink = std::min(g.mink, k);
+          for (int t = task_lo[s]; t <= s; ++t) {
+            const int ft = (int)(S.row_ptr[t + 1] - S.row_ptr[t]);
+            const int kt = S.sn_col0[t + 1] - S.sn_col0[t];
+            g.maxf = std::max(g.maxf, ft);
+            g.minf = std::min(g.minf, ft);
+            g.maxk = std::max(g.maxk, kt);
+            g.mink = std::min(g.mink, kt);
+            if (c != 3) ++N.n_small;
+          }
+          const int f = (int)(S.row_ptr[s + 1] - S.row_ptr[s]);
+          const int k = S.sn_col0[s + 1] - S.sn_col0[s];
           sched.push_back(s);
+          if (c != 3) { ++N.n_tasks; N.max_task_len = std::max(N.max_task_len, s - task_lo[s] + 1); }
           if (c == 3 && getenv("OKKT_DEBUG_FRONTS")) fprintf(stderr, "okkt: big front level %d  f %d  k %d\n", (int)l, f, k);
-          if (c == 3) { wpos[s] = wtotal; wtotal += (int64_t)f * N.nb * (f >= N.group_big_minf ? std::max(N.group, N.group_big) : N.group) * 2; ++N.n_big;   /* two super-steps of W: look-ahead double buffer */ } else ++N.n_small;
+          if (c == 3) { wpos[s] = wtotal; wtotal += (int64_t)f * N.nb * (f >= N.group_big_minf ? std::max(N.group, N.group_big) : N.group) * 2; ++N.n_big;   /* two super-steps of W: look-ahead double buffer */ }
         }
       }
     }
@@ -1370,6 +1446,8 @@ std::string numeric_setup(const Symbolic& S, const SymbolicOptions& opts, hipStr
   build(N.levels, parted ? N.part_id : 0);
   if (parted && N.part_id == 0) build(N.levels_top, -1); else N.levels_top.clear();
   if (!(e = upload(N, sched, &d.sched)).empty()) return e;
+  if (!(e = upload(N, task_lo, &d.task_lo)).empty()) return e;
+  if (getenv("OKKT_DEBUG_FRONTS")) fprintf(stderr, "okkt: %d levels of units (%d levels of fronts), %lld tasks of small fronts, longest %d\n", nulev, S.nlevels, (long long)N.n_tasks, N.max_task_len);
   if (!(e = upload(N, wpos, &d.wbuf_pos)).empty()) return e;
   N.sched_host = sched;
   {

@@ -41,4 +41,18 @@ for rep in range(2):
         assert np.array_equal(d, d_prev)
     d_prev = d
 finalize_b(h)
+# a banded system (elimination tree = one long path of small fronts) and a tree of small fronts only
+for prob in (synth.hanging_chain(N_h=300, seed=2), synth.make_config("S-small", seed=1, h_per_col=2, j_per_row=3)):
+    K = synth.augmented_matrix(prob, delta=0.5)
+    Ms = synth.symmetrize_lower(K)
+    h = linear_solver_HIP("symmetric")
+    initialize_b(h)
+    h.ls_factor_b(K, prob["n"], prob["m"])
+    w = np.linalg.eigvalsh(Ms.toarray())
+    assert h.inertia == (int((w > 0).sum()), int((w < 0).sum()), 0, 0)
+    b = rng.normal(size=K.shape[0])
+    x = h.ls_solve(b)
+    xd = np.linalg.solve(Ms.toarray(), b)
+    assert np.max(np.abs(x - xd)) <= 1e-8 * max(1.0, np.max(np.abs(xd)))
+    finalize_b(h)
 print("VARIANT_OK")

@@ -23,6 +23,8 @@ VARIANTS = [
     {"OKKT_SOLVE_SB_LAZY": "0", "OKKT_SB_TAIL_ROWS": "-1"},
     {"OKKT_ASM_CHUNKED": "0"},
     {"OKKT_ASM_LCOL": "0"},
+    {"OKKT_TASKS": "0"},                                          # one launch per level of small fronts
+    {"OKKT_TASK_ABS": "1e9"},                                     # every all-small subtree is one workgroup's task
 ]
 
 
