@@ -45,7 +45,8 @@ def test_sharded_matches_single(nparts):
 
 
 def test_block_angular_subtrees_are_balanced():
-    prob = synth.block_angular(nblocks=8, n_b=120, m_b=180, n_link=10, seed=0, j_per_row=4, h_per_col=3, w=6.0, p_far=0.0)
+    # blocks large against the amalgamation width (supernodes up to 128 columns): 1000 columns each
+    prob = synth.block_angular(nblocks=8, n_b=400, m_b=600, n_link=10, seed=0, j_per_row=4, h_per_col=3, w=6.0, p_far=0.0)
     K = synth.augmented_matrix(prob, delta=1e-8)
     sh = ShardedLinearSolver(LocalComm(8), "symmetric")
     info = sh.analyze(K)
