@@ -203,7 +203,12 @@ int okkt_kkt_form_system(okkt_kkt_handle k, const double* H_nzval, const double*
                          const double* s, const double* y);
 /* diag_min(kkt_solver) (kkt_system_solver.jl:291-294) */
 int okkt_kkt_diag_min(okkt_kkt_handle k, double* out);
-/* factor!(kkt_solver, delta): shift the first n diagonal entries by delta, refactor; 1 / 0 / <0 */
+/* factor!(kkt_solver, delta): shift the first n diagonal entries by delta, refactor; 1 / 0 / <0.
+ * A factorisation whose inertia is already decided to be wrong before the top of the elimination tree (a
+ * non-finite or zero pivot, more negative pivots than m, more positive than n) stops there and returns 0: the
+ * reference only uses the flag of a failed factor! (delta_strategy.jl:37-114) and never solves with it.  Then
+ * inertia_out holds the counts of the columns eliminated so far and a direction cannot be computed until the
+ * next successful okkt_kkt_factor.  OKKT_EARLY_EXIT=0 (environment) always runs to the end. */
 int okkt_kkt_factor(okkt_kkt_handle k, double delta, okkt_inertia* inertia_out);
 /* ipopt_strategy!: returns 1 on :success, 0 on :failure (delta > delta_max), <0 on error */
 int okkt_kkt_ipopt_strategy(okkt_kkt_handle k, double delta_prev, const okkt_kkt_pars* pars,

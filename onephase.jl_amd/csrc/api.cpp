@@ -53,6 +53,9 @@ int solver_factor_device(okkt_solver_s* h, const double* d_vals, int64_t n, int6
   if (sym_kind == OKKT_SYM_DEFINITE && m != 0) return solver_set_error(h, OKKT_ERR_INVALID, ":definite requires m == 0 (julia.jl:30)");
   const double tol = sym_kind == OKKT_SYM_DEFINITE ? 0.0 : h->opts.inertia_tol;
   h->factored = false;
+  h->N.early_check = h->early_exit;
+  h->N.early_n = n;
+  h->N.early_m = m;
   (void)hipEventRecord(h->ev0, h->stream);
   std::string e = numeric_factor_enqueue(h->N, d_vals, tol);
   if (!e.empty()) return solver_set_error(h, OKKT_ERR_HIP, e);
@@ -66,6 +69,7 @@ int solver_factor_device(okkt_solver_s* h, const double* d_vals, int64_t n, int6
   okkt_inertia in;
   in.pos = (int64_t)cnt[0]; in.neg = (int64_t)cnt[1]; in.zero = (int64_t)cnt[2]; in.nonfinite = (int64_t)cnt[3];
   if (out) *out = in;
+  if (h->N.early_exited) return 0;   // wrong inertia decided before the top of the tree: counts are partial, no factor to solve with
   h->factored = true;
   if (in.pos + in.neg + in.zero + in.nonfinite != h->S.n)
     return solver_set_error(h, OKKT_ERR_INTERNAL, "pivot counts do not add up to the matrix order");

@@ -12,6 +12,7 @@
 //
 // All sums are owner-computes (one thread per output entry, fixed order): results are bitwise
 // reproducible from run to run; there are no floating-point atomics.
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -597,6 +598,10 @@ int okkt_kkt_factor(okkt_kkt_handle k, double delta, okkt_inertia* inertia_out) 
   if (!k->formed) return kk_fail(k, OKKT_ERR_INVALID, "kkt solver not ready to factor: form_system has not been called");
   int rc = solver_ensure_numeric(k->ls);
   if (rc != OKKT_OK) return kk_check_ls(k, rc, "device plan");
+  // factor!'s only result is the inertia flag, and a factorisation with the wrong inertia is never solved with
+  // (delta_strategy.jl:37-114 refactors or gives up): it may stop as soon as the flag is decided
+  static const bool early = !(getenv("OKKT_EARLY_EXIT") && atoi(getenv("OKKT_EARLY_EXIT")) == 0);
+  k->ls->early_exit = early;
   k->delta = delta;
   // the first n diagonal entries move, the (2,2) block never does (symmetric.jl:85-102)
   launch_set_shift(k->ls->N, delta, k->n);

@@ -85,6 +85,10 @@ struct Numeric {
   int group_one_rows = 4000;                  // single block columns once fewer rows than this are left
   int small_max = 128;
   int64_t n_small = 0, n_big = 0;
+  // early exit of a factorisation whose inertia is already wrong (delta loop): checked once, before level early_level
+  int early_level = -1;                  // first level of the part of the tree that holds >= 30 % of the flops (-1: none)
+  bool early_check = false, early_exited = false;
+  int64_t early_n = 0, early_m = 0;      // the inertia the caller wants
   int64_t n_tasks = 0;     // workgroup tasks of small fronts (subtrees run by one workgroup)
   int max_task_len = 0;
   hipStream_t stream = nullptr;

@@ -1398,6 +1398,24 @@ std::string numeric_setup(const Symbolic& S, const SymbolicOptions& opts, hipStr
   for (int s2 = 0; s2 < ns; ++s2) if (unit_root[s2] == s2) nulev = std::max(nulev, ulevel[s2] + 1);
   std::vector<std::vector<int>> units_at(nulev);
   for (int s2 = 0; s2 < ns; ++s2) if (unit_root[s2] == s2) units_at[ulevel[s2]].push_back(s2);
+  {
+    // the latest level boundary that still has >= 30 % of the factorisation's flops above it (the root of S-metric: 81 %)
+    std::vector<double> lev_flops(nulev, 0.0);
+    double tot = 0.0;
+    for (int s2 = 0; s2 < ns; ++s2) {
+      const double f = (double)(S.row_ptr[s2 + 1] - S.row_ptr[s2]), k = (double)(S.sn_col0[s2 + 1] - S.sn_col0[s2]);
+      const double fl = k * f * f - k * k * f + k * k * k / 3.0;
+      lev_flops[ulevel[unit_root[s2]]] += fl;
+      tot += fl;
+    }
+    N.early_level = -1;
+    double above = 0.0;
+    for (int l = nulev - 1; l >= 1; --l) {
+      above += lev_flops[l];
+      if (above >= 0.3 * tot) { N.early_level = l; break; }
+    }
+    if (parted) N.early_level = -1;
+  }
   N.n_tasks = 0;
   N.max_task_len = 0;
   auto build = [&](std::vector<LevelSchedule>& levels, int want_owner) {
@@ -1701,6 +1719,7 @@ std::string numeric_factor_enqueue(Numeric& N, const double* d_vals, double tol,
   N.la_used = 0;
   N.sb_ready = false;            // the super-block inverses belong to the previous factorisation
   N.sb_wait = false;
+  N.early_exited = false;
   N.solves_since_factor = 0;
   const int NB = N.nb;
   static const int dbg_syrk = getenv("OKKT_DEBUG_SYRK") ? atoi(getenv("OKKT_DEBUG_SYRK")) : 0;
@@ -1708,6 +1727,17 @@ std::string numeric_factor_enqueue(Numeric& N, const double* d_vals, double tol,
   static const int dbg_stop = getenv("OKKT_DEBUG_DIAG_STOP") ? atoi(getenv("OKKT_DEBUG_DIAG_STOP")) : 0;
   for (size_t l = 0; l < levels.size(); ++l) {
     const LevelSchedule& L = levels[l];
+    if (N.early_check && which == 0 && (int)l == N.early_level && N.levels_top.empty()) {
+      // the pivots counted so far already decide a wrong inertia?  Then the (expensive) rest of the tree is skipped:
+      // one synchronisation per factorisation, 35 of 49 ms saved per failed attempt of the delta loop at S-metric
+      unsigned long long cnt[4] = {0, 0, 0, 0};
+      OKKT_HIP_TRY(hipMemcpyAsync(cnt, P.counters, sizeof(cnt), hipMemcpyDeviceToHost, st));
+      OKKT_HIP_TRY(hipStreamSynchronize(st));
+      if (cnt[3] > 0 || cnt[2] > 0 || cnt[1] > (unsigned long long)N.early_m || cnt[0] > (unsigned long long)N.early_n) {
+        N.early_exited = true;
+        return "";
+      }
+    }
     if (L.seg[0].cnt) {
       const Segment& g = L.seg[0];
       hipLaunchKernelGGL(k_front_small<64>, dim3(g.cnt), dim3(64), lds_small(g.maxf), st, P, P.sched + g.off, tol);
