@@ -293,3 +293,34 @@ def test_estimate_y_tilde_through_the_handle():
         y_hip = KS.estimate_y_tilde(prob["J"], g)
         y_ref = KO.estimate_y_tilde(prob["J"], g)
         assert np.max(np.abs(y_hip - y_ref)) <= 1e-9 * max(1.0, np.max(np.abs(y_ref)))
+
+
+def test_failed_factorisation_stops_early_and_cannot_be_solved_with():
+    # factor! of a strongly nonconvex system: the pivot counts of the lower levels already exceed m negative pivots,
+    # the top of the tree is skipped (partial counts), the flag is 0 as the oracle's, and a direction is refused
+    # until a factorisation succeeds; the delta loop's trace is the oracle's
+    prob = synth.make_config("S-small", seed=2, convex=False, neg_shift=50.0, well_scaled=True)
+    it, oit = synth_iterate(prob, KS.Class_iterate, 2), synth_iterate(prob, KO.Iterate, 2)
+    n, m = prob["n"], prob["m"]
+    k = KS.HIP_KKT_solver("symmetric")
+    k.initialize_b(it)
+    k.form_system_b(it)
+    assert k.factor_b(0.0) == 0
+    pos, neg, zero, bad = k.inertia
+    assert neg > m and pos + neg + zero + bad < n + m          # stopped before the last level
+    k.kkt_associate_rhs_b(it, KS.Reduct_affine())
+    with pytest.raises(OkktError):
+        k.compute_direction_b()
+    ko = KO.pick_KKT_solver("symmetric", perm=k.linear_solver_perm())
+    ko.initialize_b(oit)
+    ko.form_system_b(oit)
+    assert ko.factor_b(0.0) == 0
+    status, num_fac, delta = k.ipopt_strategy_b(it)
+    ostatus, onum_fac, odelta, _ = KO.ipopt_strategy_b(oit, ko)
+    # tau = 1.5 * min(schur_diag) < 0 enters delta: schur_diag is a sum (order differs from scipy's), so delta agrees to rounding
+    assert (status, num_fac) == (ostatus, onum_fac) and status == "success"
+    assert abs(delta - odelta) <= 1e-13 * abs(odelta)
+    k.kkt_associate_rhs_b(it, KS.Reduct_affine())
+    k.compute_direction_b()
+    assert k.kkt_err_norm.ratio < 1e-8
+    k.finalize_b()
