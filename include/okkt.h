@@ -78,7 +78,7 @@ typedef struct {
   double inertia_tol;         /* |d| <= tol counts as a zero pivot (julia.jl:73); default 1e-20 */
   int32_t small_front_max;    /* fronts of order <= this use the LDS-resident kernel; <=0 default */
   int32_t panel_nb;           /* block-column width in the big-front kernels; <=0 default */
-  int32_t use_graph;          /* 1: replay the numeric factorisation as a hipGraph (default 1) */
+  int32_t early_exit;         /* 1: a factorisation may stop once its inertia is decided wrong (see okkt_set_early_exit); default 0 */
   int32_t reserved;
 } okkt_opts;
 
@@ -141,6 +141,12 @@ int okkt_dev_alloc(okkt_handle h, int64_t bytes, void** d_ptr_out);
 int okkt_dev_free(okkt_handle h, void* d_ptr);
 int okkt_dev_upload(okkt_handle h, void* d_dst, const void* src, int64_t bytes);
 int okkt_dev_download(okkt_handle h, void* dst, const void* d_src, int64_t bytes);
+/* ls_factor! only returns the inertia flag and the reference never solves with a factorisation that failed it
+ * (it updates delta and refactors, delta_strategy.jl:37-114).  With early exit enabled okkt_factor / okkt_factor_dev
+ * stop before the top of the elimination tree when the pivots counted so far already decide a wrong inertia; they
+ * return 0, `out` holds the counts of the columns eliminated so far, and okkt_solve is refused until the next
+ * complete factorisation.  Off by default at this level (complete counts); the Julia glue turns it on. */
+int okkt_set_early_exit(okkt_handle h, int enable);
 /* the handle's HIP stream (hipStream_t as void*), for callers that time with their own events */
 void* okkt_get_stream(okkt_handle h);
 /* per-launch timing of the dominant kernel (the FP64-MFMA trailing update k_big_syrk): HIP events are

@@ -42,7 +42,7 @@ class OkktOpts(C.Structure):
         ("inertia_tol", C.c_double),
         ("small_front_max", C.c_int32),
         ("panel_nb", C.c_int32),
-        ("use_graph", C.c_int32),
+        ("early_exit", C.c_int32),
         ("reserved", C.c_int32),
     ]
 
@@ -111,6 +111,7 @@ _vp = C.c_void_p
 SIGNATURES = {
     "okkt_default_opts": (C.c_int, [C.POINTER(OkktOpts)]),
     "okkt_create": (C.c_int, [C.POINTER(_vp), C.POINTER(OkktOpts)]),
+    "okkt_set_early_exit": (C.c_int, [_vp, C.c_int]),
     "okkt_destroy": (C.c_int, [_vp]),
     "okkt_last_error": (C.c_char_p, [_vp]),
     "okkt_version": (C.c_char_p, []),

@@ -120,7 +120,7 @@ int okkt_default_opts(okkt_opts* o) {
   o->inertia_tol = 1e-20;
   o->small_front_max = 128;
   o->panel_nb = 128;
-  o->use_graph = 1;
+  o->early_exit = 0;
   return OKKT_OK;
 }
 
@@ -202,6 +202,7 @@ int okkt_create(okkt_handle* out, const okkt_opts* opts) {
   h->sopts.relax_any_frac = o.relax_any_frac;
   h->sopts.small_front_max = o.small_front_max;
   h->sopts.panel_nb = o.panel_nb;
+  h->early_exit = o.early_exit != 0;
   if (!o.host_symbolic_only) {
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) { delete h; return OKKT_ERR_NO_DEVICE; }
@@ -275,6 +276,12 @@ int okkt_destroy(okkt_handle h) {
     }
   }
   delete h;
+  return OKKT_OK;
+}
+
+int okkt_set_early_exit(okkt_handle h, int enable) {
+  if (!h) return OKKT_ERR_INVALID;
+  h->early_exit = enable != 0;
   return OKKT_OK;
 }
 

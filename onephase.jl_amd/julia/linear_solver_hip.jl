@@ -47,6 +47,8 @@ function initialize!(solver::linear_solver_HIP)
         rc = ccall((:okkt_create, OKKT_LIB), Cint, (Ref{Ptr{Cvoid}}, Ptr{Cvoid}), h, C_NULL)   # NULL = default options
         rc == 0 || error("okkt_create failed with code $rc (no HIP device? the KKT path has no CPU fallback)")
         solver.handle = h[]
+        # ls_factor! returns only the flag: a factorisation with the wrong inertia may stop early (never solved with)
+        ccall((:okkt_set_early_exit, OKKT_LIB), Cint, (Ptr{Cvoid}, Cint), solver.handle, 1)
         finalizer(finalize!, solver)
     end
 end

@@ -321,3 +321,23 @@ def test_super_block_solves_follow_the_factorisation():
         # the same right-hand side through the prepared inverses twice: identical bits (deterministic kernels)
         assert np.array_equal(xs[2], xs[3])
     finalize_b(h)
+
+
+def test_early_exit_of_a_failed_factorisation_is_opt_in():
+    # okkt_set_early_exit / opts.early_exit: ls_factor! only returns the flag, so a factorisation that has already counted
+    # more than m negative pivots may skip the top of the tree; by default the counts are complete
+    prob = synth.make_config("S-small", seed=2, convex=False, neg_shift=50.0, well_scaled=True)
+    n, m = prob["n"], prob["m"]
+    K0, K1 = synth.augmented_matrix(prob, delta=0.0), synth.augmented_matrix(prob, delta=80.0)
+    b = np.random.default_rng(0).normal(size=n + m)
+    full = hip_solver("symmetric")
+    assert full.ls_factor_b(K0, n, m) == 0 and sum(full.inertia) == n + m
+    early = hip_solver("symmetric", early_exit=1)
+    assert early.ls_factor_b(K0, n, m) == 0
+    assert early.inertia[1] > m and sum(early.inertia) < n + m
+    with pytest.raises(OkktError):
+        early.ls_solve(b)
+    assert early.ls_factor_b(K1, n, m) == 1 and early.inertia == (n, m, 0, 0)
+    assert full.ls_factor_b(K1, n, m) == 1
+    assert np.array_equal(early.ls_solve(b), full.ls_solve(b))
+    finalize_b(full); finalize_b(early)
