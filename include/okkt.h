@@ -116,7 +116,7 @@ const char* okkt_version(void);
 /* user permutation for opts.ordering == 2: perm[new] = old, 0-based; call before okkt_analyze */
 int okkt_set_perm(okkt_handle h, const int64_t* perm, int64_t n);
 /* pattern of a square CSC matrix (only row >= col is used; upper entries are ignored, as under
- * Symmetric(A,:L), julia.jl:34,52).  Cached by pattern hash: re-calling with the same pattern
+ * Symmetric(A,:L), julia.jl:34,52).  Cached by pattern (exact comparison with the analysed colptr/rowval): re-calling with the same pattern
  * is free, so the reference-shaped ls_factor!(A,...) can call it every time. */
 int okkt_analyze(okkt_handle h, int64_t dim, const int64_t* colptr, const int64_t* rowval, int index_base);
 int okkt_get_perm(okkt_handle h, int64_t* perm_out /* [dim], perm[new]=old, 0-based */);
