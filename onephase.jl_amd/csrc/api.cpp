@@ -54,13 +54,14 @@ int solver_factor_device(okkt_solver_s* h, const double* d_vals, int64_t n, int6
   const double tol = sym_kind == OKKT_SYM_DEFINITE ? 0.0 : h->opts.inertia_tol;
   h->factored = false;
   h->N.early_check = h->early_exit;
+  h->N.early_device = h->early_exit && h->last_failed;   // the previous factorisation failed the inertia: this one is a retry
   h->N.early_n = n;
   h->N.early_m = m;
   (void)hipEventRecord(h->ev0, h->stream);
   std::string e = numeric_factor_enqueue(h->N, d_vals, tol);
   if (!e.empty()) return solver_set_error(h, OKKT_ERR_HIP, e);
   (void)hipEventRecord(h->ev1, h->stream);
-  unsigned long long cnt[4];
+  unsigned long long cnt[5];
   hipError_t he = hipMemcpyAsync(cnt, h->N.d.counters, sizeof(cnt), hipMemcpyDeviceToHost, h->stream);
   if (he == hipSuccess) he = hipStreamSynchronize(h->stream);
   if (he != hipSuccess) return solver_set_error(h, OKKT_ERR_HIP, std::string("numeric factorisation failed: ") + hipGetErrorString(he));
@@ -69,13 +70,16 @@ int solver_factor_device(okkt_solver_s* h, const double* d_vals, int64_t n, int6
   okkt_inertia in;
   in.pos = (int64_t)cnt[0]; in.neg = (int64_t)cnt[1]; in.zero = (int64_t)cnt[2]; in.nonfinite = (int64_t)cnt[3];
   if (out) *out = in;
-  if (h->N.early_exited) return 0;   // wrong inertia decided before the top of the tree: counts are partial, no factor to solve with
+  h->last_failed = true;
+  if (h->N.early_exited || cnt[4] != 0) return 0;   // wrong inertia decided before the end: counts are partial, no factor to solve with
   h->factored = true;
   if (in.pos + in.neg + in.zero + in.nonfinite != h->S.n)
     return solver_set_error(h, OKKT_ERR_INTERNAL, "pivot counts do not add up to the matrix order");
   if (in.nonfinite > 0) return 0;                       // julia.jl:77-89
-  if (sym_kind == OKKT_SYM_DEFINITE) return in.pos == n ? 1 : 0;  // PosDefException <=> some pivot <= 0
-  return (in.pos == n && in.neg == m) ? 1 : 0;          // linear_system_solvers.jl:73-74
+  const int flag = sym_kind == OKKT_SYM_DEFINITE ? (in.pos == n ? 1 : 0)   // PosDefException <=> some pivot <= 0
+                                                 : ((in.pos == n && in.neg == m) ? 1 : 0);   // linear_system_solvers.jl:73-74
+  h->last_failed = flag == 0;
+  return flag;
 }
 
 int solver_solve_device(okkt_solver_s* h, const double* d_rhs, double* d_sol, int64_t nrhs) {

@@ -62,7 +62,8 @@ struct DevPlan {
   int* bnd = nullptr;          // boundary fronts (subtree roots under a top node)
   int64_t* bnd_cb = nullptr;   // their offsets in the contribution-block exchange buffer
   int64_t* bnd_cv = nullptr;   // ... and in the contribution-vector exchange buffer
-  unsigned long long* counters = nullptr;  // pos, neg, zero, nonfinite
+  unsigned long long* counters = nullptr;  // pos, neg, zero, nonfinite, [4] = stop flag (the inertia is already decided wrong)
+  long long want_pos = -1, want_neg = -1;  // >= 0: the kernels raise / obey the stop flag (retries of the delta loop), -1: off
   double* zero_page = nullptr;  // 2 KiB of zeros (source of out-of-panel LDS-DMA rows)
 };
 
@@ -88,6 +89,7 @@ struct Numeric {
   // early exit of a factorisation whose inertia is already wrong (delta loop): checked once, before level early_level
   int early_level = -1;                  // first level of the part of the tree that holds >= 30 % of the flops (-1: none)
   bool early_check = false, early_exited = false;
+  bool early_device = false;             // this factorisation is a retry: kernels stop on the device flag as well
   int64_t early_n = 0, early_m = 0;      // the inertia the caller wants
   int64_t n_tasks = 0;     // workgroup tasks of small fronts (subtrees run by one workgroup)
   int max_task_len = 0;

@@ -56,15 +56,33 @@ __device__ __forceinline__ unsigned wave_sum(unsigned v) {
   return v;
 }
 
-__device__ __forceinline__ void flush_counts(unsigned long long* counters, unsigned pos, unsigned neg,
-                                             unsigned zer, unsigned bad) {
+// With want_neg >= 0 (a retry of the delta loop) the running totals decide: more positive pivots than n, more negative
+// than m, a zero or a non-finite pivot can never give the inertia (n, m, 0) -> raise the stop flag counters[4]; every
+// factorisation kernel launched or started afterwards returns at once (stop_requested_*), the host reads the flag
+// with the counts.  A kernel argument decides whether any of this runs: the first attempt pays nothing.
+__device__ __forceinline__ void flush_counts(const DevPlan& P, unsigned pos, unsigned neg, unsigned zer, unsigned bad) {
+  unsigned long long* counters = P.counters;
   pos = wave_sum(pos); neg = wave_sum(neg); zer = wave_sum(zer); bad = wave_sum(bad);
   if ((threadIdx.x & 63) == 0) {
-    if (pos) atomicAdd(&counters[0], (unsigned long long)pos);
-    if (neg) atomicAdd(&counters[1], (unsigned long long)neg);
-    if (zer) atomicAdd(&counters[2], (unsigned long long)zer);
-    if (bad) atomicAdd(&counters[3], (unsigned long long)bad);
+    bool fail = false;
+    if (pos) { const unsigned long long o = atomicAdd(&counters[0], (unsigned long long)pos); fail |= P.want_pos >= 0 && o + pos > (unsigned long long)P.want_pos; }
+    if (neg) { const unsigned long long o = atomicAdd(&counters[1], (unsigned long long)neg); fail |= P.want_neg >= 0 && o + neg > (unsigned long long)P.want_neg; }
+    if (zer) { atomicAdd(&counters[2], (unsigned long long)zer); fail |= P.want_neg >= 0; }
+    if (bad) { atomicAdd(&counters[3], (unsigned long long)bad); fail |= P.want_neg >= 0; }
+    if (fail) atomicExch(&counters[4], 1ull);
   }
+}
+// workgroup-uniform (one load, one barrier) / wave-uniform forms of "has the stop flag been raised?"
+__device__ __forceinline__ bool stop_requested_wg(const DevPlan& P) {
+  if (P.want_neg < 0) return false;
+  __shared__ int s_stop;
+  if (threadIdx.x == 0) s_stop = (int)__hip_atomic_load(&P.counters[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  return s_stop != 0;
+}
+__device__ __forceinline__ bool stop_requested_wave(const DevPlan& P) {
+  if (P.want_neg < 0) return false;
+  return __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&P.counters[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0;
 }
 
 // Right-looking LDL^T of the leading npiv columns of an LDS-resident lower-triangular front.
@@ -99,6 +117,7 @@ __global__ __launch_bounds__(TPB) void k_front_small(DevPlan P, const int* __res
   const int tid = threadIdx.x, lane = tid & 31, grp = tid >> 5;
   const int s_root = list[blockIdx.x];
   unsigned pos = 0, neg = 0, zer = 0, bad = 0;
+  if (stop_requested_wg(P)) return;
   // the task: the fronts task_lo[root] .. root in postorder, children's contribution blocks pass through HBM (the
   // barrier at the end of an iteration makes the workgroup's stores visible to its own later loads)
   for (int s = P.task_lo[s_root]; s <= s_root; ++s) {
@@ -161,7 +180,7 @@ __global__ __launch_bounds__(TPB) void k_front_small(DevPlan P, const int* __res
   __threadfence_block();
   __syncthreads();
   }
-  flush_counts(P.counters, pos, neg, zer, bad);
+  flush_counts(P, pos, neg, zer, bad);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -289,6 +308,7 @@ __global__ __launch_bounds__(256) void k_big_assemble(DevPlan P, const int* __re
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int s = list[blockIdx.y];
+  if (stop_requested_wave(P)) return;
   const int col0 = P.sn_col0[s];
   const int k = P.sn_col0[s + 1] - col0;
   const int f = (int)(P.row_ptr[s + 1] - P.row_ptr[s]);
@@ -322,6 +342,7 @@ __global__ __launch_bounds__(256) void k_big_assemble_chunked(DevPlan P, const i
   __shared__ double sm[4 * kAsmChunk];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int s = list[blockIdx.y];
+  if (stop_requested_wave(P)) return;
   const int col0 = P.sn_col0[s];
   const int k = P.sn_col0[s + 1] - col0;
   const int f = (int)(P.row_ptr[s + 1] - P.row_ptr[s]);
@@ -436,6 +457,7 @@ __global__ __launch_bounds__(256) void k_big_diag(DevPlan P, const int* __restri
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, l4 = lane >> 4;
   const int s = list[blockIdx.x];
+  if (stop_requested_wg(P)) return;
   const int col0 = P.sn_col0[s];
   const int k = P.sn_col0[s + 1] - col0;
   const int f = (int)(P.row_ptr[s + 1] - P.row_ptr[s]);
@@ -574,7 +596,7 @@ __global__ __launch_bounds__(256) void k_big_diag(DevPlan P, const int* __restri
       P.dvals[col0 + j0 + tid] = my_d;
       classify_pivot(my_d, tol, pos, neg, zer, bad);
     }
-    if (dbg_stop != 9) flush_counts(P.counters, pos, neg, zer, bad);
+    if (dbg_stop != 9) flush_counts(P, pos, neg, zer, bad);
     else if (tid == 0) {   // debug: phase times (wall-clock ticks x 1000) instead of pivot counts
       atomicAdd(&P.counters[0], (unsigned long long)tL * 1000ull); atomicAdd(&P.counters[1], (unsigned long long)tA * 1000ull);
       atomicAdd(&P.counters[2], (unsigned long long)tB * 1000ull); atomicAdd(&P.counters[3], (unsigned long long)tC * 1000ull);
@@ -627,6 +649,7 @@ __global__ __launch_bounds__(256) void k_big_invert(DevPlan P, const int* __rest
   const int l15 = lane & 15, l4 = lane >> 4;
   const int s = list[blockIdx.y];
   const int step = blockIdx.x;
+  if (stop_requested_wg(P)) return;
   const int col0 = P.sn_col0[s];
   const int k = P.sn_col0[s + 1] - col0;
   const int f = (int)(P.row_ptr[s + 1] - P.row_ptr[s]);
@@ -719,6 +742,7 @@ __global__ __launch_bounds__(256) void k_big_trsm(DevPlan P, const int* __restri
   extern __shared__ __attribute__((aligned(16))) double sm[];   // NPAIR blocks of 32 x 32, then NB reciprocals
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int s = list[blockIdx.y];
+  if (stop_requested_wg(P)) return;
   const int col0 = P.sn_col0[s];
   const int k = P.sn_col0[s + 1] - col0;
   const int f = (int)(P.row_ptr[s + 1] - P.row_ptr[s]);
@@ -848,6 +872,7 @@ __global__ __launch_bounds__(kSyrkNW * 64, kSyrkNW / 2) void k_big_syrk(DevPlan 
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int s = list[blockIdx.y];
+  if (stop_requested_wg(P)) return;
   const int col0 = P.sn_col0[s];
   const int k = P.sn_col0[s + 1] - col0;
   const int f = (int)(P.row_ptr[s + 1] - P.row_ptr[s]);
@@ -1614,11 +1639,11 @@ std::string numeric_setup(const Symbolic& S, const SymbolicOptions& opts, hipStr
   if (!(e = dalloc(N, (size_t)S.n, &d.xwork, true)).empty()) return e;
   if (!(e = dalloc(N, (size_t)S.sum_r, &d.cv, true)).empty()) return e;
   if (!(e = dalloc(N, (size_t)wtotal + 512, &d.wbuf, true)).empty()) return e;
-  if (!(e = dalloc(N, (size_t)4, &d.counters, true)).empty()) return e;
+  if (!(e = dalloc(N, (size_t)8, &d.counters, true)).empty()) return e;
   if (!(e = dalloc(N, (size_t)256, &d.zero_page, true)).empty()) return e;
   if (!(e = dalloc(N, (size_t)S.nnz_in, &N.vals_owned, false)).empty()) return e;
   // kernels that may want more than 64 KiB of dynamic LDS
-  const int big_lds = 160 * 1024;
+  const int big_lds = 160 * 1024 - 64;   // the stop-flag check keeps one static LDS word per kernel
   OKKT_HIP_TRY(hipFuncSetAttribute((const void*)k_front_small<256>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds));
   OKKT_HIP_TRY(hipFuncSetAttribute((const void*)k_big_diag, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds));
   OKKT_HIP_TRY(hipFuncSetAttribute((const void*)k_big_invert, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds));
@@ -1715,7 +1740,8 @@ std::string numeric_factor_enqueue(Numeric& N, const double* d_vals, double tol,
   P.vals = d_vals;
   hipStream_t st = N.stream;
   const std::vector<LevelSchedule>& levels = which == 0 ? N.levels : N.levels_top;
-  if (reset_counters) OKKT_HIP_TRY(hipMemsetAsync(P.counters, 0, 4 * sizeof(unsigned long long), st));
+  if (reset_counters) OKKT_HIP_TRY(hipMemsetAsync(P.counters, 0, 8 * sizeof(unsigned long long), st));
+  if (N.early_check && N.early_device && which == 0 && N.levels_top.empty() && reset_counters) { P.want_pos = N.early_n; P.want_neg = N.early_m; }
   N.la_used = 0;
   N.sb_ready = false;            // the super-block inverses belong to the previous factorisation
   N.sb_wait = false;

@@ -18,6 +18,7 @@ struct okkt_solver_s {
   bool factored = false;
   bool device_ready = false;  // HIP device selected and stream created
   bool numeric_ready = false; // device plan uploaded for the current pattern
+  bool last_failed = false;   // the last factorisation did not give the wanted inertia (the next one is a retry of the delta loop)
   bool early_exit = false;    // stop a factorisation whose inertia is already wrong (set by the KKT level for factor! / the delta loop)
   int device = 0;
   hipStream_t stream = nullptr;        // the handle's stream (all CUs)
