@@ -483,6 +483,15 @@ std::string analyze_pattern(int64_t n64, const int64_t* colptr, const int64_t* r
   }
 
   lap("scatter maps");
+  if (dbg_time) {
+    long hist[7] = {0, 0, 0, 0, 0, 0, 0};
+    for (int sn = 0; sn < (int)S.sn_col0.size() - 1; ++sn) {
+      const int64_t f = S.row_ptr[sn + 1] - S.row_ptr[sn];
+      ++hist[f <= 8 ? 0 : f <= 16 ? 1 : f <= 24 ? 2 : f <= 32 ? 3 : f <= 64 ? 4 : f <= 128 ? 5 : 6];
+    }
+    fprintf(stderr, "okkt: analyze fronts by order: <=8 %ld  <=16 %ld  <=24 %ld  <=32 %ld  <=64 %ld  <=128 %ld  larger %ld\n", hist[0], hist[1],
+            hist[2], hist[3], hist[4], hist[5], hist[6]);
+  }
   // ---- level schedule (height above the leaves)
   S.sn_level.assign(ns, 0);
   for (int s = 0; s < ns; ++s) {
