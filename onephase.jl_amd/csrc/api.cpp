@@ -62,9 +62,8 @@ int solver_factor_device(okkt_solver_s* h, const double* d_vals, int64_t n, int6
   if (!e.empty()) return solver_set_error(h, OKKT_ERR_HIP, e);
   (void)hipEventRecord(h->ev1, h->stream);
   unsigned long long cnt[5];
-  hipError_t he = hipMemcpyAsync(cnt, h->N.d.counters, sizeof(cnt), hipMemcpyDeviceToHost, h->stream);
-  if (he == hipSuccess) he = hipStreamSynchronize(h->stream);
-  if (he != hipSuccess) return solver_set_error(h, OKKT_ERR_HIP, std::string("numeric factorisation failed: ") + hipGetErrorString(he));
+  e = numeric_read_counts(h->N, h->stream, cnt);
+  if (!e.empty()) return solver_set_error(h, OKKT_ERR_HIP, std::string("numeric factorisation failed: ") + e);
   float ms = 0;
   if (hipEventElapsedTime(&ms, h->ev0, h->ev1) == hipSuccess) h->last_factor_ms = ms;
   okkt_inertia in;

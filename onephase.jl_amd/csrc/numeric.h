@@ -62,10 +62,17 @@ struct DevPlan {
   int* bnd = nullptr;          // boundary fronts (subtree roots under a top node)
   int64_t* bnd_cb = nullptr;   // their offsets in the contribution-block exchange buffer
   int64_t* bnd_cv = nullptr;   // ... and in the contribution-vector exchange buffer
-  unsigned long long* counters = nullptr;  // pos, neg, zero, nonfinite, [4] = stop flag (the inertia is already decided wrong)
+  // pos, neg, zero, nonfinite per SLOT (kCountSlots slots of kCountStride words, one cache line each): the small-front
+  // kernels spread their atomic adds over slots 1.. (60 000 one-wave workgroups adding to the same four words cost
+  // 0.6 of 0.74 ms at S-metric), the big-front kernels use slot 0; slot 0 word [4] = stop flag.  Readers sum the slots.
+  unsigned long long* counters = nullptr;
   long long want_pos = -1, want_neg = -1;  // >= 0: the kernels raise / obey the stop flag (retries of the delta loop), -1: off
   double* zero_page = nullptr;  // 2 KiB of zeros (source of out-of-panel LDS-DMA rows)
 };
+
+constexpr int kCountSlots = 64, kCountStride = 16;
+// sums the slots: out[0..3] = pos, neg, zero, nonfinite, out[4] = stop flag (synchronises `stream`)
+std::string numeric_read_counts(struct Numeric& N, hipStream_t stream, unsigned long long out[5]);
 
 // front classes by order f: 0: f<=32 (one wave), 1: f<=64, 2: f<=small_max (256 threads, LDS), 3: big
 constexpr int kNumClasses = 4;

@@ -60,8 +60,9 @@ __device__ __forceinline__ unsigned wave_sum(unsigned v) {
 // than m, a zero or a non-finite pivot can never give the inertia (n, m, 0) -> raise the stop flag counters[4]; every
 // factorisation kernel launched or started afterwards returns at once (stop_requested_*), the host reads the flag
 // with the counts.  A kernel argument decides whether any of this runs: the first attempt pays nothing.
-__device__ __forceinline__ void flush_counts(const DevPlan& P, unsigned pos, unsigned neg, unsigned zer, unsigned bad) {
-  unsigned long long* counters = P.counters;
+__device__ __forceinline__ void flush_counts(const DevPlan& P, int slot, unsigned pos, unsigned neg, unsigned zer, unsigned bad) {
+  // the limits are tested on the slot's own running totals: a part of the true totals, so exceeding them is still proof
+  unsigned long long* counters = P.counters + (size_t)slot * kCountStride;
   pos = wave_sum(pos); neg = wave_sum(neg); zer = wave_sum(zer); bad = wave_sum(bad);
   if ((threadIdx.x & 63) == 0) {
     bool fail = false;
@@ -69,8 +70,23 @@ __device__ __forceinline__ void flush_counts(const DevPlan& P, unsigned pos, uns
     if (neg) { const unsigned long long o = atomicAdd(&counters[1], (unsigned long long)neg); fail |= P.want_neg >= 0 && o + neg > (unsigned long long)P.want_neg; }
     if (zer) { atomicAdd(&counters[2], (unsigned long long)zer); fail |= P.want_neg >= 0; }
     if (bad) { atomicAdd(&counters[3], (unsigned long long)bad); fail |= P.want_neg >= 0; }
-    if (fail) atomicExch(&counters[4], 1ull);
+    if (fail) atomicExch(&P.counters[4], 1ull);
   }
+}
+// Retries only, once per level behind the small-front launches: the small fronts' slots are folded into slot 0, so the
+// running totals that k_big_diag tests there are the true totals again, and the limits are tested on them.
+__global__ void k_fold_counts(DevPlan P) {
+  const int c = threadIdx.x;
+  if (c >= 4) return;
+  unsigned long long sum = 0;
+  for (int q = 1; q < kCountSlots; ++q) {
+    unsigned long long* w = P.counters + (size_t)q * kCountStride + c;
+    sum += *w;
+    *w = 0;
+  }
+  const unsigned long long tot = atomicAdd(&P.counters[c], sum) + sum;
+  const bool fail = c == 0 ? tot > (unsigned long long)P.want_pos : c == 1 ? tot > (unsigned long long)P.want_neg : tot > 0;
+  if (fail) atomicExch(&P.counters[4], 1ull);
 }
 // workgroup-uniform (one load, one barrier) / wave-uniform forms of "has the stop flag been raised?"
 __device__ __forceinline__ bool stop_requested_wg(const DevPlan& P) {
@@ -180,7 +196,7 @@ __global__ __launch_bounds__(TPB) void k_front_small(DevPlan P, const int* __res
   __threadfence_block();
   __syncthreads();
   }
-  flush_counts(P, pos, neg, zer, bad);
+  flush_counts(P, 1 + (int)(blockIdx.x % (kCountSlots - 1)), pos, neg, zer, bad);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -596,7 +612,7 @@ __global__ __launch_bounds__(256) void k_big_diag(DevPlan P, const int* __restri
       P.dvals[col0 + j0 + tid] = my_d;
       classify_pivot(my_d, tol, pos, neg, zer, bad);
     }
-    if (dbg_stop != 9) flush_counts(P, pos, neg, zer, bad);
+    if (dbg_stop != 9) flush_counts(P, 0, pos, neg, zer, bad);
     else if (tid == 0) {   // debug: phase times (wall-clock ticks x 1000) instead of pivot counts
       atomicAdd(&P.counters[0], (unsigned long long)tL * 1000ull); atomicAdd(&P.counters[1], (unsigned long long)tA * 1000ull);
       atomicAdd(&P.counters[2], (unsigned long long)tB * 1000ull); atomicAdd(&P.counters[3], (unsigned long long)tC * 1000ull);
@@ -1639,7 +1655,7 @@ std::string numeric_setup(const Symbolic& S, const SymbolicOptions& opts, hipStr
   if (!(e = dalloc(N, (size_t)S.n, &d.xwork, true)).empty()) return e;
   if (!(e = dalloc(N, (size_t)S.sum_r, &d.cv, true)).empty()) return e;
   if (!(e = dalloc(N, (size_t)wtotal + 512, &d.wbuf, true)).empty()) return e;
-  if (!(e = dalloc(N, (size_t)8, &d.counters, true)).empty()) return e;
+  if (!(e = dalloc(N, (size_t)kCountSlots * kCountStride, &d.counters, true)).empty()) return e;
   if (!(e = dalloc(N, (size_t)256, &d.zero_page, true)).empty()) return e;
   if (!(e = dalloc(N, (size_t)S.nnz_in, &N.vals_owned, false)).empty()) return e;
   // kernels that may want more than 64 KiB of dynamic LDS
@@ -1735,12 +1751,24 @@ static std::string numeric_sb_prepare(Numeric& N, hipStream_t st) {
   return "";
 }
 
+std::string numeric_read_counts(Numeric& N, hipStream_t stream, unsigned long long out[5]) {
+  unsigned long long raw[kCountSlots * kCountStride];
+  OKKT_HIP_TRY(hipMemcpyAsync(raw, N.d.counters, sizeof(raw), hipMemcpyDeviceToHost, stream));
+  OKKT_HIP_TRY(hipStreamSynchronize(stream));
+  for (int c = 0; c < 4; ++c) {
+    out[c] = 0;
+    for (int q = 0; q < kCountSlots; ++q) out[c] += raw[q * kCountStride + c];
+  }
+  out[4] = raw[4];
+  return "";
+}
+
 std::string numeric_factor_enqueue(Numeric& N, const double* d_vals, double tol, int which, bool reset_counters) {
   DevPlan P = N.d;
   P.vals = d_vals;
   hipStream_t st = N.stream;
   const std::vector<LevelSchedule>& levels = which == 0 ? N.levels : N.levels_top;
-  if (reset_counters) OKKT_HIP_TRY(hipMemsetAsync(P.counters, 0, 8 * sizeof(unsigned long long), st));
+  if (reset_counters) OKKT_HIP_TRY(hipMemsetAsync(P.counters, 0, (size_t)kCountSlots * kCountStride * sizeof(unsigned long long), st));
   if (N.early_check && N.early_device && which == 0 && N.levels_top.empty() && reset_counters) { P.want_pos = N.early_n; P.want_neg = N.early_m; }
   N.la_used = 0;
   N.sb_ready = false;            // the super-block inverses belong to the previous factorisation
@@ -1756,10 +1784,10 @@ std::string numeric_factor_enqueue(Numeric& N, const double* d_vals, double tol,
     if (N.early_check && which == 0 && (int)l == N.early_level && N.levels_top.empty()) {
       // the pivots counted so far already decide a wrong inertia?  Then the (expensive) rest of the tree is skipped:
       // one synchronisation per factorisation, 35 of 49 ms saved per failed attempt of the delta loop at S-metric
-      unsigned long long cnt[4] = {0, 0, 0, 0};
-      OKKT_HIP_TRY(hipMemcpyAsync(cnt, P.counters, sizeof(cnt), hipMemcpyDeviceToHost, st));
-      OKKT_HIP_TRY(hipStreamSynchronize(st));
-      if (cnt[3] > 0 || cnt[2] > 0 || cnt[1] > (unsigned long long)N.early_m || cnt[0] > (unsigned long long)N.early_n) {
+      unsigned long long cnt[5] = {0, 0, 0, 0, 0};
+      std::string ec = numeric_read_counts(N, st, cnt);
+      if (!ec.empty()) return ec;
+      if (cnt[4] != 0 || cnt[3] > 0 || cnt[2] > 0 || cnt[1] > (unsigned long long)N.early_m || cnt[0] > (unsigned long long)N.early_n) {
         N.early_exited = true;
         return "";
       }
@@ -1773,6 +1801,7 @@ std::string numeric_factor_enqueue(Numeric& N, const double* d_vals, double tol,
         const Segment& g = L.seg[c];
         hipLaunchKernelGGL(k_front_small<256>, dim3(g.cnt), dim3(256), lds_small(g.maxf), st, P, P.sched + g.off, tol);
       }
+    if (P.want_neg >= 0 && (L.seg[0].cnt || L.seg[1].cnt || L.seg[2].cnt)) hipLaunchKernelGGL(k_fold_counts, dim3(1), dim3(64), 0, st, P);
     if (L.seg[3].cnt) {
       const Segment& g = L.seg[3];
       const int* list = P.sched + g.off;
