@@ -321,6 +321,11 @@ int kk_check_ls(okkt_kkt_s* k, int rc, const char* what) {
 }
 
 
+// the reduction into slot `slot` of k->red, no synchronisation (several of them are fetched with one copy)
+void kk_reduce_enqueue(okkt_kkt_s* k, int64_t n, const double* v, int mode, int slot) {
+  hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, kk_stream(k), n, v, mode, k->red + slot);
+}
+
 int kk_reduce(okkt_kkt_s* k, int64_t n, const double* v, int mode, double* host_out) {
   hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, kk_stream(k), n, v, mode, k->red);
   KK_TRY(k, hipMemcpyAsync(host_out, k->red, sizeof(double), hipMemcpyDeviceToHost, kk_stream(k)));
@@ -764,17 +769,25 @@ int okkt_kkt_compute_direction(okkt_kkt_handle k, const double* dual_r, const do
     spmv_H(k, k->dx, k->vn1);
     spmv_JT(k, k->Jx, k->dy, k->vn3);
     hipLaunchKernelGGL(k_errD, grid1(n), dim3(256), 0, st, n, k->delta, k->dx, k->vn1, k->vn3, k->rD, k->big1);
-    if ((rc = kk_reduce(k, n, k->big1, 1, &eD))) return rc;
-    if ((rc = kk_reduce(k, n, k->rD, 1, &nD))) return rc;
+    kk_reduce_enqueue(k, n, k->big1, 1, 0);
+    kk_reduce_enqueue(k, n, k->rD, 1, 1);
   }
   if (m) {
     spmv_J(k, k->dx, k->vm1);
     hipLaunchKernelGGL(k_errP, grid1(m), dim3(256), 0, st, m, k->vm1, k->ds, k->rP, k->vm2);
-    if ((rc = kk_reduce(k, m, k->vm2, 1, &eP))) return rc;
+    kk_reduce_enqueue(k, m, k->vm2, 1, 2);
     hipLaunchKernelGGL(k_errMu, grid1(m), dim3(256), 0, st, m, k->s, k->dy, k->y, k->ds, k->rC, k->vm2);
-    if ((rc = kk_reduce(k, m, k->vm2, 1, &eMu))) return rc;
-    if ((rc = kk_reduce(k, m, k->rP, 1, &nP))) return rc;
-    if ((rc = kk_reduce(k, m, k->rC, 1, &nC))) return rc;
+    kk_reduce_enqueue(k, m, k->vm2, 1, 3);
+    kk_reduce_enqueue(k, m, k->rP, 1, 4);
+    kk_reduce_enqueue(k, m, k->rC, 1, 5);
+  }
+  {
+    // the six norms with one copy and one synchronisation
+    double red[6] = {0, 0, 0, 0, 0, 0};
+    KK_TRY(k, hipMemcpyAsync(red, k->red, sizeof(red), hipMemcpyDeviceToHost, st));
+    KK_TRY(k, hipStreamSynchronize(st));
+    if (n) { eD = red[0]; nD = red[1]; }
+    if (m) { eP = red[2]; eMu = red[3]; nP = red[4]; nC = red[5]; }
   }
   auto mx = [](double a, double b) { return (a != a || b != b) ? NAN : std::max(a, b); };
   E.error_D = eD; E.error_P = eP; E.error_mu = eMu;
