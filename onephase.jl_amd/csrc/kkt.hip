@@ -551,6 +551,7 @@ int okkt_kkt_form_system(okkt_kkt_handle k, const double* H_nzval, const double*
   if (k->kind == OKKT_KKT_CLEVER_SYMMETRIC && !k->indexed) return kk_fail(k, OKKT_ERR_INVALID, "okkt_kkt_compute_indicies has not been called (initialize!, clever_symmetric.jl:53-61)");
   if ((k->nnzH > 0 && !H_nzval) || (k->nnzJ > 0 && !J_nzval)) return OKKT_ERR_INVALID;
   k->have_dir = false;
+  k->have_dxnorm = false;
   hipStream_t st = kk_stream(k);
   KK_TRY(k, hipSetDevice(k->ls->device));
   if (k->nnzH) KK_TRY(k, hipMemcpyAsync(k->Hx, H_nzval, (size_t)k->nnzH * 8, hipMemcpyHostToDevice, st));
@@ -803,6 +804,7 @@ int okkt_kkt_compute_direction(okkt_kkt_handle k, const double* dual_r, const do
   KK_TRY(k, hipStreamSynchronize(st));
   KK_TRY(k, hipGetLastError());
   k->have_dir = true;
+  k->have_dxnorm = false;
   return OKKT_OK;
 }
 

@@ -14,6 +14,8 @@ struct okkt_kkt_s {
   int kind = OKKT_KKT_SCHUR;
   int64_t n = 0, m = 0, nnzH = 0, nnzJ = 0, nnzA = 0, dimA = 0;
   bool structured = false, formed = false, factored = false;
+  bool have_dxnorm = false;   // dxnorm = norm(dir.x, Inf) of the resident direction is known (step-side functions)
+  double dxnorm = 0.0;
   bool have_dir = false;   // dx, dy, ds hold the direction of the last okkt_kkt_compute_direction for the current (s, y)
   double delta = 0.0;
   std::string err;

@@ -215,8 +215,11 @@ int map_reduce(okkt_kkt_s* k, int64_t n, const F& f, const Channels<NCH>& ch, do
 
 // norm(dir.x, Inf) and lb_s_thres's scalar  norm * norm^ex  (frac_boundary.jl:3-10); pow on the host (one libm for all)
 int dx_norm(okkt_kkt_s* k, double* nx) {
+  if (k->have_dxnorm) { *nx = k->dxnorm; return OKKT_OK; }     // once per direction
   Channels<1> ch{{kNanMax}, {0.0}};
-  return map_reduce<1>(k, k->n, MapAbs{k->dx}, ch, nx);
+  const int rc = map_reduce<1>(k, k->n, MapAbs{k->dx}, ch, nx);
+  if (rc == OKKT_OK) { k->dxnorm = *nx; k->have_dxnorm = true; }
+  return rc;
 }
 double thres_scalar(double nx, double ex) { return nx * std::pow(nx, ex); }
 double jl_min(double a, double b) { return (a != a || b != b) ? NAN : std::min(a, b); }
@@ -233,6 +236,7 @@ int okkt_kkt_set_direction(okkt_kkt_handle k, const double* dx, const double* dy
   if ((rc = stage(k, k->dx, dx, k->n)) != OKKT_OK || (rc = stage(k, k->dy, dy, k->m)) != OKKT_OK || (rc = stage(k, k->ds, ds, k->m)) != OKKT_OK) return rc;
   KK_TRY(k, hipStreamSynchronize(kk_stream(k)));
   k->have_dir = true;
+  k->have_dxnorm = false;
   return OKKT_OK;
 }
 
