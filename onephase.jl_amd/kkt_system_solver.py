@@ -292,6 +292,29 @@ class HIP_KKT_solver:
             if not np.all(np.isfinite(v)):
                 raise OkktError(f"NaN in {name}")
 
+    # ---- the refactorisation after a failed step (one_phase.jl:231-242): delta from the Lagrangian gradient and the direction
+    def refactor_after_step_failure_b(self, it, old_delta, response_to_failure="lag_delta_inc", timer=None):
+        """set_delta(iter, max(norm(eval_grad_lag(iter, mu), Inf) / norm(dir.x, Inf), delta * inc, max(start, old_delta * dec)));
+        inertia = factor!(kkt_solver, delta) -- returns (inertia, delta) and stores delta in it.delta.  The gradient norm is
+        taken from the device rhs kernel (dual_r of System_rhs with eta_D = 0, eta_mu = 1 is -grad L_mu)."""
+        d = self.pars.delta
+        floor = max(d.start, old_delta * d.dec)
+        if response_to_failure == "lag_delta_inc":
+            n, m = it.dim(), it.ncon()
+            Jx = None if it is self.factor_it else L.f64(_csc(it.J).data)
+            grad, cons, s, y = L.f64(it.grad), L.f64(it.cons), L.f64(it.s), L.f64(it.y)
+            rD, rP, rC = np.zeros(n), np.zeros(m), np.zeros(m)
+            self._check(self._lib.okkt_kkt_system_rhs(self._k, L.p_f64(Jx) if Jx is not None else None, L.p_f64(grad), L.p_f64(cons), L.p_f64(s),
+                                                      L.p_f64(y), it.mu, it.a_norm_penalty_par, 0.0, 0.0, 1.0, L.p_f64(rD), L.p_f64(rP), L.p_f64(rC)),
+                        "okkt_kkt_system_rhs")
+            delta = max(float(np.max(np.abs(rD))) / float(np.max(np.abs(self.dir.x))), it.delta * d.inc, floor)
+        elif response_to_failure == "default":
+            delta = max(it.delta * d.inc, floor)
+        else:
+            raise OkktError("pars.test.response_to_failure parameter incorrectly set")
+        it.delta = delta
+        return self.factor_b(delta), delta
+
     # ---- ipopt_strategy! (delta_strategy.jl:37-114): the whole loop runs behind the C ABI
     def ipopt_strategy_b(self, it, timer=None):
         p = L.OkktKktPars()

@@ -542,3 +542,15 @@ def pick_KKT_solver(kkt_solver_type, perm=None, pars=None):
     if kkt_solver_type == "clever_symmetric":
         return Clever_Symmetric_KKT_solver(linear_solver_ORACLE("symmetric", perm=perm), pars)
     raise ValueError("pick a solver!")
+
+
+def step_failure_delta(it, dir, old_delta, pars=None, response_to_failure="lag_delta_inc"):
+    """The delta of the refactorisation after a failed step (one_phase.jl:231-242); parameters.jl:209 selects
+    :lag_delta_inc.  it.delta is the delta of the failed step, old_delta the one of the previous outer iteration."""
+    pars = pars or KKTPars()
+    floor = max(pars.delta_start, old_delta * pars.delta_dec)
+    if response_to_failure == "lag_delta_inc":
+        return max(float(np.max(np.abs(eval_grad_lag(it, it.mu)))) / float(np.max(np.abs(dir.x))), it.delta * pars.delta_inc, floor)
+    if response_to_failure == "default":
+        return max(it.delta * pars.delta_inc, floor)
+    raise ValueError("pars.test.response_to_failure parameter incorrectly set")

@@ -324,3 +324,31 @@ def test_failed_factorisation_stops_early_and_cannot_be_solved_with():
     k.compute_direction_b()
     assert k.kkt_err_norm.ratio < 1e-8
     k.finalize_b()
+
+
+@pytest.mark.parametrize("kind", ["schur", "symmetric"])
+def test_refactor_after_step_failure(golden, kind):
+    # one_phase.jl:231-242: delta <- max(|grad L_mu|_inf / |dx|_inf, 8 delta, max(1e-6, old_delta / pi)); factor!
+    rec = golden["indef5"]
+    it, oit = iterate_from_record(rec, KS.Class_iterate), iterate_from_record(rec, KO.Iterate)
+    k = KS.HIP_KKT_solver(kind)
+    k.initialize_b(it)
+    k.form_system_b(it)
+    status, num_fac, delta = k.ipopt_strategy_b(it)
+    assert status == "success"
+    it.delta = oit.delta = delta
+    k.kkt_associate_rhs_b(it, KS.Reduct_affine())
+    k.compute_direction_b()
+    d = KO.Direction(k.dir.x, k.dir.y, k.dir.s)
+    for old_delta, response in ((0.0, "lag_delta_inc"), (5.0 * delta, "lag_delta_inc"), (0.0, "default")):
+        it.delta = oit.delta = delta
+        want = KO.step_failure_delta(oit, d, old_delta, response_to_failure=response)
+        inertia, got = k.refactor_after_step_failure_b(it, old_delta, response)
+        assert inertia == 1 and it.delta == got
+        assert abs(got - want) <= 1e-14 * want and got >= 8.0 * delta
+        k.kkt_associate_rhs_b(it, KS.Reduct_affine())
+        k.compute_direction_b()                      # the new factorisation is usable
+        assert k.kkt_err_norm.ratio < 1e-8
+    with pytest.raises(OkktError):
+        k.refactor_after_step_failure_b(it, 0.0, "nonsense")
+    k.finalize_b()

@@ -1,6 +1,7 @@
 """Pins the CPU oracle: against the reference's own unit-test matrices and acceptance rules, against
 dense LAPACK known answers (tests/golden), and against dense numpy on seeded random sparse systems.
 CPU only."""
+import math
 import numpy as np
 import pytest
 import scipy.sparse as sp
@@ -225,3 +226,20 @@ def test_clever_symmetric_toy_lps(golden, rescale):
             assert np.linalg.norm(getattr(kc.dir, a) - np.array(rec["d" + a])) < 1e-6, (rec["name"], a)
         assert kc.kkt_err_norm.ratio < 1e-8
     assert merged > 0      # the toy LPs do contain parallel rows (two-sided constraints / duplicated bounds)
+
+
+def test_step_failure_delta_by_hand(golden):
+    # one_phase.jl:231-242 on the README toy: grad L_mu = 1 - J'y + mu*pen*J'1 with J = [2x; 1], x = -0.1
+    from oracle import kkt_oracle as KO
+    it = iterate_from_record(golden["readme_toy"], KO.Iterate)
+    glag = 1.0 - (-0.2 * 2.0 + 0.1) + 1.0 * 1e-4 * (-0.2 + 1.0)
+    assert abs(KO.eval_grad_lag(it, it.mu)[0] - glag) < 1e-15
+    d = KO.Direction(np.array([0.25]), np.zeros(2), np.zeros(2))
+    it.delta = 0.01
+    assert KO.step_failure_delta(it, d, 0.0) == max(abs(glag) / 0.25, 0.08, 1e-6)            # the gradient term wins
+    it.delta = 10.0
+    assert KO.step_failure_delta(it, d, 0.0) == 80.0                                            # delta * inc wins
+    it.delta = 1e-9
+    d.x = np.array([1e9])
+    assert KO.step_failure_delta(it, d, 3.0) == 3.0 / math.pi                                   # old_delta * dec wins
+    assert KO.step_failure_delta(it, d, 0.0, response_to_failure="default") == 1e-6             # delta.start
