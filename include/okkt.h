@@ -60,6 +60,9 @@ typedef enum {
 #define OKKT_KKT_SYMMETRIC 1  /* K = [[H J'];[J -diag(s/y)]]  (n+m square), LDL^T inertia (n,m,0) */
 #define OKKT_KKT_CLEVER_SYMMETRIC 2  /* parallel rows of J merged first: M = [[H 0];[J_new -U_new]] (n+m_new square),
                                       * inertia (n, m_new, 0); Clever_Symmetric_KKT_solver, clever_symmetric.jl:25-519 */
+#define OKKT_KKT_SCHUR_DIRECT 3      /* Schur_KKT_solver_direct (schur_direct.jl:3-66, kkt_system_solver.jl:270-276): the Schur system of the
+                                      * FACTORISED iterate, but rhs terms, dy and ds = (comp_r - dy .* s) ./ y from the CURRENT iterate
+                                      * (the one of the last okkt_kkt_system_rhs) */
 /* kkt_system_rescale of the clever-symmetric system (parameters.jl:24-28, clever_symmetric.jl:307-325) */
 #define OKKT_RESCALE_NONE 0
 #define OKKT_RESCALE_U_ONLY 1
@@ -142,10 +145,12 @@ int okkt_dev_free(okkt_handle h, void* d_ptr);
 int okkt_dev_upload(okkt_handle h, void* d_dst, const void* src, int64_t bytes);
 int okkt_dev_download(okkt_handle h, void* dst, const void* d_src, int64_t bytes);
 /* ls_factor! only returns the inertia flag and the reference never solves with a factorisation that failed it
- * (it updates delta and refactors, delta_strategy.jl:37-114).  With early exit enabled okkt_factor / okkt_factor_dev
- * stop before the top of the elimination tree when the pivots counted so far already decide a wrong inertia; they
- * return 0, `out` holds the counts of the columns eliminated so far, and okkt_solve is refused until the next
- * complete factorisation.  Off by default at this level (complete counts); the Julia glue turns it on. */
+ * inside the delta loop (it updates delta and refactors, delta_strategy.jl:37-114).  With early exit enabled okkt_factor /
+ * okkt_factor_dev stop before the top of the elimination tree when the pivots counted so far already decide a wrong
+ * inertia; they return 0, `out` holds the counts of the columns eliminated so far, and okkt_solve is refused until the
+ * next complete factorisation.  Off by default: outside the delta loop the reference DOES solve with a factorisation whose
+ * flag was 0 (the refactorisation after a failed step, one_phase.jl:241), so only a caller that discards failed factors
+ * may turn it on (the KKT level does so inside okkt_kkt_ipopt_strategy / okkt_kkt_factor_trial only). */
 int okkt_set_early_exit(okkt_handle h, int enable);
 /* the handle's HIP stream (hipStream_t as void*), for callers that time with their own events */
 void* okkt_get_stream(okkt_handle h);
@@ -189,6 +194,24 @@ typedef struct {
   int32_t max_it;         /* delta_strategy.jl:40 (500) */
 } okkt_kkt_pars;
 
+/* device times (HIP events on the handle's stream) of the phases of the last calls, milliseconds; 0 = not run yet.
+ * what the reference's class_advanced_timer labels "SCHUR/form_system",
+ * "SCHUR/delta_vecs", "<ls>/factorize", "KKT/rhs", "<ls>/ls_solve", "SCHUR/iterative_refinement/residual",
+ * "SCHUR/kkt_err" measure on the host */
+typedef struct {
+  double assemble_ms;      /* okkt_kkt_form_system: kernels only (after the H, J, s, y uploads) */
+  double upload_ms;        /* ... the host -> device copies of that call */
+  double shift_ms;         /* okkt_kkt_factor: the delta shift (update_delta_vecs!) */
+  double factor_ms;        /* ... the numeric factorisation */
+  double rhs_ms;           /* okkt_kkt_system_rhs kernels */
+  double solve_ms;         /* okkt_kkt_compute_direction: all triangular solves together */
+  double refine_ms;        /* ... residual evaluations of the refinement rounds and the rhs / dy / ds vector work */
+  double kkt_err_ms;       /* ... update_kkt_error! */
+  double direction_ms;     /* ... the whole call on the device */
+  int32_t n_solves;        /* triangular solves of the last direction */
+  int32_t reserved;
+} okkt_kkt_timers;
+
 typedef struct {
   double error_D, error_P, error_mu, overall, rhs_norm, ratio; /* Class_kkt_error, kkt_system_solver.jl:49-65 */
 } okkt_kkt_error;
@@ -209,13 +232,17 @@ int okkt_kkt_form_system(okkt_kkt_handle k, const double* H_nzval, const double*
                          const double* s, const double* y);
 /* diag_min(kkt_solver) (kkt_system_solver.jl:291-294) */
 int okkt_kkt_diag_min(okkt_kkt_handle k, double* out);
-/* factor!(kkt_solver, delta): shift the first n diagonal entries by delta, refactor; 1 / 0 / <0.
- * A factorisation whose inertia is already decided to be wrong before the top of the elimination tree (a
- * non-finite or zero pivot, more negative pivots than m, more positive than n) stops there and returns 0: the
- * reference only uses the flag of a failed factor! (delta_strategy.jl:37-114) and never solves with it.  Then
- * inertia_out holds the counts of the columns eliminated so far and a direction cannot be computed until the
- * next successful okkt_kkt_factor.  OKKT_EARLY_EXIT=0 (environment) always runs to the end. */
+/* factor!(kkt_solver, delta): shift the first n diagonal entries by delta, refactor; 1 / 0 / <0.  Always a complete
+ * factorisation (unless the linear-solver handle was created with opts.early_exit = 1 / okkt_set_early_exit): the
+ * reference computes a direction from a factor! whose inertia flag was 0 after a failed step (one_phase.jl:231-242,
+ * take_step2!), so the factor must exist whatever the flag says. */
 int okkt_kkt_factor(okkt_kkt_handle k, double delta, okkt_inertia* inertia_out);
+/* factor! as the delta loop uses it (delta_strategy.jl:37-114): a factorisation with the wrong inertia is thrown away by the
+ * caller, so it may stop as soon as the pivot counts decide a failure (returns 0; a direction cannot be computed from it --
+ * okkt_kkt_compute_direction then fails with OKKT_ERR_INVALID until the next complete factorisation).  A success is always
+ * a complete factorisation.  okkt_kkt_ipopt_strategy uses this internally (OKKT_EARLY_EXIT=0 in the environment disables it). */
+int okkt_kkt_factor_trial(okkt_kkt_handle k, double delta, okkt_inertia* inertia_out);
+int okkt_kkt_get_timers(okkt_kkt_handle k, okkt_kkt_timers* out);
 /* ipopt_strategy!: returns 1 on :success, 0 on :failure (delta > delta_max), <0 on error */
 int okkt_kkt_ipopt_strategy(okkt_kkt_handle k, double delta_prev, const okkt_kkt_pars* pars,
                             int32_t* num_fac_out, double* delta_out);
@@ -225,10 +252,14 @@ int okkt_kkt_ipopt_strategy(okkt_kkt_handle k, double delta_prev, const okkt_kkt
 int okkt_kkt_system_rhs(okkt_kkt_handle k, const double* J_nzval_cur, const double* grad, const double* cons,
                         const double* s, const double* y, double mu, double a_norm_penalty,
                         double eta_P, double eta_D, double eta_mu, double* dual_r, double* primal_r, double* comp_r);
-/* compute_direction!: rhs triple (dual_r[n], primal_r[m], comp_r[m]) -> (dx[n], dy[m], ds[m]) + N err */
+/* compute_direction!: rhs triple (dual_r[n], primal_r[m], comp_r[m]) -> (dx[n], dy[m], ds[m]) + N err.
+ * dual_r = primal_r = comp_r = NULL: the rhs that the last okkt_kkt_system_rhs left on the device (no copy);
+ * dx = dy = ds = NULL: the direction stays on the device only (step-side functions, okkt_kkt_get_direction).
+ * OKKT_KKT_SCHUR_DIRECT reads s, y and J of the iterate of the last okkt_kkt_system_rhs (current_it). */
 int okkt_kkt_compute_direction(okkt_kkt_handle k, const double* dual_r, const double* primal_r,
                                const double* comp_r, int32_t ItRefine_Num,
                                double* dx, double* dy, double* ds, okkt_kkt_error* err_out);
+int okkt_kkt_get_direction(okkt_kkt_handle k, double* dx, double* dy, double* ds);
 /* the assembled matrix values in the order of the analysed pattern (tests), and schur_diag */
 int okkt_kkt_get_matrix(okkt_kkt_handle k, int64_t* dim_out, int64_t* nnz_out,
                         int64_t* colptr_out, int64_t* rowval_out, double* nzval_out);

@@ -18,6 +18,7 @@ OKKT_SYM_SYMMETRIC = 1
 OKKT_KKT_SCHUR = 0
 OKKT_KKT_SYMMETRIC = 1
 OKKT_KKT_CLEVER_SYMMETRIC = 2
+OKKT_KKT_SCHUR_DIRECT = 3
 OKKT_RESCALE = {"none": 0, "u_only": 1, "u_and_x": 2}
 
 OKKT_OK = 0
@@ -104,6 +105,25 @@ class OkktKktError(C.Structure):
     ]
 
 
+class OkktKktTimers(C.Structure):
+    _fields_ = [
+        ("assemble_ms", C.c_double),
+        ("upload_ms", C.c_double),
+        ("shift_ms", C.c_double),
+        ("factor_ms", C.c_double),
+        ("rhs_ms", C.c_double),
+        ("solve_ms", C.c_double),
+        ("refine_ms", C.c_double),
+        ("kkt_err_ms", C.c_double),
+        ("direction_ms", C.c_double),
+        ("n_solves", C.c_int32),
+        ("reserved", C.c_int32),
+    ]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+
+
 # every symbol include/okkt.h declares, with its signature
 _i64p = C.POINTER(C.c_int64)
 _f64p = C.POINTER(C.c_double)
@@ -155,6 +175,9 @@ SIGNATURES = {
     "okkt_kkt_form_system": (C.c_int, [_vp, _f64p, _f64p, _f64p, _f64p]),
     "okkt_kkt_diag_min": (C.c_int, [_vp, _f64p]),
     "okkt_kkt_factor": (C.c_int, [_vp, C.c_double, C.POINTER(OkktInertia)]),
+    "okkt_kkt_factor_trial": (C.c_int, [_vp, C.c_double, C.POINTER(OkktInertia)]),
+    "okkt_kkt_get_timers": (C.c_int, [_vp, C.POINTER(OkktKktTimers)]),
+    "okkt_kkt_get_direction": (C.c_int, [_vp, _f64p, _f64p, _f64p]),
     "okkt_kkt_ipopt_strategy": (C.c_int, [_vp, C.c_double, C.POINTER(OkktKktPars), C.POINTER(C.c_int32), _f64p]),
     "okkt_kkt_system_rhs": (C.c_int, [_vp, _f64p, _f64p, _f64p, _f64p, _f64p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _f64p, _f64p, _f64p]),
     "okkt_kkt_compute_direction": (C.c_int, [_vp, _f64p, _f64p, _f64p, C.c_int32, _f64p, _f64p, _f64p, C.POINTER(OkktKktError)]),

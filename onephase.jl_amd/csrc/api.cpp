@@ -81,18 +81,24 @@ int solver_factor_device(okkt_solver_s* h, const double* d_vals, int64_t n, int6
   return flag;
 }
 
-int solver_solve_device(okkt_solver_s* h, const double* d_rhs, double* d_sol, int64_t nrhs) {
+int solver_solve_enqueue(okkt_solver_s* h, const double* d_rhs, double* d_sol, int64_t nrhs, bool accumulate) {
   int rc = solver_ensure_numeric(h);
   if (rc != OKKT_OK) return rc;
   if (!h->factored) return solver_set_error(h, OKKT_ERR_INVALID, "solve called before a factorisation");
   if (nrhs < 0) return solver_set_error(h, OKKT_ERR_INVALID, "nrhs < 0");
-  (void)hipEventRecord(h->ev0, h->stream);
   for (int64_t r = 0; r < nrhs; ++r) {
     launch_permute_in(h->N, d_rhs + r * h->S.n);
     std::string e = numeric_solve_enqueue(h->N);
     if (!e.empty()) return solver_set_error(h, OKKT_ERR_HIP, e);
-    launch_permute_out(h->N, d_sol + r * h->S.n);
+    launch_permute_out(h->N, d_sol + r * h->S.n, accumulate);
   }
+  return OKKT_OK;
+}
+
+int solver_solve_device(okkt_solver_s* h, const double* d_rhs, double* d_sol, int64_t nrhs) {
+  (void)hipEventRecord(h->ev0, h->stream);
+  int rc = solver_solve_enqueue(h, d_rhs, d_sol, nrhs, false);
+  if (rc != OKKT_OK) return rc;
   (void)hipEventRecord(h->ev1, h->stream);
   hipError_t he = hipStreamSynchronize(h->stream);
   if (he != hipSuccess) return solver_set_error(h, OKKT_ERR_HIP, std::string("solve failed: ") + hipGetErrorString(he));
@@ -244,7 +250,12 @@ int okkt_create(okkt_handle* out, const okkt_opts* opts) {
         h->stream_aux = nullptr;
       }
     }
-    if (!h->stream && hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return OKKT_ERR_HIP; }
+    if (!h->stream && hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+      // nothing of this set is registered yet: destroy the look-ahead streams that were created above
+      for (hipStream_t q : {h->stream_masked, h->stream_panel, h->stream_aux}) if (q) (void)hipStreamDestroy(q);
+      delete h;
+      return OKKT_ERR_HIP;
+    }
     h->stream_la = la ? 1 : 0;
     h->stream_reserved = reserved;
     if (set.device < 0) {   // a new set: the pool owns its streams from now on
@@ -252,7 +263,12 @@ int okkt_create(okkt_handle* out, const okkt_opts* opts) {
       set.stream = h->stream; set.masked = h->stream_masked; set.panel = h->stream_panel; set.aux = h->stream_aux;
       register_stream_set(set);
     }
-    if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) { delete h; return OKKT_ERR_HIP; }
+    if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) {
+      if (h->ev0) (void)hipEventDestroy(h->ev0);
+      give_stream_set(set);      // registered (new or reused): back to the free list for the next handle
+      delete h;
+      return OKKT_ERR_HIP;
+    }
     h->device_ready = true;
   }
   *out = h;
@@ -261,7 +277,16 @@ int okkt_create(okkt_handle* out, const okkt_opts* opts) {
 
 int okkt_destroy(okkt_handle h) {
   if (!h) return OKKT_ERR_INVALID;
-  if (h->device_ready) {
+  bool closed;
+  { std::lock_guard<std::mutex> lock(pool_mutex()); closed = g_pool_closed; }
+  if (h->device_ready && closed) {
+    // a finalizer that runs after the process-exit handler: every pooled stream has been synchronised and destroyed
+    // there, so nothing is in flight; only memory and events are released, no stream is touched
+    numeric_release(h->N);
+    if (h->d_rhs_stage) (void)hipFree(h->d_rhs_stage);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+  } else if (h->device_ready) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     numeric_release(h->N);

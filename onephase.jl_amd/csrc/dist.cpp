@@ -83,6 +83,10 @@ int okkt_dist_factor_local(okkt_handle h, const double* d_nzval, int64_t n, int6
   h->dist_n = n; h->dist_m = m; h->dist_kind = sym_kind;
   h->dist_tol = sym_kind == OKKT_SYM_DEFINITE ? 0.0 : h->opts.inertia_tol;
   h->factored = false;
+  // a handle that was used with early exit before keeps no stale state: the sharded path always runs to the end
+  h->N.early_check = false;
+  h->N.early_device = false;
+  h->N.early_exited = false;
   std::string e = numeric_factor_enqueue(h->N, d_nzval, h->dist_tol, 0, true);
   if (!e.empty()) return solver_set_error(h, OKKT_ERR_HIP, e);
   return sync_or_fail(h, "local factorisation");

@@ -100,25 +100,6 @@ __global__ void k_div(int64_t n, const double* __restrict__ a, const double* __r
 }
 
 // ---- SpMV -------------------------------------------------------------------------------------
-// y = A x with A given by compressed rows over a value map (J x through the CSR view of the CSC J)
-__global__ void k_spmv_rows(int64_t nrows, const int64_t* __restrict__ rp, const int* __restrict__ cj,
-                            const int64_t* __restrict__ map, const double* __restrict__ vals,
-                            const double* __restrict__ x, double* __restrict__ y) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= nrows) return;
-  double acc = 0.0;
-  for (int64_t p = rp[i]; p < rp[i + 1]; ++p) acc += vals[map[p]] * x[cj[p]];
-  y[i] = acc;
-}
-// y = A' v for a CSC matrix A: one thread per column (J' v)
-__global__ void k_spmv_cols(int64_t ncols, const int64_t* __restrict__ cp, const int* __restrict__ ri,
-                            const double* __restrict__ vals, const double* __restrict__ v, double* __restrict__ y) {
-  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= ncols) return;
-  double acc = 0.0;
-  for (int64_t p = cp[j]; p < cp[j + 1]; ++p) acc += vals[p] * v[ri[p]];
-  y[j] = acc;
-}
 // y = L x + L' x - diag(L) x for a lower-triangular CSC L (hess_product, eval.jl:221-234)
 __global__ void k_spmv_symlower(int64_t n, const int64_t* __restrict__ cp, const int* __restrict__ ri,
                                 const double* __restrict__ vals, const int64_t* __restrict__ rp,
@@ -140,27 +121,6 @@ __global__ void k_schur_t1(int64_t m, const double* rP, const double* rC, const 
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < m) o[i] = rP[i] * sig[i] + rC[i] / s[i];                 // schur.jl:103
 }
-__global__ void k_add(int64_t n, const double* a, const double* b, double* o) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) o[i] = a[i] + b[i];
-}
-__global__ void k_mul(int64_t n, const double* a, const double* b, double* o) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) o[i] = a[i] * b[i];
-}
-__global__ void k_refine_res(int64_t n, const double* rhs, const double* jac_res, const double* hx, const double* dx,
-                             double delta, double* res) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) res[i] = rhs[i] - (jac_res[i] + (hx[i] + delta * dx[i]));   // schur.jl:168-170
-}
-__global__ void k_schur_dyds(int64_t m, const double* Jdx, const double* rP, const double* rC, const double* y,
-                             const double* sig, double* dy, double* ds) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < m) {
-    dy[i] = -(Jdx[i] - (rP[i] + rC[i] / y[i])) * sig[i];            // schur.jl:113
-    ds[i] = Jdx[i] - rP[i];                                         // schur.jl:116
-  }
-}
 __global__ void k_sym_rhs(int64_t n, int64_t m, const double* rD, const double* rP, const double* rC, const double* y, double* o) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) o[i] = rD[i];
@@ -171,34 +131,10 @@ __global__ void k_sym_split(int64_t n, int64_t m, const double* sol, double* dx,
   if (i < n) dx[i] = sol[i];
   else if (i < n + m) dy[i - n] = -sol[i];                           // symmetric.jl:72-73
 }
-__global__ void k_sub(int64_t n, const double* a, const double* b, double* o) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) o[i] = a[i] - b[i];
-}
-__global__ void k_errD(int64_t n, double delta, const double* dx, const double* hx, const double* jty, const double* rD, double* o) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) o[i] = ((delta * dx[i] + 0.0) + hx[i] - jty[i]) - rD[i];    // kkt_system_solver.jl:27-47,76
-}
-__global__ void k_errP(int64_t m, const double* Jdx, const double* ds, const double* rP, double* o) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < m) o[i] = Jdx[i] - ds[i] - rP[i];                          // :80
-}
-__global__ void k_errMu(int64_t m, const double* s, const double* dy, const double* y, const double* ds, const double* rC, double* o) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < m) o[i] = s[i] * dy[i] + y[i] * ds[i] - rC[i];             // :84
-}
 // system_rhs.jl:57-73 + eval.jl:59-63,136-142
-__global__ void k_rhs_dual(int64_t n, const double* grad, const double* jty, const double* jt1, double mu_pen, double one_minus_D, double* o) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) o[i] = -((grad[i] - jty[i]) + mu_pen * jt1[i]) * one_minus_D;
-}
 __global__ void k_rhs_pc(int64_t m, const double* cons, const double* s, const double* y, double one_minus_P, double mu_target, double* rP, double* rC) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < m) { rP[i] = -(cons[i] - s[i]) * one_minus_P; rC[i] = mu_target - s[i] * y[i]; }
-}
-__global__ void k_fill(int64_t n, double v, double* o) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) o[i] = v;
 }
 
 // single-block reductions (inputs are O(n+m) vectors; deterministic)
@@ -268,8 +204,9 @@ __global__ void k_clever_true_diag(int64_t n, const int64_t* __restrict__ Hp, co
   for (int64_t p = Hp[j]; p < Hp[j + 1]; ++p) if (Hi[p] == j) v += Hx[p];
   o[j] = v;
 }
-// update_delta_vecs! (clever_symmetric.jl:494-519): with delta > 0 the x diagonal becomes the UNscaled
-// true_x_diag (+ delta, added by the factorisation's shift), with delta == 0 it stays D^2 * true_x_diag
+// update_delta_vecs! (clever_symmetric.jl:494-519): with sum(abs.(delta_x_vec)) > 0, i.e. delta != 0 (either sign), the x
+// diagonal becomes the UNscaled true_x_diag (+ delta, added by the factorisation's shift), with delta == 0 it stays
+// D^2 * true_x_diag
 __global__ void k_clever_xdiag(int64_t n, int delta_pos, const double* __restrict__ D, const double* __restrict__ tx, const int64_t* __restrict__ diagA, double* __restrict__ A) {
   const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j < n) A[diagA[j]] = delta_pos ? tx[j] : (D[j] * tx[j]) * D[j];
@@ -313,6 +250,231 @@ __global__ void k_clever_y(int64_t m, const int* __restrict__ row_grp, const dou
   dy[j] = uinv * symrhs[j] + (uinv * row_ratio[j]) * tmp;
 }
 
+// ---- segmented sparse products -----------------------------------------------------------------------------------
+// A row (CSR) or column (CSC) of J / H holds 10 - 40 entries at the BASELINE sizes: one thread per row reads its values
+// with a stride of a whole row between neighbouring lanes (uncoalesced), one wave per row idles most lanes.  Here a group
+// of LPR lanes (4 ... 64, chosen from the average length) owns a row: consecutive groups of a wave own consecutive rows,
+// so a wave reads one contiguous run of values and indices; the partial sums meet by xor-shuffles inside the group.
+// The summation order is fixed by LPR alone (bitwise reproducible run to run).  No early return before the shuffles:
+// rows past the end are clamped and simply not stored.
+template <int LPR>
+__device__ __forceinline__ double seg_dot(const int64_t* __restrict__ ptr, const int* __restrict__ idx, const double* __restrict__ vals,
+                                          const double* __restrict__ x, int64_t row, int sub) {
+  double a = 0.0;
+  const int64_t p1 = ptr[row + 1];
+  for (int64_t p = ptr[row] + sub; p < p1; p += LPR) a += vals[p] * x[idx[p]];
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+  return a;
+}
+// hess_product (eval.jl:221-234) of row i: (L x)_i + (L' x)_i - diag(L)_i x_i with the lower-stored H in CSR and CSC order
+template <int LPR>
+__device__ __forceinline__ double seg_hess(const int64_t* __restrict__ Hrp, const int* __restrict__ Hrj, const double* __restrict__ Hcsr,
+                                           const int64_t* __restrict__ Hp, const int* __restrict__ Hi, const double* __restrict__ Hx,
+                                           const double* __restrict__ Hdiag, const double* __restrict__ x, int64_t i, int sub) {
+  const double v1 = seg_dot<LPR>(Hrp, Hrj, Hcsr, x, i, sub);
+  const double v2 = seg_dot<LPR>(Hp, Hi, Hx, x, i, sub);
+  return (v1 + v2) - Hdiag[i] * x[i];
+}
+__device__ __forceinline__ double nan_max(double a, double b) { return (a != a || b != b) ? NAN : fmax(a, b); }
+// per-workgroup maxima of NV values per thread (NaN propagates like Julia's norm(., Inf)); slot v of workgroup b -> part[b * 8 + v]
+template <int NV>
+__device__ __forceinline__ void block_max_store(double (&v)[NV], double* __restrict__ part) {
+  __shared__ double sh[NV][4];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int q = 0; q < NV; ++q) {
+    double a = v[q];
+    for (int o = 32; o > 0; o >>= 1) a = nan_max(a, __shfl_xor(a, o, 64));
+    if (lane == 0) sh[q][wv] = a;
+  }
+  __syncthreads();
+  if (threadIdx.x < NV) {
+    const int q = threadIdx.x;
+    part[(size_t)blockIdx.x * 8 + q] = nan_max(nan_max(sh[q][0], sh[q][1]), nan_max(sh[q][2], sh[q][3]));
+  }
+}
+
+// y[i] = dot_i (* scale[i]) (+ beta * addv[i]): J x, J' v, Sigma .* (J x), rD + J' t, J dx - rP
+template <int LPR>
+__global__ __launch_bounds__(256) void k_seg_spmv(int64_t nrows, const int64_t* __restrict__ ptr, const int* __restrict__ idx,
+                                                  const double* __restrict__ vals, const double* __restrict__ x, const double* __restrict__ scale,
+                                                  const double* __restrict__ addv, double beta, double* __restrict__ y) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t row = t / LPR;
+  const int sub = (int)(t % LPR);
+  const int64_t rc = row < nrows ? row : nrows - 1;
+  double r = seg_dot<LPR>(ptr, idx, vals, x, rc, sub);
+  if (sub == 0 && row < nrows) {
+    if (scale) r *= scale[row];
+    if (addv) r = r + beta * addv[row];
+    y[row] = r;
+  }
+}
+template <int LPR>
+__global__ __launch_bounds__(256) void k_seg_hess(int64_t n, const int64_t* __restrict__ Hrp, const int* __restrict__ Hrj, const double* __restrict__ Hcsr,
+                                                  const int64_t* __restrict__ Hp, const int* __restrict__ Hi, const double* __restrict__ Hx,
+                                                  const double* __restrict__ Hdiag, const double* __restrict__ x, double* __restrict__ y) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t row = t / LPR;
+  const int sub = (int)(t % LPR);
+  const int64_t i = row < n ? row : n - 1;
+  const double h = seg_hess<LPR>(Hrp, Hrj, Hcsr, Hp, Hi, Hx, Hdiag, x, i, sub);
+  if (sub == 0 && row < n) y[i] = h;
+}
+// res = rhs - (J' v + (H dx + delta dx)) with v = Sigma .* (J dx) (schur.jl:166-170): one pass instead of J' v, H dx and
+// the vector kernel
+template <int LPR>
+__global__ __launch_bounds__(256) void k_schur_resid(int64_t n, const int64_t* __restrict__ Jp, const int* __restrict__ Ji, const double* __restrict__ Jx,
+                                                     const double* __restrict__ v, const int64_t* __restrict__ Hrp, const int* __restrict__ Hrj,
+                                                     const double* __restrict__ Hcsr, const int64_t* __restrict__ Hp, const int* __restrict__ Hi,
+                                                     const double* __restrict__ Hx, const double* __restrict__ Hdiag, const double* __restrict__ dx,
+                                                     const double* __restrict__ rhs, double delta, double* __restrict__ res) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t row = t / LPR;
+  const int sub = (int)(t % LPR);
+  const int64_t i = row < n ? row : n - 1;
+  const double jac = seg_dot<LPR>(Jp, Ji, Jx, v, i, sub);
+  const double hx = seg_hess<LPR>(Hrp, Hrj, Hcsr, Hp, Hi, Hx, Hdiag, dx, i, sub);
+  if (sub == 0 && row < n) res[i] = rhs[i] - (jac + (hx + delta * dx[i]));
+}
+// dy, ds from J dx (schur.jl:113-116); direct = 1: ds = (comp_r - dy .* s) ./ y (schur_direct.jl:54-56), y, s, sig of the CURRENT iterate
+template <int LPR>
+__global__ __launch_bounds__(256) void k_schur_dyds(int64_t m, const int64_t* __restrict__ Jrp, const int* __restrict__ Jrj, const double* __restrict__ Jcsr,
+                                                    const double* __restrict__ dx, const double* __restrict__ rP, const double* __restrict__ rC,
+                                                    const double* __restrict__ y, const double* __restrict__ s, const double* __restrict__ sig, int direct,
+                                                    double* __restrict__ dy, double* __restrict__ ds) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t row = t / LPR;
+  const int sub = (int)(t % LPR);
+  const int64_t i = row < m ? row : m - 1;
+  const double Jdx = seg_dot<LPR>(Jrp, Jrj, Jcsr, dx, i, sub);
+  if (sub == 0 && row < m) {
+    const double dyi = -(Jdx - (rP[i] + rC[i] / y[i])) * sig[i];
+    dy[i] = dyi;
+    ds[i] = direct ? (rC[i] - dyi * s[i]) / y[i] : Jdx - rP[i];
+  }
+}
+// update_kkt_error! (kkt_system_solver.jl:27-47,67-96), dual block: |predicted_lag_change - dual_r| and |dual_r|, maxima per workgroup
+template <int LPR>
+__global__ __launch_bounds__(256) void k_err_dual(int64_t n, const int64_t* __restrict__ Jp, const int* __restrict__ Ji, const double* __restrict__ Jx,
+                                                  const double* __restrict__ dy, const int64_t* __restrict__ Hrp, const int* __restrict__ Hrj,
+                                                  const double* __restrict__ Hcsr, const int64_t* __restrict__ Hp, const int* __restrict__ Hi,
+                                                  const double* __restrict__ Hx, const double* __restrict__ Hdiag, const double* __restrict__ dx,
+                                                  const double* __restrict__ rD, double delta, double* __restrict__ part) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t row = t / LPR;
+  const int sub = (int)(t % LPR);
+  const int64_t i = row < n ? row : n - 1;
+  const double jty = seg_dot<LPR>(Jp, Ji, Jx, dy, i, sub);
+  const double hx = seg_hess<LPR>(Hrp, Hrj, Hcsr, Hp, Hi, Hx, Hdiag, dx, i, sub);
+  double v[2] = {0.0, 0.0};
+  if (sub == 0 && row < n) {
+    v[0] = fabs(((delta * dx[i] + 0.0) + hx - jty) - rD[i]);
+    v[1] = fabs(rD[i]);
+  }
+  block_max_store<2>(v, part);
+}
+// primal and complementarity blocks: |J dx - ds - primal_r|, |s dy + y ds - comp_r|, |primal_r|, |comp_r|
+template <int LPR>
+__global__ __launch_bounds__(256) void k_err_pc(int64_t m, const int64_t* __restrict__ Jrp, const int* __restrict__ Jrj, const double* __restrict__ Jcsr,
+                                                const double* __restrict__ dx, const double* __restrict__ ds, const double* __restrict__ dy,
+                                                const double* __restrict__ s, const double* __restrict__ y, const double* __restrict__ rP,
+                                                const double* __restrict__ rC, double* __restrict__ part) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t row = t / LPR;
+  const int sub = (int)(t % LPR);
+  const int64_t i = row < m ? row : m - 1;
+  const double Jdx = seg_dot<LPR>(Jrp, Jrj, Jcsr, dx, i, sub);
+  double v[4] = {0.0, 0.0, 0.0, 0.0};
+  if (sub == 0 && row < m) {
+    v[0] = fabs(Jdx - ds[i] - rP[i]);
+    v[1] = fabs(s[i] * dy[i] + y[i] * ds[i] - rC[i]);
+    v[2] = fabs(rP[i]);
+    v[3] = fabs(rC[i]);
+  }
+  block_max_store<4>(v, part);
+}
+// the six norms: out[0..1] from the nbD dual partial rows, out[2..5] from the nbM rows behind them
+__global__ __launch_bounds__(256) void k_err_final(int64_t nbD, int64_t nbM, const double* __restrict__ part, double* __restrict__ out) {
+  __shared__ double sh[6][256];
+  double a[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  for (int64_t b = threadIdx.x; b < nbD; b += 256) { a[0] = nan_max(a[0], part[b * 8]); a[1] = nan_max(a[1], part[b * 8 + 1]); }
+  for (int64_t b = threadIdx.x; b < nbM; b += 256)
+    for (int q = 0; q < 4; ++q) a[2 + q] = nan_max(a[2 + q], part[(nbD + b) * 8 + q]);
+  for (int q = 0; q < 6; ++q) sh[q][threadIdx.x] = a[q];
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o)
+      for (int q = 0; q < 6; ++q) sh[q][threadIdx.x] = nan_max(sh[q][threadIdx.x], sh[q][threadIdx.x + o]);
+    __syncthreads();
+  }
+  if (threadIdx.x < 6) out[threadIdx.x] = sh[threadIdx.x][0];
+}
+// System_rhs, dual block (system_rhs.jl:57-73 + eval.jl:59-63,136-142): J' y and J' 1 in one pass over the column
+template <int LPR>
+__global__ __launch_bounds__(256) void k_rhs_dual_seg(int64_t n, const int64_t* __restrict__ Jp, const int* __restrict__ Ji, const double* __restrict__ Jx,
+                                                      const double* __restrict__ y, const double* __restrict__ grad, double mu_pen, double one_minus_D,
+                                                      double* __restrict__ o) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t row = t / LPR;
+  const int sub = (int)(t % LPR);
+  const int64_t i = row < n ? row : n - 1;
+  double jty = 0.0, jt1 = 0.0;
+  const int64_t p1 = Jp[i + 1];
+  for (int64_t p = Jp[i] + sub; p < p1; p += LPR) { const double a = Jx[p]; jty += a * y[Ji[p]]; jt1 += a; }
+#pragma unroll
+  for (int q = LPR / 2; q > 0; q >>= 1) { jty += __shfl_xor(jty, q, 64); jt1 += __shfl_xor(jt1, q, 64); }
+  if (sub == 0 && row < n) o[i] = -((grad[i] - jty) + mu_pen * jt1) * one_minus_D;
+}
+// schur_diag = diag(H) + sum_i J_ij^2 sig_i (kkt_system_solver.jl:296-300, eval.jl:89-100)
+template <int LPR>
+__global__ __launch_bounds__(256) void k_schur_diag_seg(int64_t n, const int64_t* __restrict__ Jp, const int* __restrict__ Ji, const double* __restrict__ Jx,
+                                                        const double* __restrict__ sig, const double* __restrict__ Hdiag, double* __restrict__ out) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t row = t / LPR;
+  const int sub = (int)(t % LPR);
+  const int64_t j = row < n ? row : n - 1;
+  double di = 0.0;
+  const int64_t p1 = Jp[j + 1];
+  for (int64_t p = Jp[j] + sub; p < p1; p += LPR) di += Jx[p] * Jx[p] * sig[Ji[p]];
+#pragma unroll
+  for (int q = LPR / 2; q > 0; q >>= 1) di += __shfl_xor(di, q, 64);
+  if (sub == 0 && row < n) out[j] = Hdiag[j] + di;
+}
+// values of J and H in CSR order, Sigma = y ./ s and diag(H), in one launch behind the uploads of form_system
+__global__ void k_form_prep(int64_t nnzJ, int64_t nnzH, int64_t n, int64_t m, const double* __restrict__ Jx, const int64_t* __restrict__ Jrmap,
+                            const double* __restrict__ Hx, const int64_t* __restrict__ Hrmap, const int64_t* __restrict__ Hp, const int* __restrict__ Hi,
+                            const double* __restrict__ s, const double* __restrict__ y, double* __restrict__ Jcsr, double* __restrict__ Hcsr,
+                            double* __restrict__ Hdiag, double* __restrict__ sig) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < nnzJ) Jcsr[t] = Jx[Jrmap[t]];
+  if (t < nnzH) Hcsr[t] = Hx[Hrmap[t]];
+  if (t < m) sig[t] = y[t] / s[t];
+  if (t < n) {
+    double v = 0.0;
+    for (int64_t p = Hp[t]; p < Hp[t + 1]; ++p) if (Hi[p] == t) v += Hx[p];
+    Hdiag[t] = v;
+  }
+}
+
+inline int pick_lpr(int64_t nnz, int64_t rows) {
+  const double avg = rows > 0 ? (double)nnz / (double)rows : 1.0;
+  return avg <= 5.0 ? 4 : (avg <= 10.0 ? 8 : (avg <= 24.0 ? 16 : (avg <= 56.0 ? 32 : 64)));
+}
+inline dim3 seg_grid(int64_t rows, int lpr) { return dim3((unsigned)std::max<int64_t>(1, (rows * lpr + 255) / 256)); }
+#define SEG_LAUNCH(KERN, lpr, rows, st, ...)                                                                   \
+  do {                                                                                                         \
+    const int64_t rows__ = (rows);                                                                             \
+    if (rows__ > 0) switch (lpr) {                                                                             \
+        case 4: hipLaunchKernelGGL((KERN<4>), seg_grid(rows__, 4), dim3(256), 0, st, __VA_ARGS__); break;      \
+        case 8: hipLaunchKernelGGL((KERN<8>), seg_grid(rows__, 8), dim3(256), 0, st, __VA_ARGS__); break;      \
+        case 16: hipLaunchKernelGGL((KERN<16>), seg_grid(rows__, 16), dim3(256), 0, st, __VA_ARGS__); break;   \
+        case 32: hipLaunchKernelGGL((KERN<32>), seg_grid(rows__, 32), dim3(256), 0, st, __VA_ARGS__); break;   \
+        default: hipLaunchKernelGGL((KERN<64>), seg_grid(rows__, 64), dim3(256), 0, st, __VA_ARGS__); break;   \
+      }                                                                                                        \
+  } while (0)
+
 int kk_fail(okkt_kkt_s* k, int code, const std::string& msg) { k->err = msg; return code; }
 
 int kk_check_ls(okkt_kkt_s* k, int rc, const char* what) {
@@ -321,11 +483,6 @@ int kk_check_ls(okkt_kkt_s* k, int rc, const char* what) {
 }
 
 
-// the reduction into slot `slot` of k->red, no synchronisation (several of them are fetched with one copy)
-void kk_reduce_enqueue(okkt_kkt_s* k, int64_t n, const double* v, int mode, int slot) {
-  hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, kk_stream(k), n, v, mode, k->red + slot);
-}
-
 int kk_reduce(okkt_kkt_s* k, int64_t n, const double* v, int mode, double* host_out) {
   hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, kk_stream(k), n, v, mode, k->red);
   KK_TRY(k, hipMemcpyAsync(host_out, k->red, sizeof(double), hipMemcpyDeviceToHost, kk_stream(k)));
@@ -333,15 +490,15 @@ int kk_reduce(okkt_kkt_s* k, int64_t n, const double* v, int mode, double* host_
   return OKKT_OK;
 }
 
-// J x, J' v, H x on the handle's stream
+// J x, J' v, H x on the handle's stream (segmented products; J x and H x read the CSR-ordered copies of form_system)
 void spmv_J(okkt_kkt_s* k, const double* x, double* y) {
-  hipLaunchKernelGGL(k_spmv_rows, grid1(k->m), dim3(256), 0, kk_stream(k), k->m, k->Jrp, k->Jrj, k->Jrmap, k->Jx, x, y);
+  SEG_LAUNCH(k_seg_spmv, k->lprJr, k->m, kk_stream(k), k->m, k->Jrp, k->Jrj, k->Jcsr, x, (const double*)nullptr, (const double*)nullptr, 0.0, y);
 }
 void spmv_JT(okkt_kkt_s* k, const double* Jx, const double* v, double* y) {
-  hipLaunchKernelGGL(k_spmv_cols, grid1(k->n), dim3(256), 0, kk_stream(k), k->n, k->Jp, k->Ji, Jx, v, y);
+  SEG_LAUNCH(k_seg_spmv, k->lprJc, k->n, kk_stream(k), k->n, k->Jp, k->Ji, Jx, v, (const double*)nullptr, (const double*)nullptr, 0.0, y);
 }
 void spmv_H(okkt_kkt_s* k, const double* x, double* y) {
-  hipLaunchKernelGGL(k_spmv_symlower, grid1(k->n), dim3(256), 0, kk_stream(k), k->n, k->Hp, k->Hi, k->Hx, k->Hrp, k->Hrj, k->Hrmap, x, y);
+  SEG_LAUNCH(k_seg_hess, k->lprH, k->n, kk_stream(k), k->n, k->Hrp, k->Hrj, k->Hcsr, k->Hp, k->Hi, k->Hx, k->Hdiag, x, y);
 }
 
 }  // namespace
@@ -370,7 +527,7 @@ int okkt_kkt_default_pars(okkt_kkt_pars* p) {
 int okkt_kkt_create(okkt_kkt_handle* out, const okkt_opts* opts, int kkt_kind) {
   if (!out) return OKKT_ERR_INVALID;
   *out = nullptr;
-  if (kkt_kind != OKKT_KKT_SCHUR && kkt_kind != OKKT_KKT_SYMMETRIC && kkt_kind != OKKT_KKT_CLEVER_SYMMETRIC) return OKKT_ERR_INVALID;
+  if (kkt_kind != OKKT_KKT_SCHUR && kkt_kind != OKKT_KKT_SYMMETRIC && kkt_kind != OKKT_KKT_CLEVER_SYMMETRIC && kkt_kind != OKKT_KKT_SCHUR_DIRECT) return OKKT_ERR_INVALID;
   okkt_kkt_s* k = new (std::nothrow) okkt_kkt_s();
   if (!k) return OKKT_ERR_ALLOC;
   k->kind = kkt_kind;
@@ -384,6 +541,7 @@ int okkt_kkt_destroy(okkt_kkt_handle k) {
   if (!k) return OKKT_ERR_INVALID;
   if (k->ls && k->ls->device_ready) { (void)hipSetDevice(k->ls->device); (void)hipStreamSynchronize(k->ls->stream); }
   for (void* p : k->allocs) (void)hipFree(p);
+  k->tm_form.destroy(); k->tm_factor.destroy(); k->tm_rhs.destroy(); k->tm_dir.destroy();
   if (k->ls) okkt_destroy(k->ls);
   delete k;
   return OKKT_OK;
@@ -524,8 +682,16 @@ int okkt_kkt_set_structure(okkt_kkt_handle k, int64_t n, int64_t m, const int64_
         (rc = kk_alloc(k, (size_t)m, &k->rC)) || (rc = kk_alloc(k, (size_t)n, &k->dx)) || (rc = kk_alloc(k, (size_t)m, &k->dy)) ||
         (rc = kk_alloc(k, (size_t)m, &k->ds)) || (rc = kk_alloc(k, (size_t)n, &k->vn1)) || (rc = kk_alloc(k, (size_t)n, &k->vn2)) ||
         (rc = kk_alloc(k, (size_t)n, &k->vn3)) || (rc = kk_alloc(k, (size_t)m, &k->vm1)) || (rc = kk_alloc(k, (size_t)m, &k->vm2)) ||
-        (rc = kk_alloc(k, (size_t)(n + m), &k->big1)) || (rc = kk_alloc(k, (size_t)(n + m), &k->big2)) || (rc = kk_alloc(k, (size_t)8, &k->red)))
+        (rc = kk_alloc(k, (size_t)(n + m), &k->big1)) || (rc = kk_alloc(k, (size_t)(n + m), &k->big2)) || (rc = kk_alloc(k, (size_t)8, &k->red)) ||
+        (rc = kk_alloc(k, (size_t)nnzJ, &k->Jcsr)) || (rc = kk_alloc(k, (size_t)nnzH, &k->Hcsr)) || (rc = kk_alloc(k, (size_t)n, &k->Hdiag)) ||
+        (rc = kk_alloc(k, (size_t)m, &k->cur_s)) || (rc = kk_alloc(k, (size_t)m, &k->cur_y)) || (rc = kk_alloc(k, (size_t)m, &k->cur_sig)))
       return rc;
+    k->lprJr = pick_lpr(nnzJ, m);
+    k->lprJc = pick_lpr(nnzJ, n);
+    k->lprH = pick_lpr(nnzH, n);
+    // partial maxima of the N-err kernels: one row of 8 per workgroup of the widest launch over n and over m
+    k->part_blocks = (int64_t)seg_grid(n, 64).x + (int64_t)seg_grid(m, 64).x;
+    if ((rc = kk_alloc(k, (size_t)k->part_blocks * 8, &k->part))) return rc;
     if (k->kind == OKKT_KKT_CLEVER_SYMMETRIC) {
       if ((rc = kk_alloc(k, (size_t)m, &k->rowg)) || (rc = kk_alloc(k, (size_t)n, &k->true_x_diag)) ||
           (rc = kk_alloc(k, (size_t)(n + m), &k->big3)) || (rc = kk_alloc(k, (size_t)(n + m), &k->big4)) ||
@@ -554,12 +720,20 @@ int okkt_kkt_form_system(okkt_kkt_handle k, const double* H_nzval, const double*
   k->have_dxnorm = false;
   hipStream_t st = kk_stream(k);
   KK_TRY(k, hipSetDevice(k->ls->device));
+  k->tm_form.reset();
+  const size_t e0 = k->tm_form.mark(st);
   if (k->nnzH) KK_TRY(k, hipMemcpyAsync(k->Hx, H_nzval, (size_t)k->nnzH * 8, hipMemcpyHostToDevice, st));
   if (k->nnzJ) KK_TRY(k, hipMemcpyAsync(k->Jx, J_nzval, (size_t)k->nnzJ * 8, hipMemcpyHostToDevice, st));
   if (k->m) {
     KK_TRY(k, hipMemcpyAsync(k->s, s, (size_t)k->m * 8, hipMemcpyHostToDevice, st));
     KK_TRY(k, hipMemcpyAsync(k->y, y, (size_t)k->m * 8, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_div, grid1(k->m), dim3(256), 0, st, k->m, k->y, k->s, k->sig);   // y ./ s
+  }
+  const size_t e1 = k->tm_form.mark(st);
+  {
+    // CSR-ordered value copies, Sigma = y ./ s, diag(H): everything the row-wise products and the assembly read
+    const int64_t tot = std::max(std::max(k->nnzJ, k->nnzH), std::max(k->n, k->m));
+    if (tot) hipLaunchKernelGGL(k_form_prep, grid1(tot), dim3(256), 0, st, k->nnzJ, k->nnzH, k->n, k->m, k->Jx, k->Jrmap, k->Hx, k->Hrmap, k->Hp, k->Hi,
+                                k->s, k->y, k->Jcsr, k->Hcsr, k->Hdiag, k->sig);
   }
   if (k->kind == OKKT_KKT_CLEVER_SYMMETRIC) {
     // form_system!(::Clever_Symmetric_KKT_solver), clever_symmetric.jl:341-393
@@ -573,17 +747,20 @@ int okkt_kkt_form_system(okkt_kkt_handle k, const double* H_nzval, const double*
                                 k->Hcol, k->Jcol, k->dAi, k->diagA, k->gU, k->Dres, k->Avals);
     if (k->n) {
       hipLaunchKernelGGL(k_clever_true_diag, grid1(k->n), dim3(256), 0, st, k->n, k->Hp, k->Hi, k->Hx, k->true_x_diag);
-      hipLaunchKernelGGL(k_schur_diag, grid1(k->n), dim3(256), 0, st, k->n, k->Jp, k->Ji, k->Jx, k->sig, k->Hp, k->Hi, k->Hx, k->schur_diag);
+      SEG_LAUNCH(k_schur_diag_seg, k->lprJc, k->n, st, k->n, k->Jp, k->Ji, k->Jx, k->sig, k->Hdiag, k->schur_diag);
     }
   } else if (k->kind == OKKT_KKT_SYMMETRIC) {
     KK_TRY(k, hipMemsetAsync(k->Avals, 0, (size_t)std::max<int64_t>(k->nnzA, 1) * 8, st));
     const int64_t tot = k->nnzH + k->nnzJ + k->m;
     if (tot) hipLaunchKernelGGL(k_assemble_aug, grid1(tot), dim3(256), 0, st, k->nnzH, k->nnzJ, k->n, k->m, k->Hx, k->Jx, k->s, k->y, k->mapH, k->mapJ, k->diagA, k->Avals);
-    if (k->n) hipLaunchKernelGGL(k_schur_diag, grid1(k->n), dim3(256), 0, st, k->n, k->Jp, k->Ji, k->Jx, k->sig, k->Hp, k->Hi, k->Hx, k->schur_diag);
+    SEG_LAUNCH(k_schur_diag_seg, k->lprJc, k->n, st, k->n, k->Jp, k->Ji, k->Jx, k->sig, k->Hdiag, k->schur_diag);
   } else {
     if (k->nnzA) hipLaunchKernelGGL(k_assemble_schur, grid1(k->nnzA), dim3(256), 0, st, k->nnzA, k->qptr, k->qa, k->qb, k->qi, k->qh, k->Jx, k->sig, k->Hx, k->Avals);
     if (k->n) hipLaunchKernelGGL(k_gather, grid1(k->n), dim3(256), 0, st, k->n, k->diagA, k->Avals, k->schur_diag);   // schur_diag = diag(Q), schur.jl:56
   }
+  const size_t e2 = k->tm_form.mark(st);
+  k->tm_form.seg(0, e0, e1);
+  k->tm_form.seg(1, e1, e2);
   KK_TRY(k, hipStreamSynchronize(st));
   KK_TRY(k, hipGetLastError());
   k->formed = true;
@@ -597,28 +774,63 @@ int okkt_kkt_diag_min(okkt_kkt_handle k, double* out) {
   return kk_reduce(k, k->n, k->schur_diag, 0, out);
 }
 
-int okkt_kkt_factor(okkt_kkt_handle k, double delta, okkt_inertia* inertia_out) {
-  if (!k) return OKKT_ERR_INVALID;
-  // factor!(kkt_solver, delta): update_delta! then factor! (kkt_system_solver.jl:98-113,190-204); the state
-  // machine of the reference (:system_formed -> :delta_updated -> :factored) collapses into this one call
+// factor!(kkt_solver, delta): update_delta! then factor! (kkt_system_solver.jl:98-113,190-204); the state machine of the
+// reference (:system_formed -> :delta_updated -> :factored) collapses into this one call.  trial: the caller throws a
+// factorisation with the wrong inertia away (the delta loop), so it may stop as soon as the flag is decided.
+static int kkt_factor_impl(okkt_kkt_s* k, double delta, okkt_inertia* inertia_out, bool trial) {
   if (!k->formed) return kk_fail(k, OKKT_ERR_INVALID, "kkt solver not ready to factor: form_system has not been called");
   int rc = solver_ensure_numeric(k->ls);
   if (rc != OKKT_OK) return kk_check_ls(k, rc, "device plan");
-  // factor!'s only result is the inertia flag, and a factorisation with the wrong inertia is never solved with
-  // (delta_strategy.jl:37-114 refactors or gives up): it may stop as soon as the flag is decided
-  static const bool early = !(getenv("OKKT_EARLY_EXIT") && atoi(getenv("OKKT_EARLY_EXIT")) == 0);
-  k->ls->early_exit = early;
+  static const bool env_early = !(getenv("OKKT_EARLY_EXIT") && atoi(getenv("OKKT_EARLY_EXIT")) == 0);
+  const bool saved_early = k->ls->early_exit;
+  if (trial && env_early) k->ls->early_exit = true;
   k->delta = delta;
+  k->factored = false;
+  k->have_dir = false;
+  hipStream_t st = kk_stream(k);
+  k->tm_factor.reset();
+  const size_t e0 = k->tm_factor.mark(st);
   // the first n diagonal entries move, the (2,2) block never does (symmetric.jl:85-102)
   launch_set_shift(k->ls->N, delta, k->n);
-  if (k->kind == OKKT_KKT_CLEVER_SYMMETRIC) {
-    if (k->n) hipLaunchKernelGGL(k_clever_xdiag, grid1(k->n), dim3(256), 0, kk_stream(k), k->n, delta > 0.0 ? 1 : 0, k->Dres, k->true_x_diag, k->diagA, k->Avals);
-    rc = solver_factor_device(k->ls, k->Avals, k->n, k->m_new, OKKT_SYM_SYMMETRIC, inertia_out);   // clever_symmetric.jl:395-400
-  } else if (k->kind == OKKT_KKT_SYMMETRIC) rc = solver_factor_device(k->ls, k->Avals, k->n, k->m, OKKT_SYM_SYMMETRIC, inertia_out);
+  if (k->kind == OKKT_KKT_CLEVER_SYMMETRIC && k->n)
+    hipLaunchKernelGGL(k_clever_xdiag, grid1(k->n), dim3(256), 0, st, k->n, delta != 0.0 ? 1 : 0, k->Dres, k->true_x_diag, k->diagA, k->Avals);
+  const size_t e1 = k->tm_factor.mark(st);
+  k->tm_factor.seg(0, e0, e1);
+  if (k->kind == OKKT_KKT_CLEVER_SYMMETRIC) rc = solver_factor_device(k->ls, k->Avals, k->n, k->m_new, OKKT_SYM_SYMMETRIC, inertia_out);   // clever_symmetric.jl:395-400
+  else if (k->kind == OKKT_KKT_SYMMETRIC) rc = solver_factor_device(k->ls, k->Avals, k->n, k->m, OKKT_SYM_SYMMETRIC, inertia_out);
   else rc = solver_factor_device(k->ls, k->Avals, k->n, 0, OKKT_SYM_DEFINITE, inertia_out);
+  k->ls->early_exit = saved_early;
+  k->t_factor_ms = k->ls->last_factor_ms;
   if (rc < 0) return kk_check_ls(k, rc, "factor");
   k->factored = true;
   return rc;
+}
+
+int okkt_kkt_factor(okkt_kkt_handle k, double delta, okkt_inertia* inertia_out) {
+  if (!k) return OKKT_ERR_INVALID;
+  return kkt_factor_impl(k, delta, inertia_out, false);
+}
+int okkt_kkt_factor_trial(okkt_kkt_handle k, double delta, okkt_inertia* inertia_out) {
+  if (!k) return OKKT_ERR_INVALID;
+  return kkt_factor_impl(k, delta, inertia_out, true);
+}
+
+int okkt_kkt_get_timers(okkt_kkt_handle k, okkt_kkt_timers* out) {
+  if (!k || !out) return OKKT_ERR_INVALID;
+  std::memset(out, 0, sizeof(*out));
+  if (!k->structured) return kk_fail(k, OKKT_ERR_INVALID, "structure not set");
+  KK_TRY(k, hipStreamSynchronize(kk_stream(k)));
+  out->upload_ms = k->tm_form.sum(0);
+  out->assemble_ms = k->tm_form.sum(1);
+  out->shift_ms = k->tm_factor.sum(0);
+  out->factor_ms = k->t_factor_ms;
+  out->rhs_ms = k->tm_rhs.sum(0);
+  out->solve_ms = k->tm_dir.sum(0);
+  out->refine_ms = k->tm_dir.sum(1);
+  out->kkt_err_ms = k->tm_dir.sum(2);
+  out->direction_ms = k->tm_dir.sum(3);
+  out->n_solves = k->n_solves;
+  return OKKT_OK;
 }
 
 int okkt_kkt_ipopt_strategy(okkt_kkt_handle k, double delta_prev, const okkt_kkt_pars* pars, int32_t* num_fac_out, double* delta_out) {
@@ -637,7 +849,7 @@ int okkt_kkt_ipopt_strategy(okkt_kkt_handle k, double delta_prev, const okkt_kkt
   *delta_out = delta;
   if (tau > 0.0) {
     tau = 0.0;
-    rc = okkt_kkt_factor(k, delta, nullptr);
+    rc = okkt_kkt_factor_trial(k, delta, nullptr);   // a failed attempt is discarded: it may stop early
     if (rc < 0) return rc;
     ++num_fac;
     if (rc == 1) { *num_fac_out = num_fac; *delta_out = delta; return 1; }
@@ -649,7 +861,7 @@ int okkt_kkt_ipopt_strategy(okkt_kkt_handle k, double delta_prev, const okkt_kkt
     } else {
       delta = delta * P.delta_inc;
     }
-    rc = okkt_kkt_factor(k, delta, nullptr);
+    rc = okkt_kkt_factor_trial(k, delta, nullptr);   // a failed attempt is discarded: it may stop early
     if (rc < 0) return rc;
     ++num_fac;
     *num_fac_out = num_fac;
@@ -663,72 +875,111 @@ int okkt_kkt_ipopt_strategy(okkt_kkt_handle k, double delta_prev, const okkt_kkt
 int okkt_kkt_system_rhs(okkt_kkt_handle k, const double* J_nzval_cur, const double* grad, const double* cons,
                         const double* s, const double* y, double mu, double a_norm_penalty,
                         double eta_P, double eta_D, double eta_mu, double* dual_r, double* primal_r, double* comp_r) {
-  if (!k || !grad || !cons || !s || !y || !dual_r || !primal_r || !comp_r) return OKKT_ERR_INVALID;
+  if (!k || !grad || !cons || !s || !y) return OKKT_ERR_INVALID;
   if (!k->structured) return kk_fail(k, OKKT_ERR_INVALID, "structure not set");
+  if (!k->formed) return kk_fail(k, OKKT_ERR_INVALID, "form_system has not been called");
   hipStream_t st = kk_stream(k);
   const int64_t n = k->n, m = k->m;
   // J of the CURRENT iterate (may differ from the factorised one in correction steps, one_phase.jl:262-279)
   const double* Jx = k->Jx;
+  k->cur_Jcsr = k->Jcsr;
   if (J_nzval_cur && k->nnzJ) {
     if (!k->Jcur) { int rc2 = kk_alloc(k, (size_t)k->nnzJ, &k->Jcur); if (rc2 != OKKT_OK) return rc2; }   // kept for the life of the handle
     KK_TRY(k, hipMemcpyAsync(k->Jcur, J_nzval_cur, (size_t)k->nnzJ * 8, hipMemcpyHostToDevice, st));
     Jx = k->Jcur;
+    if (k->kind == OKKT_KKT_SCHUR_DIRECT) {     // eval_jac_prod(current_it, dir.x) needs the rows of that Jacobian
+      if (!k->Jcur_csr) { int rc2 = kk_alloc(k, (size_t)k->nnzJ, &k->Jcur_csr); if (rc2 != OKKT_OK) return rc2; }
+      hipLaunchKernelGGL(k_gather, grid1(k->nnzJ), dim3(256), 0, st, k->nnzJ, k->Jrmap, k->Jcur, k->Jcur_csr);
+      k->cur_Jcsr = k->Jcur_csr;
+    }
   }
+  k->cur_Jx = Jx;
   if (n) KK_TRY(k, hipMemcpyAsync(k->vn1, grad, (size_t)n * 8, hipMemcpyHostToDevice, st));
   if (m) {
     KK_TRY(k, hipMemcpyAsync(k->vm1, cons, (size_t)m * 8, hipMemcpyHostToDevice, st));
-    KK_TRY(k, hipMemcpyAsync(k->big1, s, (size_t)m * 8, hipMemcpyHostToDevice, st));
-    KK_TRY(k, hipMemcpyAsync(k->big2, y, (size_t)m * 8, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_fill, grid1(m), dim3(256), 0, st, m, 1.0, k->vm2);
+    KK_TRY(k, hipMemcpyAsync(k->cur_s, s, (size_t)m * 8, hipMemcpyHostToDevice, st));
+    KK_TRY(k, hipMemcpyAsync(k->cur_y, y, (size_t)m * 8, hipMemcpyHostToDevice, st));
   }
-  if (n) {
-    spmv_JT(k, Jx, k->big2, k->vn2);   // J' y
-    spmv_JT(k, Jx, k->vm2, k->vn3);    // J' 1
-    hipLaunchKernelGGL(k_rhs_dual, grid1(n), dim3(256), 0, st, n, k->vn1, k->vn2, k->vn3, (mu * eta_mu) * a_norm_penalty, 1.0 - eta_D, k->rD);
-    KK_TRY(k, hipMemcpyAsync(dual_r, k->rD, (size_t)n * 8, hipMemcpyDeviceToHost, st));
-  }
+  k->tm_rhs.reset();
+  const size_t e0 = k->tm_rhs.mark(st);
+  SEG_LAUNCH(k_rhs_dual_seg, k->lprJc, n, st, n, k->Jp, k->Ji, Jx, k->cur_y, k->vn1, (mu * eta_mu) * a_norm_penalty, 1.0 - eta_D, k->rD);
   if (m) {
-    hipLaunchKernelGGL(k_rhs_pc, grid1(m), dim3(256), 0, st, m, k->vm1, k->big1, k->big2, 1.0 - eta_P, mu * eta_mu, k->rP, k->rC);
-    KK_TRY(k, hipMemcpyAsync(primal_r, k->rP, (size_t)m * 8, hipMemcpyDeviceToHost, st));
-    KK_TRY(k, hipMemcpyAsync(comp_r, k->rC, (size_t)m * 8, hipMemcpyDeviceToHost, st));
+    hipLaunchKernelGGL(k_rhs_pc, grid1(m), dim3(256), 0, st, m, k->vm1, k->cur_s, k->cur_y, 1.0 - eta_P, mu * eta_mu, k->rP, k->rC);
+    hipLaunchKernelGGL(k_div, grid1(m), dim3(256), 0, st, m, k->cur_y, k->cur_s, k->cur_sig);   // Sigma of the current iterate (schur_direct.jl:47)
   }
+  const size_t e1 = k->tm_rhs.mark(st);
+  k->tm_rhs.seg(0, e0, e1);
+  if (n && dual_r) KK_TRY(k, hipMemcpyAsync(dual_r, k->rD, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+  if (m && primal_r) KK_TRY(k, hipMemcpyAsync(primal_r, k->rP, (size_t)m * 8, hipMemcpyDeviceToHost, st));
+  if (m && comp_r) KK_TRY(k, hipMemcpyAsync(comp_r, k->rC, (size_t)m * 8, hipMemcpyDeviceToHost, st));
   KK_TRY(k, hipStreamSynchronize(st));
+  KK_TRY(k, hipGetLastError());
+  k->have_cur = true;
+  k->have_rhs = true;
   return OKKT_OK;
 }
 
 int okkt_kkt_compute_direction(okkt_kkt_handle k, const double* dual_r, const double* primal_r, const double* comp_r,
                                int32_t ItRefine_Num, double* dx, double* dy, double* ds, okkt_kkt_error* err_out) {
-  if (!k || !dual_r || !primal_r || !comp_r || !dx || !dy || !ds) return OKKT_ERR_INVALID;
+  if (!k) return OKKT_ERR_INVALID;
+  const bool host_rhs = dual_r || primal_r || comp_r;
+  if (host_rhs && (!dual_r || !primal_r || !comp_r)) return kk_fail(k, OKKT_ERR_INVALID, "the rhs triple is given as three host vectors or as three NULLs (resident rhs)");
+  const bool host_dir = dx || dy || ds;
+  if (host_dir && (!dx || !dy || !ds)) return kk_fail(k, OKKT_ERR_INVALID, "dx, dy, ds: three host vectors or three NULLs");
   if (!k->factored) return kk_fail(k, OKKT_ERR_INVALID, "kkt solver not ready to compute direction!");  // kkt_system_solver.jl:181-183
+  if (!k->ls->factored)
+    return kk_fail(k, OKKT_ERR_INVALID, "the last factorisation was a discarded trial of the delta loop (it stopped early): factor! again before a direction");
+  if (!host_rhs && !k->have_rhs) return kk_fail(k, OKKT_ERR_INVALID, "no resident rhs: okkt_kkt_system_rhs has not been called");
+  const bool direct = k->kind == OKKT_KKT_SCHUR_DIRECT;
+  if (direct && !k->have_cur) return kk_fail(k, OKKT_ERR_INVALID, "Schur_KKT_solver_direct reads current_it: kkt_associate_rhs! (okkt_kkt_system_rhs) has not been called");
   hipStream_t st = kk_stream(k);
   const int64_t n = k->n, m = k->m;
-  int rc;
-  if (n) KK_TRY(k, hipMemcpyAsync(k->rD, dual_r, (size_t)n * 8, hipMemcpyHostToDevice, st));
-  if (m) {
-    KK_TRY(k, hipMemcpyAsync(k->rP, primal_r, (size_t)m * 8, hipMemcpyHostToDevice, st));
-    KK_TRY(k, hipMemcpyAsync(k->rC, comp_r, (size_t)m * 8, hipMemcpyHostToDevice, st));
-  }
-  if (k->kind == OKKT_KKT_SCHUR) {
-    // schur.jl:89-128 + solver_schur_rhs :131-182
-    if (m) hipLaunchKernelGGL(k_schur_t1, grid1(m), dim3(256), 0, st, m, k->rP, k->rC, k->sig, k->s, k->vm1);
-    if (n) {
-      spmv_JT(k, k->Jx, k->vm1, k->vn1);
-      hipLaunchKernelGGL(k_add, grid1(n), dim3(256), 0, st, n, k->rD, k->vn1, k->vn2);   // vn2 = schur_rhs
-      KK_TRY(k, hipMemsetAsync(k->dx, 0, (size_t)n * 8, st));
-      KK_TRY(k, hipMemcpyAsync(k->big1, k->vn2, (size_t)n * 8, hipMemcpyDeviceToDevice, st));   // res_old
+  std::string e;
+  if (host_rhs) {
+    if (n) KK_TRY(k, hipMemcpyAsync(k->rD, dual_r, (size_t)n * 8, hipMemcpyHostToDevice, st));
+    if (m) {
+      KK_TRY(k, hipMemcpyAsync(k->rP, primal_r, (size_t)m * 8, hipMemcpyHostToDevice, st));
+      KK_TRY(k, hipMemcpyAsync(k->rC, comp_r, (size_t)m * 8, hipMemcpyHostToDevice, st));
     }
+    k->have_rhs = true;
+  }
+  okkt_kkt_s::Timer& T = k->tm_dir;
+  T.reset();
+  k->n_solves = 0;
+  const size_t t_begin = T.mark(st);
+  size_t t_last = t_begin;
+  auto lap = [&](int tag) { const size_t t = T.mark(st); T.seg(tag, t_last, t); t_last = t; };   // tags: 0 solve, 1 vector work, 2 N err
+  auto solve = [&](const double* rhs, double* sol, bool accumulate) -> int {
+    lap(1);
+    const int rc2 = solver_solve_enqueue(k->ls, rhs, sol, 1, accumulate);
+    lap(0);
+    ++k->n_solves;
+    return rc2;
+  };
+  int rc;
+  if (k->kind == OKKT_KKT_SCHUR || direct) {
+    // schur.jl:89-128 / schur_direct.jl:32-66 + solver_schur_rhs schur.jl:131-182.  The rhs terms, dy and ds take y, s, J of
+    // factor_it (schur) or of current_it (direct); the refinement always works on the factorised system.
+    const double* ys = direct ? k->cur_y : k->y;
+    const double* ss = direct ? k->cur_s : k->s;
+    const double* sg = direct ? k->cur_sig : k->sig;
+    const double* Jc = direct ? k->cur_Jx : k->Jx;
+    const double* Jr = direct ? k->cur_Jcsr : k->Jcsr;
+    if (m) hipLaunchKernelGGL(k_schur_t1, grid1(m), dim3(256), 0, st, m, k->rP, k->rC, sg, ss, k->vm1);
+    // vn2 = schur_rhs = dual_r + J' y_
+    SEG_LAUNCH(k_seg_spmv, k->lprJc, n, st, n, k->Jp, k->Ji, Jc, k->vm1, (const double*)nullptr, k->rD, 1.0, k->vn2);
+    if (n) KK_TRY(k, hipMemsetAsync(k->dx, 0, (size_t)n * 8, st));
     for (int it = 0; it < ItRefine_Num; ++it) {
-      rc = solver_solve_device(k->ls, k->big1, k->big2, 1);
+      rc = solve(it == 0 ? k->vn2 : k->big1, k->dx, true);          // dir_x .+= ls_solve(res_old)
       if (rc != OKKT_OK) return kk_check_ls(k, rc, "ls_solve");
-      if (n) hipLaunchKernelGGL(k_add, grid1(n), dim3(256), 0, st, n, k->dx, k->big2, k->dx);
-      if (m) { spmv_J(k, k->dx, k->vm1); hipLaunchKernelGGL(k_mul, grid1(m), dim3(256), 0, st, m, k->sig, k->vm1, k->vm2); }
-      if (n) {
-        spmv_JT(k, k->Jx, k->vm2, k->vn1);    // jac_res
-        spmv_H(k, k->dx, k->vn3);             // hess_product
-        hipLaunchKernelGGL(k_refine_res, grid1(n), dim3(256), 0, st, n, k->vn2, k->vn1, k->vn3, k->dx, k->delta, k->big1);
+      // the residual behind the last solve is only printed by the reference (output_level >= 4): not evaluated
+      if (it + 1 < ItRefine_Num && n) {
+        SEG_LAUNCH(k_seg_spmv, k->lprJr, m, st, m, k->Jrp, k->Jrj, k->Jcsr, k->dx, k->sig, (const double*)nullptr, 0.0, k->vm2);   // Sigma .* (J dx)
+        SEG_LAUNCH(k_schur_resid, k->lprJc, n, st, n, k->Jp, k->Ji, k->Jx, k->vm2, k->Hrp, k->Hrj, k->Hcsr, k->Hp, k->Hi, k->Hx, k->Hdiag, k->dx, k->vn2,
+                   k->delta, k->big1);
       }
     }
-    if (m) { spmv_J(k, k->dx, k->vm1); hipLaunchKernelGGL(k_schur_dyds, grid1(m), dim3(256), 0, st, m, k->vm1, k->rP, k->rC, k->y, k->sig, k->dy, k->ds); }
+    SEG_LAUNCH(k_schur_dyds, k->lprJr, m, st, m, k->Jrp, k->Jrj, Jr, k->dx, k->rP, k->rC, ys, ss, sg, direct ? 1 : 0, k->dy, k->ds);
   } else if (k->kind == OKKT_KKT_CLEVER_SYMMETRIC) {
     // compute_direction_implementation!(::Clever_Symmetric_KKT_solver), clever_symmetric.jl:417-492
     const int64_t mn = k->m_new, dim = n + mn;
@@ -739,72 +990,66 @@ int okkt_kkt_compute_direction(okkt_kkt_handle k, const double* dual_r, const do
       KK_TRY(k, hipMemsetAsync(k->big2, 0, (size_t)dim * 8, st));                                                  // sol
     }
     for (int it = 0; it < ItRefine_Num; ++it) {       // ls_solve with refinement, clever_symmetric.jl:402-415
-      if (it == 0) { if (dim) KK_TRY(k, hipMemcpyAsync(k->big3, k->big1, (size_t)dim * 8, hipMemcpyDeviceToDevice, st)); }
-      else if (dim) {
+      if (it > 0 && dim) {
         hipLaunchKernelGGL(k_spmv_symlower, grid1(dim), dim3(256), 0, st, dim, k->dAp, k->dAi, k->Avals, k->Arp, k->Arj, k->Armap, k->big2, k->big4);
         hipLaunchKernelGGL(k_clever_res, grid1(dim), dim3(256), 0, st, dim, n, k->delta, k->big1, k->big4, k->big2, k->big3);
       }
-      rc = solver_solve_device(k->ls, k->big3, k->big4, 1);
+      rc = solve(it == 0 ? k->big1 : k->big3, k->big2, true);       // sol += ls_solve(err)
       if (rc != OKKT_OK) return kk_check_ls(k, rc, "ls_solve");
-      if (dim) hipLaunchKernelGGL(k_add, grid1(dim), dim3(256), 0, st, dim, k->big2, k->big4, k->big2);
     }
     if (dim) hipLaunchKernelGGL(k_clever_unscale, grid1(dim), dim3(256), 0, st, n, mn, k->big2, k->Dres, k->dx, k->big4);   // big4 = v
     if (m) {
       hipLaunchKernelGGL(k_clever_y, grid1(m), dim3(256), 0, st, m, k->row_grp, k->row_ratio, k->s, k->y, k->vm1, k->crhs, k->gU, k->big4, k->dy);
-      spmv_J(k, k->dx, k->vm2);
-      hipLaunchKernelGGL(k_sub, grid1(m), dim3(256), 0, st, m, k->vm2, k->rP, k->ds);
+      SEG_LAUNCH(k_seg_spmv, k->lprJr, m, st, m, k->Jrp, k->Jrj, k->Jcsr, k->dx, (const double*)nullptr, k->rP, -1.0, k->ds);   // J dx - primal_r
     }
   } else {
     // symmetric.jl:59-83
     if (n + m) hipLaunchKernelGGL(k_sym_rhs, grid1(n + m), dim3(256), 0, st, n, m, k->rD, k->rP, k->rC, k->y, k->big1);
-    rc = solver_solve_device(k->ls, k->big1, k->big2, 1);
+    rc = solve(k->big1, k->big2, false);
     if (rc != OKKT_OK) return kk_check_ls(k, rc, "ls_solve");
     if (n + m) hipLaunchKernelGGL(k_sym_split, grid1(n + m), dim3(256), 0, st, n, m, k->big2, k->dx, k->dy);
-    if (m) { spmv_J(k, k->dx, k->vm1); hipLaunchKernelGGL(k_sub, grid1(m), dim3(256), 0, st, m, k->vm1, k->rP, k->ds); }
+    SEG_LAUNCH(k_seg_spmv, k->lprJr, m, st, m, k->Jrp, k->Jrj, k->Jcsr, k->dx, (const double*)nullptr, k->rP, -1.0, k->ds);       // J dx - primal_r
   }
-  // update_kkt_error! (p = Inf), kkt_system_solver.jl:67-96
+  lap(1);
+  // update_kkt_error! (p = Inf), kkt_system_solver.jl:67-96: always with the matrices of factor_it
   okkt_kkt_error E;
   std::memset(&E, 0, sizeof(E));
-  double eD = 0, eP = 0, eMu = 0, nD = 0, nP = 0, nC = 0;
-  if (n) {
-    spmv_H(k, k->dx, k->vn1);
-    spmv_JT(k, k->Jx, k->dy, k->vn3);
-    hipLaunchKernelGGL(k_errD, grid1(n), dim3(256), 0, st, n, k->delta, k->dx, k->vn1, k->vn3, k->rD, k->big1);
-    kk_reduce_enqueue(k, n, k->big1, 1, 0);
-    kk_reduce_enqueue(k, n, k->rD, 1, 1);
+  const int64_t nbD = n ? (int64_t)seg_grid(n, k->lprJc).x : 0, nbM = m ? (int64_t)seg_grid(m, k->lprJr).x : 0;
+  SEG_LAUNCH(k_err_dual, k->lprJc, n, st, n, k->Jp, k->Ji, k->Jx, k->dy, k->Hrp, k->Hrj, k->Hcsr, k->Hp, k->Hi, k->Hx, k->Hdiag, k->dx, k->rD, k->delta, k->part);
+  SEG_LAUNCH(k_err_pc, k->lprJr, m, st, m, k->Jrp, k->Jrj, k->Jcsr, k->dx, k->ds, k->dy, k->s, k->y, k->rP, k->rC, k->part + nbD * 8);
+  hipLaunchKernelGGL(k_err_final, dim3(1), dim3(256), 0, st, nbD, nbM, k->part, k->red);
+  lap(2);
+  T.seg(3, t_begin, t_last);
+  double red[6] = {0, 0, 0, 0, 0, 0};
+  KK_TRY(k, hipMemcpyAsync(red, k->red, sizeof(red), hipMemcpyDeviceToHost, st));
+  if (host_dir) {
+    if (n) KK_TRY(k, hipMemcpyAsync(dx, k->dx, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+    if (m) {
+      KK_TRY(k, hipMemcpyAsync(dy, k->dy, (size_t)m * 8, hipMemcpyDeviceToHost, st));
+      KK_TRY(k, hipMemcpyAsync(ds, k->ds, (size_t)m * 8, hipMemcpyDeviceToHost, st));
+    }
   }
-  if (m) {
-    spmv_J(k, k->dx, k->vm1);
-    hipLaunchKernelGGL(k_errP, grid1(m), dim3(256), 0, st, m, k->vm1, k->ds, k->rP, k->vm2);
-    kk_reduce_enqueue(k, m, k->vm2, 1, 2);
-    hipLaunchKernelGGL(k_errMu, grid1(m), dim3(256), 0, st, m, k->s, k->dy, k->y, k->ds, k->rC, k->vm2);
-    kk_reduce_enqueue(k, m, k->vm2, 1, 3);
-    kk_reduce_enqueue(k, m, k->rP, 1, 4);
-    kk_reduce_enqueue(k, m, k->rC, 1, 5);
-  }
-  {
-    // the six norms with one copy and one synchronisation
-    double red[6] = {0, 0, 0, 0, 0, 0};
-    KK_TRY(k, hipMemcpyAsync(red, k->red, sizeof(red), hipMemcpyDeviceToHost, st));
-    KK_TRY(k, hipStreamSynchronize(st));
-    if (n) { eD = red[0]; nD = red[1]; }
-    if (m) { eP = red[2]; eMu = red[3]; nP = red[4]; nC = red[5]; }
-  }
+  KK_TRY(k, hipStreamSynchronize(st));       // the only synchronisation of the call
+  KK_TRY(k, hipGetLastError());
   auto mx = [](double a, double b) { return (a != a || b != b) ? NAN : std::max(a, b); };
-  E.error_D = eD; E.error_P = eP; E.error_mu = eMu;
-  E.overall = mx(mx(eD, eP), eMu);
-  E.rhs_norm = mx(mx(nD, nP), nC);
+  E.error_D = red[0]; E.error_P = red[2]; E.error_mu = red[3];
+  E.overall = mx(mx(red[0], red[2]), red[3]);
+  E.rhs_norm = mx(mx(red[1], red[4]), red[5]);
   E.ratio = E.overall / E.rhs_norm;
   if (err_out) *err_out = E;
-  if (n) KK_TRY(k, hipMemcpyAsync(dx, k->dx, (size_t)n * 8, hipMemcpyDeviceToHost, st));
-  if (m) {
-    KK_TRY(k, hipMemcpyAsync(dy, k->dy, (size_t)m * 8, hipMemcpyDeviceToHost, st));
-    KK_TRY(k, hipMemcpyAsync(ds, k->ds, (size_t)m * 8, hipMemcpyDeviceToHost, st));
-  }
-  KK_TRY(k, hipStreamSynchronize(st));
-  KK_TRY(k, hipGetLastError());
   k->have_dir = true;
   k->have_dxnorm = false;
+  return OKKT_OK;
+}
+
+int okkt_kkt_get_direction(okkt_kkt_handle k, double* dx, double* dy, double* ds) {
+  if (!k) return OKKT_ERR_INVALID;
+  if (!k->have_dir) return kk_fail(k, OKKT_ERR_INVALID, "no resident direction");
+  hipStream_t st = kk_stream(k);
+  if (k->n && dx) KK_TRY(k, hipMemcpyAsync(dx, k->dx, (size_t)k->n * 8, hipMemcpyDeviceToHost, st));
+  if (k->m && dy) KK_TRY(k, hipMemcpyAsync(dy, k->dy, (size_t)k->m * 8, hipMemcpyDeviceToHost, st));
+  if (k->m && ds) KK_TRY(k, hipMemcpyAsync(ds, k->ds, (size_t)k->m * 8, hipMemcpyDeviceToHost, st));
+  KK_TRY(k, hipStreamSynchronize(st));
   return OKKT_OK;
 }
 

@@ -38,6 +38,40 @@ struct okkt_kkt_s {
   // step-side kernels (linesearch.hip): staged host vectors and reduction partials, allocated on first use
   double *ls_m[4] = {nullptr, nullptr, nullptr, nullptr}, *ls_n[2] = {nullptr, nullptr}, *ls_part = nullptr, *ls_out = nullptr;
   double* Jcur = nullptr; // Jacobian values of a current iterate that differs from the factorised one
+  // CSR-ordered copies of the values (refreshed by form_system): the row-wise products read values and column indices
+  // contiguously instead of gathering through the CSC -> CSR map
+  double *Jcsr = nullptr, *Hcsr = nullptr, *Hdiag = nullptr, *Jcur_csr = nullptr;
+  int lprJr = 16, lprJc = 16, lprH = 8;      // lanes per row / column of the segmented products (from the average lengths)
+  // current iterate of the last okkt_kkt_system_rhs (kkt_associate_rhs!, schur.jl:34-45): Schur_KKT_solver_direct reads it
+  double *cur_s = nullptr, *cur_y = nullptr, *cur_sig = nullptr;
+  const double* cur_Jx = nullptr;            // CSC values of the current iterate's Jacobian (Jx or Jcur)
+  const double* cur_Jcsr = nullptr;          // the same in CSR order
+  bool have_cur = false, have_rhs = false;
+  double* part = nullptr;                    // per-workgroup partial maxima of the N-err kernels
+  int64_t part_blocks = 0;
+  // device timers: (tag, start, stop) event segments of the last call of each kind, summed per tag on request
+  struct Timer {
+    std::vector<hipEvent_t> ev;
+    size_t used = 0;
+    struct Seg { int tag; size_t a, b; };
+    std::vector<Seg> segs;
+    void reset() { used = 0; segs.clear(); }
+    size_t mark(hipStream_t st) {
+      if (used == ev.size()) { hipEvent_t e = nullptr; if (hipEventCreate(&e) != hipSuccess) return used; ev.push_back(e); }
+      (void)hipEventRecord(ev[used], st);
+      return used++;
+    }
+    void seg(int tag, size_t a, size_t b) { if (a < used && b < used) segs.push_back(Seg{tag, a, b}); }
+    double sum(int tag) const {
+      double tot = 0.0;
+      for (const Seg& g : segs) { float ms = 0; if (g.tag == tag && hipEventElapsedTime(&ms, ev[g.a], ev[g.b]) == hipSuccess) tot += ms; }
+      return tot;
+    }
+    void destroy() { for (hipEvent_t e : ev) (void)hipEventDestroy(e); ev.clear(); reset(); }
+  };
+  Timer tm_form, tm_factor, tm_rhs, tm_dir;
+  double t_factor_ms = 0.0;
+  int n_solves = 0;
   // ---- clever symmetric (clever_symmetric.jl): parallel-row groups and the reduced system
   bool indexed = false;
   int64_t m_new = 0;

@@ -148,7 +148,8 @@ std::string numeric_dist_x(Numeric& N, int mode, double* d_buf);
 std::string numeric_solve_enqueue(Numeric& N);
 // permute helpers: xwork[k] = rhs[perm[k]]  /  sol[perm[k]] = xwork[k]
 void launch_permute_in(const Numeric& N, const double* d_rhs);
-void launch_permute_out(const Numeric& N, double* d_sol);
+// accumulate: sol[perm[k]] += xwork[k] (the refinement loops' dir_x .+= ls_solve(res), schur.jl:163)
+void launch_permute_out(const Numeric& N, double* d_sol, bool accumulate = false);
 // diagadd[iperm] = (orig index < nshift) ? delta : 0, via perm
 void launch_set_shift(const Numeric& N, double delta, int64_t nshift);
 

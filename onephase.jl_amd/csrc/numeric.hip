@@ -1296,9 +1296,9 @@ __global__ void k_permute_in(int n, const int* __restrict__ perm, const double* 
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) x[i] = rhs[perm[i]];
 }
-__global__ void k_permute_out(int n, const int* __restrict__ perm, const double* __restrict__ x, double* __restrict__ sol) {
+__global__ void k_permute_out(int n, const int* __restrict__ perm, const double* __restrict__ x, double* __restrict__ sol, int accumulate) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) sol[perm[i]] = x[i];
+  if (i < n) { const int d = perm[i]; sol[d] = accumulate ? sol[d] + x[i] : x[i]; }
 }
 __global__ void k_set_shift(int n, const int* __restrict__ perm, double delta, int nshift, double* __restrict__ diagadd) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2338,10 +2338,12 @@ std::string numeric_solve_enqueue(Numeric& N) {
 // ---- multi-GPU exchange helpers (contribution blocks / vectors of the cut, solution pieces) -------------
 __global__ void k_pack_cb(DevPlan P, const int* __restrict__ bnd, const int64_t* __restrict__ off, const int* __restrict__ owner,
                           int part, int unpack, double* __restrict__ buf) {
-  // one workgroup per boundary front: its r x r contribution block <-> a dense r x r slot of the buffer
+  // one workgroup per boundary front: its r x r contribution block <-> a dense r x r slot of the buffer.
+  // Packing writes EVERY slot: the owner its block, everybody else zeros -- the reduce(sum) over the parts is exact and
+  // the buffer needs no zero fill beforehand (no ordering hazard between a caller's fill and this stream)
   const int s = bnd[blockIdx.x];
   const bool mine = owner[s] == part;
-  if (unpack ? mine : !mine) return;
+  if (unpack && mine) return;
   const int k = P.sn_col0[s + 1] - P.sn_col0[s];
   const int f = (int)(P.row_ptr[s + 1] - P.row_ptr[s]);
   const int r = f - k;
@@ -2349,19 +2351,19 @@ __global__ void k_pack_cb(DevPlan P, const int* __restrict__ bnd, const int64_t*
   double* B = buf + off[blockIdx.x];
   for (int64_t idx = threadIdx.x; idx < (int64_t)r * r; idx += blockDim.x) {
     const int j = (int)(idx / r), i = (int)(idx - (int64_t)j * r);
-    if (i < j) continue;
-    if (unpack) F[(size_t)j * f + i] = B[idx]; else B[idx] = F[(size_t)j * f + i];
+    if (unpack) { if (i >= j) F[(size_t)j * f + i] = B[idx]; }
+    else B[idx] = (mine && i >= j) ? F[(size_t)j * f + i] : 0.0;
   }
 }
 __global__ void k_pack_cv(DevPlan P, const int* __restrict__ bnd, const int64_t* __restrict__ off, const int* __restrict__ owner,
                           int part, int unpack, double* __restrict__ buf) {
   const int s = bnd[blockIdx.x];
   const bool mine = owner[s] == part;
-  if (unpack ? mine : !mine) return;
+  if (unpack && mine) return;
   const int r = (int)(P.rel_ptr[s + 1] - P.rel_ptr[s]);
   double* cv = P.cv + P.cv_pos[s];
   double* B = buf + off[blockIdx.x];
-  for (int i = threadIdx.x; i < r; i += blockDim.x) { if (unpack) cv[i] = B[i]; else B[i] = cv[i]; }
+  for (int i = threadIdx.x; i < r; i += blockDim.x) { if (unpack) cv[i] = B[i]; else B[i] = mine ? cv[i] : 0.0; }
 }
 // mode 0: buf[col] = xwork[col] (all);  1: xwork[col] = buf[col] for top columns only;
 // mode 2: sol[perm[col]] = owned(col) ? xwork[col] : 0  (owned: my part, or top when I am part 0)
@@ -2392,9 +2394,9 @@ void launch_permute_in(const Numeric& N, const double* d_rhs) {
   const int n = N.d.n;
   if (n) hipLaunchKernelGGL(k_permute_in, dim3((n + 255) / 256), dim3(256), 0, N.stream, n, N.d.perm, d_rhs, N.d.xwork);
 }
-void launch_permute_out(const Numeric& N, double* d_sol) {
+void launch_permute_out(const Numeric& N, double* d_sol, bool accumulate) {
   const int n = N.d.n;
-  if (n) hipLaunchKernelGGL(k_permute_out, dim3((n + 255) / 256), dim3(256), 0, N.stream, n, N.d.perm, N.d.xwork, d_sol);
+  if (n) hipLaunchKernelGGL(k_permute_out, dim3((n + 255) / 256), dim3(256), 0, N.stream, n, N.d.perm, N.d.xwork, d_sol, accumulate ? 1 : 0);
 }
 void launch_set_shift(const Numeric& N, double delta, int64_t nshift) {
   const int n = N.d.n;

@@ -46,6 +46,9 @@ namespace okkt {
 int solver_factor_device(okkt_solver_s* h, const double* d_vals, int64_t n, int64_t m, int sym_kind,
                          okkt_inertia* out);
 int solver_solve_device(okkt_solver_s* h, const double* d_rhs, double* d_sol, int64_t nrhs);
+// the same without synchronisation or timing (the KKT level strings solves and vector kernels together on the stream);
+// accumulate: d_sol += F \ d_rhs
+int solver_solve_enqueue(okkt_solver_s* h, const double* d_rhs, double* d_sol, int64_t nrhs, bool accumulate);
 int solver_set_error(okkt_solver_s* h, int code, const std::string& msg);
 int solver_ensure_numeric(okkt_solver_s* h);
 }  // namespace okkt

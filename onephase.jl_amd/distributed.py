@@ -273,7 +273,7 @@ def speculative_ipopt_strategy(comm, kkt_solvers, it, sync_factor=True):
             raise OkktError("max it")                       # error("max it"), delta_strategy.jl:113
         local = []
         for k, r in zip(kkt_solvers, comm.ranks):
-            local.append(k.factor_b(cands[r]) if r < len(cands) else -1)
+            local.append(k.factor_b(cands[r], trial=True) if r < len(cands) else -1)    # a candidate that fails is discarded
         flags = _allgather_flags(comm, local)
         for j, d in enumerate(cands):
             if flags[j] == 1:

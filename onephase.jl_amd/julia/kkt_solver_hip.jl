@@ -17,14 +17,18 @@ mutable struct HIP_KKT_solver <: abstract_KKT_system_solver
     ready::Symbol
     Q::SparseMatrixCSC{Float64,Int64}           # left empty: the assembled matrix lives in HBM
     handle::Ptr{Cvoid}
-    kind::Cint                                   # 0 = :schur, 1 = :symmetric, 2 = :clever_symmetric
+    kind::Cint                                   # 0 = :schur, 1 = :symmetric, 2 = :clever_symmetric, 3 = :schur_direct
     pattern_set::Bool
+    current_it::Class_iterate                    # iterate of the last kkt_associate_rhs! (schur.jl:34-45)
+    reduct_factors::Class_reduction_factors
+    rhs_resident::Bool                           # k.rhs is the triple okkt_kkt_system_rhs left in HBM
 
     function HIP_KKT_solver(kind::Symbol)
         this = new()
         this.ready = :not_ready
-        this.kind = kind == :schur ? 0 : (kind == :symmetric ? 1 : 2)
+        this.kind = Dict(:schur => 0, :symmetric => 1, :clever_symmetric => 2, :schur_direct => 3)[kind]
         this.pattern_set = false
+        this.rhs_resident = false
         h = Ref{Ptr{Cvoid}}(C_NULL)
         rc = ccall((:okkt_kkt_create, OKKT_LIB), Cint, (Ref{Ptr{Cvoid}}, Ptr{Cvoid}, Cint), h, C_NULL, this.kind)
         rc == 0 || error("okkt_kkt_create failed with code $rc")
@@ -32,6 +36,17 @@ mutable struct HIP_KKT_solver <: abstract_KKT_system_solver
         finalizer(s -> ccall((:okkt_kkt_destroy, OKKT_LIB), Cint, (Ptr{Cvoid},), s.handle), this)
         return this
     end
+end
+
+struct OkktKktPars      # okkt_kkt_pars of include/okkt.h
+    delta_start::Float64
+    delta_min::Float64
+    delta_max::Float64
+    delta_inc::Float64
+    delta_dec::Float64
+    delta_zero::Float64
+    ItRefine_Num::Int32
+    max_it::Int32
 end
 
 function kkt_hip_check(k::HIP_KKT_solver, what::String, rc)
@@ -87,6 +102,9 @@ function update_delta_vecs!(k::HIP_KKT_solver, delta_x_vec::Array{Float64,1}, de
     k.ready = :delta_updated
 end
 
+# factor!(kkt_solver, timer) -> factor_implementation!: a COMPLETE factorisation whatever the inertia flag, because the
+# failed-step branch of one_phase.jl:231-242 computes a direction from it even when the flag is 0.  The delta loop, which
+# throws failed attempts away, goes through ipopt_strategy! below (trial factorisations that may stop early).
 function factor_implementation!(k::HIP_KKT_solver, timer::class_advanced_timer)
     inert = Ref(OkktInertia(0, 0, 0, 0))
     delta = length(k.delta_x_vec) > 0 ? k.delta_x_vec[1] : 0.0
@@ -94,13 +112,54 @@ function factor_implementation!(k::HIP_KKT_solver, timer::class_advanced_timer)
         (Ptr{Cvoid}, Float64, Ref{OkktInertia}), k.handle, delta, inert)))
 end
 
+# ipopt_strategy! (delta_strategy.jl:37-114) for this solver type: the whole loop behind one ccall; (status, num_fac, delta)
+# are those of the reference's loop
+function ipopt_strategy!(iter::Class_iterate, k::HIP_KKT_solver, pars::Class_parameters, timer::class_advanced_timer)
+    num_fac = Ref{Int32}(0); delta = Ref{Float64}(0.0)
+    p = OkktKktPars(pars.delta.start, pars.delta.min, pars.delta.max, pars.delta.inc, pars.delta.dec, pars.delta.zero, Int32(pars.kkt.ItRefine_Num), Int32(500))
+    rc = kkt_hip_check(k, "okkt_kkt_ipopt_strategy", ccall((:okkt_kkt_ipopt_strategy, OKKT_LIB), Cint,
+        (Ptr{Cvoid}, Float64, Ref{OkktKktPars}, Ref{Int32}, Ref{Float64}), k.handle, get_delta(iter), p, num_fac, delta))
+    k.delta_x_vec = delta[] * ones(dim(iter)); k.delta_s_vec = zeros(ncon(iter))
+    k.ready = :factored
+    # the caller reads old_delta = get_delta(iter) and then calls set_delta(iter, new_delta) itself (one_phase.jl:203-206)
+    return rc == 1 ? :success : :failure, Int(num_fac[]), delta[]
+end
+
+# kkt_associate_rhs! (schur.jl:34-45, symmetric.jl: same body): System_rhs(iter, reduct_factors) evaluated on the device from
+# the iterate's cached gradient / constraint values; the triple stays in HBM for compute_direction! and is also copied
+# back, because the IPM reads kkt_solver.rhs (e.g. the merit function).  It also tells the library which iterate is
+# current_it, which Schur_KKT_solver_direct reads (schur_direct.jl:35-37).
+function kkt_associate_rhs!(k::HIP_KKT_solver, iter::Class_iterate, reduct_factors::Class_reduction_factors, timer::class_advanced_timer)
+    start_advanced_timer(timer, "KKT/rhs")
+    n = dim(iter); m = ncon(iter)
+    rD = zeros(n); rP = zeros(m); rC = zeros(m)
+    J = get_jac(iter)
+    Jcur = iter === k.factor_it ? C_NULL : pointer(J.nzval)     # NULL: the Jacobian values of form_system! are current
+    GC.@preserve J begin
+        kkt_hip_check(k, "okkt_kkt_system_rhs", ccall((:okkt_kkt_system_rhs, OKKT_LIB), Cint,
+            (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Float64, Float64, Float64, Float64, Float64,
+             Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+            k.handle, Jcur, get_grad(iter), get_cons(iter), get_s(iter), get_y(iter), get_mu(iter), iter.a_norm_penalty_par,
+            reduct_factors.P, reduct_factors.D, reduct_factors.mu, rD, rP, rC))
+    end
+    k.rhs = System_rhs(rD, rP, rC)
+    k.rhs_resident = true
+    k.dir.mu = -(1.0 - reduct_factors.mu) * get_mu(iter)
+    k.dir.primal_scale = -(1.0 - reduct_factors.P) * iter.point.primal_scale
+    k.reduct_factors = reduct_factors
+    k.current_it = iter
+    pause_advanced_timer(timer, "KKT/rhs")
+end
+
 function compute_direction_implementation!(k::HIP_KKT_solver, timer::class_advanced_timer)
     n = dim(k.factor_it); m = ncon(k.factor_it)
     dx = zeros(n); dy = zeros(m); ds = zeros(m)
     err = zeros(6)
+    # resident rhs: three NULLs (nothing crosses PCIe on the way in); a rhs the caller replaced on the host is uploaded
+    r = k.rhs_resident ? (C_NULL, C_NULL, C_NULL) : (pointer(k.rhs.dual_r), pointer(k.rhs.primal_r), pointer(k.rhs.comp_r))
     kkt_hip_check(k, "okkt_kkt_compute_direction", ccall((:okkt_kkt_compute_direction, OKKT_LIB), Cint,
         (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
-        k.handle, k.rhs.dual_r, k.rhs.primal_r, k.rhs.comp_r, Int32(k.pars.kkt.ItRefine_Num), dx, dy, ds, err))
+        k.handle, r[1], r[2], r[3], Int32(k.pars.kkt.ItRefine_Num), dx, dy, ds, err))
     k.dir.x = dx; k.dir.y = dy; k.dir.s = ds
     check_for_nan(k.dir)
     k.kkt_err_norm = Class_kkt_error(err[1], err[2], err[3], err[4], err[5], err[6])

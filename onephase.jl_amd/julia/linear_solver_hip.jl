@@ -47,8 +47,10 @@ function initialize!(solver::linear_solver_HIP)
         rc = ccall((:okkt_create, OKKT_LIB), Cint, (Ref{Ptr{Cvoid}}, Ptr{Cvoid}), h, C_NULL)   # NULL = default options
         rc == 0 || error("okkt_create failed with code $rc (no HIP device? the KKT path has no CPU fallback)")
         solver.handle = h[]
-        # ls_factor! returns only the flag: a factorisation with the wrong inertia may stop early (never solved with)
-        ccall((:okkt_set_early_exit, OKKT_LIB), Cint, (Ptr{Cvoid}, Cint), solver.handle, 1)
+        # Early exit stays OFF at this level: ls_factor! cannot know whether its caller will solve with a factorisation
+        # whose flag is 0 -- the refactorisation after a failed step does (one_phase.jl:231-242 -> take_step2!).  A caller
+        # that discards failed factors (a delta loop of its own) may switch it on around those calls:
+        #   ccall((:okkt_set_early_exit, OKKT_LIB), Cint, (Ptr{Cvoid}, Cint), solver.handle, 1)
         finalizer(finalize!, solver)
     end
 end

@@ -111,6 +111,14 @@ class Class_parameters:
         self.delta = self.delta or Class_delta_parameters()
 
 
+def _julia_max(*vals):
+    """max(a, b, c) as Julia evaluates it: NaN wins (Python's max would drop it depending on the position)."""
+    out = vals[0]
+    for v in vals[1:]:
+        out = v if (v != v or (out == out and v > out)) else out
+    return out
+
+
 def _csc(A):
     A = sp.csc_matrix(A)
     A.sort_indices()
@@ -119,9 +127,10 @@ def _csc(A):
 
 class HIP_KKT_solver:
     """abstract_KKT_system_solver backed by the device-resident KKT path
-    (kind = 'schur' | 'symmetric' | 'clever_symmetric')."""
+    (kind = 'schur' | 'schur_direct' | 'symmetric' | 'clever_symmetric')."""
 
-    _KINDS = {"schur": L.OKKT_KKT_SCHUR, "symmetric": L.OKKT_KKT_SYMMETRIC, "clever_symmetric": L.OKKT_KKT_CLEVER_SYMMETRIC}
+    _KINDS = {"schur": L.OKKT_KKT_SCHUR, "symmetric": L.OKKT_KKT_SYMMETRIC, "clever_symmetric": L.OKKT_KKT_CLEVER_SYMMETRIC,
+              "schur_direct": L.OKKT_KKT_SCHUR_DIRECT}
 
     def __init__(self, kind, pars=None, **opts):
         if kind not in self._KINDS:
@@ -141,6 +150,7 @@ class HIP_KKT_solver:
         self.delta_s_vec = None
         self.inertia = None
         self._pattern = None
+        self._resident_rhs = None
 
     # ---- initialize! (kkt_system_solver.jl:21-25)
     def initialize_b(self, intial_it):
@@ -247,16 +257,26 @@ class HIP_KKT_solver:
         self._delta = float(delta_x)
         self.ready = "delta_updated"
 
-    def factor_b(self, delta_x=None, delta_s=0.0, timer=None):
+    def factor_b(self, delta_x=None, delta_s=0.0, timer=None, trial=False):
+        """factor!(kkt_solver, delta_x[, delta_s]) -> inertia flag.  trial=True is the delta loop's use of it: the caller
+        discards a factorisation whose flag is 0, so it may stop early (okkt_kkt_factor_trial); the default is a complete
+        factorisation that a direction can be computed from whatever the flag (one_phase.jl:231-242)."""
         if delta_x is not None:
             self.update_delta_b(delta_x, delta_s)
         if self.ready != "delta_updated":
             raise OkktError(f"kkt solver not ready to factor kkt_solver.ready = {self.ready} != :delta_updated")
         self.ready = "factored"
         inert = L.OkktInertia()
-        rc = self._check(self._lib.okkt_kkt_factor(self._k, self._delta, C.byref(inert)), "okkt_kkt_factor")
+        fn = self._lib.okkt_kkt_factor_trial if trial else self._lib.okkt_kkt_factor
+        rc = self._check(fn(self._k, self._delta, C.byref(inert)), "okkt_kkt_factor")
         self.inertia = inert.as_tuple()
         return int(rc)
+
+    def timers(self):
+        """Device times of the phases of the last calls (okkt_kkt_timers; SURVEY.md section 5, tracing)."""
+        t = L.OkktKktTimers()
+        self._check(self._lib.okkt_kkt_get_timers(self._k, C.byref(t)), "okkt_kkt_get_timers")
+        return t.as_dict()
 
     # ---- kkt_associate_rhs! (kkt_system_solver.jl:167-176, schur.jl:34-45)
     def kkt_associate_rhs_b(self, it, eta, timer=None):
@@ -270,6 +290,7 @@ class HIP_KKT_solver:
                                                   it.mu, it.a_norm_penalty_par, eta.P, eta.D, eta.mu,
                                                   L.p_f64(rD), L.p_f64(rP), L.p_f64(rC)), "okkt_kkt_system_rhs")
         self.rhs = System_rhs(rD, rP, rC)
+        self._resident_rhs = self.rhs
         self.dir.mu = -(1.0 - eta.mu) * it.mu
         self.dir.primal_scale = -(1.0 - eta.P) * it.primal_scale
         self.reduct_factors = eta
@@ -282,8 +303,13 @@ class HIP_KKT_solver:
         n, m = self.factor_it.dim(), self.factor_it.ncon()
         dx, dy, ds = np.zeros(n), np.zeros(m), np.zeros(m)
         err = L.OkktKktError()
-        rD, rP, rC = L.f64(self.rhs.dual_r), L.f64(self.rhs.primal_r), L.f64(self.rhs.comp_r)
-        self._check(self._lib.okkt_kkt_compute_direction(self._k, L.p_f64(rD), L.p_f64(rP), L.p_f64(rC), self.pars.kkt.ItRefine_Num,
+        if self.rhs is self._resident_rhs:
+            # the triple that kkt_associate_rhs_b left in HBM: nothing crosses PCIe on the way in
+            a = (None, None, None)
+        else:
+            rD, rP, rC = L.f64(self.rhs.dual_r), L.f64(self.rhs.primal_r), L.f64(self.rhs.comp_r)
+            a = (L.p_f64(rD), L.p_f64(rP), L.p_f64(rC))
+        self._check(self._lib.okkt_kkt_compute_direction(self._k, a[0], a[1], a[2], self.pars.kkt.ItRefine_Num,
                                                          L.p_f64(dx), L.p_f64(dy), L.p_f64(ds), C.byref(err)),
                     "okkt_kkt_compute_direction")
         self.dir.x, self.dir.y, self.dir.s = dx, dy, ds
@@ -307,7 +333,14 @@ class HIP_KKT_solver:
             self._check(self._lib.okkt_kkt_system_rhs(self._k, L.p_f64(Jx) if Jx is not None else None, L.p_f64(grad), L.p_f64(cons), L.p_f64(s),
                                                       L.p_f64(y), it.mu, it.a_norm_penalty_par, 0.0, 0.0, 1.0, L.p_f64(rD), L.p_f64(rP), L.p_f64(rC)),
                         "okkt_kkt_system_rhs")
-            delta = max(float(np.max(np.abs(rD))) / float(np.max(np.abs(self.dir.x))), it.delta * d.inc, floor)
+            self._resident_rhs = None      # the device rhs now holds this gradient triple, not self.rhs
+            # norm(eval_grad_lag, Inf) / norm(dir.x, Inf) with Julia's float semantics: x / 0 = Inf (the delta loop then
+            # ends with MAX_DELTA), 0 / 0 = NaN, norm of an empty vector = 0 (one_phase.jl:233)
+            gnorm = np.float64(np.max(np.abs(rD))) if n else np.float64(0.0)
+            dnorm = np.float64(np.max(np.abs(self.dir.x))) if n else np.float64(0.0)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                ratio = float(gnorm / dnorm)
+            delta = _julia_max(ratio, it.delta * d.inc, floor)
         elif response_to_failure == "default":
             delta = max(it.delta * d.inc, floor)
         else:
@@ -401,6 +434,6 @@ def pick_KKT_solver(pars):
     """kkt_system_solver.jl:232-287 with the `linear_solver_type == :HIP` branch."""
     if pars.kkt.linear_solver_type != "HIP":
         raise OkktError("pick a valid solver!")
-    if pars.kkt.kkt_solver_type in ("schur", "symmetric", "clever_symmetric"):
+    if pars.kkt.kkt_solver_type in ("schur", "schur_direct", "symmetric", "clever_symmetric"):
         return HIP_KKT_solver(pars.kkt.kkt_solver_type, pars)
     raise OkktError("pick a solver!")

@@ -3,6 +3,7 @@
 Follows, function by function:
   /root/reference/src/kkt_system_solver/kkt_system_solver.jl:27-47,67-113,167-204,291-300
   /root/reference/src/kkt_system_solver/schur.jl:47-182
+  /root/reference/src/kkt_system_solver/schur_direct.jl:32-66
   /root/reference/src/kkt_system_solver/symmetric.jl:35-102
   /root/reference/src/kkt_system_solver/system_rhs.jl:3-24,57-73
   /root/reference/src/IPM/delta_strategy.jl:37-121
@@ -174,6 +175,8 @@ class _KKTBase:
         self.rhs = System_rhs.build(it, eta)
         self.dir.mu = -(1.0 - eta.mu) * it.mu
         self.dir.primal_scale = -(1.0 - eta.P) * it.primal_scale
+        self.reduct_factors = eta          # schur.jl:42-43
+        self.current_it = it
 
     # kkt_system_solver.jl:178-188
     def compute_direction_b(self):
@@ -254,6 +257,25 @@ class Schur_KKT_solver(_KKTBase):
             hess_res = hess_product(fit, dir_x) + self.delta_x_vec * dir_x
             res_old = schur_rhs - (jac_res + hess_res)
         return dir_x
+
+
+class Schur_KKT_solver_direct(Schur_KKT_solver):
+    """schur_direct.jl:3-66 -- an abstract_schur_solver: form_system!, update_delta_vecs!, factor_implementation! and
+    solver_schur_rhs are Schur_KKT_solver's (schur.jl:47-87,131-182, all on factor_it); only the direction differs: the
+    rhs terms, dy and ds are taken at current_it, and ds comes from the complementarity row."""
+
+    def compute_direction_implementation_b(self):  # schur_direct.jl:32-66
+        it, rhs = self.current_it, self.rhs
+        y, s = it.y, it.s
+        symmetric_primal_rhs = rhs.primal_r + rhs.comp_r / y
+        S_vec = y / s
+        y_ = rhs.primal_r * S_vec + rhs.comp_r / s
+        schur_rhs = rhs.dual_r + eval_jac_T_prod(it, y_)
+        d = self.dir
+        d.x = self.solver_schur_rhs(schur_rhs)
+        d.y = -(eval_jac_prod(it, d.x) - symmetric_primal_rhs) * S_vec
+        d.s = (rhs.comp_r - d.y * s) / y
+        self.update_kkt_error_b()
 
 
 class Symmetric_KKT_solver(_KKTBase):
@@ -539,6 +561,8 @@ def pick_KKT_solver(kkt_solver_type, perm=None, pars=None):
         return Symmetric_KKT_solver(linear_solver_ORACLE("symmetric", perm=perm), pars)
     if kkt_solver_type == "schur":
         return Schur_KKT_solver(linear_solver_ORACLE("definite", perm=perm), pars)
+    if kkt_solver_type == "schur_direct":
+        return Schur_KKT_solver_direct(linear_solver_ORACLE("definite", perm=perm), pars)
     if kkt_solver_type == "clever_symmetric":
         return Clever_Symmetric_KKT_solver(linear_solver_ORACLE("symmetric", perm=perm), pars)
     raise ValueError("pick a solver!")
@@ -550,7 +574,16 @@ def step_failure_delta(it, dir, old_delta, pars=None, response_to_failure="lag_d
     pars = pars or KKTPars()
     floor = max(pars.delta_start, old_delta * pars.delta_dec)
     if response_to_failure == "lag_delta_inc":
-        return max(float(np.max(np.abs(eval_grad_lag(it, it.mu)))) / float(np.max(np.abs(dir.x))), it.delta * pars.delta_inc, floor)
+        # Julia float semantics: x / 0 = Inf, 0 / 0 = NaN, norm of an empty vector = 0; max propagates NaN
+        g = eval_grad_lag(it, it.mu)
+        gnorm = np.float64(np.max(np.abs(g))) if len(g) else np.float64(0.0)
+        dnorm = np.float64(np.max(np.abs(dir.x))) if len(dir.x) else np.float64(0.0)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            ratio = float(gnorm / dnorm)
+        out = ratio
+        for v in (it.delta * pars.delta_inc, floor):
+            out = v if (v != v or (out == out and v > out)) else out
+        return out
     if response_to_failure == "default":
         return max(it.delta * pars.delta_inc, floor)
     raise ValueError("pars.test.response_to_failure parameter incorrectly set")

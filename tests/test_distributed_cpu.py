@@ -82,7 +82,7 @@ class _FakeKKT:
     def diag_min(self):
         return self.dmin
 
-    def factor_b(self, delta):
+    def factor_b(self, delta, trial=False):
         self.calls.append(delta)
         return 1 if delta >= self.need else 0
 

@@ -295,17 +295,19 @@ def test_estimate_y_tilde_through_the_handle():
         assert np.max(np.abs(y_hip - y_ref)) <= 1e-9 * max(1.0, np.max(np.abs(y_ref)))
 
 
-def test_failed_factorisation_stops_early_and_cannot_be_solved_with():
-    # factor! of a strongly nonconvex system: the pivot counts of the lower levels already exceed m negative pivots,
-    # the top of the tree is skipped (partial counts), the flag is 0 as the oracle's, and a direction is refused
-    # until a factorisation succeeds; the delta loop's trace is the oracle's
+def test_trial_factorisation_stops_early_complete_factorisation_can_be_solved_with():
+    # A strongly nonconvex system.  (a) factor! as the delta loop uses it (trial): the pivot counts of the lower levels
+    # already exceed m negative pivots, the top of the tree is skipped (partial counts), the flag is 0 as the oracle's and a
+    # direction is refused.  (b) plain factor! (what one_phase.jl:241 calls after a failed step) runs to the end: complete
+    # counts equal to the oracle's, flag 0, and a direction CAN be computed from it, as in the reference, where
+    # take_step2! follows whatever the flag was.  (c) the delta loop's trace is the oracle's.
     prob = synth.make_config("S-small", seed=2, convex=False, neg_shift=50.0, well_scaled=True)
     it, oit = synth_iterate(prob, KS.Class_iterate, 2), synth_iterate(prob, KO.Iterate, 2)
     n, m = prob["n"], prob["m"]
     k = KS.HIP_KKT_solver("symmetric")
     k.initialize_b(it)
     k.form_system_b(it)
-    assert k.factor_b(0.0) == 0
+    assert k.factor_b(0.0, trial=True) == 0
     pos, neg, zero, bad = k.inertia
     assert neg > m and pos + neg + zero + bad < n + m          # stopped before the last level
     k.kkt_associate_rhs_b(it, KS.Reduct_affine())
@@ -315,6 +317,20 @@ def test_failed_factorisation_stops_early_and_cannot_be_solved_with():
     ko.initialize_b(oit)
     ko.form_system_b(oit)
     assert ko.factor_b(0.0) == 0
+    # (b)
+    k.form_system_b(it)
+    assert k.factor_b(0.0) == 0
+    assert sum(k.inertia) == n + m and k.inertia[:3] == ko.ls_solver.inertia()[:3]
+    k.kkt_associate_rhs_b(it, KS.Reduct_affine())
+    k.compute_direction_b()
+    ko.kkt_associate_rhs_b(oit, KO.Reduct_affine())
+    ko.compute_direction_b()
+    for a in ("x", "y", "s"):
+        ref = getattr(ko.dir, a)
+        assert np.max(np.abs(getattr(k.dir, a) - ref)) <= 1e-8 * max(1.0, np.max(np.abs(ref))), a
+    # (c)
+    k.form_system_b(it)
+    ko.form_system_b(oit)
     status, num_fac, delta = k.ipopt_strategy_b(it)
     ostatus, onum_fac, odelta, _ = KO.ipopt_strategy_b(oit, ko)
     # tau = 1.5 * min(schur_diag) < 0 enters delta: schur_diag is a sum (order differs from scipy's), so delta agrees to rounding
@@ -324,6 +340,121 @@ def test_failed_factorisation_stops_early_and_cannot_be_solved_with():
     k.compute_direction_b()
     assert k.kkt_err_norm.ratio < 1e-8
     k.finalize_b()
+
+
+def test_refactor_with_wrong_inertia_still_gives_a_direction(golden):
+    # one_phase.jl:241 ignores the flag of the refactorisation after a failed step; take_step2! then calls
+    # compute_direction!.  A delta too small for the indefinite H: flag 0, and the direction equals the oracle's.
+    rec = golden["indef5"]
+    for kind in ("schur", "symmetric"):
+        it, oit = iterate_from_record(rec, KS.Class_iterate), iterate_from_record(rec, KO.Iterate)
+        k = KS.HIP_KKT_solver(kind)
+        k.initialize_b(it); k.form_system_b(it)
+        ko = KO.pick_KKT_solver(kind)
+        ko.initialize_b(oit); ko.form_system_b(oit)
+        small = 1e-3
+        assert k.factor_b(small) == ko.factor_b(small) == 0
+        k.kkt_associate_rhs_b(it, KS.Reduct_affine()); ko.kkt_associate_rhs_b(oit, KO.Reduct_affine())
+        k.compute_direction_b(); ko.compute_direction_b()
+        for a in ("x", "y", "s"):
+            ref = getattr(ko.dir, a)
+            assert np.max(np.abs(getattr(k.dir, a) - ref)) <= 1e-8 * max(1.0, np.max(np.abs(ref))), (kind, a)
+        k.finalize_b()
+
+
+def test_refactor_after_step_failure_zero_direction(golden):
+    # norm(grad, Inf) / norm(dir.x, Inf) with dir.x = 0: Julia gives Inf, delta = Inf, the factorisation of K + Inf I
+    # reports non-finite pivots (flag 0) and the caller's loop ends with MAX_DELTA -- no Python exception on the way
+    rec = golden["indef5"]
+    it = iterate_from_record(rec, KS.Class_iterate)
+    k = KS.HIP_KKT_solver("symmetric")
+    k.initialize_b(it); k.form_system_b(it)
+    status, num_fac, delta = k.ipopt_strategy_b(it)
+    it.delta = delta
+    k.kkt_associate_rhs_b(it, KS.Reduct_affine()); k.compute_direction_b()
+    k.dir.x = np.zeros_like(k.dir.x)
+    oit = iterate_from_record(rec, KO.Iterate); oit.delta = delta
+    want = KO.step_failure_delta(oit, KO.Direction(k.dir.x, k.dir.y, k.dir.s), 0.0)
+    inertia, got = k.refactor_after_step_failure_b(it, 0.0)
+    assert np.isinf(want) and np.isinf(got) and it.delta == got and inertia == 0
+    k.finalize_b()
+
+
+# ---- Schur_KKT_solver_direct (schur_direct.jl; kkt_solver_type = :schur_direct, kkt_system_solver.jl:270-276) ----------
+def test_schur_direct_toy_lps(golden):
+    # same iterate for factor_it and current_it: the direction solves the same Newton system as schur / symmetric
+    for rec in golden["toy_lps"]:
+        i_d, kd = test_kkt_solver(rec, "schur_direct")
+        i_s, ks = test_kkt_solver(rec, "schur")
+        _, ko = oracle_solver(rec, "schur_direct", 1e-8)
+        assert i_d == 1 and i_s == 1, rec["name"]
+        for a in ("x", "y", "s"):
+            assert np.linalg.norm(getattr(kd.dir, a) - getattr(ks.dir, a)) < 1e-6, (rec["name"], a)
+            assert np.linalg.norm(getattr(kd.dir, a) - np.array(rec["d" + a])) < 1e-6, (rec["name"], a)
+            assert np.linalg.norm(getattr(kd.dir, a) - getattr(ko.dir, a)) < 1e-9 * max(1.0, np.linalg.norm(getattr(ko.dir, a))), (rec["name"], a)
+        assert kd.kkt_err_norm.ratio < 1e-8
+        kd.finalize_b(); ks.finalize_b()
+
+
+@pytest.mark.parametrize("name,seed", [("S-tiny", 1), ("S-small", 4)])
+def test_schur_direct_current_iterate_differs_from_factor_iterate(name, seed):
+    # the case that separates schur_direct from schur (schur_direct.jl:35-56 reads current_it, schur.jl:93-116 factor_it):
+    # factor at one iterate, kkt_associate_rhs! at a moved one (new s, y, Jacobian values, gradient): inner iterations of
+    # one_phase.jl:262-279.  Both solvers against their oracle restatements, and they must differ from each other.
+    prob = synth.make_config(name, seed=seed, well_scaled=True)
+    rng = np.random.default_rng(seed + 100)
+    dirs = {}
+    for kind in ("schur_direct", "schur"):
+        it, oit = synth_iterate(prob, KS.Class_iterate, seed), synth_iterate(prob, KO.Iterate, seed)
+        pars = KS.Class_parameters(); pars.kkt.kkt_solver_type = kind
+        k = KS.pick_KKT_solver(pars)
+        k.initialize_b(it); k.form_system_b(it)
+        assert k.factor_b(1e-6) == 1
+        ko = KO.pick_KKT_solver(kind, perm=k.linear_solver_perm())
+        ko.initialize_b(oit); ko.form_system_b(oit)
+        assert ko.factor_b(1e-6) == 1
+        rng2 = np.random.default_rng(seed + 100)
+        def moved(cls, base):
+            J2 = base.J.copy(); J2.data = J2.data * (1.0 + 0.05 * rng2.normal(size=J2.nnz))
+            return cls(x=base.x + 0.01, y=base.y * rng2.uniform(0.7, 1.4, size=len(base.y)), s=base.s * rng2.uniform(0.7, 1.4, size=len(base.s)),
+                       mu=0.5 * base.mu, J=J2, H=base.H, grad=base.grad + 0.1 * rng2.normal(size=len(base.x)), cons=base.cons + 0.01,
+                       a_norm_penalty_par=base.a_norm_penalty_par)
+        cur = moved(KS.Class_iterate, it)
+        rng2 = np.random.default_rng(seed + 100)
+        ocur = moved(KO.Iterate, oit)
+        k.kkt_associate_rhs_b(cur, KS.Reduct_stable()); ko.kkt_associate_rhs_b(ocur, KO.Reduct_stable())
+        assert np.allclose(k.rhs.dual_r, ko.rhs.dual_r, rtol=1e-12, atol=1e-12)
+        k.compute_direction_b(); ko.compute_direction_b()
+        for a in ("x", "y", "s"):
+            ref = getattr(ko.dir, a)
+            assert np.max(np.abs(getattr(k.dir, a) - ref)) <= 1e-9 * max(1.0, np.max(np.abs(ref))), (kind, a)
+        assert abs(k.kkt_err_norm.ratio - ko.kkt_err_norm.ratio) <= 1e-6 * max(ko.kkt_err_norm.ratio, 1e-12) + 1e-12
+        dirs[kind] = (k.dir.y.copy(), k.dir.s.copy())
+        k.finalize_b()
+    assert np.max(np.abs(dirs["schur_direct"][1] - dirs["schur"][1])) > 1e-6      # ds really comes from another row of the system
+
+
+def test_resident_rhs_and_timers():
+    # compute_direction! with the rhs triple kkt_associate_rhs! left in HBM (NULL pointers) == with the same triple
+    # uploaded from the host; the per-phase device timers of the four reference methods are filled
+    prob = synth.make_config("S-small", seed=1, well_scaled=True)
+    for kind in ("schur", "symmetric"):
+        it = synth_iterate(prob, KS.Class_iterate, 1)
+        k = KS.HIP_KKT_solver(kind)
+        k.initialize_b(it); k.form_system_b(it)
+        assert k.factor_b(1e-6) == 1
+        k.kkt_associate_rhs_b(it, KS.Reduct_affine())
+        k.compute_direction_b()
+        d1 = (k.dir.x.copy(), k.dir.y.copy(), k.dir.s.copy())
+        k.rhs = KS.System_rhs(k.rhs.dual_r.copy(), k.rhs.primal_r.copy(), k.rhs.comp_r.copy())    # a host copy: uploaded
+        k.compute_direction_b()
+        for a, b in zip(d1, (k.dir.x, k.dir.y, k.dir.s)):
+            assert np.array_equal(a, b)
+        t = k.timers()
+        assert t["n_solves"] == (3 if kind == "schur" else 1)
+        assert t["factor_ms"] > 0 and t["solve_ms"] > 0 and t["assemble_ms"] > 0 and t["kkt_err_ms"] > 0 and t["rhs_ms"] > 0
+        assert t["direction_ms"] >= t["solve_ms"] and t["direction_ms"] < 1e3
+        k.finalize_b()
 
 
 @pytest.mark.parametrize("kind", ["schur", "symmetric"])

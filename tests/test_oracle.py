@@ -243,3 +243,53 @@ def test_step_failure_delta_by_hand(golden):
     d.x = np.array([1e9])
     assert KO.step_failure_delta(it, d, 3.0) == 3.0 / math.pi                                   # old_delta * dec wins
     assert KO.step_failure_delta(it, d, 0.0, response_to_failure="default") == 1e-6             # delta.start
+
+
+def test_step_failure_delta_zero_direction(golden):
+    # Julia: norm(g, Inf) / 0.0 = Inf (delta = Inf, the caller's loop then ends with MAX_DELTA); 0 / 0 = NaN and
+    # max(NaN, ...) = NaN; an empty x gives norm 0.  No ZeroDivisionError.
+    it = iterate_from_record(golden["readme_toy"], KO.Iterate)
+    it.delta = 0.01
+    assert KO.step_failure_delta(it, KO.Direction(np.zeros(1), np.zeros(2), np.zeros(2)), 0.0) == math.inf
+    it.grad = it.grad * 0.0; it.y = it.y * 0.0; it.a_norm_penalty_par = 0.0            # grad L_mu exactly zero
+    assert np.all(KO.eval_grad_lag(it, it.mu) == 0.0)
+    assert math.isnan(KO.step_failure_delta(it, KO.Direction(np.zeros(1), np.zeros(2), np.zeros(2)), 0.0))
+
+
+# ---- Schur_KKT_solver_direct (schur_direct.jl:32-66)
+def test_schur_direct_directions(golden):
+    # factor_it == current_it: the same Newton system as schur / symmetric, ds from the complementarity row instead of
+    # the primal row -- the dense known answers pin it
+    for rec in golden["toy_lps"] + [golden["readme_toy"]]:
+        i_d, kd = _solve_kind(rec, "schur_direct")
+        i_s, ks = _solve_kind(rec, "schur")
+        assert i_d == 1 and i_s == 1
+        for a in ("x", "y", "s"):
+            assert np.linalg.norm(getattr(kd.dir, a) - np.array(rec["d" + a])) < 1e-6, (rec["name"], a)
+            assert np.linalg.norm(getattr(kd.dir, a) - getattr(ks.dir, a)) < 1e-6, (rec["name"], a)
+        assert kd.kkt_err_norm.ratio < 1e-8
+
+
+def test_schur_direct_reads_current_iterate(golden):
+    # current_it != factor_it: dy, ds and the rhs terms of schur_direct use y, s, J of the CURRENT iterate
+    # (schur_direct.jl:35-56), the linear system is still the factorised one.  Dense restatement by hand.
+    rec = golden["toy_lps"][3]
+    it = iterate_from_record(rec, KO.Iterate)
+    k = KO.pick_KKT_solver("schur_direct")
+    k.initialize_b(it); k.form_system_b(it)
+    assert k.factor_b(rec["delta"]) == 1
+    cur = iterate_from_record(rec, KO.Iterate)
+    rng = np.random.default_rng(0)
+    cur.y = cur.y * rng.uniform(0.5, 1.5, size=len(cur.y)); cur.s = cur.s * rng.uniform(0.5, 1.5, size=len(cur.s))
+    cur.J = cur.J.copy(); cur.J.data = cur.J.data * rng.uniform(0.9, 1.1, size=cur.J.nnz)
+    k.kkt_associate_rhs_b(cur, KO.Reduct_stable())
+    k.compute_direction_b()
+    r = k.rhs
+    Q = (it.J.T @ sp.diags(it.y / it.s) @ it.J + it.H + it.H.T - sp.diags(it.H.diagonal())).toarray() + rec["delta"] * np.eye(it.dim())
+    Jc = cur.J.toarray()
+    sig = cur.y / cur.s
+    dx = np.linalg.solve(Q, r.dual_r + Jc.T @ (r.primal_r * sig + r.comp_r / cur.s))
+    dy = -(Jc @ dx - (r.primal_r + r.comp_r / cur.y)) * sig
+    ds = (r.comp_r - dy * cur.s) / cur.y
+    for got, want in ((k.dir.x, dx), (k.dir.y, dy), (k.dir.s, ds)):
+        assert np.max(np.abs(got - want)) <= 1e-9 * max(1.0, np.max(np.abs(want)))
