@@ -86,11 +86,15 @@ int solver_solve_enqueue(okkt_solver_s* h, const double* d_rhs, double* d_sol, i
   if (rc != OKKT_OK) return rc;
   if (!h->factored) return solver_set_error(h, OKKT_ERR_INVALID, "solve called before a factorisation");
   if (nrhs < 0) return solver_set_error(h, OKKT_ERR_INVALID, "nrhs < 0");
-  for (int64_t r = 0; r < nrhs; ++r) {
-    launch_permute_in(h->N, d_rhs + r * h->S.n);
-    std::string e = numeric_solve_enqueue(h->N);
+  // batches of up to kMaxRhs right-hand sides: one pass over L per batch (R = 1, 2 or 4 kernels; three are padded to four)
+  for (int64_t r = 0; r < nrhs;) {
+    const int nr = (int)std::min<int64_t>(nrhs - r, kMaxRhs);
+    const int R = nr >= 3 ? 4 : nr;
+    solve_permute_in(h->N, d_rhs + r * h->S.n, h->S.n, nr, R);
+    std::string e = numeric_solve_enqueue(h->N, R);
     if (!e.empty()) return solver_set_error(h, OKKT_ERR_HIP, e);
-    launch_permute_out(h->N, d_sol + r * h->S.n, accumulate);
+    solve_permute_out(h->N, d_sol + r * h->S.n, h->S.n, nr, R, accumulate);
+    r += nr;
   }
   return OKKT_OK;
 }

@@ -136,8 +136,8 @@ int okkt_dist_solve_begin(okkt_handle h, const double* d_rhs) {
   int rc = need_dist(h);
   if (rc != OKKT_OK) return rc;
   if (!h->factored) return solver_set_error(h, OKKT_ERR_INVALID, "solve called before a factorisation");
-  launch_permute_in(h->N, d_rhs);
-  std::string e = numeric_solve_fwd_enqueue(h->N, 0);
+  solve_permute_in(h->N, d_rhs, h->S.n, 1, 1);
+  std::string e = solve_fwd_enqueue(h->N, 0, 1);
   if (!e.empty()) return solver_set_error(h, OKKT_ERR_HIP, e);
   return sync_or_fail(h, "local forward solve");
 }
@@ -155,8 +155,8 @@ int okkt_dist_solve_top(okkt_handle h) {
   if (!h) return OKKT_ERR_INVALID;
   int rc = need_dist(h);
   if (rc != OKKT_OK) return rc;
-  std::string e = numeric_solve_fwd_enqueue(h->N, 1);
-  if (e.empty()) e = numeric_solve_bwd_enqueue(h->N, 1);
+  std::string e = solve_fwd_enqueue(h->N, 1, 1);
+  if (e.empty()) e = solve_bwd_enqueue(h->N, 1, 1);
   if (!e.empty()) return solver_set_error(h, OKKT_ERR_HIP, e);
   return sync_or_fail(h, "top solve");
 }
@@ -174,7 +174,7 @@ int okkt_dist_solve_end(okkt_handle h) {
   if (!h) return OKKT_ERR_INVALID;
   int rc = need_dist(h);
   if (rc != OKKT_OK) return rc;
-  std::string e = numeric_solve_bwd_enqueue(h->N, 0);
+  std::string e = solve_bwd_enqueue(h->N, 0, 1);
   if (!e.empty()) return solver_set_error(h, OKKT_ERR_HIP, e);
   return sync_or_fail(h, "local backward solve");
 }

@@ -50,13 +50,17 @@ struct DevPlan {
   int64_t* ea_cut = nullptr;     // per item: start of the child's chunk-boundary table in cutv
   int* cutv = nullptr;           // per child of a big front: positions of the parent's 1024-row boundaries in its rel list
   int64_t* acol_lo = nullptr;    // [n_bigcols + 1] first A entry of each big-front column
-  double* xsb = nullptr;         // explicit inverses of the 1024-column diagonal blocks (super-block solves)
-  int64_t* xsb_pos = nullptr;    // [nsuper] offset into xsb, -1 if the front takes the 128-column steps
-  double* ysb = nullptr;         // block product work vector
-  int64_t* ysb_pos = nullptr;
+  // solves (solve.hip): explicit inverses of the kSolveBlock-column diagonal blocks of the fronts with more than NB pivot
+  // columns, a scratch copy of the same shape for the recursive inversion, partial vectors of the block products
+  double* xinv = nullptr;
+  double* xtmp = nullptr;
+  int64_t* xinv_pos = nullptr;   // [nsuper] offset into xinv / xtmp, -1 for fronts with k <= NB (they use invl) and small fronts
+  double* ypart = nullptr;       // [kMaxRhs][4][kSolveBlock] per wide front
+  int64_t* ypart_pos = nullptr;
+  int* ssched = nullptr;         // big fronts per level, thin (k <= NB) then wide
+  int64_t xw_stride = 0, cv_stride = 0;   // distance between the right-hand sides of a batch in xwork / cv
   double* invl = nullptr;          // inverse of the unit-lower diagonal blocks, NB x NB each
   int64_t* invl_pos = nullptr;     // [nsuper]
-  double* bigw = nullptr;          // [n_bigcols] forward-solve work vectors of the big fronts
   int* sn_owner = nullptr;     // multi-GPU partition: owner part of each supernode (-1 = top)
   int* col_owner = nullptr;    // the same per permuted column
   int* bnd = nullptr;          // boundary fronts (subtree roots under a top node)
@@ -71,6 +75,11 @@ struct DevPlan {
 };
 
 constexpr int kCountSlots = 64, kCountStride = 16;
+#ifndef OKKT_SOLVE_BLOCK
+#define OKKT_SOLVE_BLOCK 2048
+#endif
+constexpr int kSolveBlock = OKKT_SOLVE_BLOCK;   // columns of an explicitly inverted diagonal block (solve.hip)
+constexpr int kMaxRhs = 4;                      // right-hand sides carried through one pass over L
 // sums the slots: out[0..3] = pos, neg, zero, nonfinite, out[4] = stop flag (synchronises `stream`)
 std::string numeric_read_counts(struct Numeric& N, hipStream_t stream, unsigned long long out[5]);
 
@@ -79,8 +88,17 @@ constexpr int kNumClasses = 4;
 struct Segment { int off = 0, cnt = 0, maxf = 0, maxk = 0, minf = 1 << 30, mink = 1 << 30; };
 struct LevelSchedule { Segment seg[kNumClasses]; };
 
+// big fronts of one level for the solves: thin (k <= NB: one fused forward launch) and wide (block products with X_b)
+struct SolveLevel {
+  int thin_off = 0, thin_cnt = 0, thin_maxf = 0, thin_maxk = 0, thin_maxr = 0;
+  int wide_off = 0, wide_cnt = 0, wide_maxf = 0, wide_maxk = 0;
+};
+
 struct Numeric {
   DevPlan d;
+  std::vector<SolveLevel> slevels, slevels_top;
+  hipEvent_t inv_event = nullptr;        // recorded behind the block inversions that the factorisation started on the auxiliary stream
+  bool inv_wait = false;                 // ... which the next solve has to wait for
   std::vector<LevelSchedule> levels;      // subtrees owned by this part (everything when unpartitioned)
   std::vector<LevelSchedule> levels_top;  // top of the tree (part 0 of a partitioned plan only)
   int part_id = 0;
@@ -107,15 +125,7 @@ struct Numeric {
   hipStream_t stream_aux = nullptr;     // off-critical-path part of the in-group panel updates
   int split_head = 1;
   int lookahead = 1;
-  int use_sb = 1;                        // super-block solves for fronts with >= 2048 pivot columns 
-  bool sb_ready = false;                 // inverses of the current factorisation are in place
-  hipEvent_t sb_event = nullptr;         // recorded behind an inversion that the factorisation started on the auxiliary stream
-  bool sb_wait = false;                  // ... which the next solve has to wait for
-  int sb_tail_rows = 4000;               // the inversion of the finished blocks starts once fewer rows than this remain
-  int solves_since_factor = 0;
-  int sb_lazy = 0;                       // solves with the 128-column steps before the inverses are prepared
-  void* blas = nullptr;                  // rocblas_handle (TRSM for the super-block inverses)
-  std::vector<int64_t> xsb_pos_host, front_pos_host;
+  int sb_tail_rows = 4000;               // the inversion of the finished diagonal blocks starts once fewer rows than this remain
   int la_min_tiles = 600;                // rest triangle must hold at least this many 128 x 128 tiles
   std::vector<hipEvent_t> la_events;
   size_t la_used = 0;
@@ -138,18 +148,20 @@ void numeric_release(Numeric& N);
 // enqueue the whole numeric factorisation on N.stream (no sync); values read from d_vals
 // which = 0: the local schedule, 1: the top-of-tree schedule
 std::string numeric_factor_enqueue(Numeric& N, const double* d_vals, double tol, int which = 0, bool reset_counters = true);
-std::string numeric_solve_fwd_enqueue(Numeric& N, int which);
-std::string numeric_solve_bwd_enqueue(Numeric& N, int which);
+// forward (L, D^-1 fused) / backward (L') sweep over one schedule for R = 1, 2 or 4 right-hand sides held in xwork
+std::string solve_fwd_enqueue(Numeric& N, int which, int R);
+std::string solve_bwd_enqueue(Numeric& N, int which, int R);
+std::string solve_setup(const Symbolic& S, Numeric& N);
+std::string solve_invert_enqueue(Numeric& N, hipStream_t st, const SolveLevel& L, int b_lo, int b_hi);
+// xwork[q][k] = rhs[q * stride + perm[k]] for q < nr (zero for nr <= q < R)  /  sol[q * stride + perm[k]] (+)= xwork[q][k]
+void solve_permute_in(const Numeric& N, const double* d_rhs, int64_t stride, int nr, int R);
+void solve_permute_out(const Numeric& N, double* d_sol, int64_t stride, int nr, int R, bool accumulate);
 // what = 0 contribution blocks, 1 contribution vectors; unpack = 0: mine -> buffer, 1: buffer -> the others' slots
 std::string numeric_dist_pack(Numeric& N, int what, int unpack, double* d_buf);
 // mode 0: xwork -> buf; 1: buf -> xwork on top columns; 2: owned part of the solution, original order -> buf
 std::string numeric_dist_x(Numeric& N, int mode, double* d_buf);
-// enqueue forward/diagonal/backward solves for the rhs already stored (permuted) in d.xwork
-std::string numeric_solve_enqueue(Numeric& N);
-// permute helpers: xwork[k] = rhs[perm[k]]  /  sol[perm[k]] = xwork[k]
-void launch_permute_in(const Numeric& N, const double* d_rhs);
-// accumulate: sol[perm[k]] += xwork[k] (the refinement loops' dir_x .+= ls_solve(res), schur.jl:163)
-void launch_permute_out(const Numeric& N, double* d_sol, bool accumulate = false);
+// enqueue forward/diagonal/backward solves for the R right-hand sides already stored (permuted) in d.xwork
+std::string numeric_solve_enqueue(Numeric& N, int R);
 // diagadd[iperm] = (orig index < nshift) ? delta : 0, via perm
 void launch_set_shift(const Numeric& N, double delta, int64_t nshift);
 

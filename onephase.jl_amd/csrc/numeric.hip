@@ -13,8 +13,6 @@
 //     (k_big_trsm) and an FP64-MFMA trailing update C -= W * L^T (k_big_syrk).
 // Extend-add is deterministic: every destination entry is owned by exactly one workgroup that
 // adds the children's contribution blocks in a fixed order -- no floating-point atomics.
-#include <rocblas/rocblas.h>
-
 #include "numeric.h"
 
 #include <algorithm>
@@ -347,13 +345,6 @@ __global__ __launch_bounds__(256) void k_big_assemble(DevPlan P, const int* __re
 // Per child a small table gives the position in its rel list where each chunk boundary falls (the list is sorted),
 // and per front column the range of its A entries is precomputed: no searches on the device.
 constexpr int kAsmChunk = 1024;
-constexpr int kSolveSB = 1024;   // super-block width of the solves of fronts with many pivot columns (see k_sb_*)
-__global__ void k_sb_identity(double* __restrict__ X, int sb, int64_t total) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= total) return;
-  const int64_t e = i % ((int64_t)sb * sb);
-  X[i] = (e / sb == e % sb) ? 1.0 : 0.0;
-}
 __global__ __launch_bounds__(256) void k_big_assemble_chunked(DevPlan P, const int* __restrict__ list) {
   __shared__ double sm[4 * kAsmChunk];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -659,12 +650,12 @@ __global__ __launch_bounds__(256) void k_big_diag(DevPlan P, const int* __restri
 // workgroup per block, all blocks in parallel, off the critical path of the factorisation: k_big_trsm
 // only needs the 32 x 32 diagonal inverses X_ii that k_big_diag leaves in `invl`).  The blocked solves read X.
 // Off-diagonal blocks X_ij = -X_ii * (sum_{p=j}^{i-1} L_ip X_pj) by block distance, 32 x 32 MFMA products.
-__global__ __launch_bounds__(256) void k_big_invert(DevPlan P, const int* __restrict__ list, int NB) {
+__global__ __launch_bounds__(256) void k_big_invert(DevPlan P, const int* __restrict__ list, int NB, int step0) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, l4 = lane >> 4;
   const int s = list[blockIdx.y];
-  const int step = blockIdx.x;
+  const int step = step0 + (int)blockIdx.x;
   if (stop_requested_wg(P)) return;
   const int col0 = P.sn_col0[s];
   const int k = P.sn_col0[s + 1] - col0;
@@ -1035,271 +1026,6 @@ __global__ __launch_bounds__(kSyrkNW * 64, kSyrkNW / 2) void k_big_syrk(DevPlan 
   }
 }
 
-// ------------------------------------------------------------------------------------------
-// triangular solves (one workgroup per front and level)
-// ------------------------------------------------------------------------------------------
-template <int TPB>
-__global__ __launch_bounds__(TPB) void k_solve_fwd(DevPlan P, const int* __restrict__ list) {
-  extern __shared__ __attribute__((aligned(16))) double sm[];
-  const int tid = threadIdx.x;
-  const int s_root = list[blockIdx.x];
-  for (int s = P.task_lo[s_root]; s <= s_root; ++s) {      // the task's fronts, children first
-  const int col0 = P.sn_col0[s];
-  const int k = P.sn_col0[s + 1] - col0;
-  const int f = (int)(P.row_ptr[s + 1] - P.row_ptr[s]);
-  const double* L = P.arena + P.front_pos[s];
-  double* w = sm;
-  for (int i = tid; i < f; i += TPB) w[i] = i < k ? P.xwork[col0 + i] : 0.0;
-  __syncthreads();
-  for (int64_t q = P.child_ptr[s]; q < P.child_ptr[s + 1]; ++q) {
-    const int c = P.children[q];
-    const int rc = (int)(P.rel_ptr[c + 1] - P.rel_ptr[c]);
-    const int* rl = P.rel + P.rel_ptr[c];
-    const double* cvc = P.cv + P.cv_pos[c];
-    for (int ii = tid; ii < rc; ii += TPB) w[rl[ii]] += cvc[ii];
-    __syncthreads();
-  }
-  // unit lower triangular k x k
-  for (int j = 0; j < k; ++j) {
-    const double yj = w[j];
-    const double* col = L + (size_t)j * f;
-    for (int i = j + 1 + tid; i < k; i += TPB) w[i] -= col[i] * yj;
-    __syncthreads();
-  }
-  // rows below the pivot block: contribution vector for the parent
-  double* cvs = P.cv + P.cv_pos[s];
-  for (int i = k + tid; i < f; i += TPB) {
-    double acc = w[i];
-    for (int j = 0; j < k; ++j) acc -= L[(size_t)j * f + i] * w[j];
-    cvs[i - k] = acc;
-  }
-  // z = D^-1 y
-  for (int j = tid; j < k; j += TPB) P.xwork[col0 + j] = w[j] / P.dvals[col0 + j];
-  __threadfence_block();
-  __syncthreads();
-  }
-}
-
-template <int TPB>
-__global__ __launch_bounds__(TPB) void k_solve_bwd(DevPlan P, const int* __restrict__ list) {
-  extern __shared__ __attribute__((aligned(16))) double sm[];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  constexpr int NW = TPB / 64;
-  const int s_root = list[blockIdx.x];
-  for (int s = s_root; s >= P.task_lo[s_root]; --s) {      // the task's fronts, parents first
-  const int col0 = P.sn_col0[s];
-  const int k = P.sn_col0[s + 1] - col0;
-  const int f = (int)(P.row_ptr[s + 1] - P.row_ptr[s]);
-  const double* L = P.arena + P.front_pos[s];
-  const int* rows = P.rows + P.row_ptr[s];
-  double* xo = sm;  // [f]: first k = rhs of the triangular solve, rest = ancestors' solution
-  for (int i = tid; i < f; i += TPB) xo[i] = P.xwork[rows[i]];
-  __syncthreads();
-  // rhs_j = z_j - sum_{i >= k} L[i, j] * x_i
-  for (int j = wv; j < k; j += NW) {
-    const double* col = L + (size_t)j * f;
-    double acc = 0.0;
-    for (int i = k + lane; i < f; i += 64) acc += col[i] * xo[i];
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
-    if (lane == 0) xo[j] -= acc;
-  }
-  __syncthreads();
-  // unit upper triangular (L11^T) k x k, column oriented
-  for (int j = k - 1; j >= 0; --j) {
-    const double xj = xo[j];
-    for (int i = tid; i < j; i += TPB) xo[i] -= L[(size_t)i * f + j] * xj;
-    __syncthreads();
-  }
-  for (int j = tid; j < k; j += TPB) P.xwork[col0 + j] = xo[j];
-  __threadfence_block();
-  __syncthreads();
-  }
-}
-
-// ---- big fronts: multi-workgroup blocked solves with the inverse diagonal blocks ----------------
-// forward assemble: w[pc] = rhs (pivot rows) + children's contribution vectors, via the inverted lists
-__global__ __launch_bounds__(256) void k_bigsolve_fwd_asm(DevPlan P, const int* __restrict__ list) {
-  const int s = list[blockIdx.y];
-  const int col0 = P.sn_col0[s];
-  const int k = P.sn_col0[s + 1] - col0;
-  const int f = (int)(P.row_ptr[s + 1] - P.row_ptr[s]);
-  const int pc = blockIdx.x * 256 + threadIdx.x;
-  if (pc >= f) return;
-  double w = pc < k ? P.xwork[col0 + pc] : 0.0;
-  const int64_t gc = P.bigcol_base[s] + pc;
-  for (int64_t q = P.ea_ptr[gc]; q < P.ea_ptr[gc + 1]; ++q) w += P.cv[P.cv_pos[P.ea_child[q]] + P.ea_jj[q]];
-  P.bigw[gc] = w;
-}
-
-// forward step J: y_J = inv(L_JJ) w_J (every workgroup, redundantly), z_J = y_J / d_J,
-// w[r] -= L[r, J] y_J for the rows below (64 rows per workgroup, wave g takes a quarter of the
-// block's columns with all its loads in flight at once; partial sums meet in LDS)
-template <int NB>
-__global__ __launch_bounds__(256) void k_bigsolve_fwd_step(DevPlan P, const int* __restrict__ list, int step) {
-  __shared__ double wj[128], yj[128], part[4][64];
-  constexpr int HALF = NB / 2;
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int s = list[blockIdx.y];
-  const int col0 = P.sn_col0[s];
-  const int k = P.sn_col0[s + 1] - col0;
-  const int f = (int)(P.row_ptr[s + 1] - P.row_ptr[s]);
-  const int j0 = step * NB;
-  if (j0 >= k) return;
-  const int nb = min(NB, k - j0);
-  if (blockIdx.x > 0 && j0 + nb + (int)blockIdx.x * 64 >= f) return;
-  double* w = P.bigw + P.bigcol_base[s];
-  const double* X = P.invl + P.invl_pos[s] + (size_t)step * NB * NB;
-  // the panel entries of this thread's row and its right-hand-side entry do not depend on y: they are requested
-  // first, so that their round trip overlaps the one of the X block (the step is pure latency: 4 -> 2 round trips)
-  const int r = j0 + nb + blockIdx.x * 64 + lane;
-  const int rcl = min(r, f - 1);
-  double lv[32];
-  {
-    const double* L = P.arena + P.front_pos[s] + (size_t)j0 * f + rcl;
-    const int cb = wv * 32;
-#pragma unroll
-    for (int q = 0; q < 32; ++q) lv[q] = L[(size_t)min(cb + q, nb - 1) * f];
-  }
-  const double wr = w[rcl];
-  if (tid < 128) wj[tid] = tid < nb ? w[j0 + tid] : 0.0;
-  __syncthreads();
-  // y[c] = sum_{p <= c} X[c][p] w[p]: two threads per row c (row c of X is contiguous in XT), each with
-  // its 64 loads in flight at once -- one memory round trip for the whole 128 x 128 triangle
-  {
-    const int c = tid >> 1, h = tid & 1;
-    double a = 0.0;
-    if (c < nb) {
-      // X[c][p] sits at X[c + p * NB]: for a fixed p consecutive threads read consecutive addresses.  The
-      // stored block is zero above the diagonal and beyond nb, wj is zero-padded: no predicates
-      const double* xrow = X + c + (size_t)(h * HALF) * NB;
-      double v[HALF];
-#pragma unroll
-      for (int q = 0; q < HALF; ++q) v[q] = xrow[(size_t)q * NB];
-#pragma unroll
-      for (int q = 0; q < HALF; ++q) a += v[q] * wj[h * HALF + q];
-    }
-    a += __shfl_xor(a, 1, 64);
-    if (c < nb && h == 0) {
-      yj[c] = a;
-      if (blockIdx.x == 0) P.xwork[col0 + j0 + c] = a / P.dvals[col0 + j0 + c];
-    }
-  }
-  __syncthreads();
-  {
-    double a = 0.0;
-    const int cb = wv * 32;
-#pragma unroll
-    for (int q = 0; q < 32; ++q) a += (cb + q < nb) ? lv[q] * yj[(cb + q) & 127] : 0.0;   // yj beyond nb is uninitialised LDS
-    part[wv][lane] = a;
-  }
-  __syncthreads();
-  if (wv == 0 && r < f) {
-    const double acc = wr - ((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]));
-    w[r] = acc;
-    if (j0 + nb >= k && r >= k) P.cv[P.cv_pos[s] + (r - k)] = acc;   // last step: contribution vector
-  }
-}
-
-// backward, rows below the pivot block: z[c] -= sum_{r >= k} L[r, c] x[rows[r]]   (wave per column)
-__global__ __launch_bounds__(256) void k_bigsolve_bwd_pre(DevPlan P, const int* __restrict__ list) {
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int s = list[blockIdx.y];
-  const int col0 = P.sn_col0[s];
-  const int k = P.sn_col0[s + 1] - col0;
-  const int f = (int)(P.row_ptr[s + 1] - P.row_ptr[s]);
-  const int c = blockIdx.x * 4 + wv;
-  if (c >= k || f == k) return;
-  const int* rows = P.rows + P.row_ptr[s];
-  const double* col = P.arena + P.front_pos[s] + (size_t)c * f;
-  double acc = 0.0;
-  int r = k + lane;
-  for (; r + 7 * 64 < f; r += 8 * 64) {       // eight index / value / x loads in flight per lane
-    int ri[8];
-    double lv[8], xv[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) { ri[u] = rows[r + 64 * u]; lv[u] = col[r + 64 * u]; }
-#pragma unroll
-    for (int u = 0; u < 8; ++u) xv[u] = P.xwork[ri[u]];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) acc += lv[u] * xv[u];
-  }
-  for (; r < f; r += 64) acc += col[r] * P.xwork[rows[r]];
-  for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
-  if (lane == 0) P.xwork[col0 + c] -= acc;
-}
-
-// backward step I (descending): x_I = inv(L_II)^T z_I (every workgroup, redundantly), then
-// z[c] -= sum_{r in I} L[r, c] x_I[r] for the columns c left of the block (wave per column)
-template <int NB>
-__global__ __launch_bounds__(256) void k_bigsolve_bwd_step(DevPlan P, const int* __restrict__ list, int step) {
-  __shared__ double zi[128], xi[128];
-  constexpr int HALF = NB / 2;
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int s = list[blockIdx.y];
-  const int col0 = P.sn_col0[s];
-  const int k = P.sn_col0[s + 1] - col0;
-  const int f = (int)(P.row_ptr[s + 1] - P.row_ptr[s]);
-  const int j0 = step * NB;
-  if (j0 >= k) return;
-  const int nb = min(NB, k - j0);
-  if (blockIdx.x > 0 && (int)blockIdx.x * 64 >= j0) return;
-  const double* X = P.invl + P.invl_pos[s] + (size_t)step * NB * NB;
-  // as in the forward step: the panel entries and the entries of x they update are requested before x_I is known
-  const double* Lrow = P.arena + P.front_pos[s] + j0;
-  const int rl = lane & 7;
-  double lv[2][NB / 8], xold[2];
-#pragma unroll
-  for (int pass = 0; pass < 2; ++pass) {
-    const int c = blockIdx.x * 64 + wv * 16 + pass * 8 + (lane >> 3);
-    const int cc = min(c, max(j0 - 1, 0));
-    const double* col = Lrow + (size_t)cc * f;
-#pragma unroll
-    for (int it = 0; it < NB / 8; ++it) lv[pass][it] = col[min(rl + 8 * it, nb - 1)];
-    xold[pass] = P.xwork[col0 + cc];
-  }
-  if (tid < 128) zi[tid] = tid < nb ? P.xwork[col0 + j0 + tid] : 0.0;
-  __syncthreads();
-  // x[c] = sum_{p >= c} X[p][c] z[p]: two threads per c (column c of X is contiguous), 64 loads in flight each
-  {
-    const int c = tid >> 1, h = tid & 1;
-    double a = 0.0;
-    if (c < nb) {
-      const double* xcol = X + (size_t)c * NB + h * HALF;
-      double v[HALF];
-#pragma unroll
-      for (int q = 0; q < HALF; ++q) v[q] = xcol[q];
-#pragma unroll
-      for (int q = 0; q < HALF; ++q) a += v[q] * zi[h * HALF + q];
-    }
-    a += __shfl_xor(a, 1, 64);
-    if (c < nb && h == 0) xi[c] = a;
-  }
-  __syncthreads();
-  // columns [blockIdx.x*64, +64) left of the block, 16 per wave in two passes of 8: lane = (column
-  // lane>>3, row phase lane&7); every lane has its 16 loads in flight, then three shuffle steps per pass
-#pragma unroll
-  for (int pass = 0; pass < 2; ++pass) {
-    const int c = blockIdx.x * 64 + wv * 16 + pass * 8 + (lane >> 3);
-    double acc = 0.0;
-#pragma unroll
-    for (int it = 0; it < NB / 8; ++it) acc += (rl + 8 * it < nb) ? lv[pass][it] * xi[rl + 8 * it] : 0.0;
-    acc += __shfl_xor(acc, 1, 64);
-    acc += __shfl_xor(acc, 2, 64);
-    acc += __shfl_xor(acc, 4, 64);
-    if (rl == 0 && c < j0) P.xwork[col0 + c] = xold[pass] - acc;
-  }
-  // the block's own solution is written last, by the first workgroup only: the others read z_I above
-  if (blockIdx.x == 0 && tid < nb) P.xwork[col0 + j0 + tid] = xi[tid];
-}
-
-__global__ void k_permute_in(int n, const int* __restrict__ perm, const double* __restrict__ rhs, double* __restrict__ x) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) x[i] = rhs[perm[i]];
-}
-__global__ void k_permute_out(int n, const int* __restrict__ perm, const double* __restrict__ x, double* __restrict__ sol, int accumulate) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) { const int d = perm[i]; sol[d] = accumulate ? sol[d] + x[i] : x[i]; }
-}
 __global__ void k_set_shift(int n, const int* __restrict__ perm, double delta, int nshift, double* __restrict__ diagadd) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) diagadd[i] = perm[i] < nshift ? delta : 0.0;
@@ -1345,7 +1071,7 @@ size_t lds_small(int maxf) { return ((size_t)(maxf | 1) * maxf + maxf) * sizeof(
 
 std::string numeric_setup(const Symbolic& S, const SymbolicOptions& opts, hipStream_t stream, Numeric& N) {
   N.stream = stream;
-  N.nb = std::max(32, std::min((opts.panel_nb + 31) / 32 * 32, 128));
+  N.nb = opts.panel_nb >= 128 ? 128 : (opts.panel_nb >= 64 ? 64 : 32);     // powers of two: kSolveBlock is a whole number of block columns
   N.small_max = std::max(32, std::min(opts.small_front_max, 136));
   // block columns per super-step (K = group * NB of the trailing update): 2 by default; fronts of at least
   // group_big_minf rows use group_big (more flops per byte of C traffic; the longer panel chain only pays off when the
@@ -1524,7 +1250,6 @@ std::string numeric_setup(const Symbolic& S, const SymbolicOptions& opts, hipStr
     }
   }
   N.sn_f.resize(ns);
-  N.front_pos_host.assign(S.front_pos.begin(), S.front_pos.end());
   N.sn_k.resize(ns);
   for (int s = 0; s < ns; ++s) { N.sn_f[s] = (int)(S.row_ptr[s + 1] - S.row_ptr[s]); N.sn_k[s] = S.sn_col0[s + 1] - S.sn_col0[s]; }
   // big fronts: inverted extend-add lists (per front column: which (child, jj) land on it),
@@ -1603,61 +1328,22 @@ std::string numeric_setup(const Symbolic& S, const SymbolicOptions& opts, hipStr
     if (!(e = upload(N, ea_cut, &d.ea_cut)).empty()) return e;
     if (!(e = upload(N, cutv, &d.cutv)).empty()) return e;
     if (!(e = upload(N, acol_lo, &d.acol_lo)).empty()) return e;
-    if (!(e = dalloc(N, (size_t)invl_total, &d.invl, false)).empty()) return e;
-    // explicit inverses of the kSolveSB-column diagonal blocks of fronts with many pivot columns (super-block solves)
-    {
-      std::vector<int64_t> xsb_pos(ns, -1), ysb_pos(ns, -1);
-      int64_t xtot = 0, ytot = 0;
-      N.use_sb = getenv("OKKT_SOLVE_SB") ? atoi(getenv("OKKT_SOLVE_SB")) : 1;
-      N.sb_lazy = getenv("OKKT_SOLVE_SB_LAZY") ? atoi(getenv("OKKT_SOLVE_SB_LAZY")) : -1;   // -1: by size, see below
-      int64_t max_sb_k = 0;
-      for (int s2 = 0; s2 < ns; ++s2)
-        if (wpos[s2] >= 0 && N.use_sb) {
-          const int64_t k2 = S.sn_col0[s2 + 1] - S.sn_col0[s2];
-          if (k2 < 2 * kSolveSB) continue;
-          xsb_pos[s2] = xtot; xtot += ((k2 + kSolveSB - 1) / kSolveSB) * (int64_t)kSolveSB * kSolveSB;
-          ysb_pos[s2] = ytot; ytot += 4 * kSolveSB;     // four partial vectors of a block product
-          max_sb_k = std::max(max_sb_k, k2);
-        }
-      // the inversion pays for itself on the first solve only when the front is large (S-metric root: 16 641 columns);
-      // medium fronts take the 128-column steps once and prepare the inverses when a second solve arrives
-      if (N.sb_lazy < 0) N.sb_lazy = max_sb_k >= 8 * kSolveSB ? 0 : 1;
-      N.xsb_pos_host = xsb_pos;
-      if (!(e = upload(N, xsb_pos, &d.xsb_pos)).empty()) return e;
-      if (!(e = upload(N, ysb_pos, &d.ysb_pos)).empty()) return e;
-      if (!(e = dalloc(N, (size_t)xtot, &d.xsb, false)).empty()) return e;
-      if (!(e = dalloc(N, (size_t)ytot, &d.ysb, true)).empty()) return e;
-      // the library's one-time initialisation (handle + kernel load, ~1.4 s) belongs to the analysis, not to the first
-      // solve that needs the inverses: a warm-up TRSM of the shape used later, on identity blocks of the X buffer
-      if (xtot >= 2 * (int64_t)kSolveSB * kSolveSB) {
-        if (!N.blas) {
-          rocblas_handle h2 = nullptr;
-          if (rocblas_create_handle(&h2) != rocblas_status_success) return "rocblas_create_handle failed";
-          N.blas = h2;
-        }
-        rocblas_handle hb = (rocblas_handle)N.blas;
-        if (rocblas_set_stream(hb, stream) != rocblas_status_success) return "rocblas_set_stream failed";
-        const int64_t tot = 2 * (int64_t)kSolveSB * kSolveSB;
-        hipLaunchKernelGGL(k_sb_identity, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream, d.xsb, kSolveSB, tot);
-        const double one = 1.0;
-        if (rocblas_dtrsm_strided_batched(hb, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_unit, kSolveSB,
-                                          kSolveSB, &one, d.xsb, kSolveSB, 0, d.xsb + (size_t)kSolveSB * kSolveSB, kSolveSB, 0, 1) !=
-            rocblas_status_success)
-          return "rocblas warm-up failed";
-        OKKT_HIP_TRY(hipStreamSynchronize(stream));
-      }
-    }
-    if (!(e = dalloc(N, (size_t)nbigcols, &d.bigw, true)).empty()) return e;
+    // zero-filled once: the parts of a block beyond a front's last pivot column are never written and are read as zeros
+    if (!(e = dalloc(N, (size_t)invl_total, &d.invl, true)).empty()) return e;
   }
   if (!(e = dalloc(N, (size_t)S.arena_doubles + 512, &d.arena, false)).empty()) return e;
   if (!(e = dalloc(N, (size_t)S.n, &d.dvals, true)).empty()) return e;
   if (!(e = dalloc(N, (size_t)S.n, &d.diagadd, true)).empty()) return e;
-  if (!(e = dalloc(N, (size_t)S.n, &d.xwork, true)).empty()) return e;
-  if (!(e = dalloc(N, (size_t)S.sum_r, &d.cv, true)).empty()) return e;
+  // kMaxRhs right-hand sides travel through the sweeps together (solve.hip)
+  d.xw_stride = S.n;
+  d.cv_stride = S.sum_r;
+  if (!(e = dalloc(N, (size_t)S.n * kMaxRhs, &d.xwork, true)).empty()) return e;
+  if (!(e = dalloc(N, (size_t)S.sum_r * kMaxRhs, &d.cv, true)).empty()) return e;
   if (!(e = dalloc(N, (size_t)wtotal + 512, &d.wbuf, true)).empty()) return e;
   if (!(e = dalloc(N, (size_t)kCountSlots * kCountStride, &d.counters, true)).empty()) return e;
   if (!(e = dalloc(N, (size_t)256, &d.zero_page, true)).empty()) return e;
   if (!(e = dalloc(N, (size_t)S.nnz_in, &N.vals_owned, false)).empty()) return e;
+  if (!(e = solve_setup(S, N)).empty()) return e;
   // kernels that may want more than 64 KiB of dynamic LDS
   const int big_lds = 160 * 1024 - 64;   // the stop-flag check keeps one static LDS word per kernel
   OKKT_HIP_TRY(hipFuncSetAttribute((const void*)k_front_small<256>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds));
@@ -1677,78 +1363,18 @@ void numeric_release(Numeric& N) {
   N.prof_events.clear();
   N.prof_used = 0;
   N.prof_flops.clear();
-  if (N.blas) { (void)rocblas_destroy_handle((rocblas_handle)N.blas); N.blas = nullptr; }
-  if (N.sb_event) { (void)hipEventDestroy(N.sb_event); N.sb_event = nullptr; }
+  if (N.inv_event) { (void)hipEventDestroy(N.inv_event); N.inv_event = nullptr; }
+  N.inv_wait = false;
   for (hipEvent_t ev : N.la_events) (void)hipEventDestroy(ev);
   N.la_events.clear();
   N.la_used = 0;
-  N.sb_ready = false;
-  N.solves_since_factor = 0;
   for (void* p : N.allocations) (void)hipFree(p);
   N.allocations.clear();
   N.levels.clear();
+  N.slevels.clear();
+  N.slevels_top.clear();
   N.d = DevPlan();
   N.vals_owned = nullptr;
-}
-
-// Explicit inverses of the kSolveSB-column diagonal blocks of the fronts that take the super-block solves: a plain
-// library TRSM on the identity (rocblas_dtrsm_strided_batched over the full blocks of a front).  It costs about one
-// millisecond at the S-metric root (some 120 small library kernels) and saves 1.4 ms per solve (4.3 -> 3.0 ms).
-// Fronts of at least 8 * kSolveSB columns (sb_lazy == 0) start it inside the factorisation, on the auxiliary stream:
-// the blocks that are final when the front enters its chain-bound tail (fewer than sb_tail_rows rows left, idle CUs),
-// the rest behind the last panel; the first solve waits for sb_event.  Smaller fronts prepare on demand, before the
-// (sb_lazy + 1)-th solve (numeric_sb_prepare).
-static std::string sb_blas(Numeric& N, hipStream_t st, rocblas_handle* out) {
-  if (!N.blas) {
-    rocblas_handle h2 = nullptr;
-    if (rocblas_create_handle(&h2) != rocblas_status_success) return "rocblas_create_handle failed";
-    N.blas = h2;
-  }
-  *out = (rocblas_handle)N.blas;
-  if (rocblas_set_stream(*out, st) != rocblas_status_success) return "rocblas_set_stream failed";
-  return "";
-}
-// blocks [b_lo, b_hi) of front s2 (b_hi is clipped to the front's block count)
-static std::string sb_prepare_front(Numeric& N, rocblas_handle hb, hipStream_t st, int s2, int b_lo, int b_hi) {
-  DevPlan P = N.d;
-  const double one = 1.0;
-  const int64_t kk = N.sn_k[s2], ff = N.sn_f[s2];
-  const int nfull = (int)(kk / kSolveSB), klast = (int)(kk - (int64_t)nfull * kSolveSB);
-  const int nblk = nfull + (klast ? 1 : 0);
-  b_hi = std::min(b_hi, nblk);
-  if (b_lo >= b_hi) return "";
-  double* X = P.xsb + N.xsb_pos_host[s2] + (size_t)b_lo * kSolveSB * kSolveSB;
-  const double* Lf = P.arena + N.front_pos_host[s2] + (size_t)b_lo * kSolveSB * (ff + 1);
-  const int64_t tot = (int64_t)(b_hi - b_lo) * kSolveSB * kSolveSB;
-  hipLaunchKernelGGL(k_sb_identity, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, X, kSolveSB, tot);
-  const int full_hi = std::min(b_hi, nfull);
-  if (full_hi > b_lo &&
-      rocblas_dtrsm_strided_batched(hb, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_unit,
-                                    kSolveSB, kSolveSB, &one, Lf, (rocblas_int)ff, (rocblas_stride)kSolveSB * (ff + 1), X,
-                                    kSolveSB, (rocblas_stride)kSolveSB * kSolveSB, full_hi - b_lo) != rocblas_status_success)
-    return "rocblas_dtrsm_strided_batched failed";
-  if (klast && b_hi == nblk &&
-      rocblas_dtrsm(hb, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_unit, klast, klast, &one,
-                    Lf + (size_t)(nfull - b_lo) * kSolveSB * (ff + 1), (rocblas_int)ff, X + (size_t)(nfull - b_lo) * kSolveSB * kSolveSB,
-                    kSolveSB) != rocblas_status_success)
-    return "rocblas_dtrsm failed";
-  return "";
-}
-static std::string numeric_sb_prepare(Numeric& N, hipStream_t st) {
-  rocblas_handle hb = nullptr;
-  std::string e = sb_blas(N, st, &hb);
-  if (!e.empty()) return e;
-  for (int pass = 0; pass < 2; ++pass) {
-    const std::vector<LevelSchedule>& levels = pass == 0 ? N.levels : N.levels_top;
-    for (const LevelSchedule& L : levels) {
-      const Segment& g = L.seg[3];
-      if (!g.cnt || g.mink < 2 * kSolveSB) continue;
-      for (int q = 0; q < g.cnt; ++q)
-        if (!(e = sb_prepare_front(N, hb, st, N.sched_host[g.off + q], 0, 1 << 30)).empty()) return e;
-    }
-  }
-  N.sb_ready = true;
-  return "";
 }
 
 std::string numeric_read_counts(Numeric& N, hipStream_t stream, unsigned long long out[5]) {
@@ -1771,10 +1397,9 @@ std::string numeric_factor_enqueue(Numeric& N, const double* d_vals, double tol,
   if (reset_counters) OKKT_HIP_TRY(hipMemsetAsync(P.counters, 0, (size_t)kCountSlots * kCountStride * sizeof(unsigned long long), st));
   if (N.early_check && N.early_device && which == 0 && N.levels_top.empty() && reset_counters) { P.want_pos = N.early_n; P.want_neg = N.early_m; }
   N.la_used = 0;
-  N.sb_ready = false;            // the super-block inverses belong to the previous factorisation
-  N.sb_wait = false;
+  N.inv_wait = false;            // the block inverses belong to the previous factorisation
+  bool inv_on_aux = false;
   N.early_exited = false;
-  N.solves_since_factor = 0;
   const int NB = N.nb;
   static const int dbg_syrk = getenv("OKKT_DEBUG_SYRK") ? atoi(getenv("OKKT_DEBUG_SYRK")) : 0;
   static const int split_min_rows = getenv("OKKT_SPLIT_MIN_ROWS") ? atoi(getenv("OKKT_SPLIT_MIN_ROWS")) : 5000;
@@ -1963,27 +1588,42 @@ std::string numeric_factor_enqueue(Numeric& N, const double* d_vals, double tol,
       // main stream's CU mask leaves free: k_big_diag is a lone, latency-bound workgroup) runs
       // head2(q) -> Panel(q + 1)  while the main stream runs rest(q) back to back with rest(q - 1).
       // Used only while the rest is large enough; afterwards everything runs in order on the main stream.
-      // super-block inverses started inside the factorisation (see sb_prepare_front)
-      const bool sb_eager = which == 0 && N.levels_top.empty() && N.use_sb && N.sb_lazy == 0 && N.stream_aux != nullptr && g.mink >= 2 * kSolveSB;
-      int sb_done = 0;       // pivot columns (a multiple of kSolveSB, or all) whose blocks are already being inverted
-      auto sb_range = [&](int cols_final, bool last) -> std::string {
-        const int upto = last ? (1 << 30) : cols_final / kSolveSB;   // blocks [sb_done / kSolveSB, upto)
-        if (!last && upto * kSolveSB <= sb_done) return "";
-        hipEvent_t evs;
-        std::string e2 = next_event(&evs);
-        if (!e2.empty()) return e2;
-        OKKT_HIP_TRY(hipEventRecord(evs, st));
-        OKKT_HIP_TRY(hipStreamWaitEvent(N.stream_aux, evs, 0));
-        rocblas_handle hb = nullptr;
-        if (!(e2 = sb_blas(N, N.stream_aux, &hb)).empty()) return e2;
-        for (int q = 0; q < g.cnt; ++q)
-          if (!(e2 = sb_prepare_front(N, hb, N.stream_aux, N.sched_host[g.off + q], sb_done / kSolveSB, upto)).empty()) return e2;
-        sb_done = last ? (1 << 30) : upto * kSolveSB;
-        if (last) {
-          if (!N.sb_event) OKKT_HIP_TRY(hipEventCreateWithFlags(&N.sb_event, hipEventDisableTiming));
-          OKKT_HIP_TRY(hipEventRecord(N.sb_event, N.stream_aux));
-          N.sb_ready = true;
-          N.sb_wait = true;
+      // Inverses of the diagonal blocks for the solves (solve.hip).  The NB x NB ones (k_big_invert) run on `st` at the end
+      // of the level; the kSolveBlock-column ones of the wide fronts run on the auxiliary stream beside the next levels.
+      // A front of at least four such blocks starts early: the blocks that are final when it enters its chain-bound tail
+      // (fewer than sb_tail_rows rows left, idle CUs) are inverted during the tail, the rest behind the last panel.
+      const SolveLevel& SL = (which == 0 ? N.slevels : N.slevels_top)[l];
+      hipStream_t inv_st = N.stream_aux ? N.stream_aux : st;
+      const bool inv_early = N.stream_aux != nullptr && SL.wide_cnt > 0 && g.maxk >= 4 * kSolveBlock && N.sb_tail_rows >= 0;
+      int inv_steps_done = 0, inv_blocks_done = 0;
+      const size_t lds_inv = ((size_t)(NB + 2) * NB + 3 * kTld * kIB) * sizeof(double);
+      auto inv_range = [&](int steps_final, bool last) -> std::string {
+        std::string e2;
+        if (!last) {
+          const int blocks_upto = (int)((int64_t)steps_final * NB / kSolveBlock);
+          if (blocks_upto <= inv_blocks_done) return "";
+          const int steps_upto = (int)(((int64_t)blocks_upto * kSolveBlock + NB - 1) / NB);
+          hipEvent_t evs;
+          if (!(e2 = next_event(&evs)).empty()) return e2;
+          OKKT_HIP_TRY(hipEventRecord(evs, st));
+          OKKT_HIP_TRY(hipStreamWaitEvent(inv_st, evs, 0));
+          hipLaunchKernelGGL(k_big_invert, dim3(steps_upto - inv_steps_done, g.cnt), dim3(256), lds_inv, inv_st, P, list, NB, inv_steps_done);
+          if (!(e2 = solve_invert_enqueue(N, inv_st, SL, inv_blocks_done, blocks_upto)).empty()) return e2;
+          inv_steps_done = steps_upto; inv_blocks_done = blocks_upto;
+          inv_on_aux = true;
+          return "";
+        }
+        if (nsteps > inv_steps_done)
+          hipLaunchKernelGGL(k_big_invert, dim3(nsteps - inv_steps_done, g.cnt), dim3(256), lds_inv, st, P, list, NB, inv_steps_done);
+        if (SL.wide_cnt) {
+          if (inv_st != st) {
+            hipEvent_t evs;
+            if (!(e2 = next_event(&evs)).empty()) return e2;
+            OKKT_HIP_TRY(hipEventRecord(evs, st));
+            OKKT_HIP_TRY(hipStreamWaitEvent(inv_st, evs, 0));
+            inv_on_aux = true;
+          }
+          if (!(e2 = solve_invert_enqueue(N, inv_st, SL, inv_blocks_done, 1 << 30)).empty()) return e2;
         }
         return "";
       };
@@ -2011,18 +1651,14 @@ std::string numeric_factor_enqueue(Numeric& N, const double* d_vals, double tol,
           if (ev_panel) { OKKT_HIP_TRY(hipStreamWaitEvent(st, ev_panel, 0)); ev_panel = nullptr; }
           // columns below stepB * NB are final behind this point of `st`: once the front is in its chain-bound tail, the
           // inversion of the finished super-blocks starts on the auxiliary stream
-          if (sb_eager && sb_done == 0 && rem_rows(stepB) < N.sb_tail_rows && !(e = sb_range(stepB * NB, false)).empty()) return e;
+          if (inv_early && inv_blocks_done == 0 && rem_rows(stepB) < N.sb_tail_rows && !(e = inv_range(stepB, false)).empty()) return e;
           if (!(e = launch_syrk(st, stepA, gs_cur, stepB, 0, par, 0)).empty()) return e;
           if (more && !(e = launch_panels(st, stepB, gs_next, par ^ 1)).empty()) return e;
         }
         stepA = stepB; gs_cur = gs_next; par ^= 1;
       }
-      // full inverses of the diagonal blocks (for the solves), all blocks of the level in one launch
-      {
-        const size_t lds_inv = ((size_t)(NB + 2) * NB + 3 * kTld * kIB) * sizeof(double);
-        hipLaunchKernelGGL(k_big_invert, dim3(nsteps, g.cnt), dim3(256), lds_inv, st, P, list, NB);
-      }
-      if (sb_eager && !(e = sb_range(0, true)).empty()) return e;
+      // full inverses of the diagonal blocks (for the solves): the remaining block columns of the level in one launch
+      if (!(e = inv_range(nsteps, true)).empty()) return e;
       if (seg_la) {   // join the handle's stream
         hipEvent_t evj;
         if (!(e = next_event(&evj)).empty()) return e;
@@ -2031,308 +1667,22 @@ std::string numeric_factor_enqueue(Numeric& N, const double* d_vals, double tol,
       }
     }
   }
-  OKKT_HIP_TRY(hipGetLastError());
-  return "";
-}
-
-
-// ---------------------------------------------------------------------------------------------------------------
-// Super-block solves for fronts with many pivot columns (the dense root): the 128-column step kernels are pure
-// launch latency there (130 dependent launches of ~10-15 us per sweep).  After the factorisation the unit-lower
-// diagonal blocks of kSolveSB columns are inverted explicitly (X = L_bb^-1, a plain library TRSM on the identity:
-// rocblas_dtrsm_strided_batched); a sweep then takes two launches per kSolveSB columns: a block product with X
-// and one tall GEMV with the panel below (forward) / the row block to the left (backward).
-
-// forward, block b: partial products of y = X_b * w_b.  Workgroup (rb, cq): rows [rb * 64, +64), columns
-// [cq * 256, +256) (wave wv: 64 of them, two batches of 32 loads in flight); the four partial vectors are summed by
-// the consumer (k_sb_fwd_upd), which also stores z = y / d.  64 workgroups instead of 16: the product is pure latency.
-__global__ __launch_bounds__(256) void k_sb_fwd_y(DevPlan P, const int* __restrict__ list, int b) {
-  __shared__ double wj[256], part[4][64];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int s = list[blockIdx.y];
-  const int col0 = P.sn_col0[s];
-  const int k = P.sn_col0[s + 1] - col0;
-  const int c0 = b * kSolveSB;
-  if (c0 >= k) return;
-  const int kb = min(kSolveSB, k - c0);
-  const int i = blockIdx.x * 64 + lane, cq = blockIdx.z;
-  if ((int)blockIdx.x * 64 >= kb) return;
-  double* yp = P.ysb + P.ysb_pos[s] + (size_t)cq * kSolveSB;
-  // X is lower triangular (zero above the diagonal, 1 on it): no row of this workgroup reaches beyond its last row
-  const int pend = min(kb, (int)blockIdx.x * 64 + 64);
-  if (cq * 256 >= pend) { if (wv == 0 && i < kb) yp[i] = 0.0; return; }
-  const double* w = P.bigw + P.bigcol_base[s] + c0 + cq * 256;
-  const double* X = P.xsb + P.xsb_pos[s] + (size_t)b * kSolveSB * kSolveSB + (size_t)cq * 256 * kSolveSB;
-  const int kq = min(256, kb - cq * 256);          // columns of this quarter
-  const int ic = min(i, kb - 1);
-  double v[2][32];
-#pragma unroll
-  for (int h = 0; h < 2; ++h)
-#pragma unroll
-    for (int q = 0; q < 32; ++q) v[h][q] = X[(size_t)min(wv * 64 + h * 32 + q, kq - 1) * kSolveSB + ic];
-  wj[tid] = tid < kq ? w[tid] : 0.0;
-  __syncthreads();
-  double a = 0.0;
-#pragma unroll
-  for (int h = 0; h < 2; ++h)
-#pragma unroll
-    for (int q = 0; q < 32; ++q) a += (wv * 64 + h * 32 + q < kq) ? v[h][q] * wj[wv * 64 + h * 32 + q] : 0.0;
-  part[wv][lane] = a;
-  __syncthreads();
-  if (wv == 0 && i < kb) yp[i] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
-}
-// forward, block b: y = sum of the four partials, z = y / d (first workgroup), then the rows below the block:
-// w[r] -= sum_p L[r][c0 + p] y[p]   (and the contribution vector on the last block)
-__global__ __launch_bounds__(256) void k_sb_fwd_upd(DevPlan P, const int* __restrict__ list, int b) {
-  __shared__ double yj[kSolveSB], part[4][64];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int s = list[blockIdx.y];
-  const int col0 = P.sn_col0[s];
-  const int k = P.sn_col0[s + 1] - col0;
-  const int f = (int)(P.row_ptr[s + 1] - P.row_ptr[s]);
-  const int c0 = b * kSolveSB;
-  if (c0 >= k) return;
-  const int kb = min(kSolveSB, k - c0);
-  const int r = c0 + kb + blockIdx.x * 64 + lane;
-  if (blockIdx.x > 0 && c0 + kb + (int)blockIdx.x * 64 >= f) return;
-  double* w = P.bigw + P.bigcol_base[s];
-  const double* yp = P.ysb + P.ysb_pos[s];
-  const int rc = min(r, f - 1);
-  const double wr = w[rc];
-  for (int p = tid; p < kSolveSB; p += 256) {
-    const int pc = min(p, kb - 1);
-    const double y = (yp[pc] + yp[kSolveSB + pc]) + (yp[2 * kSolveSB + pc] + yp[3 * kSolveSB + pc]);
-    yj[p] = p < kb ? y : 0.0;
-    if (blockIdx.x == 0 && p < kb) P.xwork[col0 + c0 + p] = y / P.dvals[col0 + c0 + p];
-  }
-  __syncthreads();
-  if (c0 + kb + (int)blockIdx.x * 64 >= f) return;
-  const double* L = P.arena + P.front_pos[s] + (size_t)c0 * f + rc;
-  double a = 0.0;
-  for (int p0 = wv * 256; p0 < min(kb, wv * 256 + 256); p0 += 64) {
-    double v[64];       // 64 loads per lane in flight: the panel is streamed from HBM, four round trips per wave
-#pragma unroll
-    for (int q = 0; q < 64; ++q) v[q] = L[(size_t)min(p0 + q, kb - 1) * f];
-#pragma unroll
-    for (int q = 0; q < 64; ++q) a += (p0 + q < kb) ? v[q] * yj[p0 + q] : 0.0;
-  }
-  part[wv][lane] = a;
-  __syncthreads();
-  if (wv == 0 && r < f) {
-    const double acc = wr - ((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]));
-    w[r] = acc;
-    if (c0 + kb >= k && r >= k) P.cv[P.cv_pos[s] + (r - k)] = acc;
-  }
-}
-// backward, block b: partial products of x = X_b' z.  Workgroup (cb, rq): columns [cb * 64, +64), rows
-// [rq * 256, +256); wave: 16 columns, lanes along the rows (4 loads each), shuffle reduction
-__global__ __launch_bounds__(256) void k_sb_bwd_x(DevPlan P, const int* __restrict__ list, int b) {
-  __shared__ double zj[256];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int s = list[blockIdx.y];
-  const int col0 = P.sn_col0[s];
-  const int k = P.sn_col0[s + 1] - col0;
-  const int c0 = b * kSolveSB;
-  if (c0 >= k) return;
-  const int kb = min(kSolveSB, k - c0);
-  const int rq = blockIdx.z;
-  if ((int)blockIdx.x * 64 >= kb) return;
-  double* xp = P.ysb + P.ysb_pos[s] + (size_t)rq * kSolveSB;
-  const int i0 = blockIdx.x * 64 + wv * 16;
-  // column i of X is zero above row i: a row chunk that ends above the first column of this workgroup contributes nothing
-  if (rq * 256 >= kb || rq * 256 + 255 < (int)blockIdx.x * 64) {
-    if (lane < 16 && i0 + lane < kb) xp[i0 + lane] = 0.0;
-    return;
-  }
-  const double* X = P.xsb + P.xsb_pos[s] + (size_t)b * kSolveSB * kSolveSB + rq * 256;
-  const int kq = min(256, kb - rq * 256);
-  double v[16][4];
-#pragma unroll
-  for (int q = 0; q < 16; ++q) {
-    const double* xc = X + (size_t)min(i0 + q, kb - 1) * kSolveSB;
-#pragma unroll
-    for (int t = 0; t < 4; ++t) v[q][t] = xc[min(lane + 64 * t, kq - 1)];
-  }
-  zj[tid] = tid < kq ? P.xwork[col0 + c0 + rq * 256 + tid] : 0.0;
-  __syncthreads();
-#pragma unroll
-  for (int q = 0; q < 16; ++q) {
-    double a = 0.0;
-#pragma unroll
-    for (int t = 0; t < 4; ++t) a += (lane + 64 * t < kq) ? v[q][t] * zj[lane + 64 * t] : 0.0;
-    for (int o = 32; o > 0; o >>= 1) a += __shfl_down(a, o, 64);
-    if (lane == 0 && i0 + q < kb) xp[i0 + q] = a;
-  }
-}
-// backward, block b: x_b = sum of the four partials; columns c < c0:  x[c] -= sum_p L[c0 + p][c] x_b[p];
-// one extra workgroup stores x_b itself
-__global__ __launch_bounds__(256) void k_sb_bwd_upd(DevPlan P, const int* __restrict__ list, int b) {
-  __shared__ double xj[kSolveSB];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int s = list[blockIdx.y];
-  const int col0 = P.sn_col0[s];
-  const int k = P.sn_col0[s + 1] - col0;
-  const int f = (int)(P.row_ptr[s + 1] - P.row_ptr[s]);
-  const int c0 = b * kSolveSB;
-  if (c0 >= k) return;
-  const int kb = min(kSolveSB, k - c0);
-  const double* xp = P.ysb + P.ysb_pos[s];
-  const int nupd = (c0 + 63) / 64;                 // workgroups that update columns; the next one copies x_b
-  if ((int)blockIdx.x > nupd) return;
-  for (int p = tid; p < kSolveSB; p += 256) {
-    const int pc = min(p, kb - 1);
-    const double x = (xp[pc] + xp[kSolveSB + pc]) + (xp[2 * kSolveSB + pc] + xp[3 * kSolveSB + pc]);
-    xj[p] = p < kb ? x : 0.0;
-  }
-  __syncthreads();
-  if ((int)blockIdx.x == nupd) {
-    for (int p = tid; p < kb; p += 256) P.xwork[col0 + c0 + p] = xj[p];
-    return;
-  }
-  const double* Lrow = P.arena + P.front_pos[s] + c0;
-#pragma unroll 1
-  for (int q0 = 0; q0 < 16; q0 += 4) {
-    const int cb = blockIdx.x * 64 + wv * 16 + q0;
-    if (cb >= c0) break;
-    double v[4][kSolveSB / 64];       // four columns = 64 loads per lane in flight
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const double* col = Lrow + (size_t)min(cb + q, c0 - 1) * f;
-#pragma unroll
-      for (int t = 0; t < kSolveSB / 64; ++t) v[q][t] = col[min(lane + 64 * t, kb - 1)];
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      double a = 0.0;
-#pragma unroll
-      for (int t = 0; t < kSolveSB / 64; ++t) a += (lane + 64 * t < kb) ? v[q][t] * xj[lane + 64 * t] : 0.0;
-      for (int o = 32; o > 0; o >>= 1) a += __shfl_down(a, o, 64);
-      if (lane == 0 && cb + q < c0) P.xwork[col0 + cb + q] -= a;
-    }
-  }
-}
-
-static void launch_fwd_step(hipStream_t st, const DevPlan& P, const int* list, const dim3& gr, int NB, int step) {
-  switch (NB) {
-    case 32: hipLaunchKernelGGL(k_bigsolve_fwd_step<32>, gr, dim3(256), 0, st, P, list, step); break;
-    case 64: hipLaunchKernelGGL(k_bigsolve_fwd_step<64>, gr, dim3(256), 0, st, P, list, step); break;
-    case 96: hipLaunchKernelGGL(k_bigsolve_fwd_step<96>, gr, dim3(256), 0, st, P, list, step); break;
-    default: hipLaunchKernelGGL(k_bigsolve_fwd_step<128>, gr, dim3(256), 0, st, P, list, step); break;
-  }
-}
-static void launch_bwd_step(hipStream_t st, const DevPlan& P, const int* list, const dim3& gr, int NB, int step) {
-  switch (NB) {
-    case 32: hipLaunchKernelGGL(k_bigsolve_bwd_step<32>, gr, dim3(256), 0, st, P, list, step); break;
-    case 64: hipLaunchKernelGGL(k_bigsolve_bwd_step<64>, gr, dim3(256), 0, st, P, list, step); break;
-    case 96: hipLaunchKernelGGL(k_bigsolve_bwd_step<96>, gr, dim3(256), 0, st, P, list, step); break;
-    default: hipLaunchKernelGGL(k_bigsolve_bwd_step<128>, gr, dim3(256), 0, st, P, list, step); break;
-  }
-}
-
-
-// forward (L, then D^-1 fused) sweep over one schedule: which = 0 local subtrees, 1 top of the tree
-std::string numeric_solve_fwd_enqueue(Numeric& N, int which) {
-  DevPlan P = N.d;
-  hipStream_t st = N.stream;
-  const std::vector<LevelSchedule>& levels = which == 0 ? N.levels : N.levels_top;
-  const int nl = (int)levels.size();
-  const int NB = N.nb;
-  hipEvent_t ev_sb = nullptr;      // set while the inversion runs on the auxiliary stream, beside the lower levels' sweeps
-  if (which == 0 && N.use_sb && !N.sb_ready && (N.solves_since_factor >= N.sb_lazy)) {
-    hipStream_t ps = N.stream_aux ? N.stream_aux : st;
-    if (ps != st) {
-      if (N.la_used + 2 > N.la_events.size())
-        for (int q = 0; q < 64; ++q) { hipEvent_t e2; OKKT_HIP_TRY(hipEventCreateWithFlags(&e2, hipEventDisableTiming)); N.la_events.push_back(e2); }
-      hipEvent_t ev0 = N.la_events[N.la_used++];
-      ev_sb = N.la_events[N.la_used++];
-      OKKT_HIP_TRY(hipEventRecord(ev0, st));
-      OKKT_HIP_TRY(hipStreamWaitEvent(ps, ev0, 0));
-    }
-    std::string e = numeric_sb_prepare(N, ps);
-    if (!e.empty()) return e;
-    if (ev_sb) OKKT_HIP_TRY(hipEventRecord(ev_sb, ps));
-  }
-  if (getenv("OKKT_DEBUG_SB")) fprintf(stderr, "okkt: solve fwd which=%d solves_since_factor=%d sb_ready=%d use_sb=%d\n", which, N.solves_since_factor, (int)N.sb_ready, N.use_sb);
-  if (which == 0) ++N.solves_since_factor;
-  const bool sb = N.use_sb && N.sb_ready;
-  if (sb && N.sb_wait) { OKKT_HIP_TRY(hipStreamWaitEvent(st, N.sb_event, 0)); N.sb_wait = false; }   // inversion started by the factorisation
-  for (int l = 0; l < nl; ++l) {
-    const LevelSchedule& L = levels[l];
-    for (int c = 0; c < 3; ++c) {
-      const Segment& g = L.seg[c];
-      if (!g.cnt) continue;
-      const size_t lds = (size_t)g.maxf * sizeof(double);
-      if (c == 0) hipLaunchKernelGGL(k_solve_fwd<64>, dim3(g.cnt), dim3(64), lds, st, P, P.sched + g.off);
-      else hipLaunchKernelGGL(k_solve_fwd<256>, dim3(g.cnt), dim3(256), lds, st, P, P.sched + g.off);
-    }
-    const Segment& g = L.seg[3];
-    if (g.cnt) {
-      const int* list = P.sched + g.off;
-      hipLaunchKernelGGL(k_bigsolve_fwd_asm, dim3((g.maxf + 255) / 256, g.cnt), dim3(256), 0, st, P, list);
-      if (sb && g.mink >= 2 * kSolveSB) {
-        if (ev_sb) { OKKT_HIP_TRY(hipStreamWaitEvent(st, ev_sb, 0)); ev_sb = nullptr; }
-        const int nblk = (g.maxk + kSolveSB - 1) / kSolveSB;
-        for (int b = 0; b < nblk; ++b) {
-          hipLaunchKernelGGL(k_sb_fwd_y, dim3(kSolveSB / 64, g.cnt, 4), dim3(256), 0, st, P, list, b);
-          const int rem = std::max(g.maxf - b * kSolveSB, 0);      // upper bound on the rows below block b
-          hipLaunchKernelGGL(k_sb_fwd_upd, dim3(std::max(1, (rem + 63) / 64), g.cnt), dim3(256), 0, st, P, list, b);
-        }
-        continue;
-      }
-      const int nsteps = (g.maxk + NB - 1) / NB;
-      for (int step = 0; step < nsteps; ++step) {
-        const int rem = std::max(g.maxf - step * NB, 0);  // upper bound on the rows below block `step`
-        launch_fwd_step(st, P, list, dim3(std::max(1, (rem + 63) / 64), g.cnt), NB, step);
-      }
-    }
-  }
-  if (ev_sb) OKKT_HIP_TRY(hipStreamWaitEvent(st, ev_sb, 0));
-  OKKT_HIP_TRY(hipGetLastError());
-  return "";
-}
-
-std::string numeric_solve_bwd_enqueue(Numeric& N, int which) {
-  DevPlan P = N.d;
-  hipStream_t st = N.stream;
-  const std::vector<LevelSchedule>& levels = which == 0 ? N.levels : N.levels_top;
-  const int nl = (int)levels.size();
-  const int NB = N.nb;
-  for (int l = nl - 1; l >= 0; --l) {
-    const LevelSchedule& L = levels[l];
-    const Segment& gb = L.seg[3];
-    if (gb.cnt) {
-      const int* list = P.sched + gb.off;
-      hipLaunchKernelGGL(k_bigsolve_bwd_pre, dim3((gb.maxk + 3) / 4, gb.cnt), dim3(256), 0, st, P, list);
-      if (N.use_sb && N.sb_ready && gb.mink >= 2 * kSolveSB) {
-        const int nblk = (gb.maxk + kSolveSB - 1) / kSolveSB;
-        for (int b = nblk - 1; b >= 0; --b) {
-          hipLaunchKernelGGL(k_sb_bwd_x, dim3(kSolveSB / 64, gb.cnt, 4), dim3(256), 0, st, P, list, b);
-          hipLaunchKernelGGL(k_sb_bwd_upd, dim3((b * kSolveSB + 63) / 64 + 1, gb.cnt), dim3(256), 0, st, P, list, b);
-        }
-      } else {
-      const int nsteps = (gb.maxk + NB - 1) / NB;
-      for (int step = nsteps - 1; step >= 0; --step)
-        launch_bwd_step(st, P, list, dim3(std::max(1, (step * NB + 63) / 64), gb.cnt), NB, step);
-      }
-    }
-    for (int c = 0; c < 3; ++c) {
-      const Segment& g = L.seg[c];
-      if (!g.cnt) continue;
-      const size_t lds = (size_t)g.maxf * sizeof(double);
-      if (c == 0) hipLaunchKernelGGL(k_solve_bwd<64>, dim3(g.cnt), dim3(64), lds, st, P, P.sched + g.off);
-      else hipLaunchKernelGGL(k_solve_bwd<256>, dim3(g.cnt), dim3(256), lds, st, P, P.sched + g.off);
-    }
+  if (inv_on_aux) {    // the next solve waits for the block inversions that are still running on the auxiliary stream
+    if (!N.inv_event) OKKT_HIP_TRY(hipEventCreateWithFlags(&N.inv_event, hipEventDisableTiming));
+    OKKT_HIP_TRY(hipEventRecord(N.inv_event, N.stream_aux));
+    N.inv_wait = true;
   }
   OKKT_HIP_TRY(hipGetLastError());
   return "";
 }
 
-std::string numeric_solve_enqueue(Numeric& N) {
+
+std::string numeric_solve_enqueue(Numeric& N, int R) {
   std::string e;
-  if (!(e = numeric_solve_fwd_enqueue(N, 0)).empty()) return e;
-  if (!(e = numeric_solve_fwd_enqueue(N, 1)).empty()) return e;
-  if (!(e = numeric_solve_bwd_enqueue(N, 1)).empty()) return e;
-  return numeric_solve_bwd_enqueue(N, 0);
+  if (!(e = solve_fwd_enqueue(N, 0, R)).empty()) return e;
+  if (!(e = solve_fwd_enqueue(N, 1, R)).empty()) return e;
+  if (!(e = solve_bwd_enqueue(N, 1, R)).empty()) return e;
+  return solve_bwd_enqueue(N, 0, R);
 }
 
 // ---- multi-GPU exchange helpers (contribution blocks / vectors of the cut, solution pieces) -------------
@@ -2390,14 +1740,6 @@ std::string numeric_dist_x(Numeric& N, int mode, double* d_buf) {
   return "";
 }
 
-void launch_permute_in(const Numeric& N, const double* d_rhs) {
-  const int n = N.d.n;
-  if (n) hipLaunchKernelGGL(k_permute_in, dim3((n + 255) / 256), dim3(256), 0, N.stream, n, N.d.perm, d_rhs, N.d.xwork);
-}
-void launch_permute_out(const Numeric& N, double* d_sol, bool accumulate) {
-  const int n = N.d.n;
-  if (n) hipLaunchKernelGGL(k_permute_out, dim3((n + 255) / 256), dim3(256), 0, N.stream, n, N.d.perm, N.d.xwork, d_sol, accumulate ? 1 : 0);
-}
 void launch_set_shift(const Numeric& N, double delta, int64_t nshift) {
   const int n = N.d.n;
   if (n) hipLaunchKernelGGL(k_set_shift, dim3((n + 255) / 256), dim3(256), 0, N.stream, n, N.d.perm, delta, (int)nshift, N.d.diagadd);

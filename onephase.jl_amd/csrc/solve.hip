@@ -1,0 +1,956 @@
+// Triangular solves of the multifrontal LDL^T, gfx950:  x = P' L^-T D^-1 L^-1 P b  for up to kMaxRhs right-hand sides at once
+// (`F \ b`, /root/reference/src/linear_system_solvers/julia.jl:99-113; the three refinement solves of schur.jl:158-175).
+//
+// The sweeps are HBM-bound (2 * 8 * nnz(L) bytes per solve) and, on the big fronts, a chain of dependent steps; what costs
+// time is the NUMBER of dependent launches and how much of L each one streams.  Design:
+//   * every big front owns explicit inverses of its unit-lower diagonal blocks: fronts with k <= NB pivot columns use the
+//     NB x NB inverse that the factorisation leaves in `invl`; wider fronts get inverses of their kSB-column diagonal blocks
+//     (k_xinv_*: recursive doubling X = [[A^-1, 0], [-B^-1 C A^-1, B^-1]] from the NB x NB inverses, FP64 MFMA products),
+//     computed on the auxiliary stream beside the factorisation.  A sweep over a front is then one product with X and one
+//     tall GEMV per kSB columns -- two launches -- instead of two per 128 columns;
+//   * a level's fronts with k <= NB take ONE forward launch: every workgroup rebuilds y = X w redundantly (128 x 128),
+//     assembles its own rows from the children's contribution vectors and applies its 64 rows of the panel;
+//   * all kernels carry R right-hand sides through one pass over L (R = 1, 2, 4): the panel values are loaded once and
+//     multiplied with R vectors held in LDS -- a batched okkt_solve streams the factor once per batch, not once per rhs;
+//   * panel reads are 16 bytes per lane (two rows), 8 - 16 loads in flight per lane.
+// Results are deterministic: every output entry is owned by one workgroup that sums in a fixed order.
+#include "numeric.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+
+namespace okkt {
+
+#define OKKT_HIP_TRY(expr)                                                         \
+  do {                                                                             \
+    hipError_t e__ = (expr);                                                       \
+    if (e__ != hipSuccess)                                                         \
+      return std::string(#expr) + ": " + hipGetErrorString(e__);                   \
+  } while (0)
+
+typedef double d4_t __attribute__((ext_vector_type(4)));
+typedef double d2_t __attribute__((ext_vector_type(2)));
+
+constexpr int kSB = kSolveBlock;        // columns of an explicitly inverted diagonal block
+constexpr int kCS = 4;                  // splits of a block product (partial vectors summed by the consumer)
+
+__device__ __forceinline__ int round128(int v) { return (v + 127) & ~127; }
+// block b of a front with k pivot columns: first column, width, leading dimension and storage offset of its inverse
+__device__ __forceinline__ void xblock(int k, int b, int& c0, int& kb, int& ld, int64_t& off) {
+  c0 = b * kSB;
+  kb = min(kSB, k - c0);
+  ld = kb >= kSB ? kSB : round128(kb);
+  off = (int64_t)b * kSB * kSB;
+}
+
+// forward right-hand-side entry of front row r (before any block of this front has been applied): the permuted rhs on the
+// pivot rows plus the children's contribution vectors through the inverted extend-add lists (fixed order)
+template <int R>
+__device__ __forceinline__ void fwd_gather(const DevPlan& P, int64_t gcb, int col0, int k, int r, double (&w)[R]) {
+#pragma unroll
+  for (int q = 0; q < R; ++q) w[q] = r < k ? P.xwork[(size_t)q * P.xw_stride + col0 + r] : 0.0;
+  const int64_t q0 = P.ea_ptr[gcb + r], q1 = P.ea_ptr[gcb + r + 1];
+  for (int64_t e = q0; e < q1; ++e) {
+    const int64_t pos = P.cv_pos[P.ea_child[e]] + P.ea_jj[e];
+#pragma unroll
+    for (int q = 0; q < R; ++q) w[q] += P.cv[(size_t)q * P.cv_stride + pos];
+  }
+}
+// where the running forward vector of front row r lives: pivot rows in xwork, the rows below in the front's contribution vector
+template <int R>
+__device__ __forceinline__ double* fwd_slot(const DevPlan& P, int s, int col0, int k, int r, int q) {
+  return r < k ? P.xwork + (size_t)q * P.xw_stride + col0 + r : P.cv + (size_t)q * P.cv_stride + P.cv_pos[s] + (r - k);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// explicit inverses of the kSB-column diagonal blocks
+// ------------------------------------------------------------------------------------------------------------------
+// The NB x NB diagonal tiles of X_b <- the NB x NB inverses of the factorisation (one workgroup per tile).  Everything else
+// of the lower triangle is overwritten by the doubling levels below, the strict upper tiles and the padding rows / columns
+// beyond the block are zero from the allocation and are never written.
+__global__ __launch_bounds__(256) void k_xinv_init(DevPlan P, const int* __restrict__ list, int b0, int nbk, int NB) {
+  const int s = list[blockIdx.z / nbk];
+  const int b = b0 + (int)(blockIdx.z % nbk);
+  const int k = P.sn_col0[s + 1] - P.sn_col0[s];
+  int c0, kb, ld; int64_t off;
+  xblock(k, b, c0, kb, ld, off);
+  if (kb <= 0) return;
+  const int ti = blockIdx.x;
+  if (ti * NB >= kb) return;
+  double* X = P.xinv + P.xinv_pos[s] + off;
+  const double* Inb = P.invl + P.invl_pos[s] + (size_t)(c0 / NB + ti) * NB * NB;
+  for (int e = threadIdx.x; e < NB * NB; e += 256) {
+    const int i = e % NB, j = e / NB;
+    X[(size_t)(ti * NB + j) * ld + ti * NB + i] = Inb[i + (size_t)j * NB];
+  }
+}
+
+// One doubling level s -> 2s of the recursive inverse.  Pair p of block b: A = X[2ps.., 2ps..] (s x s), B = X[(2p+1)s.., (2p+1)s..]
+// (M x M, M <= s), C = L[(2p+1)s.., 2ps..] of the front.  PHASE 0: T = C * A into xtmp; PHASE 1: X21 = -B * T.
+// 64 x 64 tile per workgroup, 32 x 32 per wave as 2 x 2 v_mfma_f64_16x16x4; operands through LDS in k-chunks of 16.
+// The triangular operand bounds the k-range of a tile (A lower: k >= n0; B lower: k < m0 + 64).
+template <int PHASE>
+__global__ __launch_bounds__(256) void k_xinv_gemm(DevPlan P, const int* __restrict__ list, int b0, int nbk, int sz) {
+  __shared__ double As[16][68], Bs[16][68];
+  const int s = list[blockIdx.z / nbk];
+  const int b = b0 + (int)(blockIdx.z % nbk);
+  const int k = P.sn_col0[s + 1] - P.sn_col0[s];
+  const int f = (int)(P.row_ptr[s + 1] - P.row_ptr[s]);
+  int c0, kb, ld; int64_t off;
+  xblock(k, b, c0, kb, ld, off);
+  if (kb <= 0) return;
+  const int p = blockIdx.y;
+  const int r0 = (2 * p + 1) * sz, q0 = 2 * p * sz;       // rows of the lower half, columns of the left half (inside the block)
+  if (r0 >= kb) return;
+  const int M = min(sz, kb - r0), N = sz;
+  const int tn = (N + 63) / 64;
+  const int tile_m = (int)blockIdx.x / tn, tile_n = (int)blockIdx.x % tn;
+  const int m0 = tile_m * 64, n0 = tile_n * 64;
+  if (m0 >= M) return;
+  double* X = P.xinv + P.xinv_pos[s] + off;
+  double* T = P.xtmp + P.xinv_pos[s] + off;
+  const double* Am; int lda;
+  const double* Bm; int ldb;
+  double* Cm; int ldc;
+  int kbeg, kend;
+  if (PHASE == 0) {
+    Am = P.arena + P.front_pos[s] + (size_t)(c0 + q0) * f + (c0 + r0); lda = f;     // C block of L
+    Bm = X + (size_t)q0 * ld + q0; ldb = ld;                                        // A^-1, lower triangular
+    Cm = T + (size_t)q0 * ld + r0; ldc = ld;
+    kbeg = n0; kend = sz;
+  } else {
+    Am = X + (size_t)r0 * ld + r0; lda = ld;                                        // B^-1, lower triangular
+    Bm = T + (size_t)q0 * ld + r0; ldb = ld;
+    Cm = X + (size_t)q0 * ld + r0; ldc = ld;
+    kbeg = 0; kend = min(M, m0 + 64);
+  }
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const int wm0 = (wv & 1) * 32, wn0 = (wv >> 1) * 32;
+  d4_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = (d4_t){0.0, 0.0, 0.0, 0.0};
+  for (int k0 = kbeg & ~15; k0 < kend; k0 += 16) {
+    // stage: A tile 64 rows x 16 k (columns of A are contiguous), B tile 16 k x 64 columns
+    {
+      const int m = tid & 63;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int kk = (tid >> 6) + 4 * j;
+        const bool ok = m0 + m < M && k0 + kk >= kbeg && k0 + kk < kend;
+        const double v = Am[(size_t)min(k0 + kk, kend - 1) * lda + min(m0 + m, M - 1)];
+        As[kk][m] = ok ? v : 0.0;
+      }
+      const int kk = tid & 15;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = (tid >> 4) + 16 * j;
+        const bool ok = k0 + kk >= kbeg && k0 + kk < kend && n0 + n < N;
+        const double v = Bm[(size_t)min(n0 + n, N - 1) * ldb + min(k0 + kk, kend - 1)];
+        Bs[kk][n] = ok ? v : 0.0;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      double av[2], bv[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) av[i] = As[4 * q + l4][wm0 + 16 * i + l15];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bv[j] = Bs[4 * q + l4][wn0 + 16 * j + l15];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[i], bv[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // accumulator register `reg` of tile (i, j): row 16 i + l4 + 4 reg, column 16 j + l15
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int m = m0 + wm0 + 16 * i + l4 + 4 * reg, n = n0 + wn0 + 16 * j + l15;
+        if (m < M && n < N) Cm[(size_t)n * ldc + m] = PHASE == 0 ? acc[i][j][reg] : -acc[i][j][reg];
+      }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// small fronts (one workgroup per task of fronts, the front's vector in LDS), R right-hand sides
+// ------------------------------------------------------------------------------------------------------------------
+template <int TPB, int R>
+__global__ __launch_bounds__(TPB) void k_fs_small(DevPlan P, const int* __restrict__ list, int ldw) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];      // [R][ldw]
+  const int tid = threadIdx.x;
+  const int s_root = list[blockIdx.x];
+  for (int s = P.task_lo[s_root]; s <= s_root; ++s) {      // the task's fronts, children first
+    const int col0 = P.sn_col0[s];
+    const int k = P.sn_col0[s + 1] - col0;
+    const int f = (int)(P.row_ptr[s + 1] - P.row_ptr[s]);
+    const double* L = P.arena + P.front_pos[s];
+    for (int i = tid; i < f; i += TPB)
+#pragma unroll
+      for (int q = 0; q < R; ++q) sm[q * ldw + i] = i < k ? P.xwork[(size_t)q * P.xw_stride + col0 + i] : 0.0;
+    __syncthreads();
+    for (int64_t c = P.child_ptr[s]; c < P.child_ptr[s + 1]; ++c) {
+      const int ch = P.children[c];
+      const int rc = (int)(P.rel_ptr[ch + 1] - P.rel_ptr[ch]);
+      const int* rl = P.rel + P.rel_ptr[ch];
+      const double* cvc = P.cv + P.cv_pos[ch];
+      for (int ii = tid; ii < rc; ii += TPB) {
+        const int d = rl[ii];
+#pragma unroll
+        for (int q = 0; q < R; ++q) sm[q * ldw + d] += cvc[(size_t)q * P.cv_stride + ii];
+      }
+      __syncthreads();
+    }
+    // unit lower triangular k x k
+    for (int j = 0; j < k; ++j) {
+      const double* col = L + (size_t)j * f;
+      for (int i = j + 1 + tid; i < k; i += TPB) {
+        const double l = col[i];
+#pragma unroll
+        for (int q = 0; q < R; ++q) sm[q * ldw + i] -= l * sm[q * ldw + j];
+      }
+      __syncthreads();
+    }
+    // rows below the pivot block: contribution vector for the parent
+    double* cvs = P.cv + P.cv_pos[s];
+    for (int i = k + tid; i < f; i += TPB) {
+      double acc[R];
+#pragma unroll
+      for (int q = 0; q < R; ++q) acc[q] = sm[q * ldw + i];
+      for (int j = 0; j < k; ++j) {
+        const double l = L[(size_t)j * f + i];
+#pragma unroll
+        for (int q = 0; q < R; ++q) acc[q] -= l * sm[q * ldw + j];
+      }
+#pragma unroll
+      for (int q = 0; q < R; ++q) cvs[(size_t)q * P.cv_stride + i - k] = acc[q];
+    }
+    // z = D^-1 y
+    for (int j = tid; j < k; j += TPB) {
+      const double d = P.dvals[col0 + j];
+#pragma unroll
+      for (int q = 0; q < R; ++q) P.xwork[(size_t)q * P.xw_stride + col0 + j] = sm[q * ldw + j] / d;
+    }
+    __threadfence_block();
+    __syncthreads();
+  }
+}
+
+template <int TPB, int R>
+__global__ __launch_bounds__(TPB) void k_bs_small(DevPlan P, const int* __restrict__ list, int ldw) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];      // [R][ldw]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  constexpr int NW = TPB / 64;
+  const int s_root = list[blockIdx.x];
+  for (int s = s_root; s >= P.task_lo[s_root]; --s) {      // the task's fronts, parents first
+    const int col0 = P.sn_col0[s];
+    const int k = P.sn_col0[s + 1] - col0;
+    const int f = (int)(P.row_ptr[s + 1] - P.row_ptr[s]);
+    const double* L = P.arena + P.front_pos[s];
+    const int* rows = P.rows + P.row_ptr[s];
+    for (int i = tid; i < f; i += TPB) {
+      const int g = rows[i];
+#pragma unroll
+      for (int q = 0; q < R; ++q) sm[q * ldw + i] = P.xwork[(size_t)q * P.xw_stride + g];
+    }
+    __syncthreads();
+    // rhs_j = z_j - sum_{i >= k} L[i, j] * x_i
+    for (int j = wv; j < k; j += NW) {
+      const double* col = L + (size_t)j * f;
+      double acc[R];
+#pragma unroll
+      for (int q = 0; q < R; ++q) acc[q] = 0.0;
+      for (int i = k + lane; i < f; i += 64) {
+        const double l = col[i];
+#pragma unroll
+        for (int q = 0; q < R; ++q) acc[q] += l * sm[q * ldw + i];
+      }
+#pragma unroll
+      for (int q = 0; q < R; ++q) {
+        double a = acc[q];
+        for (int o = 32; o > 0; o >>= 1) a += __shfl_down(a, o, 64);
+        if (lane == 0) sm[q * ldw + j] -= a;
+      }
+    }
+    __syncthreads();
+    // unit upper triangular (L11^T) k x k, column oriented
+    for (int j = k - 1; j >= 0; --j) {
+      for (int i = tid; i < j; i += TPB) {
+        const double l = L[(size_t)i * f + j];
+#pragma unroll
+        for (int q = 0; q < R; ++q) sm[q * ldw + i] -= l * sm[q * ldw + j];
+      }
+      __syncthreads();
+    }
+    for (int j = tid; j < k; j += TPB)
+#pragma unroll
+      for (int q = 0; q < R; ++q) P.xwork[(size_t)q * P.xw_stride + col0 + j] = sm[q * ldw + j];
+    __threadfence_block();
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// big fronts, forward
+// ------------------------------------------------------------------------------------------------------------------
+// Fronts with k <= 128 pivot columns: the whole front in one launch.  Workgroup 0 of a front stores z = y / d, workgroup
+// 1 + c owns the rows [k + 64 c, +64) below the pivot block.  Every workgroup assembles w_K and forms y = X w_K itself.
+template <int R>
+__global__ __launch_bounds__(256) void k_fwd_thin(DevPlan P, const int* __restrict__ list, int NB) {
+  __shared__ double wk[R][128], yk[R][128], part[4][R][64];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int s = list[blockIdx.y];
+  const int col0 = P.sn_col0[s];
+  const int k = P.sn_col0[s + 1] - col0;
+  const int f = (int)(P.row_ptr[s + 1] - P.row_ptr[s]);
+  const int nbelow = f - k;
+  if (blockIdx.x > 0 && ((int)blockIdx.x - 1) * 64 >= nbelow) return;
+  const int64_t gcb = P.bigcol_base[s];
+  const double* F = P.arena + P.front_pos[s];
+  const double* X = P.invl + P.invl_pos[s];
+  // panel entries of this thread's row: requested first, they do not depend on y
+  const int row = k + ((int)blockIdx.x - 1) * 64 + lane;       // meaningless for workgroup 0
+  const int rowc = blockIdx.x > 0 ? min(row, f - 1) : 0;
+  double lv[32];
+  {
+    const int cb = wv * 32;
+#pragma unroll
+    for (int q = 0; q < 32; ++q) lv[q] = F[(size_t)min(cb + q, k - 1) * f + rowc];
+  }
+  if (tid < 128) {
+    double w[R];
+    if (tid < k) fwd_gather<R>(P, gcb, col0, k, tid, w);
+#pragma unroll
+    for (int q = 0; q < R; ++q) wk[q][tid] = tid < k ? w[q] : 0.0;
+  }
+  double wr[R];
+#pragma unroll
+  for (int q = 0; q < R; ++q) wr[q] = 0.0;
+  if (wv == 0 && blockIdx.x > 0 && row < f) fwd_gather<R>(P, gcb, col0, k, row, wr);
+  __syncthreads();
+  {
+    // y[c] = sum_{p <= c} X[c][p] w[p]: two threads per row c, 64 loads in flight each (X is zero above the diagonal
+    // and beyond k, wk is zero-padded)
+    const int c = tid >> 1, h = tid & 1;
+    const int cc = min(c, NB - 1);
+    double v[64];
+#pragma unroll
+    for (int q = 0; q < 64; ++q) v[q] = X[cc + (size_t)min(h * 64 + q, NB - 1) * NB];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      double a = 0.0;
+#pragma unroll
+      for (int q = 0; q < 64; ++q) a += (h * 64 + q < NB) ? v[q] * wk[r][h * 64 + q] : 0.0;
+      a += __shfl_xor(a, 1, 64);
+      if (h == 0 && c < NB) {
+        yk[r][c] = a;
+        if (blockIdx.x == 0 && c < k) P.xwork[(size_t)r * P.xw_stride + col0 + c] = a / P.dvals[col0 + c];
+      }
+    }
+  }
+  if (blockIdx.x == 0) return;
+  __syncthreads();
+  {
+    const int cb = wv * 32;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      double a = 0.0;
+#pragma unroll
+      for (int q = 0; q < 32; ++q) a += (cb + q < k) ? lv[q] * yk[r][cb + q] : 0.0;
+      part[wv][r][lane] = a;
+    }
+  }
+  __syncthreads();
+  if (wv == 0 && row < f) {
+    double* cvs = P.cv + P.cv_pos[s] + (row - k);
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+      cvs[(size_t)r * P.cv_stride] = wr[r] - ((part[0][r][lane] + part[1][r][lane]) + (part[2][r][lane] + part[3][r][lane]));
+  }
+}
+
+// Wide fronts, block b: partial products of y = X_b w_b.  Workgroup (i, front, cq): rows [64 i, +64) of the block, columns
+// [cq * kSB / kCS, +kSB / kCS); X_b is lower triangular, so a workgroup stops at its last row.  The kCS partial vectors are
+// summed by the consumer (k_fwd_upd).  In block 0 the right-hand side is assembled on the fly (children's contributions).
+template <int R>
+__global__ __launch_bounds__(256) void k_fwd_y(DevPlan P, const int* __restrict__ list, int b) {
+  constexpr int CW = kSB / kCS;
+  __shared__ double wj[R][CW], part[4][R][64];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int s = list[blockIdx.y];
+  const int col0 = P.sn_col0[s];
+  const int k = P.sn_col0[s + 1] - col0;
+  int c0, kb, ld; int64_t off;
+  xblock(k, b, c0, kb, ld, off);
+  if (kb <= 0) return;
+  const int i0 = blockIdx.x * 64;
+  if (i0 >= kb) return;
+  const int cq = blockIdx.z;
+  const int i = i0 + lane;
+  double* yp = P.ypart + P.ypart_pos[s] + (size_t)cq * kSB;          // [R][kCS][kSB]
+  const int pend = min(kb, i0 + 64);              // no row of this workgroup reaches beyond its last row
+  const int q0 = cq * CW;
+  if (q0 >= pend) {
+    if (wv == 0 && i < kb)
+#pragma unroll
+      for (int r = 0; r < R; ++r) yp[(size_t)r * kCS * kSB + i] = 0.0;
+    return;
+  }
+  const int kq = min(CW, pend - q0);              // columns of this split that matter
+  const double* X = P.xinv + P.xinv_pos[s] + off + (size_t)q0 * ld;
+  const int ic = min(i, kb - 1);
+  const int64_t gcb = P.bigcol_base[s];
+  for (int c = tid; c < CW; c += 256) {
+    double w[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) w[r] = 0.0;
+    if (c < kq) {
+      if (b == 0) fwd_gather<R>(P, gcb, col0, k, q0 + c, w);
+      else {
+#pragma unroll
+        for (int r = 0; r < R; ++r) w[r] = P.xwork[(size_t)r * P.xw_stride + col0 + c0 + q0 + c];
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) wj[r][c] = w[r];
+  }
+  __syncthreads();
+  double a[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) a[r] = 0.0;
+  for (int p0 = wv * (CW / 4); p0 < min(kq, (wv + 1) * (CW / 4)); p0 += 32) {
+    double v[32];
+#pragma unroll
+    for (int q = 0; q < 32; ++q) v[q] = X[(size_t)min(p0 + q, kq - 1) * ld + ic];
+#pragma unroll
+    for (int q = 0; q < 32; ++q) {
+      const double vv = p0 + q < kq ? v[q] : 0.0;
+#pragma unroll
+      for (int r = 0; r < R; ++r) a[r] += vv * wj[r][min(p0 + q, CW - 1)];
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) part[wv][r][lane] = a[r];
+  __syncthreads();
+  if (wv == 0 && i < kb)
+#pragma unroll
+    for (int r = 0; r < R; ++r) yp[(size_t)r * kCS * kSB + i] = (part[0][r][lane] + part[1][r][lane]) + (part[2][r][lane] + part[3][r][lane]);
+}
+
+// Wide fronts, block b: y = sum of the partials (z = y / d stored by the first workgroup), then the rows below the block:
+// w[r] -= sum_p L[r][c0 + p] y[p].  128 rows per workgroup, two rows per lane (16-byte loads), wave g takes the columns
+// g, g + 4, ...; eight columns in flight per lane.  Block 0 assembles the rows it touches on the fly.
+template <int R>
+__global__ __launch_bounds__(256) void k_fwd_upd(DevPlan P, const int* __restrict__ list, int b) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];      // y[R][kSB], then part[4][R][128]
+  double* yj = sm;
+  double* part = sm + (size_t)R * kSB;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int s = list[blockIdx.y];
+  const int col0 = P.sn_col0[s];
+  const int k = P.sn_col0[s + 1] - col0;
+  const int f = (int)(P.row_ptr[s + 1] - P.row_ptr[s]);
+  int c0, kb, ld; int64_t off;
+  xblock(k, b, c0, kb, ld, off);
+  if (kb <= 0) return;
+  const int rbeg = c0 + kb;                       // first row below the block
+  const int rb = rbeg + (int)blockIdx.x * 128;
+  if (blockIdx.x > 0 && rb >= f) return;
+  const double* yp = P.ypart + P.ypart_pos[s];
+  for (int p = tid; p < kSB; p += 256) {
+    const int pc = min(p, kb - 1);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const double* y4 = yp + (size_t)r * kCS * kSB + pc;
+      const double y = (y4[0] + y4[kSB]) + (y4[2 * kSB] + y4[3 * kSB]);
+      yj[r * kSB + p] = p < kb ? y : 0.0;
+      if (blockIdx.x == 0 && p < kb) P.xwork[(size_t)r * P.xw_stride + col0 + c0 + p] = y / P.dvals[col0 + c0 + p];
+    }
+  }
+  __syncthreads();
+  if (rb >= f) return;
+  // rows (pr, pr + 1): the pair start is clamped so that both loads stay inside the column; `shift` maps them back
+  const int r0 = rb + 2 * lane;
+  const int pr = max(min(r0, f - 2), 0);
+  const int shift = r0 - pr;                      // 0: both rows mine; 1: only the second value is mine (= row r0); > 1: none
+  const double* Lp = P.arena + P.front_pos[s] + (size_t)c0 * f + pr;
+  double a0[R], a1[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) { a0[r] = 0.0; a1[r] = 0.0; }
+  const bool pair_ok = f >= 2;
+  for (int p0 = wv; p0 < kb; p0 += 32) {          // columns p0, p0 + 4, ..., p0 + 28
+    d2_t v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int p = min(p0 + 4 * u, kb - 1);
+      if (pair_ok) __builtin_memcpy(&v[u], Lp + (size_t)p * f, 16);
+      else { v[u][0] = Lp[(size_t)p * f]; v[u][1] = 0.0; }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int p = p0 + 4 * u;
+      if (p < kb) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) { const double y = yj[r * kSB + p]; a0[r] += v[u][0] * y; a1[r] += v[u][1] * y; }
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    part[((size_t)wv * R + r) * 128 + 2 * lane] = a0[r];
+    part[((size_t)wv * R + r) * 128 + 2 * lane + 1] = a1[r];
+  }
+  __syncthreads();
+  // 128 rows, two per lane of waves 0 and 1 ... simpler: thread t < 128 finishes the pair slot t of its own lane pair
+  if (tid < 128) {
+    const int ln = tid >> 1, e = tid & 1;         // the value e of lane ln's pair
+    const int r0l = rb + 2 * ln;
+    const int prl = max(min(r0l, f - 2), 0);
+    const int sh = r0l - prl;
+    // which front row does pair value e belong to?  shift 0: prl + e; shift 1: only e == 1 is valid (row r0l); else none
+    const int rowv = pair_ok ? prl + e : prl;
+    const bool valid = pair_ok ? (sh == 0 || (sh == 1 && e == 1)) : (e == 0 && r0l < f);
+    if (valid && rowv >= rbeg && rowv < f) {
+      const int64_t gcb = P.bigcol_base[s];
+      double w[R];
+      if (b == 0) fwd_gather<R>(P, gcb, col0, k, rowv, w);
+      else {
+#pragma unroll
+        for (int r = 0; r < R; ++r) w[r] = *fwd_slot<R>(P, s, col0, k, rowv, r);
+      }
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const double sum = (part[((size_t)0 * R + r) * 128 + tid] + part[((size_t)1 * R + r) * 128 + tid]) +
+                           (part[((size_t)2 * R + r) * 128 + tid] + part[((size_t)3 * R + r) * 128 + tid]);
+        *fwd_slot<R>(P, s, col0, k, rowv, r) = w[r] - sum;
+      }
+    }
+  }
+  (void)shift;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// big fronts, backward
+// ------------------------------------------------------------------------------------------------------------------
+// rows below the pivot block: z[c] -= sum_{r >= k} L[r, c] x[rows[r]]   (wave per column, eight loads in flight)
+template <int R>
+__global__ __launch_bounds__(256) void k_bwd_pre(DevPlan P, const int* __restrict__ list) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int s = list[blockIdx.y];
+  const int col0 = P.sn_col0[s];
+  const int k = P.sn_col0[s + 1] - col0;
+  const int f = (int)(P.row_ptr[s + 1] - P.row_ptr[s]);
+  const int c = blockIdx.x * 4 + wv;
+  if (c >= k || f == k) return;
+  const int* rows = P.rows + P.row_ptr[s];
+  const double* col = P.arena + P.front_pos[s] + (size_t)c * f;
+  double acc[R];
+#pragma unroll
+  for (int q = 0; q < R; ++q) acc[q] = 0.0;
+  int r = k + lane;
+  for (; r + 7 * 64 < f; r += 8 * 64) {
+    int ri[8];
+    double lv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { ri[u] = rows[r + 64 * u]; lv[u] = col[r + 64 * u]; }
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+      double xv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) xv[u] = P.xwork[(size_t)q * P.xw_stride + ri[u]];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc[q] += lv[u] * xv[u];
+    }
+  }
+  for (; r < f; r += 64) {
+    const double l = col[r];
+    const int g = rows[r];
+#pragma unroll
+    for (int q = 0; q < R; ++q) acc[q] += l * P.xwork[(size_t)q * P.xw_stride + g];
+  }
+#pragma unroll
+  for (int q = 0; q < R; ++q) {
+    double a = acc[q];
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_down(a, o, 64);
+    if (lane == 0) P.xwork[(size_t)q * P.xw_stride + col0 + c] -= a;
+  }
+}
+
+// fronts with k <= 128: x_K = X' t (one workgroup per front; column c of X is contiguous)
+template <int R>
+__global__ __launch_bounds__(256) void k_bwd_thin(DevPlan P, const int* __restrict__ list, int NB) {
+  __shared__ double tk[R][128];
+  const int tid = threadIdx.x;
+  const int s = list[blockIdx.x];
+  const int col0 = P.sn_col0[s];
+  const int k = P.sn_col0[s + 1] - col0;
+  const double* X = P.invl + P.invl_pos[s];
+  const int c = tid >> 1, h = tid & 1;
+  const double* xcol = X + (size_t)min(c, NB - 1) * NB;
+  double v[64];
+#pragma unroll
+  for (int q = 0; q < 64; ++q) v[q] = xcol[min(h * 64 + q, NB - 1)];
+  if (tid < 128)
+#pragma unroll
+    for (int r = 0; r < R; ++r) tk[r][tid] = tid < k ? P.xwork[(size_t)r * P.xw_stride + col0 + tid] : 0.0;
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    double a = 0.0;
+#pragma unroll
+    for (int q = 0; q < 64; ++q) a += (h * 64 + q < NB) ? v[q] * tk[r][h * 64 + q] : 0.0;
+    a += __shfl_xor(a, 1, 64);
+    if (h == 0 && c < k) P.xwork[(size_t)r * P.xw_stride + col0 + c] = a;
+  }
+}
+
+// wide fronts, block b: partial products of x_b = X_b' z_b.  Workgroup (j, front, rq): columns [64 j, +64), rows
+// [rq * kSB / kCS, +kSB / kCS); column i of X_b is zero above row i.  A wave takes 16 columns, four at a time.
+template <int R>
+__global__ __launch_bounds__(256) void k_bwd_x(DevPlan P, const int* __restrict__ list, int b) {
+  constexpr int RW = kSB / kCS;
+  __shared__ double zj[R][RW];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int s = list[blockIdx.y];
+  const int col0 = P.sn_col0[s];
+  const int k = P.sn_col0[s + 1] - col0;
+  int c0, kb, ld; int64_t off;
+  xblock(k, b, c0, kb, ld, off);
+  if (kb <= 0) return;
+  const int rq = blockIdx.z;
+  if ((int)blockIdx.x * 64 >= kb) return;
+  double* xp = P.ypart + P.ypart_pos[s] + (size_t)rq * kSB;
+  const int i0 = blockIdx.x * 64 + wv * 16;
+  const int q0 = rq * RW;
+  if (q0 >= kb || q0 + RW - 1 < (int)blockIdx.x * 64) {        // nothing of this row range reaches these columns
+    if (lane < 16 && i0 + lane < kb)
+#pragma unroll
+      for (int r = 0; r < R; ++r) xp[(size_t)r * kCS * kSB + i0 + lane] = 0.0;
+    return;
+  }
+  const int kq = min(RW, kb - q0);
+  const double* X = P.xinv + P.xinv_pos[s] + off + q0;
+  for (int p = tid; p < RW; p += 256)
+#pragma unroll
+    for (int r = 0; r < R; ++r) zj[r][p] = p < kq ? P.xwork[(size_t)r * P.xw_stride + col0 + c0 + q0 + p] : 0.0;
+  __syncthreads();
+#pragma unroll 1
+  for (int g = 0; g < 16; g += 4) {
+    double v[4][RW / 64];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const double* xc = X + (size_t)min(i0 + g + q, kb - 1) * ld;
+#pragma unroll
+      for (int t = 0; t < RW / 64; ++t) v[q][t] = xc[min(lane + 64 * t, kq - 1)];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        double a = 0.0;
+#pragma unroll
+        for (int t = 0; t < RW / 64; ++t) a += (lane + 64 * t < kq) ? v[q][t] * zj[r][lane + 64 * t] : 0.0;
+        for (int o = 32; o > 0; o >>= 1) a += __shfl_down(a, o, 64);
+        if (lane == 0 && i0 + g + q < kb) xp[(size_t)r * kCS * kSB + i0 + g + q] = a;
+      }
+    }
+  }
+}
+
+// wide fronts, block b: x_b = sum of the partials; columns c < c0: z[c] -= sum_p L[c0 + p][c] x_b[p] (wave: 16 columns, four
+// at a time, lanes along the rows of the block); the workgroup behind the last column group stores x_b itself
+template <int R>
+__global__ __launch_bounds__(256) void k_bwd_upd(DevPlan P, const int* __restrict__ list, int b) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];      // x[R][kSB]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int s = list[blockIdx.y];
+  const int col0 = P.sn_col0[s];
+  const int k = P.sn_col0[s + 1] - col0;
+  const int f = (int)(P.row_ptr[s + 1] - P.row_ptr[s]);
+  int c0, kb, ld; int64_t off;
+  xblock(k, b, c0, kb, ld, off);
+  if (kb <= 0) return;
+  const int nupd = (c0 + 63) / 64;                // workgroups that update columns; the next one copies x_b
+  if ((int)blockIdx.x > nupd) return;
+  const double* xp = P.ypart + P.ypart_pos[s];
+  for (int p = tid; p < kSB; p += 256) {
+    const int pc = min(p, kb - 1);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const double* x4 = xp + (size_t)r * kCS * kSB + pc;
+      const double x = (x4[0] + x4[kSB]) + (x4[2 * kSB] + x4[3 * kSB]);
+      sm[r * kSB + p] = p < kb ? x : 0.0;
+    }
+  }
+  __syncthreads();
+  if ((int)blockIdx.x == nupd) {
+    for (int p = tid; p < kb; p += 256)
+#pragma unroll
+      for (int r = 0; r < R; ++r) P.xwork[(size_t)r * P.xw_stride + col0 + c0 + p] = sm[r * kSB + p];
+    return;
+  }
+  const double* Lrow = P.arena + P.front_pos[s] + c0;
+#pragma unroll 1
+  for (int g = 0; g < 16; g += 2) {
+    const int cb = blockIdx.x * 64 + wv * 16 + g;
+    if (cb >= c0) break;
+    double acc[2][R];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int r = 0; r < R; ++r) acc[q][r] = 0.0;
+    for (int t0 = 0; t0 < kb; t0 += 64 * 16) {                 // 16 loads per lane and column in flight
+      double v[2][16];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const double* col = Lrow + (size_t)min(cb + q, c0 - 1) * f;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) v[q][t] = col[min(t0 + lane + 64 * t, kb - 1)];
+      }
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const int p = t0 + lane + 64 * t;
+        if (p < kb) {
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            const double x = sm[r * kSB + p];
+            acc[0][r] += v[0][t] * x;
+            acc[1][r] += v[1][t] * x;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        double a = acc[q][r];
+        for (int o = 32; o > 0; o >>= 1) a += __shfl_down(a, o, 64);
+        if (lane == 0 && cb + q < c0) P.xwork[(size_t)r * P.xw_stride + col0 + cb + q] -= a;
+      }
+  }
+}
+
+template <int R>
+__global__ void k_permute_in_r(int n, int nr, int64_t stride_in, const int* __restrict__ perm, const double* __restrict__ rhs, double* __restrict__ x, int64_t xs) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int g = perm[i];
+#pragma unroll
+  for (int q = 0; q < R; ++q) x[(size_t)q * xs + i] = q < nr ? rhs[(size_t)q * stride_in + g] : 0.0;
+}
+template <int R>
+__global__ void k_permute_out_r(int n, int nr, int64_t stride_out, const int* __restrict__ perm, const double* __restrict__ x, int64_t xs, double* __restrict__ sol, int accumulate) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int g = perm[i];
+#pragma unroll
+  for (int q = 0; q < R; ++q)
+    if (q < nr) { double* d = sol + (size_t)q * stride_out + g; *d = accumulate ? *d + x[(size_t)q * xs + i] : x[(size_t)q * xs + i]; }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------------------------
+namespace {
+template <typename T>
+std::string up(Numeric& N, const std::vector<T>& v, T** out) {
+  *out = nullptr;
+  void* p = nullptr;
+  OKKT_HIP_TRY(hipMalloc(&p, std::max<size_t>(v.size(), 1) * sizeof(T)));
+  N.allocations.push_back(p);
+  if (!v.empty()) OKKT_HIP_TRY(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  *out = (T*)p;
+  return "";
+}
+std::string dz(Numeric& N, size_t count, double** out) {
+  *out = nullptr;
+  void* p = nullptr;
+  const size_t bytes = std::max<size_t>(count, 1) * sizeof(double);
+  OKKT_HIP_TRY(hipMalloc(&p, bytes));
+  N.allocations.push_back(p);
+  OKKT_HIP_TRY(hipMemset(p, 0, bytes));
+  OKKT_HIP_TRY(hipStreamSynchronize(nullptr));
+  *out = (double*)p;
+  return "";
+}
+}  // namespace
+
+// per level: the big fronts split by the width of the pivot block (thin: k <= NB, wide: k > NB), device lists + host segments
+std::string solve_setup(const Symbolic& S, Numeric& N) {
+  DevPlan& d = N.d;
+  const int ns = S.nsuper;
+  std::vector<int> ssched;
+  std::vector<int64_t> xinv_pos(ns, -1), ypart_pos(ns, -1);
+  int64_t xtot = 0, ytot = 0;
+  auto build = [&](const std::vector<LevelSchedule>& levels, std::vector<SolveLevel>& out) {
+    out.assign(levels.size(), SolveLevel());
+    for (size_t l = 0; l < levels.size(); ++l) {
+      const Segment& g = levels[l].seg[3];
+      SolveLevel& L = out[l];
+      std::vector<int> thin, wide;
+      for (int q = 0; q < g.cnt; ++q) {
+        const int s = N.sched_host[g.off + q];
+        (N.sn_k[s] <= N.nb ? thin : wide).push_back(s);
+      }
+      L.thin_off = (int)ssched.size(); L.thin_cnt = (int)thin.size();
+      for (int s : thin) { ssched.push_back(s); L.thin_maxf = std::max(L.thin_maxf, N.sn_f[s]); L.thin_maxk = std::max(L.thin_maxk, N.sn_k[s]); L.thin_maxr = std::max(L.thin_maxr, N.sn_f[s] - N.sn_k[s]); }
+      L.wide_off = (int)ssched.size(); L.wide_cnt = (int)wide.size();
+      for (int s : wide) {
+        ssched.push_back(s);
+        L.wide_maxf = std::max(L.wide_maxf, N.sn_f[s]); L.wide_maxk = std::max(L.wide_maxk, N.sn_k[s]);
+        if (xinv_pos[s] < 0) {
+          const int64_t k = N.sn_k[s];
+          const int64_t nfull = k / kSB, last = k - nfull * kSB, lastp = (last + 127) / 128 * 128;
+          xinv_pos[s] = xtot;
+          xtot += nfull * (int64_t)kSB * kSB + lastp * lastp;
+          ypart_pos[s] = ytot;
+          ytot += (int64_t)kMaxRhs * kCS * kSB;
+        }
+      }
+    }
+  };
+  build(N.levels, N.slevels);
+  build(N.levels_top, N.slevels_top);
+  std::string e;
+  if (!(e = up(N, ssched, &d.ssched)).empty()) return e;
+  if (!(e = up(N, xinv_pos, &d.xinv_pos)).empty()) return e;
+  if (!(e = up(N, ypart_pos, &d.ypart_pos)).empty()) return e;
+  if (!(e = dz(N, (size_t)xtot, &d.xinv)).empty()) return e;
+  if (!(e = dz(N, (size_t)xtot, &d.xtmp)).empty()) return e;
+  if (!(e = dz(N, (size_t)ytot, &d.ypart)).empty()) return e;
+  for (const void* fn : {(const void*)k_fwd_upd<1>, (const void*)k_fwd_upd<2>, (const void*)k_fwd_upd<4>, (const void*)k_bwd_upd<1>,
+                         (const void*)k_bwd_upd<2>, (const void*)k_bwd_upd<4>, (const void*)k_fs_small<256, 1>, (const void*)k_fs_small<256, 2>,
+                         (const void*)k_fs_small<256, 4>, (const void*)k_bs_small<256, 1>, (const void*)k_bs_small<256, 2>, (const void*)k_bs_small<256, 4>})
+    OKKT_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096));
+  return "";
+}
+
+// inverses of the diagonal blocks [b_lo, b_hi) of the wide fronts of one level (b_hi is clipped per front), on stream st:
+// needs the NB x NB inverses of those block columns (k_big_invert) and the final L of the columns below them
+std::string solve_invert_enqueue(Numeric& N, hipStream_t st, const SolveLevel& L, int b_lo, int b_hi) {
+  if (!L.wide_cnt) return "";
+  DevPlan P = N.d;
+  const int* list = P.ssched + L.wide_off;
+  const int nblk = (L.wide_maxk + kSB - 1) / kSB;
+  b_hi = std::min(b_hi, nblk);
+  if (b_lo >= b_hi) return "";
+  const int nbk = b_hi - b_lo;
+  const int maxkb = std::min(kSB, L.wide_maxk - b_lo * kSB);
+  const int ldmax = std::min(kSB, (maxkb + 127) / 128 * 128);
+  hipLaunchKernelGGL(k_xinv_init, dim3(ldmax / N.nb, 1, (unsigned)(L.wide_cnt * nbk)), dim3(256), 0, st, P, list, b_lo, nbk, N.nb);
+  for (int sz = N.nb; sz < ldmax; sz *= 2) {
+    const int npair = (ldmax + 2 * sz - 1) / (2 * sz);
+    const int tiles = ((sz + 63) / 64) * ((sz + 63) / 64);
+    hipLaunchKernelGGL(k_xinv_gemm<0>, dim3(tiles, npair, (unsigned)(L.wide_cnt * nbk)), dim3(256), 0, st, P, list, b_lo, nbk, sz);
+    hipLaunchKernelGGL(k_xinv_gemm<1>, dim3(tiles, npair, (unsigned)(L.wide_cnt * nbk)), dim3(256), 0, st, P, list, b_lo, nbk, sz);
+  }
+  OKKT_HIP_TRY(hipGetLastError());
+  return "";
+}
+
+template <int R>
+static std::string fwd_enqueue_r(Numeric& N, int which) {
+  DevPlan P = N.d;
+  hipStream_t st = N.stream;
+  const std::vector<LevelSchedule>& levels = which == 0 ? N.levels : N.levels_top;
+  const std::vector<SolveLevel>& sl = which == 0 ? N.slevels : N.slevels_top;
+  for (size_t l = 0; l < levels.size(); ++l) {
+    const LevelSchedule& L = levels[l];
+    for (int c = 0; c < 3; ++c) {
+      const Segment& g = L.seg[c];
+      if (!g.cnt) continue;
+      const size_t lds = (size_t)R * g.maxf * sizeof(double);
+      if (c == 0) hipLaunchKernelGGL((k_fs_small<64, R>), dim3(g.cnt), dim3(64), lds, st, P, P.sched + g.off, g.maxf);
+      else hipLaunchKernelGGL((k_fs_small<256, R>), dim3(g.cnt), dim3(256), lds, st, P, P.sched + g.off, g.maxf);
+    }
+    const SolveLevel& S = sl[l];
+    if (S.thin_cnt) hipLaunchKernelGGL(k_fwd_thin<R>, dim3(1 + (S.thin_maxr + 63) / 64, S.thin_cnt), dim3(256), 0, st, P, P.ssched + S.thin_off, N.nb);
+    if (S.wide_cnt) {
+      const int* list = P.ssched + S.wide_off;
+      const int nblk = (S.wide_maxk + kSB - 1) / kSB;
+      const size_t lds = ((size_t)R * kSB + (size_t)4 * R * 128) * sizeof(double);
+      for (int b = 0; b < nblk; ++b) {
+        const int kbmax = std::min(kSB, S.wide_maxk - b * kSB);
+        hipLaunchKernelGGL(k_fwd_y<R>, dim3((kbmax + 63) / 64, S.wide_cnt, kCS), dim3(256), 0, st, P, list, b);
+        const int rem = std::max(S.wide_maxf - b * kSB, 0);        // upper bound on the rows below the start of block b (a narrower last block leaves more rows than maxf - (b + 1) kSB)
+        hipLaunchKernelGGL(k_fwd_upd<R>, dim3(std::max(1, (rem + 127) / 128), S.wide_cnt), dim3(256), lds, st, P, list, b);
+      }
+    }
+  }
+  OKKT_HIP_TRY(hipGetLastError());
+  return "";
+}
+
+template <int R>
+static std::string bwd_enqueue_r(Numeric& N, int which) {
+  DevPlan P = N.d;
+  hipStream_t st = N.stream;
+  const std::vector<LevelSchedule>& levels = which == 0 ? N.levels : N.levels_top;
+  const std::vector<SolveLevel>& sl = which == 0 ? N.slevels : N.slevels_top;
+  for (int l = (int)levels.size() - 1; l >= 0; --l) {
+    const LevelSchedule& L = levels[l];
+    const SolveLevel& S = sl[l];
+    if (S.wide_cnt) {
+      const int* list = P.ssched + S.wide_off;
+      if (S.wide_maxf > 0) hipLaunchKernelGGL(k_bwd_pre<R>, dim3((S.wide_maxk + 3) / 4, S.wide_cnt), dim3(256), 0, st, P, list);
+      const int nblk = (S.wide_maxk + kSB - 1) / kSB;
+      const size_t lds = (size_t)R * kSB * sizeof(double);
+      for (int b = nblk - 1; b >= 0; --b) {
+        const int kbmax = std::min(kSB, S.wide_maxk - b * kSB);
+        hipLaunchKernelGGL(k_bwd_x<R>, dim3((kbmax + 63) / 64, S.wide_cnt, kCS), dim3(256), 0, st, P, list, b);
+        hipLaunchKernelGGL(k_bwd_upd<R>, dim3((b * kSB + 63) / 64 + 1, S.wide_cnt), dim3(256), lds, st, P, list, b);
+      }
+    }
+    if (S.thin_cnt) {
+      const int* list = P.ssched + S.thin_off;
+      if (S.thin_maxr > 0) hipLaunchKernelGGL(k_bwd_pre<R>, dim3((S.thin_maxk + 3) / 4, S.thin_cnt), dim3(256), 0, st, P, list);
+      hipLaunchKernelGGL(k_bwd_thin<R>, dim3(S.thin_cnt), dim3(256), 0, st, P, list, N.nb);
+    }
+    for (int c = 0; c < 3; ++c) {
+      const Segment& g = L.seg[c];
+      if (!g.cnt) continue;
+      const size_t lds = (size_t)R * g.maxf * sizeof(double);
+      if (c == 0) hipLaunchKernelGGL((k_bs_small<64, R>), dim3(g.cnt), dim3(64), lds, st, P, P.sched + g.off, g.maxf);
+      else hipLaunchKernelGGL((k_bs_small<256, R>), dim3(g.cnt), dim3(256), lds, st, P, P.sched + g.off, g.maxf);
+    }
+  }
+  OKKT_HIP_TRY(hipGetLastError());
+  return "";
+}
+
+std::string solve_fwd_enqueue(Numeric& N, int which, int R) {
+  if (which == 0 && N.inv_wait) { OKKT_HIP_TRY(hipStreamWaitEvent(N.stream, N.inv_event, 0)); N.inv_wait = false; }   // inversions started by the factorisation
+  return R == 1 ? fwd_enqueue_r<1>(N, which) : (R == 2 ? fwd_enqueue_r<2>(N, which) : fwd_enqueue_r<4>(N, which));
+}
+std::string solve_bwd_enqueue(Numeric& N, int which, int R) {
+  return R == 1 ? bwd_enqueue_r<1>(N, which) : (R == 2 ? bwd_enqueue_r<2>(N, which) : bwd_enqueue_r<4>(N, which));
+}
+
+void solve_permute_in(const Numeric& N, const double* d_rhs, int64_t stride, int nr, int R) {
+  const int n = N.d.n;
+  if (!n) return;
+  const dim3 g((n + 255) / 256), b(256);
+  if (R == 1) hipLaunchKernelGGL(k_permute_in_r<1>, g, b, 0, N.stream, n, nr, stride, N.d.perm, d_rhs, N.d.xwork, N.d.xw_stride);
+  else if (R == 2) hipLaunchKernelGGL(k_permute_in_r<2>, g, b, 0, N.stream, n, nr, stride, N.d.perm, d_rhs, N.d.xwork, N.d.xw_stride);
+  else hipLaunchKernelGGL(k_permute_in_r<4>, g, b, 0, N.stream, n, nr, stride, N.d.perm, d_rhs, N.d.xwork, N.d.xw_stride);
+}
+void solve_permute_out(const Numeric& N, double* d_sol, int64_t stride, int nr, int R, bool accumulate) {
+  const int n = N.d.n;
+  if (!n) return;
+  const dim3 g((n + 255) / 256), b(256);
+  const int acc = accumulate ? 1 : 0;
+  if (R == 1) hipLaunchKernelGGL(k_permute_out_r<1>, g, b, 0, N.stream, n, nr, stride, N.d.perm, N.d.xwork, N.d.xw_stride, d_sol, acc);
+  else if (R == 2) hipLaunchKernelGGL(k_permute_out_r<2>, g, b, 0, N.stream, n, nr, stride, N.d.perm, N.d.xwork, N.d.xw_stride, d_sol, acc);
+  else hipLaunchKernelGGL(k_permute_out_r<4>, g, b, 0, N.stream, n, nr, stride, N.d.perm, N.d.xwork, N.d.xw_stride, d_sol, acc);
+}
+
+}  // namespace okkt

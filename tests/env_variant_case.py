@@ -1,5 +1,5 @@
 """Helper of test_gpu_env_variants.py (run as a subprocess: the tuning switches are read once per process).
-Factors and solves a dense 2600 x 2600 indefinite matrix (one front, 21 block columns, super-block solves) and
+Factors and solves a dense 2600 x 2600 indefinite matrix (one front, 21 block columns, two inverted diagonal blocks) and
 the S-C3 system, checks inertia, residuals and that two solves of the same right-hand side agree bit for bit."""
 import sys
 

@@ -46,10 +46,30 @@ def test_partition_is_a_valid_cut(nparts):
             assert sn[p] == -1
     st = s.stats()
     assert abs(pf.sum() + tf - st["flops_stored"]) <= 1e-6 * st["flops_stored"]
-    if nparts == 8:
-        assert (pf > 0).all() and pf.max() <= 1.6 * pf.mean()
+    # the cut minimises the estimated parallel time T = flops(top, serial on part 0) + heaviest part: never worse than
+    # one part doing everything (blocks of 150 columns are too small against the 128-column supernodes to ask for more)
+    assert tf + pf.max() <= st["flops_stored"] * (1.0 + 1e-9)
     if nparts == 1:
         assert nb == 0 and (sn == 0).all()
+
+
+@pytest.mark.parametrize("name", ["blocks-1000", "S-C5"])
+def test_block_angular_cut_keeps_the_blocks_whole(name):
+    # BASELINE config 5 at its stated size (8 x (5 000, 7 500) + 200 linking columns) and a smaller instance: the dense
+    # roots of the eight blocks must stay inside the parts -- only the separator above them is serial.  (Round 1 kept the
+    # last state of the greedy walk instead of the best one: 25 % of the flops in the top at S-C5, model speed-up 2.9.)
+    if name == "S-C5":
+        prob = synth.make_config("S-C5", seed=0)
+    else:
+        prob = synth.block_angular(nblocks=8, n_b=400, m_b=600, n_link=10, seed=0, j_per_row=4, h_per_col=3, w=6.0, p_far=0.0)
+    K = synth.augmented_matrix(prob, delta=1e-8)
+    for nparts, want in ((2, 1.6), (4, 2.7), (8, 3.5)):
+        s, sn, col, par, pf, tf, nb = host_partition(K, nparts)
+        total = pf.sum() + tf
+        assert pf.min() > 0
+        assert total / (tf + pf.max()) >= want, (nparts, total / (tf + pf.max()))
+        if nparts == 8:
+            assert tf <= (0.08 if name == "S-C5" else 0.2) * total and pf.max() <= 1.6 * pf.mean()
 
 
 def test_partition_deterministic_across_ranks():

@@ -1,5 +1,5 @@
 """GPU tests: every schedule the tuning switches of DESIGN.md section 9 can select gives the same answers
-(look-ahead on / off / everywhere, super-step widths, split in-group updates, super-block solves on / off)."""
+(look-ahead on / off / everywhere, super-step widths, split in-group updates, when the block inversions of the solves start)."""
 import os
 import subprocess
 import sys
@@ -18,9 +18,8 @@ VARIANTS = [
     {"OKKT_GROUP_BIG": "4", "OKKT_GROUP_BIG_MINF": "0", "OKKT_GROUP_SWITCH_ROWS": "0", "OKKT_GROUP_ONE_ROWS": "0"},
     {"OKKT_GROUP_ONE_ROWS": "100000"},
     {"OKKT_RESERVED_CUS": "32", "OKKT_LA_MIN_TILES": "64"},
-    {"OKKT_SOLVE_SB": "0"},
-    {"OKKT_SOLVE_SB_LAZY": "0", "OKKT_SB_TAIL_ROWS": "1500"},    # in-factorisation inversion of the dense case's blocks
-    {"OKKT_SOLVE_SB_LAZY": "0", "OKKT_SB_TAIL_ROWS": "-1"},
+    {"OKKT_SB_TAIL_ROWS": "100000"},                              # block inversions start as early as a block is final (needs a front of >= 4 blocks)
+    {"OKKT_SB_TAIL_ROWS": "-1"},                                  # ... or only behind the last panel
     {"OKKT_ASM_CHUNKED": "0"},
     {"OKKT_ASM_LCOL": "0"},
     {"OKKT_TASKS": "0"},                                          # one launch per level of small fronts

@@ -341,3 +341,36 @@ def test_early_exit_of_a_failed_factorisation_is_opt_in():
     assert full.ls_factor_b(K1, n, m) == 1
     assert np.array_equal(early.ls_solve(b), full.ls_solve(b))
     finalize_b(full); finalize_b(early)
+
+
+@pytest.mark.parametrize("case", ["S-small", "dense-700", "dense-2600", "S-C3"])
+def test_batched_right_hand_sides(case):
+    # okkt_solve with nrhs > 1 carries up to four right-hand sides through one pass over L (solve.hip): every column of
+    # the batch must equal the single solve of that column (same summation order: to rounding of the compiler's FMA
+    # choices) -- thin fronts, wide fronts with one and two inverted diagonal blocks, small fronts, batches 1..6
+    rng = np.random.default_rng(42)
+    if case.startswith("dense"):
+        n = int(case.split("-")[1])
+        B = rng.normal(size=(n, n))
+        M = B + B.T + np.diag(np.where(rng.random(n) < 0.5, 1.0, -1.0) * (3.0 * np.sqrt(n)))
+        A = sp.csc_matrix(np.tril(M))
+        w = np.linalg.eigvalsh(M)
+        npos, nneg = int((w > 0).sum()), int((w < 0).sum())
+    else:
+        prob = synth.make_config(case, seed=0, **({"well_scaled": True} if case == "S-small" else {}))
+        A = synth.augmented_matrix(prob, delta=1e-8)
+        npos, nneg = prob["n"], prob["m"]
+    h = hip_solver("symmetric")
+    assert h.ls_factor_b(A, npos, nneg) == 1
+    dim = A.shape[0]
+    Mfull = full_sym(A)
+    from onephase_jl_amd import _lib as L
+    for nrhs in (1, 2, 3, 4, 5, 6):
+        Bm = rng.normal(size=(nrhs, dim))
+        X = np.zeros_like(Bm)
+        h._check(h._lib.okkt_solve(h._h, L.p_f64(Bm), L.p_f64(X), nrhs), "okkt_solve")
+        for r in range(nrhs):
+            x1 = h.ls_solve(Bm[r])
+            assert np.max(np.abs(X[r] - x1)) <= 1e-13 * max(1.0, np.max(np.abs(x1))), (nrhs, r)
+            assert np.max(np.abs(Mfull @ X[r] - Bm[r])) <= 1e-7 * np.max(np.abs(Bm[r])) * max(1.0, np.max(np.abs(X[r])))
+    finalize_b(h)
