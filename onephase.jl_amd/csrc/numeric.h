@@ -35,7 +35,8 @@ struct DevPlan {
   const double* vals = nullptr;  // caller's nzval in HBM
   double* dvals = nullptr;    // D, permuted order
   double* diagadd = nullptr;  // added to the diagonal at assembly (delta shift), permuted order
-  double* xwork = nullptr;    // permuted rhs / solution
+  double* xwork = nullptr;    // permuted rhs, then the solution (backward sweep)
+  double* zwork = nullptr;    // z = D^-1 L^-1 P b of the forward sweep: never written over the rhs that other workgroups still gather
   double* cv = nullptr;       // solve contribution vectors
   double* wbuf = nullptr;     // W = L21*D panels of the big fronts
   int64_t* wbuf_pos = nullptr;  // [nsuper] offset of each big front's W panel, -1 for small fronts

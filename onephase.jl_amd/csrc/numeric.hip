@@ -1338,6 +1338,7 @@ std::string numeric_setup(const Symbolic& S, const SymbolicOptions& opts, hipStr
   d.xw_stride = S.n;
   d.cv_stride = S.sum_r;
   if (!(e = dalloc(N, (size_t)S.n * kMaxRhs, &d.xwork, true)).empty()) return e;
+  if (!(e = dalloc(N, (size_t)S.n * kMaxRhs, &d.zwork, true)).empty()) return e;
   if (!(e = dalloc(N, (size_t)S.sum_r * kMaxRhs, &d.cv, true)).empty()) return e;
   if (!(e = dalloc(N, (size_t)wtotal + 512, &d.wbuf, true)).empty()) return e;
   if (!(e = dalloc(N, (size_t)kCountSlots * kCountStride, &d.counters, true)).empty()) return e;
@@ -1679,8 +1680,13 @@ std::string numeric_factor_enqueue(Numeric& N, const double* d_vals, double tol,
 
 std::string numeric_solve_enqueue(Numeric& N, int R) {
   std::string e;
+  static const int dbg_phase = getenv("OKKT_DEBUG_SOLVE_PHASE") ? atoi(getenv("OKKT_DEBUG_SOLVE_PHASE")) : 0;   // 1: forward sweep only (z = D^-1 L^-1 P b)
   if (!(e = solve_fwd_enqueue(N, 0, R)).empty()) return e;
   if (!(e = solve_fwd_enqueue(N, 1, R)).empty()) return e;
+  if (dbg_phase == 1) {   // the caller reads the sweep's result where it expects the solution
+    OKKT_HIP_TRY(hipMemcpyAsync(N.d.xwork, N.d.zwork, (size_t)N.d.n * kMaxRhs * sizeof(double), hipMemcpyDeviceToDevice, N.stream));
+    return "";
+  }
   if (!(e = solve_bwd_enqueue(N, 1, R)).empty()) return e;
   return solve_bwd_enqueue(N, 0, R);
 }

@@ -237,7 +237,7 @@ __global__ __launch_bounds__(TPB) void k_fs_small(DevPlan P, const int* __restri
     for (int j = tid; j < k; j += TPB) {
       const double d = P.dvals[col0 + j];
 #pragma unroll
-      for (int q = 0; q < R; ++q) P.xwork[(size_t)q * P.xw_stride + col0 + j] = sm[q * ldw + j] / d;
+      for (int q = 0; q < R; ++q) P.zwork[(size_t)q * P.xw_stride + col0 + j] = sm[q * ldw + j] / d;
     }
     __threadfence_block();
     __syncthreads();
@@ -257,9 +257,10 @@ __global__ __launch_bounds__(TPB) void k_bs_small(DevPlan P, const int* __restri
     const double* L = P.arena + P.front_pos[s];
     const int* rows = P.rows + P.row_ptr[s];
     for (int i = tid; i < f; i += TPB) {
-      const int g = rows[i];
+      const int g = rows[i];     // rows[i] = col0 + i for i < k: this front's z; beyond: the ancestors' solution
+      const double* src = i < k ? P.zwork : P.xwork;
 #pragma unroll
-      for (int q = 0; q < R; ++q) sm[q * ldw + i] = P.xwork[(size_t)q * P.xw_stride + g];
+      for (int q = 0; q < R; ++q) sm[q * ldw + i] = src[(size_t)q * P.xw_stride + g];
     }
     __syncthreads();
     // rhs_j = z_j - sum_{i >= k} L[i, j] * x_i
@@ -352,7 +353,7 @@ __global__ __launch_bounds__(256) void k_fwd_thin(DevPlan P, const int* __restri
       a += __shfl_xor(a, 1, 64);
       if (h == 0 && c < NB) {
         yk[r][c] = a;
-        if (blockIdx.x == 0 && c < k) P.xwork[(size_t)r * P.xw_stride + col0 + c] = a / P.dvals[col0 + c];
+        if (blockIdx.x == 0 && c < k) P.zwork[(size_t)r * P.xw_stride + col0 + c] = a / P.dvals[col0 + c];
       }
     }
   }
@@ -472,7 +473,7 @@ __global__ __launch_bounds__(256) void k_fwd_upd(DevPlan P, const int* __restric
       const double* y4 = yp + (size_t)r * kCS * kSB + pc;
       const double y = (y4[0] + y4[kSB]) + (y4[2 * kSB] + y4[3 * kSB]);
       yj[r * kSB + p] = p < kb ? y : 0.0;
-      if (blockIdx.x == 0 && p < kb) P.xwork[(size_t)r * P.xw_stride + col0 + c0 + p] = y / P.dvals[col0 + c0 + p];
+      if (blockIdx.x == 0 && p < kb) P.zwork[(size_t)r * P.xw_stride + col0 + c0 + p] = y / P.dvals[col0 + c0 + p];
     }
   }
   __syncthreads();
@@ -540,7 +541,8 @@ __global__ __launch_bounds__(256) void k_fwd_upd(DevPlan P, const int* __restric
 // ------------------------------------------------------------------------------------------------------------------
 // big fronts, backward
 // ------------------------------------------------------------------------------------------------------------------
-// rows below the pivot block: z[c] -= sum_{r >= k} L[r, c] x[rows[r]]   (wave per column, eight loads in flight)
+// rows below the pivot block: z[c] -= sum_{r >= k} L[r, c] x[rows[r]]   (wave per column, eight loads in flight); z lives in
+// zwork (forward result), the ancestors' solution in xwork
 template <int R>
 __global__ __launch_bounds__(256) void k_bwd_pre(DevPlan P, const int* __restrict__ list) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -580,7 +582,7 @@ __global__ __launch_bounds__(256) void k_bwd_pre(DevPlan P, const int* __restric
   for (int q = 0; q < R; ++q) {
     double a = acc[q];
     for (int o = 32; o > 0; o >>= 1) a += __shfl_down(a, o, 64);
-    if (lane == 0) P.xwork[(size_t)q * P.xw_stride + col0 + c] -= a;
+    if (lane == 0) P.zwork[(size_t)q * P.xw_stride + col0 + c] -= a;
   }
 }
 
@@ -600,7 +602,7 @@ __global__ __launch_bounds__(256) void k_bwd_thin(DevPlan P, const int* __restri
   for (int q = 0; q < 64; ++q) v[q] = xcol[min(h * 64 + q, NB - 1)];
   if (tid < 128)
 #pragma unroll
-    for (int r = 0; r < R; ++r) tk[r][tid] = tid < k ? P.xwork[(size_t)r * P.xw_stride + col0 + tid] : 0.0;
+    for (int r = 0; r < R; ++r) tk[r][tid] = tid < k ? P.zwork[(size_t)r * P.xw_stride + col0 + tid] : 0.0;
   __syncthreads();
 #pragma unroll
   for (int r = 0; r < R; ++r) {
@@ -640,7 +642,7 @@ __global__ __launch_bounds__(256) void k_bwd_x(DevPlan P, const int* __restrict_
   const double* X = P.xinv + P.xinv_pos[s] + off + q0;
   for (int p = tid; p < RW; p += 256)
 #pragma unroll
-    for (int r = 0; r < R; ++r) zj[r][p] = p < kq ? P.xwork[(size_t)r * P.xw_stride + col0 + c0 + q0 + p] : 0.0;
+    for (int r = 0; r < R; ++r) zj[r][p] = p < kq ? P.zwork[(size_t)r * P.xw_stride + col0 + c0 + q0 + p] : 0.0;
   __syncthreads();
 #pragma unroll 1
   for (int g = 0; g < 16; g += 4) {
@@ -734,7 +736,7 @@ __global__ __launch_bounds__(256) void k_bwd_upd(DevPlan P, const int* __restric
       for (int r = 0; r < R; ++r) {
         double a = acc[q][r];
         for (int o = 32; o > 0; o >>= 1) a += __shfl_down(a, o, 64);
-        if (lane == 0 && cb + q < c0) P.xwork[(size_t)r * P.xw_stride + col0 + cb + q] -= a;
+        if (lane == 0 && cb + q < c0) P.zwork[(size_t)r * P.xw_stride + col0 + cb + q] -= a;
       }
   }
 }
