@@ -45,6 +45,7 @@ struct DevPlan {
   int64_t* ea_ptr = nullptr;       // [n_bigcols + 1] contributions (child, jj) landing on a front column
   int* ea_child = nullptr;
   int* ea_jj = nullptr;
+  int64_t* ea_pos = nullptr;     // per item: position of the child's entry in the contribution-vector array (cv_pos[child] + jj)
   int* ea_rc = nullptr;          // per item: rows of the child's contribution block
   int64_t* ea_src = nullptr;     // per item: arena offset of the child's contribution-block column
   int64_t* ea_rel = nullptr;     // per item: start of the child's rel list
@@ -58,6 +59,8 @@ struct DevPlan {
   int64_t* xinv_pos = nullptr;   // [nsuper] offset into xinv / xtmp, -1 for fronts with k <= NB (they use invl) and small fronts
   double* ypart = nullptr;       // [kMaxRhs][4][kSolveBlock] per wide front
   int64_t* ypart_pos = nullptr;
+  double* ythin = nullptr;       // [kMaxRhs][128] per thin front: y = X w_K between the two forward launches of a level
+  int64_t* ythin_pos = nullptr;
   int* ssched = nullptr;         // big fronts per level, thin (k <= NB) then wide
   int64_t xw_stride = 0, cv_stride = 0;   // distance between the right-hand sides of a batch in xwork / cv
   double* invl = nullptr;          // inverse of the unit-lower diagonal blocks, NB x NB each

@@ -1274,7 +1274,7 @@ std::string numeric_setup(const Symbolic& S, const SymbolicOptions& opts, hipStr
     }
     for (int64_t i = 0; i < nbigcols; ++i) ea_ptr[i + 1] += ea_ptr[i];
     std::vector<int> ea_child(ea_ptr[nbigcols]), ea_jj(ea_ptr[nbigcols]), ea_rc(ea_ptr[nbigcols]);
-    std::vector<int64_t> ea_src(ea_ptr[nbigcols]), ea_rel(ea_ptr[nbigcols]), ea_cut(ea_ptr[nbigcols]);
+    std::vector<int64_t> ea_src(ea_ptr[nbigcols]), ea_rel(ea_ptr[nbigcols]), ea_cut(ea_ptr[nbigcols]), ea_pos(ea_ptr[nbigcols]);
     // per child of a big front: where each kAsmChunk-row boundary of the parent falls in its (sorted) rel list
     std::vector<int64_t> cut_pos(ns, -1);
     std::vector<int> cutv;
@@ -1308,6 +1308,7 @@ std::string numeric_setup(const Symbolic& S, const SymbolicOptions& opts, hipStr
         const int64_t slot = fill[bigcol_base[p] + S.rel[q]]++;
         ea_child[slot] = c;
         ea_jj[slot] = (int)(q - S.rel_ptr[c]);
+        ea_pos[slot] = S.cv_pos[c] + (q - S.rel_ptr[c]);
         {
           const int64_t kc = S.sn_col0[c + 1] - S.sn_col0[c], fc = S.row_ptr[c + 1] - S.row_ptr[c];
           ea_rc[slot] = (int)(fc - kc);
@@ -1322,6 +1323,7 @@ std::string numeric_setup(const Symbolic& S, const SymbolicOptions& opts, hipStr
     if (!(e = upload(N, ea_ptr, &d.ea_ptr)).empty()) return e;
     if (!(e = upload(N, ea_child, &d.ea_child)).empty()) return e;
     if (!(e = upload(N, ea_jj, &d.ea_jj)).empty()) return e;
+    if (!(e = upload(N, ea_pos, &d.ea_pos)).empty()) return e;
     if (!(e = upload(N, ea_rc, &d.ea_rc)).empty()) return e;
     if (!(e = upload(N, ea_src, &d.ea_src)).empty()) return e;
     if (!(e = upload(N, ea_rel, &d.ea_rel)).empty()) return e;

@@ -50,11 +50,24 @@ template <int R>
 __device__ __forceinline__ void fwd_gather(const DevPlan& P, int64_t gcb, int col0, int k, int r, double (&w)[R]) {
 #pragma unroll
   for (int q = 0; q < R; ++q) w[q] = r < k ? P.xwork[(size_t)q * P.xw_stride + col0 + r] : 0.0;
+  // the items are added strictly in list order, but eight of them have their position and value loads in flight together
+  // (one precomputed position per item: two dependent round trips per batch instead of four per item)
   const int64_t q0 = P.ea_ptr[gcb + r], q1 = P.ea_ptr[gcb + r + 1];
-  for (int64_t e = q0; e < q1; ++e) {
-    const int64_t pos = P.cv_pos[P.ea_child[e]] + P.ea_jj[e];
+  for (int64_t e = q0; e < q1; e += 8) {
+    int64_t pos[8];
 #pragma unroll
-    for (int q = 0; q < R; ++q) w[q] += P.cv[(size_t)q * P.cv_stride + pos];
+    for (int u = 0; u < 8; ++u) pos[u] = P.ea_pos[min(e + u, q1 - 1)];
+    double v[8][R];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+      for (int q = 0; q < R; ++q) v[u][q] = P.cv[(size_t)q * P.cv_stride + pos[u]];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (e + u < q1) {
+#pragma unroll
+        for (int q = 0; q < R; ++q) w[q] += v[u][q];
+      }
   }
 }
 // where the running forward vector of front row r lives: pivot rows in xwork, the rows below in the front's contribution vector
@@ -302,79 +315,107 @@ __global__ __launch_bounds__(TPB) void k_bs_small(DevPlan P, const int* __restri
 // ------------------------------------------------------------------------------------------------------------------
 // big fronts, forward
 // ------------------------------------------------------------------------------------------------------------------
-// Fronts with k <= 128 pivot columns: the whole front in one launch.  Workgroup 0 of a front stores z = y / d, workgroup
-// 1 + c owns the rows [k + 64 c, +64) below the pivot block.  Every workgroup assembles w_K and forms y = X w_K itself.
+// Fronts with k <= NB <= 128 pivot columns, two launches per level.  (1) one workgroup per front: assemble w_K, y = X w_K with
+// the NB x NB inverse of the factorisation, store z = y / d and y.  (2) the rows below the pivot block, 128 per workgroup
+// (two per lane, 16-byte loads; wave g takes the columns g, g + 4, ...): w[r] = assembled rhs - sum_c L[r, c] y[c] -> the
+// front's contribution vector.  (One fused launch with y recomputed by every workgroup was 2 x slower: 128 KiB of X and the
+// w_K gathers per 64 rows.)
 template <int R>
-__global__ __launch_bounds__(256) void k_fwd_thin(DevPlan P, const int* __restrict__ list, int NB) {
-  __shared__ double wk[R][128], yk[R][128], part[4][R][64];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int s = list[blockIdx.y];
+__global__ __launch_bounds__(256) void k_fwd_thin_y(DevPlan P, const int* __restrict__ list, int NB) {
+  __shared__ double wk[R][128];
+  const int tid = threadIdx.x;
+  const int s = list[blockIdx.x];
   const int col0 = P.sn_col0[s];
   const int k = P.sn_col0[s + 1] - col0;
-  const int f = (int)(P.row_ptr[s + 1] - P.row_ptr[s]);
-  const int nbelow = f - k;
-  if (blockIdx.x > 0 && ((int)blockIdx.x - 1) * 64 >= nbelow) return;
   const int64_t gcb = P.bigcol_base[s];
-  const double* F = P.arena + P.front_pos[s];
   const double* X = P.invl + P.invl_pos[s];
-  // panel entries of this thread's row: requested first, they do not depend on y
-  const int row = k + ((int)blockIdx.x - 1) * 64 + lane;       // meaningless for workgroup 0
-  const int rowc = blockIdx.x > 0 ? min(row, f - 1) : 0;
-  double lv[32];
-  {
-    const int cb = wv * 32;
+  // X first: its loads do not depend on the gather
+  const int c = tid >> 1, h = tid & 1;
+  const int cc = min(c, NB - 1);
+  double v[64];
 #pragma unroll
-    for (int q = 0; q < 32; ++q) lv[q] = F[(size_t)min(cb + q, k - 1) * f + rowc];
-  }
+  for (int q = 0; q < 64; ++q) v[q] = X[cc + (size_t)min(h * 64 + q, NB - 1) * NB];
   if (tid < 128) {
     double w[R];
     if (tid < k) fwd_gather<R>(P, gcb, col0, k, tid, w);
 #pragma unroll
     for (int q = 0; q < R; ++q) wk[q][tid] = tid < k ? w[q] : 0.0;
   }
+  __syncthreads();
+  double* yt = P.ythin + P.ythin_pos[s];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    double a = 0.0;
+#pragma unroll
+    for (int q = 0; q < 64; ++q) a += (h * 64 + q < NB) ? v[q] * wk[r][h * 64 + q] : 0.0;
+    a += __shfl_xor(a, 1, 64);
+    if (h == 0 && c < NB) {
+      yt[r * 128 + c] = c < k ? a : 0.0;
+      if (c < k) P.zwork[(size_t)r * P.xw_stride + col0 + c] = a / P.dvals[col0 + c];
+    }
+  }
+}
+
+template <int R>
+__global__ __launch_bounds__(256) void k_fwd_thin_upd(DevPlan P, const int* __restrict__ list) {
+  __shared__ double yk[R][128], part[4][R][128];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int s = list[blockIdx.y];
+  const int col0 = P.sn_col0[s];
+  const int k = P.sn_col0[s + 1] - col0;
+  const int f = (int)(P.row_ptr[s + 1] - P.row_ptr[s]);
+  const int rb = k + (int)blockIdx.x * 128;
+  if (rb >= f) return;
+  const double* F = P.arena + P.front_pos[s];
+  const int r0 = rb + 2 * lane;
+  const bool pair_ok = f >= 2;
+  const int pr = pair_ok ? max(min(r0, f - 2), 0) : 0;
+  // the panel entries: wave wv takes the columns wv, wv + 4, ... (k <= 128: at most 32 of them), all in flight
+  d2_t lv[32];
+#pragma unroll
+  for (int u = 0; u < 32; ++u) {
+    const int cq = min(wv + 4 * u, k - 1);
+    if (pair_ok) __builtin_memcpy(&lv[u], F + (size_t)cq * f + pr, 16);
+    else { lv[u][0] = F[(size_t)cq * f + pr]; lv[u][1] = 0.0; }
+  }
+  const double* yt = P.ythin + P.ythin_pos[s];
+  if (tid < 128)
+#pragma unroll
+    for (int r = 0; r < R; ++r) yk[r][tid] = yt[r * 128 + tid];
+  // this thread's row (threads 0..127: one row each), assembled while the panel loads are in flight
+  const int64_t gcb = P.bigcol_base[s];
+  const int myrow = rb + tid;
   double wr[R];
 #pragma unroll
-  for (int q = 0; q < R; ++q) wr[q] = 0.0;
-  if (wv == 0 && blockIdx.x > 0 && row < f) fwd_gather<R>(P, gcb, col0, k, row, wr);
+  for (int r = 0; r < R; ++r) wr[r] = 0.0;
+  if (tid < 128 && myrow < f) fwd_gather<R>(P, gcb, col0, k, myrow, wr);
   __syncthreads();
-  {
-    // y[c] = sum_{p <= c} X[c][p] w[p]: two threads per row c, 64 loads in flight each (X is zero above the diagonal
-    // and beyond k, wk is zero-padded)
-    const int c = tid >> 1, h = tid & 1;
-    const int cc = min(c, NB - 1);
-    double v[64];
 #pragma unroll
-    for (int q = 0; q < 64; ++q) v[q] = X[cc + (size_t)min(h * 64 + q, NB - 1) * NB];
+  for (int r = 0; r < R; ++r) {
+    double a0 = 0.0, a1 = 0.0;
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-      double a = 0.0;
+    for (int u = 0; u < 32; ++u) {
+      const int cq = wv + 4 * u;
+      if (cq < k) { const double y = yk[r][cq]; a0 += lv[u][0] * y; a1 += lv[u][1] * y; }
+    }
+    part[wv][r][2 * lane] = a0;
+    part[wv][r][2 * lane + 1] = a1;
+  }
+  __syncthreads();
+  if (tid < 128 && myrow < f) {
+    // pair value index of my row: lane ln = (myrow - rb) / 2 holds rows (pr_ln, pr_ln + 1)
+    const int ln = tid >> 1;
+    const int r0l = rb + 2 * ln;
+    const int prl = pair_ok ? max(min(r0l, f - 2), 0) : 0;
+    const int e = myrow - prl;                   // 0 or 1 (the clamped last pair: row f - 1 is value 1)
+    if (e >= 0 && e <= 1) {
+      double* cvs = P.cv + P.cv_pos[s] + (myrow - k);
 #pragma unroll
-      for (int q = 0; q < 64; ++q) a += (h * 64 + q < NB) ? v[q] * wk[r][h * 64 + q] : 0.0;
-      a += __shfl_xor(a, 1, 64);
-      if (h == 0 && c < NB) {
-        yk[r][c] = a;
-        if (blockIdx.x == 0 && c < k) P.zwork[(size_t)r * P.xw_stride + col0 + c] = a / P.dvals[col0 + c];
+      for (int r = 0; r < R; ++r) {
+        const int idx = 2 * ln + e;
+        cvs[(size_t)r * P.cv_stride] = wr[r] - ((part[0][r][idx] + part[1][r][idx]) + (part[2][r][idx] + part[3][r][idx]));
       }
     }
-  }
-  if (blockIdx.x == 0) return;
-  __syncthreads();
-  {
-    const int cb = wv * 32;
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      double a = 0.0;
-#pragma unroll
-      for (int q = 0; q < 32; ++q) a += (cb + q < k) ? lv[q] * yk[r][cb + q] : 0.0;
-      part[wv][r][lane] = a;
-    }
-  }
-  __syncthreads();
-  if (wv == 0 && row < f) {
-    double* cvs = P.cv + P.cv_pos[s] + (row - k);
-#pragma unroll
-    for (int r = 0; r < R; ++r)
-      cvs[(size_t)r * P.cv_stride] = wr[r] - ((part[0][r][lane] + part[1][r][lane]) + (part[2][r][lane] + part[3][r][lane]));
   }
 }
 
@@ -447,14 +488,16 @@ __global__ __launch_bounds__(256) void k_fwd_y(DevPlan P, const int* __restrict_
 }
 
 // Wide fronts, block b: y = sum of the partials (z = y / d stored by the first workgroup), then the rows below the block:
-// w[r] -= sum_p L[r][c0 + p] y[p].  128 rows per workgroup, two rows per lane (16-byte loads), wave g takes the columns
-// g, g + 4, ...; eight columns in flight per lane.  Block 0 assembles the rows it touches on the fly.
+// w[r] -= sum_p L[r][c0 + p] y[p].  64 rows per workgroup: a half-wave owns 32 row pairs (16-byte loads: two rows per lane),
+// the eight half-waves take the columns h, h + 8, ...; sixteen columns are in flight per lane (64 KiB per workgroup), the
+// partial sums meet in LDS.  Block 0 assembles the rows it touches on the fly.
+constexpr int kUpdRows = 64;
 template <int R>
 __global__ __launch_bounds__(256) void k_fwd_upd(DevPlan P, const int* __restrict__ list, int b) {
-  extern __shared__ __attribute__((aligned(16))) double sm[];      // y[R][kSB], then part[4][R][128]
+  extern __shared__ __attribute__((aligned(16))) double sm[];      // y[R][kSB], then part[8][R][64]
   double* yj = sm;
   double* part = sm + (size_t)R * kSB;
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int tid = threadIdx.x, l32 = tid & 31, hw = tid >> 5;
   const int s = list[blockIdx.y];
   const int col0 = P.sn_col0[s];
   const int k = P.sn_col0[s + 1] - col0;
@@ -463,7 +506,7 @@ __global__ __launch_bounds__(256) void k_fwd_upd(DevPlan P, const int* __restric
   xblock(k, b, c0, kb, ld, off);
   if (kb <= 0) return;
   const int rbeg = c0 + kb;                       // first row below the block
-  const int rb = rbeg + (int)blockIdx.x * 128;
+  const int rb = rbeg + (int)blockIdx.x * kUpdRows;
   if (blockIdx.x > 0 && rb >= f) return;
   const double* yp = P.ypart + P.ypart_pos[s];
   for (int p = tid; p < kSB; p += 256) {
@@ -478,26 +521,25 @@ __global__ __launch_bounds__(256) void k_fwd_upd(DevPlan P, const int* __restric
   }
   __syncthreads();
   if (rb >= f) return;
-  // rows (pr, pr + 1): the pair start is clamped so that both loads stay inside the column; `shift` maps them back
-  const int r0 = rb + 2 * lane;
-  const int pr = max(min(r0, f - 2), 0);
-  const int shift = r0 - pr;                      // 0: both rows mine; 1: only the second value is mine (= row r0); > 1: none
+  // rows (pr, pr + 1): the pair start is clamped so that both loads stay inside the column; the final pass maps them back
+  const int r0 = rb + 2 * l32;
+  const bool pair_ok = f >= 2;
+  const int pr = pair_ok ? max(min(r0, f - 2), 0) : 0;
   const double* Lp = P.arena + P.front_pos[s] + (size_t)c0 * f + pr;
   double a0[R], a1[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) { a0[r] = 0.0; a1[r] = 0.0; }
-  const bool pair_ok = f >= 2;
-  for (int p0 = wv; p0 < kb; p0 += 32) {          // columns p0, p0 + 4, ..., p0 + 28
-    d2_t v[8];
+  for (int p0 = hw; p0 < kb; p0 += 128) {          // columns p0, p0 + 8, ..., p0 + 120
+    d2_t v[16];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int p = min(p0 + 4 * u, kb - 1);
+    for (int u = 0; u < 16; ++u) {
+      const int p = min(p0 + 8 * u, kb - 1);
       if (pair_ok) __builtin_memcpy(&v[u], Lp + (size_t)p * f, 16);
       else { v[u][0] = Lp[(size_t)p * f]; v[u][1] = 0.0; }
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int p = p0 + 4 * u;
+    for (int u = 0; u < 16; ++u) {
+      const int p = p0 + 8 * u;
       if (p < kb) {
 #pragma unroll
         for (int r = 0; r < R; ++r) { const double y = yj[r * kSB + p]; a0[r] += v[u][0] * y; a1[r] += v[u][1] * y; }
@@ -506,15 +548,14 @@ __global__ __launch_bounds__(256) void k_fwd_upd(DevPlan P, const int* __restric
   }
 #pragma unroll
   for (int r = 0; r < R; ++r) {
-    part[((size_t)wv * R + r) * 128 + 2 * lane] = a0[r];
-    part[((size_t)wv * R + r) * 128 + 2 * lane + 1] = a1[r];
+    part[((size_t)hw * R + r) * kUpdRows + 2 * l32] = a0[r];
+    part[((size_t)hw * R + r) * kUpdRows + 2 * l32 + 1] = a1[r];
   }
   __syncthreads();
-  // 128 rows, two per lane of waves 0 and 1 ... simpler: thread t < 128 finishes the pair slot t of its own lane pair
-  if (tid < 128) {
-    const int ln = tid >> 1, e = tid & 1;         // the value e of lane ln's pair
+  if (tid < kUpdRows) {
+    const int ln = tid >> 1, e = tid & 1;         // value e of lane ln's pair
     const int r0l = rb + 2 * ln;
-    const int prl = max(min(r0l, f - 2), 0);
+    const int prl = pair_ok ? max(min(r0l, f - 2), 0) : 0;
     const int sh = r0l - prl;
     // which front row does pair value e belong to?  shift 0: prl + e; shift 1: only e == 1 is valid (row r0l); else none
     const int rowv = pair_ok ? prl + e : prl;
@@ -529,13 +570,13 @@ __global__ __launch_bounds__(256) void k_fwd_upd(DevPlan P, const int* __restric
       }
 #pragma unroll
       for (int r = 0; r < R; ++r) {
-        const double sum = (part[((size_t)0 * R + r) * 128 + tid] + part[((size_t)1 * R + r) * 128 + tid]) +
-                           (part[((size_t)2 * R + r) * 128 + tid] + part[((size_t)3 * R + r) * 128 + tid]);
+        double sum = 0.0;
+#pragma unroll
+        for (int h = 0; h < 8; ++h) sum += part[((size_t)h * R + r) * kUpdRows + tid];
         *fwd_slot<R>(P, s, col0, k, rowv, r) = w[r] - sum;
       }
     }
   }
-  (void)shift;
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -791,8 +832,8 @@ std::string solve_setup(const Symbolic& S, Numeric& N) {
   DevPlan& d = N.d;
   const int ns = S.nsuper;
   std::vector<int> ssched;
-  std::vector<int64_t> xinv_pos(ns, -1), ypart_pos(ns, -1);
-  int64_t xtot = 0, ytot = 0;
+  std::vector<int64_t> xinv_pos(ns, -1), ypart_pos(ns, -1), ythin_pos(ns, -1);
+  int64_t xtot = 0, ytot = 0, ttot = 0;
   auto build = [&](const std::vector<LevelSchedule>& levels, std::vector<SolveLevel>& out) {
     out.assign(levels.size(), SolveLevel());
     for (size_t l = 0; l < levels.size(); ++l) {
@@ -804,7 +845,7 @@ std::string solve_setup(const Symbolic& S, Numeric& N) {
         (N.sn_k[s] <= N.nb ? thin : wide).push_back(s);
       }
       L.thin_off = (int)ssched.size(); L.thin_cnt = (int)thin.size();
-      for (int s : thin) { ssched.push_back(s); L.thin_maxf = std::max(L.thin_maxf, N.sn_f[s]); L.thin_maxk = std::max(L.thin_maxk, N.sn_k[s]); L.thin_maxr = std::max(L.thin_maxr, N.sn_f[s] - N.sn_k[s]); }
+      for (int s : thin) { ssched.push_back(s); if (ythin_pos[s] < 0) { ythin_pos[s] = ttot; ttot += (int64_t)kMaxRhs * 128; } L.thin_maxf = std::max(L.thin_maxf, N.sn_f[s]); L.thin_maxk = std::max(L.thin_maxk, N.sn_k[s]); L.thin_maxr = std::max(L.thin_maxr, N.sn_f[s] - N.sn_k[s]); }
       L.wide_off = (int)ssched.size(); L.wide_cnt = (int)wide.size();
       for (int s : wide) {
         ssched.push_back(s);
@@ -826,6 +867,8 @@ std::string solve_setup(const Symbolic& S, Numeric& N) {
   if (!(e = up(N, ssched, &d.ssched)).empty()) return e;
   if (!(e = up(N, xinv_pos, &d.xinv_pos)).empty()) return e;
   if (!(e = up(N, ypart_pos, &d.ypart_pos)).empty()) return e;
+  if (!(e = up(N, ythin_pos, &d.ythin_pos)).empty()) return e;
+  if (!(e = dz(N, (size_t)ttot, &d.ythin)).empty()) return e;
   if (!(e = dz(N, (size_t)xtot, &d.xinv)).empty()) return e;
   if (!(e = dz(N, (size_t)xtot, &d.xtmp)).empty()) return e;
   if (!(e = dz(N, (size_t)ytot, &d.ypart)).empty()) return e;
@@ -875,16 +918,19 @@ static std::string fwd_enqueue_r(Numeric& N, int which) {
       else hipLaunchKernelGGL((k_fs_small<256, R>), dim3(g.cnt), dim3(256), lds, st, P, P.sched + g.off, g.maxf);
     }
     const SolveLevel& S = sl[l];
-    if (S.thin_cnt) hipLaunchKernelGGL(k_fwd_thin<R>, dim3(1 + (S.thin_maxr + 63) / 64, S.thin_cnt), dim3(256), 0, st, P, P.ssched + S.thin_off, N.nb);
+    if (S.thin_cnt) {
+      hipLaunchKernelGGL(k_fwd_thin_y<R>, dim3(S.thin_cnt), dim3(256), 0, st, P, P.ssched + S.thin_off, N.nb);
+      if (S.thin_maxr > 0) hipLaunchKernelGGL(k_fwd_thin_upd<R>, dim3((S.thin_maxr + 127) / 128, S.thin_cnt), dim3(256), 0, st, P, P.ssched + S.thin_off);
+    }
     if (S.wide_cnt) {
       const int* list = P.ssched + S.wide_off;
       const int nblk = (S.wide_maxk + kSB - 1) / kSB;
-      const size_t lds = ((size_t)R * kSB + (size_t)4 * R * 128) * sizeof(double);
+      const size_t lds = ((size_t)R * kSB + (size_t)8 * R * kUpdRows) * sizeof(double);
       for (int b = 0; b < nblk; ++b) {
         const int kbmax = std::min(kSB, S.wide_maxk - b * kSB);
         hipLaunchKernelGGL(k_fwd_y<R>, dim3((kbmax + 63) / 64, S.wide_cnt, kCS), dim3(256), 0, st, P, list, b);
         const int rem = std::max(S.wide_maxf - b * kSB, 0);        // upper bound on the rows below the start of block b (a narrower last block leaves more rows than maxf - (b + 1) kSB)
-        hipLaunchKernelGGL(k_fwd_upd<R>, dim3(std::max(1, (rem + 127) / 128), S.wide_cnt), dim3(256), lds, st, P, list, b);
+        hipLaunchKernelGGL(k_fwd_upd<R>, dim3(std::max(1, (rem + kUpdRows - 1) / kUpdRows), S.wide_cnt), dim3(256), lds, st, P, list, b);
       }
     }
   }
