@@ -129,6 +129,39 @@ mf_factor *mf_analyze(int64_t n, const int64_t *colptr, const int64_t *rowval, i
   }
   F->sn0[F->ns] = n;
   free(nchild);
+  /* relaxed amalgamation (Ashcraft & Grimes 1989; CHOLMOD's nrelax rules are of the same kind): a supernode is merged into
+   * the parent whose columns follow it directly when that costs few explicit zeros -- always up to 16 columns, up to 256
+   * columns below 10 % zeros in the merged panel.  Without it the chains of one-column supernodes below a dense separator
+   * re-add a whole contribution block per column. */
+  int64_t *sf = (int64_t *)malloc(sizeof(int64_t) * (size_t)(F->ns + 1));     /* front order per (merged) supernode */
+  {
+    int64_t *m0 = (int64_t *)malloc(sizeof(int64_t) * (size_t)(F->ns + 1));
+    int64_t *m1 = (int64_t *)malloc(sizeof(int64_t) * (size_t)(F->ns + 1));
+    int64_t *mz = (int64_t *)malloc(sizeof(int64_t) * (size_t)(F->ns + 1));   /* explicit zeros already inside the merged panel */
+    int64_t nm = 0;
+    for (int64_t p = 0; p < F->ns; ++p) {
+      int64_t c0 = F->sn0[p], c1 = F->sn0[p + 1], fp = F->count[c0], zp = 0;
+      while (nm > 0) {
+        const int64_t q = nm - 1;
+        const int64_t pq = F->parent[m1[q] - 1];
+        if (m1[q] != c0 || pq < c0 || pq >= c1) break;                         /* not the child that ends right before us */
+        const int64_t kq = m1[q] - m0[q], kp = c1 - c0, fq = sf[q];
+        const int64_t fnew = kq + fp;
+        const int64_t zeros = zp + mz[q] + kq * (fnew - fq);
+        const int64_t kn = kq + kp;
+        const int64_t entries = fnew * kn - kn * (kn - 1) / 2;
+        if (!(kn <= 16 || (kn <= 256 && zeros * 10 <= entries))) break;
+        c0 = m0[q]; fp = fnew; zp = zeros;
+        --nm;
+      }
+      m0[nm] = c0; m1[nm] = c1; sf[nm] = fp; mz[nm] = zp;
+      ++nm;
+    }
+    for (int64_t t = 0; t < nm; ++t) { F->sn0[t] = m0[t]; for (int64_t j = m0[t]; j < m1[t]; ++j) col2sn[j] = t; }
+    F->sn0[nm] = n;
+    F->ns = nm;
+    free(m0); free(m1); free(mz);
+  }
   const int64_t ns = F->ns;
   F->sparent = (int64_t *)malloc(sizeof(int64_t) * (size_t)(ns + 1));
   F->child_ptr = (int64_t *)calloc((size_t)(ns + 2), sizeof(int64_t));
@@ -152,11 +185,12 @@ mf_factor *mf_analyze(int64_t n, const int64_t *colptr, const int64_t *rowval, i
   F->lpos = (int64_t *)malloc(sizeof(int64_t) * (size_t)(ns + 2));
   F->rp[0] = 0; F->lpos[0] = 0;
   for (int64_t s = 0; s < ns; ++s) {
-    const int64_t f = F->count[F->sn0[s]], k = F->sn0[s + 1] - F->sn0[s];
+    const int64_t f = sf[s], k = F->sn0[s + 1] - F->sn0[s];
     F->rp[s + 1] = F->rp[s] + f;
     F->lpos[s + 1] = F->lpos[s] + f * k;
     if (f > F->max_front) F->max_front = f;
   }
+  free(sf);
   F->rows = (int64_t *)malloc(sizeof(int64_t) * (size_t)(F->rp[ns] + 1));
   /* column lists of the permuted strictly-lower pattern (rows > col) */
   int64_t *lp = (int64_t *)calloc((size_t)(n + 2), sizeof(int64_t));
@@ -319,10 +353,10 @@ static void do_front(mf_factor *F, const double *vals, const int64_t *ent_ptr, c
     const int64_t *Rc = F->rows + F->rp[c] + kc;
     int64_t *rel = (int64_t *)malloc(sizeof(int64_t) * (size_t)(rc + 1));
     for (int64_t t = 0, u = 0; t < rc; ++t) { while (R[u] != Rc[t]) ++u; rel[t] = u; }      /* both lists are sorted */
-    const double *C = F->cb[c];
+    const double *C = F->cb[c] + kc * fc + kc;        /* the child's front buffer: trailing rc x rc block, leading dimension fc */
     for (int64_t jj = 0; jj < rc; ++jj) {
       double *Ac = A + rel[jj] * f;
-      const double *Cc = C + jj * rc;
+      const double *Cc = C + jj * fc;
       for (int64_t ii = jj; ii < rc; ++ii) Ac[rel[ii]] += Cc[ii];
     }
     free(rel);
@@ -336,12 +370,8 @@ static void do_front(mf_factor *F, const double *vals, const int64_t *ent_ptr, c
     F->D[c0 + j] = A[j * f + j];
     memcpy(Lp + j * f, A + j * f, sizeof(double) * (size_t)f);
   }
-  if (r > 0) {
-    double *C = (double *)malloc(sizeof(double) * (size_t)(r * r));
-    for (int64_t jj = 0; jj < r; ++jj) memcpy(C + jj * r + jj, A + (k + jj) * f + k + jj, sizeof(double) * (size_t)(r - jj));
-    F->cb[s] = C;
-  }
-  free(A);
+  if (r > 0) F->cb[s] = A;      /* the contribution block stays where it is until the parent has added it */
+  else free(A);
   free(W);
 }
 

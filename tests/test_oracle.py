@@ -293,3 +293,30 @@ def test_schur_direct_reads_current_iterate(golden):
     ds = (r.comp_r - dy * cur.s) / cur.y
     for got, want in ((k.dir.x, dx), (k.dir.y, dy), (k.dir.s, ds)):
         assert np.max(np.abs(got - want)) <= 1e-9 * max(1.0, np.max(np.abs(want)))
+
+
+# ---- the supernodal multifrontal CPU baseline (okkt_oracle_mf.c) against the simplicial oracle
+@pytest.mark.parametrize("name,seed,threads", [("S-tiny", 0, 1), ("S-small", 1, 1), ("S-small", 2, 4)])
+def test_multifrontal_baseline_matches_simplicial_oracle(name, seed, threads):
+    from onephase_jl_amd import synth
+    prob = synth.make_config(name, seed=seed, well_scaled=True)
+    n, m = prob["n"], prob["m"]
+    rng = np.random.default_rng(seed)
+    perm = rng.permutation(n + m)
+    for delta, want in ((1e-7, 1), (-50.0, 0)):
+        K = synth.augmented_matrix(prob, delta=delta)
+        o1 = oracle.linear_solver_ORACLE("symmetric", perm=perm)
+        o2 = oracle.linear_solver_ORACLE_MF("symmetric", perm=perm, nthreads=threads)
+        assert o1.ls_factor_b(K, n, m) == o2.ls_factor_b(K, n, m) == want
+        assert o1.inertia()[:3] == o2.inertia()[:3]
+        d1, d2 = o1.diag(), o2.diag()
+        assert np.array_equal(np.sign(d1), np.sign(d2)) and np.allclose(d1, d2, rtol=1e-9, atol=0)
+        b = rng.normal(size=n + m)
+        x1, x2 = o1.ls_solve(b), o2.ls_solve(b)
+        assert np.max(np.abs(x1 - x2)) <= 1e-10 * np.max(np.abs(x1))
+    # Cholesky semantics on the Schur complement
+    Q = synth.schur_matrix(prob, delta=1e-6)
+    o1 = oracle.linear_solver_ORACLE("definite"); o2 = oracle.linear_solver_ORACLE_MF("definite", nthreads=threads)
+    assert o1.ls_factor_b(Q, n, 0) == o2.ls_factor_b(Q, n, 0) == 1
+    b = rng.normal(size=n)
+    assert np.max(np.abs(o1.ls_solve(b) - o2.ls_solve(b))) <= 1e-10 * np.max(np.abs(o1.ls_solve(b)))
