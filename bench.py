@@ -471,15 +471,22 @@ def cpu_baseline(sample_cfg, st_metric, K_metric, perm_metric, n_metric, m_metri
     # ---- multifrontal port: one core, all cores
     mf1 = oracle.linear_solver_ORACLE_MF("symmetric", perm=perm, nthreads=1)
     rc1, x1, dt_mf1, tsym_mf = timed(mf1)
-    mfp = oracle.linear_solver_ORACLE_MF("symmetric", perm=perm, nthreads=cores)
-    mfp._analyze(K)
-    t0 = time.perf_counter(); rcp = mfp.ls_factor_b(K, n, m); xp = mfp.ls_solve(b); dt_mfp = time.perf_counter() - t0
+    # "all host cores": OpenMP tasks over the tree and inside the large fronts; on a many-core host the task queue and the
+    # serial top of the tree can make fewer threads faster, so the sample picks the best of {all, 64, 32} and says so
+    dt_mfp, used, tried = None, cores, {}
+    for nth in sorted({cores, min(cores, 64), min(cores, 32)}, reverse=True):
+        cand = oracle.linear_solver_ORACLE_MF("symmetric", perm=perm, nthreads=nth)
+        cand._analyze(K)
+        t0 = time.perf_counter(); rcq = cand.ls_factor_b(K, n, m); xq = cand.ls_solve(b); dtq = time.perf_counter() - t0
+        tried[str(nth)] = dtq
+        if dt_mfp is None or dtq < dt_mfp:
+            dt_mfp, used, rcp, xp = dtq, nth, rcq, xq
     agree = bool(np.max(np.abs(xp - x)) <= 1e-7 * np.max(np.abs(x)) and rc1 == rcp == rc)
     # ---- the metric workload itself on all cores, when it fits the time budget
     est = dt_mfp * ratio
     direct = None
     if est <= 45.0 and K_metric is not None:
-        mfm = oracle.linear_solver_ORACLE_MF("symmetric", perm=perm_metric, nthreads=cores)
+        mfm = oracle.linear_solver_ORACLE_MF("symmetric", perm=perm_metric, nthreads=used)
         bm = np.random.default_rng(1).normal(size=n_metric + m_metric)
         t0 = time.perf_counter(); mfm._analyze(K_metric); t_sym_m = time.perf_counter() - t0
         t0 = time.perf_counter(); rcm = mfm.ls_factor_b(K_metric, n_metric, m_metric); xm = mfm.ls_solve(bm); dt_m = time.perf_counter() - t0
@@ -501,9 +508,11 @@ def cpu_baseline(sample_cfg, st_metric, K_metric, perm_metric, n_metric, m_metri
     base = {
         "value": value,
         "unit": "factor+solve/s",
-        "cores": cores,
+        "cores": used,
+        "host_cores": cores,
+        "threads_tried_sample_seconds": tried,
         "kind": "port",
-        "sample": (f"supernodal multifrontal LDL^T port (oracle/okkt_oracle_mf.c, OpenMP) on {cores} cores: "
+        "sample": (f"supernodal multifrontal LDL^T port (oracle/okkt_oracle_mf.c, OpenMP), {used} threads on a {cores}-core host: "
                    + (f"the metric workload itself, one factor+solve in {direct['seconds']:.2f} s ({direct['gflops']:.0f} GFLOP/s), analysis once"
                       if direct else f"one factor+solve of {sample_cfg} in {dt_mfp:.2f} s, scaled by the factor-flop ratio {ratio:.1f}")),
         "metric_workload_direct": direct,

@@ -304,27 +304,40 @@ static void tile_update(double *restrict A, int64_t ld, const double *restrict W
   }
 }
 
+/* rows [i0, i1) below the diagonal block of the panel [j0, j0 + jb): W = A21 L11^-T (right-looking over the panel's columns,
+ * L11 and D final in the diagonal block), L21 = W D^-1; independent across rows */
+static void panel_rows(double *restrict A, int64_t f, double *restrict W, int64_t j0, int64_t jb, int64_t i0, int64_t i1) {
+  for (int64_t j = j0; j < j0 + jb; ++j) {
+    const double rd = 1.0 / A[j * f + j];
+    double *restrict Aj = A + j * f;
+    double *restrict Wj = W + (j - j0) * f;
+    const int64_t is = i0 > j + 1 ? i0 : j + 1;  /* strictly below the pivot (matters inside the diagonal block only) */
+    for (int64_t i = is; i < i1; ++i) { Wj[i] = Aj[i]; Aj[i] *= rd; }
+    for (int64_t c = j + 1; c < j0 + jb; ++c) {
+      const double t = Aj[c];                    /* L[c, j] of the diagonal block */
+      double *restrict Ac = A + c * f;
+      const int64_t ic = is > c ? is : c;        /* lower triangle only */
+      for (int64_t i = ic; i < i1; ++i) Ac[i] -= Wj[i] * t;
+    }
+  }
+}
+
 /* partial LDL^T of the leading k columns of the f x f front A (lower), blocked; W: scratch f * MF_NB */
 static void front_factor(double *A, int64_t f, int64_t k, double *W, int par) {
   for (int64_t j0 = 0; j0 < k; j0 += MF_NB) {
     const int64_t jb = (k - j0) < MF_NB ? (k - j0) : MF_NB;
-    /* diagonal block + the rows below, column by column (right-looking inside the panel) */
-    for (int64_t j = j0; j < j0 + jb; ++j) {
-      const double d = A[j * f + j];
-      const double rd = 1.0 / d;
-      double *restrict Aj = A + j * f;
-      double *restrict Wj = W + (j - j0) * f;
-      for (int64_t i = j + 1; i < f; ++i) { Wj[i] = Aj[i]; Aj[i] *= rd; }        /* W = L * D, L = W / d */
-      for (int64_t c = j + 1; c < j0 + jb; ++c) {                                /* update the rest of the panel */
-        const double t = Aj[c];
-        double *restrict Ac = A + c * f;
-        for (int64_t i = c; i < f; ++i) Ac[i] -= Wj[i] * t;
-      }
-    }
-    /* trailing update with the whole panel: tiles of MF_NB columns x 256 rows */
     const int64_t t0 = j0 + jb;
+    /* the jb x jb diagonal block, unblocked (the only serial piece of a panel) */
+    panel_rows(A, f, W, j0, jb, j0, t0);          /* rows inside the block: entries above the diagonal of a column are never read */
     if (t0 >= f) break;
+    /* the rows below, then the trailing update: tiles of MF_NB columns x 256 rows */
     if (par && f - t0 > 1024) {
+      const int64_t nrt = (f - t0 + 255) / 256;
+#pragma omp taskloop grainsize(1) default(shared)
+      for (int64_t rt = 0; rt < nrt; ++rt) {
+        const int64_t i0 = t0 + rt * 256;
+        panel_rows(A, f, W, j0, jb, i0, (i0 + 256) < f ? (i0 + 256) : f);
+      }
       const int64_t nct = (f - t0 + MF_NB - 1) / MF_NB;
 #pragma omp taskloop grainsize(1) default(shared)
       for (int64_t ct = 0; ct < nct; ++ct) {
@@ -332,6 +345,7 @@ static void front_factor(double *A, int64_t f, int64_t k, double *W, int par) {
         for (int64_t i0 = c0; i0 < f; i0 += 256) tile_update(A, f, W, f, j0, jb, i0, (i0 + 256) < f ? (i0 + 256) : f, c0, c1);
       }
     } else {
+      panel_rows(A, f, W, j0, jb, t0, f);
       for (int64_t c0 = t0; c0 < f; c0 += MF_NB) {
         const int64_t c1 = (c0 + MF_NB) < f ? (c0 + MF_NB) : f;
         for (int64_t i0 = c0; i0 < f; i0 += 256) tile_update(A, f, W, f, j0, jb, i0, (i0 + 256) < f ? (i0 + 256) : f, c0, c1);
@@ -375,8 +389,30 @@ static void do_front(mf_factor *F, const double *vals, const int64_t *ent_ptr, c
   free(W);
 }
 
-static void run_front_task(mf_factor *F, const double *vals, const int64_t *ent_ptr, const int64_t *ent, int64_t s) {
-  /* a front, then up the tree while this task is the last child to finish */
+/* the whole subtree below s (s excluded), children before parents, on this thread: an explicit stack instead of recursion
+ * (a banded matrix has an elimination tree of depth n) */
+static void run_subtree_seq(mf_factor *F, const double *vals, const int64_t *ent_ptr, const int64_t *ent, int64_t root) {
+  int64_t cap = 64, top = 0;
+  int64_t *stk = (int64_t *)malloc(sizeof(int64_t) * (size_t)cap * 2);
+  stk[0] = root; stk[1] = F->child_ptr[root]; top = 1;
+  while (top > 0) {
+    const int64_t s = stk[2 * (top - 1)];
+    int64_t *it = &stk[2 * (top - 1) + 1];
+    if (*it < F->child_ptr[s + 1]) {
+      const int64_t c = F->child[(*it)++];
+      if (top == cap) { cap *= 2; stk = (int64_t *)realloc(stk, sizeof(int64_t) * (size_t)cap * 2); }
+      stk[2 * top] = c; stk[2 * top + 1] = F->child_ptr[c]; ++top;
+    } else {
+      if (s != root) do_front(F, vals, ent_ptr, ent, s, 0);
+      --top;
+    }
+  }
+  free(stk);
+}
+
+static void run_front_task(mf_factor *F, const double *vals, const int64_t *ent_ptr, const int64_t *ent, int64_t s, int whole_subtree) {
+  /* (the subtree below s, then) the front s, then up the tree while this task is the last child to finish */
+  if (whole_subtree) run_subtree_seq(F, vals, ent_ptr, ent, s);
   for (;;) {
     const int64_t f = F->rp[s + 1] - F->rp[s];
     do_front(F, vals, ent_ptr, ent, s, f > 1500);
@@ -408,18 +444,40 @@ int mf_factor_numeric(mf_factor *F, const double *vals, int64_t npos, int64_t nn
   for (int64_t s = 0; s < ns; ++s) F->pending[s] = (int)(F->child_ptr[s + 1] - F->child_ptr[s]);
 #ifdef _OPENMP
   if (nthreads > 0) omp_set_num_threads(nthreads);
+  const int nth = nthreads > 0 ? nthreads : omp_get_max_threads();
+#else
+  const int nth = 1;
 #endif
+  /* One task per maximal subtree of little work (run on one thread, children first) and one per front above those: tens of
+   * thousands of leaf-sized tasks would only fight over the task queue.  Dense flops of a front ~ k f^2. */
+  double *sub = (double *)malloc(sizeof(double) * (size_t)(ns + 1));
+  double total = 0.0;
+  for (int64_t s = 0; s < ns; ++s) {
+    const double f = (double)(F->rp[s + 1] - F->rp[s]), k = (double)(F->sn0[s + 1] - F->sn0[s]);
+    sub[s] = k * f * f + 1e3;
+  }
+  for (int64_t s = 0; s < ns; ++s) { total += sub[s]; if (F->sparent[s] >= 0) sub[F->sparent[s]] += sub[s]; }
+  const double small = total / (16.0 * (double)nth) > 2e7 ? total / (16.0 * (double)nth) : 2e7;
 #pragma omp parallel default(shared)
   {
 #pragma omp single
     {
-      for (int64_t s = 0; s < ns; ++s)
-        if (F->child_ptr[s + 1] == F->child_ptr[s]) {
+      for (int64_t s = 0; s < ns; ++s) {
+        const int64_t p = F->sparent[s];
+        const int is_small = sub[s] <= small;
+        const int parent_small = p >= 0 && sub[p] <= small;
+        if (parent_small) continue;                        /* inside somebody else's sequential subtree */
+        if (is_small) {
 #pragma omp task firstprivate(s) default(shared)
-          run_front_task(F, vals, ent_ptr, ent, s);
+          run_front_task(F, vals, ent_ptr, ent, s, 1);
+        } else if (F->child_ptr[s + 1] == F->child_ptr[s]) {
+#pragma omp task firstprivate(s) default(shared)
+          run_front_task(F, vals, ent_ptr, ent, s, 0);
         }
+      }
     }
   }
+  free(sub);
   free(ent_ptr);
   free(ent);
   int64_t pos = 0, neg = 0, zer = 0, bad = 0;
