@@ -249,23 +249,43 @@ def bench_sharded(args, rank, world, local_rank, config):
     n, m = prob["n"], prob["m"]
     K = synth.augmented_matrix(prob, delta=1e-8)
     dev = torch.device("cuda", local_rank)
-    sh = ShardedLinearSolver(TorchComm(device=dev), "symmetric", device=local_rank)
-    info = sh.analyze(K)
-    s0 = sh.solvers[0]
-    d_vals = [s0.dev_upload(K.data)]
     rhs = np.random.default_rng(1234).normal(size=n + m)
-    d_rhs = [s0.dev_upload(rhs)]
     steps, warm = max(args.steps, 5), max(args.warmup, 2)
+    # transport: the collectives inside the library on RCCL (okkt_dist_factor / okkt_dist_solve, what a Julia host would
+    # call; default) or the phase-by-phase C ABI with torch.distributed collectives (OKKT_DIST_TRANSPORT=torch)
+    transport = os.environ.get("OKKT_DIST_TRANSPORT", "abi")
+    if transport == "abi":
+        from onephase_jl_amd.distributed import RcclShardedLinearSolver
+        sh = RcclShardedLinearSolver(rank, world, "symmetric", device=local_rank)
+        info = sh.analyze(K)
+        s0 = sh.solver
+        dv, dr, dsol = s0.dev_upload(K.data), s0.dev_upload(rhs), s0.dev_alloc(8 * (n + m))
+        def one():
+            f = sh.factor(dv, n, m)
+            sh.solve(dr, dsol)
+            return f
+        fetch = lambda: s0.dev_download(dsol, (n + m,))
+    else:
+        sh = ShardedLinearSolver(TorchComm(device=dev), "symmetric", device=local_rank)
+        info = sh.analyze(K)
+        s0 = sh.solvers[0]
+        d_vals = [s0.dev_upload(K.data)]
+        d_rhs = [s0.dev_upload(rhs)]
+        last = {}
+        def one():
+            f = sh.factor(d_vals, n, m)
+            last["x"] = sh.solve(d_rhs)
+            return f
+        fetch = lambda: last["x"]
     for _ in range(warm):
-        flag = sh.factor(d_vals, n, m)
-        x = sh.solve(d_rhs)
+        flag = one()
     torch.cuda.synchronize(); dist.barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
-        flag = sh.factor(d_vals, n, m)
-        x = sh.solve(d_rhs)
+        flag = one()
     torch.cuda.synchronize(); dist.barrier()
     elapsed = max_over_ranks(time.perf_counter() - t0, True)
+    x = fetch()
     out = None
     if rank == 0:
         M = synth.symmetrize_lower(K)
@@ -278,6 +298,7 @@ def bench_sharded(args, rank, world, local_rank, config):
                "config": {"workload": f"{config}: n={n}, m={m}, nnz(tril K)={st['nnz_lower']}, subtree-sharded multifrontal LDL^T + solve", "inertia_flag": flag,
                           "inertia": list(sh.inertia), "residual_inf": resid, "top_flops_share": info["top_flops"] / total,
                           "part_flops": info["part_flops"], "model_speedup": total / (info["top_flops"] + max(info["part_flops"])),
+                          "transport": "RCCL inside the library (okkt_dist_factor / okkt_dist_solve)" if transport == "abi" else "torch.distributed collectives between C-ABI phases",
                           "exchange_MB_per_factor": info["cb_doubles"] * 8 / 1e6}}
     sh.finalize()
     return out

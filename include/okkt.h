@@ -187,6 +187,20 @@ int okkt_dist_solve_top(okkt_handle h);
 int okkt_dist_x(okkt_handle h, double* d_buf, int mode);
 int okkt_dist_solve_end(okkt_handle h);
 
+/* The same two sequences with the collectives INSIDE the library, on RCCL directly (ncclReduce / ncclBroadcast / ncclAllReduce
+ * enqueued on the handle's stream between the kernels: no host synchronisation between the phases, one at the end) -- what a
+ * Julia `linear_solver_HIP` uses when one process per GPU shares a factorisation; torch.distributed is not involved.
+ * librccl is opened at run time (dlopen "librccl.so.1" / "librccl.so"; OKKT_RCCL_PATH overrides), so the library loads and the
+ * single-GPU path works where RCCL is absent.  Protocol: one rank calls okkt_dist_unique_id and ships the 128 bytes to the
+ * others by any means (MPI, a file, torch's store); every rank then calls okkt_dist_set_partition(nranks, rank) and
+ * okkt_dist_comm_init(h, nranks, rank, id).  okkt_dist_factor returns the same 1 / 0 flag and the same summed pivot counts
+ * on every rank; okkt_dist_solve leaves the whole solution (original order) in d_sol on every rank. */
+int okkt_dist_unique_id(void* id_out /* 128 bytes */);
+int okkt_dist_comm_init(okkt_handle h, int nranks, int rank, const void* id /* 128 bytes */);
+int okkt_dist_comm_destroy(okkt_handle h);
+int okkt_dist_factor(okkt_handle h, const double* d_nzval, int64_t n, int64_t m, int sym_kind, okkt_inertia* inertia_out);
+int okkt_dist_solve(okkt_handle h, const double* d_rhs, double* d_sol);
+
 /* ---- level 2: device-resident KKT system solver ----------------------------------------- */
 typedef struct {
   double delta_start, delta_min, delta_max, delta_inc, delta_dec, delta_zero; /* parameters.jl:147-158 */

@@ -166,6 +166,11 @@ SIGNATURES = {
     "okkt_dist_solve_top": (C.c_int, [_vp]),
     "okkt_dist_x": (C.c_int, [_vp, _vp, C.c_int]),
     "okkt_dist_solve_end": (C.c_int, [_vp]),
+    "okkt_dist_unique_id": (C.c_int, [_vp]),
+    "okkt_dist_comm_init": (C.c_int, [_vp, C.c_int, C.c_int, _vp]),
+    "okkt_dist_comm_destroy": (C.c_int, [_vp]),
+    "okkt_dist_factor": (C.c_int, [_vp, _vp, C.c_int64, C.c_int64, C.c_int, C.POINTER(OkktInertia)]),
+    "okkt_dist_solve": (C.c_int, [_vp, _vp, _vp]),
     "okkt_kkt_default_pars": (C.c_int, [C.POINTER(OkktKktPars)]),
     "okkt_kkt_create": (C.c_int, [C.POINTER(_vp), C.POINTER(OkktOpts), C.c_int]),
     "okkt_kkt_destroy": (C.c_int, [_vp]),

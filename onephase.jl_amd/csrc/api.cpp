@@ -281,6 +281,7 @@ int okkt_create(okkt_handle* out, const okkt_opts* opts) {
 
 int okkt_destroy(okkt_handle h) {
   if (!h) return OKKT_ERR_INVALID;
+  if (h->rccl_comm || h->dist_cb || h->dist_x) (void)okkt_dist_comm_destroy(h);
   bool closed;
   { std::lock_guard<std::mutex> lock(pool_mutex()); closed = g_pool_closed; }
   if (h->device_ready && closed) {

@@ -12,6 +12,11 @@
 //            forward+backward on the top -> x of the top columns [broadcast] -> backward on local subtrees ->
 //            owned part of the solution, original order [reduce / all-reduce]
 #include <cstring>
+#include <cstdlib>
+#include <dlfcn.h>
+#include <mutex>
+
+#include <rccl/rccl.h>      // types and enums only: the entry points are resolved with dlsym at run time
 
 #include "solver.h"
 
@@ -177,6 +182,182 @@ int okkt_dist_solve_end(okkt_handle h) {
   std::string e = solve_bwd_enqueue(h->N, 0, 1);
   if (!e.empty()) return solver_set_error(h, OKKT_ERR_HIP, e);
   return sync_or_fail(h, "local backward solve");
+}
+
+// ---- RCCL transport ---------------------------------------------------------------------------------------------
+namespace {
+struct RcclApi {
+  void* lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*Reduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  std::string err;
+};
+RcclApi& rccl() {
+  static RcclApi* api = new RcclApi;      // never destructed: no ordering problem at process exit
+  static std::once_flag once;
+  std::call_once(once, [] {
+    RcclApi& a = *api;
+    const char* names[] = {getenv("OKKT_RCCL_PATH"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* nm : names) {
+      if (!nm) continue;
+      a.lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+      if (a.lib) break;
+    }
+    if (!a.lib) { a.err = std::string("librccl not found: ") + (dlerror() ? dlerror() : ""); return; }
+#define OKKT_SYM(field, name) a.field = (decltype(a.field))dlsym(a.lib, name); if (!a.field) a.err = std::string("librccl lacks ") + name
+    OKKT_SYM(GetUniqueId, "ncclGetUniqueId");
+    OKKT_SYM(CommInitRank, "ncclCommInitRank");
+    OKKT_SYM(CommDestroy, "ncclCommDestroy");
+    OKKT_SYM(Reduce, "ncclReduce");
+    OKKT_SYM(Broadcast, "ncclBroadcast");
+    OKKT_SYM(AllReduce, "ncclAllReduce");
+    OKKT_SYM(GetErrorString, "ncclGetErrorString");
+#undef OKKT_SYM
+  });
+  return *api;
+}
+int rccl_fail(okkt_solver_s* h, const char* what, ncclResult_t r) {
+  RcclApi& a = rccl();
+  return solver_set_error(h, OKKT_ERR_HIP, std::string(what) + ": " + (a.GetErrorString ? a.GetErrorString(r) : "RCCL error"));
+}
+#define OKKT_NCCL(h, what, expr) do { ncclResult_t r__ = (expr); if (r__ != ncclSuccess) return rccl_fail(h, what, r__); } while (0)
+int dist_free_buffers(okkt_solver_s* h) {
+  for (void* p : {(void*)h->dist_cb, (void*)h->dist_cv, (void*)h->dist_x, (void*)h->dist_counts}) if (p) (void)hipFree(p);
+  h->dist_cb = h->dist_cv = h->dist_x = nullptr;
+  h->dist_counts = nullptr;
+  return OKKT_OK;
+}
+}  // namespace
+
+int okkt_dist_unique_id(void* id_out) {
+  if (!id_out) return OKKT_ERR_INVALID;
+  RcclApi& a = rccl();
+  if (!a.err.empty() || !a.GetUniqueId) return OKKT_ERR_NO_DEVICE;
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+  ncclUniqueId id;
+  if (a.GetUniqueId(&id) != ncclSuccess) return OKKT_ERR_HIP;
+  std::memcpy(id_out, &id, sizeof(id));
+  return OKKT_OK;
+}
+
+int okkt_dist_comm_init(okkt_handle h, int nranks, int rank, const void* id) {
+  if (!h || !id || nranks < 1 || rank < 0 || rank >= nranks) return OKKT_ERR_INVALID;
+  RcclApi& a = rccl();
+  if (!a.err.empty()) return solver_set_error(h, OKKT_ERR_NO_DEVICE, a.err);
+  if (!h->device_ready) return solver_set_error(h, OKKT_ERR_NO_DEVICE, "no HIP device");
+  if (!h->analyzed || h->S.nparts != nranks || h->part_id != rank)
+    return solver_set_error(h, OKKT_ERR_INVALID, "okkt_dist_set_partition(nranks, rank) must precede okkt_dist_comm_init");
+  if (hipSetDevice(h->device) != hipSuccess) return solver_set_error(h, OKKT_ERR_HIP, "hipSetDevice failed");
+  if (h->rccl_comm) { (void)a.CommDestroy((ncclComm_t)h->rccl_comm); h->rccl_comm = nullptr; }
+  ncclUniqueId uid;
+  std::memcpy(&uid, id, sizeof(uid));
+  ncclComm_t comm = nullptr;
+  OKKT_NCCL(h, "ncclCommInitRank", a.CommInitRank(&comm, nranks, uid, rank));
+  h->rccl_comm = comm; h->rccl_nranks = nranks; h->rccl_rank = rank;
+  // exchange buffers (contribution blocks / vectors of the cut, solution pieces): sized by the partition
+  dist_free_buffers(h);
+  const size_t cb = h->S.boundary_cb.empty() ? 0 : (size_t)h->S.boundary_cb.back(), cv = h->S.boundary_cv.empty() ? 0 : (size_t)h->S.boundary_cv.back();
+  if (hipMalloc((void**)&h->dist_cb, std::max<size_t>(cb, 1) * 8) != hipSuccess || hipMalloc((void**)&h->dist_cv, std::max<size_t>(cv, 1) * 8) != hipSuccess ||
+      hipMalloc((void**)&h->dist_x, std::max<size_t>((size_t)h->S.n, 1) * 8) != hipSuccess || hipMalloc((void**)&h->dist_counts, 4 * sizeof(long long)) != hipSuccess)
+    return solver_set_error(h, OKKT_ERR_ALLOC, "exchange buffers");
+  return OKKT_OK;
+}
+
+int okkt_dist_comm_destroy(okkt_handle h) {
+  if (!h) return OKKT_ERR_INVALID;
+  if (h->rccl_comm) {
+    (void)hipStreamSynchronize(h->stream);
+    (void)rccl().CommDestroy((ncclComm_t)h->rccl_comm);
+    h->rccl_comm = nullptr;
+  }
+  return dist_free_buffers(h);
+}
+
+int okkt_dist_factor(okkt_handle h, const double* d_nzval, int64_t n, int64_t m, int sym_kind, okkt_inertia* inertia_out) {
+  if (!h || (!d_nzval && h->S.nnz_in > 0)) return OKKT_ERR_INVALID;
+  if (!h->rccl_comm) return solver_set_error(h, OKKT_ERR_INVALID, "okkt_dist_comm_init has not been called");
+  int rc = need_dist(h);
+  if (rc != OKKT_OK) return rc;
+  if (n < 0 || m < 0 || n + m != h->S.n) return solver_set_error(h, OKKT_ERR_INVALID, "n + m does not match the analysed dimension");
+  if (sym_kind != OKKT_SYM_DEFINITE && sym_kind != OKKT_SYM_SYMMETRIC) return solver_set_error(h, OKKT_ERR_INVALID, "unknown sym_kind");
+  RcclApi& a = rccl();
+  ncclComm_t comm = (ncclComm_t)h->rccl_comm;
+  hipStream_t st = h->stream;
+  h->dist_vals = d_nzval; h->dist_n = n; h->dist_m = m; h->dist_kind = sym_kind;
+  h->dist_tol = sym_kind == OKKT_SYM_DEFINITE ? 0.0 : h->opts.inertia_tol;
+  h->factored = false;
+  h->N.early_check = false; h->N.early_device = false; h->N.early_exited = false;
+  (void)hipEventRecord(h->ev0, st);
+  // local subtrees -> pack the contribution blocks of the cut (every slot written: zeros where another part owns it) ->
+  // reduce to part 0 -> part 0 unpacks and factors the top -> the four pivot counts summed over the parts; all on `st`
+  std::string e = numeric_factor_enqueue(h->N, d_nzval, h->dist_tol, 0, true);
+  if (e.empty()) e = numeric_dist_pack(h->N, 0, 0, h->dist_cb);
+  if (!e.empty()) return solver_set_error(h, OKKT_ERR_HIP, e);
+  const size_t cb = h->S.boundary_cb.empty() ? 0 : (size_t)h->S.boundary_cb.back();
+  if (cb && h->rccl_nranks > 1) OKKT_NCCL(h, "ncclReduce(contribution blocks)", a.Reduce(h->dist_cb, h->dist_cb, cb, ncclDouble, ncclSum, 0, comm, st));
+  if (h->rccl_rank == 0) {
+    e = numeric_dist_pack(h->N, 0, 1, h->dist_cb);
+    if (e.empty()) e = numeric_factor_enqueue(h->N, d_nzval, h->dist_tol, 1, false);
+    if (!e.empty()) return solver_set_error(h, OKKT_ERR_HIP, e);
+  }
+  numeric_sum_counts_device(h->N, h->dist_counts);
+  if (h->rccl_nranks > 1) OKKT_NCCL(h, "ncclAllReduce(pivot counts)", a.AllReduce(h->dist_counts, h->dist_counts, 4, ncclInt64, ncclSum, comm, st));
+  long long tot[4] = {0, 0, 0, 0};
+  if (hipMemcpyAsync(tot, h->dist_counts, sizeof(tot), hipMemcpyDeviceToHost, st) != hipSuccess) return solver_set_error(h, OKKT_ERR_HIP, "count download");
+  (void)hipEventRecord(h->ev1, st);
+  rc = sync_or_fail(h, "sharded factorisation");
+  if (rc != OKKT_OK) return rc;
+  float ms = 0;
+  if (hipEventElapsedTime(&ms, h->ev0, h->ev1) == hipSuccess) h->last_factor_ms = ms;
+  if (inertia_out) { inertia_out->pos = tot[0]; inertia_out->neg = tot[1]; inertia_out->zero = tot[2]; inertia_out->nonfinite = tot[3]; }
+  const int64_t t64[4] = {tot[0], tot[1], tot[2], tot[3]};
+  return okkt_dist_finish(h, t64);
+}
+
+int okkt_dist_solve(okkt_handle h, const double* d_rhs, double* d_sol) {
+  if (!h || !d_rhs || !d_sol) return OKKT_ERR_INVALID;
+  if (!h->rccl_comm) return solver_set_error(h, OKKT_ERR_INVALID, "okkt_dist_comm_init has not been called");
+  int rc = need_dist(h);
+  if (rc != OKKT_OK) return rc;
+  if (!h->factored) return solver_set_error(h, OKKT_ERR_INVALID, "solve called before a factorisation");
+  RcclApi& a = rccl();
+  ncclComm_t comm = (ncclComm_t)h->rccl_comm;
+  hipStream_t st = h->stream;
+  const bool multi = h->rccl_nranks > 1;
+  (void)hipEventRecord(h->ev0, st);
+  // forward on the subtrees -> contribution vectors of the cut reduced to part 0 -> forward + backward on the top ->
+  // separator solution broadcast -> backward on the subtrees -> owned solution pieces summed (all-reduce): every rank ends
+  // with the whole solution.  One stream, no host synchronisation before the end.
+  solve_permute_in(h->N, d_rhs, h->S.n, 1, 1);
+  std::string e = solve_fwd_enqueue(h->N, 0, 1);
+  if (e.empty()) e = numeric_dist_pack(h->N, 1, 0, h->dist_cv);
+  if (!e.empty()) return solver_set_error(h, OKKT_ERR_HIP, e);
+  const size_t cv = h->S.boundary_cv.empty() ? 0 : (size_t)h->S.boundary_cv.back();
+  if (cv && multi) OKKT_NCCL(h, "ncclReduce(contribution vectors)", a.Reduce(h->dist_cv, h->dist_cv, cv, ncclDouble, ncclSum, 0, comm, st));
+  if (h->rccl_rank == 0) {
+    e = numeric_dist_pack(h->N, 1, 1, h->dist_cv);
+    if (e.empty()) e = solve_fwd_enqueue(h->N, 1, 1);
+    if (e.empty()) e = solve_bwd_enqueue(h->N, 1, 1);
+    if (e.empty()) e = numeric_dist_x(h->N, 0, h->dist_x);
+    if (!e.empty()) return solver_set_error(h, OKKT_ERR_HIP, e);
+  }
+  if (multi) OKKT_NCCL(h, "ncclBroadcast(separator solution)", a.Broadcast(h->dist_x, h->dist_x, (size_t)h->S.n, ncclDouble, 0, comm, st));
+  if (multi || h->rccl_rank != 0) e = numeric_dist_x(h->N, 1, h->dist_x);
+  if (e.empty()) e = solve_bwd_enqueue(h->N, 0, 1);
+  if (e.empty()) e = numeric_dist_x(h->N, 2, d_sol);
+  if (!e.empty()) return solver_set_error(h, OKKT_ERR_HIP, e);
+  if (multi) OKKT_NCCL(h, "ncclAllReduce(solution)", a.AllReduce(d_sol, d_sol, (size_t)h->S.n, ncclDouble, ncclSum, comm, st));
+  (void)hipEventRecord(h->ev1, st);
+  rc = sync_or_fail(h, "sharded solve");
+  if (rc != OKKT_OK) return rc;
+  float ms = 0;
+  if (hipEventElapsedTime(&ms, h->ev0, h->ev1) == hipSuccess) h->last_solve_ms = ms;
+  return OKKT_OK;
 }
 
 }  // extern "C"

@@ -164,6 +164,8 @@ void solve_permute_out(const Numeric& N, double* d_sol, int64_t stride, int nr, 
 std::string numeric_dist_pack(Numeric& N, int what, int unpack, double* d_buf);
 // mode 0: xwork -> buf; 1: buf -> xwork on top columns; 2: owned part of the solution, original order -> buf
 std::string numeric_dist_x(Numeric& N, int mode, double* d_buf);
+// out[0..3] = pos, neg, zero, nonfinite summed over the counter slots, on the device (no synchronisation)
+void numeric_sum_counts_device(Numeric& N, long long* d_out4);
 // enqueue forward/diagonal/backward solves for the R right-hand sides already stored (permuted) in d.xwork
 std::string numeric_solve_enqueue(Numeric& N, int R);
 // diagadd[iperm] = (orig index < nshift) ? delta : 0, via perm

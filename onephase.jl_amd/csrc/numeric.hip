@@ -852,7 +852,10 @@ __global__ __launch_bounds__(256) void k_big_trsm(DevPlan P, const int* __restri
 #endif
 constexpr int kSyrkKC = OKKT_SYRK_KC;          // k-columns per ring slot
 constexpr int kSyrkStages = OKKT_SYRK_STAGES;  // ring slots (KC * stages = 32 keeps two workgroups per CU)
-constexpr int kSyrkLd = 144;
+#ifndef OKKT_SYRK_LD
+#define OKKT_SYRK_LD 144
+#endif
+constexpr int kSyrkLd = OKKT_SYRK_LD;   // leading dimension of the LDS panels (doubles)
 constexpr size_t syrk_lds_bytes(int stages) { return (size_t)stages * 2 * kSyrkKC * kSyrkLd * sizeof(double); }
 typedef __attribute__((address_space(3))) void lds_void_t;
 
@@ -1732,6 +1735,17 @@ __global__ void k_exchange_x(int n, const int* __restrict__ col_owner, const int
   if (mode == 0) buf[c] = xwork[c];
   else if (mode == 1) { if (col_owner[c] == -1) xwork[c] = buf[c]; }
   else { const int o = col_owner[c]; buf[perm[c]] = (o == part || (o == -1 && part == 0)) ? xwork[c] : 0.0; }
+}
+
+__global__ void k_sum_counts(const unsigned long long* __restrict__ counters, long long* __restrict__ out) {
+  const int c = threadIdx.x;
+  if (c >= 4) return;
+  unsigned long long sum = 0;
+  for (int q = 0; q < kCountSlots; ++q) sum += counters[(size_t)q * kCountStride + c];
+  out[c] = (long long)sum;
+}
+void numeric_sum_counts_device(Numeric& N, long long* d_out4) {
+  hipLaunchKernelGGL(k_sum_counts, dim3(1), dim3(64), 0, N.stream, N.d.counters, d_out4);
 }
 
 std::string numeric_dist_pack(Numeric& N, int what, int unpack, double* d_buf) {

@@ -37,6 +37,11 @@ struct okkt_solver_s {
   int64_t dist_n = 0, dist_m = 0;
   int dist_kind = 0;
   double dist_tol = 0;
+  // RCCL transport of the sharded path (dist.cpp): communicator and the three exchange buffers
+  void* rccl_comm = nullptr;
+  int rccl_nranks = 0, rccl_rank = 0;
+  double *dist_cb = nullptr, *dist_cv = nullptr, *dist_x = nullptr;
+  long long* dist_counts = nullptr;  // 4 summed pivot counts on the device
   double* d_rhs_stage = nullptr;  // staging for host-side rhs/sol
   int64_t rhs_stage_len = 0;
 };

@@ -217,6 +217,74 @@ class ShardedLinearSolver:
         self.solvers = []
 
 
+class RcclShardedLinearSolver:
+    """ls_factor! / ls_solve of ONE matrix sharded over `world` processes (one per GPU) with the collectives INSIDE the
+    library on RCCL (okkt_dist_factor / okkt_dist_solve: reduce of the contribution blocks, broadcast of the separator
+    solution, all-reduce of the solution pieces on the handle's stream, one synchronisation per call).  This is the path a
+    Julia host uses; Python only ships the 128-byte RCCL id from rank 0 to the others -- `exchange_id(bytes or None) ->
+    bytes` (default: torch.distributed.broadcast_object_list when a process group exists; world == 1 needs none)."""
+
+    def __init__(self, rank, world, sym="symmetric", exchange_id=None, **opts):
+        self.rank, self.world, self.sym = int(rank), int(world), sym
+        self._exchange = exchange_id
+        self.solver = linear_solver_HIP(sym, **opts)
+        initialize_b(self.solver)
+        self.inertia = None
+        self._ready = False
+
+    def _call(self, fn, *args):
+        s = self.solver
+        return s._check(getattr(s._lib, fn)(s._h, *args), fn)
+
+    def analyze(self, A):
+        s = self.solver
+        self.dim, colptr, rowval, _, base = csc_arrays(A)
+        s._check(s._lib.okkt_analyze(s._h, self.dim, L.p_i64(colptr), L.p_i64(rowval), base), "okkt_analyze")
+        s._dim = self.dim
+        self._call("okkt_dist_set_partition", self.world, self.rank)
+        uid = None
+        if self.rank == 0:
+            buf = (C.c_char * 128)()
+            rc = s._lib.okkt_dist_unique_id(C.cast(buf, C.c_void_p))
+            if rc != 0:
+                raise OkktError(f"okkt_dist_unique_id failed ({rc}): librccl could not be opened")
+            uid = bytes(buf)
+        if self.world > 1:
+            ex = self._exchange
+            if ex is None:
+                import torch.distributed as dist
+                def ex(b):
+                    box = [b]
+                    dist.broadcast_object_list(box, src=0)
+                    return box[0]
+            uid = ex(uid)
+        idbuf = C.create_string_buffer(uid, 128)
+        self._call("okkt_dist_comm_init", self.world, self.rank, C.cast(idbuf, C.c_void_p))
+        cb, cv, nb = C.c_int64(), C.c_int64(), C.c_int64()
+        pf = np.zeros(self.world)
+        tf = C.c_double()
+        self._call("okkt_dist_info", C.byref(cb), C.byref(cv), C.byref(nb), L.p_f64(pf), C.byref(tf))
+        self.info = dict(cb_doubles=cb.value, cv_doubles=cv.value, n_boundary=nb.value, part_flops=pf.tolist(), top_flops=tf.value)
+        self._ready = True
+        return self.info
+
+    def factor(self, d_vals, n, m):
+        kind = L.OKKT_SYM_DEFINITE if self.sym == "definite" else L.OKKT_SYM_SYMMETRIC
+        inert = L.OkktInertia()
+        flag = self._call("okkt_dist_factor", C.c_void_p(d_vals), n, m, kind, C.byref(inert))
+        self.inertia = inert.as_tuple()
+        return int(flag)
+
+    def solve(self, d_rhs, d_sol):
+        self._call("okkt_dist_solve", C.c_void_p(d_rhs), C.c_void_p(d_sol))
+
+    def finalize(self):
+        if self.solver is not None:
+            self.solver._lib.okkt_dist_comm_destroy(self.solver._h)
+            finalize_b(self.solver)
+            self.solver = None
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # Speculative delta loop (SURVEY.md 8e/8f): replicas of ONE KKT system, every rank factors a different candidate of
 # ipopt_strategy!'s delta sequence at the same time.  The candidates, their order and the returned

@@ -5,7 +5,7 @@ import pytest
 import scipy.sparse as sp
 
 from onephase_jl_amd import synth
-from onephase_jl_amd.distributed import LocalComm, ShardedLinearSolver
+from onephase_jl_amd.distributed import LocalComm, RcclShardedLinearSolver, ShardedLinearSolver
 from onephase_jl_amd.linear_system_solvers import finalize_b, initialize_b, linear_solver_HIP
 
 pytestmark = pytest.mark.gpu
@@ -88,3 +88,32 @@ def test_speculative_delta_loop_matches_serial(golden, world):
                     assert np.max(np.abs(d - dirs[0])) <= 1e-12 * max(1.0, np.max(np.abs(dirs[0])))
                 for k in ks + [serial]:
                     k.finalize_b()
+
+
+def test_rccl_transport_single_rank_matches_unsharded():
+    # okkt_dist_factor / okkt_dist_solve (collectives inside the library, on RCCL) with a one-rank communicator: the whole
+    # sequence -- RCCL id, ncclCommInitRank, pack / unpack, device-side count sum, one synchronisation -- against the
+    # unsharded solver.  (Two ranks on one GPU are refused by RCCL; the multi-rank protocol is the LocalComm / gloo tests'.)
+    prob = synth.make_config("S-small", seed=4, well_scaled=True)
+    n, m = prob["n"], prob["m"]
+    K = synth.augmented_matrix(prob, delta=1e-7)
+    b = np.random.default_rng(6).normal(size=n + m)
+    ref = linear_solver_HIP("symmetric")
+    initialize_b(ref)
+    assert ref.ls_factor_b(K, n, m) == 1
+    x_ref = ref.ls_solve(b)
+    sh = RcclShardedLinearSolver(0, 1, "symmetric")
+    sh.analyze(K)
+    s = sh.solver
+    d_vals, d_rhs, d_sol = s.dev_upload(K.data), s.dev_upload(b), s.dev_alloc(8 * (n + m))
+    for _ in range(2):
+        assert sh.factor(d_vals, n, m) == 1
+        assert sh.inertia == ref.inertia
+        sh.solve(d_rhs, d_sol)
+        x = s.dev_download(d_sol, (n + m,))
+        assert np.max(np.abs(x - x_ref)) <= 1e-12 * np.max(np.abs(x_ref))
+    K2 = synth.augmented_matrix(prob, delta=-50.0)
+    assert sh.factor(s.dev_upload(K2.data), n, m) == ref.ls_factor_b(K2, n, m) == 0
+    assert sh.inertia == ref.inertia
+    sh.finalize()
+    finalize_b(ref)
