@@ -384,29 +384,53 @@ __global__ __launch_bounds__(256) void k_big_assemble_chunked(DevPlan P, const i
   }
   (void)buf;
   const int64_t q0 = P.ea_ptr[gc], q1 = P.ea_ptr[gc + 1];
-  int64_t src_n = 0, rel_n = 0, cut_n = 0;
-  int rc_n = 0, jj_n = 0;
-  if (q0 < q1) { src_n = P.ea_src[q0]; rel_n = P.ea_rel[q0]; rc_n = P.ea_rc[q0]; jj_n = P.ea_jj[q0]; cut_n = P.ea_cut[q0]; }
-  for (int64_t q = q0; q < q1; ++q) {
-    const int rc = rc_n, jj = jj_n;
-    const int* rl = P.rel + rel_n;
-    const double* Ccol = P.arena + src_n;
-    const int* cut = P.cutv + cut_n;
-    if (q + 1 < q1) { src_n = P.ea_src[q + 1]; rel_n = P.ea_rel[q + 1]; rc_n = P.ea_rc[q + 1]; jj_n = P.ea_jj[q + 1]; cut_n = P.ea_cut[q + 1]; }
-    const int lo = max(jj, cut[t]), hi = min(rc, cut[t + 1]);     // rows of this item that fall into the chunk
-    int ii = lo + lane;
-    for (; ii + 192 < hi; ii += 256) {
-      int d[4];
-      double v[4], o[4];
+  // Items are applied strictly in list order (same summation order as every other assembly path: bitwise identical results),
+  // but four at a time have their records, then their chunk boundaries, then the first 64 rows of their index and value
+  // columns in flight together (clamped addresses, no branches around the loads): three dependent round trips per four
+  // items instead of two per item -- the kernel is pure memory latency (SQ_WAIT_ANY 85 % of the wave cycles).
+  constexpr int NB4 = 4;
+  for (int64_t q = q0; q < q1; q += NB4) {
+    int64_t src[NB4], rel[NB4], cutp[NB4];
+    int rc[NB4], jj[NB4], lo[NB4], hi[NB4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) d[u] = rl[ii + 64 * u] - r0;
-#pragma unroll
-      for (int u = 0; u < 4; ++u) { v[u] = Ccol[ii + 64 * u]; o[u] = base[d[u]]; }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) base[d[u]] = o[u] + v[u];
+    for (int u = 0; u < NB4; ++u) {
+      const int64_t qq = min(q + u, q1 - 1);
+      src[u] = P.ea_src[qq]; rel[u] = P.ea_rel[qq]; rc[u] = P.ea_rc[qq]; jj[u] = P.ea_jj[qq]; cutp[u] = P.ea_cut[qq];
     }
-    for (; ii < hi; ii += 64) base[rl[ii] - r0] += Ccol[ii];
-    __threadfence_block();
+#pragma unroll
+    for (int u = 0; u < NB4; ++u) {
+      const int* cut = P.cutv + cutp[u];
+      lo[u] = max(jj[u], cut[t]); hi[u] = min(rc[u], cut[t + 1]);      // rows of this item that fall into the chunk
+    }
+    int d[NB4];
+    double v[NB4];
+#pragma unroll
+    for (int u = 0; u < NB4; ++u) {
+      const int ii = min(lo[u] + lane, rc[u] - 1);
+      d[u] = P.rel[rel[u] + ii] - r0;
+      v[u] = P.arena[src[u] + ii];
+    }
+#pragma unroll
+    for (int u = 0; u < NB4; ++u) {
+      if (q + u < q1) {       // wave-uniform
+        if (lo[u] + lane < hi[u]) base[d[u]] += v[u];
+        const int* rl = P.rel + rel[u];
+        const double* Ccol = P.arena + src[u];
+        int ii = lo[u] + 64 + lane;
+        for (; ii + 192 < hi[u]; ii += 256) {
+          int dd[4];
+          double vv[4], oo[4];
+#pragma unroll
+          for (int w = 0; w < 4; ++w) dd[w] = rl[ii + 64 * w] - r0;
+#pragma unroll
+          for (int w = 0; w < 4; ++w) { vv[w] = Ccol[ii + 64 * w]; oo[w] = base[dd[w]]; }
+#pragma unroll
+          for (int w = 0; w < 4; ++w) base[dd[w]] = oo[w] + vv[w];
+        }
+        for (; ii < hi[u]; ii += 64) base[rl[ii] - r0] += Ccol[ii];
+        __threadfence_block();
+      }
+    }
   }
   double* col = P.arena + P.front_pos[s] + (size_t)pc * f + r0;
   for (int i = lane; i < n; i += 64) col[i] = base[i];
@@ -1596,11 +1620,11 @@ std::string numeric_factor_enqueue(Numeric& N, const double* d_vals, double tol,
       // Used only while the rest is large enough; afterwards everything runs in order on the main stream.
       // Inverses of the diagonal blocks for the solves (solve.hip).  The NB x NB ones (k_big_invert) run on `st` at the end
       // of the level; the kSolveBlock-column ones of the wide fronts run on the auxiliary stream beside the next levels.
-      // A front of at least four such blocks starts early: the blocks that are final when it enters its chain-bound tail
+      // A front of at least two such blocks starts early: the blocks that are final when it enters its chain-bound tail
       // (fewer than sb_tail_rows rows left, idle CUs) are inverted during the tail, the rest behind the last panel.
       const SolveLevel& SL = (which == 0 ? N.slevels : N.slevels_top)[l];
       hipStream_t inv_st = N.stream_aux ? N.stream_aux : st;
-      const bool inv_early = N.stream_aux != nullptr && SL.wide_cnt > 0 && g.maxk >= 4 * kSolveBlock && N.sb_tail_rows >= 0;
+      const bool inv_early = N.stream_aux != nullptr && SL.wide_cnt > 0 && g.maxk >= 2 * kSolveBlock && N.sb_tail_rows >= 0;
       int inv_steps_done = 0, inv_blocks_done = 0;
       const size_t lds_inv = ((size_t)(NB + 2) * NB + 3 * kTld * kIB) * sizeof(double);
       auto inv_range = [&](int steps_final, bool last) -> std::string {
@@ -1657,7 +1681,9 @@ std::string numeric_factor_enqueue(Numeric& N, const double* d_vals, double tol,
           if (ev_panel) { OKKT_HIP_TRY(hipStreamWaitEvent(st, ev_panel, 0)); ev_panel = nullptr; }
           // columns below stepB * NB are final behind this point of `st`: once the front is in its chain-bound tail, the
           // inversion of the finished super-blocks starts on the auxiliary stream
-          if (inv_early && inv_blocks_done == 0 && rem_rows(stepB) < N.sb_tail_rows && !(e = inv_range(stepB, false)).empty()) return e;
+          // (every block that has become final since the last call: in the tail the CUs are idle anyway, and the first solve
+          // then only waits for the last, partial block)
+          if (inv_early && rem_rows(stepB) < N.sb_tail_rows && !(e = inv_range(stepB, false)).empty()) return e;
           if (!(e = launch_syrk(st, stepA, gs_cur, stepB, 0, par, 0)).empty()) return e;
           if (more && !(e = launch_panels(st, stepB, gs_next, par ^ 1)).empty()) return e;
         }
