@@ -77,6 +77,42 @@ __global__ void k_assemble_schur(int64_t nnzQ, const int64_t* __restrict__ qptr,
   A[e] = v;
 }
 
+// The same sum with the column of Q resident in LDS (eval_J_T_J, eval.jl:85-87; form_system!, schur.jl:55).  A group of 16
+// lanes owns column b of Q: for every row i of J that holds column b (ascending: the reference's summation order) the lanes
+// stream the CSR segment of row i with columns a >= b -- values contiguous in the CSR-ordered copy -- and add
+// (J_ia sig_i) J_ib into the column's accumulator at a precomputed 16-bit slot; the column leaves LDS once, with H added.
+// 12 bytes per term (8 value + 2 slot + the per-row scalars) instead of 12 bytes of index lists plus three gathers, and
+// the read-modify-write chain of an entry runs in LDS.  Bitwise the same result as k_assemble_schur.
+__global__ __launch_bounds__(256) void k_assemble_schur_lds(int64_t n, int G, int maxcol, const int64_t* __restrict__ Ap, const int64_t* __restrict__ Jp,
+                                                            const int* __restrict__ Ji, const double* __restrict__ Jx, const int64_t* __restrict__ Jrp,
+                                                            const double* __restrict__ Jcsr, const int64_t* __restrict__ seg_q,
+                                                            const int64_t* __restrict__ seg_t, const uint16_t* __restrict__ tslot,
+                                                            const double* __restrict__ sig, const int64_t* __restrict__ qh,
+                                                            const double* __restrict__ Hx, double* __restrict__ A) {
+  extern __shared__ __attribute__((aligned(16))) double sacc[];
+  const int g = threadIdx.x >> 4, l = threadIdx.x & 15;
+  const int64_t b = (int64_t)blockIdx.x * G + g;
+  if (g >= G || b >= n) return;                  // no workgroup barrier below: a group only talks to itself (one wave)
+  double* acc = sacc + (size_t)g * maxcol;
+  const int64_t a0 = Ap[b];
+  const int ncol = (int)(Ap[b + 1] - a0);
+  for (int e = l; e < ncol; e += 16) acc[e] = 0.0;
+  __threadfence_block();
+  for (int64_t p = Jp[b]; p < Jp[b + 1]; ++p) {
+    const int i = Ji[p];
+    const double c = sig[i], jb = Jx[p];
+    const int64_t q0 = seg_q[p], q1 = Jrp[i + 1], t0 = seg_t[p];
+    for (int64_t q = q0 + l; q < q1; q += 16) acc[tslot[t0 + (q - q0)]] += (Jcsr[q] * c) * jb;
+    __threadfence_block();                       // the next row may touch the same slots from other lanes of the group
+  }
+  for (int e = l; e < ncol; e += 16) {
+    double v = acc[e];
+    const int64_t h = qh[a0 + e];
+    if (h >= 0) v += Hx[h];
+    A[a0 + e] = v;
+  }
+}
+
 // schur_diag = diag(H) + sum_i J_ij^2 sig_i (kkt_system_solver.jl:296-300, eval.jl:89-100)
 __global__ void k_schur_diag(int64_t n, const int64_t* __restrict__ Jp, const int* __restrict__ Ji,
                              const double* __restrict__ Jx, const double* __restrict__ sig,
@@ -649,30 +685,62 @@ int okkt_kkt_set_structure(okkt_kkt_handle k, int64_t n, int64_t m, const int64_
       Ai.resize(Ap[n]);
       for (int64_t j = 0; j < n; ++j) { std::copy(cols[j].begin(), cols[j].end(), Ai.begin() + Ap[j]); diagA[j] = Ap[j]; }
       k->nnzA = Ap[n];
-      // contribution lists
-      std::vector<int64_t> qptr(k->nnzA + 1, 0), qh(k->nnzA, -1);
+      std::vector<int64_t> qh(k->nnzA, -1);
       auto slot = [&](int a, int bcol) -> int64_t {
         auto it = std::lower_bound(Ai.begin() + Ap[bcol], Ai.begin() + Ap[bcol + 1], (int64_t)a);
         return it - Ai.begin();
       };
-      for (int64_t i = 0; i < m; ++i)
-        for (int64_t p = Jrp[i]; p < Jrp[i + 1]; ++p)
-          for (int64_t q = Jrp[i]; q < Jrp[i + 1]; ++q)
-            if (Jrj[p] >= Jrj[q]) ++qptr[slot(Jrj[p], Jrj[q]) + 1];
-      for (int64_t e = 0; e < k->nnzA; ++e) qptr[e + 1] += qptr[e];
-      std::vector<int> qa(qptr[k->nnzA]), qb(qptr[k->nnzA]), qi(qptr[k->nnzA]);
-      std::vector<int64_t> fill(qptr.begin(), qptr.end() - 1);
-      for (int64_t i = 0; i < m; ++i)   // rows ascending: fixed summation order
-        for (int64_t p = Jrp[i]; p < Jrp[i + 1]; ++p)
-          for (int64_t q = Jrp[i]; q < Jrp[i + 1]; ++q)
-            if (Jrj[p] >= Jrj[q]) {
-              const int64_t t = fill[slot(Jrj[p], Jrj[q])]++;
-              // Q[a][b] = sum_i (J'[b... the reference forms (J_T * D) * J: entry (row a of J_T) -> J[i][a] * d_i * J[i][b]
-              qa[t] = (int)Jrmap[p]; qb[t] = (int)Jrmap[q]; qi[t] = (int)i;
-            }
       for (int64_t j = 0; j < n; ++j)
         for (int64_t p = Hp[j]; p < Hp[j + 1]; ++p) qh[slot(Hi[p], (int)j)] = p;
-      UPL(qptr, qptr); UPL(qh, qh); UPL(qa, qa); UPL(qb, qb); UPL(qi, qi); UPL(diagA, diagA);
+      int64_t maxcol = 1;
+      for (int64_t j = 0; j < n; ++j) maxcol = std::max(maxcol, Ap[j + 1] - Ap[j]);
+      // LDS-staged assembly (k_assemble_schur_lds) while a column of Q fits a 16-lane group's share of 64 KiB of LDS
+      const int G = maxcol <= 512 ? 16 : (maxcol <= 1024 ? 8 : (maxcol <= 2048 ? 4 : 0));
+      k->schur_groups = G; k->schur_maxcol = (int)maxcol;
+      if (G > 0) {
+        // per CSC entry (i, b): where the columns >= b start in row i (rows are visited with growing b: one cursor per row), its
+        // first term, and per term the slot of Q(a, b) inside column b (position map of the column's pattern)
+        std::vector<int64_t> seg_q(nnzJ), seg_t(nnzJ + 1, 0), cur(Jrp.begin(), Jrp.end() - 1);
+        int64_t nterms = 0;
+        for (int64_t bcol = 0; bcol < n; ++bcol)
+          for (int64_t p = Jp[bcol]; p < Jp[bcol + 1]; ++p) {
+            const int i = Ji[p];
+            seg_q[p] = cur[i]++;
+            seg_t[p] = nterms;
+            nterms += Jrp[i + 1] - seg_q[p];
+          }
+        seg_t[nnzJ] = nterms;
+        std::vector<uint16_t> tslot((size_t)nterms);
+        std::vector<int> pos(n, -1);
+        for (int64_t bcol = 0; bcol < n; ++bcol) {
+          for (int64_t e = Ap[bcol]; e < Ap[bcol + 1]; ++e) pos[Ai[e]] = (int)(e - Ap[bcol]);
+          for (int64_t p = Jp[bcol]; p < Jp[bcol + 1]; ++p) {
+            const int i = Ji[p];
+            for (int64_t q = seg_q[p]; q < Jrp[i + 1]; ++q) tslot[(size_t)(seg_t[p] + (q - seg_q[p]))] = (uint16_t)pos[Jrj[q]];
+          }
+        }
+        UPL(seg_q, seg_q); UPL(seg_t, seg_t); UPL(tslot, tslot); UPL(dAp64, Ap);
+      } else {
+        // contribution lists per Q entry (columns of Q too long for LDS: one thread per entry, k_assemble_schur)
+        std::vector<int64_t> qptr(k->nnzA + 1, 0);
+        for (int64_t i = 0; i < m; ++i)
+          for (int64_t p = Jrp[i]; p < Jrp[i + 1]; ++p)
+            for (int64_t q = Jrp[i]; q < Jrp[i + 1]; ++q)
+              if (Jrj[p] >= Jrj[q]) ++qptr[slot(Jrj[p], Jrj[q]) + 1];
+        for (int64_t e = 0; e < k->nnzA; ++e) qptr[e + 1] += qptr[e];
+        std::vector<int> qa(qptr[k->nnzA]), qb(qptr[k->nnzA]), qi(qptr[k->nnzA]);
+        std::vector<int64_t> fill(qptr.begin(), qptr.end() - 1);
+        for (int64_t i = 0; i < m; ++i)   // rows ascending: fixed summation order
+          for (int64_t p = Jrp[i]; p < Jrp[i + 1]; ++p)
+            for (int64_t q = Jrp[i]; q < Jrp[i + 1]; ++q)
+              if (Jrj[p] >= Jrj[q]) {
+                const int64_t t = fill[slot(Jrj[p], Jrj[q])]++;
+                // the reference forms (J_T * D) * J: entry (a, b) sums J[i][a] * d_i * J[i][b] over the rows i
+                qa[t] = (int)Jrmap[p]; qb[t] = (int)Jrmap[q]; qi[t] = (int)i;
+              }
+        UPL(qptr, qptr); UPL(qa, qa); UPL(qb, qb); UPL(qi, qi);
+      }
+      UPL(qh, qh); UPL(diagA, diagA);
       k->Ap = Ap; k->Ai = Ai;
     }
 #undef UPL
@@ -755,7 +823,13 @@ int okkt_kkt_form_system(okkt_kkt_handle k, const double* H_nzval, const double*
     if (tot) hipLaunchKernelGGL(k_assemble_aug, grid1(tot), dim3(256), 0, st, k->nnzH, k->nnzJ, k->n, k->m, k->Hx, k->Jx, k->s, k->y, k->mapH, k->mapJ, k->diagA, k->Avals);
     SEG_LAUNCH(k_schur_diag_seg, k->lprJc, k->n, st, k->n, k->Jp, k->Ji, k->Jx, k->sig, k->Hdiag, k->schur_diag);
   } else {
-    if (k->nnzA) hipLaunchKernelGGL(k_assemble_schur, grid1(k->nnzA), dim3(256), 0, st, k->nnzA, k->qptr, k->qa, k->qb, k->qi, k->qh, k->Jx, k->sig, k->Hx, k->Avals);
+    if (k->nnzA && k->schur_groups > 0) {
+      const int G = k->schur_groups;
+      hipLaunchKernelGGL(k_assemble_schur_lds, dim3((unsigned)((k->n + G - 1) / G)), dim3(16 * G), (size_t)G * k->schur_maxcol * sizeof(double), st, k->n, G,
+                         k->schur_maxcol, k->dAp64, k->Jp, k->Ji, k->Jx, k->Jrp, k->Jcsr, k->seg_q, k->seg_t, k->tslot, k->sig, k->qh, k->Hx, k->Avals);
+    } else if (k->nnzA) {
+      hipLaunchKernelGGL(k_assemble_schur, grid1(k->nnzA), dim3(256), 0, st, k->nnzA, k->qptr, k->qa, k->qb, k->qi, k->qh, k->Jx, k->sig, k->Hx, k->Avals);
+    }
     if (k->n) hipLaunchKernelGGL(k_gather, grid1(k->n), dim3(256), 0, st, k->n, k->diagA, k->Avals, k->schur_diag);   // schur_diag = diag(Q), schur.jl:56
   }
   const size_t e2 = k->tm_form.mark(st);

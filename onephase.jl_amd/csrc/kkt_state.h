@@ -30,6 +30,11 @@ struct okkt_kkt_s {
   int64_t *mapH = nullptr, *mapJ = nullptr, *diagA = nullptr;   // symmetric: value slots in A
   int64_t *qptr = nullptr, *qh = nullptr;                        // schur: contributions per Q entry
   int *qa = nullptr, *qb = nullptr, *qi = nullptr;
+  // schur, LDS-staged assembly: per CSC entry (row i, column b) of J the start of row i's CSR segment with columns >= b and
+  // its first term; per term the slot of its Q entry inside column b (16 bits); groups of 16 lanes own one column of Q
+  int64_t *seg_q = nullptr, *seg_t = nullptr, *dAp64 = nullptr;
+  uint16_t* tslot = nullptr;
+  int schur_groups = 0, schur_maxcol = 0;
   double* schur_diag = nullptr;
   // work vectors
   double *rD = nullptr, *rP = nullptr, *rC = nullptr, *dx = nullptr, *dy = nullptr, *ds = nullptr;

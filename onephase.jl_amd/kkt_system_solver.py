@@ -87,6 +87,10 @@ class Class_kkt_solver_options:   # parameters.jl:4-46 (the entries the path rea
     kkt_solver_type: str = "schur"
     linear_solver_type: str = "HIP"
     ItRefine_Num: int = 3
+    # parameters.jl:6,21 (default false).  With true, solver_schur_rhs keeps dir_x in BigFloat (schur.jl:154-155) and then calls
+    # hess_product(fit, dir_x) (schur.jl:167), whose only method takes vector::Array{Float64,1} (eval.jl:232): a MethodError.
+    # The option cannot run in the reference; the mirror keeps the field and fails the same way instead of inventing a meaning.
+    ItRefine_BigFloat: bool = False
     kkt_system_rescale: str = "none"    # parameters.jl:24 (:none | :u_only | :u_and_x), clever_symmetric only
 
 
@@ -300,6 +304,9 @@ class HIP_KKT_solver:
     def compute_direction_b(self, timer=None):
         if self.ready != "factored":
             raise OkktError("kkt solver not ready to compute direction!")
+        if self.pars.kkt.ItRefine_BigFloat and self.kind in ("schur", "schur_direct"):
+            raise OkktError("MethodError: no method matching hess_product(::Class_iterate, ::Array{BigFloat,1}) "
+                            "(schur.jl:167 with pars.kkt.ItRefine_BigFloat = true; eval.jl:232 only accepts Array{Float64,1})")
         n, m = self.factor_it.dim(), self.factor_it.ncon()
         dx, dy, ds = np.zeros(n), np.zeros(m), np.zeros(m)
         err = L.OkktKktError()

@@ -132,6 +132,7 @@ class Direction:  # Class_point as a direction
 @dataclass
 class KKTPars:
     ItRefine_Num: int = 3          # parameters.jl:20
+    ItRefine_BigFloat: bool = False   # parameters.jl:21; true cannot run in the reference: schur.jl:167 -> hess_product(::Array{BigFloat}) has no method (eval.jl:232)
     delta_start: float = 1e-6      # parameters.jl:147-158
     delta_min: float = 1e-12
     delta_max: float = 1e50
@@ -248,6 +249,8 @@ class Schur_KKT_solver(_KKTBase):
 
     def solver_schur_rhs(self, schur_rhs):  # schur.jl:131-182
         fit = self.factor_it
+        if self.pars.ItRefine_BigFloat:
+            raise TypeError("MethodError: no method matching hess_product(::Class_iterate, ::Array{BigFloat,1})")   # schur.jl:154-167, eval.jl:232
         S_vec = fit.y / fit.s
         res_old = schur_rhs
         dir_x = np.zeros(fit.dim())

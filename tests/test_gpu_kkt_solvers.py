@@ -106,6 +106,13 @@ def test_state_machine_errors(golden):
         k.factor_b(1e-8, 1.0)        # delta_s != 0: "Not implemented"
     with pytest.raises(OkktError):
         KS.HIP_KKT_solver("clever")
+    # pars.kkt.ItRefine_BigFloat = true is a MethodError in the reference (schur.jl:167 -> eval.jl:232): same failure here
+    pars = KS.Class_parameters(); pars.kkt.ItRefine_BigFloat = True
+    kb = KS.HIP_KKT_solver("schur", pars)
+    kb.initialize_b(it); kb.form_system_b(it); kb.factor_b(1e-8); kb.kkt_associate_rhs_b(it, KS.Reduct_affine())
+    with pytest.raises(OkktError):
+        kb.compute_direction_b()
+    kb.finalize_b()
 
 
 def synth_iterate(prob, Iterate, seed=0):

@@ -320,3 +320,15 @@ def test_multifrontal_baseline_matches_simplicial_oracle(name, seed, threads):
     assert o1.ls_factor_b(Q, n, 0) == o2.ls_factor_b(Q, n, 0) == 1
     b = rng.normal(size=n)
     assert np.max(np.abs(o1.ls_solve(b) - o2.ls_solve(b))) <= 1e-10 * np.max(np.abs(o1.ls_solve(b)))
+
+
+def test_itrefine_bigfloat_is_a_method_error_in_the_reference(golden):
+    # parameters.jl:21 ItRefine_BigFloat: solver_schur_rhs converts dir_x to BigFloat (schur.jl:154-155) and then calls
+    # hess_product(fit, dir_x) (schur.jl:167); the only method is hess_product(it, vector::Array{Float64,1}) (eval.jl:232), so the
+    # option throws a MethodError in the reference.  The restatement (and the product's mirror) fail the same way.
+    rec = golden["toy_lps"][0]
+    it = iterate_from_record(rec, KO.Iterate)
+    k = KO.pick_KKT_solver("schur", pars=KO.KKTPars(ItRefine_BigFloat=True))
+    k.initialize_b(it); k.form_system_b(it); k.factor_b(rec["delta"]); k.kkt_associate_rhs_b(it, KO.Reduct_affine())
+    with pytest.raises(TypeError):
+        k.compute_direction_b()
