@@ -579,6 +579,16 @@ int okkt_get_profile(okkt_handle h, int64_t* n_launches, double* total_ms, doubl
       return solver_set_error(h, OKKT_ERR_HIP, "hipEventElapsedTime failed");
     ms += t;
     fl += h->N.prof_flops[i];
+    if (getenv("OKKT_DEBUG_SYRK_LOG")) fprintf(stderr, "syrk launch %3zu: %9.1f us %8.3f GFLOP %6.1f TFLOP/s\n", i, t * 1e3, h->N.prof_flops[i] * 1e-9, h->N.prof_flops[i] / (t * 1e-3) * 1e-12);
+  }
+  if (getenv("OKKT_DEBUG_SYRK_LOG") && h->N.d.zero_page) {   // phase ticks of k_big_syrk<16, .> (OKKT_DEBUG_SYRK=96), 10 ns each
+    unsigned long long T[8];
+    if (hipMemcpy(T, h->N.d.zero_page + 256, sizeof(T), hipMemcpyDeviceToHost) == hipSuccess && T[0] > 0) {
+      fprintf(stderr, "syrk workgroups %llu: per workgroup (us) start->first chunk ready %.2f, main loop %.2f (%.3f per 16-column chunk), store issue %.2f, store drain %.2f\n",
+              T[0], T[1] * 0.01 / T[0], T[2] * 0.01 / T[0], T[2] * 0.01 / (double)T[5], T[3] * 0.01 / T[0], T[4] * 0.01 / T[0]);
+      fprintf(stderr, "   of the start: scalar set-up %.2f us, C tile loaded (if waited for) %.2f us\n", T[6] * 0.01 / T[0], T[7] * 0.01 / T[0]);
+      (void)hipMemset(h->N.d.zero_page + 256, 0, sizeof(T));
+    }
   }
   *n_launches = (int64_t)n;
   *total_ms = ms;

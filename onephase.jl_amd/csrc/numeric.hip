@@ -879,6 +879,9 @@ constexpr int kSyrkStages = OKKT_SYRK_STAGES;  // ring slots (KC * stages = 32 k
 #ifndef OKKT_SYRK_LD
 #define OKKT_SYRK_LD 144
 #endif
+#ifndef OKKT_SYRK_NT
+#define OKKT_SYRK_NT 0     // bit 0: non-temporal C loads, bit 1: non-temporal C stores
+#endif
 constexpr int kSyrkLd = OKKT_SYRK_LD;   // leading dimension of the LDS panels (doubles)
 constexpr size_t syrk_lds_bytes(int stages) { return (size_t)stages * 2 * kSyrkKC * kSyrkLd * sizeof(double); }
 typedef __attribute__((address_space(3))) void lds_void_t;
@@ -905,6 +908,8 @@ __global__ __launch_bounds__(kSyrkNW * 64, kSyrkNW / 2) void k_big_syrk(DevPlan 
   constexpr int NCG = WCW / 4;          // 4-column groups per wave
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  long long tk0 = 0, tk1 = 0, tk2 = 0, tk3 = 0, tkA = 0, tkB = 0;
+  if constexpr (DBG & 16) tk0 = wall_clock64();
   const int s = list[blockIdx.y];
   if (stop_requested_wg(P)) return;
   const int col0 = P.sn_col0[s];
@@ -966,6 +971,7 @@ __global__ __launch_bounds__(kSyrkNW * 64, kSyrkNW / 2) void k_big_syrk(DevPlan 
     }
   };
 
+  if constexpr (DBG & 16) { tkA = wall_clock64(); }
   double acc[NCG][4];  // [column group of 4][row block of 16]
   // accumulators start from C (guarded; lanes outside the front or above the diagonal hold zeros)
   // Loads are unconditional on clamped (always valid) addresses and selected afterwards: a load under
@@ -973,6 +979,7 @@ __global__ __launch_bounds__(kSyrkNW * 64, kSyrkNW / 2) void k_big_syrk(DevPlan 
   // Row map of an accumulator: (l15, rb) <-> row 2*l15 + (rb & 1) + 32*(rb >> 1) of the wave's 64 rows, so
   // that a lane's (rb, rb+1) pair is 16 contiguous bytes of C: 16-byte loads/stores, 256-byte segments.
   typedef double d2_t __attribute__((ext_vector_type(2)));
+  typedef double d2u_t __attribute__((ext_vector_type(2), aligned(8)));
 #pragma unroll
   for (int cg = 0; cg < NCG; ++cg) {
     const int c = cbase + cg * 4 + l4;
@@ -983,7 +990,13 @@ __global__ __launch_bounds__(kSyrkNW * 64, kSyrkNW / 2) void k_big_syrk(DevPlan 
       const int rcl = min(r, f - 2);            // clamped pair start: always in bounds, no branch
       const int shift = r - rcl;                // 0 in the interior, 1 when r is the last row, >= 2 outside
       d2_t v = (d2_t){0.0, 0.0};
-      if constexpr (!(DBG & 1)) __builtin_memcpy(&v, colp + rcl, 16);
+      if constexpr (!(DBG & 1)) {
+#if OKKT_SYRK_NT & 1
+        v = __builtin_nontemporal_load((const d2u_t*)(colp + rcl));
+#else
+        __builtin_memcpy(&v, colp + rcl, 16);
+#endif
+      }
       const double e0 = shift == 0 ? v[0] : v[1];
       acc[cg][2 * h] = keep_f64(e0, shift <= 1 && c < climit && r >= c);
       acc[cg][2 * h + 1] = keep_f64(v[1], shift == 0 && c < climit && r + 1 >= c);
@@ -992,6 +1005,7 @@ __global__ __launch_bounds__(kSyrkNW * 64, kSyrkNW / 2) void k_big_syrk(DevPlan 
   // the LDS-DMAs go out AFTER the C loads: with an LDS-DMA in flight hipcc waits vmcnt(0) after every
   // ordinary load (64 serial round trips); in this order it issues all 64 back to back
   asm volatile("" ::: "memory");
+  if constexpr (DBG & 32) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); tkB = wall_clock64(); }
   if constexpr (!(DBG & 8)) {
 #pragma unroll
     for (int q = 0; q < STAGES - 1; ++q) if (q < nchunk) issue(q);
@@ -1006,6 +1020,7 @@ __global__ __launch_bounds__(kSyrkNW * 64, kSyrkNW / 2) void k_big_syrk(DevPlan 
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
+    if constexpr (DBG & 16) { if (ch == 0) tk1 = wall_clock64(); }   // C tile and the first operand chunk have landed
     // the slot written next was last read one iteration ago; everyone is past that barrier
     if constexpr (!(DBG & 8)) { if (ch + STAGES - 1 < nchunk) issue(ch + STAGES - 1); }
     if (active && !(DBG & 2)) {
@@ -1032,6 +1047,7 @@ __global__ __launch_bounds__(kSyrkNW * 64, kSyrkNW / 2) void k_big_syrk(DevPlan 
       }
     }
   }
+  if constexpr (DBG & 16) tk2 = wall_clock64();
   if (!active) return;
   if constexpr (DBG & 4) { double t = 0; for (int a = 0; a < NCG; ++a) for (int b = 0; b < 4; ++b) t += acc[a][b]; if (t == 1.2345e-300) F[0] = t; return; }
 #pragma unroll
@@ -1044,11 +1060,26 @@ __global__ __launch_bounds__(kSyrkNW * 64, kSyrkNW / 2) void k_big_syrk(DevPlan 
       const int r = rbase + 2 * l15 + 32 * h;
       if (r + 1 < f && r >= c) {
         const d2_t v = (d2_t){acc[cg][2 * h], acc[cg][2 * h + 1]};
+#if OKKT_SYRK_NT & 2
+        __builtin_nontemporal_store(v, (d2u_t*)(colp + r));
+#else
         __builtin_memcpy(colp + r, &v, 16);
+#endif
       } else {
         if (r < f && r >= c) colp[r] = acc[cg][2 * h];
         if (r + 1 < f && r + 1 >= c) colp[r + 1] = acc[cg][2 * h + 1];
       }
+    }
+  }
+  if constexpr (DBG & 16) {   // ticks of 10 ns: prologue + C load issue, main loop, store issue, store completion; per wave 0 of a workgroup
+    tk3 = wall_clock64();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const long long tk4 = wall_clock64();
+    if (tid == 0) {
+      unsigned long long* T = (unsigned long long*)(P.zero_page + 256);
+      atomicAdd(&T[0], 1ull); atomicAdd(&T[1], (unsigned long long)(tk1 - tk0)); atomicAdd(&T[2], (unsigned long long)(tk2 - tk1));
+      atomicAdd(&T[3], (unsigned long long)(tk3 - tk2)); atomicAdd(&T[4], (unsigned long long)(tk4 - tk3)); atomicAdd(&T[5], (unsigned long long)nchunk);
+      atomicAdd(&T[6], (unsigned long long)(tkA - tk0)); if constexpr (DBG & 32) atomicAdd(&T[7], (unsigned long long)(tkB - tkA));
     }
   }
 }
@@ -1371,7 +1402,7 @@ std::string numeric_setup(const Symbolic& S, const SymbolicOptions& opts, hipStr
   if (!(e = dalloc(N, (size_t)S.sum_r * kMaxRhs, &d.cv, true)).empty()) return e;
   if (!(e = dalloc(N, (size_t)wtotal + 512, &d.wbuf, true)).empty()) return e;
   if (!(e = dalloc(N, (size_t)kCountSlots * kCountStride, &d.counters, true)).empty()) return e;
-  if (!(e = dalloc(N, (size_t)256, &d.zero_page, true)).empty()) return e;
+  if (!(e = dalloc(N, (size_t)512, &d.zero_page, true)).empty()) return e;   // [256, 512): debug tick counters (OKKT_DEBUG_SYRK=96)
   if (!(e = dalloc(N, (size_t)S.nnz_in, &N.vals_owned, false)).empty()) return e;
   if (!(e = solve_setup(S, N)).empty()) return e;
   // kernels that may want more than 64 KiB of dynamic LDS
@@ -1383,7 +1414,7 @@ std::string numeric_setup(const Symbolic& S, const SymbolicOptions& opts, hipStr
   OKKT_HIP_TRY(hipFuncSetAttribute((const void*)k_big_trsm<4>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds));
   for (const void* fn : {(const void*)k_big_syrk<0, kSyrkTrail>, (const void*)k_big_syrk<0, kSyrkPanel>, (const void*)k_big_syrk<0, kSyrkAhead>,
                          (const void*)k_big_syrk<1, kSyrkTrail>, (const void*)k_big_syrk<2, kSyrkTrail>, (const void*)k_big_syrk<5, kSyrkTrail>,
-                         (const void*)k_big_syrk<13, kSyrkTrail>})
+                         (const void*)k_big_syrk<13, kSyrkTrail>, (const void*)k_big_syrk<16, kSyrkTrail>, (const void*)k_big_syrk<48, kSyrkTrail>})
     OKKT_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)syrk_lds_bytes(kSyrkStages)));
   return "";
 }
@@ -1563,6 +1594,8 @@ std::string numeric_factor_enqueue(Numeric& N, const double* d_vals, double tol,
           case 82: OKKT_SYRK(2, kSyrkTrail); break;    // no MFMA
           case 85: OKKT_SYRK(5, kSyrkTrail); break;    // no C load, no store
           case 93: OKKT_SYRK(13, kSyrkTrail); break;   // MFMA + LDS reads only
+          case 96: OKKT_SYRK(16, kSyrkTrail); break;   // correct results + per-workgroup phase ticks (printed by okkt_get_profile under OKKT_DEBUG_SYRK_LOG)
+          case 112: OKKT_SYRK(48, kSyrkTrail); break;  // the same with the C tile waited for before the first operand chunk is requested
           default: OKKT_SYRK(0, kSyrkTrail); break;
         }
 #undef OKKT_SYRK
