@@ -75,6 +75,8 @@ class OkktStats(C.Structure):
         ("last_solve_ms", C.c_double),
         ("pattern_hash", C.c_uint64),
         ("n_analyze_calls", C.c_int64),
+        ("ordering_used", C.c_int64),
+        ("critical_pivots", C.c_int64),
     ]
 
     def as_dict(self):

@@ -414,6 +414,8 @@ int okkt_get_stats(okkt_handle h, okkt_stats* out) {
   out->last_solve_ms = h->last_solve_ms;
   out->pattern_hash = S.pattern_hash;
   out->n_analyze_calls = h->n_analyze_calls;
+  out->ordering_used = h->S.ordering_used;
+  out->critical_pivots = h->S.critical_pivots;
   return OKKT_OK;
 }
 

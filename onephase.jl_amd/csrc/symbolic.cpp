@@ -33,9 +33,9 @@ inline int64_t trapezoid(int64_t f, int64_t k) { return f * k - k * (k - 1) / 2;
 
 }  // namespace
 
-std::string analyze_pattern(int64_t n64, const int64_t* colptr, const int64_t* rowval,
-                            int index_base, const SymbolicOptions& opts,
-                            const int64_t* user_perm, Symbolic& S) {
+static std::string analyze_one(int64_t n64, const int64_t* colptr, const int64_t* rowval,
+                               int index_base, const SymbolicOptions& opts,
+                               const int64_t* user_perm, Symbolic& S) {
   if (n64 < 0 || n64 > 0x7ffffff0) return "matrix order out of range";
   if (index_base != 0 && index_base != 1) return "index_base must be 0 or 1";
   const int n = (int)n64;
@@ -111,8 +111,11 @@ std::string analyze_pattern(int64_t n64, const int64_t* colptr, const int64_t* r
   lap("graph");
   // ---- ordering
   std::vector<int> order;
-  if (opts.ordering == 0) {
+  if (opts.ordering == 0 || opts.ordering == 3) {
     amd_order(n, gp, gi, order);
+  } else if (opts.ordering == 4) {
+    level_nd_order(n, gp, gi, opts.nd_leaf, order);
+    S.ordering_used = 4;
   } else if (opts.ordering == 1) {
     order.resize(n);
     std::iota(order.begin(), order.end(), 0);
@@ -508,7 +511,47 @@ std::string analyze_pattern(int64_t n64, const int64_t* colptr, const int64_t* r
     std::vector<int> fill(S.level_ptr.begin(), S.level_ptr.end() - 1);
     for (int s = 0; s < ns; ++s) S.level_sn[fill[S.sn_level[s]]++] = s;
   }
+  // pivots on the longest leaf-to-root path: the length of the dependency chain a factorisation cannot shorten
+  {
+    std::vector<int64_t> cp(ns, 0);
+    S.critical_pivots = 0;
+    for (int s = 0; s < ns; ++s) {          // postorder: children before parents
+      cp[s] += S.sn_col0[s + 1] - S.sn_col0[s];
+      S.critical_pivots = std::max(S.critical_pivots, cp[s]);
+      const int p = S.sn_parent[s];
+      if (p >= 0) cp[p] = std::max(cp[p], cp[s]);
+    }
+  }
+  if (opts.ordering == 1 || opts.ordering == 2) S.ordering_used = opts.ordering;
   return "";
+}
+
+// ordering = 0: AMD first.  When its elimination tree is (close to) a path of small fronts -- a banded KKT system, BASELINE
+// config 2 -- the factorisation would be one dependent pivot after the other: the analysis is redone with level-structure
+// nested dissection (nd.cpp) and that plan is kept when its dependency chain is at least three times shorter and the extra
+// fill stays small in absolute terms (such systems carry a few MFLOP; the chain length, not the flop count, is their cost).
+std::string analyze_pattern(int64_t n64, const int64_t* colptr, const int64_t* rowval,
+                            int index_base, const SymbolicOptions& opts,
+                            const int64_t* user_perm, Symbolic& S) {
+  std::string e = analyze_one(n64, colptr, rowval, index_base, opts, user_perm, S);
+  if (!e.empty() || opts.ordering != 0) return e;
+  const bool path_like = S.n >= 1024 && S.max_front <= 256 && S.critical_pivots * 5 >= S.n;
+  if (!path_like) return e;
+  SymbolicOptions o2 = opts;
+  o2.ordering = 4;
+  // no amalgamation beyond 4 columns: merging a child into its parent puts the child's pivots on the parent's level and
+  // lengthens the dependency chain (S-C2, N_h = 20000: 0.37 ms with width 4, 0.56 with 16, 0.60 with 64; AMD path: 70.8 ms)
+  o2.relax_always = o2.relax_small = o2.relax_mid = 4;
+  if (getenv("OKKT_ND_LEAF")) o2.nd_leaf = atoi(getenv("OKKT_ND_LEAF"));
+  if (getenv("OKKT_ND_RELAX")) o2.relax_always = o2.relax_small = o2.relax_mid = atoi(getenv("OKKT_ND_RELAX"));
+  Symbolic S2;
+  if (!analyze_one(n64, colptr, rowval, index_base, o2, user_perm, S2).empty()) return e;
+  const bool dbg = getenv("OKKT_DEBUG_ANALYZE") != nullptr;
+  if (dbg)
+    fprintf(stderr, "okkt: analyze path-like tree: AMD chain %ld of %ld pivots, flops %.3g, max front %d; nested dissection chain %ld, flops %.3g, max front %d\n",
+            (long)S.critical_pivots, (long)S.n, S.flops_stored, S.max_front, (long)S2.critical_pivots, S2.flops_stored, S2.max_front);
+  if (S2.critical_pivots * 3 <= S.critical_pivots && S2.flops_stored <= 20.0 * S.flops_stored + 1e8 && S2.max_front <= 512) S = std::move(S2);
+  return e;
 }
 
 

@@ -16,8 +16,13 @@ namespace okkt {
 void amd_order(int n, const std::vector<int64_t>& ap, const std::vector<int>& ai,
                std::vector<int>& order);
 
+// level-structure nested dissection (nd.cpp): the parallel ordering for path-like graphs
+void level_nd_order(int n, const std::vector<int64_t>& gp, const std::vector<int>& gi, int leaf, std::vector<int>& order);
+
 struct SymbolicOptions {
-  int ordering = 0;        // 0 = AMD, 1 = natural, 2 = user permutation
+  int ordering = 0;        // 0 = AMD, switching to level-structure nested dissection when the AMD tree is a path of small
+                           // fronts (see analyze_pattern); 1 = natural, 2 = user permutation, 3 = AMD always, 4 = nested dissection always
+  int nd_leaf = 48;        // nested dissection stops at pieces of this many nodes
   int relax_always = 64;   // merge a child into its parent when the merged width <= this (one LDS-resident front instead of a chain of launches / loop trips)
   int relax_small = 128;   // ... or when width <= relax_small and zero fraction < relax_small_frac (S-C3: 107 -> 91 big fronts, factor 5.55 -> 5.2 ms)
   double relax_small_frac = 0.5;
@@ -80,6 +85,8 @@ struct Symbolic {
   int64_t arena_doubles = 0; // sum_s f^2
   int64_t sum_r = 0;
   int max_front = 0;
+  int ordering_used = 0;     // 0 = AMD, 1 = natural, 2 = user, 4 = level-structure nested dissection
+  int64_t critical_pivots = 0;   // pivots on the longest leaf-to-root path of the supernodal tree (n for a path)
   uint64_t pattern_hash = 0;
 
   // subtree-to-GPU partition (multi-GPU row of SURVEY 8e): owner part of every supernode, -1 = "top"

@@ -1,0 +1,64 @@
+"""one row per BASELINE configuration -- sizes, GPU factor + solve device times, the CPU port on one
+thread and on the best of {all, 64, 32} threads (same box, same permutation).  Run on the GPU box; writes JSON + markdown."""
+import json, os, sys, time
+import numpy as np
+sys.path.insert(0, ".")
+import oracle
+from onephase_jl_amd import synth
+from onephase_jl_amd.linear_system_solvers import finalize_b, initialize_b, linear_solver_HIP
+
+out = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/results_table.json"
+cores = os.cpu_count() or 1
+rows = []
+cfgs = [("S-metric", lambda: synth.make_config("S-metric", seed=0)),
+        ("S-C3", lambda: synth.make_config("S-C3", seed=0)),
+        ("S-C2 (CHAIN stand-in, N_h = 400)", lambda: synth.hanging_chain(N_h=400, seed=0)),
+        ("S-C2 at N_h = 20000", lambda: synth.hanging_chain(N_h=20000, seed=0)),
+        ("S-C4 (infeasible-LP stand-in)", lambda: synth.infeasible_lp(seed=0)),
+        ("S-C5 (block-angular x 8)", lambda: synth.make_config("S-C5", seed=0))]
+for name, gen in cfgs:
+    prob = gen()
+    n, m = prob["n"], prob["m"]
+    K = synth.augmented_matrix(prob, delta=1e-8 if name.startswith("S-C2") or name.startswith("S-C4") else 1e-8)
+    if name.startswith("S-C2") or name.startswith("S-C4"):   # indefinite H / singular K(0): the shift the delta loop ends with
+        K = synth.augmented_matrix(prob, delta=float(prob.get("delta_ok", 1.0)))
+    h = linear_solver_HIP("symmetric"); initialize_b(h)
+    rc = h.ls_factor_b(K, n, m)
+    b = np.random.default_rng(0).normal(size=n + m)
+    fm, sm = [], []
+    for _ in range(5):
+        rc = h.ls_factor_b(K, n, m); x = h.ls_solve(b)
+        st = h.stats(); fm.append(st["last_factor_ms"]); sm.append(st["last_solve_ms"])
+    st = h.stats()
+    perm = h.perm()
+    row = {"config": name, "n": n, "m": m, "nnz_tril_K": int(st["nnz_lower"]), "nnz_L": int(st["nnzL"]), "factor_flops": float(st["flops_exact"]),
+           "rc": int(rc), "gpu_factor_ms": float(np.median(fm)), "gpu_solve_ms": float(np.median(sm)), "analyze_s": float(st["analyze_seconds"])}
+    row["gpu_fs_per_s"] = 1000.0 / (row["gpu_factor_ms"] + row["gpu_solve_ms"])
+    finalize_b(h)
+    def cpu(nth):
+        s = oracle.linear_solver_ORACLE_MF("symmetric", perm=perm, nthreads=nth)
+        s._analyze(K)
+        t0 = time.perf_counter(); r = s.ls_factor_b(K, n, m); xs = s.ls_solve(b); dt = time.perf_counter() - t0
+        return dt, r, xs
+    if name != "S-metric":
+        dt1, r1, x1 = cpu(1)
+        row["cpu_1thr_s"] = dt1
+        row["cpu_agrees"] = bool(r1 == rc and np.max(np.abs(x1 - x)) <= 1e-6 * max(1.0, np.max(np.abs(x))))
+    best = None
+    for nth in sorted({cores, min(cores, 64), min(cores, 32)}, reverse=True):
+        dt, r, xs = cpu(nth)
+        if best is None or dt < best[0]: best = (dt, nth)
+    row["cpu_best_s"], row["cpu_best_threads"] = best
+    rows.append(row)
+    print(json.dumps(row), flush=True)
+# S-metric on one thread: scaled from S-C3 by the flop ratio (a direct run takes minutes)
+sm_, c3 = rows[0], rows[1]
+sm_["cpu_1thr_s"] = c3["cpu_1thr_s"] * sm_["factor_flops"] / c3["factor_flops"]
+sm_["cpu_1thr_scaled"] = True
+json.dump({"host_cores": cores, "rows": rows}, open(out, "w"), indent=1)
+print("| Config | n | m | nnz(tril K) | nnz(L) | factor flops | GPU factor / solve (ms) | factor+solve/s (GPU, 1 MI355X) | CPU port 1 thread (s) | CPU port best (s, threads) | speed-up vs 1 thread / best |")
+print("|---|---|---|---|---|---|---|---|---|---|---|")
+for r in rows:
+    print(f"| {r['config']} | {r['n']} | {r['m']} | {r['nnz_tril_K']} | {r['nnz_L']} | {r['factor_flops']:.3g} | {r['gpu_factor_ms']:.3f} / {r['gpu_solve_ms']:.3f} | {r['gpu_fs_per_s']:.1f} | "
+          f"{r['cpu_1thr_s']:.3f}{' (scaled)' if r.get('cpu_1thr_scaled') else ''} | {r['cpu_best_s']:.3f} ({r['cpu_best_threads']}) | "
+          f"{r['cpu_1thr_s'] * r['gpu_fs_per_s']:.0f}× / {r['cpu_best_s'] * r['gpu_fs_per_s']:.0f}× |")

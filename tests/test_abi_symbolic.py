@@ -179,3 +179,40 @@ def test_block_angular_has_independent_subtrees():
     for j, p in enumerate(par):
         if p >= 0 and blk[j] >= 0 and blk[p] >= 0:
             assert blk[j] == blk[p]
+
+
+def test_banded_kkt_switches_to_nested_dissection():
+    # BASELINE config 2 stand-in: AMD eliminates a band from its ends (a path-shaped elimination tree, one dependent pivot
+    # after the other); ordering = 0 notices and redoes the analysis with level-structure nested dissection.  The pivot
+    # order is free for the static-pivot LDL^T: the oracle with that permutation finds the same inertia and solution.
+    prob = synth.hanging_chain(N_h=400, seed=0)
+    n, m = prob["n"], prob["m"]
+    K = synth.augmented_matrix(prob, delta=1.0)
+    amd = host_solver(ordering=3)
+    amd.analyze(K)
+    auto = host_solver(ordering=0)
+    auto.analyze(K)
+    sa, sn = amd.stats(), auto.stats()
+    assert sa["ordering_used"] == 0 and sa["critical_pivots"] >= 0.9 * (n + m)          # AMD: a path
+    assert sn["ordering_used"] == 4 and sn["critical_pivots"] * 10 <= sa["critical_pivots"]
+    assert sn["nnzL"] <= 3 * sa["nnzL"] and sn["max_front"] <= 128
+    perm = auto.perm()
+    assert sorted(perm.tolist()) == list(range(n + m))
+    b = np.random.default_rng(0).normal(size=n + m)
+    xs = []
+    for p in (perm, amd.perm()):
+        o = oracle.linear_solver_ORACLE("symmetric", perm=p)
+        assert o.ls_factor_b(K, n, m) == 1
+        xs.append(o.ls_solve(b))
+    assert np.max(np.abs(xs[0] - xs[1])) <= 1e-9 * np.max(np.abs(xs[1]))
+    # forced nested dissection on a general sparse system is still a valid ordering; the automatic rule leaves AMD in place
+    prob2 = synth.make_config("S-small", seed=0)
+    K2 = synth.augmented_matrix(prob2, delta=1e-7)
+    gen = host_solver(ordering=0)
+    gen.analyze(K2)
+    assert gen.stats()["ordering_used"] == 0
+    nd = host_solver(ordering=4)
+    nd.analyze(K2)
+    assert nd.stats()["ordering_used"] == 4 and sorted(nd.perm().tolist()) == list(range(prob2["n"] + prob2["m"]))
+    o = oracle.linear_solver_ORACLE("symmetric", perm=nd.perm())
+    assert o.ls_factor_b(K2, prob2["n"], prob2["m"]) == 1

@@ -60,3 +60,29 @@ def test_chain_has_only_small_fronts():
     st = k.linear_solver_stats()
     assert st["max_front"] <= 128 and st["n_big_fronts"] == 0, st["max_front"]
     k.finalize_b()
+
+
+def test_chain_nested_dissection_matches_amd_order_on_the_device():
+    # the same banded system factored with the path-shaped AMD tree (ordering = 3) and with the automatic choice (nested
+    # dissection): equal inertia, solutions equal to fp64 accuracy, and the oracle agrees with both
+    import oracle
+    from onephase_jl_amd.linear_system_solvers import finalize_b, initialize_b, linear_solver_HIP
+    prob = synth.hanging_chain(N_h=2000, seed=1)
+    n, m = prob["n"], prob["m"]
+    K = synth.augmented_matrix(prob, delta=1.0)
+    b = np.random.default_rng(3).normal(size=(n + m, 2))
+    out = {}
+    for ordering in (3, 0):
+        h = linear_solver_HIP("symmetric", ordering=ordering)
+        initialize_b(h)
+        assert h.ls_factor_b(K, n, m) == 1
+        st = h.stats()
+        out[ordering] = (h.inertia, np.column_stack([h.ls_solve(b[:, 0]), h.ls_solve(b[:, 1])]), st["ordering_used"], st["critical_pivots"], h.perm())
+        finalize_b(h)
+    assert out[3][2] == 0 and out[0][2] == 4 and out[0][3] * 10 <= out[3][3]
+    assert out[3][0] == out[0][0]
+    assert np.max(np.abs(out[3][1] - out[0][1])) <= 1e-9 * np.max(np.abs(out[3][1]))
+    o = oracle.linear_solver_ORACLE("symmetric", perm=out[0][4])
+    assert o.ls_factor_b(K, n, m) == 1
+    xo = np.column_stack([o.ls_solve(b[:, 0]), o.ls_solve(b[:, 1])])
+    assert np.max(np.abs(out[0][1] - xo)) <= 1e-9 * np.max(np.abs(xo))
