@@ -33,7 +33,21 @@ typedef double d4_t __attribute__((ext_vector_type(4)));
 typedef double d2_t __attribute__((ext_vector_type(2)));
 
 constexpr int kSB = kSolveBlock;        // columns of an explicitly inverted diagonal block
-constexpr int kCS = 4;                  // splits of a block product (partial vectors summed by the consumer)
+#ifndef OKKT_SOLVE_SPLITS
+#define OKKT_SOLVE_SPLITS 8
+#endif
+constexpr int kCS = OKKT_SOLVE_SPLITS;  // splits of a block product (partial vectors summed by the consumer in a fixed order)
+// sum of the kCS partial values p[0], p[kSB], ... (pairwise, fixed order)
+__device__ __forceinline__ double sum_splits(const double* p) {
+  double t[kCS];
+#pragma unroll
+  for (int q = 0; q < kCS; ++q) t[q] = p[(size_t)q * kSB];
+#pragma unroll
+  for (int w = 1; w < kCS; w *= 2)
+#pragma unroll
+    for (int q = 0; q + w < kCS; q += 2 * w) t[q] += t[q + w];
+  return t[0];
+}
 
 __device__ __forceinline__ int round128(int v) { return (v + 127) & ~127; }
 // block b of a front with k pivot columns: first column, width, leading dimension and storage offset of its inverse
@@ -513,8 +527,7 @@ __global__ __launch_bounds__(256) void k_fwd_upd(DevPlan P, const int* __restric
     const int pc = min(p, kb - 1);
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      const double* y4 = yp + (size_t)r * kCS * kSB + pc;
-      const double y = (y4[0] + y4[kSB]) + (y4[2 * kSB] + y4[3 * kSB]);
+      const double y = sum_splits(yp + (size_t)r * kCS * kSB + pc);
       yj[r * kSB + p] = p < kb ? y : 0.0;
       if (blockIdx.x == 0 && p < kb) P.zwork[(size_t)r * P.xw_stride + col0 + c0 + p] = y / P.dvals[col0 + c0 + p];
     }
@@ -728,8 +741,7 @@ __global__ __launch_bounds__(256) void k_bwd_upd(DevPlan P, const int* __restric
     const int pc = min(p, kb - 1);
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      const double* x4 = xp + (size_t)r * kCS * kSB + pc;
-      const double x = (x4[0] + x4[kSB]) + (x4[2 * kSB] + x4[3 * kSB]);
+      const double x = sum_splits(xp + (size_t)r * kCS * kSB + pc);
       sm[r * kSB + p] = p < kb ? x : 0.0;
     }
   }
