@@ -12,7 +12,7 @@ T="timeout -s KILL 240"
 prof() { d=$1; shift; mkdir -p $W/$d; $T rocprofv3 --kernel-trace --output-format csv -d $W/$d "$@" > $W/$d.log 2>&1; }
 
 # ---- kernel statistics
-$T rocprofv3 --kernel-trace --stats --output-format csv -d $W/bench_stats -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-kkt-level > $OUT/${R}_bench_under_rocprof.json 2> $W/bench_stats.log
+$T rocprofv3 --kernel-trace --stats --output-format csv -d $W/bench_stats -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-kkt-level --no-live-pmc > $OUT/${R}_bench_under_rocprof.json 2> $W/bench_stats.log
 cp $(find $W/bench_stats -name "*kernel_stats.csv" | head -1) $OUT/${R}_bench_kernel_stats.csv
 $T rocprofv3 --kernel-trace --stats --output-format csv -d $W/sc3_stats -- python3 scripts/probe.py S-C3 5 > $W/sc3_stats.log 2>&1
 cp $(find $W/sc3_stats -name "*kernel_stats.csv" | head -1) $OUT/${R}_sc3_kernel_stats.csv
