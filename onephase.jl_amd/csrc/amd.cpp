@@ -19,7 +19,10 @@
 
 #include <algorithm>
 #include <cmath>
+#include <chrono>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 namespace okkt {
@@ -104,7 +107,15 @@ void amd_order(int n, const std::vector<int64_t>& ap, const std::vector<int>& ai
   };
 
   int eliminated = 0;
+  const bool dbg = getenv("OKKT_DEBUG_AMD") != nullptr;
+  auto t_start = std::chrono::steady_clock::now();
+  int dbg_next = 0; int64_t work_scan = 0;
   while (eliminated < nleft) {
+    if (dbg && eliminated >= dbg_next) {
+      fprintf(stderr, "okkt: amd %8d of %d eliminated, %zu pivots, %.3f s, mindeg %d, scanned %ld\n", eliminated, nleft, pivots.size(),
+              std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count(), mindeg, (long)work_scan);
+      dbg_next += nleft / 20;
+    }
     // ---- pivot of least approximate degree
     while (mindeg < n && head[mindeg] < 0) ++mindeg;
     const int me = head[mindeg];
@@ -148,6 +159,7 @@ void amd_order(int n, const std::vector<int64_t>& ap, const std::vector<int>& ai
       const int i = iw[q];
       const int nvi = -nd[i].nv;
       const int64_t p0 = nd[i].pe;
+      work_scan += nd[i].len;
       for (int t = 0; t < nd[i].elen; ++t) {
         const int e = iw[p0 + t];
         const int64_t we = w[e];
