@@ -374,3 +374,50 @@ def test_batched_right_hand_sides(case):
             assert np.max(np.abs(X[r] - x1)) <= 1e-13 * max(1.0, np.max(np.abs(x1))), (nrhs, r)
             assert np.max(np.abs(Mfull @ X[r] - Bm[r])) <= 1e-7 * np.max(np.abs(Bm[r])) * max(1.0, np.max(np.abs(X[r])))
     finalize_b(h)
+
+
+def _kkt_from(J, n, rng, h_pattern=None):
+    """Quasi-definite K = [[H, J'], [J, -D]] (lower triangle stored) from a constraint pattern: H diagonally dominant positive."""
+    m = J.shape[0]
+    H = sp.diags(1.0 + rng.random(n)) if h_pattern is None else h_pattern
+    K = sp.bmat([[sp.tril(H), None], [J, -sp.diags(0.5 + rng.random(m))]], format="csc")
+    return K, n, m
+
+
+@pytest.mark.parametrize("shape", ["arrow", "band", "blocks_with_isolated_nodes", "star", "dense_rows", "two_by_two_chain", "all_in_one_column"])
+@pytest.mark.parametrize("seed", [0, 1])
+@pytest.mark.parametrize("ordering", [0, 4])
+def test_structure_zoo_vs_oracle(shape, seed, ordering):
+    # sparsity shapes that stress different parts of the plan (one huge separator, a path-shaped tree, forests with singleton
+    # fronts, dense rows set aside by the orderings, a 3 x 3 system, a single dense column), each under the
+    # default ordering and under forced nested dissection: inertia counts, sign(D), D and solutions against the oracle with
+    # the library's permutation
+    rng = np.random.default_rng(17 * seed + len(shape))
+    if shape == "arrow":
+        n, m = 60, 90
+        J = sp.lil_matrix((m, n)); J[:, 0] = rng.normal(size=(m, 1)); J.setdiag(rng.normal(size=min(m, n)) + 2.0)
+    elif shape == "band":
+        n, m = 300, 299
+        J = sp.diags([rng.normal(size=m) + 2.0, rng.normal(size=m)], [0, 1], shape=(m, n)).tolil()
+    elif shape == "blocks_with_isolated_nodes":
+        n, m = 120, 40
+        J = sp.lil_matrix((m, n))
+        for i in range(m):
+            J[i, 3 * (i % 20): 3 * (i % 20) + 3] = rng.normal(size=3)       # columns 60..119 touch no constraint: singleton fronts
+    elif shape == "star":
+        n, m = 1, 150
+        J = sp.lil_matrix(rng.normal(size=(m, 1)))
+    elif shape == "dense_rows":
+        n, m = 400, 30
+        J = sp.lil_matrix((m, n))
+        for i in range(m):
+            cols = rng.choice(n, size=220 if i < 3 else 4, replace=False)
+            J[i, cols] = rng.normal(size=len(cols))
+    elif shape == "two_by_two_chain":
+        n, m = 2, 1
+        J = sp.lil_matrix(np.array([[1.5, -0.5]]))
+    else:   # all_in_one_column
+        n, m = 50, 50
+        J = sp.lil_matrix((m, n)); J[:, 7] = rng.normal(size=(m, 1)) + 3.0
+    K, n, m = _kkt_from(sp.csc_matrix(J), n, rng)
+    compare_with_oracle(K, n, m, seed=seed, tol=1e-9, ordering=ordering)
