@@ -879,9 +879,6 @@ constexpr int kSyrkStages = OKKT_SYRK_STAGES;  // ring slots (KC * stages = 32 k
 #ifndef OKKT_SYRK_LD
 #define OKKT_SYRK_LD 144
 #endif
-#ifndef OKKT_SYRK_NT
-#define OKKT_SYRK_NT 0     // bit 0: non-temporal C loads, bit 1: non-temporal C stores
-#endif
 constexpr int kSyrkLd = OKKT_SYRK_LD;   // leading dimension of the LDS panels (doubles)
 constexpr size_t syrk_lds_bytes(int stages) { return (size_t)stages * 2 * kSyrkKC * kSyrkLd * sizeof(double); }
 typedef __attribute__((address_space(3))) void lds_void_t;
@@ -979,7 +976,6 @@ __global__ __launch_bounds__(kSyrkNW * 64, kSyrkNW / 2) void k_big_syrk(DevPlan 
   // Row map of an accumulator: (l15, rb) <-> row 2*l15 + (rb & 1) + 32*(rb >> 1) of the wave's 64 rows, so
   // that a lane's (rb, rb+1) pair is 16 contiguous bytes of C: 16-byte loads/stores, 256-byte segments.
   typedef double d2_t __attribute__((ext_vector_type(2)));
-  typedef double d2u_t __attribute__((ext_vector_type(2), aligned(8)));
 #pragma unroll
   for (int cg = 0; cg < NCG; ++cg) {
     const int c = cbase + cg * 4 + l4;
@@ -990,13 +986,7 @@ __global__ __launch_bounds__(kSyrkNW * 64, kSyrkNW / 2) void k_big_syrk(DevPlan 
       const int rcl = min(r, f - 2);            // clamped pair start: always in bounds, no branch
       const int shift = r - rcl;                // 0 in the interior, 1 when r is the last row, >= 2 outside
       d2_t v = (d2_t){0.0, 0.0};
-      if constexpr (!(DBG & 1)) {
-#if OKKT_SYRK_NT & 1
-        v = __builtin_nontemporal_load((const d2u_t*)(colp + rcl));
-#else
-        __builtin_memcpy(&v, colp + rcl, 16);
-#endif
-      }
+      if constexpr (!(DBG & 1)) __builtin_memcpy(&v, colp + rcl, 16);
       const double e0 = shift == 0 ? v[0] : v[1];
       acc[cg][2 * h] = keep_f64(e0, shift <= 1 && c < climit && r >= c);
       acc[cg][2 * h + 1] = keep_f64(v[1], shift == 0 && c < climit && r + 1 >= c);
@@ -1060,11 +1050,7 @@ __global__ __launch_bounds__(kSyrkNW * 64, kSyrkNW / 2) void k_big_syrk(DevPlan 
       const int r = rbase + 2 * l15 + 32 * h;
       if (r + 1 < f && r >= c) {
         const d2_t v = (d2_t){acc[cg][2 * h], acc[cg][2 * h + 1]};
-#if OKKT_SYRK_NT & 2
-        __builtin_nontemporal_store(v, (d2u_t*)(colp + r));
-#else
         __builtin_memcpy(colp + r, &v, 16);
-#endif
       } else {
         if (r < f && r >= c) colp[r] = acc[cg][2 * h];
         if (r + 1 < f && r + 1 >= c) colp[r + 1] = acc[cg][2 * h + 1];
