@@ -73,7 +73,9 @@ typedef struct {
   int32_t host_symbolic_only; /* 1: never touch the GPU (analysis + queries only; CPU-side tests) */
   int32_t ordering;           /* 0 automatic (default): AMD, replaced by level-structure nested dissection when the AMD
                                  elimination tree is a path of small fronts (banded KKT systems: a dependent pivot chain on a
-                                 GPU); 1 natural, 2 user permutation (okkt_set_perm), 3 AMD always, 4 nested dissection always */
+                                 GPU), and by multilevel nested dissection when that needs at least 10 % fewer factor flops (n >= 10 000; both candidates are
+                                 computed side by side); 1 natural, 2 user permutation (okkt_set_perm), 3 AMD always, 4 level-structure nested
+                                 dissection always, 5 multilevel nested dissection always */
   int32_t relax_always;       /* supernode amalgamation knobs, <=0 = default */
   int32_t relax_small;
   int32_t relax_mid;
@@ -109,7 +111,7 @@ typedef struct {
   double last_solve_ms;   /* device time of the last solve */
   uint64_t pattern_hash;
   int64_t n_analyze_calls; /* how many times a new pattern forced a re-analysis */
-  int64_t ordering_used;   /* 0 AMD, 1 natural, 2 user, 4 level-structure nested dissection */
+  int64_t ordering_used;   /* 0 AMD, 1 natural, 2 user, 4 level-structure nested dissection, 5 multilevel nested dissection */
   int64_t critical_pivots; /* pivots on the longest leaf-to-root path of the supernodal elimination tree */
 } okkt_stats;
 

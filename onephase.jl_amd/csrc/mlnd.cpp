@@ -1,0 +1,648 @@
+// Multilevel nested dissection: the fill-reducing ordering for KKT systems whose graph has small separators that a
+// minimum-degree ordering does not find.
+//
+// Why (round 3): the reference takes CHOLMOD's default AMD ordering on every ls_factor! (julia.jl:34,52).  On the metric
+// workload (n + m = 1e5: a banded coupling pattern plus 1 % long-range entries) AMD ends in one dense front of 16 641 rows
+// that alone holds 81 % of 1.8e12 factor flops.  The pivot order of a static-pivot LDL^T is free, and a dissection of the same
+// graph needs a third of the arithmetic: top separator ~7 600 vertices, the fronts below it shrink geometrically
+// (5.7e11 flops, nnz(L) 1.87e8 -> 1.12e8).  The factorisation is bound by FP64 MFMA throughput, so the ordering is worth more
+// than any kernel change.
+//
+// Algorithm (the multilevel scheme of Karypis & Kumar / Hendrickson & Leland, written for this project):
+//   bisect(G):  coarsen by heavy-edge matching until ~120 vertices; bisect the coarsest graph by greedy graph growing
+//               (several seeds, best cut); project back level by level with boundary Fiduccia-Mattheyses refinement of the
+//               edge cut under a balance bound; at the finest level turn the edge cut into a vertex separator by a minimum
+//               vertex cover of the cut edges (Koenig's theorem on a Hopcroft-Karp matching) and refine the separator itself
+//               with a node-FM pass (a separator vertex moves to one side, its neighbours on the other side enter).
+//   order(G) = [order(A), order(B), S]; pieces below `leaf` vertices are ordered by approximate minimum degree (amd.cpp).
+// Deterministic: every random choice comes from a generator seeded by the position in the recursion tree, the pieces are
+// independent, so the threads that order them in parallel cannot change the result (every rank of a multi-GPU run computes the
+// same permutation).
+#include "symbolic.h"
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <thread>
+#include <chrono>
+
+namespace okkt {
+
+namespace {
+
+struct Rng {
+  uint64_t s;
+  explicit Rng(uint64_t seed) : s(seed * 0x9E3779B97F4A7C15ull + 0x1234567ull) {}
+  uint64_t next() { uint64_t z = (s += 0x9E3779B97F4A7C15ull); z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); }
+  int below(int n) { return (int)(next() % (uint64_t)n); }
+};
+
+struct Graph {
+  int n = 0;
+  std::vector<int> xadj;   // n + 1
+  std::vector<int> adj;
+  std::vector<int> vw;     // vertex weights
+  std::vector<int> ew;     // edge weights
+  int64_t tvw = 0;
+};
+
+// indexed binary max-heap over vertices: key, then smaller vertex number (deterministic)
+struct Heap {
+  std::vector<int> heap, pos;
+  std::vector<int64_t> key;
+  void init(int n) { heap.clear(); pos.assign(n, -1); key.assign(n, 0); }
+  bool less(int a, int b) const { return key[a] < key[b] || (key[a] == key[b] && a > b); }
+  void up(int i) {
+    const int v = heap[i];
+    while (i > 0) { const int p = (i - 1) >> 1; if (!less(heap[p], v)) break; heap[i] = heap[p]; pos[heap[i]] = i; i = p; }
+    heap[i] = v; pos[v] = i;
+  }
+  void down(int i) {
+    const int v = heap[i], sz = (int)heap.size();
+    for (;;) {
+      int c = 2 * i + 1;
+      if (c >= sz) break;
+      if (c + 1 < sz && less(heap[c], heap[c + 1])) ++c;
+      if (!less(v, heap[c])) break;
+      heap[i] = heap[c]; pos[heap[i]] = i; i = c;
+    }
+    heap[i] = v; pos[v] = i;
+  }
+  bool has(int v) const { return pos[v] >= 0; }
+  void push(int v, int64_t k) { key[v] = k; heap.push_back(v); up((int)heap.size() - 1); }
+  void update(int v, int64_t k) {
+    if (pos[v] < 0) { push(v, k); return; }
+    const int64_t old = key[v]; key[v] = k;
+    if (k > old) up(pos[v]); else if (k < old) down(pos[v]);
+  }
+  void remove(int v) {
+    const int i = pos[v];
+    if (i < 0) return;
+    const int last = heap.back(); heap.pop_back(); pos[v] = -1;
+    if (last != v) { heap[i] = last; pos[last] = i; up(i); down(pos[last]); }
+  }
+  bool empty() const { return heap.empty(); }
+  int top() const { return heap[0]; }
+  void clear() { for (int v : heap) pos[v] = -1; heap.clear(); }
+};
+
+// ---- coarsening: heavy-edge matching ---------------------------------------------------------
+void coarsen(const Graph& g, Graph& c, std::vector<int>& cmap, Rng& rng, int maxvw) {
+  const int n = g.n;
+  std::vector<int> match(n, -1), perm(n);
+  for (int i = 0; i < n; ++i) perm[i] = i;
+  for (int i = n - 1; i > 0; --i) std::swap(perm[i], perm[rng.below(i + 1)]);
+  cmap.assign(n, -1);
+  int nc = 0;
+  for (int q = 0; q < n; ++q) {
+    const int v = perm[q];
+    if (match[v] >= 0) continue;
+    // heaviest edge to an unmatched neighbour -- but never an edge much lighter than v's heaviest one: when the
+    // neighbours v belongs with are taken, matching it across a stray long-range edge would glue two distant regions into
+    // one coarse vertex (seen on the metric workload: coarse vertices with 40 % foreign content, seven-piece "bisections");
+    // v stays single at this level instead
+    int best = -1, bw = -1, heaviest = 0;
+    for (int p = g.xadj[v]; p < g.xadj[v + 1]; ++p) heaviest = std::max(heaviest, g.ew[p]);
+    const int floor_w = (heaviest + 3) / 4;
+    for (int p = g.xadj[v]; p < g.xadj[v + 1]; ++p) {
+      const int u = g.adj[p];
+      if (match[u] >= 0 || g.vw[v] + g.vw[u] > maxvw || g.ew[p] < floor_w) continue;
+      if (g.ew[p] > bw || (g.ew[p] == bw && g.vw[u] < g.vw[best])) { best = u; bw = g.ew[p]; }
+    }
+    if (best >= 0) { match[v] = best; match[best] = v; cmap[v] = cmap[best] = nc++; }
+    else { match[v] = v; cmap[v] = nc++; }
+  }
+  c.n = nc;
+  c.xadj.assign(nc + 1, 0);
+  c.vw.assign(nc, 0);
+  c.tvw = g.tvw;
+  c.adj.clear(); c.ew.clear();
+  c.adj.reserve(g.adj.size()); c.ew.reserve(g.adj.size());
+  std::vector<int> slot(nc, -1);
+  // coarse vertices in the order of their ids: the first fine vertex of id k in `perm` order defines it
+  std::vector<int> rep(nc, -1);
+  for (int q = 0; q < n; ++q) { const int v = perm[q]; if (rep[cmap[v]] < 0) rep[cmap[v]] = v; }
+  for (int k = 0; k < nc; ++k) {
+    const int v = rep[k], u = match[v];
+    const int start = (int)c.adj.size();
+    for (int pass = 0; pass < 2; ++pass) {
+      const int x = pass == 0 ? v : u;
+      if (pass == 1 && u == v) break;
+      c.vw[k] += g.vw[x];
+      for (int p = g.xadj[x]; p < g.xadj[x + 1]; ++p) {
+        const int ck = cmap[g.adj[p]];
+        if (ck == k) continue;
+        if (slot[ck] < start) { slot[ck] = (int)c.adj.size(); c.adj.push_back(ck); c.ew.push_back(g.ew[p]); }
+        else c.ew[slot[ck]] += g.ew[p];
+      }
+    }
+    c.xadj[k + 1] = (int)c.adj.size();
+  }
+}
+
+// ---- 2-way edge-cut FM refinement --------------------------------------------------------------
+struct Bisection {
+  std::vector<int8_t> where;   // 0 / 1
+  int64_t pw[2] = {0, 0};
+  int64_t cut = 0;
+};
+
+void compute_cut(const Graph& g, Bisection& b, std::vector<int64_t>& id, std::vector<int64_t>& ed) {
+  const int n = g.n;
+  id.assign(n, 0); ed.assign(n, 0);
+  b.pw[0] = b.pw[1] = 0; b.cut = 0;
+  for (int v = 0; v < n; ++v) {
+    b.pw[b.where[v]] += g.vw[v];
+    for (int p = g.xadj[v]; p < g.xadj[v + 1]; ++p) {
+      if (b.where[g.adj[p]] == b.where[v]) id[v] += g.ew[p]; else ed[v] += g.ew[p];
+    }
+    b.cut += ed[v];
+  }
+  b.cut /= 2;
+}
+
+// boundary FM; maxw = largest admissible part weight.  Returns true when the cut or the balance improved.
+bool fm_edge(const Graph& g, Bisection& b, int64_t maxw, int npass, Heap hp[2]) {
+  const int n = g.n;
+  std::vector<int64_t> id, ed;
+  compute_cut(g, b, id, ed);
+  std::vector<char> locked(n, 0);
+  std::vector<int> moved;
+  bool any = false;
+  const int limit = std::max(40, std::min(n / 50, 400));
+  for (int pass = 0; pass < npass; ++pass) {
+    hp[0].init(n); hp[1].init(n);
+    for (int v = 0; v < n; ++v) if (ed[v] > 0 || g.xadj[v] == g.xadj[v + 1]) hp[b.where[v]].push(v, ed[v] - id[v]);
+    moved.clear();
+    int64_t cur = b.cut, best = b.cut;
+    int64_t bestdiff = std::llabs(b.pw[0] - b.pw[1]);
+    const bool start_ok = std::max(b.pw[0], b.pw[1]) <= maxw;
+    bool best_ok = start_ok;
+    int bestn = 0;
+    for (;;) {
+      // side to move FROM: the overweight side when out of balance, else the better gain (ties: the heavier side)
+      int from;
+      const bool over0 = b.pw[0] > maxw, over1 = b.pw[1] > maxw;
+      if (over0 != over1) from = over0 ? 0 : 1;
+      else if (hp[0].empty() && hp[1].empty()) break;
+      else if (hp[0].empty()) from = 1;
+      else if (hp[1].empty()) from = 0;
+      else {
+        const int64_t k0 = hp[0].key[hp[0].top()], k1 = hp[1].key[hp[1].top()];
+        from = k0 > k1 ? 0 : (k1 > k0 ? 1 : (b.pw[0] >= b.pw[1] ? 0 : 1));
+      }
+      if (hp[from].empty()) break;
+      const int v = hp[from].top();
+      hp[from].remove(v);
+      const int to = 1 - from;
+      if (b.pw[to] + g.vw[v] > maxw && !(b.pw[from] > maxw)) continue;   // would break the balance: skip (stays unlocked but out of the heap)
+      cur -= ed[v] - id[v];
+      b.pw[from] -= g.vw[v]; b.pw[to] += g.vw[v];
+      b.where[v] = (int8_t)to;
+      locked[v] = 1;
+      moved.push_back(v);
+      std::swap(id[v], ed[v]);
+      for (int p = g.xadj[v]; p < g.xadj[v + 1]; ++p) {
+        const int u = g.adj[p];
+        const int w = g.ew[p];
+        if (b.where[u] == to) { id[u] += w; ed[u] -= w; } else { id[u] -= w; ed[u] += w; }
+        if (locked[u]) continue;
+        if (ed[u] > 0) hp[b.where[u]].update(u, ed[u] - id[u]);
+        else hp[b.where[u]].remove(u);
+      }
+      const bool ok = std::max(b.pw[0], b.pw[1]) <= maxw;
+      const int64_t diff = std::llabs(b.pw[0] - b.pw[1]);
+      const bool better = (ok && !best_ok) || (ok == best_ok && (cur < best || (cur == best && diff < bestdiff)));
+      if (better) { best = cur; bestdiff = diff; best_ok = ok; bestn = (int)moved.size(); }
+      else if ((int)moved.size() - bestn > limit) break;
+    }
+    // roll back behind the best prefix
+    for (int q = (int)moved.size() - 1; q >= bestn; --q) {
+      const int v = moved[q];
+      const int to = 1 - b.where[v], from = b.where[v];
+      b.pw[from] -= g.vw[v]; b.pw[to] += g.vw[v];
+      b.where[v] = (int8_t)to;
+      std::swap(id[v], ed[v]);
+      for (int p = g.xadj[v]; p < g.xadj[v + 1]; ++p) {
+        const int u = g.adj[p];
+        const int w = g.ew[p];
+        if (b.where[u] == to) { id[u] += w; ed[u] -= w; } else { id[u] -= w; ed[u] += w; }
+      }
+    }
+    for (int v : moved) locked[v] = 0;
+    const bool improved = best < b.cut || (best_ok && !start_ok);
+    b.cut = best;
+    if (!improved) break;
+    any = true;
+  }
+  return any;
+}
+
+// ---- initial bisection of the coarsest graph: greedy graph growing ---------------------------------
+void initial_bisection(const Graph& g, Bisection& out, Rng& rng, int64_t maxw, int ntrial) {
+  const int n = g.n;
+  Bisection best;
+  bool have = false;
+  Heap hp[2];
+  std::vector<int64_t> gain(n);
+  std::vector<char> infront(n);
+  for (int t = 0; t < ntrial; ++t) {
+    Bisection b;
+    b.where.assign(n, 1);
+    int64_t w0 = 0;
+    const int64_t target = g.tvw / 2;
+    std::fill(infront.begin(), infront.end(), 0);
+    std::vector<int> front;
+    while (w0 < target) {
+      int v = -1;
+      if (front.empty()) {           // new seed (first one, or the component is exhausted)
+        int tries = 0;
+        do { v = rng.below(n); } while (b.where[v] == 0 && ++tries < 8 * n);
+        if (b.where[v] == 0) break;
+      } else {
+        // frontier vertex with the largest (weight towards the grown side - weight away from it)
+        int bq = 0;
+        for (int q = 1; q < (int)front.size(); ++q)
+          if (gain[front[q]] > gain[front[bq]] || (gain[front[q]] == gain[front[bq]] && front[q] < front[bq])) bq = q;
+        v = front[bq];
+        front[bq] = front.back(); front.pop_back();
+      }
+      if (w0 + g.vw[v] > maxw) { if (front.empty()) break; continue; }
+      b.where[v] = 0; w0 += g.vw[v];
+      for (int p = g.xadj[v]; p < g.xadj[v + 1]; ++p) {
+        const int u = g.adj[p];
+        if (b.where[u] == 0) continue;
+        if (!infront[u]) {
+          infront[u] = 1; front.push_back(u);
+          int64_t gu = 0;
+          for (int p2 = g.xadj[u]; p2 < g.xadj[u + 1]; ++p2) gu += b.where[g.adj[p2]] == 0 ? g.ew[p2] : -g.ew[p2];
+          gain[u] = gu;
+        } else gain[u] += 2 * g.ew[p];
+      }
+    }
+    fm_edge(g, b, maxw, 4, hp);
+    const bool ok = std::max(b.pw[0], b.pw[1]) <= maxw, bok = have && std::max(best.pw[0], best.pw[1]) <= maxw;
+    if (!have || (ok && !bok) || (ok == bok && b.cut < best.cut)) { best = b; have = true; }
+  }
+  out = best;
+}
+
+// ---- vertex separator from an edge cut: minimum vertex cover of the cut edges -------------------------
+// where: 0 / 1 in, 0 / 1 / 2 (separator) out
+void cover_separator(const Graph& g, std::vector<int8_t>& where) {
+  const int n = g.n;
+  std::vector<int> lid(n, -1), L, R;   // boundary vertices of side 0 (left) and side 1 (right)
+  for (int v = 0; v < n; ++v) {
+    bool bnd = false;
+    for (int p = g.xadj[v]; p < g.xadj[v + 1] && !bnd; ++p) bnd = where[g.adj[p]] != where[v];
+    if (!bnd) continue;
+    if (where[v] == 0) { lid[v] = (int)L.size(); L.push_back(v); } else { lid[v] = (int)R.size(); R.push_back(v); }
+  }
+  const int nl = (int)L.size(), nr = (int)R.size();
+  if (nl == 0) return;
+  std::vector<int> ml(nl, -1), mr(nr, -1), dist(nl), q, it(nl);
+  auto nbr_begin = [&](int l) { return g.xadj[L[l]]; };
+  auto nbr_end = [&](int l) { return g.xadj[L[l] + 1]; };
+  // Hopcroft-Karp
+  for (;;) {
+    q.clear();
+    for (int l = 0; l < nl; ++l) { if (ml[l] < 0) { dist[l] = 0; q.push_back(l); } else dist[l] = -1; }
+    bool found = false;
+    for (size_t h = 0; h < q.size(); ++h) {
+      const int l = q[h];
+      for (int p = nbr_begin(l); p < nbr_end(l); ++p) {
+        const int u = g.adj[p];
+        if (where[u] != 1) continue;
+        const int l2 = mr[lid[u]];
+        if (l2 < 0) found = true;
+        else if (dist[l2] < 0) { dist[l2] = dist[l] + 1; q.push_back(l2); }
+      }
+    }
+    if (!found) break;
+    for (int l = 0; l < nl; ++l) it[l] = nbr_begin(l);
+    // iterative DFS along the layers
+    std::vector<int> stack;
+    for (int l0 = 0; l0 < nl; ++l0) {
+      if (ml[l0] >= 0) continue;
+      stack.assign(1, l0);
+      while (!stack.empty()) {
+        const int l = stack.back();
+        bool advanced = false;
+        while (it[l] < nbr_end(l)) {
+          const int u = g.adj[it[l]++];
+          if (where[u] != 1) continue;
+          const int r = lid[u], l2 = mr[r];
+          if (l2 < 0) {
+            // augment along the stack
+            int rr = r;
+            for (int s = (int)stack.size() - 1; s >= 0; --s) { const int ll = stack[s]; const int prev = ml[ll]; ml[ll] = rr; mr[rr] = ll; rr = prev; }
+            stack.clear();
+            advanced = true;
+            break;
+          }
+          if (dist[l2] == dist[l] + 1) { stack.push_back(l2); advanced = true; break; }
+        }
+        if (!advanced) { dist[l] = -1; stack.pop_back(); }
+      }
+    }
+  }
+  // Koenig: Z = reachable from unmatched left vertices by alternating paths; cover = (L \ Z) + (R & Z)
+  std::vector<char> zl(nl, 0), zr(nr, 0);
+  q.clear();
+  for (int l = 0; l < nl; ++l) if (ml[l] < 0) { zl[l] = 1; q.push_back(l); }
+  for (size_t h = 0; h < q.size(); ++h) {
+    const int l = q[h];
+    for (int p = nbr_begin(l); p < nbr_end(l); ++p) {
+      const int u = g.adj[p];
+      if (where[u] != 1) continue;
+      const int r = lid[u];
+      if (zr[r]) continue;
+      zr[r] = 1;
+      const int l2 = mr[r];
+      if (l2 >= 0 && !zl[l2]) { zl[l2] = 1; q.push_back(l2); }
+    }
+  }
+  for (int l = 0; l < nl; ++l) if (!zl[l]) where[L[l]] = 2;
+  for (int r = 0; r < nr; ++r) if (zr[r]) where[R[r]] = 2;
+}
+
+// ---- node FM: refine a vertex separator ---------------------------------------------------------------
+// A separator vertex v moves to side s; its neighbours on side 1 - s enter the separator.
+// gain = vw[v] - (weight of those neighbours).
+void fm_node(const Graph& g, std::vector<int8_t>& where, int64_t maxw, int npass) {
+  const int n = g.n;
+  int64_t pw[3] = {0, 0, 0};
+  for (int v = 0; v < n; ++v) pw[where[v]] += g.vw[v];
+  Heap hp[2];
+  std::vector<char> locked(n, 0);
+  struct Move { int v; int to; int npulled; };
+  std::vector<Move> moves;
+  std::vector<int> pulled, touched;
+  auto gain_to = [&](int v, int to) {
+    int64_t out = 0;
+    for (int p = g.xadj[v]; p < g.xadj[v + 1]; ++p) if (where[g.adj[p]] == 1 - to) out += g.vw[g.adj[p]];
+    return (int64_t)g.vw[v] - out;
+  };
+  const int limit = std::max(60, std::min(n / 40, 600));
+  for (int pass = 0; pass < npass; ++pass) {
+    hp[0].init(n); hp[1].init(n);
+    for (int v = 0; v < n; ++v) if (where[v] == 2) { hp[0].push(v, gain_to(v, 0)); hp[1].push(v, gain_to(v, 1)); }
+    moves.clear(); pulled.clear();
+    int64_t cur = pw[2], best = pw[2];
+    int64_t bestdiff = std::llabs(pw[0] - pw[1]);
+    int bestn = 0;
+    for (;;) {
+      if (hp[0].empty() && hp[1].empty()) break;
+      int to;
+      if (hp[0].empty()) to = 1;
+      else if (hp[1].empty()) to = 0;
+      else {
+        const int64_t k0 = hp[0].key[hp[0].top()], k1 = hp[1].key[hp[1].top()];
+        to = k0 > k1 ? 0 : (k1 > k0 ? 1 : (pw[0] <= pw[1] ? 0 : 1));
+      }
+      // balance: do not grow a side beyond maxw; try the other side then
+      int v = hp[to].top();
+      if (pw[to] + g.vw[v] > maxw) {
+        to = 1 - to;
+        if (hp[to].empty()) break;
+        v = hp[to].top();
+        if (pw[to] + g.vw[v] > maxw) break;
+      }
+      hp[0].remove(v); hp[1].remove(v);
+      locked[v] = 1;
+      where[v] = (int8_t)to;
+      pw[2] -= g.vw[v]; pw[to] += g.vw[v];
+      cur -= g.vw[v];
+      int np = 0;
+      touched.clear();
+      const size_t pulled0 = pulled.size();
+      for (int p = g.xadj[v]; p < g.xadj[v + 1]; ++p) {
+        const int u = g.adj[p];
+        if (where[u] == 1 - to) {            // enters the separator
+          where[u] = 2; pw[1 - to] -= g.vw[u]; pw[2] += g.vw[u]; cur += g.vw[u];
+          pulled.push_back(u); ++np;
+          touched.push_back(u);
+        } else if (where[u] == 2) touched.push_back(u);   // its gain towards 1 - to no longer counts v
+      }
+      // separator neighbours of the vertices that entered: their gain towards `to` no longer counts those
+      for (size_t q = pulled0; q < pulled.size(); ++q) {
+        const int u = pulled[q];
+        for (int p = g.xadj[u]; p < g.xadj[u + 1]; ++p) { const int x = g.adj[p]; if (where[x] == 2) touched.push_back(x); }
+      }
+      std::sort(touched.begin(), touched.end());
+      touched.erase(std::unique(touched.begin(), touched.end()), touched.end());
+      for (int u : touched) {
+        if (where[u] != 2 || locked[u]) continue;
+        hp[0].update(u, gain_to(u, 0));
+        hp[1].update(u, gain_to(u, 1));
+      }
+      moves.push_back({v, to, np});
+      const int64_t diff = std::llabs(pw[0] - pw[1]);
+      if (cur < best || (cur == best && diff < bestdiff)) { best = cur; bestdiff = diff; bestn = (int)moves.size(); }
+      else if ((int)moves.size() - bestn > limit) break;
+    }
+    // roll back
+    for (int q = (int)moves.size() - 1; q >= bestn; --q) {
+      const Move& mv = moves[q];
+      for (int j = 0; j < mv.npulled; ++j) {
+        const int u = pulled.back(); pulled.pop_back();
+        where[u] = (int8_t)(1 - mv.to); pw[2] -= g.vw[u]; pw[1 - mv.to] += g.vw[u];
+      }
+      where[mv.v] = 2; pw[mv.to] -= g.vw[mv.v]; pw[2] += g.vw[mv.v];
+    }
+    for (const Move& mv : moves) locked[mv.v] = 0;
+    if (bestn == 0) break;
+  }
+}
+
+// ---- one multilevel bisection -> vertex separator ----------------------------------------------------------
+void ml_separator(const Graph& g0, uint64_t seed, double max_frac, std::vector<int8_t>& where) {
+  Rng rng(seed);
+  const bool tdbg = getenv("OKKT_DEBUG_MLND") != nullptr && g0.n > 50000;
+  auto t0 = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (!tdbg) return;
+    auto t = std::chrono::steady_clock::now();
+    fprintf(stderr, "okkt: mlnd %-20s %.3f s\n", what, std::chrono::duration<double>(t - t0).count());
+    t0 = t;
+  };
+  std::vector<Graph> levels;       // levels[i] = coarse graph i + 1
+  std::vector<std::vector<int>> cmaps;
+  const Graph* g = &g0;
+  const int coarsen_to = 120;
+  while (g->n > coarsen_to) {
+    Graph c;
+    std::vector<int> cmap;
+    const int maxvw = (int)std::max<int64_t>(1, (3 * g->tvw) / (2 * coarsen_to));
+    coarsen(*g, c, cmap, rng, maxvw);
+    if (c.n > 0.97 * g->n) { if (c.n < g->n) { levels.push_back(std::move(c)); cmaps.push_back(std::move(cmap)); g = &levels.back(); } break; }
+    levels.push_back(std::move(c));
+    cmaps.push_back(std::move(cmap));
+    g = &levels.back();
+    if (levels.size() > 60) break;
+  }
+  // note: `levels` may reallocate while growing; take the pointers again
+  const int nlev = (int)levels.size();
+  auto graph_at = [&](int l) -> const Graph& { return l == 0 ? g0 : levels[l - 1]; };
+  Bisection b;
+  const Graph& gc = graph_at(nlev);
+  const int64_t maxw_c = (int64_t)std::ceil(max_frac * (double)gc.tvw);
+  lap("coarsen");
+  if (tdbg && seed == 31 && getenv("OKKT_DEBUG_MLND_CMAP")) {
+    std::vector<int> f2c(g0.n);
+    for (int v = 0; v < g0.n; ++v) { int c = v; for (int l = 0; l < nlev; ++l) c = cmaps[l][c]; f2c[v] = c; }
+    FILE* fp = fopen(getenv("OKKT_DEBUG_MLND_CMAP"), "wb"); fwrite(f2c.data(), 4, f2c.size(), fp); fclose(fp);
+  }
+  initial_bisection(gc, b, rng, maxw_c, 12);
+  lap("initial");
+  if (tdbg) fprintf(stderr, "okkt: mlnd coarsest n %d cut %ld parts %ld | %ld\n", gc.n, (long)b.cut, (long)b.pw[0], (long)b.pw[1]);
+  Heap hp[2];
+  for (int l = nlev - 1; l >= 0; --l) {
+    const Graph& gf = graph_at(l);
+    Bisection bf;
+    bf.where.resize(gf.n);
+    const std::vector<int>& cm = cmaps[l];
+    for (int v = 0; v < gf.n; ++v) bf.where[v] = b.where[cm[v]];
+    fm_edge(gf, bf, (int64_t)std::ceil(max_frac * (double)gf.tvw), 6, hp);
+    b = std::move(bf);
+    if (tdbg) fprintf(stderr, "okkt: mlnd level %d n %d cut %ld parts %ld | %ld\n", l, gf.n, (long)b.cut, (long)b.pw[0], (long)b.pw[1]);
+  }
+  if (nlev == 0) { /* tiny graph: the initial bisection is on g0 itself */ }
+  lap("uncoarsen");
+  if (tdbg) fprintf(stderr, "okkt: mlnd edge cut %ld, parts %ld | %ld\n", (long)b.cut, (long)b.pw[0], (long)b.pw[1]);
+  where = b.where;
+  cover_separator(g0, where);
+  lap("cover");
+  if (tdbg) { long c2 = 0; for (int v = 0; v < g0.n; ++v) c2 += where[v] == 2; fprintf(stderr, "okkt: mlnd cover separator %ld\n", c2); }
+  fm_node(g0, where, (int64_t)std::ceil(max_frac * (double)g0.tvw), 6);
+  lap("node fm");
+  if (tdbg && seed == 31 && getenv("OKKT_DEBUG_MLND_DUMP")) { FILE* fp = fopen(getenv("OKKT_DEBUG_MLND_DUMP"), "wb"); fwrite(where.data(), 1, where.size(), fp); fwrite(b.where.data(), 1, b.where.size(), fp); fclose(fp); }
+  if (tdbg) { long c2 = 0; for (int v = 0; v < g0.n; ++v) c2 += where[v] == 2; fprintf(stderr, "okkt: mlnd refined separator %ld\n", c2); }
+}
+
+struct NdCtx {
+  int leaf;
+  int ntrial_top;
+  std::atomic<int> threads_free;
+  bool dbg;
+};
+
+void amd_leaf(const Graph& g, const std::vector<int>& label, int* out) {
+  std::vector<int64_t> ap(g.n + 1);
+  for (int i = 0; i <= g.n; ++i) ap[i] = g.xadj[i];
+  std::vector<int> ord;
+  amd_order(g.n, ap, g.adj, ord);
+  for (int k = 0; k < g.n; ++k) out[k] = label[ord[k]];
+}
+
+void induced(const Graph& g, const std::vector<int>& label, const std::vector<int8_t>& where, int side, Graph& s, std::vector<int>& slabel) {
+  std::vector<int> id(g.n, -1);
+  int ns = 0;
+  for (int v = 0; v < g.n; ++v) if (where[v] == side) id[v] = ns++;
+  s.n = ns; s.xadj.assign(ns + 1, 0); s.adj.clear(); s.vw.assign(ns, 1); s.tvw = ns;
+  slabel.resize(ns);
+  for (int v = 0; v < g.n; ++v) {
+    if (where[v] != side) continue;
+    slabel[id[v]] = label[v];
+    for (int p = g.xadj[v]; p < g.xadj[v + 1]; ++p) if (where[g.adj[p]] == side) s.adj.push_back(id[g.adj[p]]);
+    s.xadj[id[v] + 1] = (int)s.adj.size();
+  }
+  s.ew.assign(s.adj.size(), 1);
+}
+
+void nd_rec(NdCtx& cx, Graph g, std::vector<int> label, int* out, int depth, uint64_t seed) {
+  if (g.n <= cx.leaf) { amd_leaf(g, label, out); return; }
+  const double max_frac = 0.6;
+  const int ntrial = depth < 2 ? cx.ntrial_top : 1;
+  std::vector<std::vector<int8_t>> cand(ntrial);
+  {
+    std::vector<std::thread> th;
+    for (int t = 1; t < ntrial; ++t) {
+      if (cx.threads_free.fetch_sub(1) > 0) th.emplace_back([&, t] { ml_separator(g, seed * 31 + t, max_frac, cand[t]); });
+      else { cx.threads_free.fetch_add(1); ml_separator(g, seed * 31 + t, max_frac, cand[t]); }
+    }
+    ml_separator(g, seed * 31, max_frac, cand[0]);
+    for (auto& t : th) { t.join(); cx.threads_free.fetch_add(1); }
+  }
+  int bestt = 0;
+  int64_t bests = -1, bestimb = 0;
+  for (int t = 0; t < ntrial; ++t) {
+    int64_t c[3] = {0, 0, 0};
+    for (int v = 0; v < g.n; ++v) ++c[cand[t][v]];
+    const int64_t imb = std::llabs(c[0] - c[1]);
+    if (bests < 0 || c[2] < bests || (c[2] == bests && imb < bestimb)) { bests = c[2]; bestimb = imb; bestt = t; }
+  }
+  std::vector<int8_t>& where = cand[bestt];
+  int cnt[3] = {0, 0, 0};
+  for (int v = 0; v < g.n; ++v) ++cnt[where[v]];
+  if (cx.dbg && depth < 4) fprintf(stderr, "okkt: nd depth %d: %d vertices -> %d | %d | separator %d\n", depth, g.n, cnt[0], cnt[1], cnt[2]);
+  // a useless split (everything in the separator or on one side): minimum degree on the whole piece
+  if (cnt[0] == 0 || cnt[1] == 0 || cnt[2] * 2 > g.n) { amd_leaf(g, label, out); return; }
+  {
+    int* so = out + cnt[0] + cnt[1];
+    std::vector<int> sep;
+    for (int v = 0; v < g.n; ++v) if (where[v] == 2) sep.push_back(label[v]);
+    std::sort(sep.begin(), sep.end());
+    for (size_t k = 0; k < sep.size(); ++k) so[k] = sep[k];
+  }
+  Graph ga, gb;
+  std::vector<int> la, lb;
+  induced(g, label, where, 0, ga, la);
+  induced(g, label, where, 1, gb, lb);
+  g = Graph();
+  std::vector<int>().swap(label);
+  std::vector<std::vector<int8_t>>().swap(cand);
+  int* outa = out;
+  int* outb = out + cnt[0];
+  if (ga.n > 2000 && cx.threads_free.fetch_sub(1) > 0) {
+    std::thread th([&cx, &ga, &la, outa, depth, seed]() mutable { nd_rec(cx, std::move(ga), std::move(la), outa, depth + 1, seed * 2 + 1); });
+    nd_rec(cx, std::move(gb), std::move(lb), outb, depth + 1, seed * 2 + 2);
+    th.join();
+    cx.threads_free.fetch_add(1);
+  } else {
+    if (ga.n > 2000) cx.threads_free.fetch_add(1);
+    nd_rec(cx, std::move(ga), std::move(la), outa, depth + 1, seed * 2 + 1);
+    nd_rec(cx, std::move(gb), std::move(lb), outb, depth + 1, seed * 2 + 2);
+  }
+}
+
+}  // namespace
+
+void ml_nd_order(int n, const std::vector<int64_t>& gp, const std::vector<int>& gi, int leaf, int ntrial_top, std::vector<int>& order) {
+  order.assign(n, -1);
+  if (n == 0) return;
+  if (gi.size() > 0x7ffffff0u) { order.clear(); return; }   // 32-bit adjacency offsets below: the caller keeps minimum degree
+  // dense rows leave the graph first and are eliminated last, as in the minimum-degree code
+  const double dense = std::max(16.0, 10.0 * std::sqrt((double)n));
+  std::vector<int> id(n, -1), label, last;
+  for (int i = 0; i < n; ++i) {
+    if ((double)(gp[i + 1] - gp[i]) > dense) last.push_back(i);
+    else { id[i] = (int)label.size(); label.push_back(i); }
+  }
+  Graph g;
+  g.n = (int)label.size();
+  g.xadj.assign(g.n + 1, 0);
+  g.adj.reserve(gi.size());
+  for (int v = 0; v < g.n; ++v) {
+    const int i = label[v];
+    for (int64_t p = gp[i]; p < gp[i + 1]; ++p) { const int j = gi[p]; if (j != i && id[j] >= 0) g.adj.push_back(id[j]); }
+    g.xadj[v + 1] = (int)g.adj.size();
+  }
+  g.vw.assign(g.n, 1);
+  g.ew.assign(g.adj.size(), 1);
+  g.tvw = g.n;
+  NdCtx cx;
+  cx.leaf = std::max(leaf, 32);
+  cx.ntrial_top = std::max(1, ntrial_top);
+  int hw = (int)std::thread::hardware_concurrency();
+  if (getenv("OKKT_ANALYZE_THREADS")) hw = atoi(getenv("OKKT_ANALYZE_THREADS"));
+  cx.threads_free.store(std::max(0, std::min(hw, 32) - 1));
+  cx.dbg = getenv("OKKT_DEBUG_ANALYZE") != nullptr;
+  const int ng = g.n;
+  nd_rec(cx, std::move(g), std::move(label), order.data(), 0, 1);
+  for (size_t k = 0; k < last.size(); ++k) order[ng + k] = last[k];
+}
+
+}  // namespace okkt

@@ -19,10 +19,17 @@ void amd_order(int n, const std::vector<int64_t>& ap, const std::vector<int>& ai
 // level-structure nested dissection (nd.cpp): the parallel ordering for path-like graphs
 void level_nd_order(int n, const std::vector<int64_t>& gp, const std::vector<int>& gi, int leaf, std::vector<int>& order);
 
+// multilevel nested dissection (mlnd.cpp): heavy-edge coarsening, FM-refined bisections, minimum-vertex-cover separators,
+// minimum degree on the pieces of at most `leaf` vertices; the top two levels keep the best of `ntrial_top` bisections.
+// Leaves `order` empty when the graph is beyond its 32-bit offsets (the caller keeps minimum degree).
+void ml_nd_order(int n, const std::vector<int64_t>& gp, const std::vector<int>& gi, int leaf, int ntrial_top, std::vector<int>& order);
+
 struct SymbolicOptions {
   int ordering = 0;        // 0 = AMD, switching to level-structure nested dissection when the AMD tree is a path of small
-                           // fronts (see analyze_pattern); 1 = natural, 2 = user permutation, 3 = AMD always, 4 = nested dissection always
+                           // fronts (see analyze_pattern); 1 = natural, 2 = user permutation, 3 = AMD always, 4 = level-structure nested dissection always, 5 = multilevel nested dissection always
   int nd_leaf = 48;        // nested dissection stops at pieces of this many nodes
+  int mlnd_leaf = 1500;    // multilevel nested dissection (ordering 5, or chosen by ordering 0): pieces ordered by minimum degree
+  int mlnd_trials = 3;     // bisections tried (different seeds, side by side on host threads) on the top two levels
   int relax_always = 64;   // merge a child into its parent when the merged width <= this (one LDS-resident front instead of a chain of launches / loop trips)
   int relax_small = 128;   // ... or when width <= relax_small and zero fraction < relax_small_frac (S-C3: 107 -> 91 big fronts, factor 5.55 -> 5.2 ms)
   double relax_small_frac = 0.5;
