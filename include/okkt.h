@@ -266,6 +266,14 @@ int okkt_kkt_get_timers(okkt_kkt_handle k, okkt_kkt_timers* out);
 /* ipopt_strategy!: returns 1 on :success, 0 on :failure (delta > delta_max), <0 on error */
 int okkt_kkt_ipopt_strategy(okkt_kkt_handle k, double delta_prev, const okkt_kkt_pars* pars,
                             int32_t* num_fac_out, double* delta_out);
+/* is_diag_dom(kkt_solver.Q[1:n,1:n]) (delta_strategy.jl:1-9) at the delta of the last factor call, as a device scan:
+ * *out = 1 dominant, 0 not, -1 not evaluated (clever-symmetric system).  ipopt_strategy! runs it after every failed attempt and
+ * prints "WARNING: Inertia calculation incorrect" when it holds (delta_strategy.jl:94-98): okkt_kkt_ipopt_strategy does the same
+ * scan and okkt_kkt_diag_dom_warnings returns how many of its failed attempts would have printed the warning. */
+int okkt_kkt_is_diag_dom(okkt_kkt_handle k, int32_t* out);
+int okkt_kkt_diag_dom_warnings(okkt_kkt_handle k, int32_t* count);
+/* the tail of estimate_y_tilde (guess-vars.jl:155-160) with the factor and the Jacobian of the handle: y = -J (F \ (-g)) */
+int okkt_kkt_estimate_y_tilde(okkt_kkt_handle k, const double* g, double* y_out);
 /* System_rhs(it, reduct) (system_rhs.jl:57-73): dual_r = -(grad - J'y + eta_mu*mu*pen*J'1)(1 - eta_D),
  * primal_r = -(cons - s)(1 - eta_P), comp_r = eta_mu*mu - s.*y, at the CURRENT iterate.  J_nzval_cur = NULL
  * uses the J values of the factorised iterate (form_system) */

@@ -33,10 +33,10 @@ int solver_ensure_numeric(okkt_solver_s* h) {
   if (!h->analyzed) return solver_set_error(h, OKKT_ERR_INVALID, "okkt_analyze has not been called");
   if (h->numeric_ready) return OKKT_OK;
   h->N.part_id = h->part_id;
-  std::string e = numeric_setup(h->S, h->sopts, h->stream, h->N);
-  h->N.stream_masked = h->stream_masked;
+  h->N.stream_masked = h->stream_masked;     // before the set-up: the lanes of the plan are given streams there
   h->N.stream_panel = h->stream_panel;
   h->N.stream_aux = h->stream_aux;
+  std::string e = numeric_setup(h->S, h->sopts, h->stream, h->N);
   if (const char* sh = getenv("OKKT_SPLIT_HEAD")) h->N.split_head = atoi(sh);
   if (const char* mt = getenv("OKKT_LA_MIN_TILES")) h->N.la_min_tiles = atoi(mt);
   if (!e.empty()) { numeric_release(h->N); return solver_set_error(h, OKKT_ERR_HIP, e); }

@@ -229,6 +229,7 @@ int rccl_fail(okkt_solver_s* h, const char* what, ncclResult_t r) {
 int dist_free_buffers(okkt_solver_s* h) {
   for (void* p : {(void*)h->dist_cb, (void*)h->dist_cv, (void*)h->dist_x, (void*)h->dist_counts}) if (p) (void)hipFree(p);
   h->dist_cb = h->dist_cv = h->dist_x = nullptr;
+  h->dist_cb_cap = h->dist_cv_cap = h->dist_x_cap = 0;
   h->dist_counts = nullptr;
   return OKKT_OK;
 }
@@ -265,6 +266,17 @@ int okkt_dist_comm_init(okkt_handle h, int nranks, int rank, const void* id) {
   if (hipMalloc((void**)&h->dist_cb, std::max<size_t>(cb, 1) * 8) != hipSuccess || hipMalloc((void**)&h->dist_cv, std::max<size_t>(cv, 1) * 8) != hipSuccess ||
       hipMalloc((void**)&h->dist_x, std::max<size_t>((size_t)h->S.n, 1) * 8) != hipSuccess || hipMalloc((void**)&h->dist_counts, 4 * sizeof(long long)) != hipSuccess)
     return solver_set_error(h, OKKT_ERR_ALLOC, "exchange buffers");
+  h->dist_cb_cap = cb; h->dist_cv_cap = cv; h->dist_x_cap = (size_t)h->S.n;
+  return OKKT_OK;
+}
+
+// the exchange buffers were sized for the partition that was current at okkt_dist_comm_init: a re-analysis or a new
+// okkt_dist_set_partition without a new comm_init must not pack into the old allocation
+static int dist_buffers_fit(okkt_handle h) {
+  const size_t cb = h->S.boundary_cb.empty() ? 0 : (size_t)h->S.boundary_cb.back(), cv = h->S.boundary_cv.empty() ? 0 : (size_t)h->S.boundary_cv.back();
+  if (!h->dist_cb || !h->dist_cv || !h->dist_x || cb > h->dist_cb_cap || cv > h->dist_cv_cap || (size_t)h->S.n > h->dist_x_cap ||
+      h->S.nparts != h->rccl_nranks || h->part_id != h->rccl_rank)
+    return solver_set_error(h, OKKT_ERR_INVALID, "the partition or the pattern changed after okkt_dist_comm_init: call okkt_dist_comm_init again");
   return OKKT_OK;
 }
 
@@ -283,6 +295,7 @@ int okkt_dist_factor(okkt_handle h, const double* d_nzval, int64_t n, int64_t m,
   if (!h->rccl_comm) return solver_set_error(h, OKKT_ERR_INVALID, "okkt_dist_comm_init has not been called");
   int rc = need_dist(h);
   if (rc != OKKT_OK) return rc;
+  if ((rc = dist_buffers_fit(h)) != OKKT_OK) return rc;
   if (n < 0 || m < 0 || n + m != h->S.n) return solver_set_error(h, OKKT_ERR_INVALID, "n + m does not match the analysed dimension");
   if (sym_kind != OKKT_SYM_DEFINITE && sym_kind != OKKT_SYM_SYMMETRIC) return solver_set_error(h, OKKT_ERR_INVALID, "unknown sym_kind");
   RcclApi& a = rccl();
@@ -324,6 +337,7 @@ int okkt_dist_solve(okkt_handle h, const double* d_rhs, double* d_sol) {
   if (!h->rccl_comm) return solver_set_error(h, OKKT_ERR_INVALID, "okkt_dist_comm_init has not been called");
   int rc = need_dist(h);
   if (rc != OKKT_OK) return rc;
+  if ((rc = dist_buffers_fit(h)) != OKKT_OK) return rc;
   if (!h->factored) return solver_set_error(h, OKKT_ERR_INVALID, "solve called before a factorisation");
   RcclApi& a = rccl();
   ncclComm_t comm = (ncclComm_t)h->rccl_comm;

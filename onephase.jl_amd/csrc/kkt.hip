@@ -130,6 +130,10 @@ __global__ void k_gather(int64_t n, const int64_t* __restrict__ idx, const doubl
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) dst[i] = src[idx[i]];
 }
+__global__ void k_scale(int64_t n, double a, const double* __restrict__ x, double* __restrict__ o) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) o[i] = a * x[i];
+}
 __global__ void k_div(int64_t n, const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ o) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) o[i] = a[i] / b[i];
@@ -332,6 +336,19 @@ __device__ __forceinline__ void block_max_store(double (&v)[NV], double* __restr
 }
 
 // y[i] = dot_i (* scale[i]) (+ beta * addv[i]): J x, J' v, Sigma .* (J x), rD + J' t, J dx - rP
+// is_diag_dom (delta_strategy.jl:1-9): margin[i] = 3 Q[i,i] - (sum(Q[:,i]) + sum(Q[i,:])) over the STORED entries of the x-block
+// (H lower-stored; the Schur matrix carries the full J' Sigma J on top).  hcol / hrow: column / row sums of the stored H,
+// jsj: row sum (= column sum) of J' Sigma J or NULL, qdiag: the block's diagonal without delta.  NaN compares false in Julia.
+__global__ void k_diag_dom_margin(int64_t n, const double* __restrict__ hcol, const double* __restrict__ hrow, const double* __restrict__ jsj,
+                                  const double* __restrict__ qdiag, double delta, double* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double d = qdiag[i] + delta;
+  const double cs = hcol[i] + (jsj ? jsj[i] : 0.0) + delta, rs = hrow[i] + (jsj ? jsj[i] : 0.0) + delta;
+  const double v = 3.0 * d - (cs + rs);
+  out[i] = (v != v) ? 1.0e308 : v;
+}
+
 template <int LPR>
 __global__ __launch_bounds__(256) void k_seg_spmv(int64_t nrows, const int64_t* __restrict__ ptr, const int* __restrict__ idx,
                                                   const double* __restrict__ vals, const double* __restrict__ x, const double* __restrict__ scale,
@@ -848,6 +865,72 @@ int okkt_kkt_diag_min(okkt_kkt_handle k, double* out) {
   return kk_reduce(k, k->n, k->schur_diag, 0, out);
 }
 
+// is_diag_dom(kkt_solver.Q[1:n,1:n]) of delta_strategy.jl:1-9,95 at the delta of the last factor call, on the device: O(nnz)
+// segmented sums instead of the reference's O(n nnz) sparse slicing.  out = 1 (dominant: the reference prints "Inertia
+// calculation incorrect" when the inertia flag was 0), 0 (not), -1 (not evaluated: clever-symmetric system).
+int okkt_kkt_is_diag_dom(okkt_kkt_handle k, int32_t* out) {
+  if (!k || !out) return OKKT_ERR_INVALID;
+  if (!k->formed) return kk_fail(k, OKKT_ERR_INVALID, "form_system has not been called");
+  *out = -1;
+  if (k->kind == OKKT_KKT_CLEVER_SYMMETRIC) return OKKT_OK;
+  const int64_t n = k->n, m = k->m;
+  if (n == 0) { *out = 1; return OKKT_OK; }
+  hipStream_t st = kk_stream(k);
+  if (!k->ones) {
+    const int64_t len = std::max(n, m);
+    int rc2 = kk_alloc(k, (size_t)len, &k->ones);
+    if (rc2 != OKKT_OK) return rc2;
+    std::vector<double> one((size_t)len, 1.0);
+    KK_TRY(k, hipMemcpyAsync(k->ones, one.data(), (size_t)len * 8, hipMemcpyHostToDevice, st));
+    KK_TRY(k, hipStreamSynchronize(st));
+  }
+  const bool schur = k->kind == OKKT_KKT_SCHUR || k->kind == OKKT_KKT_SCHUR_DIRECT;
+  // column sums of the stored H (CSC columns as rows of the segmented product), row sums (CSR copy)
+  SEG_LAUNCH(k_seg_spmv, k->lprH, n, st, n, k->Hp, k->Hi, k->Hx, k->ones, (const double*)nullptr, (const double*)nullptr, 0.0, k->vn1);
+  SEG_LAUNCH(k_seg_spmv, k->lprH, n, st, n, k->Hrp, k->Hrj, k->Hcsr, k->ones, (const double*)nullptr, (const double*)nullptr, 0.0, k->vn2);
+  if (schur && m) {   // (J' Sigma J) 1 = J' (Sigma .* (J 1)): row sums = column sums (symmetric block, stored in full)
+    SEG_LAUNCH(k_seg_spmv, k->lprJr, m, st, m, k->Jrp, k->Jrj, k->Jcsr, k->ones, k->sig, (const double*)nullptr, 0.0, k->vm2);
+    SEG_LAUNCH(k_seg_spmv, k->lprJc, n, st, n, k->Jp, k->Ji, k->Jx, k->vm2, (const double*)nullptr, (const double*)nullptr, 0.0, k->vn3);
+  }
+  hipLaunchKernelGGL(k_diag_dom_margin, grid1(n), dim3(256), 0, st, n, k->vn1, k->vn2, (schur && m) ? k->vn3 : (const double*)nullptr,
+                     schur ? k->schur_diag : k->Hdiag, k->delta, k->big1);
+  double mn = 0.0;
+  int rc = kk_reduce(k, n, k->big1, 0, &mn);
+  if (rc != OKKT_OK) return rc;
+  *out = mn < 0.0 ? 0 : 1;
+  return OKKT_OK;
+}
+int okkt_kkt_diag_dom_warnings(okkt_kkt_handle k, int32_t* count) {
+  if (!k || !count) return OKKT_ERR_INVALID;
+  *count = k->diag_dom_warnings;
+  return OKKT_OK;
+}
+
+// estimate_y_tilde's tail (guess-vars.jl:155-160) on the device: dx = F \ (-g), y = -J dx with the factor and the Jacobian
+// the handle holds (the Schur system of Sigma = I, H = lambda I, Cholesky semantics); nothing but g and y crosses PCIe
+int okkt_kkt_estimate_y_tilde(okkt_kkt_handle k, const double* g, double* y_out) {
+  if (!k || !g || !y_out) return OKKT_ERR_INVALID;
+  if (k->kind != OKKT_KKT_SCHUR && k->kind != OKKT_KKT_SCHUR_DIRECT) return kk_fail(k, OKKT_ERR_INVALID, "estimate_y_tilde runs on the Schur system");
+  if (!k->factored || !k->ls->factored) return kk_fail(k, OKKT_ERR_INVALID, "kkt solver not ready: factor! first");
+  const int64_t n = k->n, m = k->m;
+  hipStream_t st = kk_stream(k);
+  if (n) {
+    KK_TRY(k, hipMemcpyAsync(k->vn1, g, (size_t)n * 8, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_scale, grid1(n), dim3(256), 0, st, n, -1.0, k->vn1, k->vn2);
+    int rc = solver_solve_enqueue(k->ls, k->vn2, k->dx, 1, false);
+    if (rc != OKKT_OK) return kk_check_ls(k, rc, "ls_solve");
+  }
+  if (m) {
+    SEG_LAUNCH(k_seg_spmv, k->lprJr, m, st, m, k->Jrp, k->Jrj, k->Jcsr, k->dx, (const double*)nullptr, (const double*)nullptr, 0.0, k->vm1);
+    hipLaunchKernelGGL(k_scale, grid1(m), dim3(256), 0, st, m, -1.0, k->vm1, k->vm2);
+    KK_TRY(k, hipMemcpyAsync(y_out, k->vm2, (size_t)m * 8, hipMemcpyDeviceToHost, st));
+  }
+  KK_TRY(k, hipStreamSynchronize(st));
+  KK_TRY(k, hipGetLastError());
+  k->have_dir = false;
+  return OKKT_OK;
+}
+
 // factor!(kkt_solver, delta): update_delta! then factor! (kkt_system_solver.jl:98-113,190-204); the state machine of the
 // reference (:system_formed -> :delta_updated -> :factored) collapses into this one call.  trial: the caller throws a
 // factorisation with the wrong inertia away (the delta loop), so it may stop as soon as the flag is decided.
@@ -915,6 +998,17 @@ int okkt_kkt_ipopt_strategy(okkt_kkt_handle k, double delta_prev, const okkt_kkt
   // delta_strategy.jl:37-114
   int num_fac = 0;
   double dmin = 0.0;
+  k->diag_dom_warnings = 0;
+  // after a failed attempt the reference scans the x-block for diagonal dominance and prints a warning
+  // (delta_strategy.jl:94-98); here a device scan, counted for the glue to print (okkt_kkt_diag_dom_warnings)
+  auto scan_after_failure = [&]() -> int {
+    static const bool on = !(getenv("OKKT_DIAG_DOM_SCAN") && atoi(getenv("OKKT_DIAG_DOM_SCAN")) == 0);
+    if (!on) return OKKT_OK;
+    int32_t dom = -1;
+    const int rc3 = okkt_kkt_is_diag_dom(k, &dom);
+    if (rc3 == OKKT_OK && dom == 1) ++k->diag_dom_warnings;
+    return rc3;
+  };
   int rc = okkt_kkt_diag_min(k, &dmin);
   if (rc != OKKT_OK) return rc;
   double tau = 1.5 * dmin;
@@ -927,6 +1021,7 @@ int okkt_kkt_ipopt_strategy(okkt_kkt_handle k, double delta_prev, const okkt_kkt
     if (rc < 0) return rc;
     ++num_fac;
     if (rc == 1) { *num_fac_out = num_fac; *delta_out = delta; return 1; }
+    if ((rc = scan_after_failure()) < 0) return rc;
   }
   for (int i = 1; i <= P.max_it; ++i) {
     if (i == 1) {
@@ -941,7 +1036,17 @@ int okkt_kkt_ipopt_strategy(okkt_kkt_handle k, double delta_prev, const okkt_kkt
     *num_fac_out = num_fac;
     *delta_out = delta;
     if (rc == 1) return 1;
-    if (delta > P.delta_max) return 0;   // :failure
+    { const int rc3 = scan_after_failure(); if (rc3 < 0) return rc3; }
+    if (delta > P.delta_max) {   // :failure
+      // The reference's default initialiser does not look at the status: gertz_init.jl:25-27 runs ipopt_strategy!,
+      // kkt_associate_rhs! and compute_direction! whatever came back, i.e. it solves with the failed factor of the last
+      // delta.  A trial that stopped early has no factor to solve with: complete it (not counted as an attempt).
+      if (!k->ls->factored) {
+        rc = okkt_kkt_factor(k, delta, nullptr);
+        if (rc < 0) return rc;
+      }
+      return 0;
+    }
   }
   return kk_fail(k, OKKT_ERR_INTERNAL, "max it");   // error("max it"), delta_strategy.jl:113
 }

@@ -40,6 +40,8 @@ struct okkt_kkt_s {
   double *rD = nullptr, *rP = nullptr, *rC = nullptr, *dx = nullptr, *dy = nullptr, *ds = nullptr;
   double *vn1 = nullptr, *vn2 = nullptr, *vn3 = nullptr, *vm1 = nullptr, *vm2 = nullptr, *big1 = nullptr, *big2 = nullptr;
   double* red = nullptr;  // reduction outputs
+  double* ones = nullptr; // max(n, m) ones (row / column sums of the diagonal-dominance scan), allocated on first use
+  int diag_dom_warnings = 0;   // failed attempts of the last ipopt_strategy! whose x-block was diagonally dominant (delta_strategy.jl:95)
   // step-side kernels (linesearch.hip): staged host vectors and reduction partials, allocated on first use
   double *ls_m[4] = {nullptr, nullptr, nullptr, nullptr}, *ls_n[2] = {nullptr, nullptr}, *ls_part = nullptr, *ls_out = nullptr;
   double* Jcur = nullptr; // Jacobian values of a current iterate that differs from the factorised one

@@ -554,7 +554,7 @@ void induced(const Graph& g, const std::vector<int>& label, const std::vector<in
 
 void nd_rec(NdCtx& cx, Graph g, std::vector<int> label, int* out, int depth, uint64_t seed) {
   if (g.n <= cx.leaf) { amd_leaf(g, label, out); return; }
-  const double max_frac = 0.6;
+  static const double max_frac = getenv("OKKT_MLND_FRAC") ? atof(getenv("OKKT_MLND_FRAC")) : 0.6;
   const int ntrial = depth < 2 ? cx.ntrial_top : 1;
   std::vector<std::vector<int8_t>> cand(ntrial);
   {
@@ -634,8 +634,8 @@ void ml_nd_order(int n, const std::vector<int64_t>& gp, const std::vector<int>& 
   g.ew.assign(g.adj.size(), 1);
   g.tvw = g.n;
   NdCtx cx;
-  cx.leaf = std::max(leaf, 32);
-  cx.ntrial_top = std::max(1, ntrial_top);
+  cx.leaf = std::max(getenv("OKKT_MLND_LEAF") ? atoi(getenv("OKKT_MLND_LEAF")) : leaf, 32);
+  cx.ntrial_top = std::max(1, getenv("OKKT_MLND_TRIALS") ? atoi(getenv("OKKT_MLND_TRIALS")) : ntrial_top);
   int hw = (int)std::thread::hardware_concurrency();
   if (getenv("OKKT_ANALYZE_THREADS")) hw = atoi(getenv("OKKT_ANALYZE_THREADS"));
   cx.threads_free.store(std::max(0, std::min(hw, 32) - 1));

@@ -98,8 +98,21 @@ struct SolveLevel {
   int wide_off = 0, wide_cnt = 0, wide_maxf = 0, wide_maxk = 0;
 };
 
+// Lanes: independent subtrees of ONE factorisation that run side by side on separate streams of the same GPU (the two halves
+// below the top separator of a nested-dissection tree); lane 0 is `levels` / `slevels`, the others live here, the part of the
+// tree above them is `levels_top`.  Empty when the tree has no two substantial independent subtrees or the plan is partitioned
+// over several GPUs.
+struct LaneSched { std::vector<LevelSchedule> levels; std::vector<SolveLevel> slevels; hipStream_t stream = nullptr; };
+struct LaneStreams { hipStream_t main = nullptr, masked = nullptr, panel = nullptr, aux = nullptr; };
+
 struct Numeric {
   DevPlan d;
+  std::vector<LaneSched> xlanes;         // lanes 1, 2, ...
+  std::vector<hipEvent_t> lane_events;   // fork / join of the lanes
+  size_t lane_ev_used = 0;
+  bool early_before_top = false;         // lanes: the pivot counts are read once, between the lanes and the top of the tree
+  std::vector<double> lane_flops;        // dense-front flops per lane (statistics)
+  double lanes_top_flops = 0;
   std::vector<SolveLevel> slevels, slevels_top;
   hipEvent_t inv_event = nullptr;        // recorded behind the block inversions that the factorisation started on the auxiliary stream
   bool inv_wait = false;                 // ... which the next solve has to wait for

@@ -79,8 +79,7 @@ __global__ void k_fold_counts(DevPlan P) {
   unsigned long long sum = 0;
   for (int q = 1; q < kCountSlots; ++q) {
     unsigned long long* w = P.counters + (size_t)q * kCountStride + c;
-    sum += *w;
-    *w = 0;
+    sum += atomicExch(w, 0ull);     // two lanes may fold at the same time: every count is taken exactly once
   }
   const unsigned long long tot = atomicAdd(&P.counters[c], sum) + sum;
   const bool fail = c == 0 ? tot > (unsigned long long)P.want_pos : c == 1 ? tot > (unsigned long long)P.want_neg : tot > 0;
@@ -1158,6 +1157,29 @@ std::string numeric_setup(const Symbolic& S, const SymbolicOptions& opts, hipStr
   int64_t wtotal = 0;
   N.n_small = N.n_big = 0;
   const bool parted = S.nparts > 1 && (int)S.sn_owner.size() == ns;
+  // lanes (see numeric.h): only for an unpartitioned plan with the extra streams at hand
+  std::vector<int> lane_of;
+  N.xlanes.clear(); N.lane_flops.clear(); N.lanes_top_flops = 0; N.early_before_top = false;
+  {
+    const int want = getenv("OKKT_LANES") ? atoi(getenv("OKKT_LANES")) : 1;   // off by default: measured neutral
+    const int avail = 1 + (N.stream_aux ? 1 : 0) + (N.stream_aux && N.stream_panel ? 1 : 0);
+    const int nl = std::min(std::min(want, avail), 3);
+    if (!parted && nl >= 2) {
+      const double own_frac = getenv("OKKT_LANE_OWN_FRAC") ? atof(getenv("OKKT_LANE_OWN_FRAC")) : 0.08;
+      const double min_frac = getenv("OKKT_LANE_MIN_FRAC") ? atof(getenv("OKKT_LANE_MIN_FRAC")) : 0.05;
+      lane_cut(S, nl, own_frac, min_frac, lane_of, N.lane_flops, N.lanes_top_flops);
+      if (!lane_of.empty()) {
+        N.xlanes.resize(nl - 1);
+        for (int i = 1; i < nl; ++i) N.xlanes[i - 1].stream = i == 1 ? N.stream_aux : N.stream_panel;
+        if (getenv("OKKT_DEBUG_FRONTS")) {
+          fprintf(stderr, "okkt: %d lanes, flops", nl);
+          for (double x : N.lane_flops) fprintf(stderr, " %.3g", x);
+          fprintf(stderr, ", top %.3g\n", N.lanes_top_flops);
+        }
+      }
+    }
+  }
+  const bool laned = !lane_of.empty();
   // Tasks: a workgroup runs a whole subtree of small fronts, children before parents (the supernodes are numbered
   // in postorder, so a subtree is the index range [first descendant, root]); one launch per LEVEL OF TASKS instead of
   // one per level of fronts.  A banded KKT (the hanging chain of BASELINE config 2) has an elimination tree that is
@@ -1234,8 +1256,9 @@ std::string numeric_setup(const Symbolic& S, const SymbolicOptions& opts, hipStr
     for (int l = 0; l < nulev; ++l) {
       std::vector<int> cls[kNumClasses];
       for (int s : units_at[l]) {
-        if (parted && S.sn_owner[s] != want_owner) continue;
-        if (!parted && want_owner == -1) continue;
+        if (parted) { if (S.sn_owner[s] != want_owner) continue; }
+        else if (laned) { if (lane_of[s] != want_owner) continue; }
+        else if (want_owner != 0) continue;
         int f = 0;                                            // largest front of the unit decides the class
         for (int t = task_lo[s]; t <= s; ++t) f = std::max(f, (int)(S.row_ptr[t + 1] - S.row_ptr[t]));
         int c = f <= 32 ? 0 : (f <= 64 ? 1 : (f <= N.small_max ? 2 : 3));
@@ -1273,7 +1296,14 @@ std::string numeric_setup(const Symbolic& S, const SymbolicOptions& opts, hipStr
     }
   };
   build(N.levels, parted ? N.part_id : 0);
-  if (parted && N.part_id == 0) build(N.levels_top, -1); else N.levels_top.clear();
+  for (size_t i = 0; i < N.xlanes.size(); ++i) build(N.xlanes[i].levels, (int)i + 1);
+  if ((parted && N.part_id == 0) || laned) build(N.levels_top, -1); else N.levels_top.clear();
+  if (laned) {
+    double tot = N.lanes_top_flops;
+    for (double x : N.lane_flops) tot += x;
+    N.early_before_top = N.lanes_top_flops >= 0.3 * tot;
+    N.early_level = -1;    // the in-loop check belongs to the single-schedule plan
+  }
   if (!(e = upload(N, sched, &d.sched)).empty()) return e;
   if (!(e = upload(N, task_lo, &d.task_lo)).empty()) return e;
   if (getenv("OKKT_DEBUG_FRONTS")) fprintf(stderr, "okkt: %d levels of units (%d levels of fronts), %lld tasks of small fronts, longest %d\n", nulev, S.nlevels, (long long)N.n_tasks, N.max_task_len);
@@ -1418,6 +1448,11 @@ void numeric_release(Numeric& N) {
   for (void* p : N.allocations) (void)hipFree(p);
   N.allocations.clear();
   N.levels.clear();
+  N.levels_top.clear();
+  N.xlanes.clear();
+  for (hipEvent_t ev : N.lane_events) (void)hipEventDestroy(ev);
+  N.lane_events.clear();
+  N.lane_ev_used = 0;
   N.slevels.clear();
   N.slevels_top.clear();
   N.d = DevPlan();
@@ -1436,24 +1471,104 @@ std::string numeric_read_counts(Numeric& N, hipStream_t stream, unsigned long lo
   return "";
 }
 
+namespace {
+hipEvent_t lane_event(Numeric& N) {
+  if (N.lane_ev_used >= N.lane_events.size()) {
+    hipEvent_t e2 = nullptr;
+    if (hipEventCreateWithFlags(&e2, hipEventDisableTiming) != hipSuccess) return nullptr;
+    N.lane_events.push_back(e2);
+  }
+  return N.lane_events[N.lane_ev_used++];
+}
+}  // namespace
+
+// `from` -> every lane stream (fork) or every lane stream -> `to` (join)
+std::string lanes_fork(Numeric& N, hipStream_t from) {
+  if (N.xlanes.empty()) return "";
+  hipEvent_t ev = lane_event(N);
+  if (!ev) return "hipEventCreate failed";
+  OKKT_HIP_TRY(hipEventRecord(ev, from));
+  for (LaneSched& X : N.xlanes) OKKT_HIP_TRY(hipStreamWaitEvent(X.stream, ev, 0));
+  return "";
+}
+std::string lanes_join(Numeric& N, hipStream_t to) {
+  for (LaneSched& X : N.xlanes) {
+    hipEvent_t ev = lane_event(N);
+    if (!ev) return "hipEventCreate failed";
+    OKKT_HIP_TRY(hipEventRecord(ev, X.stream));
+    OKKT_HIP_TRY(hipStreamWaitEvent(to, ev, 0));
+  }
+  return "";
+}
+
+// one schedule (a lane, the local subtrees of a part, or the top of the tree) on the streams of `ss`
+static std::string factor_sched(Numeric& N, DevPlan P, const std::vector<LevelSchedule>& levels, const std::vector<SolveLevel>& slevels,
+                                const LaneStreams& ss, double tol, bool in_loop_check, bool& inv_on_aux, size_t l_begin = 0, size_t l_end = (size_t)-1);
+
 std::string numeric_factor_enqueue(Numeric& N, const double* d_vals, double tol, int which, bool reset_counters) {
   DevPlan P = N.d;
   P.vals = d_vals;
   hipStream_t st = N.stream;
-  const std::vector<LevelSchedule>& levels = which == 0 ? N.levels : N.levels_top;
+  const bool laned = which == 0 && !N.xlanes.empty();
   if (reset_counters) OKKT_HIP_TRY(hipMemsetAsync(P.counters, 0, (size_t)kCountSlots * kCountStride * sizeof(unsigned long long), st));
-  if (N.early_check && N.early_device && which == 0 && N.levels_top.empty() && reset_counters) { P.want_pos = N.early_n; P.want_neg = N.early_m; }
+  if (N.early_check && N.early_device && which == 0 && (N.levels_top.empty() || laned) && reset_counters) { P.want_pos = N.early_n; P.want_neg = N.early_m; }
   N.la_used = 0;
-  N.inv_wait = false;            // the block inverses belong to the previous factorisation
+  if (which == 0) N.inv_wait = false;   // the block inverses belong to the previous factorisation (the top phase of a partitioned
+                                        // plan keeps the wait its local phase has set up)
   bool inv_on_aux = false;
   N.early_exited = false;
+  std::string e;
+  if (!laned) {
+    const LaneStreams ss{N.stream, N.stream_masked, N.stream_panel, N.stream_aux};
+    e = factor_sched(N, P, which == 0 ? N.levels : N.levels_top, which == 0 ? N.slevels : N.slevels_top, ss, tol,
+                     which == 0 && N.levels_top.empty(), inv_on_aux);
+    if (!e.empty()) return e;
+  } else {
+    // lanes side by side (lane 0 keeps the look-ahead streams, the others are single streams), then the top of the tree
+    N.lane_ev_used = 0;
+    if (!(e = lanes_fork(N, st)).empty()) return e;
+    bool dummy = false;
+    const LaneStreams s0{N.stream, N.stream_masked, N.xlanes.size() >= 2 ? nullptr : N.stream_panel, nullptr};
+    // enqueued level by level in turn: a stream's launches reach the GPU in host order, and a lane whose launches are all
+    // queued behind the whole of another lane starts when that one is nearly done
+    for (size_t l = 0; l < N.levels.size(); ++l) {
+      if (!(e = factor_sched(N, P, N.levels, N.slevels, s0, tol, false, dummy, l, l + 1)).empty()) return e;
+      for (LaneSched& X : N.xlanes) {
+        const LaneStreams sx{X.stream, nullptr, nullptr, nullptr};
+        if (!(e = factor_sched(N, P, X.levels, X.slevels, sx, tol, false, dummy, l, l + 1)).empty()) return e;
+      }
+    }
+    if (!(e = lanes_join(N, st)).empty()) return e;
+    if (N.early_check && N.early_before_top) {
+      unsigned long long cnt[5] = {0, 0, 0, 0, 0};
+      if (!(e = numeric_read_counts(N, st, cnt)).empty()) return e;
+      if (cnt[4] != 0 || cnt[3] > 0 || cnt[2] > 0 || cnt[1] > (unsigned long long)N.early_m || cnt[0] > (unsigned long long)N.early_n) {
+        N.early_exited = true;
+        return "";
+      }
+    }
+    const LaneStreams ss{N.stream, N.stream_masked, N.stream_panel, N.stream_aux};
+    if (!(e = factor_sched(N, P, N.levels_top, N.slevels_top, ss, tol, false, inv_on_aux)).empty()) return e;
+  }
+  if (inv_on_aux) {    // the next solve waits for the block inversions that are still running on the auxiliary stream
+    if (!N.inv_event) OKKT_HIP_TRY(hipEventCreateWithFlags(&N.inv_event, hipEventDisableTiming));
+    OKKT_HIP_TRY(hipEventRecord(N.inv_event, N.stream_aux));
+    N.inv_wait = true;
+  }
+  OKKT_HIP_TRY(hipGetLastError());
+  return "";
+}
+
+static std::string factor_sched(Numeric& N, DevPlan P, const std::vector<LevelSchedule>& levels, const std::vector<SolveLevel>& slevels,
+                                const LaneStreams& ss, double tol, bool in_loop_check, bool& inv_on_aux, size_t l_begin, size_t l_end) {
+  hipStream_t st = ss.main;
   const int NB = N.nb;
   static const int dbg_syrk = getenv("OKKT_DEBUG_SYRK") ? atoi(getenv("OKKT_DEBUG_SYRK")) : 0;
   static const int split_min_rows = getenv("OKKT_SPLIT_MIN_ROWS") ? atoi(getenv("OKKT_SPLIT_MIN_ROWS")) : 5000;
   static const int dbg_stop = getenv("OKKT_DEBUG_DIAG_STOP") ? atoi(getenv("OKKT_DEBUG_DIAG_STOP")) : 0;
-  for (size_t l = 0; l < levels.size(); ++l) {
+  for (size_t l = l_begin; l < std::min(l_end, levels.size()); ++l) {
     const LevelSchedule& L = levels[l];
-    if (N.early_check && which == 0 && (int)l == N.early_level && N.levels_top.empty()) {
+    if (N.early_check && in_loop_check && (int)l == N.early_level) {
       // the pivots counted so far already decide a wrong inertia?  Then the (expensive) rest of the tree is skipped:
       // one synchronisation per factorisation, 35 of 49 ms saved per failed attempt of the delta loop at S-metric
       unsigned long long cnt[5] = {0, 0, 0, 0, 0};
@@ -1498,7 +1613,7 @@ std::string numeric_factor_enqueue(Numeric& N, const double* d_vals, double tol,
       // look-ahead for the trailing update of the super-step that starts at block column stepA (gs_cur wide)?
       auto la_at = [&](int stepA, int gs_cur) {
         const int stepB = stepA + gs_cur;
-        if (stepB >= nsteps || !N.lookahead || N.stream_panel == nullptr || N.stream_masked == nullptr) return false;
+        if (stepB >= nsteps || !N.lookahead || ss.panel == nullptr || ss.masked == nullptr) return false;
         const int remr = g.maxf - (stepB + gs_at(stepB)) * NB;     // rows of the rest triangle (upper bound)
         const int Trr = remr > 0 ? (remr + 127) / 128 : 0;
         return (int64_t)Trr * (Trr + 1) / 2 * g.cnt >= N.la_min_tiles;
@@ -1506,14 +1621,14 @@ std::string numeric_factor_enqueue(Numeric& N, const double* d_vals, double tol,
       // A level that uses the look-ahead runs on the CU-masked twin of the handle's stream (the reserved CUs belong
       // to the panel streams); every other level keeps all CUs
       const bool seg_la = la_at(0, gs_at(0));
-      hipStream_t st = N.stream;
+      hipStream_t st = ss.main;
       if (seg_la) {
         hipEvent_t evf;
         std::string e = next_event(&evf);
         if (!e.empty()) return e;
-        OKKT_HIP_TRY(hipEventRecord(evf, N.stream));
-        OKKT_HIP_TRY(hipStreamWaitEvent(N.stream_masked, evf, 0));
-        st = N.stream_masked;
+        OKKT_HIP_TRY(hipEventRecord(evf, ss.main));
+        OKKT_HIP_TRY(hipStreamWaitEvent(ss.masked, evf, 0));
+        st = ss.masked;
       }
       {
         // LDS-resident columns up to 2048 rows (16 KiB per wave); smaller fronts take less LDS for more waves per CU
@@ -1598,15 +1713,15 @@ std::string numeric_factor_enqueue(Numeric& N, const double* d_vals, double tol,
           // other tiles run on the auxiliary stream beside k_big_diag and are joined before k_big_trsm
           hipEvent_t ev_rest = nullptr;
           if (i > 0) {
-            const bool split = N.stream_aux != nullptr && N.split_head && rem_rows(step) > split_min_rows;   // the two extra stream hops cost more than they hide on small fronts
+            const bool split = ss.aux != nullptr && N.split_head && rem_rows(step) > split_min_rows;   // the two extra stream hops cost more than they hide on small fronts
             if (split) {
               hipEvent_t ev_t;
               std::string e = next_event(&ev_t);
               if (!e.empty() || !(e = next_event(&ev_rest)).empty()) return e;
               OKKT_HIP_TRY(hipEventRecord(ev_t, pst));                         // trsm of panel i - 1 is behind this
-              OKKT_HIP_TRY(hipStreamWaitEvent(N.stream_aux, ev_t, 0));
-              if (!(e = launch_syrk(N.stream_aux, stepA, i, step, 1, par, 0, 2)).empty()) return e;
-              OKKT_HIP_TRY(hipEventRecord(ev_rest, N.stream_aux));
+              OKKT_HIP_TRY(hipStreamWaitEvent(ss.aux, ev_t, 0));
+              if (!(e = launch_syrk(ss.aux, stepA, i, step, 1, par, 0, 2)).empty()) return e;
+              OKKT_HIP_TRY(hipEventRecord(ev_rest, ss.aux));
               if (!(e = launch_syrk(pst, stepA, i, step, 1, par, 0, 1)).empty()) return e;
             } else {
               std::string e = launch_syrk(pst, stepA, i, step, 1, par, 0);
@@ -1641,9 +1756,9 @@ std::string numeric_factor_enqueue(Numeric& N, const double* d_vals, double tol,
       // of the level; the kSolveBlock-column ones of the wide fronts run on the auxiliary stream beside the next levels.
       // A front of at least two such blocks starts early: the blocks that are final when it enters its chain-bound tail
       // (fewer than sb_tail_rows rows left, idle CUs) are inverted during the tail, the rest behind the last panel.
-      const SolveLevel& SL = (which == 0 ? N.slevels : N.slevels_top)[l];
-      hipStream_t inv_st = N.stream_aux ? N.stream_aux : st;
-      const bool inv_early = N.stream_aux != nullptr && SL.wide_cnt > 0 && g.maxk >= 2 * kSolveBlock && N.sb_tail_rows >= 0;
+      const SolveLevel& SL = slevels[l];
+      hipStream_t inv_st = ss.aux ? ss.aux : st;
+      const bool inv_early = ss.aux != nullptr && SL.wide_cnt > 0 && g.maxk >= 2 * kSolveBlock && N.sb_tail_rows >= 0;
       int inv_steps_done = 0, inv_blocks_done = 0;
       const size_t lds_inv = ((size_t)(NB + 2) * NB + 3 * kTld * kIB) * sizeof(double);
       auto inv_range = [&](int steps_final, bool last) -> std::string {
@@ -1689,10 +1804,10 @@ std::string numeric_factor_enqueue(Numeric& N, const double* d_vals, double tol,
           hipEvent_t eva, evp;
           if (!(e = next_event(&eva)).empty() || !(e = next_event(&evp)).empty()) return e;
           OKKT_HIP_TRY(hipEventRecord(eva, st));                     // rest(q - 1) (and Panel(0)) are behind this
-          OKKT_HIP_TRY(hipStreamWaitEvent(N.stream_panel, eva, 0));
-          if (!(e = launch_syrk(N.stream_panel, stepA, gs_cur, stepB, 2, par, gs_next)).empty()) return e;
-          if (!(e = launch_panels(N.stream_panel, stepB, gs_next, par ^ 1)).empty()) return e;
-          OKKT_HIP_TRY(hipEventRecord(evp, N.stream_panel));
+          OKKT_HIP_TRY(hipStreamWaitEvent(ss.panel, eva, 0));
+          if (!(e = launch_syrk(ss.panel, stepA, gs_cur, stepB, 2, par, gs_next)).empty()) return e;
+          if (!(e = launch_panels(ss.panel, stepB, gs_next, par ^ 1)).empty()) return e;
+          OKKT_HIP_TRY(hipEventRecord(evp, ss.panel));
           if (ev_panel) OKKT_HIP_TRY(hipStreamWaitEvent(st, ev_panel, 0));
           if (!(e = launch_syrk(st, stepA, gs_cur, stepB, 3, par, gs_next)).empty()) return e;
           ev_panel = evp;
@@ -1714,16 +1829,10 @@ std::string numeric_factor_enqueue(Numeric& N, const double* d_vals, double tol,
         hipEvent_t evj;
         if (!(e = next_event(&evj)).empty()) return e;
         OKKT_HIP_TRY(hipEventRecord(evj, st));
-        OKKT_HIP_TRY(hipStreamWaitEvent(N.stream, evj, 0));
+        OKKT_HIP_TRY(hipStreamWaitEvent(ss.main, evj, 0));
       }
     }
   }
-  if (inv_on_aux) {    // the next solve waits for the block inversions that are still running on the auxiliary stream
-    if (!N.inv_event) OKKT_HIP_TRY(hipEventCreateWithFlags(&N.inv_event, hipEventDisableTiming));
-    OKKT_HIP_TRY(hipEventRecord(N.inv_event, N.stream_aux));
-    N.inv_wait = true;
-  }
-  OKKT_HIP_TRY(hipGetLastError());
   return "";
 }
 
@@ -1731,13 +1840,14 @@ std::string numeric_factor_enqueue(Numeric& N, const double* d_vals, double tol,
 std::string numeric_solve_enqueue(Numeric& N, int R) {
   std::string e;
   static const int dbg_phase = getenv("OKKT_DEBUG_SOLVE_PHASE") ? atoi(getenv("OKKT_DEBUG_SOLVE_PHASE")) : 0;   // 1: forward sweep only (z = D^-1 L^-1 P b)
+  const bool laned = !N.xlanes.empty();    // then which = 0 covers the lanes AND the top of the tree
   if (!(e = solve_fwd_enqueue(N, 0, R)).empty()) return e;
-  if (!(e = solve_fwd_enqueue(N, 1, R)).empty()) return e;
+  if (!laned && !(e = solve_fwd_enqueue(N, 1, R)).empty()) return e;
   if (dbg_phase == 1) {   // the caller reads the sweep's result where it expects the solution
     OKKT_HIP_TRY(hipMemcpyAsync(N.d.xwork, N.d.zwork, (size_t)N.d.n * kMaxRhs * sizeof(double), hipMemcpyDeviceToDevice, N.stream));
     return "";
   }
-  if (!(e = solve_bwd_enqueue(N, 1, R)).empty()) return e;
+  if (!laned && !(e = solve_bwd_enqueue(N, 1, R)).empty()) return e;
   return solve_bwd_enqueue(N, 0, R);
 }
 

@@ -874,6 +874,7 @@ std::string solve_setup(const Symbolic& S, Numeric& N) {
     }
   };
   build(N.levels, N.slevels);
+  for (LaneSched& X : N.xlanes) build(X.levels, X.slevels);
   build(N.levels_top, N.slevels_top);
   std::string e;
   if (!(e = up(N, ssched, &d.ssched)).empty()) return e;
@@ -915,12 +916,9 @@ std::string solve_invert_enqueue(Numeric& N, hipStream_t st, const SolveLevel& L
 }
 
 template <int R>
-static std::string fwd_enqueue_r(Numeric& N, int which) {
+static std::string fwd_enqueue_r(Numeric& N, const std::vector<LevelSchedule>& levels, const std::vector<SolveLevel>& sl, hipStream_t st, int l_lo, int l_hi) {
   DevPlan P = N.d;
-  hipStream_t st = N.stream;
-  const std::vector<LevelSchedule>& levels = which == 0 ? N.levels : N.levels_top;
-  const std::vector<SolveLevel>& sl = which == 0 ? N.slevels : N.slevels_top;
-  for (size_t l = 0; l < levels.size(); ++l) {
+  for (size_t l = (size_t)l_lo; l < std::min((size_t)l_hi, levels.size()); ++l) {
     const LevelSchedule& L = levels[l];
     for (int c = 0; c < 3; ++c) {
       const Segment& g = L.seg[c];
@@ -951,12 +949,9 @@ static std::string fwd_enqueue_r(Numeric& N, int which) {
 }
 
 template <int R>
-static std::string bwd_enqueue_r(Numeric& N, int which) {
+static std::string bwd_enqueue_r(Numeric& N, const std::vector<LevelSchedule>& levels, const std::vector<SolveLevel>& sl, hipStream_t st, int l_lo, int l_hi) {
   DevPlan P = N.d;
-  hipStream_t st = N.stream;
-  const std::vector<LevelSchedule>& levels = which == 0 ? N.levels : N.levels_top;
-  const std::vector<SolveLevel>& sl = which == 0 ? N.slevels : N.slevels_top;
-  for (int l = (int)levels.size() - 1; l >= 0; --l) {
+  for (int l = std::min(l_hi, (int)levels.size()) - 1; l >= l_lo; --l) {
     const LevelSchedule& L = levels[l];
     const SolveLevel& S = sl[l];
     if (S.wide_cnt) {
@@ -987,12 +982,43 @@ static std::string bwd_enqueue_r(Numeric& N, int which) {
   return "";
 }
 
+std::string lanes_fork(Numeric& N, hipStream_t from);
+std::string lanes_join(Numeric& N, hipStream_t to);
+
+static std::string sweep(Numeric& N, bool fwd, const std::vector<LevelSchedule>& levels, const std::vector<SolveLevel>& sl, hipStream_t st, int R,
+                         int l_lo = 0, int l_hi = 1 << 30) {
+  if (fwd) return R == 1 ? fwd_enqueue_r<1>(N, levels, sl, st, l_lo, l_hi) : (R == 2 ? fwd_enqueue_r<2>(N, levels, sl, st, l_lo, l_hi) : fwd_enqueue_r<4>(N, levels, sl, st, l_lo, l_hi));
+  return R == 1 ? bwd_enqueue_r<1>(N, levels, sl, st, l_lo, l_hi) : (R == 2 ? bwd_enqueue_r<2>(N, levels, sl, st, l_lo, l_hi) : bwd_enqueue_r<4>(N, levels, sl, st, l_lo, l_hi));
+}
+
+// which = 0: the local subtrees -- with lanes, every lane on its own stream (forked from / joined into the handle's stream)
+// followed (forward) or preceded (backward) by the top of the tree; which = 1: the top schedule of a partitioned plan
+static std::string sweep_which(Numeric& N, bool fwd, int which, int R) {
+  std::string e;
+  if (which != 0) return sweep(N, fwd, N.levels_top, N.slevels_top, N.stream, R);
+  if (N.xlanes.empty()) return sweep(N, fwd, N.levels, N.slevels, N.stream, R);
+  if (!fwd && !(e = sweep(N, false, N.levels_top, N.slevels_top, N.stream, R)).empty()) return e;
+  if (!(e = lanes_fork(N, N.stream)).empty()) return e;
+  // level by level in turn (host order = submission order: see numeric_factor_enqueue)
+  const int nl = (int)N.levels.size();
+  for (int q = 0; q < nl; ++q) {
+    const int l = fwd ? q : nl - 1 - q;
+    if (!(e = sweep(N, fwd, N.levels, N.slevels, N.stream, R, l, l + 1)).empty()) return e;
+    for (LaneSched& X : N.xlanes)
+      if (!(e = sweep(N, fwd, X.levels, X.slevels, X.stream, R, l, l + 1)).empty()) return e;
+  }
+  if (!(e = lanes_join(N, N.stream)).empty()) return e;
+  if (fwd && !(e = sweep(N, true, N.levels_top, N.slevels_top, N.stream, R)).empty()) return e;
+  return "";
+}
+
 std::string solve_fwd_enqueue(Numeric& N, int which, int R) {
   if (which == 0 && N.inv_wait) { OKKT_HIP_TRY(hipStreamWaitEvent(N.stream, N.inv_event, 0)); N.inv_wait = false; }   // inversions started by the factorisation
-  return R == 1 ? fwd_enqueue_r<1>(N, which) : (R == 2 ? fwd_enqueue_r<2>(N, which) : fwd_enqueue_r<4>(N, which));
+  if (which == 0) N.lane_ev_used = 0;
+  return sweep_which(N, true, which, R);
 }
 std::string solve_bwd_enqueue(Numeric& N, int which, int R) {
-  return R == 1 ? bwd_enqueue_r<1>(N, which) : (R == 2 ? bwd_enqueue_r<2>(N, which) : bwd_enqueue_r<4>(N, which));
+  return sweep_which(N, false, which, R);
 }
 
 void solve_permute_in(const Numeric& N, const double* d_rhs, int64_t stride, int nr, int R) {

@@ -41,6 +41,7 @@ struct okkt_solver_s {
   void* rccl_comm = nullptr;
   int rccl_nranks = 0, rccl_rank = 0;
   double *dist_cb = nullptr, *dist_cv = nullptr, *dist_x = nullptr;
+  size_t dist_cb_cap = 0, dist_cv_cap = 0, dist_x_cap = 0;   // doubles the exchange buffers were allocated for (okkt_dist_comm_init)
   long long* dist_counts = nullptr;  // 4 summed pivot counts on the device
   double* d_rhs_stage = nullptr;  // staging for host-side rhs/sol
   int64_t rhs_stage_len = 0;

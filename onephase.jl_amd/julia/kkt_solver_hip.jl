@@ -21,14 +21,14 @@ mutable struct HIP_KKT_solver <: abstract_KKT_system_solver
     pattern_set::Bool
     current_it::Class_iterate                    # iterate of the last kkt_associate_rhs! (schur.jl:34-45)
     reduct_factors::Class_reduction_factors
-    rhs_resident::Bool                           # k.rhs is the triple okkt_kkt_system_rhs left in HBM
+    resident_rhs::Any                            # the System_rhs object whose triple okkt_kkt_system_rhs left in HBM (nothing: none)
 
     function HIP_KKT_solver(kind::Symbol)
         this = new()
         this.ready = :not_ready
         this.kind = Dict(:schur => 0, :symmetric => 1, :clever_symmetric => 2, :schur_direct => 3)[kind]
         this.pattern_set = false
-        this.rhs_resident = false
+        this.resident_rhs = nothing
         h = Ref{Ptr{Cvoid}}(C_NULL)
         rc = ccall((:okkt_kkt_create, OKKT_LIB), Cint, (Ref{Ptr{Cvoid}}, Ptr{Cvoid}, Cint), h, C_NULL, this.kind)
         rc == 0 || error("okkt_kkt_create failed with code $rc")
@@ -143,7 +143,8 @@ function kkt_associate_rhs!(k::HIP_KKT_solver, iter::Class_iterate, reduct_facto
             reduct_factors.P, reduct_factors.D, reduct_factors.mu, rD, rP, rC))
     end
     k.rhs = System_rhs(rD, rP, rC)
-    k.rhs_resident = true
+    k.resident_rhs = k.rhs     # identity, not a flag: reference code that assigns k.rhs afterwards (compute_eigenvector!,
+                               # kkt_system_solver.jl:205-228) must get ITS rhs solved, not the stale device copy
     k.dir.mu = -(1.0 - reduct_factors.mu) * get_mu(iter)
     k.dir.primal_scale = -(1.0 - reduct_factors.P) * iter.point.primal_scale
     k.reduct_factors = reduct_factors
@@ -155,11 +156,16 @@ function compute_direction_implementation!(k::HIP_KKT_solver, timer::class_advan
     n = dim(k.factor_it); m = ncon(k.factor_it)
     dx = zeros(n); dy = zeros(m); ds = zeros(m)
     err = zeros(6)
-    # resident rhs: three NULLs (nothing crosses PCIe on the way in); a rhs the caller replaced on the host is uploaded
-    r = k.rhs_resident ? (C_NULL, C_NULL, C_NULL) : (pointer(k.rhs.dual_r), pointer(k.rhs.primal_r), pointer(k.rhs.comp_r))
-    kkt_hip_check(k, "okkt_kkt_compute_direction", ccall((:okkt_kkt_compute_direction, OKKT_LIB), Cint,
-        (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
-        k.handle, r[1], r[2], r[3], Int32(k.pars.kkt.ItRefine_Num), dx, dy, ds, err))
+    # resident rhs (k.rhs is still the object kkt_associate_rhs! created): three NULLs, nothing crosses PCIe on the way in;
+    # a rhs the caller replaced on the host is uploaded
+    rhs = k.rhs
+    resident = rhs === k.resident_rhs
+    GC.@preserve rhs begin
+        r = resident ? (C_NULL, C_NULL, C_NULL) : (pointer(rhs.dual_r), pointer(rhs.primal_r), pointer(rhs.comp_r))
+        kkt_hip_check(k, "okkt_kkt_compute_direction", ccall((:okkt_kkt_compute_direction, OKKT_LIB), Cint,
+            (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+            k.handle, r[1], r[2], r[3], Int32(k.pars.kkt.ItRefine_Num), dx, dy, ds, err))
+    end
     k.dir.x = dx; k.dir.y = dy; k.dir.s = ds
     check_for_nan(k.dir)
     k.kkt_err_norm = Class_kkt_error(err[1], err[2], err[3], err[4], err[5], err[6])

@@ -369,7 +369,26 @@ class HIP_KKT_solver:
         self.delta_x_vec = delta.value * np.ones(it.dim())
         self.delta_s_vec = np.zeros(it.ncon())
         self.ready = "factored"
+        # delta_strategy.jl:94-98: after a failed attempt on a diagonally dominant x-block the reference prints a warning
+        nwarn = C.c_int32()
+        if self._lib.okkt_kkt_diag_dom_warnings(self._k, C.byref(nwarn)) == 0:
+            self.diag_dom_warnings = int(nwarn.value)
+            for _ in range(self.diag_dom_warnings):
+                print("WARNING: Inertia calculation incorrect")
         return ("success" if rc == 1 else "failure"), int(nfac.value), float(delta.value)
+
+    def is_diag_dom(self):
+        """is_diag_dom(kkt_solver.Q[1:n,1:n]) (delta_strategy.jl:1-9) at the delta of the last factor!, scanned on the device."""
+        out = C.c_int32()
+        self._check(self._lib.okkt_kkt_is_diag_dom(self._k, C.byref(out)), "okkt_kkt_is_diag_dom")
+        return None if out.value < 0 else bool(out.value)
+
+    def estimate_y_tilde_tail(self, g):
+        """y = -J (F \\ (-g)) on the device (guess-vars.jl:155-160)."""
+        g = L.f64(np.asarray(g, dtype=float))
+        y = np.zeros(self._m)
+        self._check(self._lib.okkt_kkt_estimate_y_tilde(self._k, L.p_f64(g), L.p_f64(y)), "okkt_kkt_estimate_y_tilde")
+        return y
 
     # ---- diagnostics
     def matrix(self):
@@ -429,8 +448,7 @@ def estimate_y_tilde(J, g, pars=None, **opts):
         k.form_system_b(it)
         if k.factor_b(0.0) != 1:
             return np.ones(m)
-        dx = k.ls_solve(-it.grad)
-        return -(J @ dx)
+        return k.estimate_y_tilde_tail(it.grad)     # dx = M \ (-g), y = -J dx: both on the device
     except OkktError:
         return np.ones(m)
     finally:

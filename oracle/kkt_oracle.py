@@ -525,6 +525,19 @@ def estimate_y_tilde(J, g):  # guess-vars.jl:128-169 (cholesky branch), dense re
     return -(J @ dx)
 
 
+def is_diag_dom(Q):
+    """delta_strategy.jl:1-9: false as soon as 3 Q[i,i] < sum(Q[:,i]) + sum(Q[i,:]) for some column i (plain sums of the STORED
+    entries -- H is lower-stored, the Schur matrix carries the full J'SJ on top)."""
+    Q = sp.csc_matrix(Q)
+    col = np.asarray(Q.sum(axis=0)).ravel()
+    row = np.asarray(Q.sum(axis=1)).ravel()
+    d = Q.diagonal()
+    for i in range(Q.shape[1]):
+        if 3 * d[i] < col[i] + row[i]:
+            return False
+    return True
+
+
 def ipopt_strategy_b(it, kkt_solver, pars=None):
     """delta_strategy.jl:37-114.  Returns (status, num_fac, delta) and the list of deltas tried."""
     pars = pars or kkt_solver.pars

@@ -490,3 +490,54 @@ def test_refactor_after_step_failure(golden, kind):
     with pytest.raises(OkktError):
         k.refactor_after_step_failure_b(it, 0.0, "nonsense")
     k.finalize_b()
+
+
+@pytest.mark.parametrize("kind", ["schur", "symmetric"])
+def test_is_diag_dom_scan_matches_the_reference_rule(golden, kind):
+    # delta_strategy.jl:1-9,94-98: the scan the reference runs after every failed attempt of the delta loop, here on the device.
+    # Instances on both sides of the rule: toy LPs (H = 0: dominant only through delta), a convex H = B'B-like synthetic (dominant
+    # columns) and a nonconvex one; several deltas each.
+    cases = [iterate_from_record(rec, KS.Class_iterate) for rec in golden["toy_lps"][:3]]
+    ocases = [iterate_from_record(rec, KO.Iterate) for rec in golden["toy_lps"][:3]]
+    for seed, convex in ((1, True), (2, False)):
+        prob = synth.make_config("S-small", seed=seed, convex=convex, well_scaled=True)
+        cases.append(synth_iterate(prob, KS.Class_iterate, seed)); ocases.append(synth_iterate(prob, KO.Iterate, seed))
+    seen = set()
+    for it, oit in zip(cases, ocases):
+        n = it.dim()
+        k = KS.HIP_KKT_solver(kind)
+        k.initialize_b(it); k.form_system_b(it)
+        ko = KO.pick_KKT_solver(kind)
+        ko.initialize_b(oit); ko.form_system_b(oit)
+        for delta in (0.0, 1e-3, 10.0, 1e6):
+            k.factor_b(delta); ko.factor_b(delta)
+            want = KO.is_diag_dom(sp.csc_matrix(ko.Q)[:n, :n])
+            assert k.is_diag_dom() == want, (kind, n, delta)
+            seen.add(want)
+        k.finalize_b()
+    assert seen == {True, False}
+
+
+@pytest.mark.parametrize("kind", ["schur", "symmetric"])
+def test_delta_loop_failure_still_leaves_a_factor_to_solve_with(kind):
+    # gertz_init.jl:25-27 calls ipopt_strategy!, kkt_associate_rhs! and compute_direction! without looking at the status: on
+    # :failure the reference solves with the failed factor of the last delta.  delta_max far below what the nonconvex H needs
+    # forces :failure at the first attempt; the direction must equal the oracle's, computed from the same (wrong-inertia) factor.
+    prob = synth.make_config("S-small", seed=2, convex=False, neg_shift=50.0, well_scaled=True)
+    it, oit = synth_iterate(prob, KS.Class_iterate, 2), synth_iterate(prob, KO.Iterate, 2)
+    pars = KS.Class_parameters(); pars.delta.max = 1e-9
+    k = KS.HIP_KKT_solver(kind, pars)
+    k.initialize_b(it); k.form_system_b(it)
+    status, num_fac, delta = k.ipopt_strategy_b(it)
+    opars = KO.KKTPars(delta_max=1e-9)
+    ko = KO.pick_KKT_solver(kind, perm=k.linear_solver_perm(), pars=opars)
+    ko.initialize_b(oit); ko.form_system_b(oit)
+    ostatus, onum_fac, odelta, _ = KO.ipopt_strategy_b(oit, ko)
+    assert status == ostatus == "failure" and num_fac == onum_fac
+    assert abs(delta - odelta) <= 1e-12 * abs(odelta)
+    k.kkt_associate_rhs_b(it, KS.Reduct_affine()); k.compute_direction_b()       # must not raise
+    ko.kkt_associate_rhs_b(oit, KO.Reduct_affine()); ko.compute_direction_b()
+    for a in ("x", "y", "s"):
+        ref = getattr(ko.dir, a)
+        assert np.max(np.abs(getattr(k.dir, a) - ref)) <= 1e-7 * max(1.0, np.max(np.abs(ref))), a
+    k.finalize_b()
