@@ -893,14 +893,19 @@ enum { kSyrkTrail = 0, kSyrkPanel = 1, kSyrkAhead = 2 };
 constexpr int kSyrkNW = 8;   // 2 x 4 waves of 64 rows x 32 columns: four waves per SIMD with two workgroups per CU,
                              // so a wave's C-tile load/store hides behind three other waves' MFMAs
 
-template <int DBG, int HEAD>
+// TC = tile width in columns (round 3): 128, or 64 for trailing updates of few tiles -- a launch that cannot give every CU two
+// workgroups of 128 x 128 (<= 496 tiles: the chain-bound tail of every front, 45 us per 128-column step whatever is left)
+// runs as 128 x 64 tiles: twice the workgroups with half the work each, all four SIMDs of a CU busy.  The L operand is still
+// staged 128 rows deep (the DMA shape stays), only the first 64 are read.
+template <int DBG, int HEAD, int TC = 128>
 __global__ __launch_bounds__(kSyrkNW * 64, kSyrkNW / 2) void k_big_syrk(DevPlan P, const int* __restrict__ list, int stepA, int npan,
                                                                         int tstep, int NB, int wofs, int csplit) {
+  static_assert(TC == 128 || (TC == 64 && HEAD == kSyrkTrail), "64-column tiles exist for the trailing triangle only");
   // Applies the panels [stepA, stepA + npan) (K = up to npan * NB columns, W panels side by side in wbuf from
   // column wofs) to the region that starts at block column tstep; K = GS * NB halves the C traffic per flop.
   constexpr int NW = kSyrkNW, STAGES = kSyrkStages;
   constexpr int DMA = 2 * (kSyrkKC / NW);   // LDS-DMA instructions per wave and chunk
-  constexpr int WCW = 128 / (NW / 2);   // columns per wave
+  constexpr int WCW = TC / (NW / 2);    // columns per wave
   constexpr int NCG = WCW / 4;          // 4-column groups per wave
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -919,7 +924,7 @@ __global__ __launch_bounds__(kSyrkNW * 64, kSyrkNW / 2) void k_big_syrk(DevPlan 
   const int climit = HEAD == kSyrkPanel ? min(t0 + NB, k) : f;  // columns this launch may write
   const int T = (f - t0 + 127) >> 7;
   int ntiles;
-  if (HEAD == kSyrkTrail) { const int Tr = max(T - csplit, 0); ntiles = Tr * (Tr + 1) / 2; }
+  if (HEAD == kSyrkTrail) { const int Tr = max(T - csplit, 0); ntiles = TC == 128 ? Tr * (Tr + 1) / 2 : Tr * (Tr + 1); }   // 64-wide: row tile ti has 2 ti + 2 tiles
   else if (HEAD == kSyrkPanel) ntiles = csplit == 1 ? min(T, 1) : (csplit == 2 ? max(T - 1, 0) : T);   // all / diagonal tile / the rest
   else { ntiles = 0; for (int c = 0; c < csplit && c < T; ++c) ntiles += T - c; }
   // XCD-aware order: consecutive tile indices (which share operand panels) stay on one XCD and its L2
@@ -935,14 +940,20 @@ __global__ __launch_bounds__(kSyrkNW * 64, kSyrkNW / 2) void k_big_syrk(DevPlan 
     int rest = idx; tj = 0;
     while (rest >= T - tj) { rest -= T - tj; ++tj; }
     ti = tj + rest;
-  } else {
+  } else if (TC == 128) {
     ti = (int)((sqrtf(8.0f * (float)idx + 1.0f) - 1.0f) * 0.5f);
     while ((ti + 1) * (ti + 2) / 2 <= idx) ++ti;
     while (ti * (ti + 1) / 2 > idx) --ti;
     tj = idx - ti * (ti + 1) / 2;
     ti += csplit; tj += csplit;
+  } else {
+    ti = (int)((sqrtf(4.0f * (float)idx + 1.0f) - 1.0f) * 0.5f);
+    while ((ti + 1) * (ti + 2) <= idx) ++ti;
+    while (ti * (ti + 1) > idx) --ti;
+    tj = idx - ti * (ti + 1);             // 0 .. 2 ti + 1, in 64-column units
+    ti += csplit; tj += 2 * csplit;
   }
-  const int rt0 = t0 + ti * 128, ct0 = t0 + tj * 128;   // tile origin
+  const int rt0 = t0 + ti * 128, ct0 = t0 + tj * TC;   // tile origin
   const int rbase = rt0 + (wv & 1) * 64;
   const int cbase = ct0 + (wv >> 1) * WCW;
   const bool active = !(rbase + 63 < cbase) && rbase < f && cbase < climit;
@@ -1188,8 +1199,12 @@ std::string numeric_setup(const Symbolic& S, const SymbolicOptions& opts, hipStr
   // units) or without parallelism to lose (total cost <= task_ratio x its critical path); otherwise its root is a
   // task of its own and the rule is applied to the children.  Big fronts are units of their own.
   const bool use_tasks = !parted && !(getenv("OKKT_TASKS") && atoi(getenv("OKKT_TASKS")) == 0);
-  const double task_abs = getenv("OKKT_TASK_ABS") ? atof(getenv("OKKT_TASK_ABS")) : 48.0;
-  const double task_ratio = getenv("OKKT_TASK_RATIO") ? atof(getenv("OKKT_TASK_RATIO")) : 1.5;
+  // plans of the level-structure dissection (banded systems) are all small fronts and nothing but launch latency: finer tasks
+  // (12 front units, ratio 1.1) cut the hanging chain at the CUTEst size from 0.19 + 0.15 ms to 0.11 + 0.10 ms, N_h = 20 000 from
+  // 0.37 + 0.29 to 0.24 + 0.19 ms (round 3 sweep); the general plans keep the coarser round-2 setting
+  const bool level_nd = S.ordering_used == 4;
+  const double task_abs = getenv("OKKT_TASK_ABS") ? atof(getenv("OKKT_TASK_ABS")) : (level_nd ? 12.0 : 48.0);
+  const double task_ratio = getenv("OKKT_TASK_RATIO") ? atof(getenv("OKKT_TASK_RATIO")) : (level_nd ? 1.1 : 1.5);
   std::vector<int> task_lo(ns), unit_root(ns), ulevel(ns, 0);
   {
     auto fof = [&](int s2) { return (int)(S.row_ptr[s2 + 1] - S.row_ptr[s2]); };
@@ -1428,7 +1443,7 @@ std::string numeric_setup(const Symbolic& S, const SymbolicOptions& opts, hipStr
   OKKT_HIP_TRY(hipFuncSetAttribute((const void*)k_big_invert, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds));
   OKKT_HIP_TRY(hipFuncSetAttribute((const void*)k_big_trsm<3>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds));
   OKKT_HIP_TRY(hipFuncSetAttribute((const void*)k_big_trsm<4>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds));
-  for (const void* fn : {(const void*)k_big_syrk<0, kSyrkTrail>, (const void*)k_big_syrk<0, kSyrkPanel>, (const void*)k_big_syrk<0, kSyrkAhead>,
+  for (const void* fn : {(const void*)k_big_syrk<0, kSyrkTrail>, (const void*)k_big_syrk<0, kSyrkTrail, 64>, (const void*)k_big_syrk<0, kSyrkPanel>, (const void*)k_big_syrk<0, kSyrkAhead>,
                          (const void*)k_big_syrk<1, kSyrkTrail>, (const void*)k_big_syrk<2, kSyrkTrail>, (const void*)k_big_syrk<5, kSyrkTrail>,
                          (const void*)k_big_syrk<13, kSyrkTrail>, (const void*)k_big_syrk<16, kSyrkTrail>, (const void*)k_big_syrk<48, kSyrkTrail>})
     OKKT_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)syrk_lds_bytes(kSyrkStages)));
@@ -1659,6 +1674,10 @@ static std::string factor_sched(Numeric& N, DevPlan P, const std::vector<LevelSc
         else if (head == 2) { ntile = 0; for (int c = 0; c < cs && c < T; ++c) ntile += T - c; }
         else if (head == 3) ntile = Tr * (Tr + 1) / 2;
         if (ntile == 0) return "";
+        // few tiles: 128 x 64 tiles (see k_big_syrk); decided on the largest front of the launch
+        static const int small_max = getenv("OKKT_SYRK_SMALL_TILES") ? atoi(getenv("OKKT_SYRK_SMALL_TILES")) : 4000;
+        const bool narrow = (head == 0 || head == 3) && dbg_syrk == 0 && (int64_t)ntile * g.cnt <= small_max;
+        if (narrow) ntile = head == 0 ? T * (T + 1) : Tr * (Tr + 1);
         const dim3 grid((ntile + 7) / 8 * 8, g.cnt);
         const int wofs = par * GS * NB;
         const bool prof = N.profile && (head == 0 || head == 3);   // the dominant kernel: k_big_syrk<0, kSyrkTrail>
@@ -1690,6 +1709,7 @@ static std::string factor_sched(Numeric& N, DevPlan P, const std::vector<LevelSc
         const int csplit = head == 1 ? sub : (head == 0 ? 0 : cs);
         if (head == 1) OKKT_SYRK(0, kSyrkPanel);
         else if (head == 2) OKKT_SYRK(0, kSyrkAhead);
+        else if (narrow) hipLaunchKernelGGL((k_big_syrk<0, kSyrkTrail, 64>), grid, dim3(kSyrkNW * 64), syrk_lds_bytes(kSyrkStages), sst, P, list, stepA, npan, tstep, NB, wofs, csplit);
         else switch (dbg_syrk) {   // timing-only ablations of the trailing update (OKKT_DEBUG_SYRK): wrong outputs
           case 81: OKKT_SYRK(1, kSyrkTrail); break;    // no C load
           case 82: OKKT_SYRK(2, kSyrkTrail); break;    // no MFMA

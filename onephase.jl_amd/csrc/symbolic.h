@@ -27,7 +27,7 @@ void ml_nd_order(int n, const std::vector<int64_t>& gp, const std::vector<int>& 
 struct SymbolicOptions {
   int ordering = 0;        // 0 = AMD, switching to level-structure nested dissection when the AMD tree is a path of small
                            // fronts (see analyze_pattern); 1 = natural, 2 = user permutation, 3 = AMD always, 4 = level-structure nested dissection always, 5 = multilevel nested dissection always
-  int nd_leaf = 48;        // nested dissection stops at pieces of this many nodes
+  int nd_leaf = 24;        // level-structure nested dissection stops at pieces of this many nodes (round 2: 48)
   int mlnd_leaf = 1500;    // multilevel nested dissection (ordering 5, or chosen by ordering 0): pieces ordered by minimum degree
   int mlnd_trials = 3;     // bisections tried (different seeds, side by side on host threads) on the top two levels
   int relax_always = 64;   // merge a child into its parent when the merged width <= this (one LDS-resident front instead of a chain of launches / loop trips)
