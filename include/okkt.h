@@ -266,6 +266,14 @@ int okkt_kkt_get_timers(okkt_kkt_handle k, okkt_kkt_timers* out);
 /* ipopt_strategy!: returns 1 on :success, 0 on :failure (delta > delta_max), <0 on error */
 int okkt_kkt_ipopt_strategy(okkt_kkt_handle k, double delta_prev, const okkt_kkt_pars* pars,
                             int32_t* num_fac_out, double* delta_out);
+/* compute_direction! for nrhs reduction-factor triples in one pass over the factor: the probe of the aggressive step
+ * (Reduct_affine, take_step.jl:2-3) and the candidates of take_step2! (take_step.jl:34-66) share the factorised system.
+ * System_rhs (system_rhs.jl:57-73) is evaluated on the device for every triple from the iterate of the last okkt_kkt_system_rhs;
+ * the triangular solves (and the Schur refinement rounds) carry up to four right-hand sides per sweep over L.
+ * etas: nrhs x (eta_P, eta_D, eta_mu); dx: nrhs x n, dy, ds: nrhs x m (NULL: not downloaded); err: nrhs records or NULL.
+ * Schur, Schur-direct and symmetric systems; 1 <= nrhs <= 16. */
+int okkt_kkt_compute_directions(okkt_kkt_handle k, int32_t nrhs, const double* etas, int32_t ItRefine_Num,
+                                double* dx, double* dy, double* ds, okkt_kkt_error* err);
 /* is_diag_dom(kkt_solver.Q[1:n,1:n]) (delta_strategy.jl:1-9) at the delta of the last factor call, as a device scan:
  * *out = 1 dominant, 0 not, -1 not evaluated (clever-symmetric system).  ipopt_strategy! runs it after every failed attempt and
  * prints "WARNING: Inertia calculation incorrect" when it holds (delta_strategy.jl:94-98): okkt_kkt_ipopt_strategy does the same

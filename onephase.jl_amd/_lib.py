@@ -186,6 +186,7 @@ SIGNATURES = {
     "okkt_kkt_get_timers": (C.c_int, [_vp, C.POINTER(OkktKktTimers)]),
     "okkt_kkt_get_direction": (C.c_int, [_vp, _f64p, _f64p, _f64p]),
     "okkt_kkt_ipopt_strategy": (C.c_int, [_vp, C.c_double, C.POINTER(OkktKktPars), C.POINTER(C.c_int32), _f64p]),
+    "okkt_kkt_compute_directions": (C.c_int, [_vp, C.c_int32, _f64p, C.c_int32, _f64p, _f64p, _f64p, C.POINTER(OkktKktError)]),
     "okkt_kkt_is_diag_dom": (C.c_int, [_vp, C.POINTER(C.c_int32)]),
     "okkt_kkt_diag_dom_warnings": (C.c_int, [_vp, C.POINTER(C.c_int32)]),
     "okkt_kkt_estimate_y_tilde": (C.c_int, [_vp, _f64p, _f64p]),

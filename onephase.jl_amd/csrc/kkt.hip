@@ -1073,9 +1073,16 @@ int okkt_kkt_system_rhs(okkt_kkt_handle k, const double* J_nzval_cur, const doub
     }
   }
   k->cur_Jx = Jx;
-  if (n) KK_TRY(k, hipMemcpyAsync(k->vn1, grad, (size_t)n * 8, hipMemcpyHostToDevice, st));
+  if (!k->cur_grad) { int rc2 = kk_alloc(k, (size_t)std::max<int64_t>(n, 1), &k->cur_grad); if (rc2 != OKKT_OK) return rc2; }
+  if (!k->cur_cons) { int rc2 = kk_alloc(k, (size_t)std::max<int64_t>(m, 1), &k->cur_cons); if (rc2 != OKKT_OK) return rc2; }
+  k->cur_mu = mu; k->cur_pen = a_norm_penalty;
+  if (n) {
+    KK_TRY(k, hipMemcpyAsync(k->cur_grad, grad, (size_t)n * 8, hipMemcpyHostToDevice, st));     // kept for okkt_kkt_compute_directions
+    KK_TRY(k, hipMemcpyAsync(k->vn1, k->cur_grad, (size_t)n * 8, hipMemcpyDeviceToDevice, st));
+  }
   if (m) {
-    KK_TRY(k, hipMemcpyAsync(k->vm1, cons, (size_t)m * 8, hipMemcpyHostToDevice, st));
+    KK_TRY(k, hipMemcpyAsync(k->cur_cons, cons, (size_t)m * 8, hipMemcpyHostToDevice, st));
+    KK_TRY(k, hipMemcpyAsync(k->vm1, k->cur_cons, (size_t)m * 8, hipMemcpyDeviceToDevice, st));
     KK_TRY(k, hipMemcpyAsync(k->cur_s, s, (size_t)m * 8, hipMemcpyHostToDevice, st));
     KK_TRY(k, hipMemcpyAsync(k->cur_y, y, (size_t)m * 8, hipMemcpyHostToDevice, st));
   }
@@ -1218,6 +1225,122 @@ int okkt_kkt_compute_direction(okkt_kkt_handle k, const double* dual_r, const do
   if (err_out) *err_out = E;
   k->have_dir = true;
   k->have_dxnorm = false;
+  return OKKT_OK;
+}
+
+
+// compute_direction! for several reduction-factor triples in ONE pass over the factor: the probe of the aggressive step
+// (Reduct_affine, take_step.jl:2-3) and the candidates of take_step2! (take_step.jl:34-66) are right-hand sides of the same
+// factorised system -- System_rhs (system_rhs.jl:57-73) is evaluated on the device for every triple from the gradient, constraint
+// values, s and y that the last okkt_kkt_system_rhs left in HBM, the triangular solves carry up to four right-hand sides per
+// sweep (okkt_solve(nrhs)), the Schur refinement rounds are batched the same way.  etas: nrhs x (eta_P, eta_D, eta_mu);
+// dx: nrhs x n, dy / ds: nrhs x m (any of the three NULL: not downloaded); err: nrhs records or NULL.
+int okkt_kkt_compute_directions(okkt_kkt_handle k, int32_t nrhs, const double* etas, int32_t ItRefine_Num,
+                                double* dx, double* dy, double* ds, okkt_kkt_error* err_out) {
+  if (!k || !etas || nrhs < 1 || nrhs > 16) return OKKT_ERR_INVALID;
+  if (k->kind == OKKT_KKT_CLEVER_SYMMETRIC) return kk_fail(k, OKKT_ERR_INVALID, "batched directions: schur, schur_direct and symmetric systems");
+  if (!k->factored) return kk_fail(k, OKKT_ERR_INVALID, "kkt solver not ready to compute direction!");
+  if (!k->ls->factored) return kk_fail(k, OKKT_ERR_INVALID, "the last factorisation was a discarded trial of the delta loop: factor! again before a direction");
+  if (!k->have_cur || !k->cur_grad) return kk_fail(k, OKKT_ERR_INVALID, "okkt_kkt_system_rhs (kkt_associate_rhs!) has not been called: no resident iterate");
+  const bool schur = k->kind != OKKT_KKT_SYMMETRIC, direct = k->kind == OKKT_KKT_SCHUR_DIRECT;
+  hipStream_t st = kk_stream(k);
+  const int64_t n = k->n, m = k->m, dim = schur ? n : n + m;
+  if (k->batch_cap < nrhs) {
+    const size_t c = (size_t)nrhs;
+    int rc2;
+    if ((rc2 = kk_alloc(k, c * std::max<int64_t>(n, 1), &k->b_rD)) || (rc2 = kk_alloc(k, c * std::max<int64_t>(m, 1), &k->b_rP)) ||
+        (rc2 = kk_alloc(k, c * std::max<int64_t>(m, 1), &k->b_rC)) || (rc2 = kk_alloc(k, c * (size_t)(n + m + 1), &k->b_rhs)) ||
+        (rc2 = kk_alloc(k, c * (size_t)(n + m + 1), &k->b_sol)) || (rc2 = kk_alloc(k, c * std::max<int64_t>(n, 1), &k->b_res)) ||
+        (rc2 = kk_alloc(k, c * std::max<int64_t>(n, 1), &k->b_dx)) || (rc2 = kk_alloc(k, c * std::max<int64_t>(m, 1), &k->b_dy)) ||
+        (rc2 = kk_alloc(k, c * std::max<int64_t>(m, 1), &k->b_ds)) || (rc2 = kk_alloc(k, c * 8, &k->b_red)))
+      return rc2;
+    k->batch_cap = nrhs;     // the smaller buffers of an earlier call stay on the handle's allocation list until it is destroyed
+  }
+  okkt_kkt_s::Timer& T = k->tm_dir;
+  T.reset();
+  k->n_solves = 0;
+  const size_t t_begin = T.mark(st);
+  size_t t_last = t_begin;
+  auto lap = [&](int tag) { const size_t t = T.mark(st); T.seg(tag, t_last, t); t_last = t; };
+  const double* Jcur = k->cur_Jx;
+  const double* ys = direct ? k->cur_y : k->y;
+  const double* ss = direct ? k->cur_s : k->s;
+  const double* sg = direct ? k->cur_sig : k->sig;
+  const double* Jc = direct ? k->cur_Jx : k->Jx;
+  const double* Jr = direct ? k->cur_Jcsr : k->Jcsr;
+  // System_rhs for every triple, then the rhs of the linear system
+  for (int q = 0; q < nrhs; ++q) {
+    const double eP = etas[3 * q], eD = etas[3 * q + 1], eM = etas[3 * q + 2];
+    double* rD = k->b_rD + (size_t)q * n; double* rP = k->b_rP + (size_t)q * m; double* rC = k->b_rC + (size_t)q * m;
+    SEG_LAUNCH(k_rhs_dual_seg, k->lprJc, n, st, n, k->Jp, k->Ji, Jcur, k->cur_y, k->cur_grad, (k->cur_mu * eM) * k->cur_pen, 1.0 - eD, rD);
+    if (m) hipLaunchKernelGGL(k_rhs_pc, grid1(m), dim3(256), 0, st, m, k->cur_cons, k->cur_s, k->cur_y, 1.0 - eP, k->cur_mu * eM, rP, rC);
+    if (schur) {
+      if (m) hipLaunchKernelGGL(k_schur_t1, grid1(m), dim3(256), 0, st, m, rP, rC, sg, ss, k->vm1);
+      SEG_LAUNCH(k_seg_spmv, k->lprJc, n, st, n, k->Jp, k->Ji, Jc, k->vm1, (const double*)nullptr, rD, 1.0, k->b_rhs + (size_t)q * n);
+    } else if (dim) {
+      hipLaunchKernelGGL(k_sym_rhs, grid1(dim), dim3(256), 0, st, n, m, rD, rP, rC, k->y, k->b_rhs + (size_t)q * dim);
+    }
+  }
+  lap(1);
+  int rc;
+  if (schur) {
+    if (n) KK_TRY(k, hipMemsetAsync(k->b_dx, 0, (size_t)nrhs * n * 8, st));
+    for (int it = 0; it < ItRefine_Num; ++it) {
+      rc = solver_solve_enqueue(k->ls, it == 0 ? k->b_rhs : k->b_res, k->b_dx, nrhs, true);     // dir_x .+= ls_solve(res_old), all right-hand sides per sweep
+      if (rc != OKKT_OK) return kk_check_ls(k, rc, "ls_solve");
+      k->n_solves += nrhs;
+      lap(0);
+      if (it + 1 < ItRefine_Num && n)
+        for (int q = 0; q < nrhs; ++q) {
+          double* dxq = k->b_dx + (size_t)q * n;
+          SEG_LAUNCH(k_seg_spmv, k->lprJr, m, st, m, k->Jrp, k->Jrj, k->Jcsr, dxq, k->sig, (const double*)nullptr, 0.0, k->vm2);
+          SEG_LAUNCH(k_schur_resid, k->lprJc, n, st, n, k->Jp, k->Ji, k->Jx, k->vm2, k->Hrp, k->Hrj, k->Hcsr, k->Hp, k->Hi, k->Hx, k->Hdiag, dxq,
+                     k->b_rhs + (size_t)q * n, k->delta, k->b_res + (size_t)q * n);
+        }
+      lap(1);
+    }
+    for (int q = 0; q < nrhs; ++q)
+      SEG_LAUNCH(k_schur_dyds, k->lprJr, m, st, m, k->Jrp, k->Jrj, Jr, k->b_dx + (size_t)q * n, k->b_rP + (size_t)q * m, k->b_rC + (size_t)q * m, ys, ss, sg,
+                 direct ? 1 : 0, k->b_dy + (size_t)q * m, k->b_ds + (size_t)q * m);
+  } else {
+    rc = solver_solve_enqueue(k->ls, k->b_rhs, k->b_sol, nrhs, false);
+    if (rc != OKKT_OK) return kk_check_ls(k, rc, "ls_solve");
+    k->n_solves += nrhs;
+    lap(0);
+    for (int q = 0; q < nrhs; ++q) {
+      if (dim) hipLaunchKernelGGL(k_sym_split, grid1(dim), dim3(256), 0, st, n, m, k->b_sol + (size_t)q * dim, k->b_dx + (size_t)q * n, k->b_dy + (size_t)q * m);
+      SEG_LAUNCH(k_seg_spmv, k->lprJr, m, st, m, k->Jrp, k->Jrj, k->Jcsr, k->b_dx + (size_t)q * n, (const double*)nullptr, k->b_rP + (size_t)q * m, -1.0,
+                 k->b_ds + (size_t)q * m);
+    }
+  }
+  lap(1);
+  const int64_t nbD = n ? (int64_t)seg_grid(n, k->lprJc).x : 0, nbM = m ? (int64_t)seg_grid(m, k->lprJr).x : 0;
+  for (int q = 0; q < nrhs; ++q) {
+    const double* dxq = k->b_dx + (size_t)q * n; const double* dyq = k->b_dy + (size_t)q * m; const double* dsq = k->b_ds + (size_t)q * m;
+    SEG_LAUNCH(k_err_dual, k->lprJc, n, st, n, k->Jp, k->Ji, k->Jx, dyq, k->Hrp, k->Hrj, k->Hcsr, k->Hp, k->Hi, k->Hx, k->Hdiag, dxq, k->b_rD + (size_t)q * n, k->delta, k->part);
+    SEG_LAUNCH(k_err_pc, k->lprJr, m, st, m, k->Jrp, k->Jrj, k->Jcsr, dxq, dsq, dyq, k->s, k->y, k->b_rP + (size_t)q * m, k->b_rC + (size_t)q * m, k->part + nbD * 8);
+    hipLaunchKernelGGL(k_err_final, dim3(1), dim3(256), 0, st, nbD, nbM, k->part, k->b_red + (size_t)q * 8);
+  }
+  lap(2);
+  T.seg(3, t_begin, t_last);
+  std::vector<double> red((size_t)nrhs * 8, 0.0);
+  KK_TRY(k, hipMemcpyAsync(red.data(), k->b_red, red.size() * 8, hipMemcpyDeviceToHost, st));
+  if (dx && n) KK_TRY(k, hipMemcpyAsync(dx, k->b_dx, (size_t)nrhs * n * 8, hipMemcpyDeviceToHost, st));
+  if (dy && m) KK_TRY(k, hipMemcpyAsync(dy, k->b_dy, (size_t)nrhs * m * 8, hipMemcpyDeviceToHost, st));
+  if (ds && m) KK_TRY(k, hipMemcpyAsync(ds, k->b_ds, (size_t)nrhs * m * 8, hipMemcpyDeviceToHost, st));
+  KK_TRY(k, hipStreamSynchronize(st));
+  KK_TRY(k, hipGetLastError());
+  auto mx = [](double a, double b) { return (a != a || b != b) ? NAN : std::max(a, b); };
+  for (int q = 0; q < nrhs && err_out; ++q) {
+    const double* r = red.data() + (size_t)q * 8;
+    okkt_kkt_error E;
+    E.error_D = r[0]; E.error_P = r[2]; E.error_mu = r[3];
+    E.overall = mx(mx(r[0], r[2]), r[3]);
+    E.rhs_norm = mx(mx(r[1], r[4]), r[5]);
+    E.ratio = E.overall / E.rhs_norm;
+    err_out[q] = E;
+  }
+  k->have_dir = false;     // the resident single direction of okkt_kkt_compute_direction is not touched; the step-side kernels keep refusing until it is set
   return OKKT_OK;
 }
 

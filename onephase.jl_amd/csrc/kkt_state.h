@@ -40,6 +40,12 @@ struct okkt_kkt_s {
   double *rD = nullptr, *rP = nullptr, *rC = nullptr, *dx = nullptr, *dy = nullptr, *ds = nullptr;
   double *vn1 = nullptr, *vn2 = nullptr, *vn3 = nullptr, *vm1 = nullptr, *vm2 = nullptr, *big1 = nullptr, *big2 = nullptr;
   double* red = nullptr;  // reduction outputs
+  // batched directions (okkt_kkt_compute_directions): gradient and constraint values of the last okkt_kkt_system_rhs kept resident,
+  // per-rhs slots of the rhs triples, the linear-system rhs / solution, the directions and the error reductions
+  double *cur_grad = nullptr, *cur_cons = nullptr;
+  double cur_mu = 0.0, cur_pen = 0.0;
+  int batch_cap = 0;
+  double *b_rD = nullptr, *b_rP = nullptr, *b_rC = nullptr, *b_rhs = nullptr, *b_sol = nullptr, *b_res = nullptr, *b_dx = nullptr, *b_dy = nullptr, *b_ds = nullptr, *b_red = nullptr;
   double* ones = nullptr; // max(n, m) ones (row / column sums of the diagonal-dominance scan), allocated on first use
   int diag_dom_warnings = 0;   // failed attempts of the last ipopt_strategy! whose x-block was diagonally dominant (delta_strategy.jl:95)
   // step-side kernels (linesearch.hip): staged host vectors and reduction partials, allocated on first use

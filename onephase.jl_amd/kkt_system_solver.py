@@ -300,6 +300,28 @@ class HIP_KKT_solver:
         self.reduct_factors = eta
         self.current_it = it
 
+    # ---- several directions of the same factor in one pass (probe + candidates of take_step2!, take_step.jl:2-66)
+    def compute_directions_b(self, etas):
+        """[(dir, kkt_err_norm)] for the reduction factors `etas` at the iterate of the last kkt_associate_rhs_b: System_rhs on
+        the device per triple, the solves batched (up to four right-hand sides per sweep over L)."""
+        if self.ready != "factored":
+            raise OkktError("kkt solver not ready to compute direction!")
+        n, m = self.factor_it.dim(), self.factor_it.ncon()
+        q = len(etas)
+        e = L.f64(np.array([[t.P, t.D, t.mu] for t in etas], dtype=float).ravel())
+        dx, dy, ds = np.zeros((q, n)), np.zeros((q, m)), np.zeros((q, m))
+        err = (L.OkktKktError * q)()
+        self._check(self._lib.okkt_kkt_compute_directions(self._k, q, L.p_f64(e), self.pars.kkt.ItRefine_Num,
+                                                          L.p_f64(dx), L.p_f64(dy), L.p_f64(ds), err), "okkt_kkt_compute_directions")
+        out = []
+        for i in range(q):
+            d = Class_point(x=dx[i].copy(), y=dy[i].copy(), s=ds[i].copy())
+            d.mu = -(1.0 - etas[i].mu) * self.current_it.mu
+            d.primal_scale = -(1.0 - etas[i].P) * self.current_it.primal_scale
+            ke = err[i]
+            out.append((d, Class_kkt_error(ke.error_D, ke.error_P, ke.error_mu, ke.overall, ke.rhs_norm, ke.ratio)))
+        return out
+
     # ---- compute_direction! (kkt_system_solver.jl:178-188)
     def compute_direction_b(self, timer=None):
         if self.ready != "factored":

@@ -528,8 +528,12 @@ def test_delta_loop_failure_still_leaves_a_factor_to_solve_with(kind):
     pars = KS.Class_parameters(); pars.delta.max = 1e-9
     k = KS.HIP_KKT_solver(kind, pars)
     k.initialize_b(it); k.form_system_b(it)
+    # the first delta of the loop is delta_start - tau with tau = 1.5 * diag_min < 0 here: delta_start is chosen so that it comes
+    # out as 1.0 -- far too small for a diagonal shifted by -50 (wrong inertia), far above delta_max (:failure at once)
+    start = 1.0 + 1.5 * k.diag_min()
+    pars.delta.start = start
     status, num_fac, delta = k.ipopt_strategy_b(it)
-    opars = KO.KKTPars(delta_max=1e-9)
+    opars = KO.KKTPars(delta_max=1e-9, delta_start=start)
     ko = KO.pick_KKT_solver(kind, perm=k.linear_solver_perm(), pars=opars)
     ko.initialize_b(oit); ko.form_system_b(oit)
     ostatus, onum_fac, odelta, _ = KO.ipopt_strategy_b(oit, ko)
@@ -540,4 +544,36 @@ def test_delta_loop_failure_still_leaves_a_factor_to_solve_with(kind):
     for a in ("x", "y", "s"):
         ref = getattr(ko.dir, a)
         assert np.max(np.abs(getattr(k.dir, a) - ref)) <= 1e-7 * max(1.0, np.max(np.abs(ref))), a
+    k.finalize_b()
+
+
+@pytest.mark.parametrize("kind", ["schur", "schur_direct", "symmetric"])
+def test_batched_directions_equal_the_one_by_one_ones(kind):
+    # take_step.jl:2-66: the probe (Reduct_affine) and the candidates of take_step2! (gamma-triples, Reduct_stable, the constant
+    # (0.2, 0, 0.2)) are right-hand sides of ONE factorised system: okkt_kkt_compute_directions solves them in one pass over L
+    # (five triples = one sweep of four + one of one).  Every direction must equal compute_direction!'s for the same triple
+    # (1e-9) and the oracle's; the N-err of every triple comes back too.
+    prob = synth.make_config("S-small", seed=4, well_scaled=True)
+    it, oit = synth_iterate(prob, KS.Class_iterate, 4), synth_iterate(prob, KO.Iterate, 4)
+    etas = [KS.Reduct_affine(), KS.Class_reduction_factors(0.3, 0.3, 0.3), KS.Reduct_stable(), KS.Class_reduction_factors(0.2, 0.0, 0.2),
+            KS.Class_reduction_factors(0.05, 0.0, 0.05)]
+    k = KS.HIP_KKT_solver(kind)
+    k.initialize_b(it); k.form_system_b(it)
+    assert k.factor_b(1e-6) == 1
+    k.kkt_associate_rhs_b(it, etas[0])
+    batch = k.compute_directions_b(etas)
+    assert len(batch) == len(etas)
+    ko = KO.pick_KKT_solver(kind, perm=k.linear_solver_perm())
+    ko.initialize_b(oit); ko.form_system_b(oit)
+    assert ko.factor_b(1e-6) == 1
+    for eta, (d, kerr) in zip(etas, batch):
+        k.kkt_associate_rhs_b(it, eta); k.compute_direction_b()
+        ko.kkt_associate_rhs_b(oit, KO.Class_reduction_factors(eta.P, eta.D, eta.mu)); ko.compute_direction_b()
+        for a in ("x", "y", "s"):
+            one, ref, got = getattr(k.dir, a), getattr(ko.dir, a), getattr(d, a)
+            scale = max(1.0, np.max(np.abs(ref)))
+            assert np.max(np.abs(got - one)) <= 1e-9 * scale, (kind, a)
+            assert np.max(np.abs(got - ref)) <= 1e-8 * scale, (kind, a)
+        assert abs(kerr.ratio - k.kkt_err_norm.ratio) <= 1e-6 * max(k.kkt_err_norm.ratio, 1e-12) + 1e-14
+        assert d.mu == k.dir.mu and d.primal_scale == k.dir.primal_scale
     k.finalize_b()
