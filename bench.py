@@ -107,6 +107,8 @@ def main():
                          "elimination-tree subtrees over the ranks with an RCCL reduce of the contribution blocks (strong scaling, "
                          "S-C5); both (default) = the replica line with the sharded numbers in config.sharded")
     ap.add_argument("--sharded-config", default="S-C5")
+    ap.add_argument("--no-sharded-model", action="store_true",
+                    help="skip config.sharded_model: the measured multi-GPU prediction for BASELINE config 5 (per-part phases timed on this one GPU)")
     ap.add_argument("--strict-sharded", action="store_true",
                     help="exit with code 3 (after printing the metric line) when the sharded leg fails or times out; without it the failure only shows as config.sharded.error")
     args = ap.parse_args()
@@ -277,6 +279,15 @@ def main():
             out["roofline"]["traffic_detail"] = {"source": "committed summary profiles/r02_syrk_pmc.json (scripts/profile_r02.sh)"}
         if world == 1 and not args.no_kkt_level:
             out["config"]["kkt_level"] = kkt_level_breakdown(prob, local_rank)
+        if world == 1 and not args.no_sharded_model:
+            # the strong-scaling case (BASELINE config 5) predicted from MEASURED components: every part's local phases and the
+            # top of the tree timed alone on this GPU (scripts/sharded_model.py), not from flops
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "scripts"))
+                from sharded_model import measure
+                out["config"]["sharded_model"] = measure(args.sharded_config, reps=3, device=local_rank)
+            except Exception as exc:
+                out["config"]["sharded_model"] = {"error": f"{type(exc).__name__}: {str(exc)[:200]}"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"], out["parity"] = cpu_baseline(args.cpu_sample, st, K, perm_metric, n, m, local_rank)
             # BASELINE.md holds no published number for this metric (the reference publishes none): the ratio is against the

@@ -142,7 +142,7 @@ int okkt_default_opts(okkt_opts* o) {
 // in the same process) ran the look-ahead schedule 13 % slower (62.9 vs 54.6 ms on the Schur-shape S-metric system)
 // -- the runtime's hardware-queue assignment of later streams differs -- while a reused set keeps the first timing.
 struct StreamSet {
-  int device = -1, la = 0, reserved = 0;
+  int device = -1, la = 0, reserved = 0, seq = 0;   // seq: order of creation in this process (1, 2, ...)
   hipStream_t stream = nullptr, masked = nullptr, panel = nullptr, aux = nullptr;
 };
 // heap objects that are never destructed: no static-destruction order to get wrong at process exit
@@ -169,20 +169,25 @@ static void pool_close() {
 static bool take_stream_set(int device, int la, int reserved, StreamSet* out) {
   std::lock_guard<std::mutex> lock(pool_mutex());
   std::vector<StreamSet>& fr = pool_free();
+  // the OLDEST matching set: later sets share the hardware queues of the earlier ones (a part of the sharded model measured on
+  // the third set of a process ran 2.5x slower than on the first), so a lone handle should always get the first one back
+  long best = -1;
   for (size_t q = 0; q < fr.size(); ++q)
-    if (fr[q].device == device && fr[q].la == la && fr[q].reserved == reserved) {
-      *out = fr[q];
-      fr.erase(fr.begin() + (long)q);
-      return true;
-    }
-  return false;
+    if (fr[q].device == device && fr[q].la == la && fr[q].reserved == reserved && (best < 0 || fr[q].seq < fr[(size_t)best].seq)) best = (long)q;
+  if (best < 0) return false;
+  *out = fr[(size_t)best];
+  fr.erase(fr.begin() + best);
+  return true;
 }
+static int pool_size();
 static void register_stream_set(const StreamSet& set) {
   std::lock_guard<std::mutex> lock(pool_mutex());
   static bool registered = false;
   if (!registered) { registered = true; (void)atexit(pool_close); }
   pool_all().push_back(set);
+  pool_all().back().seq = (int)pool_all().size();
 }
+static int pool_size() { std::lock_guard<std::mutex> lock(pool_mutex()); return (int)pool_all().size(); }
 static void give_stream_set(const StreamSet& set) {
   std::lock_guard<std::mutex> lock(pool_mutex());
   if (!g_pool_closed) pool_free().push_back(set);
@@ -239,6 +244,7 @@ int okkt_create(okkt_handle* out, const okkt_opts* opts) {
     StreamSet set;
     if (take_stream_set(dev, la ? 1 : 0, reserved, &set)) {
       h->stream = set.stream; h->stream_masked = set.masked; h->stream_panel = set.panel; h->stream_aux = set.aux;
+      h->stream_seq = set.seq;
     } else if (la) {
       std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
       for (int b = reserved; b < ncu; ++b) mask[(size_t)b >> 5] |= 1u << (b & 31);
@@ -266,6 +272,7 @@ int okkt_create(okkt_handle* out, const okkt_opts* opts) {
       set.device = dev; set.la = h->stream_la; set.reserved = reserved;
       set.stream = h->stream; set.masked = h->stream_masked; set.panel = h->stream_panel; set.aux = h->stream_aux;
       register_stream_set(set);
+      h->stream_seq = pool_size();
     }
     if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) {
       if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -305,6 +312,7 @@ int okkt_destroy(okkt_handle h) {
       StreamSet set;
       set.device = h->device; set.la = h->stream_la; set.reserved = h->stream_reserved;
       set.stream = h->stream; set.masked = h->stream_masked; set.panel = h->stream_panel; set.aux = h->stream_aux;
+      set.seq = h->stream_seq;
       give_stream_set(set);
     }
   }

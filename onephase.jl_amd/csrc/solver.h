@@ -24,6 +24,7 @@ struct okkt_solver_s {
   hipStream_t stream = nullptr;        // the handle's stream (all CUs)
   hipStream_t stream_masked = nullptr; // look-ahead main stream: CU mask without the reserved CUs (segments that use the look-ahead run here)
   int stream_la = 0, stream_reserved = 0;   // key of the pooled stream set (api.cpp)
+  int stream_seq = 0;                       // its order of creation in the process
   hipStream_t stream_panel = nullptr;  // look-ahead panel stream (high priority, all CUs)
   hipStream_t stream_aux = nullptr;    // second panel stream: the part of the in-group updates that k_big_diag does not wait for
   hipEvent_t ev0 = nullptr, ev1 = nullptr;

@@ -160,21 +160,32 @@ class ShardedLinearSolver:
         self._call(s, "okkt_dist_get_owner", L.p_i64(sn), L.p_i64(col), L.p_i64(par))
         return sn, col, par
 
-    def factor(self, d_vals_per_rank, n, m):
+    def _timed(self, timings, key, rank, s, fn, *args):
+        """One blocking C-ABI phase; with a timings dict its wall-clock (ms, the call synchronises the handle's stream) is
+        appended to timings[key][rank] -- the measured components of the multi-GPU prediction (scripts/sharded_model.py)."""
+        if timings is None:
+            return self._call(s, fn, *args)
+        import time
+        t = time.perf_counter()
+        rc = self._call(s, fn, *args)
+        timings.setdefault(key, {}).setdefault(rank, []).append(1e3 * (time.perf_counter() - t))
+        return rc
+
+    def factor(self, d_vals_per_rank, n, m, timings=None):
         """d_vals_per_rank: device pointers of nzval, one per local rank.  Returns the 1/0 inertia flag."""
         kind = L.OKKT_SYM_DEFINITE if self.sym == "definite" else L.OKKT_SYM_SYMMETRIC
         cbs = self._bufs["cb"]
         for b in cbs:
             b.zero()
-        for s, dv in zip(self.solvers, d_vals_per_rank):
-            self._call(s, "okkt_dist_factor_local", C.c_void_p(dv), n, m, kind)
-        for s, b in zip(self.solvers, cbs):
-            self._call(s, "okkt_dist_cb", C.c_void_p(b.ptr), 0)
+        for s, dv, r in zip(self.solvers, d_vals_per_rank, self.comm.ranks):
+            self._timed(timings, "factor_local", r, s, "okkt_dist_factor_local", C.c_void_p(dv), n, m, kind)
+        for s, b, r in zip(self.solvers, cbs, self.comm.ranks):
+            self._timed(timings, "pack_cb", r, s, "okkt_dist_cb", C.c_void_p(b.ptr), 0)
         self.comm.reduce_sum(cbs, dst=0)                      # RCCL reduce of the parent-front contribution blocks
         for s, b, r in zip(self.solvers, cbs, self.comm.ranks):
             if r == 0:
-                self._call(s, "okkt_dist_cb", C.c_void_p(b.ptr), 1)
-                self._call(s, "okkt_dist_factor_top")
+                self._timed(timings, "unpack_cb", r, s, "okkt_dist_cb", C.c_void_p(b.ptr), 1)
+                self._timed(timings, "factor_top", r, s, "okkt_dist_factor_top")
         counts = []
         for s in self.solvers:
             c = np.zeros(4, dtype=np.int64)
@@ -188,25 +199,25 @@ class ShardedLinearSolver:
             self.inertia = tuple(int(v) for v in t)
         return int(flag)
 
-    def solve(self, d_rhs_per_rank):
+    def solve(self, d_rhs_per_rank, timings=None):
         """Returns the solution (original ordering) as a numpy array on every rank that owns buffer 0."""
         cvs, xs, sols = self._bufs["cv"], self._bufs["x"], self._bufs["sol"]
         for b in cvs:
             b.zero()
-        for s, dr in zip(self.solvers, d_rhs_per_rank):
-            self._call(s, "okkt_dist_solve_begin", C.c_void_p(dr))
+        for s, dr, r in zip(self.solvers, d_rhs_per_rank, self.comm.ranks):
+            self._timed(timings, "solve_fwd_local", r, s, "okkt_dist_solve_begin", C.c_void_p(dr))
         for s, b in zip(self.solvers, cvs):
             self._call(s, "okkt_dist_cv", C.c_void_p(b.ptr), 0)
         self.comm.reduce_sum(cvs, dst=0)
         for s, b, xb, r in zip(self.solvers, cvs, xs, self.comm.ranks):
             if r == 0:
                 self._call(s, "okkt_dist_cv", C.c_void_p(b.ptr), 1)
-                self._call(s, "okkt_dist_solve_top")
+                self._timed(timings, "solve_top", r, s, "okkt_dist_solve_top")
                 self._call(s, "okkt_dist_x", C.c_void_p(xb.ptr), 0)
         self.comm.broadcast(xs, src=0)                        # separator solution to every part
-        for s, xb, sb in zip(self.solvers, xs, sols):
+        for s, xb, sb, r in zip(self.solvers, xs, sols, self.comm.ranks):
             self._call(s, "okkt_dist_x", C.c_void_p(xb.ptr), 1)
-            self._call(s, "okkt_dist_solve_end")
+            self._timed(timings, "solve_bwd_local", r, s, "okkt_dist_solve_end")
             self._call(s, "okkt_dist_x", C.c_void_p(sb.ptr), 2)
         self.comm.reduce_sum(sols, dst=0)
         return sols[0].download()
