@@ -27,5 +27,7 @@ def test_sharded_path_on_real_ranks(world):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.join(ROOT, "tests", "multi_gpu_case.py")]
-    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and r.stdout.count("MULTI_GPU_OK") == world, (r.stdout[-800:], r.stderr[-2000:])
+    assert r.stdout.count("MULTI_GPU_SC5") == world          # full-size BASELINE config 5 ran on every rank
+    print("\n".join(l for l in r.stdout.splitlines() if l.startswith("MULTI_GPU")))
