@@ -452,6 +452,9 @@ static std::string analyze_one(int64_t n64, const int64_t* colptr, const int64_t
   }
   {
     std::vector<int64_t> cnt(ns + 1, 0);
+    std::vector<int> ent_sn((size_t)nnz_in, -1);     // destination supernode of every used entry
+    // position of a row inside the front of supernode s: the pivot rows are the columns themselves (no search), the rest
+    // by binary search in the sorted tail of the row list
     for (int j = 0; j < n; ++j)
       for (int64_t p = colptr[j] - base; p < colptr[j + 1] - base; ++p) {
         int i = (int)(rowval[p] - base);
@@ -461,11 +464,18 @@ static std::string analyze_one(int64_t n64, const int64_t* colptr, const int64_t
         int s = S.col2sn[c];
         const int* rb = &S.rows[S.row_ptr[s]];
         const int* re = &S.rows[S.row_ptr[s + 1]];
-        const int* it = std::lower_bound(rb, re, r);
-        if (it == re || *it != r) return "internal error: entry outside the symbolic structure";
+        const int ksn = col0[s + 1] - col0[s];
+        int64_t pos;
+        if (r < col0[s + 1]) pos = r - col0[s];
+        else {
+          const int* it = std::lower_bound(rb + ksn, re, r);
+          if (it == re || *it != r) return "internal error: entry outside the symbolic structure";
+          pos = it - rb;
+        }
         int64_t f = re - rb;
-        int64_t off = (int64_t)(c - col0[s]) * f + (it - rb);
+        int64_t off = (int64_t)(c - col0[s]) * f + pos;
         S.amap[p] = S.front_pos[s] + off;
+        ent_sn[p] = s;
         ++cnt[s + 1];
       }
     S.aent_ptr.assign(ns + 1, 0);
@@ -474,13 +484,11 @@ static std::string analyze_one(int64_t n64, const int64_t* colptr, const int64_t
     S.aent_dst.resize(S.aent_ptr[ns]);
     std::vector<int64_t> fill(S.aent_ptr.begin(), S.aent_ptr.end() - 1);
     for (int64_t p = 0; p < nnz_in; ++p) {
-      int64_t off = S.amap[p];
-      if (off < 0) continue;
-      // locate the destination supernode from the arena offset
-      int s = (int)(std::upper_bound(S.front_pos.begin(), S.front_pos.end(), off) - S.front_pos.begin()) - 1;
+      const int s = ent_sn[p];
+      if (s < 0) continue;
       int64_t q = fill[s]++;
       S.aent_src[q] = p;
-      S.aent_dst[q] = (int)(off - S.front_pos[s]);
+      S.aent_dst[q] = (int)(S.amap[p] - S.front_pos[s]);
     }
     // inside a supernode keep the entries sorted by destination: the big-front assemble kernel
     // locates the entries of a column block by binary search
@@ -556,9 +564,18 @@ std::string analyze_pattern(int64_t n64, const int64_t* colptr, const int64_t* r
     SymbolicOptions oa = opts, ob = opts;
     oa.ordering = 3;
     ob.ordering = 5;
-    Symbolic Sa, Sb;
-    std::string ea, eb;
-    std::thread tb([&] { eb = analyze_one(n64, colptr, rowval, index_base, ob, user_perm, Sb, nullptr, true); });
+    Symbolic Sa, Sb, Sspec;
+    std::string ea, eb, espec = "not run";
+    // The dissection is the faster of the two on many-core hosts (its pieces are ordered in parallel, minimum degree is one
+    // thread): its thread goes on with the FULL analysis of its own ordering while minimum degree is still running -- the plan
+    // is ready when the comparison is decided, and is thrown away when minimum degree wins
+    std::thread tb([&] {
+      eb = analyze_one(n64, colptr, rowval, index_base, ob, user_perm, Sb, nullptr, true);
+      if (eb.empty() && Sb.ordering_used == 5 && Sb.flops_exact >= 1e9) {
+        const std::vector<int> ord = Sb.perm;
+        espec = analyze_one(n64, colptr, rowval, index_base, ob, user_perm, Sspec, &ord, false);
+      }
+    });
     ea = analyze_one(n64, colptr, rowval, index_base, oa, user_perm, Sa, nullptr, true);
     tb.join();
     if (!ea.empty()) return ea;
@@ -567,6 +584,7 @@ std::string analyze_pattern(int64_t n64, const int64_t* colptr, const int64_t* r
       fprintf(stderr, "okkt: analyze candidates: AMD flops %.4g nnz(L) %ld | nested dissection flops %.4g nnz(L) %ld -> %s\n",
               Sa.flops_exact, (long)Sa.nnzL, Sb.flops_exact, (long)Sb.nnzL, nd_wins ? "nested dissection" : "AMD");
     if (nd_wins) {
+      if (espec.empty()) { S = std::move(Sspec); return ""; }
       const std::vector<int> ord = Sb.perm;
       return analyze_one(n64, colptr, rowval, index_base, ob, user_perm, S, &ord, false);
     }
