@@ -116,6 +116,7 @@ struct Numeric {
   std::vector<SolveLevel> slevels, slevels_top;
   hipEvent_t inv_event = nullptr;        // recorded behind the block inversions that the factorisation started on the auxiliary stream
   bool inv_wait = false;                 // ... which the next solve has to wait for
+  hipStream_t inv_stream = nullptr;      // the stream those inversions were put on
   std::vector<LevelSchedule> levels;      // subtrees owned by this part (everything when unpartitioned)
   std::vector<LevelSchedule> levels_top;  // top of the tree (part 0 of a partitioned plan only)
   int part_id = 0;
@@ -141,6 +142,8 @@ struct Numeric {
   hipStream_t stream_panel = nullptr;
   hipStream_t stream_aux = nullptr;     // off-critical-path part of the in-group panel updates
   int split_head = 1;
+  int decouple = 0;                      // OKKT_DECOUPLE=1: single-block steps with the diagonal chain ahead of the wide trsm / trailing update (aux stream); measured slower
+  int decouple_min_rows = 256;           // ... while at least this many rows are left below the step
   int lookahead = 1;
   int sb_tail_rows = 4000;               // the inversion of the finished diagonal blocks starts once fewer rows than this remain
   int la_min_tiles = 600;                // rest triangle must hold at least this many 128 x 128 tiles

@@ -766,7 +766,9 @@ __global__ __launch_bounds__(256) void k_big_invert(DevPlan P, const int* __rest
 // feeds the later products straight from registers.  L blocks and X_ii are staged once per workgroup in LDS
 // and read as broadcast A operands.  L21 = W * D^-1.
 template <int NBLK>
-__global__ __launch_bounds__(256) void k_big_trsm(DevPlan P, const int* __restrict__ list, int step, int wcol0) {
+__global__ __launch_bounds__(256) void k_big_trsm(DevPlan P, const int* __restrict__ list, int step, int wcol0, int blk_lo) {
+  // blk_lo: first 64-row block of the panel this launch handles (the grid covers blocks blk_lo, blk_lo + 1, ...): the decoupled
+  // schedule solves the first 128 rows on the critical path and the rest beside the next diagonal block
   constexpr int NB = NBLK * kIB;
   constexpr int NPAIR = NBLK * (NBLK + 1) / 2;
   extern __shared__ __attribute__((aligned(16))) double sm[];   // NPAIR blocks of 32 x 32, then NB reciprocals
@@ -779,7 +781,7 @@ __global__ __launch_bounds__(256) void k_big_trsm(DevPlan P, const int* __restri
   const int j0 = step * NB;
   if (j0 >= k) return;
   const int nb = min(NB, k - j0);
-  const int r0 = j0 + nb + blockIdx.x * 64;
+  const int r0 = j0 + nb + ((int)blockIdx.x + blk_lo) * 64;
   if (r0 >= f) return;
   double* F = P.arena + P.front_pos[s];
   double* Wb = P.wbuf + P.wbuf_pos[s] + (size_t)wcol0 * f;   // this panel's slot inside the super-step's W
@@ -899,7 +901,9 @@ constexpr int kSyrkNW = 8;   // 2 x 4 waves of 64 rows x 32 columns: four waves 
 // staged 128 rows deep (the DMA shape stays), only the first 64 are read.
 template <int DBG, int HEAD, int TC = 128>
 __global__ __launch_bounds__(kSyrkNW * 64, kSyrkNW / 2) void k_big_syrk(DevPlan P, const int* __restrict__ list, int stepA, int npan,
-                                                                        int tstep, int NB, int wofs, int csplit) {
+                                                                        int tstep, int NB, int wofs, int csplit, int sub0) {
+  // sub0 (kSyrkTrail only): 0 the whole region, 1 only its first 128 x 128 tile (the next diagonal block: critical path of the
+  // decoupled schedule), 2 everything but that tile
   static_assert(TC == 128 || (TC == 64 && HEAD == kSyrkTrail), "64-column tiles exist for the trailing triangle only");
   // Applies the panels [stepA, stepA + npan) (K = up to npan * NB columns, W panels side by side in wbuf from
   // column wofs) to the region that starts at block column tstep; K = GS * NB halves the C traffic per flop.
@@ -930,10 +934,14 @@ __global__ __launch_bounds__(kSyrkNW * 64, kSyrkNW / 2) void k_big_syrk(DevPlan 
   // XCD-aware order: consecutive tile indices (which share operand panels) stay on one XCD and its L2
   // `per` from THIS front's tile count, not from the grid (which is sized for the largest front of the level):
   // otherwise a smaller front of a batched launch runs on the first one or two XCDs only
+  int skip = 0;
+  if (HEAD == kSyrkTrail && sub0 == 1) ntiles = min(ntiles, TC == 128 ? 1 : 2);
+  else if (HEAD == kSyrkTrail && sub0 == 2) { skip = TC == 128 ? 1 : 2; ntiles = max(ntiles - skip, 0); }
   const int per = (ntiles + 7) >> 3;
   if ((int)(blockIdx.x >> 3) >= per) return;
-  const int idx = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+  int idx = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
   if (idx >= ntiles) return;
+  idx += skip;
   int ti, tj;
   if (HEAD == kSyrkPanel) { ti = idx + (csplit == 2 ? 1 : 0); tj = 0; }
   else if (HEAD == kSyrkAhead) {
@@ -1567,7 +1575,7 @@ std::string numeric_factor_enqueue(Numeric& N, const double* d_vals, double tol,
   }
   if (inv_on_aux) {    // the next solve waits for the block inversions that are still running on the auxiliary stream
     if (!N.inv_event) OKKT_HIP_TRY(hipEventCreateWithFlags(&N.inv_event, hipEventDisableTiming));
-    OKKT_HIP_TRY(hipEventRecord(N.inv_event, N.stream_aux));
+    OKKT_HIP_TRY(hipEventRecord(N.inv_event, N.inv_stream ? N.inv_stream : N.stream_aux));
     N.inv_wait = true;
   }
   OKKT_HIP_TRY(hipGetLastError());
@@ -1676,8 +1684,12 @@ static std::string factor_sched(Numeric& N, DevPlan P, const std::vector<LevelSc
         if (ntile == 0) return "";
         // few tiles: 128 x 64 tiles (see k_big_syrk); decided on the largest front of the launch
         static const int small_max = getenv("OKKT_SYRK_SMALL_TILES") ? atoi(getenv("OKKT_SYRK_SMALL_TILES")) : 4000;
-        const bool narrow = (head == 0 || head == 3) && dbg_syrk == 0 && (int64_t)ntile * g.cnt <= small_max;
+        const int sub0 = head == 0 ? (sub == 11 ? 1 : (sub == 12 ? 2 : 0)) : 0;     // decoupled schedule: the next diagonal tile / the rest
+        const bool narrow = (head == 0 || head == 3) && dbg_syrk == 0 && sub0 != 1 && (int64_t)ntile * g.cnt <= small_max;
         if (narrow) ntile = head == 0 ? T * (T + 1) : Tr * (Tr + 1);
+        if (sub0 == 1) ntile = 1;
+        else if (sub0 == 2) ntile -= narrow ? 2 : 1;
+        if (ntile <= 0) return "";
         const dim3 grid((ntile + 7) / 8 * 8, g.cnt);
         const int wofs = par * GS * NB;
         const bool prof = N.profile && (head == 0 || head == 3);   // the dominant kernel: k_big_syrk<0, kSyrkTrail>
@@ -1698,18 +1710,22 @@ static std::string factor_sched(Numeric& N, DevPlan P, const std::vector<LevelSc
             if (head == 1) { const double w = std::min<double>(t0 + NB, kk) - t0; fl += 2.0 * K * (w * remq - w * (w - 1.0) / 2.0); }
             else if (head == 2) fl += 2.0 * K * (w2 * remq - w2 * (w2 - 1.0) / 2.0);
             else if (head == 3) fl += K * remr * (remr + 1.0);
-            else fl += K * remq * (remq + 1.0);
+            else {
+              const double tw = std::min(128.0, remq);
+              const double first = K * tw * (tw + 1.0);
+              fl += sub0 == 1 ? first : (sub0 == 2 ? K * remq * (remq + 1.0) - first : K * remq * (remq + 1.0));
+            }
           }
           if (N.prof_used + 2 > N.prof_events.size())
             for (int q = 0; q < 512; ++q) { hipEvent_t ev; OKKT_HIP_TRY(hipEventCreate(&ev)); N.prof_events.push_back(ev); }
           N.prof_flops.push_back(fl);
           OKKT_HIP_TRY(hipEventRecord(N.prof_events[N.prof_used++], sst));
         }
-#define OKKT_SYRK(D, H) hipLaunchKernelGGL((k_big_syrk<D, H>), grid, dim3(kSyrkNW * 64), syrk_lds_bytes(kSyrkStages), sst, P, list, stepA, npan, tstep, NB, wofs, csplit)
+#define OKKT_SYRK(D, H) hipLaunchKernelGGL((k_big_syrk<D, H>), grid, dim3(kSyrkNW * 64), syrk_lds_bytes(kSyrkStages), sst, P, list, stepA, npan, tstep, NB, wofs, csplit, sub0)
         const int csplit = head == 1 ? sub : (head == 0 ? 0 : cs);
         if (head == 1) OKKT_SYRK(0, kSyrkPanel);
         else if (head == 2) OKKT_SYRK(0, kSyrkAhead);
-        else if (narrow) hipLaunchKernelGGL((k_big_syrk<0, kSyrkTrail, 64>), grid, dim3(kSyrkNW * 64), syrk_lds_bytes(kSyrkStages), sst, P, list, stepA, npan, tstep, NB, wofs, csplit);
+        else if (narrow) hipLaunchKernelGGL((k_big_syrk<0, kSyrkTrail, 64>), grid, dim3(kSyrkNW * 64), syrk_lds_bytes(kSyrkStages), sst, P, list, stepA, npan, tstep, NB, wofs, csplit, sub0);
         else switch (dbg_syrk) {   // timing-only ablations of the trailing update (OKKT_DEBUG_SYRK): wrong outputs
           case 81: OKKT_SYRK(1, kSyrkTrail); break;    // no C load
           case 82: OKKT_SYRK(2, kSyrkTrail); break;    // no MFMA
@@ -1724,6 +1740,24 @@ static std::string factor_sched(Numeric& N, DevPlan P, const std::vector<LevelSc
         return "";
       };
       auto rem_rows = [&](int step) { return g.maxf - step * NB; };
+      // rows below the diagonal block of `step`, 64-row blocks [blk_lo, blk_lo + blk_cnt) (blk_cnt < 0: to the end); W goes to
+      // slot i of the super-step with parity par
+      auto launch_trsm = [&](hipStream_t pst, int step, int par, int i, int blk_lo, int blk_cnt) {
+        const int rem = g.maxf - step * NB;  // upper bound on rows below the diagonal block
+        int nblk = (rem + 63) / 64 - blk_lo;
+        if (blk_cnt >= 0) nblk = std::min(nblk, blk_cnt);
+        if (rem <= 0 || nblk <= 0) return;
+        const dim3 gr(nblk, g.cnt);
+        const int nbl = NB / kIB;
+        const size_t lds_trsm = ((size_t)nbl * (nbl + 1) / 2 * kIB * kIB + NB) * sizeof(double);
+        const int wc = (par * GS + i) * NB;
+        switch (nbl) {
+          case 1: hipLaunchKernelGGL(k_big_trsm<1>, gr, dim3(256), lds_trsm, pst, P, list, step, wc, blk_lo); break;
+          case 2: hipLaunchKernelGGL(k_big_trsm<2>, gr, dim3(256), lds_trsm, pst, P, list, step, wc, blk_lo); break;
+          case 3: hipLaunchKernelGGL(k_big_trsm<3>, gr, dim3(256), lds_trsm, pst, P, list, step, wc, blk_lo); break;
+          default: hipLaunchKernelGGL(k_big_trsm<4>, gr, dim3(256), lds_trsm, pst, P, list, step, wc, blk_lo); break;
+        }
+      };
       // the panels of super-step q (block columns [q * GS, (q + 1) * GS)): diag -> trsm, with the in-group
       // "head" update that brings each later panel of the group up to date first
       auto launch_panels = [&](hipStream_t pst, int stepA, int gs, int par) -> std::string {
@@ -1757,10 +1791,10 @@ static std::string factor_sched(Numeric& N, DevPlan P, const std::vector<LevelSc
             const size_t lds_trsm = ((size_t)nbl * (nbl + 1) / 2 * kIB * kIB + NB) * sizeof(double);
             const int wc = (par * GS + i) * NB;
             switch (nbl) {
-              case 1: hipLaunchKernelGGL(k_big_trsm<1>, gr, dim3(256), lds_trsm, pst, P, list, step, wc); break;
-              case 2: hipLaunchKernelGGL(k_big_trsm<2>, gr, dim3(256), lds_trsm, pst, P, list, step, wc); break;
-              case 3: hipLaunchKernelGGL(k_big_trsm<3>, gr, dim3(256), lds_trsm, pst, P, list, step, wc); break;
-              default: hipLaunchKernelGGL(k_big_trsm<4>, gr, dim3(256), lds_trsm, pst, P, list, step, wc); break;
+              case 1: hipLaunchKernelGGL(k_big_trsm<1>, gr, dim3(256), lds_trsm, pst, P, list, step, wc, 0); break;
+              case 2: hipLaunchKernelGGL(k_big_trsm<2>, gr, dim3(256), lds_trsm, pst, P, list, step, wc, 0); break;
+              case 3: hipLaunchKernelGGL(k_big_trsm<3>, gr, dim3(256), lds_trsm, pst, P, list, step, wc, 0); break;
+              default: hipLaunchKernelGGL(k_big_trsm<4>, gr, dim3(256), lds_trsm, pst, P, list, step, wc, 0); break;
             }
           }
         }
@@ -1777,7 +1811,9 @@ static std::string factor_sched(Numeric& N, DevPlan P, const std::vector<LevelSc
       // A front of at least two such blocks starts early: the blocks that are final when it enters its chain-bound tail
       // (fewer than sb_tail_rows rows left, idle CUs) are inverted during the tail, the rest behind the last panel.
       const SolveLevel& SL = slevels[l];
-      hipStream_t inv_st = ss.aux ? ss.aux : st;
+      // (with the decoupled schedule the auxiliary stream carries the wide trsm / trailing updates of the tail, and the panel
+      // stream is idle there: the inversions go to the panel stream)
+      hipStream_t inv_st = (N.decouple && ss.aux && ss.panel) ? ss.panel : (ss.aux ? ss.aux : st);
       const bool inv_early = ss.aux != nullptr && SL.wide_cnt > 0 && g.maxk >= 2 * kSolveBlock && N.sb_tail_rows >= 0;
       int inv_steps_done = 0, inv_blocks_done = 0;
       const size_t lds_inv = ((size_t)(NB + 2) * NB + 3 * kTld * kIB) * sizeof(double);
@@ -1794,7 +1830,7 @@ static std::string factor_sched(Numeric& N, DevPlan P, const std::vector<LevelSc
           hipLaunchKernelGGL(k_big_invert, dim3(steps_upto - inv_steps_done, g.cnt), dim3(256), lds_inv, inv_st, P, list, NB, inv_steps_done);
           if (!(e2 = solve_invert_enqueue(N, inv_st, SL, inv_blocks_done, blocks_upto)).empty()) return e2;
           inv_steps_done = steps_upto; inv_blocks_done = blocks_upto;
-          inv_on_aux = true;
+          inv_on_aux = true; N.inv_stream = inv_st;
           return "";
         }
         if (nsteps > inv_steps_done)
@@ -1805,7 +1841,7 @@ static std::string factor_sched(Numeric& N, DevPlan P, const std::vector<LevelSc
             if (!(e2 = next_event(&evs)).empty()) return e2;
             OKKT_HIP_TRY(hipEventRecord(evs, st));
             OKKT_HIP_TRY(hipStreamWaitEvent(inv_st, evs, 0));
-            inv_on_aux = true;
+            inv_on_aux = true; N.inv_stream = inv_st;
           }
           if (!(e2 = solve_invert_enqueue(N, inv_st, SL, inv_blocks_done, 1 << 30)).empty()) return e2;
         }
@@ -1815,6 +1851,7 @@ static std::string factor_sched(Numeric& N, DevPlan P, const std::vector<LevelSc
       std::string e = launch_panels(st, 0, gs_cur, par);
       if (!e.empty()) return e;
       hipEvent_t ev_panel = nullptr;   // set while the panels of the current super-step are on the panel stream
+      bool dec_partial = false;        // decoupled schedule: only the first 128 rows of the current panel's trsm have been done
       for (int stepA = 0; stepA < nsteps;) {
         const int stepB = stepA + gs_cur;                          // first block column of the next super-step
         const bool more = stepB < nsteps;
@@ -1831,8 +1868,35 @@ static std::string factor_sched(Numeric& N, DevPlan P, const std::vector<LevelSc
           if (ev_panel) OKKT_HIP_TRY(hipStreamWaitEvent(st, ev_panel, 0));
           if (!(e = launch_syrk(st, stepA, gs_cur, stepB, 3, par, gs_next)).empty()) return e;
           ev_panel = evp;
+        } else if (N.decouple && ss.aux != nullptr && gs_cur == 1 && (!more || gs_next == 1) && rem_rows(stepB) >= N.decouple_min_rows && dbg_syrk == 0) {
+          // Decoupled single-block steps (round 3): the chain  diag(q) -> first 128 rows of trsm(q) -> update of the next
+          // diagonal tile -> diag(q + 1)  runs on `st`; the rest of trsm(q) and the rest of the trailing update follow one
+          // step behind on the auxiliary stream.  Every tile still receives its updates in the same order as in the
+          // in-order schedule (bitwise the same factor): the next diagonal tile gets panel q - 1 from the auxiliary stream
+          // before panel q from the chain (the chain waited for it before the tile solve of step q).
+          if (ev_panel) { OKKT_HIP_TRY(hipStreamWaitEvent(st, ev_panel, 0)); ev_panel = nullptr; }
+          hipEvent_t evT, evR;
+          if (!(e = next_event(&evT)).empty() || !(e = next_event(&evR)).empty()) return e;
+          OKKT_HIP_TRY(hipEventRecord(evT, st));                        // diag(stepA) and the first tile of its trsm are behind this
+          OKKT_HIP_TRY(hipStreamWaitEvent(ss.aux, evT, 0));
+          // panels before stepA are final behind this point of `st` (it waited for their wide trsm): block inversions for the solves
+          if (inv_early && rem_rows(stepB) < N.sb_tail_rows && !(e = inv_range(stepA, false)).empty()) return e;
+          if (dec_partial) launch_trsm(ss.aux, stepA, par, 0, 2, -1);    // the rows below the first 128
+          if (!(e = launch_syrk(ss.aux, stepA, 1, stepB, 0, par, 0, more ? 12 : 0)).empty()) return e;
+          OKKT_HIP_TRY(hipEventRecord(evR, ss.aux));
+          dec_partial = false;
+          if (more) {
+            if (!(e = launch_syrk(st, stepA, 1, stepB, 0, par, 0, 11)).empty()) return e;      // the next diagonal tile
+            hipLaunchKernelGGL(k_big_diag, dim3(g.cnt), dim3(256), lds_diag, st, P, list, stepB, NB, tol, dbg_stop);
+            OKKT_HIP_TRY(hipStreamWaitEvent(st, evR, 0));               // column stepB is up to date
+            launch_trsm(st, stepB, par ^ 1, 0, 0, 2);
+            dec_partial = true;
+          } else {
+            OKKT_HIP_TRY(hipStreamWaitEvent(st, evR, 0));
+          }
         } else {
           if (ev_panel) { OKKT_HIP_TRY(hipStreamWaitEvent(st, ev_panel, 0)); ev_panel = nullptr; }
+          if (dec_partial) { launch_trsm(st, stepA, par, 0, 2, -1); dec_partial = false; }   // leaving the decoupled schedule: finish the panel
           // columns below stepB * NB are final behind this point of `st`: once the front is in its chain-bound tail, the
           // inversion of the finished super-blocks starts on the auxiliary stream
           // (every block that has become final since the last call: in the tail the CUs are idle anyway, and the first solve
