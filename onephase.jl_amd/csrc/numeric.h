@@ -142,6 +142,7 @@ struct Numeric {
   hipStream_t stream_panel = nullptr;
   hipStream_t stream_aux = nullptr;     // off-critical-path part of the in-group panel updates
   int split_head = 1;
+  int diag2 = 1;                         // k_big_diag2 (role-split, pipelined) instead of k_big_diag; OKKT_DIAG2=0 switches back
   int decouple = 0;                      // OKKT_DECOUPLE=1: single-block steps with the diagonal chain ahead of the wide trsm / trailing update (aux stream); measured slower
   int decouple_min_rows = 256;           // ... while at least this many rows are left below the step
   int lookahead = 1;

@@ -669,6 +669,200 @@ __global__ __launch_bounds__(256) void k_big_diag(DevPlan P, const int* __restri
   }
 }
 
+// k_big_diag2 (round 3): the same factorisation with the two kinds of work on different waves, software-pipelined.
+//   waves 2, 3 hold ALL 36 accumulator tiles (18 each) and do every MFMA; waves 0, 1 are the 128 row threads.
+//   Micro-step m:   waves 2, 3: rank-8 update of step m - 1 on the tile column that holds panel m, copy panel m out -> barrier
+//                   waves 0, 1: 8 x 8 factor + row solve of panel m      ||      waves 2, 3: rest of the update of step m - 1 -> barrier
+//   In k_big_diag the row threads and the MFMA updates alternate and half of the workgroup idles in each; here a micro-step
+//   costs max(row work, rest of the previous update) + the short head.  -L / W panels are double-buffered in LDS.  The
+//   arithmetic per entry is the same sequence of operations: bitwise the same factor.
+__global__ __launch_bounds__(384) void k_big_diag2(DevPlan P, const int* __restrict__ list, int step, int NB, double tol) {
+  static_assert(kMW == 8, "micro-panels of 8 columns");
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const int s = list[blockIdx.x];
+  if (stop_requested_wg(P)) return;
+  const int col0 = P.sn_col0[s];
+  const int k = P.sn_col0[s + 1] - col0;
+  const int f = (int)(P.row_ptr[s + 1] - P.row_ptr[s]);
+  const int j0 = step * NB;
+  if (j0 >= k) return;
+  const int nb = min(NB, k - j0);
+  double* Praw = sm;                           // 8 x kPLD: raw micro-panel (columns as rows of the array)
+  double* LpB = Praw + kMW * kPLD;             // -L of the micro-panel, two buffers
+  double* WpB = LpB + 2 * kMW * kPLD;          // W = L * D, two buffers
+  double* Ld = WpB + 2 * kMW * kPLD;           // 4 diagonal 32 x 32 blocks of L, leading dimension 33
+  double* Xs = Ld + 4 * 32 * kXld;             // their inverses
+  double* F = P.arena + P.front_pos[s];
+  const bool mm = wave >= 2;                   // MFMA wave (four of them: one per SIMD; the two row waves share two of the SIMDs)
+  // tiles of an MFMA wave: t = 4 q + (wave - 2), column-major over the lower triangle of the 8 x 8 tile grid
+  int ti_s[9], tj_s[9];
+#pragma unroll
+  for (int q = 0; q < 9; ++q) {
+    const int t = 4 * q + ((wave + 2) & 3);
+    const int tj = (t >= 8) + (t >= 15) + (t >= 21) + (t >= 26) + (t >= 30) + (t >= 33) + (t >= 35);
+    const int start = tj * 8 - tj * (tj - 1) / 2;
+    tj_s[q] = tj;
+    ti_s[q] = tj + (t - start);
+  }
+  d4_t acc[9];
+  if (mm) {
+    double raw[9][4];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+      const int r = 16 * ti_s[q] + l15;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int c = 16 * tj_s[q] + 4 * v + l4;
+        raw[q][v] = F[(size_t)(j0 + min(c, nb - 1)) * f + j0 + min(r, nb - 1)];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+      const int r = 16 * ti_s[q] + l15;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int c = 16 * tj_s[q] + 4 * v + l4;
+        const double pad = r == c ? 1.0 : 0.0;
+        acc[q][v] = (r < nb && c < nb && r >= c) ? raw[q][v] : pad;
+      }
+    }
+  }
+  double my_d = 1.0;
+  const int nms = (nb + kMW - 1) / kMW;        // micro-steps
+  for (int ms = 0; ms < nms; ++ms) {
+    const int p8 = ms * kMW, pp = ms >> 1, h = ms & 1;
+    const double* Lprev = LpB + ((ms + 1) & 1) * kMW * kPLD;    // panels of micro-step ms - 1
+    const double* Wprev = WpB + ((ms + 1) & 1) * kMW * kPLD;
+    if (mm) {
+      // head: update of step ms - 1 on the tile column of panel ms, then the copy-out of panel ms
+      if (ms > 0) {
+#pragma unroll
+        for (int q = 0; q < 9; ++q)
+          if (tj_s[q] == pp) {
+            const int rr = 16 * ti_s[q] + l15, cc = 16 * tj_s[q] + l15;
+            double av[2], bv[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) { av[e] = Wprev[(4 * e + l4) * kPLD + cc]; bv[e] = Lprev[(4 * e + l4) * kPLD + rr]; }
+#pragma unroll
+            for (int e = 0; e < 2; ++e) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[e], bv[e], acc[q], 0, 0, 0);
+          }
+      }
+#pragma unroll
+      for (int q = 0; q < 9; ++q)
+        if (tj_s[q] == pp) {
+          const int r = 16 * ti_s[q] + l15;
+#pragma unroll
+          for (int e = 0; e < 2; ++e) Praw[(4 * e + l4) * kPLD + r] = h == 0 ? acc[q][e] : acc[q][2 + e];
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (!mm) {
+      // row threads: 8 x 8 diagonal LDL^T redundantly in registers, own row solved, panels and final entries written
+      double* Lp = LpB + (ms & 1) * kMW * kPLD;
+      double* Wp = WpB + (ms & 1) * kMW * kPLD;
+      if (tid >= p8 && tid < 128) {
+        const int r = tid;
+        double A[kMW][kMW], a[kMW], rd[kMW], w[kMW], lr[kMW];
+#pragma unroll
+        for (int c = 0; c < kMW; ++c) {
+          a[c] = Praw[c * kPLD + r];
+#pragma unroll
+          for (int i = c; i < kMW; ++i) A[i][c] = Praw[c * kPLD + p8 + i];
+        }
+#pragma unroll
+        for (int c = 0; c < kMW; ++c) {
+          rd[c] = fast_rcp_f64(A[c][c]);
+          w[c] = a[c];
+          lr[c] = w[c] * rd[c];
+#pragma unroll
+          for (int i = c + 1; i < kMW; ++i) {
+            const double lic = A[i][c] * rd[c];
+#pragma unroll
+            for (int j = c + 1; j <= i; ++j) A[i][j] = __builtin_fma(-lic, A[j][c], A[i][j]);
+          }
+#pragma unroll
+          for (int j = c + 1; j < kMW; ++j) a[j] = __builtin_fma(-lr[c], A[j][c], a[j]);
+        }
+        const int i = r - p8;
+        double* Fr = F + (size_t)(j0 + p8) * f + j0 + r;
+#pragma unroll
+        for (int c = 0; c < kMW; ++c) {
+          Lp[c * kPLD + r] = -lr[c];
+          Wp[c * kPLD + r] = w[c];
+          const double val = i == c ? w[c] : lr[c];
+          if (i >= c && r < nb && p8 + c < nb) {
+            Fr[(size_t)c * f] = val;
+            if ((r >> 5) == ((p8 + c) >> 5)) Ld[(r >> 5) * 32 * kXld + (r & 31) + ((p8 + c) & 31) * kXld] = val;
+          }
+        }
+        if (i < kMW) {
+#pragma unroll
+          for (int c = 0; c < kMW; ++c) my_d = i == c ? w[c] : my_d;
+        }
+      }
+    } else if (ms > 0) {
+      // rest of the update of step ms - 1: the tile columns to the right of panel ms's
+#pragma unroll
+      for (int q = 0; q < 9; ++q)
+        if (tj_s[q] > pp) {
+          const int rr = 16 * ti_s[q] + l15, cc = 16 * tj_s[q] + l15;
+          double av[2], bv[2];
+#pragma unroll
+          for (int e = 0; e < 2; ++e) { av[e] = Wprev[(4 * e + l4) * kPLD + cc]; bv[e] = Lprev[(4 * e + l4) * kPLD + rr]; }
+#pragma unroll
+          for (int e = 0; e < 2; ++e) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[e], bv[e], acc[q], 0, 0, 0);
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  }
+  {
+    unsigned pos = 0, neg = 0, zer = 0, bad = 0;
+    if (tid < nb) {
+      P.dvals[col0 + j0 + tid] = my_d;
+      classify_pivot(my_d, tol, pos, neg, zer, bad);
+    }
+    flush_counts(P, 0, pos, neg, zer, bad);
+  }
+  // X_bb = inv(L_bb): wave b, one column per lane (Ld is complete behind the last barrier of the loop)
+  const int off = wave * 32;
+  if (wave < 4 && off < nb) {
+    const int w = min(32, nb - off);
+    const double* Lb = Ld + wave * 32 * kXld;
+    double* Xb = Xs + wave * 32 * kXld;
+    if (lane < 32) {
+      const int c = lane;
+      double x[32];
+#pragma unroll
+      for (int r = 0; r < 32; ++r) {
+        double v = (r == c) ? 1.0 : 0.0;
+        if (r < w) {
+#pragma unroll
+          for (int p = 0; p < r; ++p) v = __builtin_fma(-Lb[r + p * kXld], x[p], v);
+        }
+        x[r] = (r < w && c < w && r >= c) ? v : 0.0;
+      }
+#pragma unroll
+      for (int r = 0; r < 32; ++r) Xb[r + c * kXld] = x[r];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    double* Xg = P.invl + P.invl_pos[s] + (size_t)step * NB * NB;
+    const int r = lane & 31;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int c = (lane >> 5) + 2 * q;
+      Xg[(off + r) + (size_t)(off + c) * NB] = Xb[r + c * kXld];
+    }
+  }
+}
+
 // Deferred full inverse X = inv(L11) of every NB x NB diagonal block of the big fronts of a level (one
 // workgroup per block, all blocks in parallel, off the critical path of the factorisation: k_big_trsm
 // only needs the 32 x 32 diagonal inverses X_ii that k_big_diag leaves in `invl`).  The blocked solves read X.
@@ -1448,6 +1642,7 @@ std::string numeric_setup(const Symbolic& S, const SymbolicOptions& opts, hipStr
   const int big_lds = 160 * 1024 - 64;   // the stop-flag check keeps one static LDS word per kernel
   OKKT_HIP_TRY(hipFuncSetAttribute((const void*)k_front_small<256>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds));
   OKKT_HIP_TRY(hipFuncSetAttribute((const void*)k_big_diag, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds));
+  OKKT_HIP_TRY(hipFuncSetAttribute((const void*)k_big_diag2, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds));
   OKKT_HIP_TRY(hipFuncSetAttribute((const void*)k_big_invert, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds));
   OKKT_HIP_TRY(hipFuncSetAttribute((const void*)k_big_trsm<3>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds));
   OKKT_HIP_TRY(hipFuncSetAttribute((const void*)k_big_trsm<4>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds));
@@ -1617,6 +1812,7 @@ static std::string factor_sched(Numeric& N, DevPlan P, const std::vector<LevelSc
       const int* list = P.sched + g.off;
       const int nsteps = (g.maxk + NB - 1) / NB;
       const size_t lds_diag = ((size_t)3 * kMW * kPLD + (size_t)2 * 4 * 32 * kXld) * sizeof(double);
+      const size_t lds_diag2 = ((size_t)5 * kMW * kPLD + (size_t)2 * 4 * 32 * kXld) * sizeof(double);
       // every front of the segment must own a W buffer for this group size: decided on the smallest front
       const int GS = g.minf >= N.group_big_minf ? N.group_big : N.group;     // widest super-step of this segment (sizes wbuf)
       // Super-step widths adapt: GS block columns while the trailing update is long enough to hide the panel chain,
@@ -1782,7 +1978,8 @@ static std::string factor_sched(Numeric& N, DevPlan P, const std::vector<LevelSc
               if (!e.empty()) return e;
             }
           }
-          hipLaunchKernelGGL(k_big_diag, dim3(g.cnt), dim3(256), lds_diag, pst, P, list, step, NB, tol, dbg_stop);
+          if (N.diag2 && dbg_stop == 0) hipLaunchKernelGGL(k_big_diag2, dim3(g.cnt), dim3(384), lds_diag2, pst, P, list, step, NB, tol);
+          else hipLaunchKernelGGL(k_big_diag, dim3(g.cnt), dim3(256), lds_diag, pst, P, list, step, NB, tol, dbg_stop);
           if (ev_rest) OKKT_HIP_TRY(hipStreamWaitEvent(pst, ev_rest, 0));
           const int rem = g.maxf - step * NB;  // upper bound on rows below the diagonal block
           if (rem > 0) {
@@ -1887,7 +2084,8 @@ static std::string factor_sched(Numeric& N, DevPlan P, const std::vector<LevelSc
           dec_partial = false;
           if (more) {
             if (!(e = launch_syrk(st, stepA, 1, stepB, 0, par, 0, 11)).empty()) return e;      // the next diagonal tile
-            hipLaunchKernelGGL(k_big_diag, dim3(g.cnt), dim3(256), lds_diag, st, P, list, stepB, NB, tol, dbg_stop);
+            if (N.diag2 && dbg_stop == 0) hipLaunchKernelGGL(k_big_diag2, dim3(g.cnt), dim3(384), lds_diag2, st, P, list, stepB, NB, tol);
+            else hipLaunchKernelGGL(k_big_diag, dim3(g.cnt), dim3(256), lds_diag, st, P, list, stepB, NB, tol, dbg_stop);
             OKKT_HIP_TRY(hipStreamWaitEvent(st, evR, 0));               // column stepB is up to date
             launch_trsm(st, stepB, par ^ 1, 0, 0, 2);
             dec_partial = true;

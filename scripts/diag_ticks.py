@@ -15,7 +15,7 @@ h._lib.okkt_analyze(h._h, dim, L.p_i64(colptr), L.p_i64(rowval), base)
 inert = L.OkktInertia()
 for _ in range(2):
     h._lib.okkt_factor(h._h, L.p_f64(nzval), n, m, 1, C.byref(inert))
-nd = 49
+nd = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 c = [int(v) // 1000 for v in inert.as_tuple()]
 print("per launch (us): load %.2f  extract+barrier %.2f  compute+barrier %.2f  mfma(wave0) %.2f" % tuple(v * 0.01 / nd for v in c))
 finalize_b(h)
