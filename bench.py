@@ -207,7 +207,7 @@ def main():
         # (scripts/profile_bench.sh; FETCH_SIZE doubled as the MI355X guide prescribes for 16-byte-per-lane streams):
         # counters cannot be read from inside the timed process, so the committed summary of the latest round is quoted
         traffic = None
-        for name in ("r02_syrk_pmc.json", "r01_syrk_pmc.json"):
+        for name in ("r03_syrk_pmc.json", "r02_syrk_pmc.json", "r01_syrk_pmc.json"):
             pmc = os.path.join(ROOT, "profiles", name)
             if os.path.exists(pmc):
                 try:
@@ -243,7 +243,7 @@ def main():
                 "inertia_ok": bool(ok), "residual_inf": resid,
             },
             "roofline": {
-                "kernel": "k_big_syrk<0, 0> (kSyrkTrail: FP64 MFMA trailing update of the big fronts, main stream)",
+                "kernel": "k_big_syrk<0, 0, TC> (kSyrkTrail: FP64 MFMA trailing update of the big fronts, 128 x 128 tiles, or 128 x 64 on launches of few tiles)",
                 "bound": "mfma",
                 "achieved": achieved,
                 "peak": FP64_MFMA_PEAK_TFLOPS,
@@ -273,10 +273,10 @@ def main():
             live, detail = live_traffic(args.config)
             if live is not None:
                 out["roofline"]["traffic"] = live
-            detail.setdefault("source", "committed summary profiles/r02_syrk_pmc.json (live passes failed)")
+            detail.setdefault("source", "committed summary profiles/r03_syrk_pmc.json (live passes failed)")
             out["roofline"]["traffic_detail"] = detail
         else:
-            out["roofline"]["traffic_detail"] = {"source": "committed summary profiles/r02_syrk_pmc.json (scripts/profile_r02.sh)"}
+            out["roofline"]["traffic_detail"] = {"source": "committed summary profiles/r03_syrk_pmc.json (scripts/profile_r03.sh)"}
         if world == 1 and not args.no_kkt_level:
             out["config"]["kkt_level"] = kkt_level_breakdown(prob, local_rank)
         if world == 1 and not args.no_sharded_model:

@@ -18,9 +18,9 @@ work, out, rnd = sys.argv[1], sys.argv[2], sys.argv[3]
 CUS = 256
 # kernels of interest: (substring, label, reads are 16 B / lane ("wide": FETCH_SIZE doubled))
 KERNELS = [
-    ("k_big_syrk<0, 0>", "k_big_syrk<0,0> trailing update (dominant)", True),
-    ("k_big_syrk<0, 1>", "k_big_syrk<0,1> in-group update", True),
-    ("k_big_syrk<0, 2>", "k_big_syrk<0,2> look-ahead columns", True),
+    ("k_big_syrk<0, 0,", "k_big_syrk<0,0> trailing update (dominant)", True),
+    ("k_big_syrk<0, 1,", "k_big_syrk<0,1> in-group update", True),
+    ("k_big_syrk<0, 2,", "k_big_syrk<0,2> look-ahead columns", True),
     ("k_big_trsm", "k_big_trsm", False),
     ("k_big_diag", "k_big_diag", False),
     ("k_big_assemble_chunked", "k_big_assemble_chunked", False),
