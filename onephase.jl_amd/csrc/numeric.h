@@ -108,6 +108,9 @@ struct LaneStreams { hipStream_t main = nullptr, masked = nullptr, panel = nullp
 struct Numeric {
   DevPlan d;
   std::vector<LaneSched> xlanes;         // lanes 1, 2, ...
+  std::vector<hipEvent_t> solve_events;  // per-level fork / join of the sweeps (thin fronts beside wide fronts)
+  size_t solve_ev_used = 0;
+  int solve_fork = 0;                    // OKKT_SOLVE_FORK=1: the wide fronts of a level on the auxiliary stream beside the thin ones
   std::vector<hipEvent_t> lane_events;   // fork / join of the lanes
   size_t lane_ev_used = 0;
   bool early_before_top = false;         // lanes: the pivot counts are read once, between the lanes and the top of the tree

@@ -1670,6 +1670,9 @@ void numeric_release(Numeric& N) {
   N.xlanes.clear();
   for (hipEvent_t ev : N.lane_events) (void)hipEventDestroy(ev);
   N.lane_events.clear();
+  for (hipEvent_t ev : N.solve_events) (void)hipEventDestroy(ev);
+  N.solve_events.clear();
+  N.solve_ev_used = 0;
   N.lane_ev_used = 0;
   N.slevels.clear();
   N.slevels_top.clear();

@@ -915,6 +915,16 @@ std::string solve_invert_enqueue(Numeric& N, hipStream_t st, const SolveLevel& L
   return "";
 }
 
+// events of the per-level fork of the sweeps (a pool on the handle, reused by every solve)
+static hipEvent_t solve_event(Numeric& N) {
+  if (N.solve_ev_used >= N.solve_events.size()) {
+    hipEvent_t e2 = nullptr;
+    if (hipEventCreateWithFlags(&e2, hipEventDisableTiming) != hipSuccess) return nullptr;
+    N.solve_events.push_back(e2);
+  }
+  return N.solve_events[N.solve_ev_used++];
+}
+
 template <int R>
 static std::string fwd_enqueue_r(Numeric& N, const std::vector<LevelSchedule>& levels, const std::vector<SolveLevel>& sl, hipStream_t st, int l_lo, int l_hi) {
   DevPlan P = N.d;
@@ -928,11 +938,25 @@ static std::string fwd_enqueue_r(Numeric& N, const std::vector<LevelSchedule>& l
       else hipLaunchKernelGGL((k_fs_small<256, R>), dim3(g.cnt), dim3(256), lds, st, P, P.sched + g.off, g.maxf);
     }
     const SolveLevel& S = sl[l];
+    // the thin and the wide fronts of a level are independent: with both present the wide chain runs on the auxiliary stream
+    // beside the thin pair (OKKT_SOLVE_FORK, measured in DESIGN section 6)
+    hipStream_t wst = st;
+    hipEvent_t ev_join = nullptr;
+    if (S.thin_cnt && S.wide_cnt && N.solve_fork && N.stream_aux && N.stream_aux != st) {
+      hipEvent_t ev_fork = solve_event(N);
+      ev_join = solve_event(N);
+      if (ev_fork && ev_join) {
+        OKKT_HIP_TRY(hipEventRecord(ev_fork, st));
+        OKKT_HIP_TRY(hipStreamWaitEvent(N.stream_aux, ev_fork, 0));
+        wst = N.stream_aux;
+      } else ev_join = nullptr;
+    }
     if (S.thin_cnt) {
       hipLaunchKernelGGL(k_fwd_thin_y<R>, dim3(S.thin_cnt), dim3(256), 0, st, P, P.ssched + S.thin_off, N.nb);
       if (S.thin_maxr > 0) hipLaunchKernelGGL(k_fwd_thin_upd<R>, dim3((S.thin_maxr + 127) / 128, S.thin_cnt), dim3(256), 0, st, P, P.ssched + S.thin_off);
     }
     if (S.wide_cnt) {
+      hipStream_t st = wst;
       const int* list = P.ssched + S.wide_off;
       const int nblk = (S.wide_maxk + kSB - 1) / kSB;
       const size_t lds = ((size_t)R * kSB + (size_t)8 * R * kUpdRows) * sizeof(double);
@@ -942,6 +966,10 @@ static std::string fwd_enqueue_r(Numeric& N, const std::vector<LevelSchedule>& l
         const int rem = std::max(S.wide_maxf - b * kSB, 0);        // upper bound on the rows below the start of block b (a narrower last block leaves more rows than maxf - (b + 1) kSB)
         hipLaunchKernelGGL(k_fwd_upd<R>, dim3(std::max(1, (rem + kUpdRows - 1) / kUpdRows), S.wide_cnt), dim3(256), lds, st, P, list, b);
       }
+    }
+    if (ev_join) {
+      OKKT_HIP_TRY(hipEventRecord(ev_join, wst));
+      OKKT_HIP_TRY(hipStreamWaitEvent(st, ev_join, 0));
     }
   }
   OKKT_HIP_TRY(hipGetLastError());
@@ -954,7 +982,19 @@ static std::string bwd_enqueue_r(Numeric& N, const std::vector<LevelSchedule>& l
   for (int l = std::min(l_hi, (int)levels.size()) - 1; l >= l_lo; --l) {
     const LevelSchedule& L = levels[l];
     const SolveLevel& S = sl[l];
+    hipStream_t wst = st;
+    hipEvent_t ev_join = nullptr;
+    if (S.thin_cnt && S.wide_cnt && N.solve_fork && N.stream_aux && N.stream_aux != st) {
+      hipEvent_t ev_fork = solve_event(N);
+      ev_join = solve_event(N);
+      if (ev_fork && ev_join) {
+        OKKT_HIP_TRY(hipEventRecord(ev_fork, st));
+        OKKT_HIP_TRY(hipStreamWaitEvent(N.stream_aux, ev_fork, 0));
+        wst = N.stream_aux;
+      } else ev_join = nullptr;
+    }
     if (S.wide_cnt) {
+      hipStream_t st = wst;
       const int* list = P.ssched + S.wide_off;
       if (S.wide_maxf > 0) hipLaunchKernelGGL(k_bwd_pre<R>, dim3((S.wide_maxk + 3) / 4, S.wide_cnt), dim3(256), 0, st, P, list);
       const int nblk = (S.wide_maxk + kSB - 1) / kSB;
@@ -969,6 +1009,10 @@ static std::string bwd_enqueue_r(Numeric& N, const std::vector<LevelSchedule>& l
       const int* list = P.ssched + S.thin_off;
       if (S.thin_maxr > 0) hipLaunchKernelGGL(k_bwd_pre<R>, dim3((S.thin_maxk + 3) / 4, S.thin_cnt), dim3(256), 0, st, P, list);
       hipLaunchKernelGGL(k_bwd_thin<R>, dim3(S.thin_cnt), dim3(256), 0, st, P, list, N.nb);
+    }
+    if (ev_join) {
+      OKKT_HIP_TRY(hipEventRecord(ev_join, wst));
+      OKKT_HIP_TRY(hipStreamWaitEvent(st, ev_join, 0));
     }
     for (int c = 0; c < 3; ++c) {
       const Segment& g = L.seg[c];
@@ -1014,7 +1058,7 @@ static std::string sweep_which(Numeric& N, bool fwd, int which, int R) {
 
 std::string solve_fwd_enqueue(Numeric& N, int which, int R) {
   if (which == 0 && N.inv_wait) { OKKT_HIP_TRY(hipStreamWaitEvent(N.stream, N.inv_event, 0)); N.inv_wait = false; }   // inversions started by the factorisation
-  if (which == 0) N.lane_ev_used = 0;
+  if (which == 0) { N.lane_ev_used = 0; N.solve_ev_used = 0; }
   return sweep_which(N, true, which, R);
 }
 std::string solve_bwd_enqueue(Numeric& N, int which, int R) {
