@@ -121,6 +121,15 @@ function ipopt_strategy!(iter::Class_iterate, k::HIP_KKT_solver, pars::Class_par
         (Ptr{Cvoid}, Float64, Ref{OkktKktPars}, Ref{Int32}, Ref{Float64}), k.handle, get_delta(iter), p, num_fac, delta))
     k.delta_x_vec = delta[] * ones(dim(iter)); k.delta_s_vec = zeros(ncon(iter))
     k.ready = :factored
+    # delta_strategy.jl:94-98: a failed attempt on a diagonally dominant x-block prints a warning; the library ran the scan on the
+    # device after every failed attempt and counted
+    nwarn = Ref{Int32}(0)
+    if ccall((:okkt_kkt_diag_dom_warnings, OKKT_LIB), Cint, (Ptr{Cvoid}, Ref{Int32}), k.handle, nwarn) == 0
+        for _ in 1:nwarn[]
+            println("WARNING: Inertia calculation incorrect")
+            @warn("Inertia calculation incorrect")
+        end
+    end
     # the caller reads old_delta = get_delta(iter) and then calls set_delta(iter, new_delta) itself (one_phase.jl:203-206)
     return rc == 1 ? :success : :failure, Int(num_fac[]), delta[]
 end
@@ -169,4 +178,29 @@ function compute_direction_implementation!(k::HIP_KKT_solver, timer::class_advan
     k.dir.x = dx; k.dir.y = dy; k.dir.s = ds
     check_for_nan(k.dir)
     k.kkt_err_norm = Class_kkt_error(err[1], err[2], err[3], err[4], err[5], err[6])
+end
+
+
+# Several directions of the same factor in one pass over L: the probe of the aggressive step (Reduct_affine, take_step.jl:2-3) and the
+# candidates of take_step2! (take_step.jl:34-66) are right-hand sides of one factorised system.  Returns [(dir, kkt_err_norm)];
+# kkt_associate_rhs!(k, iter, ...) must have told the library the current iterate.
+function compute_directions!(k::HIP_KKT_solver, etas::Vector{Class_reduction_factors})
+    n = dim(k.factor_it); m = ncon(k.factor_it); q = length(etas)
+    e = zeros(3 * q)
+    for i in 1:q
+        e[3i - 2] = etas[i].P; e[3i - 1] = etas[i].D; e[3i] = etas[i].mu
+    end
+    dx = zeros(n * q); dy = zeros(m * q); ds = zeros(m * q); err = zeros(6 * q)
+    kkt_hip_check(k, "okkt_kkt_compute_directions", ccall((:okkt_kkt_compute_directions, OKKT_LIB), Cint,
+        (Ptr{Cvoid}, Int32, Ptr{Float64}, Int32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+        k.handle, Int32(q), e, Int32(k.pars.kkt.ItRefine_Num), dx, dy, ds, err))
+    out = Vector{Tuple{Class_point, Class_kkt_error}}()
+    for i in 1:q
+        d = Class_point(); d.x = dx[(i - 1) * n + 1:i * n]; d.y = dy[(i - 1) * m + 1:i * m]; d.s = ds[(i - 1) * m + 1:i * m]
+        d.mu = -(1.0 - etas[i].mu) * get_mu(k.current_it)
+        d.primal_scale = -(1.0 - etas[i].P) * k.current_it.point.primal_scale
+        r = err[6 * (i - 1) + 1:6 * i]
+        push!(out, (d, Class_kkt_error(r[1], r[2], r[3], r[4], r[5], r[6])))
+    end
+    return out
 end
