@@ -110,6 +110,10 @@ struct Numeric {
   std::vector<LaneSched> xlanes;         // lanes 1, 2, ...
   std::vector<hipEvent_t> solve_events;  // per-level fork / join of the sweeps (thin fronts beside wide fronts)
   size_t solve_ev_used = 0;
+  int solve_fuse = 1;                    // thin fronts: the two dependent launches of a level and sweep fused into one (in-launch hand-offs); OKKT_SOLVE_FUSE=0 switches back
+  int* solve_flags = nullptr;            // [nsuper] monotonic y flags of the fused forward launches
+  int* solve_counters = nullptr;         // [nsuper] arrival counters of the fused backward launches
+  int solve_epoch = 0;
   int solve_fork = 0;                    // OKKT_SOLVE_FORK=1: the wide fronts of a level on the auxiliary stream beside the thin ones
   std::vector<hipEvent_t> lane_events;   // fork / join of the lanes
   size_t lane_ev_used = 0;

@@ -326,6 +326,37 @@ __global__ __launch_bounds__(TPB) void k_bs_small(DevPlan P, const int* __restri
   }
 }
 
+
+// ---- in-launch hand-offs between the workgroups of one front (round 3): a level's two dependent launches become one.
+// Producer workgroups have LOWER block indices than their consumers (dispatch order = dependency order, so a waiting
+// consumer never keeps its producer from being scheduled); the protocol is the MI355X guide's: every storing wave drains its
+// stores, the workgroup meets at a barrier, one lane releases at agent scope and then raises the flag / counter; the consumer
+// polls with relaxed agent-scope loads (bounded: a hand-off that never arrives ends the wait instead of hanging the GPU, and
+// the solve is then wrong in a way the residual checks of the callers see), acquires once, and only then reads the data.
+// The handed-off bytes are a few hundred doubles per front: they are written and read with agent-scope (sc1) accesses, which
+// bypass the CU's L1 and are served by the memory side -- no release / acquire fences (an agent release writes back the whole L2,
+// an acquire invalidates the whole L1: 2 - 7 us each, per workgroup, measured as a net loss on the fused sweeps).
+__device__ __forceinline__ void st_agent(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double ld_agent(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void front_signal_store(int* flag, int value) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every storing wave: its sc1 stores have been acknowledged
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void front_signal_add(int* counter) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// waits until *flag >= value (monotonic flags); the payload is then read with ld_agent only
+__device__ __forceinline__ void front_wait(const int* flag, int value) {
+  if (threadIdx.x == 0) {
+    int spins = 0;
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < value && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(2);
+  }
+  __syncthreads();
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // big fronts, forward
 // ------------------------------------------------------------------------------------------------------------------
@@ -334,11 +365,9 @@ __global__ __launch_bounds__(TPB) void k_bs_small(DevPlan P, const int* __restri
 // (two per lane, 16-byte loads; wave g takes the columns g, g + 4, ...): w[r] = assembled rhs - sum_c L[r, c] y[c] -> the
 // front's contribution vector.  (One fused launch with y recomputed by every workgroup was 2 x slower: 128 KiB of X and the
 // w_K gathers per 64 rows.)
-template <int R>
-__global__ __launch_bounds__(256) void k_fwd_thin_y(DevPlan P, const int* __restrict__ list, int NB) {
-  __shared__ double wk[R][128];
+template <int R, bool SC1>
+__device__ __forceinline__ void fwd_thin_y_body(const DevPlan& P, int s, int NB, double (*wk)[128]) {
   const int tid = threadIdx.x;
-  const int s = list[blockIdx.x];
   const int col0 = P.sn_col0[s];
   const int k = P.sn_col0[s + 1] - col0;
   const int64_t gcb = P.bigcol_base[s];
@@ -364,21 +393,26 @@ __global__ __launch_bounds__(256) void k_fwd_thin_y(DevPlan P, const int* __rest
     for (int q = 0; q < 64; ++q) a += (h * 64 + q < NB) ? v[q] * wk[r][h * 64 + q] : 0.0;
     a += __shfl_xor(a, 1, 64);
     if (h == 0 && c < NB) {
-      yt[r * 128 + c] = c < k ? a : 0.0;
+      if (SC1) st_agent(&yt[r * 128 + c], c < k ? a : 0.0); else yt[r * 128 + c] = c < k ? a : 0.0;
       if (c < k) P.zwork[(size_t)r * P.xw_stride + col0 + c] = a / P.dvals[col0 + c];
     }
   }
 }
-
 template <int R>
-__global__ __launch_bounds__(256) void k_fwd_thin_upd(DevPlan P, const int* __restrict__ list) {
-  __shared__ double yk[R][128], part[4][R][128];
+__global__ __launch_bounds__(256) void k_fwd_thin_y(DevPlan P, const int* __restrict__ list, int NB) {
+  __shared__ double wk[R][128];
+  fwd_thin_y_body<R, false>(P, list[blockIdx.x], NB, wk);
+}
+
+// rows below the pivot block.  xoff = 0 / flag = NULL: the second launch of the two-launch form; xoff = 1: workgroup blockIdx.x - 1
+// of the fused launch, which waits for the front's y flag behind its own panel loads and gathers
+template <int R>
+__device__ __forceinline__ void fwd_thin_upd_body(const DevPlan& P, int s, int xblk, const int* flag, int epoch, double (*yk)[128], double (*part)[R][128]) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int s = list[blockIdx.y];
   const int col0 = P.sn_col0[s];
   const int k = P.sn_col0[s + 1] - col0;
   const int f = (int)(P.row_ptr[s + 1] - P.row_ptr[s]);
-  const int rb = k + (int)blockIdx.x * 128;
+  const int rb = k + xblk * 128;
   if (rb >= f) return;
   const double* F = P.arena + P.front_pos[s];
   const int r0 = rb + 2 * lane;
@@ -392,10 +426,6 @@ __global__ __launch_bounds__(256) void k_fwd_thin_upd(DevPlan P, const int* __re
     if (pair_ok) __builtin_memcpy(&lv[u], F + (size_t)cq * f + pr, 16);
     else { lv[u][0] = F[(size_t)cq * f + pr]; lv[u][1] = 0.0; }
   }
-  const double* yt = P.ythin + P.ythin_pos[s];
-  if (tid < 128)
-#pragma unroll
-    for (int r = 0; r < R; ++r) yk[r][tid] = yt[r * 128 + tid];
   // this thread's row (threads 0..127: one row each), assembled while the panel loads are in flight
   const int64_t gcb = P.bigcol_base[s];
   const int myrow = rb + tid;
@@ -403,6 +433,11 @@ __global__ __launch_bounds__(256) void k_fwd_thin_upd(DevPlan P, const int* __re
 #pragma unroll
   for (int r = 0; r < R; ++r) wr[r] = 0.0;
   if (tid < 128 && myrow < f) fwd_gather<R>(P, gcb, col0, k, myrow, wr);
+  if (flag) front_wait(flag, epoch);          // y of this front (fused launch): the loads above are already in flight
+  const double* yt = P.ythin + P.ythin_pos[s];
+  if (tid < 128)
+#pragma unroll
+    for (int r = 0; r < R; ++r) yk[r][tid] = flag ? ld_agent(&yt[r * 128 + tid]) : yt[r * 128 + tid];
   __syncthreads();
 #pragma unroll
   for (int r = 0; r < R; ++r) {
@@ -430,6 +465,24 @@ __global__ __launch_bounds__(256) void k_fwd_thin_upd(DevPlan P, const int* __re
         cvs[(size_t)r * P.cv_stride] = wr[r] - ((part[0][r][idx] + part[1][r][idx]) + (part[2][r][idx] + part[3][r][idx]));
       }
     }
+  }
+}
+
+template <int R>
+__global__ __launch_bounds__(256) void k_fwd_thin_upd(DevPlan P, const int* __restrict__ list) {
+  __shared__ double yk[R][128], part[4][R][128];
+  fwd_thin_upd_body<R>(P, list[blockIdx.y], (int)blockIdx.x, nullptr, 0, yk, part);
+}
+// one launch per level: workgroup 0 of a front computes y and raises the front's flag, the others apply the panel rows
+template <int R>
+__global__ __launch_bounds__(256) void k_fwd_thin_fused(DevPlan P, const int* __restrict__ list, int NB, int* __restrict__ flags, int epoch) {
+  __shared__ double yk[R][128], part[4][R][128];
+  const int s = list[blockIdx.y];
+  if (blockIdx.x == 0) {
+    fwd_thin_y_body<R, true>(P, s, NB, yk);
+    front_signal_store(flags + s, epoch);
+  } else {
+    fwd_thin_upd_body<R>(P, s, (int)blockIdx.x - 1, flags + s, epoch, yk, part);
   }
 }
 
@@ -597,14 +650,13 @@ __global__ __launch_bounds__(256) void k_fwd_upd(DevPlan P, const int* __restric
 // ------------------------------------------------------------------------------------------------------------------
 // rows below the pivot block: z[c] -= sum_{r >= k} L[r, c] x[rows[r]]   (wave per column, eight loads in flight); z lives in
 // zwork (forward result), the ancestors' solution in xwork
-template <int R>
-__global__ __launch_bounds__(256) void k_bwd_pre(DevPlan P, const int* __restrict__ list) {
+template <int R, bool SC1>
+__device__ __forceinline__ void bwd_pre_body(const DevPlan& P, int s, int xblk) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int s = list[blockIdx.y];
   const int col0 = P.sn_col0[s];
   const int k = P.sn_col0[s + 1] - col0;
   const int f = (int)(P.row_ptr[s + 1] - P.row_ptr[s]);
-  const int c = blockIdx.x * 4 + wv;
+  const int c = xblk * 4 + wv;
   if (c >= k || f == k) return;
   const int* rows = P.rows + P.row_ptr[s];
   const double* col = P.arena + P.front_pos[s] + (size_t)c * f;
@@ -636,16 +688,22 @@ __global__ __launch_bounds__(256) void k_bwd_pre(DevPlan P, const int* __restric
   for (int q = 0; q < R; ++q) {
     double a = acc[q];
     for (int o = 32; o > 0; o >>= 1) a += __shfl_down(a, o, 64);
-    if (lane == 0) P.zwork[(size_t)q * P.xw_stride + col0 + c] -= a;
+    if (lane == 0) {
+      double* zp = &P.zwork[(size_t)q * P.xw_stride + col0 + c];
+      if (SC1) st_agent(zp, *zp - a); else *zp -= a;
+    }
   }
 }
-
-// fronts with k <= 128: x_K = X' t (one workgroup per front; column c of X is contiguous)
 template <int R>
-__global__ __launch_bounds__(256) void k_bwd_thin(DevPlan P, const int* __restrict__ list, int NB) {
-  __shared__ double tk[R][128];
+__global__ __launch_bounds__(256) void k_bwd_pre(DevPlan P, const int* __restrict__ list) {
+  bwd_pre_body<R, false>(P, list[blockIdx.y], (int)blockIdx.x);
+}
+
+// fronts with k <= 128: x_K = X' t (one workgroup per front; column c of X is contiguous).  counter != NULL (fused launch): the
+// products of the rows below the pivot block arrive from `expected` workgroups of the same launch; X is loaded before the wait
+template <int R>
+__device__ __forceinline__ void bwd_thin_body(const DevPlan& P, int s, int NB, int* counter, double (*tk)[128]) {
   const int tid = threadIdx.x;
-  const int s = list[blockIdx.x];
   const int col0 = P.sn_col0[s];
   const int k = P.sn_col0[s + 1] - col0;
   const double* X = P.invl + P.invl_pos[s];
@@ -654,9 +712,18 @@ __global__ __launch_bounds__(256) void k_bwd_thin(DevPlan P, const int* __restri
   double v[64];
 #pragma unroll
   for (int q = 0; q < 64; ++q) v[q] = xcol[min(h * 64 + q, NB - 1)];
+  if (counter) {
+    const int f = (int)(P.row_ptr[s + 1] - P.row_ptr[s]);
+    const int expected = f > k ? (k + 3) / 4 : 0;
+    front_wait(counter, expected);
+    if (tid == 0) __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // everybody has arrived: ready for the next solve
+  }
   if (tid < 128)
 #pragma unroll
-    for (int r = 0; r < R; ++r) tk[r][tid] = tid < k ? P.zwork[(size_t)r * P.xw_stride + col0 + tid] : 0.0;
+    for (int r = 0; r < R; ++r) {
+      const double* zp = &P.zwork[(size_t)r * P.xw_stride + col0 + min(tid, max(k - 1, 0))];
+      tk[r][tid] = tid < k ? (counter ? ld_agent(zp) : *zp) : 0.0;
+    }
   __syncthreads();
 #pragma unroll
   for (int r = 0; r < R; ++r) {
@@ -665,6 +732,27 @@ __global__ __launch_bounds__(256) void k_bwd_thin(DevPlan P, const int* __restri
     for (int q = 0; q < 64; ++q) a += (h * 64 + q < NB) ? v[q] * tk[r][h * 64 + q] : 0.0;
     a += __shfl_xor(a, 1, 64);
     if (h == 0 && c < k) P.xwork[(size_t)r * P.xw_stride + col0 + c] = a;
+  }
+}
+template <int R>
+__global__ __launch_bounds__(256) void k_bwd_thin(DevPlan P, const int* __restrict__ list, int NB) {
+  __shared__ double tk[R][128];
+  bwd_thin_body<R>(P, list[blockIdx.x], NB, nullptr, tk);
+}
+// one launch per level: workgroups 0 .. npre - 1 of a front (four columns each) fold the rows below the pivot block into z and
+// arrive on the front's counter; the last workgroup waits for them and finishes the pivot block
+template <int R>
+__global__ __launch_bounds__(256) void k_bwd_thin_fused(DevPlan P, const int* __restrict__ list, int NB, int* __restrict__ counters) {
+  __shared__ double tk[R][128];
+  const int s = list[blockIdx.y];
+  if (blockIdx.x + 1 < gridDim.x) {
+    const int k = P.sn_col0[s + 1] - P.sn_col0[s];
+    const int f = (int)(P.row_ptr[s + 1] - P.row_ptr[s]);
+    if ((int)blockIdx.x * 4 >= k || f == k) return;         // nothing to add for this front: not counted either
+    bwd_pre_body<R, true>(P, s, (int)blockIdx.x);
+    front_signal_add(counters + s);
+  } else {
+    bwd_thin_body<R>(P, s, NB, counters + s, tk);
   }
 }
 
@@ -885,6 +973,14 @@ std::string solve_setup(const Symbolic& S, Numeric& N) {
   if (!(e = dz(N, (size_t)xtot, &d.xinv)).empty()) return e;
   if (!(e = dz(N, (size_t)xtot, &d.xtmp)).empty()) return e;
   if (!(e = dz(N, (size_t)ytot, &d.ypart)).empty()) return e;
+  {
+    // hand-off words of the fused sweeps: a monotonic y flag and an arrival counter per supernode (zero-filled once)
+    double* raw = nullptr;
+    if (!(e = dz(N, (size_t)ns + 64, &raw)).empty()) return e;      // ns + 64 doubles = room for 2 x ns ints
+    N.solve_flags = (int*)raw;
+    N.solve_counters = (int*)raw + ns + 16;
+    N.solve_epoch = 0;
+  }
   for (const void* fn : {(const void*)k_fwd_upd<1>, (const void*)k_fwd_upd<2>, (const void*)k_fwd_upd<4>, (const void*)k_bwd_upd<1>,
                          (const void*)k_bwd_upd<2>, (const void*)k_bwd_upd<4>, (const void*)k_fs_small<256, 1>, (const void*)k_fs_small<256, 2>,
                          (const void*)k_fs_small<256, 4>, (const void*)k_bs_small<256, 1>, (const void*)k_bs_small<256, 2>, (const void*)k_bs_small<256, 4>})
@@ -951,7 +1047,10 @@ static std::string fwd_enqueue_r(Numeric& N, const std::vector<LevelSchedule>& l
         wst = N.stream_aux;
       } else ev_join = nullptr;
     }
-    if (S.thin_cnt) {
+    if (S.thin_cnt && N.solve_fuse && N.solve_flags) {
+      // one launch: workgroup 0 of a front computes y and raises its flag, the others apply the panel rows behind it
+      hipLaunchKernelGGL(k_fwd_thin_fused<R>, dim3((S.thin_maxr + 127) / 128 + 1, S.thin_cnt), dim3(256), 0, st, P, P.ssched + S.thin_off, N.nb, N.solve_flags, N.solve_epoch);
+    } else if (S.thin_cnt) {
       hipLaunchKernelGGL(k_fwd_thin_y<R>, dim3(S.thin_cnt), dim3(256), 0, st, P, P.ssched + S.thin_off, N.nb);
       if (S.thin_maxr > 0) hipLaunchKernelGGL(k_fwd_thin_upd<R>, dim3((S.thin_maxr + 127) / 128, S.thin_cnt), dim3(256), 0, st, P, P.ssched + S.thin_off);
     }
@@ -1005,7 +1104,9 @@ static std::string bwd_enqueue_r(Numeric& N, const std::vector<LevelSchedule>& l
         hipLaunchKernelGGL(k_bwd_upd<R>, dim3((b * kSB + 63) / 64 + 1, S.wide_cnt), dim3(256), lds, st, P, list, b);
       }
     }
-    if (S.thin_cnt) {
+    if (S.thin_cnt && N.solve_fuse && N.solve_counters) {
+      hipLaunchKernelGGL(k_bwd_thin_fused<R>, dim3((S.thin_maxk + 3) / 4 + 1, S.thin_cnt), dim3(256), 0, st, P, P.ssched + S.thin_off, N.nb, N.solve_counters);
+    } else if (S.thin_cnt) {
       const int* list = P.ssched + S.thin_off;
       if (S.thin_maxr > 0) hipLaunchKernelGGL(k_bwd_pre<R>, dim3((S.thin_maxk + 3) / 4, S.thin_cnt), dim3(256), 0, st, P, list);
       hipLaunchKernelGGL(k_bwd_thin<R>, dim3(S.thin_cnt), dim3(256), 0, st, P, list, N.nb);
@@ -1059,6 +1160,7 @@ static std::string sweep_which(Numeric& N, bool fwd, int which, int R) {
 std::string solve_fwd_enqueue(Numeric& N, int which, int R) {
   if (which == 0 && N.inv_wait) { OKKT_HIP_TRY(hipStreamWaitEvent(N.stream, N.inv_event, 0)); N.inv_wait = false; }   // inversions started by the factorisation
   if (which == 0) { N.lane_ev_used = 0; N.solve_ev_used = 0; }
+  ++N.solve_epoch;          // the y flags of the fused forward launches are monotonic: one value per forward sweep
   return sweep_which(N, true, which, R);
 }
 std::string solve_bwd_enqueue(Numeric& N, int which, int R) {
