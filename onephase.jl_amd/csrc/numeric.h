@@ -111,9 +111,12 @@ struct Numeric {
   std::vector<hipEvent_t> solve_events;  // per-level fork / join of the sweeps (thin fronts beside wide fronts)
   size_t solve_ev_used = 0;
   int solve_fuse = 1;                    // thin fronts: the two dependent launches of a level and sweep fused into one (in-launch hand-offs); OKKT_SOLVE_FUSE=0 switches back
+  int solve_fuse_wide_max = 0;           // wide fronts: fused while the partial block products of a launch are at most this many workgroups (OKKT_SOLVE_FUSE_WIDE_MAX; 0 = never: measured neutral to slower, the consumers cannot start their panel loads before the hand-off)
   int* solve_flags = nullptr;            // [nsuper] monotonic y flags of the fused forward launches
   int* solve_counters = nullptr;         // [nsuper] arrival counters of the fused backward launches
   int solve_epoch = 0;
+  unsigned long long* solve_counters64 = nullptr;   // [nsuper] epoch-based arrival counters of the fused wide-front launches
+  unsigned long long solve_epoch64 = 0;
   int solve_fork = 0;                    // OKKT_SOLVE_FORK=1: the wide fronts of a level on the auxiliary stream beside the thin ones
   std::vector<hipEvent_t> lane_events;   // fork / join of the lanes
   size_t lane_ev_used = 0;

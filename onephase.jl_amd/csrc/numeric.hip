@@ -1673,7 +1673,7 @@ void numeric_release(Numeric& N) {
   for (hipEvent_t ev : N.solve_events) (void)hipEventDestroy(ev);
   N.solve_events.clear();
   N.solve_ev_used = 0;
-  N.solve_flags = nullptr; N.solve_counters = nullptr; N.solve_epoch = 0;
+  N.solve_flags = nullptr; N.solve_counters = nullptr; N.solve_epoch = 0; N.solve_counters64 = nullptr; N.solve_epoch64 = 0;
   N.lane_ev_used = 0;
   N.slevels.clear();
   N.slevels_top.clear();

@@ -49,6 +49,17 @@ __device__ __forceinline__ double sum_splits(const double* p) {
   return t[0];
 }
 
+__device__ __forceinline__ double sum_splits_agent(const double* p) {
+  double t[kCS];
+#pragma unroll
+  for (int q = 0; q < kCS; ++q) t[q] = __hip_atomic_load(p + (size_t)q * kSB, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+  for (int w = 1; w < kCS; w *= 2)
+#pragma unroll
+    for (int q = 0; q + w < kCS; q += 2 * w) t[q] += t[q + w];
+  return t[0];
+}
+
 __device__ __forceinline__ int round128(int v) { return (v + 127) & ~127; }
 // block b of a front with k pivot columns: first column, width, leading dimension and storage offset of its inverse
 __device__ __forceinline__ void xblock(int k, int b, int& c0, int& kb, int& ld, int64_t& off) {
@@ -348,6 +359,25 @@ __device__ __forceinline__ void front_signal_add(int* counter) {
   __syncthreads();
   if (threadIdx.x == 0) __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// Arrival counters shared by many producers and many consumers of one launch: value = (epoch << 20) + arrivals.  Every producer
+// first raises the counter to its launch's epoch base (atomic max: idempotent, whoever comes first sets it), then adds one;
+// the consumers of that launch wait for base + expected.  Epochs grow with every fused launch of the handle, so nothing is reset.
+__device__ __forceinline__ void front_arrive64(unsigned long long* counter, unsigned long long epoch) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_max(counter, epoch << 20, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(counter, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+__device__ __forceinline__ void front_wait64(const unsigned long long* counter, unsigned long long epoch, int expected) {
+  if (threadIdx.x == 0) {
+    const unsigned long long want = (epoch << 20) + (unsigned long long)expected;
+    int spins = 0;
+    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(2);
+  }
+  __syncthreads();
+}
 // waits until *flag >= value (monotonic flags); the payload is then read with ld_agent only
 __device__ __forceinline__ void front_wait(const int* flag, int value) {
   if (threadIdx.x == 0) {
@@ -489,20 +519,19 @@ __global__ __launch_bounds__(256) void k_fwd_thin_fused(DevPlan P, const int* __
 // Wide fronts, block b: partial products of y = X_b w_b.  Workgroup (i, front, cq): rows [64 i, +64) of the block, columns
 // [cq * kSB / kCS, +kSB / kCS); X_b is lower triangular, so a workgroup stops at its last row.  The kCS partial vectors are
 // summed by the consumer (k_fwd_upd).  In block 0 the right-hand side is assembled on the fly (children's contributions).
-template <int R>
-__global__ __launch_bounds__(256) void k_fwd_y(DevPlan P, const int* __restrict__ list, int b) {
+// returns false when the workgroup has no row of the block (it then takes no part in the hand-off of the fused launch)
+template <int R, bool AG>
+__device__ __forceinline__ bool fwd_y_body(const DevPlan& P, int s, int b, int bx, int cq) {
   constexpr int CW = kSB / kCS;
   __shared__ double wj[R][CW], part[4][R][64];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int s = list[blockIdx.y];
   const int col0 = P.sn_col0[s];
   const int k = P.sn_col0[s + 1] - col0;
   int c0, kb, ld; int64_t off;
   xblock(k, b, c0, kb, ld, off);
-  if (kb <= 0) return;
-  const int i0 = blockIdx.x * 64;
-  if (i0 >= kb) return;
-  const int cq = blockIdx.z;
+  if (kb <= 0) return false;
+  const int i0 = bx * 64;
+  if (i0 >= kb) return false;
   const int i = i0 + lane;
   double* yp = P.ypart + P.ypart_pos[s] + (size_t)cq * kSB;          // [R][kCS][kSB]
   const int pend = min(kb, i0 + 64);              // no row of this workgroup reaches beyond its last row
@@ -510,8 +539,8 @@ __global__ __launch_bounds__(256) void k_fwd_y(DevPlan P, const int* __restrict_
   if (q0 >= pend) {
     if (wv == 0 && i < kb)
 #pragma unroll
-      for (int r = 0; r < R; ++r) yp[(size_t)r * kCS * kSB + i] = 0.0;
-    return;
+      for (int r = 0; r < R; ++r) { if (AG) st_agent(&yp[(size_t)r * kCS * kSB + i], 0.0); else yp[(size_t)r * kCS * kSB + i] = 0.0; }
+    return true;
   }
   const int kq = min(CW, pend - q0);              // columns of this split that matter
   const double* X = P.xinv + P.xinv_pos[s] + off + (size_t)q0 * ld;
@@ -551,7 +580,15 @@ __global__ __launch_bounds__(256) void k_fwd_y(DevPlan P, const int* __restrict_
   __syncthreads();
   if (wv == 0 && i < kb)
 #pragma unroll
-    for (int r = 0; r < R; ++r) yp[(size_t)r * kCS * kSB + i] = (part[0][r][lane] + part[1][r][lane]) + (part[2][r][lane] + part[3][r][lane]);
+    for (int r = 0; r < R; ++r) {
+      const double v = (part[0][r][lane] + part[1][r][lane]) + (part[2][r][lane] + part[3][r][lane]);
+      if (AG) st_agent(&yp[(size_t)r * kCS * kSB + i], v); else yp[(size_t)r * kCS * kSB + i] = v;
+    }
+  return true;
+}
+template <int R>
+__global__ __launch_bounds__(256) void k_fwd_y(DevPlan P, const int* __restrict__ list, int b) {
+  (void)fwd_y_body<R, false>(P, list[blockIdx.y], b, (int)blockIdx.x, (int)blockIdx.z);
 }
 
 // Wide fronts, block b: y = sum of the partials (z = y / d stored by the first workgroup), then the rows below the block:
@@ -559,13 +596,12 @@ __global__ __launch_bounds__(256) void k_fwd_y(DevPlan P, const int* __restrict_
 // the eight half-waves take the columns h, h + 8, ...; sixteen columns are in flight per lane (64 KiB per workgroup), the
 // partial sums meet in LDS.  Block 0 assembles the rows it touches on the fly.
 constexpr int kUpdRows = 64;
+// counter != NULL: a workgroup of the fused launch -- it waits for the partial products of its front before it sums them
 template <int R>
-__global__ __launch_bounds__(256) void k_fwd_upd(DevPlan P, const int* __restrict__ list, int b) {
-  extern __shared__ __attribute__((aligned(16))) double sm[];      // y[R][kSB], then part[8][R][64]
-  double* yj = sm;
+__device__ __forceinline__ void fwd_upd_body(const DevPlan& P, int s, int b, int bx, double* sm, const unsigned long long* counter, unsigned long long epoch) {
+  double* yj = sm;                                 // y[R][kSB], then part[8][R][64]
   double* part = sm + (size_t)R * kSB;
   const int tid = threadIdx.x, l32 = tid & 31, hw = tid >> 5;
-  const int s = list[blockIdx.y];
   const int col0 = P.sn_col0[s];
   const int k = P.sn_col0[s + 1] - col0;
   const int f = (int)(P.row_ptr[s + 1] - P.row_ptr[s]);
@@ -573,16 +609,17 @@ __global__ __launch_bounds__(256) void k_fwd_upd(DevPlan P, const int* __restric
   xblock(k, b, c0, kb, ld, off);
   if (kb <= 0) return;
   const int rbeg = c0 + kb;                       // first row below the block
-  const int rb = rbeg + (int)blockIdx.x * kUpdRows;
-  if (blockIdx.x > 0 && rb >= f) return;
+  const int rb = rbeg + bx * kUpdRows;
+  if (bx > 0 && rb >= f) return;
+  if (counter) front_wait64(counter, epoch, ((kb + 63) / 64) * kCS);
   const double* yp = P.ypart + P.ypart_pos[s];
   for (int p = tid; p < kSB; p += 256) {
     const int pc = min(p, kb - 1);
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      const double y = sum_splits(yp + (size_t)r * kCS * kSB + pc);
+      const double y = counter ? sum_splits_agent(yp + (size_t)r * kCS * kSB + pc) : sum_splits(yp + (size_t)r * kCS * kSB + pc);
       yj[r * kSB + p] = p < kb ? y : 0.0;
-      if (blockIdx.x == 0 && p < kb) P.zwork[(size_t)r * P.xw_stride + col0 + c0 + p] = y / P.dvals[col0 + c0 + p];
+      if (bx == 0 && p < kb) P.zwork[(size_t)r * P.xw_stride + col0 + c0 + p] = y / P.dvals[col0 + c0 + p];
     }
   }
   __syncthreads();
@@ -642,6 +679,25 @@ __global__ __launch_bounds__(256) void k_fwd_upd(DevPlan P, const int* __restric
         *fwd_slot<R>(P, s, col0, k, rowv, r) = w[r] - sum;
       }
     }
+  }
+}
+
+template <int R>
+__global__ __launch_bounds__(256) void k_fwd_upd(DevPlan P, const int* __restrict__ list, int b) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  fwd_upd_body<R>(P, list[blockIdx.y], b, (int)blockIdx.x, sm, nullptr, 0ull);
+}
+// one launch per block column b of the wide fronts of a level: workgroups [0, ny * kCS) are the partial block products (row tile
+// x % ny, column split x / ny), the others the panel rows below the block, waiting for their front's partials
+template <int R>
+__global__ __launch_bounds__(256) void k_fwd_wide_fused(DevPlan P, const int* __restrict__ list, int b, int ny, unsigned long long* __restrict__ counters, unsigned long long epoch) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int s = list[blockIdx.y];
+  const int x = (int)blockIdx.x;
+  if (x < ny * kCS) {
+    if (fwd_y_body<R, true>(P, s, b, x % ny, x / ny)) front_arrive64(counters + s, epoch);
+  } else {
+    fwd_upd_body<R>(P, s, b, x - ny * kCS, sm, counters + s, epoch);
   }
 }
 
@@ -758,27 +814,25 @@ __global__ __launch_bounds__(256) void k_bwd_thin_fused(DevPlan P, const int* __
 
 // wide fronts, block b: partial products of x_b = X_b' z_b.  Workgroup (j, front, rq): columns [64 j, +64), rows
 // [rq * kSB / kCS, +kSB / kCS); column i of X_b is zero above row i.  A wave takes 16 columns, four at a time.
-template <int R>
-__global__ __launch_bounds__(256) void k_bwd_x(DevPlan P, const int* __restrict__ list, int b) {
+template <int R, bool AG>
+__device__ __forceinline__ bool bwd_x_body(const DevPlan& P, int s, int b, int bx, int rq) {
   constexpr int RW = kSB / kCS;
   __shared__ double zj[R][RW];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int s = list[blockIdx.y];
   const int col0 = P.sn_col0[s];
   const int k = P.sn_col0[s + 1] - col0;
   int c0, kb, ld; int64_t off;
   xblock(k, b, c0, kb, ld, off);
-  if (kb <= 0) return;
-  const int rq = blockIdx.z;
-  if ((int)blockIdx.x * 64 >= kb) return;
+  if (kb <= 0) return false;
+  if (bx * 64 >= kb) return false;
   double* xp = P.ypart + P.ypart_pos[s] + (size_t)rq * kSB;
-  const int i0 = blockIdx.x * 64 + wv * 16;
+  const int i0 = bx * 64 + wv * 16;
   const int q0 = rq * RW;
-  if (q0 >= kb || q0 + RW - 1 < (int)blockIdx.x * 64) {        // nothing of this row range reaches these columns
+  if (q0 >= kb || q0 + RW - 1 < bx * 64) {        // nothing of this row range reaches these columns
     if (lane < 16 && i0 + lane < kb)
 #pragma unroll
-      for (int r = 0; r < R; ++r) xp[(size_t)r * kCS * kSB + i0 + lane] = 0.0;
-    return;
+      for (int r = 0; r < R; ++r) { if (AG) st_agent(&xp[(size_t)r * kCS * kSB + i0 + lane], 0.0); else xp[(size_t)r * kCS * kSB + i0 + lane] = 0.0; }
+    return true;
   }
   const int kq = min(RW, kb - q0);
   const double* X = P.xinv + P.xinv_pos[s] + off + q0;
@@ -803,19 +857,22 @@ __global__ __launch_bounds__(256) void k_bwd_x(DevPlan P, const int* __restrict_
 #pragma unroll
         for (int t = 0; t < RW / 64; ++t) a += (lane + 64 * t < kq) ? v[q][t] * zj[r][lane + 64 * t] : 0.0;
         for (int o = 32; o > 0; o >>= 1) a += __shfl_down(a, o, 64);
-        if (lane == 0 && i0 + g + q < kb) xp[(size_t)r * kCS * kSB + i0 + g + q] = a;
+        if (lane == 0 && i0 + g + q < kb) { if (AG) st_agent(&xp[(size_t)r * kCS * kSB + i0 + g + q], a); else xp[(size_t)r * kCS * kSB + i0 + g + q] = a; }
       }
     }
   }
+  return true;
+}
+template <int R>
+__global__ __launch_bounds__(256) void k_bwd_x(DevPlan P, const int* __restrict__ list, int b) {
+  (void)bwd_x_body<R, false>(P, list[blockIdx.y], b, (int)blockIdx.x, (int)blockIdx.z);
 }
 
 // wide fronts, block b: x_b = sum of the partials; columns c < c0: z[c] -= sum_p L[c0 + p][c] x_b[p] (wave: 16 columns, four
 // at a time, lanes along the rows of the block); the workgroup behind the last column group stores x_b itself
 template <int R>
-__global__ __launch_bounds__(256) void k_bwd_upd(DevPlan P, const int* __restrict__ list, int b) {
-  extern __shared__ __attribute__((aligned(16))) double sm[];      // x[R][kSB]
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int s = list[blockIdx.y];
+__device__ __forceinline__ void bwd_upd_body(const DevPlan& P, int s, int b, int bx, double* sm, const unsigned long long* counter, unsigned long long epoch) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;       // sm: x[R][kSB]
   const int col0 = P.sn_col0[s];
   const int k = P.sn_col0[s + 1] - col0;
   const int f = (int)(P.row_ptr[s + 1] - P.row_ptr[s]);
@@ -823,18 +880,19 @@ __global__ __launch_bounds__(256) void k_bwd_upd(DevPlan P, const int* __restric
   xblock(k, b, c0, kb, ld, off);
   if (kb <= 0) return;
   const int nupd = (c0 + 63) / 64;                // workgroups that update columns; the next one copies x_b
-  if ((int)blockIdx.x > nupd) return;
+  if (bx > nupd) return;
+  if (counter) front_wait64(counter, epoch, ((kb + 63) / 64) * kCS);
   const double* xp = P.ypart + P.ypart_pos[s];
   for (int p = tid; p < kSB; p += 256) {
     const int pc = min(p, kb - 1);
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      const double x = sum_splits(xp + (size_t)r * kCS * kSB + pc);
+      const double x = counter ? sum_splits_agent(xp + (size_t)r * kCS * kSB + pc) : sum_splits(xp + (size_t)r * kCS * kSB + pc);
       sm[r * kSB + p] = p < kb ? x : 0.0;
     }
   }
   __syncthreads();
-  if ((int)blockIdx.x == nupd) {
+  if (bx == nupd) {
     for (int p = tid; p < kb; p += 256)
 #pragma unroll
       for (int r = 0; r < R; ++r) P.xwork[(size_t)r * P.xw_stride + col0 + c0 + p] = sm[r * kSB + p];
@@ -843,7 +901,7 @@ __global__ __launch_bounds__(256) void k_bwd_upd(DevPlan P, const int* __restric
   const double* Lrow = P.arena + P.front_pos[s] + c0;
 #pragma unroll 1
   for (int g = 0; g < 16; g += 2) {
-    const int cb = blockIdx.x * 64 + wv * 16 + g;
+    const int cb = bx * 64 + wv * 16 + g;
     if (cb >= c0) break;
     double acc[2][R];
 #pragma unroll
@@ -879,6 +937,24 @@ __global__ __launch_bounds__(256) void k_bwd_upd(DevPlan P, const int* __restric
         for (int o = 32; o > 0; o >>= 1) a += __shfl_down(a, o, 64);
         if (lane == 0 && cb + q < c0) P.zwork[(size_t)r * P.xw_stride + col0 + cb + q] -= a;
       }
+  }
+}
+template <int R>
+__global__ __launch_bounds__(256) void k_bwd_upd(DevPlan P, const int* __restrict__ list, int b) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  bwd_upd_body<R>(P, list[blockIdx.y], b, (int)blockIdx.x, sm, nullptr, 0ull);
+}
+// one launch per block column b, backward: workgroups [0, nx * kCS) are the partial products of x_b = X_b' z_b (column tile
+// x % nx, row split x / nx), the others update the columns to the left / store x_b once their front's partials have arrived
+template <int R>
+__global__ __launch_bounds__(256) void k_bwd_wide_fused(DevPlan P, const int* __restrict__ list, int b, int nx, unsigned long long* __restrict__ counters, unsigned long long epoch) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int s = list[blockIdx.y];
+  const int x = (int)blockIdx.x;
+  if (x < nx * kCS) {
+    if (bwd_x_body<R, true>(P, s, b, x % nx, x / nx)) front_arrive64(counters + s, epoch);
+  } else {
+    bwd_upd_body<R>(P, s, b, x - nx * kCS, sm, counters + s, epoch);
   }
 }
 
@@ -980,7 +1056,14 @@ std::string solve_setup(const Symbolic& S, Numeric& N) {
     N.solve_flags = (int*)raw;
     N.solve_counters = (int*)raw + ns + 16;
     N.solve_epoch = 0;
+    double* raw64 = nullptr;
+    if (!(e = dz(N, (size_t)ns + 8, &raw64)).empty()) return e;
+    N.solve_counters64 = (unsigned long long*)raw64;
+    N.solve_epoch64 = 0;
   }
+  for (const void* fn : {(const void*)k_fwd_wide_fused<1>, (const void*)k_fwd_wide_fused<2>, (const void*)k_fwd_wide_fused<4>, (const void*)k_bwd_wide_fused<1>,
+                         (const void*)k_bwd_wide_fused<2>, (const void*)k_bwd_wide_fused<4>})
+    OKKT_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096 - 16 * 1024));
   for (const void* fn : {(const void*)k_fwd_upd<1>, (const void*)k_fwd_upd<2>, (const void*)k_fwd_upd<4>, (const void*)k_bwd_upd<1>,
                          (const void*)k_bwd_upd<2>, (const void*)k_bwd_upd<4>, (const void*)k_fs_small<256, 1>, (const void*)k_fs_small<256, 2>,
                          (const void*)k_fs_small<256, 4>, (const void*)k_bs_small<256, 1>, (const void*)k_bs_small<256, 2>, (const void*)k_bs_small<256, 4>})
@@ -1061,9 +1144,14 @@ static std::string fwd_enqueue_r(Numeric& N, const std::vector<LevelSchedule>& l
       const size_t lds = ((size_t)R * kSB + (size_t)8 * R * kUpdRows) * sizeof(double);
       for (int b = 0; b < nblk; ++b) {
         const int kbmax = std::min(kSB, S.wide_maxk - b * kSB);
-        hipLaunchKernelGGL(k_fwd_y<R>, dim3((kbmax + 63) / 64, S.wide_cnt, kCS), dim3(256), 0, st, P, list, b);
         const int rem = std::max(S.wide_maxf - b * kSB, 0);        // upper bound on the rows below the start of block b (a narrower last block leaves more rows than maxf - (b + 1) kSB)
-        hipLaunchKernelGGL(k_fwd_upd<R>, dim3(std::max(1, (rem + kUpdRows - 1) / kUpdRows), S.wide_cnt), dim3(256), lds, st, P, list, b);
+        const int ny = (kbmax + 63) / 64, nupd = std::max(1, (rem + kUpdRows - 1) / kUpdRows);
+        if (N.solve_fuse && N.solve_counters64 && ny * kCS * S.wide_cnt <= N.solve_fuse_wide_max) {
+          hipLaunchKernelGGL(k_fwd_wide_fused<R>, dim3(ny * kCS + nupd, S.wide_cnt), dim3(256), lds, st, P, list, b, ny, N.solve_counters64, ++N.solve_epoch64);
+        } else {
+          hipLaunchKernelGGL(k_fwd_y<R>, dim3(ny, S.wide_cnt, kCS), dim3(256), 0, st, P, list, b);
+          hipLaunchKernelGGL(k_fwd_upd<R>, dim3(nupd, S.wide_cnt), dim3(256), lds, st, P, list, b);
+        }
       }
     }
     if (ev_join) {
@@ -1100,8 +1188,13 @@ static std::string bwd_enqueue_r(Numeric& N, const std::vector<LevelSchedule>& l
       const size_t lds = (size_t)R * kSB * sizeof(double);
       for (int b = nblk - 1; b >= 0; --b) {
         const int kbmax = std::min(kSB, S.wide_maxk - b * kSB);
-        hipLaunchKernelGGL(k_bwd_x<R>, dim3((kbmax + 63) / 64, S.wide_cnt, kCS), dim3(256), 0, st, P, list, b);
-        hipLaunchKernelGGL(k_bwd_upd<R>, dim3((b * kSB + 63) / 64 + 1, S.wide_cnt), dim3(256), lds, st, P, list, b);
+        const int nx = (kbmax + 63) / 64, nupd = (b * kSB + 63) / 64 + 1;
+        if (N.solve_fuse && N.solve_counters64 && nx * kCS * S.wide_cnt <= N.solve_fuse_wide_max) {
+          hipLaunchKernelGGL(k_bwd_wide_fused<R>, dim3(nx * kCS + nupd, S.wide_cnt), dim3(256), lds, st, P, list, b, nx, N.solve_counters64, ++N.solve_epoch64);
+        } else {
+          hipLaunchKernelGGL(k_bwd_x<R>, dim3(nx, S.wide_cnt, kCS), dim3(256), 0, st, P, list, b);
+          hipLaunchKernelGGL(k_bwd_upd<R>, dim3(nupd, S.wide_cnt), dim3(256), lds, st, P, list, b);
+        }
       }
     }
     if (S.thin_cnt && N.solve_fuse && N.solve_counters) {
