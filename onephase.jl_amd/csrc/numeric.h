@@ -152,6 +152,9 @@ struct Numeric {
   hipStream_t stream_panel = nullptr;
   hipStream_t stream_aux = nullptr;     // off-critical-path part of the in-group panel updates
   int split_head = 1;
+  int fuse_diag_trsm = 0;                // OKKT_FUSE_DIAG_TRSM=1: k_diag_trsm_fused, the diagonal block and the rows below it in one launch (measured: the waiting trsm workgroups hold CUs the trailing update wants; S-metric 23.7 -> 24.1 ms, S-C3 3.96 -> 3.87 ms)
+  int* chain_flags = nullptr;            // [nsuper] monotonic flags of those launches
+  int chain_epoch = 0;
   int diag2 = 1;                         // k_big_diag2 (role-split, pipelined) instead of k_big_diag; OKKT_DIAG2=0 switches back
   int decouple = 0;                      // OKKT_DECOUPLE=1: single-block steps with the diagonal chain ahead of the wide trsm / trailing update (aux stream); measured slower
   int decouple_min_rows = 256;           // ... while at least this many rows are left below the step

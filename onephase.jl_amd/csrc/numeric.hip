@@ -676,14 +676,16 @@ __global__ __launch_bounds__(256) void k_big_diag(DevPlan P, const int* __restri
 //   In k_big_diag the row threads and the MFMA updates alternate and half of the workgroup idles in each; here a micro-step
 //   costs max(row work, rest of the previous update) + the short head.  -L / W panels are double-buffered in LDS.  The
 //   arithmetic per entry is the same sequence of operations: bitwise the same factor.
-__global__ __launch_bounds__(384) void k_big_diag2(DevPlan P, const int* __restrict__ list, int step, int NB, double tol) {
+// agent-scope (sc1) store: outputs that another workgroup of the SAME launch reads (fused diag + trsm launch below)
+__device__ __forceinline__ void st_agent_f64(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double ld_agent_f64(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+template <bool AG>
+__device__ __forceinline__ void diag2_body(const DevPlan& P, int s, int step, int NB, double tol, double* sm) {
   static_assert(kMW == 8, "micro-panels of 8 columns");
-  extern __shared__ __attribute__((aligned(16))) double sm[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, l4 = lane >> 4;
-  const int s = list[blockIdx.x];
-  if (stop_requested_wg(P)) return;
   const int col0 = P.sn_col0[s];
   const int k = P.sn_col0[s + 1] - col0;
   const int f = (int)(P.row_ptr[s + 1] - P.row_ptr[s]);
@@ -796,7 +798,7 @@ __global__ __launch_bounds__(384) void k_big_diag2(DevPlan P, const int* __restr
           Wp[c * kPLD + r] = w[c];
           const double val = i == c ? w[c] : lr[c];
           if (i >= c && r < nb && p8 + c < nb) {
-            Fr[(size_t)c * f] = val;
+            if (AG) st_agent_f64(&Fr[(size_t)c * f], val); else Fr[(size_t)c * f] = val;
             if ((r >> 5) == ((p8 + c) >> 5)) Ld[(r >> 5) * 32 * kXld + (r & 31) + ((p8 + c) & 31) * kXld] = val;
           }
         }
@@ -825,7 +827,7 @@ __global__ __launch_bounds__(384) void k_big_diag2(DevPlan P, const int* __restr
   {
     unsigned pos = 0, neg = 0, zer = 0, bad = 0;
     if (tid < nb) {
-      P.dvals[col0 + j0 + tid] = my_d;
+      if (AG) st_agent_f64(&P.dvals[col0 + j0 + tid], my_d); else P.dvals[col0 + j0 + tid] = my_d;
       classify_pivot(my_d, tol, pos, neg, zer, bad);
     }
     flush_counts(P, 0, pos, neg, zer, bad);
@@ -858,10 +860,17 @@ __global__ __launch_bounds__(384) void k_big_diag2(DevPlan P, const int* __restr
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
       const int c = (lane >> 5) + 2 * q;
-      Xg[(off + r) + (size_t)(off + c) * NB] = Xb[r + c * kXld];
+      if (AG) st_agent_f64(&Xg[(off + r) + (size_t)(off + c) * NB], Xb[r + c * kXld]); else Xg[(off + r) + (size_t)(off + c) * NB] = Xb[r + c * kXld];
     }
   }
 }
+__global__ __launch_bounds__(384) void k_big_diag2(DevPlan P, const int* __restrict__ list, int step, int NB, double tol) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int s = list[blockIdx.x];
+  if (stop_requested_wg(P)) return;
+  diag2_body<false>(P, s, step, NB, tol, sm);
+}
+
 
 // Deferred full inverse X = inv(L11) of every NB x NB diagonal block of the big fronts of a level (one
 // workgroup per block, all blocks in parallel, off the critical path of the factorisation: k_big_trsm
@@ -959,30 +968,45 @@ __global__ __launch_bounds__(256) void k_big_invert(DevPlan P, const int* __rest
 // (lane <-> column l>>4, row l&15) and is, unchanged, the B operand of the k-step over those 4 columns: W_p
 // feeds the later products straight from registers.  L blocks and X_ii are staged once per workgroup in LDS
 // and read as broadcast A operands.  L21 = W * D^-1.
-template <int NBLK>
-__global__ __launch_bounds__(256) void k_big_trsm(DevPlan P, const int* __restrict__ list, int step, int wcol0, int blk_lo) {
-  // blk_lo: first 64-row block of the panel this launch handles (the grid covers blocks blk_lo, blk_lo + 1, ...): the decoupled
-  // schedule solves the first 128 rows on the critical path and the rest beside the next diagonal block
+// flag != NULL: a workgroup of the fused diag + trsm launch (384 threads: the last two waves only meet the barriers) -- the rows
+// of the panel are loaded first, then the front's diagonal block is awaited and staged with agent-scope loads
+template <int NBLK, bool AG>
+__device__ __forceinline__ void trsm_body(const DevPlan& P, int s, int step, int wcol0, int blk, double* sm, const int* flag, int epoch) {
   constexpr int NB = NBLK * kIB;
   constexpr int NPAIR = NBLK * (NBLK + 1) / 2;
-  extern __shared__ __attribute__((aligned(16))) double sm[];   // NPAIR blocks of 32 x 32, then NB reciprocals
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int s = list[blockIdx.y];
-  if (stop_requested_wg(P)) return;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;          // sm: NPAIR blocks of 32 x 32, then NB reciprocals
+  const bool worker = tid < 256;
   const int col0 = P.sn_col0[s];
   const int k = P.sn_col0[s + 1] - col0;
   const int f = (int)(P.row_ptr[s + 1] - P.row_ptr[s]);
   const int j0 = step * NB;
   if (j0 >= k) return;
   const int nb = min(NB, k - j0);
-  const int r0 = j0 + nb + ((int)blockIdx.x + blk_lo) * 64;
+  const int r0 = j0 + nb + blk * 64;
   if (r0 >= f) return;
   double* F = P.arena + P.front_pos[s];
   double* Wb = P.wbuf + P.wbuf_pos[s] + (size_t)wcol0 * f;   // this panel's slot inside the super-step's W
   const double* X = P.invl + P.invl_pos[s] + (size_t)step * NB * NB;
   double* rdv = sm + NPAIR * kIB * kIB;
+  const int row = r0 + (wv & 3) * 16 + (lane & 15);
+  const int rowc = min(row, f - 1);
+  const int lk = lane >> 4, li = lane & 3;
+  double t[NBLK * 8];
+  // the rows of the panel do not depend on the diagonal block: in flight before the wait
+#pragma unroll
+  for (int q = 0; q < NBLK * 8; ++q) {
+    const int c = 4 * q + lk;
+    t[q] = keep_f64(F[(size_t)(j0 + min(c, nb - 1)) * f + rowc], c < nb && row < f && worker);
+  }
+  if (AG) {
+    if (tid == 0) {
+      int spins = 0;
+      while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(2);
+    }
+    __syncthreads();
+  }
   // stage block (bi, bp), bp <= bi, at index bi(bi+1)/2 + bp: L_{bi,bp} below the diagonal, X_ii on it
-  {
+  if (worker) {
     const int e = tid * 4;                 // 4 consecutive rows of one column per thread and block
     const int cc = e / kIB, rr = e - cc * kIB;
 #pragma unroll
@@ -995,24 +1019,16 @@ __global__ __launch_bounds__(256) void k_big_trsm(DevPlan P, const int* __restri
         for (int u = 0; u < 4; ++u) {
           const double* src = bp == bi ? X + (gr + u) + (size_t)gc * NB
                                        : F + (size_t)(j0 + min(gc, nb - 1)) * f + j0 + min(gr + u, nb - 1);
-          v[u] = keep_f64(*src, gr + u < nb && gc < nb);
+          v[u] = keep_f64(AG ? ld_agent_f64(src) : *src, gr + u < nb && gc < nb);
         }
         double* dst = sm + (bi * (bi + 1) / 2 + bp) * kIB * kIB + e;
 #pragma unroll
         for (int u = 0; u < 4; ++u) dst[u] = v[u];
       }
-    if (tid < NB) rdv[tid] = tid < nb ? 1.0 / P.dvals[col0 + j0 + tid] : 0.0;
+    if (tid < NB) rdv[tid] = tid < nb ? 1.0 / (AG ? ld_agent_f64(&P.dvals[col0 + j0 + tid]) : P.dvals[col0 + j0 + tid]) : 0.0;
   }
   __syncthreads();
-  const int row = r0 + wv * 16 + (lane & 15);
-  const int rowc = min(row, f - 1);
-  const int lk = lane >> 4, li = lane & 3;
-  double t[NBLK * 8];
-#pragma unroll
-  for (int q = 0; q < NBLK * 8; ++q) {
-    const int c = 4 * q + lk;
-    t[q] = keep_f64(F[(size_t)(j0 + min(c, nb - 1)) * f + rowc], c < nb && row < f);
-  }
+  if (!worker) return;
 #pragma unroll
   for (int bi = 0; bi < NBLK; ++bi) {
 #pragma unroll
@@ -1045,6 +1061,32 @@ __global__ __launch_bounds__(256) void k_big_trsm(DevPlan P, const int* __restri
         F[(size_t)(j0 + c) * f + row] = t[q] * rdv[c];
       }
     }
+  }
+}
+template <int NBLK>
+__global__ __launch_bounds__(256) void k_big_trsm(DevPlan P, const int* __restrict__ list, int step, int wcol0, int blk_lo) {
+  // blk_lo: first 64-row block of the panel this launch handles (the grid covers blocks blk_lo, blk_lo + 1, ...): the decoupled
+  // schedule solves the first 128 rows on the critical path and the rest beside the next diagonal block
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int s = list[blockIdx.y];
+  if (stop_requested_wg(P)) return;
+  trsm_body<NBLK, false>(P, s, step, wcol0, (int)blockIdx.x + blk_lo, sm, nullptr, 0);
+}
+// k_big_diag2 and k_big_trsm<4> of one panel step in ONE launch (round 3): workgroup 0 of a front factors the diagonal block
+// and raises the front's flag; the others have their panel rows in flight by then, wait, stage the block and solve.  What
+// crosses workgroups inside the launch (L11, its 32 x 32 inverses, D) is written and read with agent-scope accesses.
+__global__ __launch_bounds__(384) void k_diag_trsm_fused(DevPlan P, const int* __restrict__ list, int step, int NB, double tol, int wcol0,
+                                                         int* __restrict__ flags, int epoch) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int s = list[blockIdx.y];
+  if (stop_requested_wg(P)) return;
+  if (blockIdx.x == 0) {
+    diag2_body<true>(P, s, step, NB, tol, sm);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every storing wave: its agent-scope stores have been acknowledged
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(flags + s, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else {
+    trsm_body<4, true>(P, s, step, wcol0, (int)blockIdx.x - 1, sm, flags + s, epoch);
   }
 }
 
@@ -1637,12 +1679,19 @@ std::string numeric_setup(const Symbolic& S, const SymbolicOptions& opts, hipStr
   if (!(e = dalloc(N, (size_t)kCountSlots * kCountStride, &d.counters, true)).empty()) return e;
   if (!(e = dalloc(N, (size_t)512, &d.zero_page, true)).empty()) return e;   // [256, 512): debug tick counters (OKKT_DEBUG_SYRK=96)
   if (!(e = dalloc(N, (size_t)S.nnz_in, &N.vals_owned, false)).empty()) return e;
+  {
+    double* raw = nullptr;       // one monotonic flag (int) per supernode for the fused diag + trsm launches
+    if (!(e = dalloc(N, (size_t)ns / 2 + 8, &raw, true)).empty()) return e;
+    N.chain_flags = (int*)raw;
+    N.chain_epoch = 0;
+  }
   if (!(e = solve_setup(S, N)).empty()) return e;
   // kernels that may want more than 64 KiB of dynamic LDS
   const int big_lds = 160 * 1024 - 64;   // the stop-flag check keeps one static LDS word per kernel
   OKKT_HIP_TRY(hipFuncSetAttribute((const void*)k_front_small<256>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds));
   OKKT_HIP_TRY(hipFuncSetAttribute((const void*)k_big_diag, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds));
   OKKT_HIP_TRY(hipFuncSetAttribute((const void*)k_big_diag2, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds));
+  OKKT_HIP_TRY(hipFuncSetAttribute((const void*)k_diag_trsm_fused, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds));
   OKKT_HIP_TRY(hipFuncSetAttribute((const void*)k_big_invert, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds));
   OKKT_HIP_TRY(hipFuncSetAttribute((const void*)k_big_trsm<3>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds));
   OKKT_HIP_TRY(hipFuncSetAttribute((const void*)k_big_trsm<4>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds));
@@ -1673,6 +1722,7 @@ void numeric_release(Numeric& N) {
   for (hipEvent_t ev : N.solve_events) (void)hipEventDestroy(ev);
   N.solve_events.clear();
   N.solve_ev_used = 0;
+  N.chain_flags = nullptr; N.chain_epoch = 0;
   N.solve_flags = nullptr; N.solve_counters = nullptr; N.solve_epoch = 0; N.solve_counters64 = nullptr; N.solve_epoch64 = 0;
   N.lane_ev_used = 0;
   N.slevels.clear();
@@ -1817,6 +1867,7 @@ static std::string factor_sched(Numeric& N, DevPlan P, const std::vector<LevelSc
       const int nsteps = (g.maxk + NB - 1) / NB;
       const size_t lds_diag = ((size_t)3 * kMW * kPLD + (size_t)2 * 4 * 32 * kXld) * sizeof(double);
       const size_t lds_diag2 = ((size_t)5 * kMW * kPLD + (size_t)2 * 4 * 32 * kXld) * sizeof(double);
+      const size_t lds_trsm_max = ((size_t)10 * kIB * kIB + 128) * sizeof(double);
       // every front of the segment must own a W buffer for this group size: decided on the smallest front
       const int GS = g.minf >= N.group_big_minf ? N.group_big : N.group;     // widest super-step of this segment (sizes wbuf)
       // Super-step widths adapt: GS block columns while the trailing update is long enough to hide the panel chain,
@@ -1982,22 +2033,22 @@ static std::string factor_sched(Numeric& N, DevPlan P, const std::vector<LevelSc
               if (!e.empty()) return e;
             }
           }
+          {
+            // one launch for the diagonal block and the rows below it (k_diag_trsm_fused) unless something has to happen between
+            // the two (the rest of a split in-group update is joined before the trsm)
+            const int rem_f = g.maxf - step * NB;
+            const int ntr = rem_f > 0 ? (rem_f + 63) / 64 : 0;
+            if (N.diag2 && N.fuse_diag_trsm && N.chain_flags && dbg_stop == 0 && NB == 128 && ev_rest == nullptr && ntr > 0) {
+              const int wc = (par * GS + i) * NB;
+              hipLaunchKernelGGL(k_diag_trsm_fused, dim3(1 + ntr, g.cnt), dim3(384), std::max(lds_diag2, lds_trsm_max), pst, P, list, step, NB, tol, wc,
+                                 N.chain_flags, ++N.chain_epoch);
+              continue;
+            }
+          }
           if (N.diag2 && dbg_stop == 0) hipLaunchKernelGGL(k_big_diag2, dim3(g.cnt), dim3(384), lds_diag2, pst, P, list, step, NB, tol);
           else hipLaunchKernelGGL(k_big_diag, dim3(g.cnt), dim3(256), lds_diag, pst, P, list, step, NB, tol, dbg_stop);
           if (ev_rest) OKKT_HIP_TRY(hipStreamWaitEvent(pst, ev_rest, 0));
-          const int rem = g.maxf - step * NB;  // upper bound on rows below the diagonal block
-          if (rem > 0) {
-            const dim3 gr((rem + 63) / 64, g.cnt);
-            const int nbl = NB / kIB;
-            const size_t lds_trsm = ((size_t)nbl * (nbl + 1) / 2 * kIB * kIB + NB) * sizeof(double);
-            const int wc = (par * GS + i) * NB;
-            switch (nbl) {
-              case 1: hipLaunchKernelGGL(k_big_trsm<1>, gr, dim3(256), lds_trsm, pst, P, list, step, wc, 0); break;
-              case 2: hipLaunchKernelGGL(k_big_trsm<2>, gr, dim3(256), lds_trsm, pst, P, list, step, wc, 0); break;
-              case 3: hipLaunchKernelGGL(k_big_trsm<3>, gr, dim3(256), lds_trsm, pst, P, list, step, wc, 0); break;
-              default: hipLaunchKernelGGL(k_big_trsm<4>, gr, dim3(256), lds_trsm, pst, P, list, step, wc, 0); break;
-            }
-          }
+          launch_trsm(pst, step, par, i, 0, -1);
         }
         return "";
       };

@@ -25,10 +25,12 @@ for x in xs:
 assert np.array_equal(xs[2], xs[3])
 finalize_b(h)
 
+import os
+ordering = int(os.environ.get("OKKT_ORDERING_TEST", "0"))
 prob = synth.make_config("S-C3", seed=0)
 K = synth.augmented_matrix(prob, delta=1e-8)
 Ms = synth.symmetrize_lower(K)
-h = linear_solver_HIP("symmetric")
+h = linear_solver_HIP("symmetric", ordering=ordering)
 initialize_b(h)
 for rep in range(2):
     assert h.ls_factor_b(K, prob["n"], prob["m"]) == 1

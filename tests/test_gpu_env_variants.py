@@ -24,6 +24,20 @@ VARIANTS = [
     {"OKKT_ASM_LCOL": "0"},
     {"OKKT_TASKS": "0"},                                          # one launch per level of small fronts
     {"OKKT_TASK_ABS": "1e9"},                                     # every all-small subtree is one workgroup's task
+    # round 3
+    {"OKKT_SYRK_SMALL_TILES": "0"},                               # 128 x 128 tiles everywhere
+    {"OKKT_SYRK_SMALL_TILES": "100000000"},                       # 128 x 64 tiles everywhere
+    {"OKKT_DIAG2": "0"},                                          # the round-2 diagonal-block kernel
+    {"OKKT_LANES": "2"},                                          # independent subtrees as lanes on two streams
+    {"OKKT_LANES": "3", "OKKT_LANE_MIN_FRAC": "0.01", "OKKT_LANE_OWN_FRAC": "0.5"},
+    {"OKKT_DECOUPLE": "1", "OKKT_GROUP": "1"},                    # diagonal chain one step ahead of the wide kernels, on every step
+    {"OKKT_DECOUPLE": "1", "OKKT_DECOUPLE_MIN_ROWS": "0"},
+    {"OKKT_FUSE_DIAG_TRSM": "1"},                                 # diagonal block and the rows below it in one launch
+    {"OKKT_FUSE_DIAG_TRSM": "1", "OKKT_LA_MIN_TILES": "1", "OKKT_SPLIT_MIN_ROWS": "0"},
+    {"OKKT_SOLVE_FUSE": "0"},                                     # the sweeps with two launches per level of thin fronts
+    {"OKKT_SOLVE_FUSE_WIDE_MAX": "100000000"},                    # the wide fronts fused as well
+    {"OKKT_SOLVE_FORK": "1"},
+    {"OKKT_ORDERING_TEST": "3"},                                  # (read by the case) AMD instead of the automatic choice
 ]
 
 
