@@ -39,6 +39,7 @@ int solver_ensure_numeric(okkt_solver_s* h) {
   std::string e = numeric_setup(h->S, h->sopts, h->stream, h->N);
   if (const char* sh = getenv("OKKT_SPLIT_HEAD")) h->N.split_head = atoi(sh);
   if (const char* dc = getenv("OKKT_DECOUPLE")) h->N.decouple = atoi(dc);
+  if (const char* af = getenv("OKKT_AHEAD_FIRST")) h->N.ahead_first = atoi(af);
   if (const char* d2 = getenv("OKKT_DIAG2")) h->N.diag2 = atoi(d2);
   if (const char* fd = getenv("OKKT_FUSE_DIAG_TRSM")) h->N.fuse_diag_trsm = atoi(fd);
   if (const char* sf = getenv("OKKT_SOLVE_FORK")) h->N.solve_fork = atoi(sf);

@@ -152,6 +152,7 @@ struct Numeric {
   hipStream_t stream_panel = nullptr;
   hipStream_t stream_aux = nullptr;     // off-critical-path part of the in-group panel updates
   int split_head = 1;
+  int ahead_first = 0;                   // OKKT_AHEAD_FIRST=1: look-ahead columns on the trailing update's stream ahead of it instead of beside it on the panel stream (measured slower: 23.1 -> 23.7 ms, the delayed trailing update costs more than the chain gains)
   int fuse_diag_trsm = 0;                // OKKT_FUSE_DIAG_TRSM=1: k_diag_trsm_fused, the diagonal block and the rows below it in one launch (measured: the waiting trsm workgroups hold CUs the trailing update wants; S-metric 23.7 -> 24.1 ms, S-C3 3.96 -> 3.87 ms)
   int* chain_flags = nullptr;            // [nsuper] monotonic flags of those launches
   int chain_epoch = 0;

@@ -2112,6 +2112,20 @@ static std::string factor_sched(Numeric& N, DevPlan P, const std::vector<LevelSc
         if (la) {
           hipEvent_t eva, evp;
           if (!(e = next_event(&eva)).empty() || !(e = next_event(&evp)).empty()) return e;
+          if (N.ahead_first) {
+            // round 3: the look-ahead columns go FIRST on the trailing update's own stream -- 136 tiles alone on 248 CUs take
+            // 45 us, beside a queued trailing update (2 000 workgroups ahead of them on every CU but the reserved ones) 85 - 150 us,
+            // and the panel chain waits for them either way; the trailing update starts that much later and is not the
+            // critical path while the chain is
+            if (ev_panel) OKKT_HIP_TRY(hipStreamWaitEvent(st, ev_panel, 0));       // Panel(q) (its W panels) is behind this
+            if (!(e = launch_syrk(st, stepA, gs_cur, stepB, 2, par, gs_next)).empty()) return e;
+            OKKT_HIP_TRY(hipEventRecord(eva, st));
+            OKKT_HIP_TRY(hipStreamWaitEvent(ss.panel, eva, 0));
+            if (!(e = launch_panels(ss.panel, stepB, gs_next, par ^ 1)).empty()) return e;
+            OKKT_HIP_TRY(hipEventRecord(evp, ss.panel));
+            if (!(e = launch_syrk(st, stepA, gs_cur, stepB, 3, par, gs_next)).empty()) return e;
+            ev_panel = evp;
+          } else {
           OKKT_HIP_TRY(hipEventRecord(eva, st));                     // rest(q - 1) (and Panel(0)) are behind this
           OKKT_HIP_TRY(hipStreamWaitEvent(ss.panel, eva, 0));
           if (!(e = launch_syrk(ss.panel, stepA, gs_cur, stepB, 2, par, gs_next)).empty()) return e;
@@ -2120,6 +2134,7 @@ static std::string factor_sched(Numeric& N, DevPlan P, const std::vector<LevelSc
           if (ev_panel) OKKT_HIP_TRY(hipStreamWaitEvent(st, ev_panel, 0));
           if (!(e = launch_syrk(st, stepA, gs_cur, stepB, 3, par, gs_next)).empty()) return e;
           ev_panel = evp;
+          }
         } else if (N.decouple && ss.aux != nullptr && gs_cur == 1 && (!more || gs_next == 1) && rem_rows(stepB) >= N.decouple_min_rows && dbg_syrk == 0) {
           // Decoupled single-block steps (round 3): the chain  diag(q) -> first 128 rows of trsm(q) -> update of the next
           // diagonal tile -> diag(q + 1)  runs on `st`; the rest of trsm(q) and the rest of the trailing update follow one
