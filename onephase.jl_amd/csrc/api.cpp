@@ -36,6 +36,7 @@ int solver_ensure_numeric(okkt_solver_s* h) {
   h->N.stream_masked = h->stream_masked;     // before the set-up: the lanes of the plan are given streams there
   h->N.stream_panel = h->stream_panel;
   h->N.stream_aux = h->stream_aux;
+  if (const char* fl = getenv("OKKT_FLOW")) h->N.flow = atoi(fl);   // read by the set-up
   std::string e = numeric_setup(h->S, h->sopts, h->stream, h->N);
   if (const char* sh = getenv("OKKT_SPLIT_HEAD")) h->N.split_head = atoi(sh);
   if (const char* dc = getenv("OKKT_DECOUPLE")) h->N.decouple = atoi(dc);

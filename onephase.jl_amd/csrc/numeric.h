@@ -30,6 +30,7 @@ struct DevPlan {
   int* perm = nullptr;
   int* sched = nullptr;  // supernode ids grouped by (level, class); for the small classes: the ROOT of a task
   int* task_lo = nullptr;  // [supernode] first supernode of the task rooted there (small fronts): the workgroup runs task_lo[s] .. s in order
+  int* unit_parent = nullptr;  // [supernode] for the root of a task: root of the task that holds its parent front, -1 at a tree root
   // numeric state
   double* arena = nullptr;    // all fronts, f x f column-major each
   const double* vals = nullptr;  // caller's nzval in HBM
@@ -156,6 +157,13 @@ struct Numeric {
   int fuse_diag_trsm = 0;                // OKKT_FUSE_DIAG_TRSM=1: k_diag_trsm_fused, the diagonal block and the rows below it in one launch (measured: the waiting trsm workgroups hold CUs the trailing update wants; S-metric 23.7 -> 24.1 ms, S-C3 3.96 -> 3.87 ms)
   int* chain_flags = nullptr;            // [nsuper] monotonic flags of those launches
   int chain_epoch = 0;
+  // several levels of small-front tasks in ONE launch (in-launch hand-offs between a task and its children tasks): the leading
+  // flow_levels levels of `levels` hold no big front; flow_off / flow_cnt is their range in `sched`.  OKKT_FLOW=0 switches back
+  // to one launch per level.
+  int flow = 1;
+  int flow_levels = 0, flow_off = 0, flow_cnt = 0, flow_maxf = 0, flow_maxk = 0;
+  int* flow_flags = nullptr;             // [3][nsuper] monotonic flags: factorisation, forward sweep, backward sweep
+  int flow_epoch = 0;
   int diag2 = 1;                         // k_big_diag2 (role-split, pipelined) instead of k_big_diag; OKKT_DIAG2=0 switches back
   int decouple = 0;                      // OKKT_DECOUPLE=1: single-block steps with the diagonal chain ahead of the wide trsm / trailing update (aux stream); measured slower
   int decouple_min_rows = 256;           // ... while at least this many rows are left below the step

@@ -123,17 +123,41 @@ __device__ __forceinline__ void ldl_partial_lds(double* F, double* wcol, int ldf
 // ------------------------------------------------------------------------------------------
 // small fronts: one workgroup, front resident in LDS
 // ------------------------------------------------------------------------------------------
-template <int TPB>
-__global__ __launch_bounds__(TPB) void k_front_small(DevPlan P, const int* __restrict__ list, double tol) {
+// FLOW (round 3): the tasks of SEVERAL levels in one launch.  `list` holds them level by level, so a task's children tasks have
+// lower block indices (dispatch order = dependency order: a waiting workgroup never keeps its producers from being scheduled).
+// A task raises flags[root] = epoch once its last front is in HBM; a parent waits on the flag of every child that lies outside
+// its own index range.  The contribution blocks travel with agent-scope (sc1) accesses, which the memory side serves: no
+// release / acquire fences.  A banded KKT system (BASELINE config 2) is factored by one launch instead of one per level.
+__device__ __forceinline__ void flow_st(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double flow_ld(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void flow_wait(const int* flag, int value) {   // bounded: a hand-off that never comes ends the wait, the residual checks of the callers see the wrong factor
+  if (threadIdx.x == 0) {
+    int spins = 0;
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < value && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(1);
+  }
+  __syncthreads();
+}
+__device__ __forceinline__ void flow_signal(int* flag, int value) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every storing wave: its stores have been acknowledged
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <int TPB, bool FLOW = false>
+__global__ __launch_bounds__(TPB) void k_front_small(DevPlan P, const int* __restrict__ list, double tol, int* __restrict__ flags = nullptr, int epoch = 0) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   constexpr int G = TPB / 32;
   const int tid = threadIdx.x, lane = tid & 31, grp = tid >> 5;
   const int s_root = list[blockIdx.x];
   unsigned pos = 0, neg = 0, zer = 0, bad = 0;
-  if (stop_requested_wg(P)) return;
+  if (stop_requested_wg(P)) {
+    if (FLOW) flow_signal(flags + s_root, epoch);    // the consumers must not wait for a task that will never run
+    return;
+  }
+  const int t_lo = P.task_lo[s_root];
   // the task: the fronts task_lo[root] .. root in postorder, children's contribution blocks pass through HBM (the
   // barrier at the end of an iteration makes the workgroup's stores visible to its own later loads)
-  for (int s = P.task_lo[s_root]; s <= s_root; ++s) {
+  for (int s = t_lo; s <= s_root; ++s) {
   const int col0 = P.sn_col0[s];
   const int k = P.sn_col0[s + 1] - col0;
   const int f = (int)(P.row_ptr[s + 1] - P.row_ptr[s]);
@@ -172,10 +196,11 @@ __global__ __launch_bounds__(TPB) void k_front_small(DevPlan P, const int* __res
     const int rc = fc - kc;
     const double* C = P.arena + P.front_pos[c];
     const int* rl = P.rel + P.rel_ptr[c];
+    if (FLOW && c < t_lo) flow_wait(flags + c, epoch);      // a child task of this launch (workgroup-uniform)
     for (int jj = grp; jj < rc; jj += G) {
       const int pj = rl[jj];
       const double* Ccol = C + (size_t)(kc + jj) * fc + kc;
-      for (int ii = jj + lane; ii < rc; ii += 32) F[rl[ii] + pj * ldf] += Ccol[ii];
+      for (int ii = jj + lane; ii < rc; ii += 32) F[rl[ii] + pj * ldf] += FLOW ? flow_ld(Ccol + ii) : Ccol[ii];
     }
     __syncthreads();
   }
@@ -183,17 +208,20 @@ __global__ __launch_bounds__(TPB) void k_front_small(DevPlan P, const int* __res
   // write back: L panel (rows >= col), contribution block (lower), D, inertia counts
   for (int c = grp; c < f; c += G) {
     double* dst = front + (size_t)c * f;
-    for (int i = c + lane; i < f; i += 32) dst[i] = F[i + c * ldf];
+    if (FLOW && c >= k) { for (int i = c + lane; i < f; i += 32) flow_st(dst + i, F[i + c * ldf]); }
+    else for (int i = c + lane; i < f; i += 32) dst[i] = F[i + c * ldf];
   }
   for (int j = tid; j < k; j += TPB) {
     const double d = F[j + j * ldf];
     P.dvals[col0 + j] = d;
     classify_pivot(d, tol, pos, neg, zer, bad);
   }
+  if (FLOW) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next front of the task reads this contribution block back
   __threadfence_block();
   __syncthreads();
   }
   flush_counts(P, 1 + (int)(blockIdx.x % (kCountSlots - 1)), pos, neg, zer, bad);
+  if (FLOW) flow_signal(flags + s_root, epoch);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1565,6 +1593,30 @@ std::string numeric_setup(const Symbolic& S, const SymbolicOptions& opts, hipStr
   }
   if (!(e = upload(N, sched, &d.sched)).empty()) return e;
   if (!(e = upload(N, task_lo, &d.task_lo)).empty()) return e;
+  // the leading levels without a big front run as one launch (k_front_small<.., FLOW>, the flow kernels of solve.hip)
+  N.flow_levels = N.flow_off = N.flow_cnt = N.flow_maxf = N.flow_maxk = 0;
+  if (!parted && !laned && N.flow) {
+    int nl = 0;
+    while (nl < (int)N.levels.size() && N.levels[nl].seg[3].cnt == 0) ++nl;
+    if (nl >= 2) {
+      N.flow_levels = nl;
+      N.flow_off = N.levels[0].seg[0].off;
+      for (int l = 0; l < nl; ++l)
+        for (int c = 0; c < 3; ++c) { N.flow_cnt += N.levels[l].seg[c].cnt; if (N.levels[l].seg[c].cnt) { N.flow_maxf = std::max(N.flow_maxf, N.levels[l].seg[c].maxf); N.flow_maxk = std::max(N.flow_maxk, N.levels[l].seg[c].maxk); } }
+      if (N.flow_cnt == 0) N.flow_levels = 0;
+    }
+  }
+  {
+    // backward sweep of those levels: a task waits for the task that holds its root's parent front -- if that one is part of the
+    // same launch (a parent above the flow levels has been solved by an earlier launch)
+    std::vector<int> unit_parent(ns, -1);
+    for (int s2 = 0; s2 < ns; ++s2) {
+      if (unit_root[s2] != s2 || S.sn_parent[s2] < 0) continue;
+      const int up = unit_root[S.sn_parent[s2]];
+      if (ulevel[up] < N.flow_levels) unit_parent[s2] = up;
+    }
+    if (!(e = upload(N, unit_parent, &d.unit_parent)).empty()) return e;
+  }
   if (getenv("OKKT_DEBUG_FRONTS")) fprintf(stderr, "okkt: %d levels of units (%d levels of fronts), %lld tasks of small fronts, longest %d\n", nulev, S.nlevels, (long long)N.n_tasks, N.max_task_len);
   if (!(e = upload(N, wpos, &d.wbuf_pos)).empty()) return e;
   N.sched_host = sched;
@@ -1684,11 +1736,16 @@ std::string numeric_setup(const Symbolic& S, const SymbolicOptions& opts, hipStr
     if (!(e = dalloc(N, (size_t)ns / 2 + 8, &raw, true)).empty()) return e;
     N.chain_flags = (int*)raw;
     N.chain_epoch = 0;
+    raw = nullptr;               // three per supernode for the multi-level launches of small-front tasks
+    if (!(e = dalloc(N, (size_t)3 * ns / 2 + 8, &raw, true)).empty()) return e;
+    N.flow_flags = (int*)raw;
+    N.flow_epoch = 0;
   }
   if (!(e = solve_setup(S, N)).empty()) return e;
   // kernels that may want more than 64 KiB of dynamic LDS
   const int big_lds = 160 * 1024 - 64;   // the stop-flag check keeps one static LDS word per kernel
   OKKT_HIP_TRY(hipFuncSetAttribute((const void*)k_front_small<256>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds));
+  OKKT_HIP_TRY(hipFuncSetAttribute((const void*)k_front_small<256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds));
   OKKT_HIP_TRY(hipFuncSetAttribute((const void*)k_big_diag, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds));
   OKKT_HIP_TRY(hipFuncSetAttribute((const void*)k_big_diag2, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds));
   OKKT_HIP_TRY(hipFuncSetAttribute((const void*)k_diag_trsm_fused, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds));
@@ -1723,6 +1780,7 @@ void numeric_release(Numeric& N) {
   N.solve_events.clear();
   N.solve_ev_used = 0;
   N.chain_flags = nullptr; N.chain_epoch = 0;
+  N.flow_flags = nullptr; N.flow_epoch = 0; N.flow_levels = 0;
   N.solve_flags = nullptr; N.solve_counters = nullptr; N.solve_epoch = 0; N.solve_counters64 = nullptr; N.solve_epoch64 = 0;
   N.lane_ev_used = 0;
   N.slevels.clear();
@@ -1851,14 +1909,23 @@ static std::string factor_sched(Numeric& N, DevPlan P, const std::vector<LevelSc
         return "";
       }
     }
+    if (l == 0 && &levels == &N.levels && N.flow_levels >= 2 && l_end >= (size_t)N.flow_levels && N.flow_flags) {
+      // levels [0, flow_levels): every task in one launch, children tasks at lower block indices than their parents
+      const int ep = ++N.flow_epoch;
+      if (N.flow_maxf <= 32) hipLaunchKernelGGL((k_front_small<64, true>), dim3(N.flow_cnt), dim3(64), lds_small(N.flow_maxf), st, P, P.sched + N.flow_off, tol, N.flow_flags, ep);
+      else hipLaunchKernelGGL((k_front_small<256, true>), dim3(N.flow_cnt), dim3(256), lds_small(N.flow_maxf), st, P, P.sched + N.flow_off, tol, N.flow_flags, ep);
+      if (P.want_neg >= 0) hipLaunchKernelGGL(k_fold_counts, dim3(1), dim3(64), 0, st, P);
+      l = (size_t)N.flow_levels - 1;
+      continue;
+    }
     if (L.seg[0].cnt) {
       const Segment& g = L.seg[0];
-      hipLaunchKernelGGL(k_front_small<64>, dim3(g.cnt), dim3(64), lds_small(g.maxf), st, P, P.sched + g.off, tol);
+      hipLaunchKernelGGL(k_front_small<64>, dim3(g.cnt), dim3(64), lds_small(g.maxf), st, P, P.sched + g.off, tol, (int*)nullptr, 0);
     }
     for (int c = 1; c <= 2; ++c)
       if (L.seg[c].cnt) {
         const Segment& g = L.seg[c];
-        hipLaunchKernelGGL(k_front_small<256>, dim3(g.cnt), dim3(256), lds_small(g.maxf), st, P, P.sched + g.off, tol);
+        hipLaunchKernelGGL(k_front_small<256>, dim3(g.cnt), dim3(256), lds_small(g.maxf), st, P, P.sched + g.off, tol, (int*)nullptr, 0);
       }
     if (P.want_neg >= 0 && (L.seg[0].cnt || L.seg[1].cnt || L.seg[2].cnt)) hipLaunchKernelGGL(k_fold_counts, dim3(1), dim3(64), 0, st, P);
     if (L.seg[3].cnt) {

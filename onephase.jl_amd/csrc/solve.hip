@@ -218,126 +218,6 @@ __global__ __launch_bounds__(256) void k_xinv_gemm(DevPlan P, const int* __restr
       }
 }
 
-// ------------------------------------------------------------------------------------------------------------------
-// small fronts (one workgroup per task of fronts, the front's vector in LDS), R right-hand sides
-// ------------------------------------------------------------------------------------------------------------------
-template <int TPB, int R>
-__global__ __launch_bounds__(TPB) void k_fs_small(DevPlan P, const int* __restrict__ list, int ldw) {
-  extern __shared__ __attribute__((aligned(16))) double sm[];      // [R][ldw]
-  const int tid = threadIdx.x;
-  const int s_root = list[blockIdx.x];
-  for (int s = P.task_lo[s_root]; s <= s_root; ++s) {      // the task's fronts, children first
-    const int col0 = P.sn_col0[s];
-    const int k = P.sn_col0[s + 1] - col0;
-    const int f = (int)(P.row_ptr[s + 1] - P.row_ptr[s]);
-    const double* L = P.arena + P.front_pos[s];
-    for (int i = tid; i < f; i += TPB)
-#pragma unroll
-      for (int q = 0; q < R; ++q) sm[q * ldw + i] = i < k ? P.xwork[(size_t)q * P.xw_stride + col0 + i] : 0.0;
-    __syncthreads();
-    for (int64_t c = P.child_ptr[s]; c < P.child_ptr[s + 1]; ++c) {
-      const int ch = P.children[c];
-      const int rc = (int)(P.rel_ptr[ch + 1] - P.rel_ptr[ch]);
-      const int* rl = P.rel + P.rel_ptr[ch];
-      const double* cvc = P.cv + P.cv_pos[ch];
-      for (int ii = tid; ii < rc; ii += TPB) {
-        const int d = rl[ii];
-#pragma unroll
-        for (int q = 0; q < R; ++q) sm[q * ldw + d] += cvc[(size_t)q * P.cv_stride + ii];
-      }
-      __syncthreads();
-    }
-    // unit lower triangular k x k
-    for (int j = 0; j < k; ++j) {
-      const double* col = L + (size_t)j * f;
-      for (int i = j + 1 + tid; i < k; i += TPB) {
-        const double l = col[i];
-#pragma unroll
-        for (int q = 0; q < R; ++q) sm[q * ldw + i] -= l * sm[q * ldw + j];
-      }
-      __syncthreads();
-    }
-    // rows below the pivot block: contribution vector for the parent
-    double* cvs = P.cv + P.cv_pos[s];
-    for (int i = k + tid; i < f; i += TPB) {
-      double acc[R];
-#pragma unroll
-      for (int q = 0; q < R; ++q) acc[q] = sm[q * ldw + i];
-      for (int j = 0; j < k; ++j) {
-        const double l = L[(size_t)j * f + i];
-#pragma unroll
-        for (int q = 0; q < R; ++q) acc[q] -= l * sm[q * ldw + j];
-      }
-#pragma unroll
-      for (int q = 0; q < R; ++q) cvs[(size_t)q * P.cv_stride + i - k] = acc[q];
-    }
-    // z = D^-1 y
-    for (int j = tid; j < k; j += TPB) {
-      const double d = P.dvals[col0 + j];
-#pragma unroll
-      for (int q = 0; q < R; ++q) P.zwork[(size_t)q * P.xw_stride + col0 + j] = sm[q * ldw + j] / d;
-    }
-    __threadfence_block();
-    __syncthreads();
-  }
-}
-
-template <int TPB, int R>
-__global__ __launch_bounds__(TPB) void k_bs_small(DevPlan P, const int* __restrict__ list, int ldw) {
-  extern __shared__ __attribute__((aligned(16))) double sm[];      // [R][ldw]
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  constexpr int NW = TPB / 64;
-  const int s_root = list[blockIdx.x];
-  for (int s = s_root; s >= P.task_lo[s_root]; --s) {      // the task's fronts, parents first
-    const int col0 = P.sn_col0[s];
-    const int k = P.sn_col0[s + 1] - col0;
-    const int f = (int)(P.row_ptr[s + 1] - P.row_ptr[s]);
-    const double* L = P.arena + P.front_pos[s];
-    const int* rows = P.rows + P.row_ptr[s];
-    for (int i = tid; i < f; i += TPB) {
-      const int g = rows[i];     // rows[i] = col0 + i for i < k: this front's z; beyond: the ancestors' solution
-      const double* src = i < k ? P.zwork : P.xwork;
-#pragma unroll
-      for (int q = 0; q < R; ++q) sm[q * ldw + i] = src[(size_t)q * P.xw_stride + g];
-    }
-    __syncthreads();
-    // rhs_j = z_j - sum_{i >= k} L[i, j] * x_i
-    for (int j = wv; j < k; j += NW) {
-      const double* col = L + (size_t)j * f;
-      double acc[R];
-#pragma unroll
-      for (int q = 0; q < R; ++q) acc[q] = 0.0;
-      for (int i = k + lane; i < f; i += 64) {
-        const double l = col[i];
-#pragma unroll
-        for (int q = 0; q < R; ++q) acc[q] += l * sm[q * ldw + i];
-      }
-#pragma unroll
-      for (int q = 0; q < R; ++q) {
-        double a = acc[q];
-        for (int o = 32; o > 0; o >>= 1) a += __shfl_down(a, o, 64);
-        if (lane == 0) sm[q * ldw + j] -= a;
-      }
-    }
-    __syncthreads();
-    // unit upper triangular (L11^T) k x k, column oriented
-    for (int j = k - 1; j >= 0; --j) {
-      for (int i = tid; i < j; i += TPB) {
-        const double l = L[(size_t)i * f + j];
-#pragma unroll
-        for (int q = 0; q < R; ++q) sm[q * ldw + i] -= l * sm[q * ldw + j];
-      }
-      __syncthreads();
-    }
-    for (int j = tid; j < k; j += TPB)
-#pragma unroll
-      for (int q = 0; q < R; ++q) P.xwork[(size_t)q * P.xw_stride + col0 + j] = sm[q * ldw + j];
-    __threadfence_block();
-    __syncthreads();
-  }
-}
-
-
 // ---- in-launch hand-offs between the workgroups of one front (round 3): a level's two dependent launches become one.
 // Producer workgroups have LOWER block indices than their consumers (dispatch order = dependency order, so a waiting
 // consumer never keeps its producer from being scheduled); the protocol is the MI355X guide's: every storing wave drains its
@@ -386,6 +266,140 @@ __device__ __forceinline__ void front_wait(const int* flag, int value) {
   }
   __syncthreads();
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// small fronts (one workgroup per task of fronts, the front's vector in LDS), R right-hand sides
+// ------------------------------------------------------------------------------------------------------------------
+// FLOW: the tasks of several levels in one launch (see k_front_small<.., FLOW> in numeric.hip): a task waits for the flags of its
+// children tasks, contribution vectors travel with agent-scope accesses, flags[root] = epoch when the task is done.
+template <int TPB, int R, bool FLOW = false>
+__global__ __launch_bounds__(TPB) void k_fs_small(DevPlan P, const int* __restrict__ list, int ldw, int* __restrict__ flags = nullptr, int epoch = 0) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];      // [R][ldw]
+  const int tid = threadIdx.x;
+  const int s_root = list[blockIdx.x];
+  const int t_lo = P.task_lo[s_root];
+  for (int s = t_lo; s <= s_root; ++s) {      // the task's fronts, children first
+    const int col0 = P.sn_col0[s];
+    const int k = P.sn_col0[s + 1] - col0;
+    const int f = (int)(P.row_ptr[s + 1] - P.row_ptr[s]);
+    const double* L = P.arena + P.front_pos[s];
+    for (int i = tid; i < f; i += TPB)
+#pragma unroll
+      for (int q = 0; q < R; ++q) sm[q * ldw + i] = i < k ? P.xwork[(size_t)q * P.xw_stride + col0 + i] : 0.0;
+    __syncthreads();
+    for (int64_t c = P.child_ptr[s]; c < P.child_ptr[s + 1]; ++c) {
+      const int ch = P.children[c];
+      const int rc = (int)(P.rel_ptr[ch + 1] - P.rel_ptr[ch]);
+      const int* rl = P.rel + P.rel_ptr[ch];
+      const double* cvc = P.cv + P.cv_pos[ch];
+      if (FLOW && ch < t_lo) front_wait(flags + ch, epoch);
+      for (int ii = tid; ii < rc; ii += TPB) {
+        const int d = rl[ii];
+#pragma unroll
+        for (int q = 0; q < R; ++q) sm[q * ldw + d] += FLOW ? ld_agent(cvc + (size_t)q * P.cv_stride + ii) : cvc[(size_t)q * P.cv_stride + ii];
+      }
+      __syncthreads();
+    }
+    // unit lower triangular k x k
+    for (int j = 0; j < k; ++j) {
+      const double* col = L + (size_t)j * f;
+      for (int i = j + 1 + tid; i < k; i += TPB) {
+        const double l = col[i];
+#pragma unroll
+        for (int q = 0; q < R; ++q) sm[q * ldw + i] -= l * sm[q * ldw + j];
+      }
+      __syncthreads();
+    }
+    // rows below the pivot block: contribution vector for the parent
+    double* cvs = P.cv + P.cv_pos[s];
+    for (int i = k + tid; i < f; i += TPB) {
+      double acc[R];
+#pragma unroll
+      for (int q = 0; q < R; ++q) acc[q] = sm[q * ldw + i];
+      for (int j = 0; j < k; ++j) {
+        const double l = L[(size_t)j * f + i];
+#pragma unroll
+        for (int q = 0; q < R; ++q) acc[q] -= l * sm[q * ldw + j];
+      }
+#pragma unroll
+      for (int q = 0; q < R; ++q) { if (FLOW) st_agent(cvs + (size_t)q * P.cv_stride + i - k, acc[q]); else cvs[(size_t)q * P.cv_stride + i - k] = acc[q]; }
+    }
+    // z = D^-1 y
+    for (int j = tid; j < k; j += TPB) {
+      const double d = P.dvals[col0 + j];
+#pragma unroll
+      for (int q = 0; q < R; ++q) P.zwork[(size_t)q * P.xw_stride + col0 + j] = sm[q * ldw + j] / d;
+    }
+    if (FLOW) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __threadfence_block();
+    __syncthreads();
+  }
+  if (FLOW) front_signal_store(flags + s_root, epoch);
+}
+
+// FLOW, backward: block b takes list[gridDim.x - 1 - b] (parents before children in dispatch order), waits for the task that
+// holds its root's parent front and reads the ancestors' solution with agent-scope loads.
+template <int TPB, int R, bool FLOW = false>
+__global__ __launch_bounds__(TPB) void k_bs_small(DevPlan P, const int* __restrict__ list, int ldw, int* __restrict__ flags = nullptr, int epoch = 0) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];      // [R][ldw]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  constexpr int NW = TPB / 64;
+  const int s_root = list[FLOW ? gridDim.x - 1 - blockIdx.x : blockIdx.x];
+  if (FLOW) {
+    const int up = P.unit_parent[s_root];
+    if (up >= 0) front_wait(flags + up, epoch);
+  }
+  for (int s = s_root; s >= P.task_lo[s_root]; --s) {      // the task's fronts, parents first
+    const int col0 = P.sn_col0[s];
+    const int k = P.sn_col0[s + 1] - col0;
+    const int f = (int)(P.row_ptr[s + 1] - P.row_ptr[s]);
+    const double* L = P.arena + P.front_pos[s];
+    const int* rows = P.rows + P.row_ptr[s];
+    for (int i = tid; i < f; i += TPB) {
+      const int g = rows[i];     // rows[i] = col0 + i for i < k: this front's z; beyond: the ancestors' solution
+      const double* src = i < k ? P.zwork : P.xwork;
+#pragma unroll
+      for (int q = 0; q < R; ++q) sm[q * ldw + i] = (FLOW && i >= k) ? ld_agent(src + (size_t)q * P.xw_stride + g) : src[(size_t)q * P.xw_stride + g];
+    }
+    __syncthreads();
+    // rhs_j = z_j - sum_{i >= k} L[i, j] * x_i
+    for (int j = wv; j < k; j += NW) {
+      const double* col = L + (size_t)j * f;
+      double acc[R];
+#pragma unroll
+      for (int q = 0; q < R; ++q) acc[q] = 0.0;
+      for (int i = k + lane; i < f; i += 64) {
+        const double l = col[i];
+#pragma unroll
+        for (int q = 0; q < R; ++q) acc[q] += l * sm[q * ldw + i];
+      }
+#pragma unroll
+      for (int q = 0; q < R; ++q) {
+        double a = acc[q];
+        for (int o = 32; o > 0; o >>= 1) a += __shfl_down(a, o, 64);
+        if (lane == 0) sm[q * ldw + j] -= a;
+      }
+    }
+    __syncthreads();
+    // unit upper triangular (L11^T) k x k, column oriented
+    for (int j = k - 1; j >= 0; --j) {
+      for (int i = tid; i < j; i += TPB) {
+        const double l = L[(size_t)i * f + j];
+#pragma unroll
+        for (int q = 0; q < R; ++q) sm[q * ldw + i] -= l * sm[q * ldw + j];
+      }
+      __syncthreads();
+    }
+    for (int j = tid; j < k; j += TPB)
+#pragma unroll
+      for (int q = 0; q < R; ++q) { if (FLOW) st_agent(P.xwork + (size_t)q * P.xw_stride + col0 + j, sm[q * ldw + j]); else P.xwork[(size_t)q * P.xw_stride + col0 + j] = sm[q * ldw + j]; }
+    if (FLOW) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __threadfence_block();
+    __syncthreads();
+  }
+  if (FLOW) front_signal_store(flags + s_root, epoch);
+}
+
 
 // ------------------------------------------------------------------------------------------------------------------
 // big fronts, forward
@@ -1107,14 +1121,24 @@ static hipEvent_t solve_event(Numeric& N) {
 template <int R>
 static std::string fwd_enqueue_r(Numeric& N, const std::vector<LevelSchedule>& levels, const std::vector<SolveLevel>& sl, hipStream_t st, int l_lo, int l_hi) {
   DevPlan P = N.d;
+  const bool flow = &levels == &N.levels && N.flow_levels >= 2 && N.flow_flags && l_lo == 0 && l_hi >= N.flow_levels;
   for (size_t l = (size_t)l_lo; l < std::min((size_t)l_hi, levels.size()); ++l) {
     const LevelSchedule& L = levels[l];
+    if (flow && l == 0) {     // the small-front tasks of the levels [0, flow_levels) in one launch
+      const size_t lds = (size_t)R * N.flow_maxf * sizeof(double);
+      int* flags = N.flow_flags + (size_t)N.d.nsuper;
+      const int ep = ++N.flow_epoch;
+      if (N.flow_maxf <= 32) hipLaunchKernelGGL((k_fs_small<64, R, true>), dim3(N.flow_cnt), dim3(64), lds, st, P, P.sched + N.flow_off, N.flow_maxf, flags, ep);
+      else hipLaunchKernelGGL((k_fs_small<256, R, true>), dim3(N.flow_cnt), dim3(256), lds, st, P, P.sched + N.flow_off, N.flow_maxf, flags, ep);
+      l = (size_t)N.flow_levels - 1;
+      continue;
+    }
     for (int c = 0; c < 3; ++c) {
       const Segment& g = L.seg[c];
       if (!g.cnt) continue;
       const size_t lds = (size_t)R * g.maxf * sizeof(double);
-      if (c == 0) hipLaunchKernelGGL((k_fs_small<64, R>), dim3(g.cnt), dim3(64), lds, st, P, P.sched + g.off, g.maxf);
-      else hipLaunchKernelGGL((k_fs_small<256, R>), dim3(g.cnt), dim3(256), lds, st, P, P.sched + g.off, g.maxf);
+      if (c == 0) hipLaunchKernelGGL((k_fs_small<64, R>), dim3(g.cnt), dim3(64), lds, st, P, P.sched + g.off, g.maxf, (int*)nullptr, 0);
+      else hipLaunchKernelGGL((k_fs_small<256, R>), dim3(g.cnt), dim3(256), lds, st, P, P.sched + g.off, g.maxf, (int*)nullptr, 0);
     }
     const SolveLevel& S = sl[l];
     // the thin and the wide fronts of a level are independent: with both present the wide chain runs on the auxiliary stream
@@ -1166,8 +1190,17 @@ static std::string fwd_enqueue_r(Numeric& N, const std::vector<LevelSchedule>& l
 template <int R>
 static std::string bwd_enqueue_r(Numeric& N, const std::vector<LevelSchedule>& levels, const std::vector<SolveLevel>& sl, hipStream_t st, int l_lo, int l_hi) {
   DevPlan P = N.d;
+  const bool flow = &levels == &N.levels && N.flow_levels >= 2 && N.flow_flags && l_lo == 0 && l_hi >= N.flow_levels;
   for (int l = std::min(l_hi, (int)levels.size()) - 1; l >= l_lo; --l) {
     const LevelSchedule& L = levels[l];
+    if (flow && l == N.flow_levels - 1) {     // the levels [0, flow_levels) in one launch, parents at the lower block indices
+      const size_t lds = (size_t)R * N.flow_maxf * sizeof(double);
+      int* flags = N.flow_flags + (size_t)2 * N.d.nsuper;
+      const int ep = ++N.flow_epoch;
+      if (N.flow_maxf <= 32) hipLaunchKernelGGL((k_bs_small<64, R, true>), dim3(N.flow_cnt), dim3(64), lds, st, P, P.sched + N.flow_off, N.flow_maxf, flags, ep);
+      else hipLaunchKernelGGL((k_bs_small<256, R, true>), dim3(N.flow_cnt), dim3(256), lds, st, P, P.sched + N.flow_off, N.flow_maxf, flags, ep);
+      break;
+    }
     const SolveLevel& S = sl[l];
     hipStream_t wst = st;
     hipEvent_t ev_join = nullptr;
@@ -1212,8 +1245,8 @@ static std::string bwd_enqueue_r(Numeric& N, const std::vector<LevelSchedule>& l
       const Segment& g = L.seg[c];
       if (!g.cnt) continue;
       const size_t lds = (size_t)R * g.maxf * sizeof(double);
-      if (c == 0) hipLaunchKernelGGL((k_bs_small<64, R>), dim3(g.cnt), dim3(64), lds, st, P, P.sched + g.off, g.maxf);
-      else hipLaunchKernelGGL((k_bs_small<256, R>), dim3(g.cnt), dim3(256), lds, st, P, P.sched + g.off, g.maxf);
+      if (c == 0) hipLaunchKernelGGL((k_bs_small<64, R>), dim3(g.cnt), dim3(64), lds, st, P, P.sched + g.off, g.maxf, (int*)nullptr, 0);
+      else hipLaunchKernelGGL((k_bs_small<256, R>), dim3(g.cnt), dim3(256), lds, st, P, P.sched + g.off, g.maxf, (int*)nullptr, 0);
     }
   }
   OKKT_HIP_TRY(hipGetLastError());

@@ -421,3 +421,41 @@ def test_structure_zoo_vs_oracle(shape, seed, ordering):
         J = sp.lil_matrix((m, n)); J[:, 7] = rng.normal(size=(m, 1)) + 3.0
     K, n, m = _kkt_from(sp.csc_matrix(J), n, rng)
     compare_with_oracle(K, n, m, seed=seed, tol=1e-9, ordering=ordering)
+
+
+@pytest.mark.parametrize("case", ["chain", "small_fronts_below_a_big_front", "small_fronts_only"])
+@pytest.mark.parametrize("nrhs", [1, 4])
+def test_levels_of_small_fronts_in_one_launch(case, nrhs):
+    """The leading levels of the tree that hold small fronts only run as ONE launch per phase (factorisation, forward sweep,
+    backward sweep), a task waiting in the launch for its children (its parent in the backward sweep).  Answers equal a dense
+    solve, repeated calls agree bit for bit, and no hand-off runs into its time-out (a wait that is never answered ends after
+    about 0.7 s instead of hanging the GPU: the device times below would show it)."""
+    if case == "chain":
+        prob = synth.hanging_chain(N_h=300, seed=2)
+    elif case == "small_fronts_below_a_big_front":
+        prob = synth.make_config("S-small", seed=1, h_per_col=2, j_per_row=3)    # one front of 158 rows above three levels of tasks
+    else:
+        prob = synth.make_config("S-tiny", seed=3)
+    K = synth.augmented_matrix(prob, delta=0.5)
+    Ms = synth.symmetrize_lower(K).toarray()
+    w = np.linalg.eigvalsh(Ms)
+    h = hip_solver("symmetric")
+    rng = np.random.default_rng(5)
+    B = rng.normal(size=(nrhs, K.shape[0]))
+    X = []
+    for rep in range(3):
+        h.ls_factor_b(K, prob["n"], prob["m"])
+        assert h.inertia == (int((w > 0).sum()), int((w < 0).sum()), 0, 0)
+        if nrhs > 1:
+            from onephase_jl_amd import _lib as L
+            x = np.zeros_like(B)
+            h._check(h._lib.okkt_solve(h._h, L.p_f64(B), L.p_f64(x), nrhs), "okkt_solve")
+        else:
+            x = h.ls_solve(B[0])[None, :]
+        st = h.stats()
+        assert st["last_factor_ms"] < 50.0 and st["last_solve_ms"] < 50.0, st
+        X.append(np.array(x))
+    xd = np.linalg.solve(Ms, B.T).T
+    assert np.max(np.abs(X[0] - xd)) <= 1e-8 * max(1.0, np.max(np.abs(xd)))
+    assert np.array_equal(X[0], X[1]) and np.array_equal(X[1], X[2])
+    finalize_b(h)
