@@ -2105,7 +2105,7 @@ static std::string factor_sched(Numeric& N, DevPlan P, const std::vector<LevelSc
             // the two (the rest of a split in-group update is joined before the trsm)
             const int rem_f = g.maxf - step * NB;
             const int ntr = rem_f > 0 ? (rem_f + 63) / 64 : 0;
-            if (N.diag2 && N.fuse_diag_trsm && N.chain_flags && dbg_stop == 0 && NB == 128 && ev_rest == nullptr && ntr > 0) {
+            if (N.diag2 && (N.fuse_diag_trsm == 1 || (N.fuse_diag_trsm == 2 && pst == st)) && N.chain_flags && dbg_stop == 0 && NB == 128 && ev_rest == nullptr && ntr > 0) {
               const int wc = (par * GS + i) * NB;
               hipLaunchKernelGGL(k_diag_trsm_fused, dim3(1 + ntr, g.cnt), dim3(384), std::max(lds_diag2, lds_trsm_max), pst, P, list, step, NB, tol, wc,
                                  N.chain_flags, ++N.chain_epoch);

@@ -31,8 +31,13 @@ struct SymbolicOptions {
   int mlnd_leaf = 1500;    // multilevel nested dissection (ordering 5, or chosen by ordering 0): pieces ordered by minimum degree
   int mlnd_trials = 3;     // bisections tried (different seeds, side by side on host threads) on the top two levels
   int relax_always = 64;   // merge a child into its parent when the merged width <= this (one LDS-resident front instead of a chain of launches / loop trips)
-  int relax_small = 128;   // ... or when width <= relax_small and zero fraction < relax_small_frac (S-C3: 107 -> 91 big fronts, factor 5.55 -> 5.2 ms)
-  double relax_small_frac = 0.5;
+  int relax_small = 256;   // ... or when width <= relax_small and zero fraction < relax_small_frac.  Round 3 sweep (scripts/relax_sweep.sh,
+                           // 40 settings x 3 configurations; round 2 had 128 / 0.5): a level of fronts with 128 pivot columns costs 0.5 ms of
+                           // assembly and launch chain whatever its flops, and a stricter zero fraction with a wider limit removes levels
+                           // without adding flops -- S-metric 15 -> 11 levels (23.0 + 1.86 -> 21.8 + 1.60 ms), S-C3 10 -> 8 (3.95 + 0.93 ->
+                           // 3.69 + 0.86).  512 / 0.3 is faster still on S-C5 (-12 %) but its wide fronts take the solves through the
+                           // 2048-column inverses: forward error 3.5e-8 instead of 2e-9 (scripts/forward_error.py), so it is not the default
+  double relax_small_frac = 0.25;
   int relax_mid = 96;
   double relax_mid_frac = 0.15;
   double relax_any_frac = 0.03;

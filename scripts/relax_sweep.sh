@@ -1,6 +1,8 @@
 #!/bin/bash
-# amalgamation sweep: factor ms and stored flops for relax_any_frac / relax_mid settings
-for cfg in S-metric S-C3; do
-for a in 0.03 0.06 0.1 0.15 0.25 0.4; do
-  echo "$cfg relax_any_frac=$a $(python3 scripts/probe.py $cfg 2 relax_any_frac=$a 2>&1 | grep -E "^rep 1|nsuper" | sed 's/.*flops_stored.: \([0-9.e+]*\).*nsuper.: \([0-9]*\).*n_big_fronts.: \([0-9]*\).*/stored_flops \1 nsuper \2 big \3/' | cut -c1-110 | tr '\n' ' ')"
-done; done
+# amalgamation sweep: relax_sweep.sh <config> ; prints factor / solve device ms per setting
+CFG=${1:-S-metric}
+for small in 256 384 512 1024; do for frac in 0.2 0.25 0.3 0.35 0.4; do for any in 0.03 0.08; do
+  opt="relax_small=$small relax_small_frac=$frac relax_any_frac=$any"
+  python scripts/probe.py $CFG 5 $opt 2>&1 | grep -E "nsuper|rep [34]" | sed -e "s/.*'flops_stored': \([0-9.e+]*\).*'nlevels': \([0-9]*\).*'n_big_fronts': \([0-9]*\).*/flops \1 levels \2 big \3/" -e "s/rep \([0-9]\): factor dev \([0-9.]*\) ms.*solve dev \([0-9.]*\) ms.*/f \2 s \3/" | tr "\n" " "
+  echo " | $CFG $opt"
+done; done; done
