@@ -125,7 +125,12 @@ void level_nd_order(int n, const std::vector<int64_t>& gp, const std::vector<int
   LevelNd nd(n, gp, gi, std::max(leaf, 4), order);
   // dense rows (a constraint over all variables, e.g. the length constraint of the hanging chain) would make every level
   // structure two levels deep: they leave the graph first and are eliminated last, as in the minimum-degree code
-  const double dense = std::max(16.0, 10.0 * std::sqrt((double)n));
+  // Threshold: 10 sqrt(n) as in the minimum-degree code, but not more than 8 x the average degree -- on a small system 10 sqrt(n)
+  // is most of the graph (hanging chain, N_h = 300: the length constraint has 301 entries, 10 sqrt(1208) = 348, and the level
+  // structure stayed two levels deep; at the CUTEst size N_h = 400 it passed by one entry).  Being generous is safe here: the caller
+  // keeps this ordering only if its elimination tree is three times shallower than minimum degree's at bounded extra flops.
+  const double avg_deg = n > 0 ? (double)gp[n] / (double)n : 0.0;
+  const double dense = std::max(16.0, std::min(10.0 * std::sqrt((double)n), 8.0 * avg_deg));
   std::vector<int> all, last;
   for (int i = 0; i < n; ++i) {
     if ((double)(gp[i + 1] - gp[i]) > dense) { last.push_back(i); nd.tag[i] = -1; }

@@ -130,10 +130,13 @@ __device__ __forceinline__ void ldl_partial_lds(double* F, double* wcol, int ldf
 // release / acquire fences.  A banded KKT system (BASELINE config 2) is factored by one launch instead of one per level.
 __device__ __forceinline__ void flow_st(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ double flow_ld(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void flow_wait(const int* flag, int value) {   // bounded: a hand-off that never comes ends the wait, the residual checks of the callers see the wrong factor
+// bounded: a hand-off that never comes ends the wait instead of hanging the GPU -- and is counted as a non-finite pivot (`bad`,
+// slot 0 word 3) and in the time-out word (slot 0 word 5): the factorisation reports a wrong inertia, solves return NaN
+__device__ __forceinline__ void flow_wait(const int* flag, int value, unsigned long long* counters) {
   if (threadIdx.x == 0) {
     int spins = 0;
     while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < value && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(1);
+    if (spins >= (1 << 22)) { atomicAdd(&counters[3], 1ull); atomicExch(&counters[5], 1ull); }
   }
   __syncthreads();
 }
@@ -144,7 +147,7 @@ __device__ __forceinline__ void flow_signal(int* flag, int value) {
 }
 
 template <int TPB, bool FLOW = false>
-__global__ __launch_bounds__(TPB) void k_front_small(DevPlan P, const int* __restrict__ list, double tol, int* __restrict__ flags = nullptr, int epoch = 0) {
+__global__ __launch_bounds__(TPB) void k_front_small(DevPlan P, const int* __restrict__ list, double tol, int* __restrict__ flags = nullptr, int epoch = 0, int wait_epoch = 0) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   constexpr int G = TPB / 32;
   const int tid = threadIdx.x, lane = tid & 31, grp = tid >> 5;
@@ -196,7 +199,7 @@ __global__ __launch_bounds__(TPB) void k_front_small(DevPlan P, const int* __res
     const int rc = fc - kc;
     const double* C = P.arena + P.front_pos[c];
     const int* rl = P.rel + P.rel_ptr[c];
-    if (FLOW && c < t_lo) flow_wait(flags + c, epoch);      // a child task of this launch (workgroup-uniform)
+    if (FLOW && c < t_lo) flow_wait(flags + c, wait_epoch, P.counters);      // a child task of this launch (workgroup-uniform)
     for (int jj = grp; jj < rc; jj += G) {
       const int pj = rl[jj];
       const double* Ccol = C + (size_t)(kc + jj) * fc + kc;
@@ -1912,20 +1915,23 @@ static std::string factor_sched(Numeric& N, DevPlan P, const std::vector<LevelSc
     if (l == 0 && &levels == &N.levels && N.flow_levels >= 2 && l_end >= (size_t)N.flow_levels && N.flow_flags) {
       // levels [0, flow_levels): every task in one launch, children tasks at lower block indices than their parents
       const int ep = ++N.flow_epoch;
-      if (N.flow_maxf <= 32) hipLaunchKernelGGL((k_front_small<64, true>), dim3(N.flow_cnt), dim3(64), lds_small(N.flow_maxf), st, P, P.sched + N.flow_off, tol, N.flow_flags, ep);
-      else hipLaunchKernelGGL((k_front_small<256, true>), dim3(N.flow_cnt), dim3(256), lds_small(N.flow_maxf), st, P, P.sched + N.flow_off, tol, N.flow_flags, ep);
+      // OKKT_DEBUG_DROP_HANDOFF=1 (tests): the consumers wait for an epoch nobody raises -- every wait runs into its bound
+      static const int drop = getenv("OKKT_DEBUG_DROP_HANDOFF") ? atoi(getenv("OKKT_DEBUG_DROP_HANDOFF")) : 0;
+      const int wep = ep + ((drop & 1) ? (1 << 20) : 0);
+      if (N.flow_maxf <= 32) hipLaunchKernelGGL((k_front_small<64, true>), dim3(N.flow_cnt), dim3(64), lds_small(N.flow_maxf), st, P, P.sched + N.flow_off, tol, N.flow_flags, ep, wep);
+      else hipLaunchKernelGGL((k_front_small<256, true>), dim3(N.flow_cnt), dim3(256), lds_small(N.flow_maxf), st, P, P.sched + N.flow_off, tol, N.flow_flags, ep, wep);
       if (P.want_neg >= 0) hipLaunchKernelGGL(k_fold_counts, dim3(1), dim3(64), 0, st, P);
       l = (size_t)N.flow_levels - 1;
       continue;
     }
     if (L.seg[0].cnt) {
       const Segment& g = L.seg[0];
-      hipLaunchKernelGGL(k_front_small<64>, dim3(g.cnt), dim3(64), lds_small(g.maxf), st, P, P.sched + g.off, tol, (int*)nullptr, 0);
+      hipLaunchKernelGGL(k_front_small<64>, dim3(g.cnt), dim3(64), lds_small(g.maxf), st, P, P.sched + g.off, tol, (int*)nullptr, 0, 0);
     }
     for (int c = 1; c <= 2; ++c)
       if (L.seg[c].cnt) {
         const Segment& g = L.seg[c];
-        hipLaunchKernelGGL(k_front_small<256>, dim3(g.cnt), dim3(256), lds_small(g.maxf), st, P, P.sched + g.off, tol, (int*)nullptr, 0);
+        hipLaunchKernelGGL(k_front_small<256>, dim3(g.cnt), dim3(256), lds_small(g.maxf), st, P, P.sched + g.off, tol, (int*)nullptr, 0, 0);
       }
     if (P.want_neg >= 0 && (L.seg[0].cnt || L.seg[1].cnt || L.seg[2].cnt)) hipLaunchKernelGGL(k_fold_counts, dim3(1), dim3(64), 0, st, P);
     if (L.seg[3].cnt) {

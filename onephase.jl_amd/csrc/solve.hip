@@ -222,8 +222,8 @@ __global__ __launch_bounds__(256) void k_xinv_gemm(DevPlan P, const int* __restr
 // Producer workgroups have LOWER block indices than their consumers (dispatch order = dependency order, so a waiting
 // consumer never keeps its producer from being scheduled); the protocol is the MI355X guide's: every storing wave drains its
 // stores, the workgroup meets at a barrier, one lane releases at agent scope and then raises the flag / counter; the consumer
-// polls with relaxed agent-scope loads (bounded: a hand-off that never arrives ends the wait instead of hanging the GPU, and
-// the solve is then wrong in a way the residual checks of the callers see), acquires once, and only then reads the data.
+// polls with relaxed agent-scope loads (bounded: a hand-off that never arrives ends the wait instead of hanging the GPU and
+// raises the plan's time-out word, which turns the solution into NaN in k_permute_out_r), acquires once, and only then reads the data.
 // The handed-off bytes are a few hundred doubles per front: they are written and read with agent-scope (sc1) accesses, which
 // bypass the CU's L1 and are served by the memory side -- no release / acquire fences (an agent release writes back the whole L2,
 // an acquire invalidates the whole L1: 2 - 7 us each, per workgroup, measured as a net loss on the fused sweeps).
@@ -250,19 +250,23 @@ __device__ __forceinline__ void front_arrive64(unsigned long long* counter, unsi
     __hip_atomic_fetch_add(counter, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
-__device__ __forceinline__ void front_wait64(const unsigned long long* counter, unsigned long long epoch, int expected) {
+// `tmo` (slot 0, word 5 of the plan's counters): raised when a wait runs into its bound; the last kernel of a solve
+// (k_permute_out_r) then returns NaN instead of a solution that was computed from data that had not arrived
+__device__ __forceinline__ void front_wait64(const unsigned long long* counter, unsigned long long epoch, int expected, unsigned long long* tmo = nullptr) {
   if (threadIdx.x == 0) {
     const unsigned long long want = (epoch << 20) + (unsigned long long)expected;
     int spins = 0;
     while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(2);
+    if (spins >= (1 << 22) && tmo) atomicExch(tmo, 1ull);
   }
   __syncthreads();
 }
 // waits until *flag >= value (monotonic flags); the payload is then read with ld_agent only
-__device__ __forceinline__ void front_wait(const int* flag, int value) {
+__device__ __forceinline__ void front_wait(const int* flag, int value, unsigned long long* tmo = nullptr) {
   if (threadIdx.x == 0) {
     int spins = 0;
     while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < value && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(2);
+    if (spins >= (1 << 22) && tmo) atomicExch(tmo, 1ull);
   }
   __syncthreads();
 }
@@ -273,7 +277,7 @@ __device__ __forceinline__ void front_wait(const int* flag, int value) {
 // FLOW: the tasks of several levels in one launch (see k_front_small<.., FLOW> in numeric.hip): a task waits for the flags of its
 // children tasks, contribution vectors travel with agent-scope accesses, flags[root] = epoch when the task is done.
 template <int TPB, int R, bool FLOW = false>
-__global__ __launch_bounds__(TPB) void k_fs_small(DevPlan P, const int* __restrict__ list, int ldw, int* __restrict__ flags = nullptr, int epoch = 0) {
+__global__ __launch_bounds__(TPB) void k_fs_small(DevPlan P, const int* __restrict__ list, int ldw, int* __restrict__ flags = nullptr, int epoch = 0, int wait_epoch = 0) {
   extern __shared__ __attribute__((aligned(16))) double sm[];      // [R][ldw]
   const int tid = threadIdx.x;
   const int s_root = list[blockIdx.x];
@@ -292,7 +296,7 @@ __global__ __launch_bounds__(TPB) void k_fs_small(DevPlan P, const int* __restri
       const int rc = (int)(P.rel_ptr[ch + 1] - P.rel_ptr[ch]);
       const int* rl = P.rel + P.rel_ptr[ch];
       const double* cvc = P.cv + P.cv_pos[ch];
-      if (FLOW && ch < t_lo) front_wait(flags + ch, epoch);
+      if (FLOW && ch < t_lo) front_wait(flags + ch, wait_epoch, P.counters + 5);
       for (int ii = tid; ii < rc; ii += TPB) {
         const int d = rl[ii];
 #pragma unroll
@@ -347,7 +351,7 @@ __global__ __launch_bounds__(TPB) void k_bs_small(DevPlan P, const int* __restri
   const int s_root = list[FLOW ? gridDim.x - 1 - blockIdx.x : blockIdx.x];
   if (FLOW) {
     const int up = P.unit_parent[s_root];
-    if (up >= 0) front_wait(flags + up, epoch);
+    if (up >= 0) front_wait(flags + up, epoch, P.counters + 5);
   }
   for (int s = s_root; s >= P.task_lo[s_root]; --s) {      // the task's fronts, parents first
     const int col0 = P.sn_col0[s];
@@ -477,7 +481,7 @@ __device__ __forceinline__ void fwd_thin_upd_body(const DevPlan& P, int s, int x
 #pragma unroll
   for (int r = 0; r < R; ++r) wr[r] = 0.0;
   if (tid < 128 && myrow < f) fwd_gather<R>(P, gcb, col0, k, myrow, wr);
-  if (flag) front_wait(flag, epoch);          // y of this front (fused launch): the loads above are already in flight
+  if (flag) front_wait(flag, epoch, P.counters + 5);          // y of this front (fused launch): the loads above are already in flight
   const double* yt = P.ythin + P.ythin_pos[s];
   if (tid < 128)
 #pragma unroll
@@ -625,7 +629,7 @@ __device__ __forceinline__ void fwd_upd_body(const DevPlan& P, int s, int b, int
   const int rbeg = c0 + kb;                       // first row below the block
   const int rb = rbeg + bx * kUpdRows;
   if (bx > 0 && rb >= f) return;
-  if (counter) front_wait64(counter, epoch, ((kb + 63) / 64) * kCS);
+  if (counter) front_wait64(counter, epoch, ((kb + 63) / 64) * kCS, P.counters + 5);
   const double* yp = P.ypart + P.ypart_pos[s];
   for (int p = tid; p < kSB; p += 256) {
     const int pc = min(p, kb - 1);
@@ -785,7 +789,7 @@ __device__ __forceinline__ void bwd_thin_body(const DevPlan& P, int s, int NB, i
   if (counter) {
     const int f = (int)(P.row_ptr[s + 1] - P.row_ptr[s]);
     const int expected = f > k ? (k + 3) / 4 : 0;
-    front_wait(counter, expected);
+    front_wait(counter, expected, P.counters + 5);
     if (tid == 0) __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // everybody has arrived: ready for the next solve
   }
   if (tid < 128)
@@ -895,7 +899,7 @@ __device__ __forceinline__ void bwd_upd_body(const DevPlan& P, int s, int b, int
   if (kb <= 0) return;
   const int nupd = (c0 + 63) / 64;                // workgroups that update columns; the next one copies x_b
   if (bx > nupd) return;
-  if (counter) front_wait64(counter, epoch, ((kb + 63) / 64) * kCS);
+  if (counter) front_wait64(counter, epoch, ((kb + 63) / 64) * kCS, P.counters + 5);
   const double* xp = P.ypart + P.ypart_pos[s];
   for (int p = tid; p < kSB; p += 256) {
     const int pc = min(p, kb - 1);
@@ -981,13 +985,20 @@ __global__ void k_permute_in_r(int n, int nr, int64_t stride_in, const int* __re
   for (int q = 0; q < R; ++q) x[(size_t)q * xs + i] = q < nr ? rhs[(size_t)q * stride_in + g] : 0.0;
 }
 template <int R>
-__global__ void k_permute_out_r(int n, int nr, int64_t stride_out, const int* __restrict__ perm, const double* __restrict__ x, int64_t xs, double* __restrict__ sol, int accumulate) {
+__global__ void k_permute_out_r(int n, int nr, int64_t stride_out, const int* __restrict__ perm, const double* __restrict__ x, int64_t xs, double* __restrict__ sol, int accumulate,
+                                const unsigned long long* __restrict__ tmo) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int g = perm[i];
+  // an in-launch hand-off of this solve (or of the factorisation behind it) ran into its bound: no solution rather than a wrong one
+  const bool lost = __hip_atomic_load(tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
 #pragma unroll
   for (int q = 0; q < R; ++q)
-    if (q < nr) { double* d = sol + (size_t)q * stride_out + g; *d = accumulate ? *d + x[(size_t)q * xs + i] : x[(size_t)q * xs + i]; }
+    if (q < nr) {
+      double* d = sol + (size_t)q * stride_out + g;
+      const double v = lost ? __builtin_nan("") : x[(size_t)q * xs + i];
+      *d = accumulate ? *d + v : v;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1128,8 +1139,10 @@ static std::string fwd_enqueue_r(Numeric& N, const std::vector<LevelSchedule>& l
       const size_t lds = (size_t)R * N.flow_maxf * sizeof(double);
       int* flags = N.flow_flags + (size_t)N.d.nsuper;
       const int ep = ++N.flow_epoch;
-      if (N.flow_maxf <= 32) hipLaunchKernelGGL((k_fs_small<64, R, true>), dim3(N.flow_cnt), dim3(64), lds, st, P, P.sched + N.flow_off, N.flow_maxf, flags, ep);
-      else hipLaunchKernelGGL((k_fs_small<256, R, true>), dim3(N.flow_cnt), dim3(256), lds, st, P, P.sched + N.flow_off, N.flow_maxf, flags, ep);
+      static const int drop = getenv("OKKT_DEBUG_DROP_HANDOFF") ? atoi(getenv("OKKT_DEBUG_DROP_HANDOFF")) : 0;   // tests: bit 1 = the forward sweep's waits never end
+      const int wep = ep + ((drop & 2) ? (1 << 20) : 0);
+      if (N.flow_maxf <= 32) hipLaunchKernelGGL((k_fs_small<64, R, true>), dim3(N.flow_cnt), dim3(64), lds, st, P, P.sched + N.flow_off, N.flow_maxf, flags, ep, wep);
+      else hipLaunchKernelGGL((k_fs_small<256, R, true>), dim3(N.flow_cnt), dim3(256), lds, st, P, P.sched + N.flow_off, N.flow_maxf, flags, ep, wep);
       l = (size_t)N.flow_levels - 1;
       continue;
     }
@@ -1137,8 +1150,8 @@ static std::string fwd_enqueue_r(Numeric& N, const std::vector<LevelSchedule>& l
       const Segment& g = L.seg[c];
       if (!g.cnt) continue;
       const size_t lds = (size_t)R * g.maxf * sizeof(double);
-      if (c == 0) hipLaunchKernelGGL((k_fs_small<64, R>), dim3(g.cnt), dim3(64), lds, st, P, P.sched + g.off, g.maxf, (int*)nullptr, 0);
-      else hipLaunchKernelGGL((k_fs_small<256, R>), dim3(g.cnt), dim3(256), lds, st, P, P.sched + g.off, g.maxf, (int*)nullptr, 0);
+      if (c == 0) hipLaunchKernelGGL((k_fs_small<64, R>), dim3(g.cnt), dim3(64), lds, st, P, P.sched + g.off, g.maxf, (int*)nullptr, 0, 0);
+      else hipLaunchKernelGGL((k_fs_small<256, R>), dim3(g.cnt), dim3(256), lds, st, P, P.sched + g.off, g.maxf, (int*)nullptr, 0, 0);
     }
     const SolveLevel& S = sl[l];
     // the thin and the wide fronts of a level are independent: with both present the wide chain runs on the auxiliary stream
@@ -1306,9 +1319,9 @@ void solve_permute_out(const Numeric& N, double* d_sol, int64_t stride, int nr, 
   if (!n) return;
   const dim3 g((n + 255) / 256), b(256);
   const int acc = accumulate ? 1 : 0;
-  if (R == 1) hipLaunchKernelGGL(k_permute_out_r<1>, g, b, 0, N.stream, n, nr, stride, N.d.perm, N.d.xwork, N.d.xw_stride, d_sol, acc);
-  else if (R == 2) hipLaunchKernelGGL(k_permute_out_r<2>, g, b, 0, N.stream, n, nr, stride, N.d.perm, N.d.xwork, N.d.xw_stride, d_sol, acc);
-  else hipLaunchKernelGGL(k_permute_out_r<4>, g, b, 0, N.stream, n, nr, stride, N.d.perm, N.d.xwork, N.d.xw_stride, d_sol, acc);
+  if (R == 1) hipLaunchKernelGGL(k_permute_out_r<1>, g, b, 0, N.stream, n, nr, stride, N.d.perm, N.d.xwork, N.d.xw_stride, d_sol, acc, N.d.counters + 5);
+  else if (R == 2) hipLaunchKernelGGL(k_permute_out_r<2>, g, b, 0, N.stream, n, nr, stride, N.d.perm, N.d.xwork, N.d.xw_stride, d_sol, acc, N.d.counters + 5);
+  else hipLaunchKernelGGL(k_permute_out_r<4>, g, b, 0, N.stream, n, nr, stride, N.d.perm, N.d.xwork, N.d.xw_stride, d_sol, acc, N.d.counters + 5);
 }
 
 }  // namespace okkt

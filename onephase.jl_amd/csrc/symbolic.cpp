@@ -597,7 +597,7 @@ std::string analyze_pattern(int64_t n64, const int64_t* colptr, const int64_t* r
     if (!e.empty() || opts.ordering != 0) return e;
   }
   std::string e;
-  const bool path_like = S.n >= 1024 && S.max_front <= 256 && S.critical_pivots * 5 >= S.n;
+  const bool path_like = S.n >= 128 && S.max_front <= 256 && S.critical_pivots * 5 >= S.n;
   if (!path_like) return e;
   SymbolicOptions o2 = opts;
   o2.ordering = 4;

@@ -48,3 +48,35 @@ def test_schedule_variant(env):
     e.update(env)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "env_variant_case.py")], cwd=ROOT, env=e, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "VARIANT_OK" in r.stdout, (env, r.stdout[-400:], r.stderr[-1200:])
+
+
+@pytest.mark.parametrize("drop,what", [("1", "factor"), ("2", "solve")])
+def test_a_lost_hand_off_is_loud(drop, what):
+    """The in-launch waits are bounded (a GPU never hangs on them).  When one runs into its bound -- forced here by letting the
+    consumers wait for an epoch nobody raises -- the factorisation fails with an error (the lost hand-offs are counted apart, so
+    the pivot counts no longer add up to the matrix order), and a solve returns NaN instead of numbers computed from data that
+    had not arrived."""
+    code = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, '.')\n"
+        "from onephase_jl_amd import synth\n"
+        "from onephase_jl_amd.linear_system_solvers import OkktError, finalize_b, initialize_b, linear_solver_HIP\n"
+        "prob = synth.hanging_chain(N_h=300, seed=2)\n"
+        "K = synth.augmented_matrix(prob, delta=0.5)\n"
+        "h = linear_solver_HIP('symmetric'); initialize_b(h)\n"
+        "try:\n"
+        "    rc = h.ls_factor_b(K, prob['n'], prob['m'])\n"
+        "except OkktError as e:\n"
+        "    print('FACTOR_ERROR', e); sys.exit(0)\n"
+        "x = h.ls_solve(np.ones(K.shape[0]))\n"
+        "print('RC', rc, 'NAN', int(np.isnan(x).all()))\n"
+        "finalize_b(h)\n")
+    e = dict(os.environ)
+    e["OKKT_DEBUG_DROP_HANDOFF"] = drop
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=e, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-1200:]
+    if what == "factor":
+        assert "FACTOR_ERROR" in r.stdout and "pivot counts" in r.stdout, r.stdout[-400:]
+    else:
+        line = [l for l in r.stdout.splitlines() if l.startswith("RC")][-1].split()
+        assert int(line[1]) == 1 and int(line[3]) == 1, r.stdout[-400:]

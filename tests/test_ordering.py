@@ -132,3 +132,18 @@ def test_metric_like_pattern_at_reduced_size_prefers_the_dissection(monkeypatch)
     assert st_auto["flops_exact"] <= st_amd["flops_exact"]
     if st_auto["ordering_used"] == 5:
         assert st_auto["flops_exact"] < 0.9 * st_amd["flops_exact"]
+
+
+@pytest.mark.parametrize("N_h", [60, 150, 300, 400, 1000])
+def test_banded_systems_of_every_size_get_the_parallel_ordering(N_h):
+    # the hanging chain (BASELINE config 2 stand-in) has one constraint over all nodes; the level-structure dissection has to take
+    # that row out of the graph at every size (it used to pass at the CUTEst size N_h = 400 by one entry and fail below it:
+    # 10 sqrt(n) is most of a small graph), otherwise minimum degree's path of fronts is kept -- 12 times slower on the GPU
+    prob = synth.hanging_chain(N_h=N_h, seed=2)
+    K = synth.augmented_matrix(prob, delta=0.5)
+    st, p = analyse(K, 0)
+    assert sorted(p) == list(range(K.shape[0]))
+    assert st["ordering_used"] == 4
+    sa, _ = analyse(K, 3)
+    assert st["nlevels"] <= 16 and st["max_front"] <= 16          # a balanced tree of small separators ...
+    assert st["flops_stored"] <= sa["flops_stored"]                # ... and not more arithmetic than the minimum-degree path
