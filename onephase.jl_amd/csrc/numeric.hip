@@ -2007,7 +2007,7 @@ static std::string factor_sched(Numeric& N, DevPlan P, const std::vector<LevelSc
         else if (head == 3) ntile = Tr * (Tr + 1) / 2;
         if (ntile == 0) return "";
         // few tiles: 128 x 64 tiles (see k_big_syrk); decided on the largest front of the launch
-        static const int small_max = getenv("OKKT_SYRK_SMALL_TILES") ? atoi(getenv("OKKT_SYRK_SMALL_TILES")) : 4000;
+        static const int small_max = getenv("OKKT_SYRK_SMALL_TILES") ? atoi(getenv("OKKT_SYRK_SMALL_TILES")) : 1500;
         const int sub0 = head == 0 ? (sub == 11 ? 1 : (sub == 12 ? 2 : 0)) : 0;     // decoupled schedule: the next diagonal tile / the rest
         const bool narrow = (head == 0 || head == 3) && dbg_syrk == 0 && sub0 != 1 && (int64_t)ntile * g.cnt <= small_max;
         if (narrow) ntile = head == 0 ? T * (T + 1) : Tr * (Tr + 1);
