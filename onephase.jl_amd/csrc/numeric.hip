@@ -1757,7 +1757,7 @@ std::string numeric_setup(const Symbolic& S, const SymbolicOptions& opts, hipStr
   OKKT_HIP_TRY(hipFuncSetAttribute((const void*)k_big_trsm<4>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds));
   for (const void* fn : {(const void*)k_big_syrk<0, kSyrkTrail>, (const void*)k_big_syrk<0, kSyrkTrail, 64>, (const void*)k_big_syrk<0, kSyrkPanel>, (const void*)k_big_syrk<0, kSyrkAhead>,
                          (const void*)k_big_syrk<1, kSyrkTrail>, (const void*)k_big_syrk<2, kSyrkTrail>, (const void*)k_big_syrk<5, kSyrkTrail>,
-                         (const void*)k_big_syrk<13, kSyrkTrail>, (const void*)k_big_syrk<16, kSyrkTrail>, (const void*)k_big_syrk<48, kSyrkTrail>})
+                         (const void*)k_big_syrk<13, kSyrkTrail>, (const void*)k_big_syrk<16, kSyrkTrail>, (const void*)k_big_syrk<16, kSyrkTrail, 64>, (const void*)k_big_syrk<48, kSyrkTrail>})
     OKKT_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)syrk_lds_bytes(kSyrkStages)));
   return "";
 }
@@ -2049,6 +2049,7 @@ static std::string factor_sched(Numeric& N, DevPlan P, const std::vector<LevelSc
         const int csplit = head == 1 ? sub : (head == 0 ? 0 : cs);
         if (head == 1) OKKT_SYRK(0, kSyrkPanel);
         else if (head == 2) OKKT_SYRK(0, kSyrkAhead);
+        else if (narrow && dbg_syrk == 96) hipLaunchKernelGGL((k_big_syrk<16, kSyrkTrail, 64>), grid, dim3(kSyrkNW * 64), syrk_lds_bytes(kSyrkStages), sst, P, list, stepA, npan, tstep, NB, wofs, csplit, sub0);
         else if (narrow) hipLaunchKernelGGL((k_big_syrk<0, kSyrkTrail, 64>), grid, dim3(kSyrkNW * 64), syrk_lds_bytes(kSyrkStages), sst, P, list, stepA, npan, tstep, NB, wofs, csplit, sub0);
         else switch (dbg_syrk) {   // timing-only ablations of the trailing update (OKKT_DEBUG_SYRK): wrong outputs
           case 81: OKKT_SYRK(1, kSyrkTrail); break;    // no C load
