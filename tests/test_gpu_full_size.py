@@ -106,3 +106,32 @@ def test_block_angular_sharded_against_the_oracle(nparts):
             xo = o.ls_solve(b)
             assert np.max(np.abs(x - xo)) <= 1e-10 * np.max(np.abs(xo))
     sh.finalize()
+
+
+def test_sc3_forward_error_against_the_extended_precision_solution():
+    """Both solutions against the TRUE solution of the fp64 matrix (the oracle's solve refined with long-double residuals until the
+    correction is at rounding level) instead of against each other: the HIP path may not be less accurate than the CPU restatement by
+    more than a small factor.  This is what caught an amalgamation setting that was 12 % faster on S-C5 and wrong by 3.5e-8 instead of
+    2e-9 (fronts of 256-512 pivot columns take the solves through the explicit inverses of the 2048-column blocks)."""
+    prob = synth.make_config("S-C3", seed=0)
+    n, m = prob["n"], prob["m"]
+    K = synth.augmented_matrix(prob, delta=1e-8)
+    M = synth.symmetrize_lower(K).tocsr()
+    h = hip_solver("symmetric")
+    assert h.ls_factor_b(K, n, m) == 1
+    o = oracle.linear_solver_ORACLE_MF("symmetric", perm=h.perm(), nthreads=8)
+    o._analyze(K)
+    assert o.ls_factor_b(K, n, m) == 1
+    rng = np.random.default_rng(3)
+    for b in rng.normal(size=(2, n + m)):
+        xo = o.ls_solve(b)
+        xt = xo.copy()
+        for _ in range(4):
+            prod = M.data.astype(np.longdouble) * xt.astype(np.longdouble)[M.indices]
+            r = (b.astype(np.longdouble) - np.add.reduceat(prod, M.indptr[:-1])).astype(np.float64)
+            xt = xt + o.ls_solve(r)
+        xh = h.ls_solve(b)
+        sc = np.max(np.abs(xt))
+        e_o, e_h = np.max(np.abs(xo - xt)) / sc, np.max(np.abs(xh - xt)) / sc
+        assert e_h <= TOL_X and e_h <= 8.0 * e_o + 1e-12, (e_h, e_o)
+    finalize_b(h)
