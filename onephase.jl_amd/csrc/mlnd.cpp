@@ -4,8 +4,8 @@
 // Why (round 3): the reference takes CHOLMOD's default AMD ordering on every ls_factor! (julia.jl:34,52).  On the metric
 // workload (n + m = 1e5: a banded coupling pattern plus 1 % long-range entries) AMD ends in one dense front of 16 641 rows
 // that alone holds 81 % of 1.8e12 factor flops.  The pivot order of a static-pivot LDL^T is free, and a dissection of the same
-// graph needs a third of the arithmetic: top separator ~7 600 vertices, the fronts below it shrink geometrically
-// (5.7e11 flops, nnz(L) 1.87e8 -> 1.12e8).  The factorisation is bound by FP64 MFMA throughput, so the ordering is worth more
+// graph needs a third of the arithmetic: top separator 8 586 vertices, the fronts below it shrink geometrically
+// (5.33e11 flops, nnz(L) 1.87e8 -> 1.07e8).  The factorisation is bound by FP64 MFMA throughput, so the ordering is worth more
 // than any kernel change.
 //
 // Algorithm (the multilevel scheme of Karypis & Kumar / Hendrickson & Leland, written for this project):

@@ -65,19 +65,21 @@ summary = {"round": rnd, "command": "python3 scripts/solve_profile.py S-metric 3
 for sub, label, wide in KERNELS:
     rec = {"kernel": label, "fetch_doubled": wide}
     for pname, (agg, nd) in passes.items():
+        n_pass = 0          # a kernel family may have several instantiations (k_big_syrk<0, 0, 64> and <0, 0, 128>): all of them count
         for k, ctr in agg.items():
             if sub in k:
-                n = max(len(nd[k]), 1)
-                rec.setdefault("dispatches", n)
+                n_pass += len(nd[k])
                 for c, v in ctr.items():
                     rec[c] = rec.get(c, 0.0) + v
+        if n_pass:
+            rec["dispatches"] = max(rec.get("dispatches", 0), n_pass)
     if "dispatches" not in rec:
         continue
     n = rec["dispatches"]
     for table in (dur_bench if "syrk" in sub or "trsm" in sub or "diag" in sub or "assemble" in sub else dur, dur, dur_bench):
         hit = [v for k, v in table.items() if sub in k]
         if hit:
-            rec["avg_duration_us_unprofiled"] = hit[0][1] / 1e3
+            rec["avg_duration_us_unprofiled"] = sum(c * a for c, a in hit) / max(sum(c for c, a in hit), 1) / 1e3
             break
     if "SQ_VALU_MFMA_BUSY_CYCLES" in rec and rec.get("GRBM_GUI_ACTIVE", 0) > 0:
         rec["mfma_util_pct"] = 100.0 * rec["SQ_VALU_MFMA_BUSY_CYCLES"] / (rec["GRBM_GUI_ACTIVE"] / 8.0 * CUS * 4)
