@@ -81,9 +81,15 @@ struct DevPlan {
 
 constexpr int kCountSlots = 64, kCountStride = 16;
 #ifndef OKKT_SOLVE_BLOCK
-#define OKKT_SOLVE_BLOCK 2048
+#define OKKT_SOLVE_BLOCK 1024
 #endif
-constexpr int kSolveBlock = OKKT_SOLVE_BLOCK;   // columns of an explicitly inverted diagonal block (solve.hip)
+// columns of an explicitly inverted diagonal block (solve.hip).  Round 2 (AMD tree, root of 16 641 columns): 2048 was the fastest
+// (512 / 1024 / 2048: 2.9 / 2.4 / 2.1 ms per S-metric solve).  Round 3 (dissected tree, root of 8 586): 1024 costs the S-metric solve
+// nothing (1.68 against 1.60-1.72 ms), saves a doubling level of the inversion (factor 22.1 -> 21.5 ms) and a quarter of the S-C3
+// solve (0.87 -> 0.63 ms); the forward error is the same (scripts/forward_error.py).  512 is NOT supported by the block-product
+// kernels any more (wrong results, found in round 3): the assertion keeps the knob honest.
+constexpr int kSolveBlock = OKKT_SOLVE_BLOCK;
+static_assert(kSolveBlock == 1024 || kSolveBlock == 2048, "solve.hip is validated for 1024- and 2048-column inverse blocks only");
 constexpr int kMaxRhs = 4;                      // right-hand sides carried through one pass over L
 // sums the slots: out[0..3] = pos, neg, zero, nonfinite, out[4] = stop flag (synchronises `stream`)
 std::string numeric_read_counts(struct Numeric& N, hipStream_t stream, unsigned long long out[5]);
