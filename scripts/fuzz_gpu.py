@@ -63,9 +63,31 @@ for case in range(cases):
     opts = {"ordering": ordering}
     if rng.random() < 0.3: opts.update(relax_small=int(rng.choice([64, 128, 512, 1024])), relax_small_frac=float(rng.choice([0.1, 0.3, 0.6])))
     tag = f"case {case} {fam} n={n} m={m} {opts}"
+    # how the matrix is handed over: scipy CSC, or a raw CSC through the C ABI's contract -- entries split into duplicates that have
+    # to be summed, an upper triangle full of garbage that has to be ignored (julia.jl:34: Symmetric(A, :L)), 1-based indices
+    form = ["scipy", "scipy", "duplicates", "upper_garbage", "one_based"][int(rng.integers(0, 5))]
+    Karg = K
+    if form != "scipy" and N > 0:
+        Kc = sp.csc_matrix(sp.tril(K)); Kc.sort_indices()
+        cols = np.repeat(np.arange(N), np.diff(Kc.indptr)); rows = Kc.indices.copy(); vals = Kc.data.copy()
+        if form == "duplicates":
+            pick = rng.random(len(vals)) < 0.3
+            frac = rng.uniform(0.2, 0.8, size=int(pick.sum()))
+            rows = np.concatenate([rows, rows[pick]]); cols = np.concatenate([cols, cols[pick]])
+            extra = vals[pick] * frac; vals[pick] -= extra; vals = np.concatenate([vals, extra])
+        elif form == "upper_garbage":
+            ng = max(1, len(vals) // 3)
+            gr = rng.integers(0, N, size=ng); gc = rng.integers(0, N, size=ng); keep = gr < gc
+            rows = np.concatenate([rows, gr[keep]]); cols = np.concatenate([cols, gc[keep]]); vals = np.concatenate([vals, 1e3 * rng.normal(size=int(keep.sum()))])
+        order = np.lexsort((rng.random(len(rows)) if form == "duplicates" else rows, cols))
+        rows, cols, vals = rows[order], cols[order], vals[order]
+        colptr = np.zeros(N + 1, dtype=np.int64); np.add.at(colptr, cols + 1, 1); colptr = np.cumsum(colptr)
+        base = 1 if form == "one_based" else 0
+        Karg = (N, colptr + base, rows.astype(np.int64) + base, vals, base)
+    tag += f" {form}"
     try:
         h = linear_solver_HIP("symmetric", **opts); initialize_b(h)
-        rc = h.ls_factor_b(K, n, m)
+        rc = h.ls_factor_b(Karg, n, m)
         want = (int((w > 0).sum()), int((w < 0).sum()), 0, 0)
         ok = h.inertia == want and rc == (1 if want[:2] == (n, m) else 0)
         B = rng.normal(size=(3, N))
