@@ -160,7 +160,7 @@ struct Numeric {
   hipStream_t stream_aux = nullptr;     // off-critical-path part of the in-group panel updates
   int split_head = 1;
   int ahead_first = 0;                   // OKKT_AHEAD_FIRST=1: look-ahead columns on the trailing update's stream ahead of it instead of beside it on the panel stream (measured slower: 23.1 -> 23.7 ms, the delayed trailing update costs more than the chain gains)
-  int fuse_diag_trsm = 0;                // OKKT_FUSE_DIAG_TRSM=1: k_diag_trsm_fused, the diagonal block and the rows below it in one launch (measured: the waiting trsm workgroups hold CUs the trailing update wants; S-metric 23.7 -> 24.1 ms, S-C3 3.96 -> 3.87 ms)
+  int fuse_diag_trsm = 3;                // k_diag_trsm_fused, the diagonal block and the rows below it in one launch.  OKKT_FUSE_DIAG_TRSM: 0 never; 1 always (S-metric 23.7 -> 24.1 ms: the waiting trsm workgroups hold CUs the trailing update wants); 2 wherever the panels run in order (S-C5 +5 %: with many fronts per level they hold the CUs of the other fronts' diagonal blocks); 3 (default) in order AND at most OKKT_FUSE_MAX_FRONTS (8) fronts in the level: S-C3 3.53 -> 3.47 ms, S-C5 4.70 -> 4.67, S-metric unchanged
   int* chain_flags = nullptr;            // [nsuper] monotonic flags of those launches
   int chain_epoch = 0;
   // several levels of small-front tasks in ONE launch (in-launch hand-offs between a task and its children tasks): the leading

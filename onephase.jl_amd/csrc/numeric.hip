@@ -1899,6 +1899,7 @@ static std::string factor_sched(Numeric& N, DevPlan P, const std::vector<LevelSc
   static const int dbg_syrk = getenv("OKKT_DEBUG_SYRK") ? atoi(getenv("OKKT_DEBUG_SYRK")) : 0;
   static const int split_min_rows = getenv("OKKT_SPLIT_MIN_ROWS") ? atoi(getenv("OKKT_SPLIT_MIN_ROWS")) : 5000;
   static const int dbg_stop = getenv("OKKT_DEBUG_DIAG_STOP") ? atoi(getenv("OKKT_DEBUG_DIAG_STOP")) : 0;
+  static const int fuse_max_fronts = getenv("OKKT_FUSE_MAX_FRONTS") ? atoi(getenv("OKKT_FUSE_MAX_FRONTS")) : 8;
   for (size_t l = l_begin; l < std::min(l_end, levels.size()); ++l) {
     const LevelSchedule& L = levels[l];
     if (N.early_check && in_loop_check && (int)l == N.early_level) {
@@ -2112,7 +2113,7 @@ static std::string factor_sched(Numeric& N, DevPlan P, const std::vector<LevelSc
             // the two (the rest of a split in-group update is joined before the trsm)
             const int rem_f = g.maxf - step * NB;
             const int ntr = rem_f > 0 ? (rem_f + 63) / 64 : 0;
-            if (N.diag2 && (N.fuse_diag_trsm == 1 || (N.fuse_diag_trsm == 2 && pst == st)) && N.chain_flags && dbg_stop == 0 && NB == 128 && ev_rest == nullptr && ntr > 0) {
+            if (N.diag2 && (N.fuse_diag_trsm == 1 || (N.fuse_diag_trsm == 2 && pst == st) || (N.fuse_diag_trsm == 3 && pst == st && g.cnt <= fuse_max_fronts)) && N.chain_flags && dbg_stop == 0 && NB == 128 && ev_rest == nullptr && ntr > 0) {
               const int wc = (par * GS + i) * NB;
               hipLaunchKernelGGL(k_diag_trsm_fused, dim3(1 + ntr, g.cnt), dim3(384), std::max(lds_diag2, lds_trsm_max), pst, P, list, step, NB, tol, wc,
                                  N.chain_flags, ++N.chain_epoch);

@@ -32,7 +32,9 @@ VARIANTS = [
     {"OKKT_LANES": "3", "OKKT_LANE_MIN_FRAC": "0.01", "OKKT_LANE_OWN_FRAC": "0.5"},
     {"OKKT_DECOUPLE": "1", "OKKT_GROUP": "1"},                    # diagonal chain one step ahead of the wide kernels, on every step
     {"OKKT_DECOUPLE": "1", "OKKT_DECOUPLE_MIN_ROWS": "0"},
-    {"OKKT_FUSE_DIAG_TRSM": "1"},                                 # diagonal block and the rows below it in one launch
+    {"OKKT_FUSE_DIAG_TRSM": "0"},                                 # diagonal block and the rows below it always in two launches
+    {"OKKT_FUSE_DIAG_TRSM": "1"},                                 # ... in one launch everywhere (default: only in-order panels of levels with few fronts)
+    {"OKKT_FUSE_DIAG_TRSM": "2"},
     {"OKKT_FUSE_DIAG_TRSM": "1", "OKKT_LA_MIN_TILES": "1", "OKKT_SPLIT_MIN_ROWS": "0"},
     {"OKKT_SOLVE_FUSE": "0"},                                     # the sweeps with two launches per level of thin fronts
     {"OKKT_SOLVE_FUSE_WIDE_MAX": "100000000"},                    # the wide fronts fused as well
