@@ -44,6 +44,7 @@ int solver_ensure_numeric(okkt_solver_s* h) {
   if (const char* d2 = getenv("OKKT_DIAG2")) h->N.diag2 = atoi(d2);
   if (const char* fd = getenv("OKKT_FUSE_DIAG_TRSM")) h->N.fuse_diag_trsm = atoi(fd);
   if (const char* sf = getenv("OKKT_SOLVE_FORK")) h->N.solve_fork = atoi(sf);
+  if (const char* ss = getenv("OKKT_SOLVE_SPLIT_SMALL")) h->N.solve_split_small = atoi(ss);
   if (const char* su = getenv("OKKT_SOLVE_FUSE")) h->N.solve_fuse = atoi(su);
   if (const char* sw = getenv("OKKT_SOLVE_FUSE_WIDE_MAX")) h->N.solve_fuse_wide_max = atoi(sw);
   if (const char* dr = getenv("OKKT_DECOUPLE_MIN_ROWS")) h->N.decouple_min_rows = atoi(dr);

@@ -124,6 +124,7 @@ struct Numeric {
   int solve_epoch = 0;
   unsigned long long* solve_counters64 = nullptr;   // [nsuper] epoch-based arrival counters of the fused wide-front launches
   unsigned long long solve_epoch64 = 0;
+  int solve_split_small = 400;           // panel GEMVs of the wide fronts: launches of fewer 64-row / 64-column workgroups than this use 32 rows / 16 columns per workgroup (OKKT_SOLVE_SPLIT_SMALL; 0 = never)
   int solve_fork = 0;                    // OKKT_SOLVE_FORK=1: the wide fronts of a level on the auxiliary stream beside the thin ones
   std::vector<hipEvent_t> lane_events;   // fork / join of the lanes
   size_t lane_ev_used = 0;

@@ -37,6 +37,7 @@ constexpr int kSB = kSolveBlock;        // columns of an explicitly inverted dia
 #define OKKT_SOLVE_SPLITS 8
 #endif
 constexpr int kCS = OKKT_SOLVE_SPLITS;  // splits of a block product (partial vectors summed by the consumer in a fixed order)
+static_assert(kSB / kCS >= 128 && (kCS & (kCS - 1)) == 0, "the block-product kernels need column splits of at least 128 columns (64 gave wrong results: found in round 3)");
 // sum of the kCS partial values p[0], p[kSB], ... (pairwise, fixed order)
 __device__ __forceinline__ double sum_splits(const double* p) {
   double t[kCS];
@@ -615,11 +616,14 @@ __global__ __launch_bounds__(256) void k_fwd_y(DevPlan P, const int* __restrict_
 // partial sums meet in LDS.  Block 0 assembles the rows it touches on the fly.
 constexpr int kUpdRows = 64;
 // counter != NULL: a workgroup of the fused launch -- it waits for the partial products of its front before it sums them
-template <int R>
+// ROWS = rows per workgroup: 64 (two per lane, eight groups of 32 lanes share the columns) or 32 (sixteen groups of 16 lanes) for
+// launches that would otherwise leave most CUs idle (the later blocks of a front: rows / 64 workgroups)
+template <int R, int ROWS = kUpdRows>
 __device__ __forceinline__ void fwd_upd_body(const DevPlan& P, int s, int b, int bx, double* sm, const unsigned long long* counter, unsigned long long epoch) {
-  double* yj = sm;                                 // y[R][kSB], then part[8][R][64]
+  constexpr int GW = ROWS / 2, NG = 256 / GW;      // lanes per group, groups
+  double* yj = sm;                                 // y[R][kSB], then part[NG][R][ROWS]
   double* part = sm + (size_t)R * kSB;
-  const int tid = threadIdx.x, l32 = tid & 31, hw = tid >> 5;
+  const int tid = threadIdx.x, l32 = tid % GW, hw = tid / GW;
   const int col0 = P.sn_col0[s];
   const int k = P.sn_col0[s + 1] - col0;
   const int f = (int)(P.row_ptr[s + 1] - P.row_ptr[s]);
@@ -627,7 +631,7 @@ __device__ __forceinline__ void fwd_upd_body(const DevPlan& P, int s, int b, int
   xblock(k, b, c0, kb, ld, off);
   if (kb <= 0) return;
   const int rbeg = c0 + kb;                       // first row below the block
-  const int rb = rbeg + bx * kUpdRows;
+  const int rb = rbeg + bx * ROWS;
   if (bx > 0 && rb >= f) return;
   if (counter) front_wait64(counter, epoch, ((kb + 63) / 64) * kCS, P.counters + 5);
   const double* yp = P.ypart + P.ypart_pos[s];
@@ -650,17 +654,17 @@ __device__ __forceinline__ void fwd_upd_body(const DevPlan& P, int s, int b, int
   double a0[R], a1[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) { a0[r] = 0.0; a1[r] = 0.0; }
-  for (int p0 = hw; p0 < kb; p0 += 128) {          // columns p0, p0 + 8, ..., p0 + 120
+  for (int p0 = hw; p0 < kb; p0 += 16 * NG) {          // columns p0, p0 + NG, ..., p0 + 15 NG
     d2_t v[16];
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
-      const int p = min(p0 + 8 * u, kb - 1);
+      const int p = min(p0 + NG * u, kb - 1);
       if (pair_ok) __builtin_memcpy(&v[u], Lp + (size_t)p * f, 16);
       else { v[u][0] = Lp[(size_t)p * f]; v[u][1] = 0.0; }
     }
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
-      const int p = p0 + 8 * u;
+      const int p = p0 + NG * u;
       if (p < kb) {
 #pragma unroll
         for (int r = 0; r < R; ++r) { const double y = yj[r * kSB + p]; a0[r] += v[u][0] * y; a1[r] += v[u][1] * y; }
@@ -669,11 +673,11 @@ __device__ __forceinline__ void fwd_upd_body(const DevPlan& P, int s, int b, int
   }
 #pragma unroll
   for (int r = 0; r < R; ++r) {
-    part[((size_t)hw * R + r) * kUpdRows + 2 * l32] = a0[r];
-    part[((size_t)hw * R + r) * kUpdRows + 2 * l32 + 1] = a1[r];
+    part[((size_t)hw * R + r) * ROWS + 2 * l32] = a0[r];
+    part[((size_t)hw * R + r) * ROWS + 2 * l32 + 1] = a1[r];
   }
   __syncthreads();
-  if (tid < kUpdRows) {
+  if (tid < ROWS) {
     const int ln = tid >> 1, e = tid & 1;         // value e of lane ln's pair
     const int r0l = rb + 2 * ln;
     const int prl = pair_ok ? max(min(r0l, f - 2), 0) : 0;
@@ -693,17 +697,17 @@ __device__ __forceinline__ void fwd_upd_body(const DevPlan& P, int s, int b, int
       for (int r = 0; r < R; ++r) {
         double sum = 0.0;
 #pragma unroll
-        for (int h = 0; h < 8; ++h) sum += part[((size_t)h * R + r) * kUpdRows + tid];
+        for (int h = 0; h < NG; ++h) sum += part[((size_t)h * R + r) * ROWS + tid];
         *fwd_slot<R>(P, s, col0, k, rowv, r) = w[r] - sum;
       }
     }
   }
 }
 
-template <int R>
+template <int R, int ROWS = kUpdRows>
 __global__ __launch_bounds__(256) void k_fwd_upd(DevPlan P, const int* __restrict__ list, int b) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
-  fwd_upd_body<R>(P, list[blockIdx.y], b, (int)blockIdx.x, sm, nullptr, 0ull);
+  fwd_upd_body<R, ROWS>(P, list[blockIdx.y], b, (int)blockIdx.x, sm, nullptr, 0ull);
 }
 // one launch per block column b of the wide fronts of a level: workgroups [0, ny * kCS) are the partial block products (row tile
 // x % ny, column split x / ny), the others the panel rows below the block, waiting for their front's partials
@@ -888,7 +892,8 @@ __global__ __launch_bounds__(256) void k_bwd_x(DevPlan P, const int* __restrict_
 
 // wide fronts, block b: x_b = sum of the partials; columns c < c0: z[c] -= sum_p L[c0 + p][c] x_b[p] (wave: 16 columns, four
 // at a time, lanes along the rows of the block); the workgroup behind the last column group stores x_b itself
-template <int R>
+// COLS = columns per workgroup: 64 (a wave takes 16) or 16 (a wave takes 4) for launches of few workgroups (the early blocks of a front)
+template <int R, int COLS = 64>
 __device__ __forceinline__ void bwd_upd_body(const DevPlan& P, int s, int b, int bx, double* sm, const unsigned long long* counter, unsigned long long epoch) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;       // sm: x[R][kSB]
   const int col0 = P.sn_col0[s];
@@ -897,7 +902,7 @@ __device__ __forceinline__ void bwd_upd_body(const DevPlan& P, int s, int b, int
   int c0, kb, ld; int64_t off;
   xblock(k, b, c0, kb, ld, off);
   if (kb <= 0) return;
-  const int nupd = (c0 + 63) / 64;                // workgroups that update columns; the next one copies x_b
+  const int nupd = (c0 + COLS - 1) / COLS;        // workgroups that update columns; the next one copies x_b
   if (bx > nupd) return;
   if (counter) front_wait64(counter, epoch, ((kb + 63) / 64) * kCS, P.counters + 5);
   const double* xp = P.ypart + P.ypart_pos[s];
@@ -918,8 +923,8 @@ __device__ __forceinline__ void bwd_upd_body(const DevPlan& P, int s, int b, int
   }
   const double* Lrow = P.arena + P.front_pos[s] + c0;
 #pragma unroll 1
-  for (int g = 0; g < 16; g += 2) {
-    const int cb = bx * 64 + wv * 16 + g;
+  for (int g = 0; g < COLS / 4; g += 2) {
+    const int cb = bx * COLS + wv * (COLS / 4) + g;
     if (cb >= c0) break;
     double acc[2][R];
 #pragma unroll
@@ -957,10 +962,10 @@ __device__ __forceinline__ void bwd_upd_body(const DevPlan& P, int s, int b, int
       }
   }
 }
-template <int R>
+template <int R, int COLS = 64>
 __global__ __launch_bounds__(256) void k_bwd_upd(DevPlan P, const int* __restrict__ list, int b) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
-  bwd_upd_body<R>(P, list[blockIdx.y], b, (int)blockIdx.x, sm, nullptr, 0ull);
+  bwd_upd_body<R, COLS>(P, list[blockIdx.y], b, (int)blockIdx.x, sm, nullptr, 0ull);
 }
 // one launch per block column b, backward: workgroups [0, nx * kCS) are the partial products of x_b = X_b' z_b (column tile
 // x % nx, row split x / nx), the others update the columns to the left / store x_b once their front's partials have arrived
@@ -1090,7 +1095,7 @@ std::string solve_setup(const Symbolic& S, Numeric& N) {
                          (const void*)k_bwd_wide_fused<2>, (const void*)k_bwd_wide_fused<4>})
     OKKT_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096 - 16 * 1024));
   for (const void* fn : {(const void*)k_fwd_upd<1>, (const void*)k_fwd_upd<2>, (const void*)k_fwd_upd<4>, (const void*)k_bwd_upd<1>,
-                         (const void*)k_bwd_upd<2>, (const void*)k_bwd_upd<4>, (const void*)k_fs_small<256, 1>, (const void*)k_fs_small<256, 2>,
+                         (const void*)k_bwd_upd<2>, (const void*)k_bwd_upd<4>, (const void*)k_fwd_upd<1, 32>, (const void*)k_fwd_upd<2, 32>, (const void*)k_fwd_upd<4, 32>, (const void*)k_bwd_upd<1, 16>, (const void*)k_bwd_upd<2, 16>, (const void*)k_bwd_upd<4, 16>, (const void*)k_fs_small<256, 1>, (const void*)k_fs_small<256, 2>,
                          (const void*)k_fs_small<256, 4>, (const void*)k_bs_small<256, 1>, (const void*)k_bs_small<256, 2>, (const void*)k_bs_small<256, 4>})
     OKKT_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096));
   return "";
@@ -1187,7 +1192,9 @@ static std::string fwd_enqueue_r(Numeric& N, const std::vector<LevelSchedule>& l
           hipLaunchKernelGGL(k_fwd_wide_fused<R>, dim3(ny * kCS + nupd, S.wide_cnt), dim3(256), lds, st, P, list, b, ny, N.solve_counters64, ++N.solve_epoch64);
         } else {
           hipLaunchKernelGGL(k_fwd_y<R>, dim3(ny, S.wide_cnt, kCS), dim3(256), 0, st, P, list, b);
-          hipLaunchKernelGGL(k_fwd_upd<R>, dim3(nupd, S.wide_cnt), dim3(256), lds, st, P, list, b);
+          // few workgroups of 64 rows (the later blocks of a front): 32 rows each, so that the launch reaches more CUs
+          if (N.solve_split_small && nupd * S.wide_cnt < N.solve_split_small) hipLaunchKernelGGL((k_fwd_upd<R, 32>), dim3(std::max(1, (rem + 31) / 32), S.wide_cnt), dim3(256), lds, st, P, list, b);
+          else hipLaunchKernelGGL(k_fwd_upd<R>, dim3(nupd, S.wide_cnt), dim3(256), lds, st, P, list, b);
         }
       }
     }
@@ -1239,7 +1246,8 @@ static std::string bwd_enqueue_r(Numeric& N, const std::vector<LevelSchedule>& l
           hipLaunchKernelGGL(k_bwd_wide_fused<R>, dim3(nx * kCS + nupd, S.wide_cnt), dim3(256), lds, st, P, list, b, nx, N.solve_counters64, ++N.solve_epoch64);
         } else {
           hipLaunchKernelGGL(k_bwd_x<R>, dim3(nx, S.wide_cnt, kCS), dim3(256), 0, st, P, list, b);
-          hipLaunchKernelGGL(k_bwd_upd<R>, dim3(nupd, S.wide_cnt), dim3(256), lds, st, P, list, b);
+          if (N.solve_split_small && nupd * S.wide_cnt < N.solve_split_small) hipLaunchKernelGGL((k_bwd_upd<R, 16>), dim3((b * kSB + 15) / 16 + 1, S.wide_cnt), dim3(256), lds, st, P, list, b);
+          else hipLaunchKernelGGL(k_bwd_upd<R>, dim3(nupd, S.wide_cnt), dim3(256), lds, st, P, list, b);
         }
       }
     }

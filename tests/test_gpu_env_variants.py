@@ -39,6 +39,7 @@ VARIANTS = [
     {"OKKT_SOLVE_FUSE": "0"},                                     # the sweeps with two launches per level of thin fronts
     {"OKKT_SOLVE_FUSE_WIDE_MAX": "100000000"},                    # the wide fronts fused as well
     {"OKKT_SOLVE_FORK": "1"},
+    {"OKKT_SOLVE_SPLIT_SMALL": "0"},                              # panel GEMVs of the wide fronts always with 64 rows / columns per workgroup
     {"OKKT_FLOW": "0"},                                           # small-front tasks: one launch per level instead of one for all levels
     {"OKKT_ORDERING_TEST": "3"},                                  # (read by the case) AMD instead of the automatic choice
 ]
