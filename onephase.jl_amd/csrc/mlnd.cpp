@@ -522,6 +522,62 @@ void ml_separator(const Graph& g0, uint64_t seed, double max_frac, std::vector<i
   if (tdbg) { long c2 = 0; for (int v = 0; v < g0.n; ++v) c2 += where[v] == 2; fprintf(stderr, "okkt: mlnd refined separator %ld\n", c2); }
 }
 
+// ---- level-structure bisection (George): a candidate beside the multilevel ones (round 3) -------------------------------
+// Breadth-first levels from a pseudo-peripheral vertex; the smallest level that leaves both sides within the balance bound is
+// the separator, then the same node-FM pass as above.  On mesh-like graphs these are the grid planes, which the multilevel
+// bisection of a 40^3 grid misses by a factor of two in factor flops; on graphs with long-range edges the level structure is a
+// few levels deep and the candidate loses the comparison (or is not produced at all).  Returns false when the graph is not
+// connected or has fewer than five levels.
+bool bfs_separator(const Graph& g, double max_frac, std::vector<int8_t>& where) {
+  const int n = g.n;
+  if (n < 8) return false;
+  std::vector<int> dist(n, -1), queue;
+  queue.reserve(n);
+  auto bfs = [&](int root) {
+    std::fill(dist.begin(), dist.end(), -1);
+    queue.clear(); queue.push_back(root); dist[root] = 0;
+    for (size_t h = 0; h < queue.size(); ++h) {
+      const int v = queue[h];
+      for (int p = g.xadj[v]; p < g.xadj[v + 1]; ++p) { const int u = g.adj[p]; if (dist[u] < 0) { dist[u] = dist[v] + 1; queue.push_back(u); } }
+    }
+    return dist[queue.back()] + 1;
+  };
+  int root = 0;
+  for (int v = 1; v < n; ++v) if (g.xadj[v + 1] - g.xadj[v] < g.xadj[root + 1] - g.xadj[root]) root = v;   // a vertex of least degree
+  int nlev = bfs(root);
+  if ((int)queue.size() != n) return false;
+  for (int it = 0; it < 4; ++it) {
+    // a vertex of least degree in the last level
+    int best = -1;
+    for (size_t q = queue.size(); q-- > 0;) {
+      const int v = queue[q];
+      if (dist[v] != nlev - 1) break;
+      if (best < 0 || g.xadj[v + 1] - g.xadj[v] < g.xadj[best + 1] - g.xadj[best] || (g.xadj[v + 1] - g.xadj[v] == g.xadj[best + 1] - g.xadj[best] && v < best)) best = v;
+    }
+    if (best < 0 || best == root) break;
+    const int nl2 = bfs(best);
+    root = best;
+    if (nl2 <= nlev) { nlev = nl2; break; }
+    nlev = nl2;
+  }
+  if (nlev < 5) return false;
+  std::vector<int64_t> lw(nlev, 0);
+  for (int v = 0; v < n; ++v) lw[dist[v]] += g.vw[v];
+  const int64_t maxw = (int64_t)std::ceil(max_frac * (double)g.tvw);
+  int ls = -1;
+  int64_t below = 0;
+  for (int l = 1; l <= nlev - 2; ++l) {
+    below += lw[l - 1];
+    const int64_t above = g.tvw - below - lw[l];
+    if (below <= maxw && above <= maxw && below > 0 && above > 0 && (ls < 0 || lw[l] < lw[ls])) ls = l;
+  }
+  if (ls < 0 || lw[ls] * 8 > g.tvw) return false;       // a level of more than an eighth of the graph is no separator (graphs with long-range edges): not worth the refinement pass
+  where.assign(n, 0);
+  for (int v = 0; v < n; ++v) where[v] = (int8_t)(dist[v] < ls ? 0 : (dist[v] > ls ? 1 : 2));
+  fm_node(g, where, maxw, 6);
+  return true;
+}
+
 struct NdCtx {
   int leaf;
   int ntrial_top;
@@ -566,9 +622,15 @@ void nd_rec(NdCtx& cx, Graph g, std::vector<int> label, int* out, int depth, uin
     ml_separator(g, seed * 31, max_frac, cand[0]);
     for (auto& t : th) { t.join(); cx.threads_free.fetch_add(1); }
   }
+  // one more candidate: the level-structure bisection (deterministic, no seed)
+  static const bool use_bfs = !(getenv("OKKT_MLND_BFS") && atoi(getenv("OKKT_MLND_BFS")) == 0);
+  if (use_bfs) {
+    std::vector<int8_t> wb;
+    if (bfs_separator(g, max_frac, wb)) cand.push_back(std::move(wb));
+  }
   int bestt = 0;
   int64_t bests = -1, bestimb = 0;
-  for (int t = 0; t < ntrial; ++t) {
+  for (int t = 0; t < (int)cand.size(); ++t) {
     int64_t c[3] = {0, 0, 0};
     for (int v = 0; v < g.n; ++v) ++c[cand[t][v]];
     const int64_t imb = std::llabs(c[0] - c[1]);

@@ -1477,7 +1477,7 @@ std::string numeric_setup(const Symbolic& S, const SymbolicOptions& opts, hipStr
   // plans of the level-structure dissection (banded systems) are all small fronts and nothing but launch latency: finer tasks
   // (12 front units, ratio 1.1) cut the hanging chain at the CUTEst size from 0.19 + 0.15 ms to 0.11 + 0.10 ms, N_h = 20 000 from
   // 0.37 + 0.29 to 0.24 + 0.19 ms (round 3 sweep); the general plans keep the coarser round-2 setting
-  const bool level_nd = S.ordering_used == 4;
+  const bool level_nd = S.ordering_used == 4 && S.max_front <= N.small_max;   // the banded plans: all small fronts (a mesh-like system ordered by the level structure keeps the general setting)
   const double task_abs = getenv("OKKT_TASK_ABS") ? atof(getenv("OKKT_TASK_ABS")) : (level_nd ? 12.0 : 48.0);
   const double task_ratio = getenv("OKKT_TASK_RATIO") ? atof(getenv("OKKT_TASK_RATIO")) : (level_nd ? 1.1 : 1.5);
   std::vector<int> task_lo(ns), unit_root(ns), ulevel(ns, 0);

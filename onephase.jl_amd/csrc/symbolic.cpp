@@ -561,11 +561,17 @@ std::string analyze_pattern(int64_t n64, const int64_t* colptr, const int64_t* r
   const bool dbg = getenv("OKKT_DEBUG_ANALYZE") != nullptr;
   const int64_t mlnd_min_n = getenv("OKKT_MLND_MIN_N") ? atoll(getenv("OKKT_MLND_MIN_N")) : 10000;
   if (opts.ordering == 0 && n64 >= mlnd_min_n && n64 <= 0x7ffffff0) {
-    SymbolicOptions oa = opts, ob = opts;
+    SymbolicOptions oa = opts, ob = opts, oc = opts;
     oa.ordering = 3;
     ob.ordering = 5;
-    Symbolic Sa, Sb, Sspec;
-    std::string ea, eb, espec = "not run";
+    oc.ordering = 4;
+    Symbolic Sa, Sb, Sc, Sspec;
+    std::string ea, eb, ec, espec = "not run";
+    // third candidate (round 3): the level-structure dissection.  On mesh-like graphs (discretised PDE constraints) its separators
+    // are the grid planes: 40^3 grid 1.0e10 flops against 2.1e10 (multilevel dissection) and 4.6e10 (minimum degree), 400^2 grid
+    // 6.1e8 against 1.2e9 and 1.0e9; on graphs with long-range edges it is hopeless (S-metric: 50 x more flops) and loses the
+    // comparison.  It costs 0.1 s of one more thread, statistics only.
+    std::thread tc([&] { ec = analyze_one(n64, colptr, rowval, index_base, oc, user_perm, Sc, nullptr, true); });
     // The dissection is the faster of the two on many-core hosts (its pieces are ordered in parallel, minimum degree is one
     // thread): its thread goes on with the FULL analysis of its own ordering while minimum degree is still running -- the plan
     // is ready when the comparison is decided, and is thrown away when minimum degree wins
@@ -578,11 +584,19 @@ std::string analyze_pattern(int64_t n64, const int64_t* colptr, const int64_t* r
     });
     ea = analyze_one(n64, colptr, rowval, index_base, oa, user_perm, Sa, nullptr, true);
     tb.join();
+    tc.join();
     if (!ea.empty()) return ea;
-    const bool nd_wins = eb.empty() && Sb.ordering_used == 5 && Sb.flops_exact < 0.9 * Sa.flops_exact && Sa.flops_exact >= 1e9;
+    const bool b_ok = eb.empty() && Sb.ordering_used == 5 && Sb.flops_exact < 0.9 * Sa.flops_exact && Sa.flops_exact >= 1e9;
+    const bool c_ok = ec.empty() && Sc.ordering_used == 4 && Sc.flops_exact < 0.9 * Sa.flops_exact && Sa.flops_exact >= 1e9;
+    const bool lv_wins = c_ok && (!b_ok || Sc.flops_exact < 0.9 * Sb.flops_exact);      // the multilevel plan is already built: the level structure has to be clearly better
+    const bool nd_wins = b_ok && !lv_wins;
     if (dbg)
-      fprintf(stderr, "okkt: analyze candidates: AMD flops %.4g nnz(L) %ld | nested dissection flops %.4g nnz(L) %ld -> %s\n",
-              Sa.flops_exact, (long)Sa.nnzL, Sb.flops_exact, (long)Sb.nnzL, nd_wins ? "nested dissection" : "AMD");
+      fprintf(stderr, "okkt: analyze candidates: AMD flops %.4g nnz(L) %ld | nested dissection flops %.4g nnz(L) %ld | level-structure dissection flops %.4g nnz(L) %ld -> %s\n",
+              Sa.flops_exact, (long)Sa.nnzL, Sb.flops_exact, (long)Sb.nnzL, Sc.flops_exact, (long)Sc.nnzL, lv_wins ? "level-structure dissection" : (nd_wins ? "nested dissection" : "AMD"));
+    if (lv_wins) {
+      const std::vector<int> ord = Sc.perm;
+      return analyze_one(n64, colptr, rowval, index_base, oc, user_perm, S, &ord, false);
+    }
     if (nd_wins) {
       if (espec.empty()) { S = std::move(Sspec); return ""; }
       const std::vector<int> ord = Sb.perm;

@@ -73,22 +73,26 @@ def grid3d_laplacian(n):
 
 
 def test_automatic_mode_keeps_the_ordering_with_fewer_factor_flops():
-    # 3-D grid (28^3 = 21 952 unknowns, separators of n^(2/3)): the dissection needs clearly fewer flops and is chosen
+    # 3-D grid (28^3 = 21 952 unknowns, separators of n^(2/3)): the multilevel dissection needs clearly fewer flops than minimum degree
     A = grid3d_laplacian(28)
     st_amd, _ = analyse(A, 3)
     st_nd, _ = analyse(A, 5)
     assert st_nd["ordering_used"] == 5 and st_amd["ordering_used"] == 0
     assert st_nd["flops_exact"] < 0.9 * st_amd["flops_exact"]
+    # on a mesh the level-structure dissection finds the grid planes; since the multilevel dissection tries the level structure
+    # as one of its bisections it stays within 10 % of it (without that candidate: a factor of two), and the automatic mode takes
+    # the level-structure plan only when it is clearly better than the one already built
+    st_lv, _ = analyse(A, 4)
+    assert st_lv["ordering_used"] == 4 and st_nd["flops_exact"] <= 1.1 * st_lv["flops_exact"]
     st_auto, _ = analyse(A, 0)
-    assert st_auto["ordering_used"] == 5 and st_auto["flops_exact"] == st_nd["flops_exact"]
-    # 2-D grid (160^2): the dissection finds the perfect separators (160, 80, ...) and minimum degree is still the cheaper
-    # ordering at this size -- the reason the automatic mode compares instead of trusting either
+    want = st_lv if st_lv["flops_exact"] < 0.9 * st_nd["flops_exact"] else st_nd
+    assert st_auto["ordering_used"] == want["ordering_used"] and st_auto["flops_exact"] == want["flops_exact"]
+    # 2-D grid (160^2): 5e7 flops either way -- below 1e9 the automatic mode keeps minimum degree whatever the dissection
+    # finds (nothing to gain there, and the comparison is not worth a second plan)
     B = grid_laplacian(160, 160)
     sa, _ = analyse(B, 3)
-    sn, _ = analyse(B, 5)
     s0, _ = analyse(B, 0)
-    assert sa["flops_exact"] < sn["flops_exact"]             # the separators do not pay yet
-    assert s0["ordering_used"] == 0 and s0["flops_exact"] == sa["flops_exact"]
+    assert sa["flops_exact"] < 1e9 and s0["ordering_used"] == 0 and s0["flops_exact"] == sa["flops_exact"]
     # a graph without useful separators (a random expander): whichever needs fewer flops
     rng = np.random.default_rng(1)
     n = 12000
