@@ -1473,7 +1473,10 @@ std::string numeric_setup(const Symbolic& S, const SymbolicOptions& opts, hipStr
   // with them.  A subtree becomes one task when it is all small fronts and either little work (cost <= task_abs front
   // units) or without parallelism to lose (total cost <= task_ratio x its critical path); otherwise its root is a
   // task of its own and the rule is applied to the children.  Big fronts are units of their own.
-  const bool use_tasks = !parted && !(getenv("OKKT_TASKS") && atoi(getenv("OKKT_TASKS")) == 0);
+  // (a partitioned plan: a task must not cross the cut -- only subtrees whose fronts all have the owner of their root become tasks;
+  // round 3, until then partitioned plans ran one launch per level of fronts)
+  static const bool parted_tasks = !(getenv("OKKT_PARTED_TASKS") && atoi(getenv("OKKT_PARTED_TASKS")) == 0);
+  const bool use_tasks = (!parted || parted_tasks) && !(getenv("OKKT_TASKS") && atoi(getenv("OKKT_TASKS")) == 0);
   // plans of the level-structure dissection (banded systems) are all small fronts and nothing but launch latency: finer tasks
   // (12 front units, ratio 1.1) cut the hanging chain at the CUTEst size from 0.19 + 0.15 ms to 0.11 + 0.10 ms, N_h = 20 000 from
   // 0.37 + 0.29 to 0.24 + 0.19 ms (round 3 sweep); the general plans keep the coarser round-2 setting
@@ -1497,7 +1500,7 @@ std::string numeric_setup(const Symbolic& S, const SymbolicOptions& opts, hipStr
       cpath[s2] += cmaxchild[s2];
       const int p2 = S.sn_parent[s2];
       if (p2 < 0) continue;
-      if (!allsmall[s2]) allsmall[p2] = 0;
+      if (!allsmall[s2] || (parted && S.sn_owner[s2] != S.sn_owner[p2])) allsmall[p2] = 0;      // "all small" also means "all of one part"
       first[p2] = std::min(first[p2], first[s2]);
       ctot[p2] += ctot[s2];
       cmaxchild[p2] = std::max(cmaxchild[p2], cpath[s2]);
@@ -1598,7 +1601,7 @@ std::string numeric_setup(const Symbolic& S, const SymbolicOptions& opts, hipStr
   if (!(e = upload(N, task_lo, &d.task_lo)).empty()) return e;
   // the leading levels without a big front run as one launch (k_front_small<.., FLOW>, the flow kernels of solve.hip)
   N.flow_levels = N.flow_off = N.flow_cnt = N.flow_maxf = N.flow_maxk = 0;
-  if (!parted && !laned && N.flow) {
+  if (!laned && N.flow && (!parted || parted_tasks)) {
     int nl = 0;
     while (nl < (int)N.levels.size() && N.levels[nl].seg[3].cnt == 0) ++nl;
     if (nl >= 2) {
@@ -1616,7 +1619,7 @@ std::string numeric_setup(const Symbolic& S, const SymbolicOptions& opts, hipStr
     for (int s2 = 0; s2 < ns; ++s2) {
       if (unit_root[s2] != s2 || S.sn_parent[s2] < 0) continue;
       const int up = unit_root[S.sn_parent[s2]];
-      if (ulevel[up] < N.flow_levels) unit_parent[s2] = up;
+      if (ulevel[up] < N.flow_levels && (!parted || S.sn_owner[up] == S.sn_owner[s2])) unit_parent[s2] = up;     // a parent in the top schedule of a partitioned plan is not part of the launch
     }
     if (!(e = upload(N, unit_parent, &d.unit_parent)).empty()) return e;
   }
