@@ -1107,17 +1107,21 @@ __global__ __launch_bounds__(256) void k_big_trsm(DevPlan P, const int* __restri
 // and raises the front's flag; the others have their panel rows in flight by then, wait, stage the block and solve.  What
 // crosses workgroups inside the launch (L11, its 32 x 32 inverses, D) is written and read with agent-scope accesses.
 __global__ __launch_bounds__(384) void k_diag_trsm_fused(DevPlan P, const int* __restrict__ list, int step, int NB, double tol, int wcol0,
-                                                         int* __restrict__ flags, int epoch) {
+                                                         int* __restrict__ flags, int epoch, int cnt, int ntr) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
-  const int s = list[blockIdx.y];
+  // one-dimensional grid, the diagonal blocks of ALL fronts first (cnt workgroups), then the trsm workgroups front by front: with
+  // (1 + ntr, cnt) the waiting trsm workgroups of the first fronts filled the CUs before the other fronts' diagonal blocks were
+  // dispatched (one 110-KB workgroup per CU) and a level of 50 fronts took three rounds
+  const int x = (int)blockIdx.x;
+  const int s = list[x < cnt ? x : (x - cnt) / ntr];
   if (stop_requested_wg(P)) return;
-  if (blockIdx.x == 0) {
+  if (x < cnt) {
     diag2_body<true>(P, s, step, NB, tol, sm);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every storing wave: its agent-scope stores have been acknowledged
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_store(flags + s, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   } else {
-    trsm_body<4, true>(P, s, step, wcol0, (int)blockIdx.x - 1, sm, flags + s, epoch);
+    trsm_body<4, true>(P, s, step, wcol0, (x - cnt) % ntr, sm, flags + s, epoch);
   }
 }
 
@@ -2118,8 +2122,8 @@ static std::string factor_sched(Numeric& N, DevPlan P, const std::vector<LevelSc
             const int ntr = rem_f > 0 ? (rem_f + 63) / 64 : 0;
             if (N.diag2 && (N.fuse_diag_trsm == 1 || (N.fuse_diag_trsm == 2 && pst == st) || (N.fuse_diag_trsm == 3 && pst == st && g.cnt <= fuse_max_fronts)) && N.chain_flags && dbg_stop == 0 && NB == 128 && ev_rest == nullptr && ntr > 0) {
               const int wc = (par * GS + i) * NB;
-              hipLaunchKernelGGL(k_diag_trsm_fused, dim3(1 + ntr, g.cnt), dim3(384), std::max(lds_diag2, lds_trsm_max), pst, P, list, step, NB, tol, wc,
-                                 N.chain_flags, ++N.chain_epoch);
+              hipLaunchKernelGGL(k_diag_trsm_fused, dim3((1 + ntr) * g.cnt), dim3(384), std::max(lds_diag2, lds_trsm_max), pst, P, list, step, NB, tol, wc,
+                                 N.chain_flags, ++N.chain_epoch, g.cnt, ntr);
               continue;
             }
           }
