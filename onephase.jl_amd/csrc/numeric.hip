@@ -1765,7 +1765,7 @@ std::string numeric_setup(const Symbolic& S, const SymbolicOptions& opts, hipStr
   for (const void* fn : {(const void*)k_big_syrk<0, kSyrkTrail>, (const void*)k_big_syrk<0, kSyrkTrail, 64>, (const void*)k_big_syrk<0, kSyrkPanel>, (const void*)k_big_syrk<0, kSyrkAhead>,
                          (const void*)k_big_syrk<1, kSyrkTrail>, (const void*)k_big_syrk<2, kSyrkTrail>, (const void*)k_big_syrk<5, kSyrkTrail>,
                          (const void*)k_big_syrk<13, kSyrkTrail>, (const void*)k_big_syrk<16, kSyrkTrail>, (const void*)k_big_syrk<16, kSyrkTrail, 64>, (const void*)k_big_syrk<48, kSyrkTrail>})
-    OKKT_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)syrk_lds_bytes(kSyrkStages)));
+    OKKT_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
   return "";
 }
 
@@ -2016,6 +2016,7 @@ static std::string factor_sched(Numeric& N, DevPlan P, const std::vector<LevelSc
         if (ntile == 0) return "";
         // few tiles: 128 x 64 tiles (see k_big_syrk); decided on the largest front of the launch
         static const int small_max = getenv("OKKT_SYRK_SMALL_TILES") ? atoi(getenv("OKKT_SYRK_SMALL_TILES")) : 1500;
+        static const int lds_pad = getenv("OKKT_DEBUG_SYRK_LDS_PAD") ? atoi(getenv("OKKT_DEBUG_SYRK_LDS_PAD")) : 0;   // experiment: extra dynamic LDS of the 128 x 64 trailing update (caps its workgroups per CU)
         const int sub0 = head == 0 ? (sub == 11 ? 1 : (sub == 12 ? 2 : 0)) : 0;     // decoupled schedule: the next diagonal tile / the rest
         const bool narrow = (head == 0 || head == 3) && dbg_syrk == 0 && sub0 != 1 && (int64_t)ntile * g.cnt <= small_max;
         if (narrow) ntile = head == 0 ? T * (T + 1) : Tr * (Tr + 1);
@@ -2057,6 +2058,7 @@ static std::string factor_sched(Numeric& N, DevPlan P, const std::vector<LevelSc
         const int csplit = head == 1 ? sub : (head == 0 ? 0 : cs);
         if (head == 1) OKKT_SYRK(0, kSyrkPanel);
         else if (head == 2) OKKT_SYRK(0, kSyrkAhead);
+        else if (narrow && lds_pad > 0) hipLaunchKernelGGL((k_big_syrk<0, kSyrkTrail, 64>), grid, dim3(kSyrkNW * 64), syrk_lds_bytes(kSyrkStages) + (size_t)lds_pad, sst, P, list, stepA, npan, tstep, NB, wofs, csplit, sub0);
         else if (narrow && dbg_syrk == 96) hipLaunchKernelGGL((k_big_syrk<16, kSyrkTrail, 64>), grid, dim3(kSyrkNW * 64), syrk_lds_bytes(kSyrkStages), sst, P, list, stepA, npan, tstep, NB, wofs, csplit, sub0);
         else if (narrow) hipLaunchKernelGGL((k_big_syrk<0, kSyrkTrail, 64>), grid, dim3(kSyrkNW * 64), syrk_lds_bytes(kSyrkStages), sst, P, list, stepA, npan, tstep, NB, wofs, csplit, sub0);
         else switch (dbg_syrk) {   // timing-only ablations of the trailing update (OKKT_DEBUG_SYRK): wrong outputs
