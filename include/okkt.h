@@ -166,6 +166,14 @@ void* okkt_get_stream(okkt_handle h);
  * (rem * (rem + 1) * nb per front and block column, DESIGN.md "Kernels") */
 int okkt_profile_dominant(okkt_handle h, int enable);
 int okkt_get_profile(okkt_handle h, int64_t* n_launches, double* total_ms, double* total_flops);
+/* Test hook, host only (no device, no handle): the task queue of the dataflow launch (csrc/dataflow.hip) for one level of
+ * nfronts big fronts of orders f[] with k[] pivot columns each, as it would be uploaded for `workers` workers and `group` panels
+ * per update task.  tasks receives 4 ints per task: front index, type | nq << 8 (type 0 = D diagonal tile, 1 = T panel tile,
+ * 2 = U update), i | j << 16 (tile row / column; for T: j = the panel), q0 (first panel of an update).  Returns the number of
+ * tasks (also when it exceeds cap; only cap tasks are written), or a negative error code.  tests/test_dataflow_queue.py replays
+ * the queue on a dense matrix with numpy and checks the dependency order. */
+int64_t okkt_debug_dataflow_queue(int32_t nfronts, const int32_t* f, const int32_t* k, int32_t workers, int32_t group,
+                                  int32_t* tasks, int64_t cap, double* model_us);
 
 /* ---- multi-GPU: subtree-to-GPU sharding of ONE factorisation (one process per GPU) -------------------
  * No reference counterpart (the reference is single-process).  Every rank analyses the same

@@ -1,0 +1,390 @@
+// Dataflow factorisation of the big fronts of one level: ONE persistent launch instead of one launch per block column and kernel.
+//
+// Replaces, for the fronts above small_max rows, the per-step sequence k_big_diag2 -> k_big_trsm -> k_big_syrk of numeric.hip (the
+// reference reaches the same arithmetic through CHOLMOD's numeric factorisation, /root/reference/src/linear_system_solvers/julia.jl:21-97).
+// The level's fronts are cut into 128 x 128 tiles; dataflow_sched.cpp turns the blocked right-looking LDL^T into tasks D (diagonal
+// tile), T (tile of the panel below it) and U (update of a trailing tile by one or two panels) and orders them in ONE queue.
+// Every workgroup of this launch is a worker: pop the next task, wait until the tile states it depends on have been published
+// (bounded spin on agent-scope loads), run the task's body, publish the new state of its tile.  No kernel boundaries and no
+// stream events between the steps: the diagonal block of block column q + 1 starts as soon as ITS tile has received panel q,
+// while the rest of panel q's update is still running on the other CUs.
+//
+// Hand-off protocol (MI355X guide, "Workgroup dispatch, XCD placement & inter-workgroup visibility"): a producer writes every
+// byte that another task reads with sc1 (write-through) stores, every storing wave drains its stores (s_waitcnt vmcnt(0)), the
+// workgroup meets at a barrier, one lane publishes the tile state with an agent-scope store.  A consumer polls the state with
+// agent-scope loads from one lane, that lane runs an agent-scope acquire (invalidates the CU's L1) and drains it, the workgroup
+// meets at a barrier, and only then loads -- plain loads and LDS-DMA.
+//
+// The arithmetic per entry is the sequence of the per-step kernels (same bodies, same order of the panels per tile): the factor
+// is bitwise the same, which is how the GPU tests pin this path (tests/test_gpu_dataflow.py).
+#include "front_device.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+
+namespace okkt {
+
+#define OKKT_HIP_TRY(expr)                                                         \
+  do {                                                                             \
+    hipError_t e__ = (expr);                                                       \
+    if (e__ != hipSuccess)                                                         \
+      return std::string(#expr) + ": " + hipGetErrorString(e__);                   \
+  } while (0)
+
+typedef double d2_t __attribute__((ext_vector_type(2)));
+
+// 16-byte write-through store (global_store_dwordx4 ... sc1): the C tiles leave the CU at the rate of plain stores and are
+// visible to every other CU once the storing wave's vmcnt has drained
+__device__ __forceinline__ void st_sc1_f64x2(double* p, d2_t v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ int ld_state(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// first row / column of block b of a front with KB pivot blocks: 128 b inside the pivot block, k + 128 (b - KB) behind it
+__device__ __forceinline__ int df_block_lo(int b, int KB, int k, int f) { return b < KB ? b * 128 : min(k + (b - KB) * 128, f); }
+
+// ---- T: rows [r0, rlim) (at most 128) of the panel below diagonal block q ---------------------------------------------------
+// k_big_trsm's body (front_device.h: trsm_body) for a workgroup of eight waves, 16 rows each; every load behind the task's
+// acquire is a plain load, W and L leave with sc1 stores.
+__device__ __attribute__((noinline)) void df_trsm_tile(const DevPlan& P, int s, int q, int r0, int rlim, double* sm) {
+  constexpr int NBLK = 4, NB = 128, NPAIR = NBLK * (NBLK + 1) / 2;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int col0 = P.sn_col0[s];
+  const int k = P.sn_col0[s + 1] - col0;
+  const int f = (int)(P.row_ptr[s + 1] - P.row_ptr[s]);
+  const int j0 = q * NB;
+  const int nb = min(NB, k - j0);
+  double* F = P.arena + P.front_pos[s];
+  double* Wb = P.wbuf + P.wbuf_pos[s] + (size_t)j0 * f;
+  const double* X = P.invl + P.invl_pos[s] + (size_t)q * NB * NB;
+  double* rdv = sm + NPAIR * kIB * kIB;
+  const int row = r0 + wv * 16 + (lane & 15);
+  const int rowc = min(row, f - 1);
+  const bool valid = row < rlim;
+  const int lk = lane >> 4, li = lane & 3;
+  double t[NBLK * 8];
+#pragma unroll
+  for (int qq = 0; qq < NBLK * 8; ++qq) {
+    const int c = 4 * qq + lk;
+    t[qq] = keep_f64(F[(size_t)(j0 + min(c, nb - 1)) * f + rowc], c < nb && valid);
+  }
+  {
+    const int e = tid * 2;                 // 2 consecutive rows of one column per thread and block
+    const int cc = e / kIB, rr = e - cc * kIB;
+#pragma unroll
+    for (int bi = 0; bi < NBLK; ++bi)
+#pragma unroll
+      for (int bp = 0; bp <= bi; ++bp) {
+        double v[2];
+        const int gr = bi * kIB + rr, gc = bp * kIB + cc;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const double* src = bp == bi ? X + (gr + u) + (size_t)gc * NB
+                                       : F + (size_t)(j0 + min(gc, nb - 1)) * f + j0 + min(gr + u, nb - 1);
+          v[u] = keep_f64(*src, gr + u < nb && gc < nb);
+        }
+        double* dst = sm + (bi * (bi + 1) / 2 + bp) * kIB * kIB + e;
+        dst[0] = v[0]; dst[1] = v[1];
+      }
+    if (tid < NB) rdv[tid] = tid < nb ? 1.0 / P.dvals[col0 + j0 + tid] : 0.0;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int bi = 0; bi < NBLK; ++bi) {
+#pragma unroll
+    for (int bp = 0; bp < bi; ++bp) {
+      const double* Lb = sm + (bi * (bi + 1) / 2 + bp) * kIB * kIB;
+#pragma unroll
+      for (int gp = 0; gp < 8; ++gp)
+#pragma unroll
+        for (int g = 0; g < 8; ++g)
+          t[bi * 8 + gp] = __builtin_amdgcn_mfma_f64_4x4x4f64(Lb[(gp * 4 + li) + (g * 4 + lk) * kIB], t[bp * 8 + g], t[bi * 8 + gp], 0, 0, 1 /* neg A */);
+    }
+    const double* Xb = sm + (bi * (bi + 1) / 2 + bi) * kIB * kIB;
+    double wt[8];
+#pragma unroll
+    for (int gp = 0; gp < 8; ++gp) {
+      wt[gp] = 0.0;
+#pragma unroll
+      for (int g = 0; g <= gp; ++g)   // X_ii is lower triangular
+        wt[gp] = __builtin_amdgcn_mfma_f64_4x4x4f64(Xb[(gp * 4 + li) + (g * 4 + lk) * kIB], t[bi * 8 + g], wt[gp], 0, 0, 0);
+    }
+#pragma unroll
+    for (int gp = 0; gp < 8; ++gp) t[bi * 8 + gp] = wt[gp];
+  }
+  if (valid) {
+#pragma unroll
+    for (int qq = 0; qq < NBLK * 8; ++qq) {
+      const int c = 4 * qq + lk;
+      if (c < nb) {
+        st_agent_f64(&Wb[(size_t)c * f + row], t[qq]);
+        st_agent_f64(&F[(size_t)(j0 + c) * f + row], t[qq] * rdv[c]);
+      }
+    }
+  }
+}
+
+// ---- U: tile rows [rt0, rlim) x columns [ct0, clim) -= W[rows, j0 .. j0 + nb) * L[columns, j0 .. j0 + nb)^T --------------------
+// k_big_syrk's tile (numeric.hip: 128 x 128 per workgroup of 2 x 4 waves, v_mfma_f64_4x4x4 with neg-A, both operand panels through
+// an LDS-DMA ring of two 16-column chunks) with a row limit (the last pivot block of a front may be shorter than 128 rows) and sc1
+// stores of the C tile.
+__device__ __attribute__((noinline)) void df_syrk_tile(const DevPlan& P, int s, int j0, int nb, int rt0, int ct0, int rlim, int clim, double* sm) {
+  constexpr int NW = kSyrkNW, STAGES = kSyrkStages;
+  constexpr int WCW = 128 / (NW / 2);   // columns per wave
+  constexpr int NCG = WCW / 4;          // 4-column groups per wave
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int f = (int)(P.row_ptr[s + 1] - P.row_ptr[s]);
+  const int rbase = rt0 + (wv & 1) * 64;
+  const int cbase = ct0 + (wv >> 1) * WCW;
+  const bool active = !(rbase + 63 < cbase) && rbase < rlim && cbase < clim;
+  double* F = P.arena + P.front_pos[s];
+  const double* Wg = P.wbuf + P.wbuf_pos[s] + (size_t)j0 * f + rt0 + lane * 2;
+  const double* Lg = F + (size_t)j0 * f + ct0 + lane * 2;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const int nchunk = (nb + kSyrkKC - 1) / kSyrkKC;
+  auto issue = [&](int ch) {
+    double* slot = sm + (size_t)(ch % STAGES) * 2 * kSyrkKC * kSyrkLd;
+#pragma unroll
+    for (int qq = 0; qq < kSyrkKC / NW; ++qq) {
+      const int prow = qq * NW + wv;
+      const int p = ch * kSyrkKC + prow;
+      const double* wsrc = p < nb ? Wg + (size_t)p * f : P.zero_page + lane * 2;
+      const double* lsrc = p < nb ? Lg + (size_t)p * f : P.zero_page + lane * 2;
+      __builtin_amdgcn_global_load_lds(wsrc, (lds_void_t*)(slot + prow * kSyrkLd), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(lsrc, (lds_void_t*)(slot + (kSyrkKC + prow) * kSyrkLd), 16, 0, 0);
+    }
+  };
+  double acc[NCG][4];
+#pragma unroll
+  for (int cg = 0; cg < NCG; ++cg) {
+    const int c = cbase + cg * 4 + l4;
+    const double* colp = F + (size_t)min(c, f - 1) * f;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int r = rbase + 2 * l15 + 32 * h;
+      const int rcl = min(r, f - 2);            // clamped pair start: always in bounds, no branch
+      const int shift = r - rcl;                // 0 in the interior, 1 when r is the last row, >= 2 outside
+      d2_t v;
+      __builtin_memcpy(&v, colp + rcl, 16);
+      const double e0 = shift == 0 ? v[0] : v[1];
+      acc[cg][2 * h] = keep_f64(e0, r < rlim && c < clim && r >= c);
+      acc[cg][2 * h + 1] = keep_f64(v[1], shift == 0 && r + 1 < rlim && c < clim && r + 1 >= c);
+    }
+  }
+  asm volatile("" ::: "memory");
+#pragma unroll
+  for (int qq = 0; qq < STAGES - 1; ++qq) if (qq < nchunk) issue(qq);
+  for (int ch = 0; ch < nchunk; ++ch) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (ch + STAGES - 1 < nchunk) issue(ch + STAGES - 1);
+    if (active) {
+      const double* slot = sm + (size_t)(ch % STAGES) * 2 * kSyrkKC * kSyrkLd;
+      const double* bw = slot + (wv & 1) * 64 + 2 * l15;
+      const double* bl = slot + kSyrkKC * kSyrkLd + (wv >> 1) * WCW + (lane & 3);
+#pragma unroll
+      for (int kk = 0; kk < kSyrkKC / 4; ++kk) {
+        double bv[4];
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) bv[rb] = bw[(kk * 4 + l4) * kSyrkLd + (rb & 1) + 32 * (rb >> 1)];
+#pragma unroll
+        for (int half = 0; half < NCG / 4; ++half) {
+          double av[4];
+#pragma unroll
+          for (int qq = 0; qq < 4; ++qq) av[qq] = bl[(kk * 4 + l4) * kSyrkLd + (half * 4 + qq) * 4];
+#pragma unroll
+          for (int qq = 0; qq < 4; ++qq)
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb)
+              acc[half * 4 + qq][rb] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[qq], bv[rb], acc[half * 4 + qq][rb], 0, 0, 1 /* neg A */);
+        }
+      }
+    }
+  }
+  if (active) {
+#pragma unroll
+    for (int cg = 0; cg < NCG; ++cg) {
+      const int c = cbase + cg * 4 + l4;
+      if (c >= clim) continue;
+      double* colp = F + (size_t)c * f;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int r = rbase + 2 * l15 + 32 * h;
+        if (r + 1 < rlim && r >= c) {
+          st_sc1_f64x2(colp + r, (d2_t){acc[cg][2 * h], acc[cg][2 * h + 1]});
+        } else {
+          if (r < rlim && r >= c) st_agent_f64(colp + r, acc[cg][2 * h]);
+          if (r + 1 < rlim && r + 1 >= c) st_agent_f64(colp + r + 1, acc[cg][2 * h + 1]);
+        }
+      }
+    }
+  }
+  // the ring's slots are reused by the next task of this workgroup: every wave is done reading them behind the caller's barrier
+}
+
+__device__ __attribute__((noinline)) void df_diag_tile(const DevPlan& P, int s, int q, double tol, double* sm) { diag2_body<true>(P, s, q, 128, tol, sm); }
+
+constexpr int kDfThreads = 512;
+constexpr size_t kDfLds = ((size_t)5 * kMW * kPLD + (size_t)2 * 4 * 32 * kXld) * sizeof(double);   // diag2_body's; the other roles need less
+
+// counters[5] = a wait ran into its bound (or another worker's did): every worker leaves, the factorisation reports a wrong
+// inertia ("pivot counts do not add up") and the solves return NaN -- never numbers computed from tiles that had not arrived
+__global__ __launch_bounds__(kDfThreads, 1) void k_front_dataflow(DevPlan P, const DfTask* __restrict__ tasks, int ntasks, int* __restrict__ head, double tol, int drop) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  __shared__ int s_ctl[8];
+  const int tid = threadIdx.x;
+  for (;;) {
+    if (tid == 0) {
+      const int t = atomicAdd(head, 1);
+      int ok = 1;
+      if (t < ntasks) {
+        const DfTask tk = tasks[t];
+        const int s = tk.front, type = tk.type_nq & 255, nq = tk.type_nq >> 8, i = tk.ij & 0xffff, j = tk.ij >> 16, q0 = tk.q0;
+        const int k = P.sn_col0[s + 1] - P.sn_col0[s];
+        const int f = (int)(P.row_ptr[s + 1] - P.row_ptr[s]);
+        const int KB = (k + 127) >> 7;
+        const int TB = KB + ((f - k + 127) >> 7);
+        const int* st = P.df_state + P.df_state_pos[s];
+        // up to three states to wait for: (address, least value)
+        const int* a0; const int* a1; const int* a2;
+        int v0, v1, v2;
+        if (type == kDfD) { a0 = a1 = a2 = st + (size_t)i * TB + i; v0 = v1 = v2 = i; }
+        else if (type == kDfT) { a0 = st + (size_t)j * TB + j; v0 = j + 1; a1 = a2 = st + (size_t)i * TB + j; v1 = v2 = j; }
+        else {
+          const int ql = q0 + nq - 1;
+          a0 = st + (size_t)i * TB + ql; v0 = ql + 1;
+          a1 = st + (size_t)j * TB + ql; v1 = ql + 1;
+          a2 = st + (size_t)i * TB + j; v2 = q0;
+        }
+        if (drop) v2 += 1 << 20;      // tests: a hand-off that never comes
+        int spins = 0;
+        for (;;) {
+          const int c0 = ld_state(a0), c1 = ld_state(a1), c2 = ld_state(a2);
+          if (c0 >= v0 && c1 >= v1 && c2 >= v2) break;
+          // the stop flag of the delta loop (retries only) and the time-out word end every wait
+          const unsigned long long stop = P.want_neg >= 0 ? __hip_atomic_load(&P.counters[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+          const unsigned long long dead = __hip_atomic_load(&P.counters[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (stop | dead) { ok = 0; break; }
+          if (++spins >= (1 << 21)) { atomicAdd(&P.counters[3], 1ull); atomicExch(&P.counters[5], 1ull); ok = 0; break; }
+          __builtin_amdgcn_s_sleep(2);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      s_ctl[0] = t; s_ctl[1] = ok;
+    }
+    __syncthreads();
+    const int t = s_ctl[0];
+    if (t >= ntasks || s_ctl[1] == 0) return;
+    const DfTask tk = tasks[t];
+    const int s = __builtin_amdgcn_readfirstlane(tk.front);
+    const int type_nq = __builtin_amdgcn_readfirstlane(tk.type_nq);
+    const int ij = __builtin_amdgcn_readfirstlane(tk.ij);
+    const int q0 = __builtin_amdgcn_readfirstlane(tk.q0);
+    const int type = type_nq & 255, nq = type_nq >> 8, i = ij & 0xffff, j = ij >> 16;
+    const int k = P.sn_col0[s + 1] - P.sn_col0[s];
+    const int f = (int)(P.row_ptr[s + 1] - P.row_ptr[s]);
+    const int KB = (k + 127) >> 7;
+    const int TB = KB + ((f - k + 127) >> 7);
+    int* st = P.df_state + P.df_state_pos[s];
+    int* mine;
+    int newv;
+    if (type == kDfD) {
+      df_diag_tile(P, s, i, tol, sm);
+      mine = st + (size_t)i * TB + i; newv = i + 1;
+    } else if (type == kDfT) {
+      df_trsm_tile(P, s, j, df_block_lo(i, KB, k, f), df_block_lo(i + 1, KB, k, f), sm);
+      mine = st + (size_t)i * TB + j; newv = j + 1;
+    } else {
+      const int j0 = q0 * 128;
+      df_syrk_tile(P, s, j0, min(nq * 128, k - j0), df_block_lo(i, KB, k, f), df_block_lo(j, KB, k, f), df_block_lo(i + 1, KB, k, f), df_block_lo(j + 1, KB, k, f), sm);
+      mine = st + (size_t)i * TB + j; newv = q0 + nq;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every storing wave: its sc1 stores have been acknowledged
+    __syncthreads();                                      // ... and every wave is done with the LDS of this task and with s_ctl
+    if (tid == 0) __hip_atomic_store(mine, newv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// ---- host side ------------------------------------------------------------------------------------------------------------------
+
+std::string df_setup(Numeric& N) {
+  DevPlan& d = N.d;
+  const int ns = d.nsuper;
+  N.df_tasks = nullptr; N.df_heads = nullptr; N.n_df_heads = 0; N.df_state_ints = 0;
+  d.df_state = nullptr; d.df_state_pos = nullptr;
+  if (!N.dataflow || N.nb != 128) { N.dataflow = 0; return ""; }
+  std::vector<int64_t> spos(ns, -1);
+  int64_t total = 0;
+  std::vector<DfTask> all;
+  std::vector<DfTask> q;
+  int nheads = 0;
+  int dev = 0, ncu = 256;
+  if (hipGetDevice(&dev) == hipSuccess) { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ncu = pr.multiProcessorCount; }
+  N.df_workers = getenv("OKKT_DF_WORKERS") ? std::max(1, atoi(getenv("OKKT_DF_WORKERS"))) : ncu;
+  N.df_group = getenv("OKKT_DF_GROUP") ? std::max(1, std::min(atoi(getenv("OKKT_DF_GROUP")), 4)) : 2;
+  auto do_sched = [&](std::vector<LevelSchedule>& levels) {
+    for (LevelSchedule& L : levels) {
+      Segment& g = L.seg[3];
+      g.df_off = -1; g.df_cnt = 0; g.df_head = -1; g.df_flops = 0;
+      if (g.cnt == 0) continue;
+      std::vector<DfFront> fronts;
+      for (int a = 0; a < g.cnt; ++a) {
+        const int s = N.sched_host[g.off + a];
+        const int f = N.sn_f[s], k = N.sn_k[s];
+        fronts.push_back({s, f, k});
+        if (spos[s] < 0) {
+          const int64_t TB = (k + 127) / 128 + (f - k + 127) / 128;
+          spos[s] = total;
+          total += TB * TB;
+        }
+        g.df_flops += (double)k * f * f - (double)k * k * f + (double)k * k * k / 3.0;
+      }
+      double model = 0;
+      df_build_queue(fronts, N.df_workers, N.df_group, q, &model);
+      g.df_off = (int64_t)all.size();
+      g.df_cnt = (int)q.size();
+      g.df_head = nheads++;
+      all.insert(all.end(), q.begin(), q.end());
+      if (getenv("OKKT_DEBUG_FRONTS")) fprintf(stderr, "okkt: dataflow level: %d fronts (largest %d x %d), %d tasks, model %.0f us\n", g.cnt, g.maxf, g.maxk, g.df_cnt, model);
+    }
+  };
+  do_sched(N.levels);
+  do_sched(N.levels_top);
+  for (LaneSched& X : N.xlanes) do_sched(X.levels);
+  N.n_df_heads = nheads;
+  N.df_state_ints = total;
+  auto up = [&](const void* src, size_t bytes, void** out) -> std::string {
+    void* p = nullptr;
+    OKKT_HIP_TRY(hipMalloc(&p, std::max<size_t>(bytes, 16)));
+    N.allocations.push_back(p);
+    if (bytes) OKKT_HIP_TRY(hipMemcpy(p, src, bytes, hipMemcpyHostToDevice));
+    *out = p;
+    return "";
+  };
+  std::string e;
+  if (!(e = up(spos.data(), spos.size() * sizeof(int64_t), (void**)&d.df_state_pos)).empty()) return e;
+  if (!(e = up(all.data(), all.size() * sizeof(DfTask), (void**)&N.df_tasks)).empty()) return e;
+  {
+    void* p = nullptr;      // tile states, then the queue heads: one fill per factorisation clears both
+    const size_t bytes = ((size_t)total + (size_t)nheads + 16) * sizeof(int);
+    OKKT_HIP_TRY(hipMalloc(&p, bytes));
+    N.allocations.push_back(p);
+    OKKT_HIP_TRY(hipMemset(p, 0, bytes));
+    OKKT_HIP_TRY(hipStreamSynchronize(nullptr));
+    d.df_state = (int*)p;
+    N.df_heads = d.df_state + total;
+  }
+  OKKT_HIP_TRY(hipFuncSetAttribute((const void*)k_front_dataflow, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+  return "";
+}
+
+std::string df_launch(Numeric& N, const DevPlan& P, const Segment& g, hipStream_t st, double tol) {
+  if (g.df_cnt <= 0) return "";
+  static const int drop = getenv("OKKT_DEBUG_DROP_HANDOFF") ? atoi(getenv("OKKT_DEBUG_DROP_HANDOFF")) : 0;
+  const int grid = std::min(g.df_cnt, N.df_workers);
+  hipLaunchKernelGGL(k_front_dataflow, dim3(grid), dim3(kDfThreads), kDfLds, st, P, N.df_tasks + g.df_off, g.df_cnt, N.df_heads + g.df_head, tol, (drop & 4) ? 1 : 0);
+  OKKT_HIP_TRY(hipGetLastError());
+  return "";
+}
+
+}  // namespace okkt

@@ -37,6 +37,7 @@ int solver_ensure_numeric(okkt_solver_s* h) {
   h->N.stream_panel = h->stream_panel;
   h->N.stream_aux = h->stream_aux;
   if (const char* fl = getenv("OKKT_FLOW")) h->N.flow = atoi(fl);   // read by the set-up
+  if (const char* df = getenv("OKKT_DATAFLOW")) h->N.dataflow = atoi(df);
   std::string e = numeric_setup(h->S, h->sopts, h->stream, h->N);
   if (const char* sh = getenv("OKKT_SPLIT_HEAD")) h->N.split_head = atoi(sh);
   if (const char* dc = getenv("OKKT_DECOUPLE")) h->N.decouple = atoi(dc);
@@ -614,6 +615,26 @@ int okkt_get_profile(okkt_handle h, int64_t* n_launches, double* total_ms, doubl
   *total_ms = ms;
   *total_flops = fl;
   return OKKT_OK;
+}
+
+int64_t okkt_debug_dataflow_queue(int32_t nfronts, const int32_t* f, const int32_t* k, int32_t workers, int32_t group,
+                                  int32_t* tasks, int64_t cap, double* model_us) {
+  if (nfronts < 0 || !f || !k || (cap > 0 && !tasks)) return OKKT_ERR_INVALID;
+  try {
+    std::vector<okkt::DfFront> fronts;
+    for (int a = 0; a < nfronts; ++a) {
+      if (k[a] < 1 || f[a] < k[a]) return OKKT_ERR_INVALID;
+      fronts.push_back({a, f[a], k[a]});
+    }
+    std::vector<okkt::DfTask> q;
+    double model = 0;
+    okkt::df_build_queue(fronts, workers, group, q, &model);
+    if (model_us) *model_us = model;
+    for (int64_t t = 0; t < (int64_t)q.size() && t < cap; ++t) {
+      tasks[4 * t] = q[t].front; tasks[4 * t + 1] = q[t].type_nq; tasks[4 * t + 2] = q[t].ij; tasks[4 * t + 3] = q[t].q0;
+    }
+    return (int64_t)q.size();
+  } catch (...) { return OKKT_ERR_ALLOC; }
 }
 
 }  // extern "C"

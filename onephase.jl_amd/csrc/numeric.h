@@ -77,7 +77,19 @@ struct DevPlan {
   unsigned long long* counters = nullptr;
   long long want_pos = -1, want_neg = -1;  // >= 0: the kernels raise / obey the stop flag (retries of the delta loop), -1: off
   double* zero_page = nullptr;  // 2 KiB of zeros (source of out-of-panel LDS-DMA rows)
+  // dataflow factorisation of the big fronts (dataflow.hip): per tile (i, j) of a big front's 128-block grid the number of tasks that
+  // have been applied to it (updates, then the factorisation of the tile itself), TB x TB ints per front
+  int* df_state = nullptr;
+  int64_t* df_state_pos = nullptr;   // [nsuper] offset of the front's states, -1 for small fronts
 };
+
+// one task of the dataflow factorisation (dataflow_sched.cpp builds the queues, dataflow.hip runs them)
+enum { kDfD = 0, kDfT = 1, kDfU = 2 };
+struct DfTask { int front; int type_nq; int ij; int q0; };     // type | nq << 8, i | j << 16
+struct DfFront { int s, f, k; };
+// queue of the fronts of one level in the start order of a simulated list schedule on `workers` workers; `group` panels per
+// update task where the tile allows it; model_us = the simulated makespan
+void df_build_queue(const std::vector<DfFront>& fronts, int workers, int group, std::vector<DfTask>& out, double* model_us);
 
 constexpr int kCountSlots = 64, kCountStride = 16;
 #ifndef OKKT_SOLVE_BLOCK
@@ -96,7 +108,12 @@ std::string numeric_read_counts(struct Numeric& N, hipStream_t stream, unsigned 
 
 // front classes by order f: 0: f<=32 (one wave), 1: f<=64, 2: f<=small_max (256 threads, LDS), 3: big
 constexpr int kNumClasses = 4;
-struct Segment { int off = 0, cnt = 0, maxf = 0, maxk = 0, minf = 1 << 30, mink = 1 << 30; };
+struct Segment {
+  int off = 0, cnt = 0, maxf = 0, maxk = 0, minf = 1 << 30, mink = 1 << 30;
+  int64_t df_off = -1;     // class 3 (big fronts): the level's task queue in Numeric::df_tasks, its length, its head counter, its flops
+  int df_cnt = 0, df_head = -1;
+  double df_flops = 0;
+};
 struct LevelSchedule { Segment seg[kNumClasses]; };
 
 // big fronts of one level for the solves: thin (k <= NB: one fused forward launch) and wide (block products with X_b)
@@ -171,6 +188,15 @@ struct Numeric {
   int flow_levels = 0, flow_off = 0, flow_cnt = 0, flow_maxf = 0, flow_maxk = 0;
   int* flow_flags = nullptr;             // [3][nsuper] monotonic flags: factorisation, forward sweep, backward sweep
   int flow_epoch = 0;
+  // big fronts of a level as ONE persistent launch (dataflow.hip): tasks on 128 x 128 tiles popped from a queue in a precomputed order,
+  // hand-offs through per-tile states.  OKKT_DATAFLOW=0 switches back to the per-step launches of factor_sched.
+  int dataflow = 1;
+  int df_group = 2;                    // panels per update task (K = 128 * group) where the column allows it
+  int df_workers = 256;                // workers of the simulated schedule (and the grid of the launch): one workgroup per CU
+  DfTask* df_tasks = nullptr;
+  int* df_heads = nullptr;
+  int n_df_heads = 0;
+  int64_t df_state_ints = 0;
   int diag2 = 1;                         // k_big_diag2 (role-split, pipelined) instead of k_big_diag; OKKT_DIAG2=0 switches back
   int decouple = 0;                      // OKKT_DECOUPLE=1: single-block steps with the diagonal chain ahead of the wide trsm / trailing update (aux stream); measured slower
   int decouple_min_rows = 256;           // ... while at least this many rows are left below the step
@@ -216,5 +242,8 @@ void numeric_sum_counts_device(Numeric& N, long long* d_out4);
 std::string numeric_solve_enqueue(Numeric& N, int R);
 // diagadd[iperm] = (orig index < nshift) ? delta : 0, via perm
 void launch_set_shift(const Numeric& N, double delta, int64_t nshift);
+// dataflow.hip: the big fronts of one level (class-3 segment g, already assembled) as one persistent launch on `st`
+std::string df_setup(Numeric& N);
+std::string df_launch(Numeric& N, const DevPlan& P, const Segment& g, hipStream_t st, double tol);
 
 }  // namespace okkt

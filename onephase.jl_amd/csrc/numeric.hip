@@ -14,6 +14,7 @@
 // Extend-add is deterministic: every destination entry is owned by exactly one workgroup that
 // adds the children's contribution blocks in a fixed order -- no floating-point atomics.
 #include "numeric.h"
+#include "front_device.h"
 
 #include <algorithm>
 #include <cmath>
@@ -22,7 +23,6 @@
 
 namespace okkt {
 
-typedef double d4_t __attribute__((ext_vector_type(4)));
 
 #define OKKT_HIP_TRY(expr)                                                         \
   do {                                                                             \
@@ -31,46 +31,6 @@ typedef double d4_t __attribute__((ext_vector_type(4)));
       return std::string(#expr) + ": " + hipGetErrorString(e__);                   \
   } while (0)
 
-// ------------------------------------------------------------------------------------------
-// helpers
-// ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void classify_pivot(double d, double tol, unsigned& pos, unsigned& neg,
-                                                unsigned& zer, unsigned& bad) {
-  // julia.jl:72-78: pos = d > tol, neg = d < -tol, zero = rest; NaN/Inf counted apart
-  if (isnan(d) || isinf(d)) ++bad;
-  else if (d > tol) ++pos;
-  else if (d < -tol) ++neg;
-  else ++zer;
-}
-
-// keep ? v : +0.0 as a bit mask.  A `cond ? load : 0` select lets hipcc sink the load under a branch
-// and wait vmcnt(0) for every element (serial memory round trips); the AND keeps the load unconditional.
-__device__ __forceinline__ double keep_f64(double v, bool keep) {
-  return __longlong_as_double(__double_as_longlong(v) & (keep ? -1ll : 0ll));
-}
-
-__device__ __forceinline__ unsigned wave_sum(unsigned v) {
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-  return v;
-}
-
-// With want_neg >= 0 (a retry of the delta loop) the running totals decide: more positive pivots than n, more negative
-// than m, a zero or a non-finite pivot can never give the inertia (n, m, 0) -> raise the stop flag counters[4]; every
-// factorisation kernel launched or started afterwards returns at once (stop_requested_*), the host reads the flag
-// with the counts.  A kernel argument decides whether any of this runs: the first attempt pays nothing.
-__device__ __forceinline__ void flush_counts(const DevPlan& P, int slot, unsigned pos, unsigned neg, unsigned zer, unsigned bad) {
-  // the limits are tested on the slot's own running totals: a part of the true totals, so exceeding them is still proof
-  unsigned long long* counters = P.counters + (size_t)slot * kCountStride;
-  pos = wave_sum(pos); neg = wave_sum(neg); zer = wave_sum(zer); bad = wave_sum(bad);
-  if ((threadIdx.x & 63) == 0) {
-    bool fail = false;
-    if (pos) { const unsigned long long o = atomicAdd(&counters[0], (unsigned long long)pos); fail |= P.want_pos >= 0 && o + pos > (unsigned long long)P.want_pos; }
-    if (neg) { const unsigned long long o = atomicAdd(&counters[1], (unsigned long long)neg); fail |= P.want_neg >= 0 && o + neg > (unsigned long long)P.want_neg; }
-    if (zer) { atomicAdd(&counters[2], (unsigned long long)zer); fail |= P.want_neg >= 0; }
-    if (bad) { atomicAdd(&counters[3], (unsigned long long)bad); fail |= P.want_neg >= 0; }
-    if (fail) atomicExch(&P.counters[4], 1ull);
-  }
-}
 // Retries only, once per level behind the small-front launches: the small fronts' slots are folded into slot 0, so the
 // running totals that k_big_diag tests there are the true totals again, and the limits are tested on them.
 __global__ void k_fold_counts(DevPlan P) {
@@ -84,18 +44,6 @@ __global__ void k_fold_counts(DevPlan P) {
   const unsigned long long tot = atomicAdd(&P.counters[c], sum) + sum;
   const bool fail = c == 0 ? tot > (unsigned long long)P.want_pos : c == 1 ? tot > (unsigned long long)P.want_neg : tot > 0;
   if (fail) atomicExch(&P.counters[4], 1ull);
-}
-// workgroup-uniform (one load, one barrier) / wave-uniform forms of "has the stop flag been raised?"
-__device__ __forceinline__ bool stop_requested_wg(const DevPlan& P) {
-  if (P.want_neg < 0) return false;
-  __shared__ int s_stop;
-  if (threadIdx.x == 0) s_stop = (int)__hip_atomic_load(&P.counters[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __syncthreads();
-  return s_stop != 0;
-}
-__device__ __forceinline__ bool stop_requested_wave(const DevPlan& P) {
-  if (P.want_neg < 0) return false;
-  return __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&P.counters[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0;
 }
 
 // Right-looking LDL^T of the leading npiv columns of an LDS-resident lower-triangular front.
@@ -466,25 +414,8 @@ __global__ __launch_bounds__(256) void k_big_assemble_chunked(DevPlan P, const i
   for (int i = lane; i < n; i += 64) col[i] = base[i];
 }
 
-// 1/d from v_rcp_f64 and two Newton steps (about 1 ulp); d = 0 gives inf/NaN like the division would
-__device__ __forceinline__ double fast_rcp_f64(double d) {
-  double r = __builtin_amdgcn_rcp(d);
-  r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
-  r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
-  return r;
-}
-
-__device__ __forceinline__ double readlane_f64(double v, int src_lane) {
-  // wave-uniform broadcast through SGPRs (v_readlane_b32 x 2); src_lane must be wave-uniform
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_readlane(lo, src_lane);
-  hi = __builtin_amdgcn_readlane(hi, src_lane);
-  return __hiloint2double(hi, lo);
-}
 
 
-constexpr int kIB = 32;  // inner block width of the diagonal-block kernel
-constexpr int kTld = 33; // leading dimension of the 32 x 32 scratch blocks (odd: conflict-free column access)
 
 // NB x NB diagonal block of block-column `step`: LDL^T in LDS (inner width 32: register/readlane
 // 32 x 32 kernel on one wave, row-parallel solve below it, MFMA rank-32 update), D and inertia out,
@@ -505,12 +436,6 @@ constexpr int kTld = 33; // leading dimension of the 32 x 32 scratch blocks (odd
 //   Entries above the diagonal and columns already factored are dead: the updates may write garbage there.
 //   Finally wave b inverts the unit-lower 32 x 32 diagonal block b: one COLUMN of X per lane, forward
 //   substitution with broadcast LDS reads of L (no cross-lane traffic at all).
-#ifndef OKKT_DIAG_MW
-#define OKKT_DIAG_MW 8
-#endif
-constexpr int kMW = OKKT_DIAG_MW;   // micro-panel width (4 or 8)
-constexpr int kPLD = 144;     // leading dimension of the LDS panels: 16-lane groups of an MFMA fragment hit disjoint banks
-constexpr int kXld = 33;
 
 __global__ __launch_bounds__(256) void k_big_diag(DevPlan P, const int* __restrict__ list, int step, int NB, double tol, int dbg_stop) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
@@ -700,201 +625,6 @@ __global__ __launch_bounds__(256) void k_big_diag(DevPlan P, const int* __restri
   }
 }
 
-// k_big_diag2 (round 3): the same factorisation with the two kinds of work on different waves, software-pipelined.
-//   waves 2, 3 hold ALL 36 accumulator tiles (18 each) and do every MFMA; waves 0, 1 are the 128 row threads.
-//   Micro-step m:   waves 2, 3: rank-8 update of step m - 1 on the tile column that holds panel m, copy panel m out -> barrier
-//                   waves 0, 1: 8 x 8 factor + row solve of panel m      ||      waves 2, 3: rest of the update of step m - 1 -> barrier
-//   In k_big_diag the row threads and the MFMA updates alternate and half of the workgroup idles in each; here a micro-step
-//   costs max(row work, rest of the previous update) + the short head.  -L / W panels are double-buffered in LDS.  The
-//   arithmetic per entry is the same sequence of operations: bitwise the same factor.
-// agent-scope (sc1) store: outputs that another workgroup of the SAME launch reads (fused diag + trsm launch below)
-__device__ __forceinline__ void st_agent_f64(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ double ld_agent_f64(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
-template <bool AG>
-__device__ __forceinline__ void diag2_body(const DevPlan& P, int s, int step, int NB, double tol, double* sm) {
-  static_assert(kMW == 8, "micro-panels of 8 columns");
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l15 = lane & 15, l4 = lane >> 4;
-  const int col0 = P.sn_col0[s];
-  const int k = P.sn_col0[s + 1] - col0;
-  const int f = (int)(P.row_ptr[s + 1] - P.row_ptr[s]);
-  const int j0 = step * NB;
-  if (j0 >= k) return;
-  const int nb = min(NB, k - j0);
-  double* Praw = sm;                           // 8 x kPLD: raw micro-panel (columns as rows of the array)
-  double* LpB = Praw + kMW * kPLD;             // -L of the micro-panel, two buffers
-  double* WpB = LpB + 2 * kMW * kPLD;          // W = L * D, two buffers
-  double* Ld = WpB + 2 * kMW * kPLD;           // 4 diagonal 32 x 32 blocks of L, leading dimension 33
-  double* Xs = Ld + 4 * 32 * kXld;             // their inverses
-  double* F = P.arena + P.front_pos[s];
-  const bool mm = wave >= 2;                   // MFMA wave (four of them: one per SIMD; the two row waves share two of the SIMDs)
-  // tiles of an MFMA wave: t = 4 q + (wave - 2), column-major over the lower triangle of the 8 x 8 tile grid
-  int ti_s[9], tj_s[9];
-#pragma unroll
-  for (int q = 0; q < 9; ++q) {
-    const int t = 4 * q + ((wave + 2) & 3);
-    const int tj = (t >= 8) + (t >= 15) + (t >= 21) + (t >= 26) + (t >= 30) + (t >= 33) + (t >= 35);
-    const int start = tj * 8 - tj * (tj - 1) / 2;
-    tj_s[q] = tj;
-    ti_s[q] = tj + (t - start);
-  }
-  d4_t acc[9];
-  if (mm) {
-    double raw[9][4];
-#pragma unroll
-    for (int q = 0; q < 9; ++q) {
-      const int r = 16 * ti_s[q] + l15;
-#pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        const int c = 16 * tj_s[q] + 4 * v + l4;
-        raw[q][v] = F[(size_t)(j0 + min(c, nb - 1)) * f + j0 + min(r, nb - 1)];
-      }
-    }
-#pragma unroll
-    for (int q = 0; q < 9; ++q) {
-      const int r = 16 * ti_s[q] + l15;
-#pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        const int c = 16 * tj_s[q] + 4 * v + l4;
-        const double pad = r == c ? 1.0 : 0.0;
-        acc[q][v] = (r < nb && c < nb && r >= c) ? raw[q][v] : pad;
-      }
-    }
-  }
-  double my_d = 1.0;
-  const int nms = (nb + kMW - 1) / kMW;        // micro-steps
-  for (int ms = 0; ms < nms; ++ms) {
-    const int p8 = ms * kMW, pp = ms >> 1, h = ms & 1;
-    const double* Lprev = LpB + ((ms + 1) & 1) * kMW * kPLD;    // panels of micro-step ms - 1
-    const double* Wprev = WpB + ((ms + 1) & 1) * kMW * kPLD;
-    if (mm) {
-      // head: update of step ms - 1 on the tile column of panel ms, then the copy-out of panel ms
-      if (ms > 0) {
-#pragma unroll
-        for (int q = 0; q < 9; ++q)
-          if (tj_s[q] == pp) {
-            const int rr = 16 * ti_s[q] + l15, cc = 16 * tj_s[q] + l15;
-            double av[2], bv[2];
-#pragma unroll
-            for (int e = 0; e < 2; ++e) { av[e] = Wprev[(4 * e + l4) * kPLD + cc]; bv[e] = Lprev[(4 * e + l4) * kPLD + rr]; }
-#pragma unroll
-            for (int e = 0; e < 2; ++e) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[e], bv[e], acc[q], 0, 0, 0);
-          }
-      }
-#pragma unroll
-      for (int q = 0; q < 9; ++q)
-        if (tj_s[q] == pp) {
-          const int r = 16 * ti_s[q] + l15;
-#pragma unroll
-          for (int e = 0; e < 2; ++e) Praw[(4 * e + l4) * kPLD + r] = h == 0 ? acc[q][e] : acc[q][2 + e];
-        }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    if (!mm) {
-      // row threads: 8 x 8 diagonal LDL^T redundantly in registers, own row solved, panels and final entries written
-      double* Lp = LpB + (ms & 1) * kMW * kPLD;
-      double* Wp = WpB + (ms & 1) * kMW * kPLD;
-      if (tid >= p8 && tid < 128) {
-        const int r = tid;
-        double A[kMW][kMW], a[kMW], rd[kMW], w[kMW], lr[kMW];
-#pragma unroll
-        for (int c = 0; c < kMW; ++c) {
-          a[c] = Praw[c * kPLD + r];
-#pragma unroll
-          for (int i = c; i < kMW; ++i) A[i][c] = Praw[c * kPLD + p8 + i];
-        }
-#pragma unroll
-        for (int c = 0; c < kMW; ++c) {
-          rd[c] = fast_rcp_f64(A[c][c]);
-          w[c] = a[c];
-          lr[c] = w[c] * rd[c];
-#pragma unroll
-          for (int i = c + 1; i < kMW; ++i) {
-            const double lic = A[i][c] * rd[c];
-#pragma unroll
-            for (int j = c + 1; j <= i; ++j) A[i][j] = __builtin_fma(-lic, A[j][c], A[i][j]);
-          }
-#pragma unroll
-          for (int j = c + 1; j < kMW; ++j) a[j] = __builtin_fma(-lr[c], A[j][c], a[j]);
-        }
-        const int i = r - p8;
-        double* Fr = F + (size_t)(j0 + p8) * f + j0 + r;
-#pragma unroll
-        for (int c = 0; c < kMW; ++c) {
-          Lp[c * kPLD + r] = -lr[c];
-          Wp[c * kPLD + r] = w[c];
-          const double val = i == c ? w[c] : lr[c];
-          if (i >= c && r < nb && p8 + c < nb) {
-            if (AG) st_agent_f64(&Fr[(size_t)c * f], val); else Fr[(size_t)c * f] = val;
-            if ((r >> 5) == ((p8 + c) >> 5)) Ld[(r >> 5) * 32 * kXld + (r & 31) + ((p8 + c) & 31) * kXld] = val;
-          }
-        }
-        if (i < kMW) {
-#pragma unroll
-          for (int c = 0; c < kMW; ++c) my_d = i == c ? w[c] : my_d;
-        }
-      }
-    } else if (ms > 0) {
-      // rest of the update of step ms - 1: the tile columns to the right of panel ms's
-#pragma unroll
-      for (int q = 0; q < 9; ++q)
-        if (tj_s[q] > pp) {
-          const int rr = 16 * ti_s[q] + l15, cc = 16 * tj_s[q] + l15;
-          double av[2], bv[2];
-#pragma unroll
-          for (int e = 0; e < 2; ++e) { av[e] = Wprev[(4 * e + l4) * kPLD + cc]; bv[e] = Lprev[(4 * e + l4) * kPLD + rr]; }
-#pragma unroll
-          for (int e = 0; e < 2; ++e) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[e], bv[e], acc[q], 0, 0, 0);
-        }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-  }
-  {
-    unsigned pos = 0, neg = 0, zer = 0, bad = 0;
-    if (tid < nb) {
-      if (AG) st_agent_f64(&P.dvals[col0 + j0 + tid], my_d); else P.dvals[col0 + j0 + tid] = my_d;
-      classify_pivot(my_d, tol, pos, neg, zer, bad);
-    }
-    flush_counts(P, 0, pos, neg, zer, bad);
-  }
-  // X_bb = inv(L_bb): wave b, one column per lane (Ld is complete behind the last barrier of the loop)
-  const int off = wave * 32;
-  if (wave < 4 && off < nb) {
-    const int w = min(32, nb - off);
-    const double* Lb = Ld + wave * 32 * kXld;
-    double* Xb = Xs + wave * 32 * kXld;
-    if (lane < 32) {
-      const int c = lane;
-      double x[32];
-#pragma unroll
-      for (int r = 0; r < 32; ++r) {
-        double v = (r == c) ? 1.0 : 0.0;
-        if (r < w) {
-#pragma unroll
-          for (int p = 0; p < r; ++p) v = __builtin_fma(-Lb[r + p * kXld], x[p], v);
-        }
-        x[r] = (r < w && c < w && r >= c) ? v : 0.0;
-      }
-#pragma unroll
-      for (int r = 0; r < 32; ++r) Xb[r + c * kXld] = x[r];
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-    double* Xg = P.invl + P.invl_pos[s] + (size_t)step * NB * NB;
-    const int r = lane & 31;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int c = (lane >> 5) + 2 * q;
-      if (AG) st_agent_f64(&Xg[(off + r) + (size_t)(off + c) * NB], Xb[r + c * kXld]); else Xg[(off + r) + (size_t)(off + c) * NB] = Xb[r + c * kXld];
-    }
-  }
-}
 __global__ __launch_bounds__(384) void k_big_diag2(DevPlan P, const int* __restrict__ list, int step, int NB, double tol) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int s = list[blockIdx.x];
@@ -992,108 +722,6 @@ __global__ __launch_bounds__(256) void k_big_invert(DevPlan P, const int* __rest
   }
 }
 
-// Rows below the diagonal block: W = A21 * L11^-T by blocked forward substitution over the four 32-column
-// blocks, W_i = (A_i - sum_{p<i} W_p L_ip^T) X_ii^T, with only the 32 x 32 inverses X_ii (k_big_diag) -- the full
-// 128 x 128 inverse is not needed on the critical path.  One wave owns 16 front rows and all 128 columns, so
-// there is no cross-wave dependency.  FP64 MFMA 4x4x4: an accumulator register holds a 4-column x 16-row strip
-// (lane <-> column l>>4, row l&15) and is, unchanged, the B operand of the k-step over those 4 columns: W_p
-// feeds the later products straight from registers.  L blocks and X_ii are staged once per workgroup in LDS
-// and read as broadcast A operands.  L21 = W * D^-1.
-// flag != NULL: a workgroup of the fused diag + trsm launch (384 threads: the last two waves only meet the barriers) -- the rows
-// of the panel are loaded first, then the front's diagonal block is awaited and staged with agent-scope loads
-template <int NBLK, bool AG>
-__device__ __forceinline__ void trsm_body(const DevPlan& P, int s, int step, int wcol0, int blk, double* sm, const int* flag, int epoch) {
-  constexpr int NB = NBLK * kIB;
-  constexpr int NPAIR = NBLK * (NBLK + 1) / 2;
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;          // sm: NPAIR blocks of 32 x 32, then NB reciprocals
-  const bool worker = tid < 256;
-  const int col0 = P.sn_col0[s];
-  const int k = P.sn_col0[s + 1] - col0;
-  const int f = (int)(P.row_ptr[s + 1] - P.row_ptr[s]);
-  const int j0 = step * NB;
-  if (j0 >= k) return;
-  const int nb = min(NB, k - j0);
-  const int r0 = j0 + nb + blk * 64;
-  if (r0 >= f) return;
-  double* F = P.arena + P.front_pos[s];
-  double* Wb = P.wbuf + P.wbuf_pos[s] + (size_t)wcol0 * f;   // this panel's slot inside the super-step's W
-  const double* X = P.invl + P.invl_pos[s] + (size_t)step * NB * NB;
-  double* rdv = sm + NPAIR * kIB * kIB;
-  const int row = r0 + (wv & 3) * 16 + (lane & 15);
-  const int rowc = min(row, f - 1);
-  const int lk = lane >> 4, li = lane & 3;
-  double t[NBLK * 8];
-  // the rows of the panel do not depend on the diagonal block: in flight before the wait
-#pragma unroll
-  for (int q = 0; q < NBLK * 8; ++q) {
-    const int c = 4 * q + lk;
-    t[q] = keep_f64(F[(size_t)(j0 + min(c, nb - 1)) * f + rowc], c < nb && row < f && worker);
-  }
-  if (AG) {
-    if (tid == 0) {
-      int spins = 0;
-      while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(2);
-    }
-    __syncthreads();
-  }
-  // stage block (bi, bp), bp <= bi, at index bi(bi+1)/2 + bp: L_{bi,bp} below the diagonal, X_ii on it
-  if (worker) {
-    const int e = tid * 4;                 // 4 consecutive rows of one column per thread and block
-    const int cc = e / kIB, rr = e - cc * kIB;
-#pragma unroll
-    for (int bi = 0; bi < NBLK; ++bi)
-#pragma unroll
-      for (int bp = 0; bp <= bi; ++bp) {
-        double v[4];
-        const int gr = bi * kIB + rr, gc = bp * kIB + cc;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const double* src = bp == bi ? X + (gr + u) + (size_t)gc * NB
-                                       : F + (size_t)(j0 + min(gc, nb - 1)) * f + j0 + min(gr + u, nb - 1);
-          v[u] = keep_f64(AG ? ld_agent_f64(src) : *src, gr + u < nb && gc < nb);
-        }
-        double* dst = sm + (bi * (bi + 1) / 2 + bp) * kIB * kIB + e;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) dst[u] = v[u];
-      }
-    if (tid < NB) rdv[tid] = tid < nb ? 1.0 / (AG ? ld_agent_f64(&P.dvals[col0 + j0 + tid]) : P.dvals[col0 + j0 + tid]) : 0.0;
-  }
-  __syncthreads();
-  if (!worker) return;
-#pragma unroll
-  for (int bi = 0; bi < NBLK; ++bi) {
-#pragma unroll
-    for (int bp = 0; bp < bi; ++bp) {
-      const double* Lb = sm + (bi * (bi + 1) / 2 + bp) * kIB * kIB;
-#pragma unroll
-      for (int gp = 0; gp < 8; ++gp)
-#pragma unroll
-        for (int g = 0; g < 8; ++g)
-          t[bi * 8 + gp] = __builtin_amdgcn_mfma_f64_4x4x4f64(Lb[(gp * 4 + li) + (g * 4 + lk) * kIB], t[bp * 8 + g], t[bi * 8 + gp], 0, 0, 1 /* neg A */);
-    }
-    const double* Xb = sm + (bi * (bi + 1) / 2 + bi) * kIB * kIB;
-    double wt[8];
-#pragma unroll
-    for (int gp = 0; gp < 8; ++gp) {
-      wt[gp] = 0.0;
-#pragma unroll
-      for (int g = 0; g <= gp; ++g)   // X_ii is lower triangular
-        wt[gp] = __builtin_amdgcn_mfma_f64_4x4x4f64(Xb[(gp * 4 + li) + (g * 4 + lk) * kIB], t[bi * 8 + g], wt[gp], 0, 0, 0);
-    }
-#pragma unroll
-    for (int gp = 0; gp < 8; ++gp) t[bi * 8 + gp] = wt[gp];
-  }
-  if (row < f) {
-#pragma unroll
-    for (int q = 0; q < NBLK * 8; ++q) {
-      const int c = 4 * q + lk;
-      if (c < nb) {
-        Wb[(size_t)c * f + row] = t[q];
-        F[(size_t)(j0 + c) * f + row] = t[q] * rdv[c];
-      }
-    }
-  }
-}
 template <int NBLK>
 __global__ __launch_bounds__(256) void k_big_trsm(DevPlan P, const int* __restrict__ list, int step, int wcol0, int blk_lo) {
   // blk_lo: first 64-row block of the panel this launch handles (the grid covers blocks blk_lo, blk_lo + 1, ...): the decoupled
@@ -1140,31 +768,6 @@ __global__ __launch_bounds__(384) void k_diag_trsm_fused(DevPlan P, const int* _
 //    across the (raw) barrier behind a counted s_waitcnt vmcnt.  LDS rows are padded to 144 doubles so the
 //    four k-slices of a B fragment fall on disjoint banks.
 //  * tile order: workgroups b, b+8, .. share an XCD; they get consecutive tiles (same W row block in L2).
-#ifndef OKKT_SYRK_KC
-#define OKKT_SYRK_KC 16
-#endif
-#ifndef OKKT_SYRK_STAGES
-#define OKKT_SYRK_STAGES 2
-#endif
-constexpr int kSyrkKC = OKKT_SYRK_KC;          // k-columns per ring slot
-constexpr int kSyrkStages = OKKT_SYRK_STAGES;  // ring slots (KC * stages = 32 keeps two workgroups per CU)
-#ifndef OKKT_SYRK_LD
-#define OKKT_SYRK_LD 144
-#endif
-constexpr int kSyrkLd = OKKT_SYRK_LD;   // leading dimension of the LDS panels (doubles)
-constexpr size_t syrk_lds_bytes(int stages) { return (size_t)stages * 2 * kSyrkKC * kSyrkLd * sizeof(double); }
-typedef __attribute__((address_space(3))) void lds_void_t;
-
-// HEAD selects which tiles of the region that starts at block column tstep a launch updates:
-//   kSyrkTrail (the dominant kernel): the lower triangle without its first `csplit` tile columns
-//                (csplit = 0: the whole super-step update; csplit = GS: what is left beside the look-ahead columns)
-//   kSyrkPanel : only the next panel's own columns [t0, min(t0 + NB, k)) -- what that panel needs before it
-//                can be factored (in-group update, K = NB)
-//   kSyrkAhead : the first `csplit` tile columns -- all that the next super-step's panels need (look-ahead)
-// DBG != 0 are timing-only ablations (wrong results): bit0 no C load, bit1 no MFMA, bit2 no store, bit3 no LDS-DMA.
-enum { kSyrkTrail = 0, kSyrkPanel = 1, kSyrkAhead = 2 };
-constexpr int kSyrkNW = 8;   // 2 x 4 waves of 64 rows x 32 columns: four waves per SIMD with two workgroups per CU,
-                             // so a wave's C-tile load/store hides behind three other waves' MFMAs
 
 // TC = tile width in columns (round 3): 128, or 64 for trailing updates of few tiles -- a launch that cannot give every CU two
 // workgroups of 128 x 128 (<= 496 tiles: the chain-bound tail of every front, 45 us per 128-column step whatever is left)
@@ -1587,7 +1190,12 @@ std::string numeric_setup(const Symbolic& S, const SymbolicOptions& opts, hipStr
           sched.push_back(s);
           if (c != 3) { ++N.n_tasks; N.max_task_len = std::max(N.max_task_len, s - task_lo[s] + 1); }
           if (c == 3 && getenv("OKKT_DEBUG_FRONTS")) fprintf(stderr, "okkt: big front level %d  f %d  k %d\n", (int)l, f, k);
-          if (c == 3) { wpos[s] = wtotal; wtotal += (int64_t)f * N.nb * (f >= N.group_big_minf ? std::max(N.group, N.group_big) : N.group) * 2; ++N.n_big;   /* two super-steps of W: look-ahead double buffer */ }
+          if (c == 3) {
+            // two super-steps of W (look-ahead double buffer of the per-step schedule); the dataflow launch keeps the W of EVERY panel of
+            // the front (a task may still read panel q while the chain is several block columns ahead: no slot is ever reused)
+            const int64_t wcols = std::max<int64_t>((int64_t)N.nb * (f >= N.group_big_minf ? std::max(N.group, N.group_big) : N.group) * 2, N.dataflow ? ((int64_t)k + N.nb - 1) / N.nb * N.nb : 0);
+            wpos[s] = wtotal; wtotal += (int64_t)f * wcols; ++N.n_big;
+          }
         }
       }
     }
@@ -1752,6 +1360,7 @@ std::string numeric_setup(const Symbolic& S, const SymbolicOptions& opts, hipStr
     N.flow_epoch = 0;
   }
   if (!(e = solve_setup(S, N)).empty()) return e;
+  if (!(e = df_setup(N)).empty()) return e;
   // kernels that may want more than 64 KiB of dynamic LDS
   const int big_lds = 160 * 1024 - 64;   // the stop-flag check keeps one static LDS word per kernel
   OKKT_HIP_TRY(hipFuncSetAttribute((const void*)k_front_small<256>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds));
@@ -1790,6 +1399,7 @@ void numeric_release(Numeric& N) {
   N.solve_events.clear();
   N.solve_ev_used = 0;
   N.chain_flags = nullptr; N.chain_epoch = 0;
+  N.df_tasks = nullptr; N.df_heads = nullptr; N.n_df_heads = 0; N.df_state_ints = 0;
   N.flow_flags = nullptr; N.flow_epoch = 0; N.flow_levels = 0;
   N.solve_flags = nullptr; N.solve_counters = nullptr; N.solve_epoch = 0; N.solve_counters64 = nullptr; N.solve_epoch64 = 0;
   N.lane_ev_used = 0;
@@ -1851,6 +1461,7 @@ std::string numeric_factor_enqueue(Numeric& N, const double* d_vals, double tol,
   hipStream_t st = N.stream;
   const bool laned = which == 0 && !N.xlanes.empty();
   if (reset_counters) OKKT_HIP_TRY(hipMemsetAsync(P.counters, 0, (size_t)kCountSlots * kCountStride * sizeof(unsigned long long), st));
+  if (N.dataflow && P.df_state) OKKT_HIP_TRY(hipMemsetAsync(P.df_state, 0, ((size_t)N.df_state_ints + (size_t)N.n_df_heads) * sizeof(int), st));   // tile states and queue heads
   if (N.early_check && N.early_device && which == 0 && (N.levels_top.empty() || laned) && reset_counters) { P.want_pos = N.early_n; P.want_neg = N.early_m; }
   N.la_used = 0;
   if (which == 0) N.inv_wait = false;   // the block inverses belong to the previous factorisation (the top phase of a partitioned
@@ -1975,7 +1586,9 @@ static std::string factor_sched(Numeric& N, DevPlan P, const std::vector<LevelSc
       };
       // A level that uses the look-ahead runs on the CU-masked twin of the handle's stream (the reserved CUs belong
       // to the panel streams); every other level keeps all CUs
-      const bool seg_la = la_at(0, gs_at(0));
+      // the level's big fronts as one persistent dataflow launch (dataflow.hip) instead of the per-step launches below
+      const bool use_df = N.dataflow && g.df_cnt > 0 && NB == 128 && dbg_syrk == 0 && dbg_stop == 0 && P.df_state != nullptr;
+      const bool seg_la = !use_df && la_at(0, gs_at(0));
       hipStream_t st = ss.main;
       if (seg_la) {
         hipEvent_t evf;
@@ -2185,6 +1798,20 @@ static std::string factor_sched(Numeric& N, DevPlan P, const std::vector<LevelSc
         }
         return "";
       };
+      if (use_df) {
+        const bool prof = N.profile;
+        if (prof) {
+          if (N.prof_used + 2 > N.prof_events.size())
+            for (int q = 0; q < 512; ++q) { hipEvent_t ev; OKKT_HIP_TRY(hipEventCreate(&ev)); N.prof_events.push_back(ev); }
+          N.prof_flops.push_back(g.df_flops);
+          OKKT_HIP_TRY(hipEventRecord(N.prof_events[N.prof_used++], st));
+        }
+        std::string e = df_launch(N, P, g, st, tol);
+        if (!e.empty()) return e;
+        if (prof) OKKT_HIP_TRY(hipEventRecord(N.prof_events[N.prof_used++], st));
+        if (!(e = inv_range(nsteps, true)).empty()) return e;
+        continue;
+      }
       int gs_cur = gs_at(0), par = 0;
       std::string e = launch_panels(st, 0, gs_cur, par);
       if (!e.empty()) return e;

@@ -1,0 +1,158 @@
+"""The task queue of the dataflow launch (csrc/dataflow_sched.cpp, run by csrc/dataflow.hip), checked on the CPU.
+
+The queue is replayed IN ORDER on dense matrices with numpy: every task must find the tile states it waits for already
+published (the persistent kernel pops the queue in order, so a dependency later in the queue would be a deadlock), every
+tile must receive its panels in ascending order exactly once, and the result must be the partial LDL^T of the front
+(the arithmetic the reference reaches through CHOLMOD, src/linear_system_solvers/julia.jl:34,52)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from onephase_jl_amd import _lib
+
+D, T, U = 0, 1, 2
+
+
+def build_queue(fronts, workers=256, group=2):
+    lib = _lib.load()
+    n = len(fronts)
+    f = (C.c_int32 * n)(*[a for a, _ in fronts])
+    k = (C.c_int32 * n)(*[b for _, b in fronts])
+    model = C.c_double(0)
+    cnt = lib.okkt_debug_dataflow_queue(n, f, k, workers, group, None, 0, C.byref(model))
+    assert cnt >= 0
+    buf = (C.c_int32 * (4 * max(cnt, 1)))()
+    assert lib.okkt_debug_dataflow_queue(n, f, k, workers, group, buf, cnt, C.byref(model)) == cnt
+    q = np.frombuffer(buf, dtype=np.int32).reshape(-1, 4)[:cnt]
+    tasks = [(int(a), int(b) & 255, int(b) >> 8, int(c) & 0xFFFF, int(c) >> 16, int(d)) for a, b, c, d in q]
+    return tasks, model.value
+
+
+def bounds(f, k):
+    KB = (k + 127) // 128
+    b = [min(128 * x, k) for x in range(KB)] + [k]
+    while b[-1] < f:
+        b.append(min(b[-1] + 128, f))
+    if b[-1] != f or (len(b) >= 2 and b[-2] == b[-1]):
+        b = sorted(set(b))
+    return KB, b
+
+
+def dense_partial_ldlt(A, k):
+    A = A.copy()
+    n = A.shape[0]
+    for j in range(k):
+        d = A[j, j]
+        l = A[j + 1:, j] / d
+        A[j + 1:, j + 1:] -= np.outer(l, A[j + 1:, j])
+        A[j + 1:, j] = l
+    return A
+
+
+def replay(fronts, tasks, group):
+    rng = np.random.default_rng(7)
+    mats, refs, states, Ws, grids = [], [], [], [], []
+    for f, k in fronts:
+        B = rng.normal(size=(f, f))
+        A = B + B.T + np.diag(rng.choice([-1.0, 1.0], size=f) * (4.0 + 2 * np.sqrt(f)))
+        mats.append(A.copy())
+        refs.append(dense_partial_ldlt(A, k))
+        KB, b = bounds(f, k)
+        TB = len(b) - 1
+        grids.append((KB, TB, b))
+        states.append(np.zeros((TB, TB), dtype=int))
+        Ws.append(np.zeros((f, k)))
+    for (a, typ, nq, i, j, q0) in tasks:
+        f, k = fronts[a]
+        KB, TB, b = grids[a]
+        st, A, W = states[a], mats[a], Ws[a]
+        ri = slice(b[i], b[i + 1])
+        if typ == D:
+            assert i == j and i < KB and st[i, i] == i, ("D out of order", a, i, st[i, i])
+            blk = A[ri, ri]
+            nb = blk.shape[0]
+            for c in range(nb):
+                d = blk[c, c]
+                l = blk[c + 1:, c] / d
+                blk[c + 1:, c + 1:] -= np.outer(l, blk[c + 1:, c])
+                blk[c + 1:, c] = l
+            st[i, i] = i + 1
+        elif typ == T:
+            q = j
+            assert i > q and q < KB and st[q, q] >= q + 1 and st[i, q] == q, ("T out of order", a, i, q)
+            cq = slice(b[q], b[q + 1])
+            Lqq = np.tril(A[cq, cq], -1) + np.eye(b[q + 1] - b[q])
+            d = np.diag(A[cq, cq])
+            Wt = np.linalg.solve(Lqq, A[ri, cq].T).T
+            W[ri, cq] = Wt
+            A[ri, cq] = Wt / d
+            st[i, q] = q + 1
+        else:
+            ql = q0 + nq - 1
+            assert 1 <= nq <= group and i >= j > ql and ql < KB, ("U shape", a, i, j, q0, nq)
+            assert st[i, ql] >= ql + 1 and st[j, ql] >= ql + 1 and st[i, j] == q0, ("U out of order", a, i, j, q0, nq, st[i, j])
+            cj = slice(b[j], b[j + 1])
+            kk = slice(b[q0], b[ql + 1])
+            upd = W[ri, kk] @ A[cj, kk].T
+            if i == j:
+                upd = np.tril(upd)
+            A[ri, cj] -= upd
+            st[i, j] = q0 + nq
+    for a, (f, k) in enumerate(fronts):
+        KB, TB, b = grids[a]
+        for i in range(TB):
+            for j in range(i + 1):
+                want = j + 1 if j < KB else KB
+                assert states[a][i, j] == want, (a, i, j, states[a][i, j], want)
+        got = np.tril(mats[a])
+        ref = np.tril(refs[a])
+        scale = np.max(np.abs(ref))
+        assert np.max(np.abs(got - ref)) <= 1e-9 * scale, (a, np.max(np.abs(got - ref)) / scale)
+
+
+CASES = [
+    [(129, 1)],
+    [(300, 128)],
+    [(300, 100)],
+    [(700, 700)],
+    [(700, 333)],
+    [(1000, 256), (400, 130), (129, 129)],
+    [(1500, 1030)],
+]
+
+
+@pytest.mark.parametrize("fronts", CASES)
+@pytest.mark.parametrize("group", [1, 2, 3])
+def test_queue_replays_to_the_partial_factorisation(fronts, group):
+    tasks, model = build_queue(fronts, workers=16, group=group)
+    assert model > 0
+    replay(fronts, tasks, group)
+
+
+def test_queue_is_the_same_every_time_and_scales():
+    a, _ = build_queue([(2000, 900), (600, 200)], workers=256, group=2)
+    b, _ = build_queue([(2000, 900), (600, 200)], workers=256, group=2)
+    assert a == b
+    # task counts: D = KB, T = sum over panels of the blocks below, U = groups per tile
+    f, k = 2000, 900
+    KB, bb = bounds(f, k)
+    TB = len(bb) - 1
+    nD = sum(1 for t in a if t[0] == 0 and t[1] == D)
+    nT = sum(1 for t in a if t[0] == 0 and t[1] == T)
+    nU = sum(1 for t in a if t[0] == 0 and t[1] == U)
+    assert nD == KB and nT == sum(TB - 1 - q for q in range(KB))
+    assert nU == sum((min(j, KB) + 1) // 2 for i in range(TB) for j in range(i + 1))
+
+
+def test_chain_is_woven_into_the_bulk():
+    """On a front with many tiles the next diagonal block must not sit behind the whole trailing update of the previous
+    panel: its position in the queue is early among that panel's update tasks."""
+    tasks, _ = build_queue([(6000, 6000)], workers=256, group=2)
+    pos = {}
+    for p, (a, typ, nq, i, j, q0) in enumerate(tasks):
+        pos.setdefault((typ, i, j, q0), p)
+    for q in (2, 10, 20):
+        d_next = pos[(D, q + 1, q + 1, q + 1)]
+        ups = [p for p, (a, typ, nq, i, j, q0) in enumerate(tasks) if typ == U and q0 <= q < q0 + nq and j > q + 1]
+        assert ups and d_next < np.percentile(ups, 60), (q, d_next, np.percentile(ups, [10, 50, 90]))
