@@ -125,6 +125,185 @@ __device__ __forceinline__ void df_trsm_tile(const DevPlan& P, int s, int q, int
   }
 }
 
+// ---- TU: T(q + 1, q) and the update of the diagonal tile (q + 1, q + 1) by panel q in one task -------------------------------
+// The two steps between the diagonal blocks of consecutive block columns.  The task is popped beside D(q): the rows of tile
+// (q + 1, q) and the diagonal tile are in flight while D(q) runs; then the task waits for D(q) (second wait, same protocol as the
+// worker's), solves its 128 rows like df_trsm_tile, keeps W in LDS (128 x 128, the layout of the trailing update's operand
+// slots; L = W * (1 / d) is formed on the fly, the very product that is stored) and applies it to the diagonal tile with the
+// trailing update's MFMA loop.  Same operations per entry in the same order as T followed by U: bitwise the same numbers.
+constexpr size_t kDfTuLds = ((size_t)128 * kSyrkLd + 128) * sizeof(double);
+__device__ __forceinline__ bool df_tu_tile(const DevPlan& P, int s, int q, int r0, int rlim, const int* dstate, int dval, int* s_flag, double* sm, long long* marks) {
+  constexpr int NBLK = 4, NB = 128, NPAIR = NBLK * (NBLK + 1) / 2;
+  constexpr int NW = kSyrkNW, WCW = 128 / (NW / 2), NCG = WCW / 4;
+  int tid_ = threadIdx.x;
+  asm volatile("" : "+v"(tid_));
+  const int tid = tid_, lane = tid & 63, wv = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(wv);
+  const int col0 = P.sn_col0[s];
+  const int f = (int)(P.row_ptr[s + 1] - P.row_ptr[s]);
+  const int j0 = q * NB;
+  // q + 1 < KB: panel q is a whole block column (nb = 128)
+  double* F = P.arena + P.front_pos[s];
+  double* Wb = P.wbuf + P.wbuf_pos[s] + (size_t)j0 * f;
+  const double* X = P.invl + P.invl_pos[s] + (size_t)q * NB * NB;
+  double* rdv = sm + NPAIR * kIB * kIB;
+  const int row = r0 + wv * 16 + (lane & 15);
+  const int rowc = min(row, f - 1);
+  const bool valid = row < rlim;
+  const int lk = lane >> 4, li = lane & 3;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  double t[NBLK * 8];
+#pragma unroll
+  for (int qq = 0; qq < NBLK * 8; ++qq) {
+    const int c = 4 * qq + lk;
+    t[qq] = keep_f64(F[(size_t)(j0 + c) * f + rowc], valid);
+  }
+  // the wave's 64 x 32 piece of the diagonal tile (rows and columns [r0, rlim))
+  const int rbase = r0 + (wv & 1) * 64;
+  const int cbase = r0 + (wv >> 1) * WCW;
+  const bool active = !(rbase + 63 < cbase) && rbase < rlim && cbase < rlim;
+  double acc[NCG][4];
+#pragma unroll
+  for (int cg = 0; cg < NCG; ++cg) {
+    const int c = cbase + cg * 4 + l4;
+    const double* colp = F + (size_t)min(c, f - 1) * f;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int r = rbase + 2 * l15 + 32 * h;
+      const int rcl = min(r, f - 2);
+      const int shift = r - rcl;
+      d2_t v;
+      __builtin_memcpy(&v, colp + rcl, 16);
+      const double e0 = shift == 0 ? v[0] : v[1];
+      acc[cg][2 * h] = keep_f64(e0, r < rlim && c < rlim && r >= c);
+      acc[cg][2 * h + 1] = keep_f64(v[1], shift == 0 && r + 1 < rlim && c < rlim && r + 1 >= c);
+    }
+  }
+  // second wait: the diagonal block of panel q
+  if (wave == 0) {
+    int ok = 1, spins = 0;
+    for (;;) {
+      if (__builtin_amdgcn_readfirstlane(ld_state(dstate)) >= dval) break;
+      const int stop = P.want_neg >= 0 ? __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&P.counters[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : 0;
+      const int dead = __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&P.counters[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      if (stop | dead) { ok = 0; break; }
+      if (++spins >= (1 << 21)) {
+        if (lane == 0) { atomicAdd(&P.counters[3], 1ull); atomicExch(&P.counters[5], 1ull); }
+        ok = 0;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    *s_flag = ok;
+  }
+  __syncthreads();
+  if (__builtin_amdgcn_readfirstlane(*s_flag) == 0) return false;
+  if (marks && tid == 0) marks[0] = wall_clock64();        // D(q) has arrived
+  {
+    const int e = tid * 2;
+    const int cc = e / kIB, rr = e - cc * kIB;
+#pragma unroll
+    for (int bi = 0; bi < NBLK; ++bi)
+#pragma unroll
+      for (int bp = 0; bp <= bi; ++bp) {
+        double v[2];
+        const int gr = bi * kIB + rr, gc = bp * kIB + cc;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const double* src = bp == bi ? X + (gr + u) + (size_t)gc * NB : F + (size_t)(j0 + gc) * f + j0 + gr + u;
+          v[u] = *src;
+        }
+        double* dst = sm + (bi * (bi + 1) / 2 + bp) * kIB * kIB + e;
+        dst[0] = v[0]; dst[1] = v[1];
+      }
+    if (tid < NB) rdv[tid] = 1.0 / P.dvals[col0 + j0 + tid];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int bi = 0; bi < NBLK; ++bi) {
+#pragma unroll
+    for (int bp = 0; bp < bi; ++bp) {
+      const double* Lb = sm + (bi * (bi + 1) / 2 + bp) * kIB * kIB;
+#pragma unroll
+      for (int gp = 0; gp < 8; ++gp)
+#pragma unroll
+        for (int g = 0; g < 8; ++g)
+          t[bi * 8 + gp] = __builtin_amdgcn_mfma_f64_4x4x4f64(Lb[(gp * 4 + li) + (g * 4 + lk) * kIB], t[bp * 8 + g], t[bi * 8 + gp], 0, 0, 1 /* neg A */);
+    }
+    const double* Xb = sm + (bi * (bi + 1) / 2 + bi) * kIB * kIB;
+    double wt[8];
+#pragma unroll
+    for (int gp = 0; gp < 8; ++gp) {
+      wt[gp] = 0.0;
+#pragma unroll
+      for (int g = 0; g <= gp; ++g)
+        wt[gp] = __builtin_amdgcn_mfma_f64_4x4x4f64(Xb[(gp * 4 + li) + (g * 4 + lk) * kIB], t[bi * 8 + g], wt[gp], 0, 0, 0);
+    }
+#pragma unroll
+    for (int gp = 0; gp < 8; ++gp) t[bi * 8 + gp] = wt[gp];
+  }
+  if (marks && tid == 0) marks[1] = wall_clock64();        // rows solved
+  double myrd = tid < NB ? rdv[tid] : 0.0;
+  if (valid) {
+#pragma unroll
+    for (int qq = 0; qq < NBLK * 8; ++qq) {
+      const int c = 4 * qq + lk;
+      st_agent_f64(&Wb[(size_t)c * f + row], t[qq]);
+      st_agent_f64(&F[(size_t)(j0 + c) * f + row], t[qq] * rdv[c]);
+    }
+  }
+  __syncthreads();                       // every wave is done with the staged blocks and the reciprocals
+  double* Wl = sm;                       // [128 panel columns][kSyrkLd]: W(r0 + r, j0 + p) at p * kSyrkLd + r
+  double* rd2 = sm + (size_t)128 * kSyrkLd;
+#pragma unroll
+  for (int qq = 0; qq < NBLK * 8; ++qq) Wl[(size_t)(4 * qq + lk) * kSyrkLd + wv * 16 + l15] = t[qq];      // rows past the block are zero
+  if (tid < NB) rd2[tid] = myrd;
+  __syncthreads();
+  if (marks && tid == 0) marks[2] = wall_clock64();        // W and L stored, W in LDS
+  if (active) {
+    const double* bw = Wl + (wv & 1) * 64 + 2 * l15;
+    const double* bl = Wl + (wv >> 1) * WCW + (lane & 3);
+#pragma unroll 4
+    for (int kk = 0; kk < NB / 4; ++kk) {
+      const double rdp = rd2[kk * 4 + l4];
+      double bv[4];
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) bv[rb] = bw[(kk * 4 + l4) * kSyrkLd + (rb & 1) + 32 * (rb >> 1)];
+#pragma unroll
+      for (int half = 0; half < NCG / 4; ++half) {
+        double av[4];
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) av[qq] = bl[(kk * 4 + l4) * kSyrkLd + (half * 4 + qq) * 4] * rdp;
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq)
+#pragma unroll
+          for (int rb = 0; rb < 4; ++rb)
+            acc[half * 4 + qq][rb] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[qq], bv[rb], acc[half * 4 + qq][rb], 0, 0, 1 /* neg A */);
+      }
+    }
+    if (marks && tid == 0) marks[3] = wall_clock64();      // diagonal tile updated
+#pragma unroll
+    for (int cg = 0; cg < NCG; ++cg) {
+      const int c = cbase + cg * 4 + l4;
+      if (c >= rlim) continue;
+      double* colp = F + (size_t)c * f;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int r = rbase + 2 * l15 + 32 * h;
+        if (r + 1 < rlim && r >= c) {
+          st_sc1_f64x2(colp + r, (d2_t){acc[cg][2 * h], acc[cg][2 * h + 1]});
+        } else {
+          if (r < rlim && r >= c) st_agent_f64(colp + r, acc[cg][2 * h]);
+          if (r + 1 < rlim && r + 1 >= c) st_agent_f64(colp + r + 1, acc[cg][2 * h + 1]);
+        }
+      }
+    }
+  }
+  return true;
+}
+
 // ---- U: tile rows [rt0, rlim) x columns [ct0, clim) -= W[rows, j0 .. j0 + nb) * L[columns, j0 .. j0 + nb)^T --------------------
 // k_big_syrk's tile (numeric.hip: 128 x 128 per workgroup of 2 x 4 waves, v_mfma_f64_4x4x4 with neg-A, both operand panels through
 // an LDS-DMA ring of two 16-column chunks) with a row limit (the last pivot block of a front may be shorter than 128 rows) and sc1
@@ -226,11 +405,11 @@ __device__ __forceinline__ void df_syrk_tile(const DevPlan& P, int s, int j0, in
 }
 
 constexpr int kDfThreads = 512;
-constexpr size_t kDfLds = ((size_t)5 * kMW * kPLD + (size_t)2 * 4 * 32 * kXld) * sizeof(double);   // diag2_body's; the other roles need less
+constexpr size_t kDfLds = std::max(((size_t)5 * kMW * kPLD + (size_t)2 * 4 * 32 * kXld) * sizeof(double), kDfTuLds);   // diag2_body's and df_tu_tile's; the other roles need less
 
 // counters[5] = a wait ran into its bound (or another worker's did): every worker leaves, the factorisation reports a wrong
 // inertia ("pivot counts do not add up") and the solves return NaN -- never numbers computed from tiles that had not arrived
-__global__ __launch_bounds__(kDfThreads, 1) void k_front_dataflow(DevPlan P, const DfTask* __restrict__ tasks, int ntasks, int* __restrict__ head, double tol, int drop, int dbg) {
+__global__ __launch_bounds__(kDfThreads, 1) void k_front_dataflow(DevPlan P, const DfTask* __restrict__ tasks, int ntasks, int* __restrict__ head, double tol, int drop, int dbg, long long* __restrict__ tlog) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   __shared__ int s_ctl[8];
   const int tid = threadIdx.x;
@@ -244,6 +423,7 @@ __global__ __launch_bounds__(kDfThreads, 1) void k_front_dataflow(DevPlan P, con
       if ((tid & 63) == 0) t = atomicAdd(head, 1);
       t = __builtin_amdgcn_readfirstlane(t);
       int ok = 1;
+      if (tlog && t < ntasks && (tid & 63) == 0) { tlog[(size_t)t * 8] = wall_clock64(); tlog[(size_t)t * 8 + 3] = blockIdx.x; }
       if (t < ntasks) {
         const DfTask tk = tasks[t];
         const int s = __builtin_amdgcn_readfirstlane(tk.front), type_nq = __builtin_amdgcn_readfirstlane(tk.type_nq), ij = __builtin_amdgcn_readfirstlane(tk.ij), q0 = __builtin_amdgcn_readfirstlane(tk.q0);
@@ -258,6 +438,7 @@ __global__ __launch_bounds__(kDfThreads, 1) void k_front_dataflow(DevPlan P, con
         int v0, v1, v2;
         if (type == kDfD) { a0 = a1 = a2 = st + (size_t)i * TB + i; v0 = v1 = v2 = i; }
         else if (type == kDfT) { a0 = st + (size_t)j * TB + j; v0 = j + 1; a1 = a2 = st + (size_t)i * TB + j; v1 = v2 = j; }
+        else if (type == kDfTU) { a0 = a1 = st + (size_t)i * TB + j; v0 = v1 = j; a2 = st + (size_t)i * TB + i; v2 = j; }      // the tiles (q + 1, q) and (q + 1, q + 1), q = j; D(q) is awaited inside the task
         else {
           const int ql = q0 + nq - 1;
           a0 = st + (size_t)i * TB + ql; v0 = ql + 1;
@@ -282,6 +463,7 @@ __global__ __launch_bounds__(kDfThreads, 1) void k_front_dataflow(DevPlan P, con
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tlog && (tid & 63) == 0) tlog[(size_t)t * 8 + 1] = wall_clock64();
       }
       s_ctl[0] = t; s_ctl[1] = ok;       // every lane of the wave writes the same two words
     }
@@ -300,6 +482,7 @@ __global__ __launch_bounds__(kDfThreads, 1) void k_front_dataflow(DevPlan P, con
     const int TB = KB + ((f - k + 127) >> 7);
     int* st = P.df_state + P.df_state_pos[s];
     int* mine;
+    int* mine2 = nullptr;      // TU publishes two tiles (the same new value)
     int newv;
     if (type == kDfD) {
       if (!(dbg & 1)) diag2_body<true>(P, s, i, 128, tol, sm);
@@ -307,6 +490,10 @@ __global__ __launch_bounds__(kDfThreads, 1) void k_front_dataflow(DevPlan P, con
     } else if (type == kDfT) {
       if (!(dbg & 2)) df_trsm_tile(P, s, j, df_block_lo(i, KB, k, f), df_block_lo(i + 1, KB, k, f), sm);
       mine = st + (size_t)i * TB + j; newv = j + 1;
+    } else if (type == kDfTU) {
+      if (!df_tu_tile(P, s, j, df_block_lo(i, KB, k, f), df_block_lo(i + 1, KB, k, f), st + (size_t)j * TB + j, j + 1, &s_ctl[2], sm, tlog ? tlog + (size_t)t * 8 + 4 : nullptr)) return;
+      mine = st + (size_t)i * TB + j; newv = j + 1;
+      mine2 = st + (size_t)i * TB + i;
     } else {
       const int j0 = q0 * 128;
       if (!(dbg & 4)) df_syrk_tile(P, s, j0, min(nq * 128, k - j0), df_block_lo(i, KB, k, f), df_block_lo(j, KB, k, f), df_block_lo(i + 1, KB, k, f), df_block_lo(j + 1, KB, k, f), sm);
@@ -314,7 +501,11 @@ __global__ __launch_bounds__(kDfThreads, 1) void k_front_dataflow(DevPlan P, con
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every storing wave: its sc1 stores have been acknowledged
     __syncthreads();                                      // ... and every wave is done with the LDS of this task and with s_ctl
-    if (wave == 0) __hip_atomic_store(mine, newv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // the same word from every lane of the wave
+    if (tlog && tid == 0) tlog[(size_t)t * 8 + 2] = wall_clock64();
+    if (wave == 0) {
+      __hip_atomic_store(mine, newv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // the same word from every lane of the wave
+      if (mine2) __hip_atomic_store(mine2, newv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 }
 
@@ -394,12 +585,29 @@ std::string df_setup(Numeric& N) {
 std::string df_launch(Numeric& N, const DevPlan& P, const Segment& g, hipStream_t st, double tol) {
   if (g.df_cnt <= 0) return "";
   static const int drop = getenv("OKKT_DEBUG_DROP_HANDOFF") ? atoi(getenv("OKKT_DEBUG_DROP_HANDOFF")) : 0;
-  static const int dbg = getenv("OKKT_DEBUG_DATAFLOW") ? atoi(getenv("OKKT_DEBUG_DATAFLOW")) : 0;   // 1 / 2 / 4: skip the bodies of D / T / U (wrong results), 8: synchronise and report every launch
+  static const int dbg = getenv("OKKT_DEBUG_DATAFLOW") ? atoi(getenv("OKKT_DEBUG_DATAFLOW")) : 0;   // 1 / 2 / 4: skip the bodies of D / T / U (wrong results), 8: synchronise and report every launch, 16: per-task time stamps appended to $OKKT_DF_LOG
   const int grid = std::min(g.df_cnt, N.df_workers);
-  hipLaunchKernelGGL(k_front_dataflow, dim3(grid), dim3(kDfThreads), kDfLds, st, P, N.df_tasks + g.df_off, g.df_cnt, N.df_heads + g.df_head, tol, (drop & 4) ? 1 : 0, dbg);
-  if (dbg & 8) {
+  long long* tlog = nullptr;
+  if (dbg & 16) { OKKT_HIP_TRY(hipMalloc((void**)&tlog, (size_t)g.df_cnt * 8 * sizeof(long long))); OKKT_HIP_TRY(hipMemsetAsync(tlog, 0, (size_t)g.df_cnt * 8 * sizeof(long long), st)); }   // debug only: per task pop / ready / end ticks (10 ns) and the worker
+  hipLaunchKernelGGL(k_front_dataflow, dim3(grid), dim3(kDfThreads), kDfLds, st, P, N.df_tasks + g.df_off, g.df_cnt, N.df_heads + g.df_head, tol, (drop & 4) ? 1 : 0, dbg, tlog);
+  if (dbg & 24) {
     hipError_t e2 = hipStreamSynchronize(st);
     fprintf(stderr, "okkt: dataflow launch of %d tasks on %d workers: %s\n", g.df_cnt, grid, hipGetErrorString(e2));
+  }
+  if (tlog) {
+    std::vector<long long> hl((size_t)g.df_cnt * 8);
+    std::vector<DfTask> ht((size_t)g.df_cnt);
+    OKKT_HIP_TRY(hipMemcpy(hl.data(), tlog, hl.size() * sizeof(long long), hipMemcpyDeviceToHost));
+    OKKT_HIP_TRY(hipMemcpy(ht.data(), N.df_tasks + g.df_off, ht.size() * sizeof(DfTask), hipMemcpyDeviceToHost));
+    (void)hipFree(tlog);
+    const char* path = getenv("OKKT_DF_LOG");
+    if (FILE* fp = fopen(path ? path : "/tmp/okkt_df_log.txt", "a")) {
+      fprintf(fp, "# launch %d tasks %d workers (index front type i j q0 nq worker pop ready end [10 ns ticks])\n", g.df_cnt, grid);
+      for (int t = 0; t < g.df_cnt; ++t)
+        fprintf(fp, "%d %d %d %d %d %d %d %lld %lld %lld %lld %lld %lld %lld %lld\n", t, ht[t].front, ht[t].type_nq & 255, ht[t].ij & 0xffff, ht[t].ij >> 16, ht[t].q0, ht[t].type_nq >> 8,
+                hl[(size_t)t * 8 + 3], hl[(size_t)t * 8], hl[(size_t)t * 8 + 1], hl[(size_t)t * 8 + 2], hl[(size_t)t * 8 + 4], hl[(size_t)t * 8 + 5], hl[(size_t)t * 8 + 6], hl[(size_t)t * 8 + 7]);
+      fclose(fp);
+    }
   }
   OKKT_HIP_TRY(hipGetLastError());
   return "";

@@ -2,19 +2,23 @@
 //
 // A front of order f with k pivot columns is cut into blocks of 128 rows / columns: KB = ceil(k / 128) pivot blocks
 // [128 b, min(128 (b + 1), k)) and then blocks of 128 from k on (the contribution block), TB blocks in all.  The blocked
-// right-looking LDL^T of numeric.hip (k_big_diag2 -> k_big_trsm -> k_big_syrk per block column) becomes three kinds of tasks
-// on the tiles (i, j), i >= j, of that grid:
+// right-looking LDL^T of numeric.hip (k_big_diag2 -> k_big_trsm -> k_big_syrk per block column) becomes tasks on the tiles
+// (i, j), i >= j, of that grid:
 //   D(q)             factor the diagonal tile (q, q), q < KB                         after every update of (q, q)
 //   T(i, q)          W = A(i, q) L(q, q)^-T, L = W D^-1 for block row i > q          after D(q) and every update of (i, q)
 //   U(i, j, q0, nq)  A(i, j) -= sum_{q0 <= q < q0 + nq} W(i, q) L(j, q)^T             after T(i, q), T(j, q) and the previous update of (i, j)
+//   TU(q)            T(q + 1, q) and U(q + 1, q + 1, q, 1) in one task (q + 1 < KB): the two steps between the diagonal blocks of
+//                    consecutive block columns -- the critical path -- without a hand-off and without a trip through memory
 // A tile receives the panels in ascending order (the same sequence of operations per entry as the per-step kernels: bitwise the
-// same factor); two panels per task (K = 256) wherever the column is not the very next one to be factored.
+// same factor).  Panels are applied `group` at a time (K = 128 * group) except that the LAST panel of a pivot column comes alone:
+// it is the one the next diagonal block (or panel tile) waits for.
 //
 // The persistent kernel (dataflow.hip) pops tasks from ONE queue in order; a task spins until the tile states it depends on have
 // been published.  Every dependency of a task lies earlier in the queue, so the launch cannot deadlock whatever the number of
 // resident workgroups.  The ORDER decides the overlap: it is the start order of a list schedule simulated here with a crude time
-// model (critical-path priority = leftmost target column first) -- the chain D -> T -> U -> D of the next block column is
-// woven into the bulk updates of the previous ones at the positions where its inputs are expected to be ready.
+// model (critical-path priority = leftmost target column first) -- the chain D -> TU -> D of the next block column is woven
+// into the bulk updates of the previous ones at the positions where its inputs are expected to be ready.  TU(q) is started
+// together with D(q): its worker has the rows of its tiles in flight while the diagonal block is being factored.
 #include <algorithm>
 #include <cstdint>
 #include <functional>
@@ -29,11 +33,17 @@ namespace {
 
 struct FrontGrid {
   int f, k, KB, TB;
-  int64_t offD, offT, offU;          // first task index of each kind
+  int64_t offD, offT, offTU, offU;   // first task index of each kind
   std::vector<int> tq;               // [KB] prefix of the T tasks per panel
   std::vector<int64_t> uoff;         // [TB * TB] first U task of tile (i, j)
+  std::vector<std::vector<int>> gstart;   // [TB] first panel of every update group of tile column j, plus the end
   int npanels(int j) const { return std::min(j, KB); }                      // panels tile column j receives
-  int ngroups(int j, int G) const { return (npanels(j) + G - 1) / G; }
+  // index of the group of column j that ENDS with panel q, or -1
+  int group_ending(int j, int q) const {
+    const std::vector<int>& g = gstart[j];
+    for (size_t a = 0; a + 1 < g.size(); ++a) if (g[a + 1] - 1 == q) return (int)a;
+    return -1;
+  }
 };
 
 }  // namespace
@@ -49,38 +59,57 @@ void df_build_queue(const std::vector<DfFront>& fronts, int workers, int group, 
     g.KB = (g.k + 127) / 128;
     g.TB = g.KB + (g.f - g.k + 127) / 128;
     const int KB = g.KB, TB = g.TB;
+    // update groups of every tile column
+    g.gstart.assign(TB, std::vector<int>());
+    for (int j = 0; j < TB; ++j) {
+      const int np = g.npanels(j);
+      const int paired = j < KB ? std::max(np - 1, 0) : np;     // a pivot column takes its last panel alone
+      std::vector<int>& gs = g.gstart[j];
+      for (int q0 = 0; q0 < paired; q0 += G) gs.push_back(q0);
+      if (j < KB && np > 0) gs.push_back(np - 1);
+      gs.push_back(np);
+    }
     // priority: target column relative to the end of the pivot block (a front with a longer chain ahead of it goes first), then
-    // the kind (D, T, U), then the row.  Smaller = more urgent.
+    // the kind (D, TU, T, U), then the row.  Smaller = more urgent.
     auto key = [&](int col, int kind, int row, int q0) { return ((int64_t)(col - KB + 4096) << 40) | ((int64_t)kind << 36) | ((int64_t)q0 << 20) | (int64_t)row; };
     g.offD = (int64_t)nodes.size();
     for (int q = 0; q < KB; ++q) {
       const int nb = std::min(128, g.k - 128 * q);
-      nodes.push_back({(int)a, kDfD, q, q, q, 1, q > 0 ? 1 : 0, 5.0f + 2.1f * (float)((nb + 7) / 8), key(q, 0, q, q)});
+      nodes.push_back({(int)a, kDfD, q, q, q, 1, q > 0 ? 1 : 0, 5.0f + 2.3f * (float)((nb + 7) / 8), key(q, 0, q, q)});
     }
+    g.offTU = (int64_t)nodes.size();
+    for (int q = 0; q + 1 < KB; ++q)     // needs D(q) [released when D(q) STARTS], the updates of (q + 1, q) and the earlier updates of (q + 1, q + 1)
+      nodes.push_back({(int)a, kDfTU, q + 1, q, q, 1, 1 + (q > 0 ? 2 : 0), 0.0f, key(q, 1, q + 1, q)});
     g.offT = (int64_t)nodes.size();
     g.tq.assign(KB + 1, 0);
     for (int q = 0; q < KB; ++q) {
-      g.tq[q + 1] = g.tq[q] + (TB - 1 - q);
-      for (int i = q + 1; i < TB; ++i) nodes.push_back({(int)a, kDfT, i, q, q, 1, 1 + (q > 0 ? 1 : 0), 12.0f, key(q, 1, i, q)});
+      const int first = q + 1 < KB ? q + 2 : q + 1;             // block row q + 1 belongs to TU(q)
+      g.tq[q + 1] = g.tq[q] + std::max(TB - first, 0);
+      for (int i = first; i < TB; ++i) nodes.push_back({(int)a, kDfT, i, q, q, 1, 1 + (q > 0 ? 1 : 0), 26.0f, key(q, 2, i, q)});
     }
     g.offU = (int64_t)nodes.size();
     g.uoff.assign((size_t)TB * TB, -1);
     for (int i = 0; i < TB; ++i)
       for (int j = 0; j <= i; ++j) {
         g.uoff[(size_t)i * TB + j] = (int64_t)nodes.size();
-        const int np = g.npanels(j);
-        for (int q0 = 0; q0 < np; q0 += G) {
-          const int nq = std::min(G, np - q0);
-          nodes.push_back({(int)a, kDfU, i, j, q0, nq, (i != j ? 2 : 1) + (q0 > 0 ? 1 : 0), 9.0f + 0.165f * 128.0f * (float)nq, key(j, 2, i, q0)});
+        const std::vector<int>& gs = g.gstart[j];
+        for (size_t c = 0; c + 1 < gs.size(); ++c) {
+          const int q0 = gs[c], nq = gs[c + 1] - gs[c];
+          const bool in_tu = i == j && j < KB && c + 2 == gs.size();       // the last panel of a diagonal pivot tile: part of TU(j - 1)
+          nodes.push_back({(int)a, in_tu ? -1 : kDfU, i, j, q0, nq, (i != j ? 2 : 1) + (q0 > 0 ? 1 : 0), 7.0f + 0.165f * 128.0f * (float)nq, key(j, 3, i, q0)});
         }
       }
   }
+  auto t_index = [&](const FrontGrid& g, int i, int q) -> int64_t {       // T(i, q) or, for i == q + 1 < KB, TU(q)
+    if (q + 1 < g.KB) return i == q + 1 ? g.offTU + q : g.offT + g.tq[q] + (i - q - 2);
+    return g.offT + g.tq[q] + (i - q - 1);
+  };
   // list schedule: `workers` identical workers, a ready task with the smallest key starts as soon as a worker is free
   typedef std::pair<int64_t, int64_t> KI;   // (key, node)
   std::priority_queue<KI, std::vector<KI>, std::greater<KI>> ready;
   typedef std::pair<double, int64_t> TI;    // (finish time, node)
   std::priority_queue<TI, std::vector<TI>, std::greater<TI>> running;
-  for (int64_t x = 0; x < (int64_t)nodes.size(); ++x) if (nodes[x].ndep == 0) ready.push({nodes[x].key, x});
+  for (int64_t x = 0; x < (int64_t)nodes.size(); ++x) if (nodes[x].type >= 0 && nodes[x].ndep == 0) ready.push({nodes[x].key, x});
   out.clear();
   out.reserve(nodes.size());
   double now = 0;
@@ -90,10 +119,15 @@ void df_build_queue(const std::vector<DfFront>& fronts, int workers, int group, 
     while (idle > 0 && !ready.empty()) {
       const int64_t x = ready.top().second;
       ready.pop();
-      const Node& nd = nodes[x];
+      Node& nd = nodes[x];
       out.push_back({fronts[nd.front].s, nd.type | (nd.nq << 8), nd.i | (nd.j << 16), nd.q0});
       running.push({now + nd.dur, x});
       --idle;
+      if (nd.type == kDfD && nd.i + 1 < grids[nd.front].KB) {      // TU(q) starts beside D(q) and ends 24 us behind it
+        const int64_t tu = grids[nd.front].offTU + nd.i;
+        nodes[tu].dur = nd.dur + 24.0f;
+        release(tu);
+      }
     }
     if (running.empty()) break;
     const int64_t x = running.top().second;
@@ -105,25 +139,26 @@ void df_build_queue(const std::vector<DfFront>& fronts, int workers, int group, 
     const int KB = g.KB, TB = g.TB;
     if (nd.type == kDfD) {
       const int q = nd.i;
-      for (int i = q + 1; i < TB; ++i) release(g.offT + g.tq[q] + (i - q - 1));
-    } else if (nd.type == kDfT) {
-      // T(i, q): the update groups whose LAST panel is q and that read block row i as the row operand (tiles (i, j), q < j <= i)
-      // or as the column operand (tiles (i2, i), i2 >= i)
+      for (int i = (q + 1 < KB ? q + 2 : q + 1); i < TB; ++i) release(t_index(g, i, q));
+    } else if (nd.type == kDfT || nd.type == kDfTU) {
+      // block row i of panel q is done: the update groups whose LAST panel is q and that read block row i as the row operand
+      // (tiles (i, j), q < j <= i) or as the column operand (tiles (i2, i), i2 >= i)
       const int i = nd.i, q = nd.j;
-      auto group_of = [&](int j) -> int64_t {   // index (within tile column j) of the group that ends with panel q, or -1
-        const int np = g.npanels(j);
-        if (q >= np) return -1;
-        const int gq = q / G;
-        const int last = std::min(gq * G + G, np) - 1;
-        return last == q ? gq : -1;
-      };
-      for (int j = q + 1; j <= i; ++j) { const int64_t gq = group_of(j); if (gq >= 0) release(g.uoff[(size_t)i * TB + j] + gq); }
-      { const int64_t gq = group_of(i); if (gq >= 0) for (int i2 = i + 1; i2 < TB; ++i2) release(g.uoff[(size_t)i2 * TB + i] + gq); }
+      for (int j = q + 1; j <= i; ++j) {
+        if (nd.type == kDfTU && j == i) continue;                 // its own diagonal tile: updated inside the task
+        const int gq = g.group_ending(j, q);
+        if (gq >= 0) release(g.uoff[(size_t)i * TB + j] + gq);
+      }
+      { const int gq = g.group_ending(i, q); if (gq >= 0) for (int i2 = i + 1; i2 < TB; ++i2) release(g.uoff[(size_t)i2 * TB + i] + gq); }
+      if (nd.type == kDfTU) release(g.offD + i);                  // tile (q + 1, q + 1) has received panel q
     } else {
       const int i = nd.i, j = nd.j;
       const int np = g.npanels(j);
-      if (nd.q0 + nd.nq < np) release(g.uoff[(size_t)i * TB + j] + nd.q0 / G + 1);
-      else if (j < KB) release(i == j ? g.offD + j : g.offT + g.tq[j] + (i - j - 1));
+      if (nd.q0 + nd.nq < np) {
+        const int64_t nxt = x + 1;                               // the next group of the same tile
+        if (nodes[nxt].type >= 0) release(nxt);
+        else release(g.offTU + (j - 1));                          // ... which is the one inside TU(j - 1)
+      } else if (j < KB) release(i == j ? g.offD + j : t_index(g, i, j));
     }
   }
   if (model_us) *model_us = now;

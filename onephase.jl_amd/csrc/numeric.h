@@ -84,7 +84,7 @@ struct DevPlan {
 };
 
 // one task of the dataflow factorisation (dataflow_sched.cpp builds the queues, dataflow.hip runs them)
-enum { kDfD = 0, kDfT = 1, kDfU = 2 };
+enum { kDfD = 0, kDfT = 1, kDfU = 2, kDfTU = 3 };
 struct DfTask { int front; int type_nq; int ij; int q0; };     // type | nq << 8, i | j << 16
 struct DfFront { int s, f, k; };
 // queue of the fronts of one level in the start order of a simulated list schedule on `workers` workers; `group` panels per

@@ -1,0 +1,83 @@
+"""Reads the per-task time stamps of a dataflow launch (OKKT_DEBUG_DATAFLOW=16, OKKT_DF_LOG=<file>) and prints where the time of
+the launch goes: durations per task kind, the chain D(q) -> T(q+1, q) -> U(q+1, q+1) -> D(q+1) of the largest front step by step,
+and how busy the workers were.
+usage: python scripts/df_log.py <log> [launch index, default: the one with most tasks]"""
+import sys
+
+import numpy as np
+
+path = sys.argv[1]
+launches = []
+cur = None
+for line in open(path):
+    if line.startswith("#"):
+        cur = []
+        launches.append(cur)
+        continue
+    cur.append([int(x) for x in line.split()])
+if not launches:
+    sys.exit("no launches in the log")
+for n_, l_ in enumerate(launches):
+    if not l_:
+        continue
+    A = np.array(l_, dtype=np.int64)
+    sp_ = (A[:, 10].max() - A[:, 8].min()) / 100.0
+    nw_ = len(set(A[:, 7]))
+    body_ = (A[:, 10] - A[:, 9]).sum() / 100.0
+    print(f"launch {n_:3d}: {len(A):6d} tasks {len(set(A[:, 1])):4d} fronts {nw_:4d} workers span {sp_:8.1f} us  busy {body_ / (nw_ * sp_) * 100:5.1f} %  D {int((A[:, 2] == 0).sum()):4d}")
+which = int(sys.argv[2]) if len(sys.argv) > 2 else int(np.argmax([len(l) for l in launches]))
+L = np.array(launches[which], dtype=np.int64)
+idx, front, typ, ti, tj, q0, nq, worker, pop, ready, end = L.T[:11]
+marks = L[:, 11:15] if L.shape[1] >= 15 else None
+t0 = pop.min()
+pop = (pop - t0) / 100.0
+ready = (ready - t0) / 100.0
+end = (end - t0) / 100.0
+span = end.max()
+print(f"launch {which}: {len(L)} tasks, {len(set(worker))} workers, span {span:.1f} us")
+names = {0: "D", 1: "T", 2: "U", 3: "TU"}
+for k in (0, 1, 2, 3):
+    m = typ == k
+    if not m.any():
+        continue
+    for sel, label in ((m, names[k]),) if k != 2 else ((m & (nq == 1), "U K=128"), (m & (nq == 2), "U K=256"), (m & (nq > 2), "U K>256")):
+        if not sel.any():
+            continue
+        body = end[sel] - ready[sel]
+        wait = ready[sel] - pop[sel]
+        print(f"  {label:8s} n {sel.sum():6d}  body us: mean {body.mean():6.1f} med {np.median(body):6.1f} max {body.max():6.1f} | wait us: mean {wait.mean():6.1f} med {np.median(wait):6.1f} max {wait.max():7.1f} | sum body {body.sum() / 1e3:8.2f} ms")
+busy = (end - ready).sum()
+waits = (ready - pop).sum()
+nw = len(set(worker))
+print(f"  workers: body {busy / (nw * span) * 100:.1f} % of {nw} x span, waiting in a popped task {waits / (nw * span) * 100:.1f} %")
+# chain of the largest front
+big = np.bincount(front).argmax()
+sel = front == big
+D = {int(i): (pop[a], ready[a], end[a]) for a, i in zip(np.where(sel & (typ == 0))[0], ti[sel & (typ == 0)])}
+T = {(int(i), int(j)): (pop[a], ready[a], end[a]) for a, i, j in zip(np.where(sel & (typ == 1))[0], ti[sel & (typ == 1)], tj[sel & (typ == 1)])}
+U = {}
+for a in np.where(sel & (typ == 2))[0]:
+    U[(int(ti[a]), int(tj[a]), int(q0[a]) + int(nq[a]))] = (pop[a], ready[a], end[a])
+print(f"chain of front {big}: step | D pop ready end (body) | T(q+1,q) ready end | U(q+1,q+1,->q+1) ready end | D(q+1) ready - D(q) end")
+qs = sorted(D)
+for q in qs:
+    d = D[q]
+    t = T.get((q + 1, q))
+    u = U.get((q + 1, q + 1, q + 1))
+    dn = D.get(q + 1)
+    row = f"  {q:3d} | {d[0]:8.1f} {d[1]:8.1f} {d[2]:8.1f} ({d[2] - d[1]:5.1f})"
+    if t:
+        row += f" | {t[1]:8.1f} {t[2]:8.1f} ({t[2] - t[1]:5.1f})"
+    if u:
+        row += f" | {u[1]:8.1f} {u[2]:8.1f} ({u[2] - u[1]:5.1f})"
+    if dn:
+        row += f" | {dn[1] - d[2]:6.1f}"
+    if q < 6 or q % 8 == 0 or q >= qs[-1] - 2:
+        print(row)
+if marks is not None and (typ == 3).any():
+    m = typ == 3
+    mk = (marks[m] - t0) / 100.0
+    print(f"  TU phases (us, mean): ready -> D arrived {np.mean(mk[:, 0] - ready[m]):.1f}, rows solved +{np.mean(mk[:, 1] - mk[:, 0]):.1f}, stored + W in LDS +{np.mean(mk[:, 2] - mk[:, 1]):.1f}, tile updated +{np.mean(mk[:, 3] - mk[:, 2]):.1f}, C stored + drained +{np.mean(end[m] - mk[:, 3]):.1f}")
+if len(qs) > 1:
+    per = (D[qs[-1]][2] - D[qs[0]][1]) / (len(qs) - 1)
+    print(f"  mean distance between diagonal blocks {per:.1f} us")

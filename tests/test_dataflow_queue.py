@@ -11,7 +11,7 @@ import pytest
 
 from onephase_jl_amd import _lib
 
-D, T, U = 0, 1, 2
+D, T, U, TU = 0, 1, 2, 3
 
 
 def build_queue(fronts, workers=256, group=2):
@@ -78,9 +78,11 @@ def replay(fronts, tasks, group):
                 blk[c + 1:, c + 1:] -= np.outer(l, blk[c + 1:, c])
                 blk[c + 1:, c] = l
             st[i, i] = i + 1
-        elif typ == T:
+        elif typ in (T, TU):
             q = j
             assert i > q and q < KB and st[q, q] >= q + 1 and st[i, q] == q, ("T out of order", a, i, q)
+            if typ == TU:
+                assert i == q + 1 and i < KB and st[i, i] == q, ("TU out of order", a, i, q, st[i, i])
             cq = slice(b[q], b[q + 1])
             Lqq = np.tril(A[cq, cq], -1) + np.eye(b[q + 1] - b[q])
             d = np.diag(A[cq, cq])
@@ -88,6 +90,9 @@ def replay(fronts, tasks, group):
             W[ri, cq] = Wt
             A[ri, cq] = Wt / d
             st[i, q] = q + 1
+            if typ == TU:      # ... and the diagonal tile of block row i receives panel q
+                A[ri, ri] -= np.tril(W[ri, cq] @ A[ri, cq].T)
+                st[i, i] = q + 1
         else:
             ql = q0 + nq - 1
             assert 1 <= nq <= group and i >= j > ql and ql < KB, ("U shape", a, i, j, q0, nq)
@@ -139,10 +144,13 @@ def test_queue_is_the_same_every_time_and_scales():
     KB, bb = bounds(f, k)
     TB = len(bb) - 1
     nD = sum(1 for t in a if t[0] == 0 and t[1] == D)
-    nT = sum(1 for t in a if t[0] == 0 and t[1] == T)
-    nU = sum(1 for t in a if t[0] == 0 and t[1] == U)
-    assert nD == KB and nT == sum(TB - 1 - q for q in range(KB))
-    assert nU == sum((min(j, KB) + 1) // 2 for i in range(TB) for j in range(i + 1))
+    nT = sum(1 for t in a if t[0] == 0 and t[1] in (T, TU))
+    nTU = sum(1 for t in a if t[0] == 0 and t[1] == TU)
+    assert nD == KB and nTU == KB - 1 and nT == sum(TB - 1 - q for q in range(KB))
+    # the last panel of a pivot column comes alone (K = 128): it is what the next diagonal block / panel tile waits for
+    for (fr, typ, nq, i, j, q0) in a:
+        if fr == 0 and typ == U and j < KB and q0 + nq == j:
+            assert nq == 1
 
 
 def test_chain_is_woven_into_the_bulk():
@@ -154,5 +162,6 @@ def test_chain_is_woven_into_the_bulk():
         pos.setdefault((typ, i, j, q0), p)
     for q in (2, 10, 20):
         d_next = pos[(D, q + 1, q + 1, q + 1)]
+        assert pos[(D, q, q, q)] < pos[(TU, q + 1, q, q)] < d_next      # TU(q) is popped while D(q) runs (its loads are in flight by the time D(q) is done)
         ups = [p for p, (a, typ, nq, i, j, q0) in enumerate(tasks) if typ == U and q0 <= q < q0 + nq and j > q + 1]
         assert ups and d_next < np.percentile(ups, 60), (q, d_next, np.percentile(ups, [10, 50, 90]))
