@@ -33,6 +33,11 @@ namespace okkt {
   } while (0)
 
 typedef double d2_t __attribute__((ext_vector_type(2)));
+constexpr int kDfThreadsC = 512;   // threads of a worker
+#ifndef OKKT_DF_STAGES
+#define OKKT_DF_STAGES 4
+#endif
+constexpr int kDfStages = OKKT_DF_STAGES;   // operand ring of the update tasks: 16-column chunks in LDS (one workgroup per CU: nobody else covers a chunk that is late)
 
 // 16-byte write-through store (global_store_dwordx4 ... sc1): the C tiles leave the CU at the rate of plain stores and are
 // visible to every other CU once the storing wave's vmcnt has drained
@@ -132,7 +137,7 @@ __device__ __forceinline__ void df_trsm_tile(const DevPlan& P, int s, int q, int
 // slots; L = W * (1 / d) is formed on the fly, the very product that is stored) and applies it to the diagonal tile with the
 // trailing update's MFMA loop.  Same operations per entry in the same order as T followed by U: bitwise the same numbers.
 constexpr size_t kDfTuLds = ((size_t)128 * kSyrkLd + 128) * sizeof(double);
-__device__ __forceinline__ bool df_tu_tile(const DevPlan& P, int s, int q, int r0, int rlim, const int* dstate, int dval, int* s_flag, double* sm, long long* marks) {
+__device__ __forceinline__ bool df_tu_tile(const DevPlan& P, int s, int q, int r0, int rlim, const int* dstate, int dval, int* diag_state, int* s_flag, double* sm, long long* marks) {
   constexpr int NBLK = 4, NB = 128, NPAIR = NBLK * (NBLK + 1) / 2;
   constexpr int NW = kSyrkNW, WCW = 128 / (NW / 2), NCG = WCW / 4;
   int tid_ = threadIdx.x;
@@ -245,15 +250,7 @@ __device__ __forceinline__ bool df_tu_tile(const DevPlan& P, int s, int q, int r
     for (int gp = 0; gp < 8; ++gp) t[bi * 8 + gp] = wt[gp];
   }
   if (marks && tid == 0) marks[1] = wall_clock64();        // rows solved
-  double myrd = tid < NB ? rdv[tid] : 0.0;
-  if (valid) {
-#pragma unroll
-    for (int qq = 0; qq < NBLK * 8; ++qq) {
-      const int c = 4 * qq + lk;
-      st_agent_f64(&Wb[(size_t)c * f + row], t[qq]);
-      st_agent_f64(&F[(size_t)(j0 + c) * f + row], t[qq] * rdv[c]);
-    }
-  }
+  const double myrd = tid < NB ? rdv[tid] : 0.0;
   __syncthreads();                       // every wave is done with the staged blocks and the reciprocals
   double* Wl = sm;                       // [128 panel columns][kSyrkLd]: W(r0 + r, j0 + p) at p * kSyrkLd + r
   double* rd2 = sm + (size_t)128 * kSyrkLd;
@@ -261,7 +258,7 @@ __device__ __forceinline__ bool df_tu_tile(const DevPlan& P, int s, int q, int r
   for (int qq = 0; qq < NBLK * 8; ++qq) Wl[(size_t)(4 * qq + lk) * kSyrkLd + wv * 16 + l15] = t[qq];      // rows past the block are zero
   if (tid < NB) rd2[tid] = myrd;
   __syncthreads();
-  if (marks && tid == 0) marks[2] = wall_clock64();        // W and L stored, W in LDS
+  if (marks && tid == 0) marks[2] = wall_clock64();        // W in LDS
   if (active) {
     const double* bw = Wl + (wv & 1) * 64 + 2 * l15;
     const double* bl = Wl + (wv >> 1) * WCW + (lane & 3);
@@ -283,7 +280,6 @@ __device__ __forceinline__ bool df_tu_tile(const DevPlan& P, int s, int q, int r
             acc[half * 4 + qq][rb] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[qq], bv[rb], acc[half * 4 + qq][rb], 0, 0, 1 /* neg A */);
       }
     }
-    if (marks && tid == 0) marks[3] = wall_clock64();      // diagonal tile updated
 #pragma unroll
     for (int cg = 0; cg < NCG; ++cg) {
       const int c = cbase + cg * 4 + l4;
@@ -301,31 +297,62 @@ __device__ __forceinline__ bool df_tu_tile(const DevPlan& P, int s, int q, int r
       }
     }
   }
+  // the diagonal tile first: it is what D(q + 1) waits for.  Every storing wave drains, the workgroup meets, one wave publishes.
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (wave == 0) __hip_atomic_store(diag_state, dval, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // tile (q + 1, q + 1) has received panel q (= q + 1 tasks)
+  if (marks && tid == 0) marks[3] = wall_clock64();        // diagonal tile published
+  // W and L = W D^-1 of the block row leave from LDS: 16-byte write-through stores of two consecutive rows, 1 KiB of one column
+  // per wave instruction (the 8-byte sc1 stores straight from the solve's register layout took 9 us of the 42 between two diagonal blocks)
+  {
+    const int nrow = rlim - r0;
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+      const int idx = it * kDfThreadsC + tid;
+      const int p = idx >> 6, x2 = (idx & 63) * 2;
+      d2_t w;
+      __builtin_memcpy(&w, Wl + (size_t)p * kSyrkLd + x2, 16);
+      const double rp = rd2[p];
+      const d2_t l = (d2_t){w[0] * rp, w[1] * rp};
+      double* wdst = Wb + (size_t)p * f + r0 + x2;
+      double* ldst = F + (size_t)(j0 + p) * f + r0 + x2;
+      if (x2 + 1 < nrow) { st_sc1_f64x2(wdst, w); st_sc1_f64x2(ldst, l); }
+      else if (x2 < nrow) { st_agent_f64(wdst, w[0]); st_agent_f64(ldst, l[0]); }
+    }
+  }
   return true;
 }
 
-// ---- U: tile rows [rt0, rlim) x columns [ct0, clim) -= W[rows, j0 .. j0 + nb) * L[columns, j0 .. j0 + nb)^T --------------------
+// ---- U: tiles (i .. i + R - 1, j) -= W[rows, j0 .. j0 + nb) * L[columns of block j, j0 .. j0 + nb)^T ------------------------------
 // k_big_syrk's tile (numeric.hip: 128 x 128 per workgroup of 2 x 4 waves, v_mfma_f64_4x4x4 with neg-A, both operand panels through
 // an LDS-DMA ring of two 16-column chunks) with a row limit (the last pivot block of a front may be shorter than 128 rows) and sc1
-// stores of the C tile.
-__device__ __forceinline__ void df_syrk_tile(const DevPlan& P, int s, int j0, int nb, int rt0, int ct0, int rlim, int clim, double* sm) {
-  constexpr int NW = kSyrkNW, STAGES = kSyrkStages;
+// stores of the C tile.  One workgroup per CU has nobody to hide a tile's prologue (C tile: 6 us until it has landed, 4 us for the
+// first operand chunk behind it) and epilogue, so a bulk task carries R row tiles of one tile column as ONE stream of operand
+// chunks: the C tile of the next row block is requested while the current one is in its main loop (raw pairs in registers, masked
+// when the accumulators switch), its first operand chunk follows the last chunk of the current tile through the ring, and the
+// stores of a finished tile drain behind the next tile's first chunk.
+__device__ __forceinline__ void df_syrk_tiles(const DevPlan& P, int s, int j0, int nb, int i, int R, int j, int KB, int k, double* sm) {
+  constexpr int NW = kSyrkNW, STAGES = kDfStages;
+  constexpr int DMA = 2 * (kSyrkKC / NW);   // LDS-DMA instructions per wave and chunk
   constexpr int WCW = 128 / (NW / 2);   // columns per wave
   constexpr int NCG = WCW / 4;          // 4-column groups per wave
   int tid_ = threadIdx.x;
   asm volatile("" : "+v"(tid_));      // opaque: nothing derived from the lane id is hoisted out of the worker's loop and kept live across the other roles
   const int tid = tid_, lane = tid & 63, wv = tid >> 6;
   const int f = (int)(P.row_ptr[s + 1] - P.row_ptr[s]);
-  const int rbase = rt0 + (wv & 1) * 64;
+  const int ct0 = df_block_lo(j, KB, k, f), clim = df_block_lo(j + 1, KB, k, f);
   const int cbase = ct0 + (wv >> 1) * WCW;
-  const bool active = !(rbase + 63 < cbase) && rbase < rlim && cbase < clim;
   double* F = P.arena + P.front_pos[s];
-  const double* Wg = P.wbuf + P.wbuf_pos[s] + (size_t)j0 * f + rt0 + lane * 2;
+  const double* Wcol = P.wbuf + P.wbuf_pos[s] + (size_t)j0 * f + lane * 2;
   const double* Lg = F + (size_t)j0 * f + ct0 + lane * 2;
   const int l15 = lane & 15, l4 = lane >> 4;
   const int nchunk = (nb + kSyrkKC - 1) / kSyrkKC;
-  auto issue = [&](int ch) {
-    double* slot = sm + (size_t)(ch % STAGES) * 2 * kSyrkKC * kSyrkLd;
+  const int total = R * nchunk;
+  // operand chunk g of the stream: chunk g % nchunk of row tile g / nchunk
+  auto issue = [&](int g) {
+    const int r = g / nchunk, ch = g - r * nchunk;
+    const double* Wg = Wcol + df_block_lo(i + r, KB, k, f);
+    double* slot = sm + (size_t)(g % STAGES) * 2 * kSyrkKC * kSyrkLd;
 #pragma unroll
     for (int qq = 0; qq < kSyrkKC / NW; ++qq) {
       const int prow = qq * NW + wv;
@@ -336,32 +363,63 @@ __device__ __forceinline__ void df_syrk_tile(const DevPlan& P, int s, int j0, in
       __builtin_amdgcn_global_load_lds(lsrc, (lds_void_t*)(slot + (kSyrkKC + prow) * kSyrkLd), 16, 0, 0);
     }
   };
-  double acc[NCG][4];
+  // raw C pairs of a row tile (clamped addresses, no branches) and the masks that turn them into accumulators
+  d2_t raw[NCG][2];
+  auto load_c = [&](int r) {
+    const int rbase = df_block_lo(i + r, KB, k, f) + (wv & 1) * 64;
 #pragma unroll
-  for (int cg = 0; cg < NCG; ++cg) {
-    const int c = cbase + cg * 4 + l4;
-    const double* colp = F + (size_t)min(c, f - 1) * f;
+    for (int cg = 0; cg < NCG; ++cg) {
+      const int c = cbase + cg * 4 + l4;
+      const double* colp = F + (size_t)min(c, f - 1) * f;
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int r = rbase + 2 * l15 + 32 * h;
-      const int rcl = min(r, f - 2);            // clamped pair start: always in bounds, no branch
-      const int shift = r - rcl;                // 0 in the interior, 1 when r is the last row, >= 2 outside
-      d2_t v;
-      __builtin_memcpy(&v, colp + rcl, 16);
-      const double e0 = shift == 0 ? v[0] : v[1];
-      acc[cg][2 * h] = keep_f64(e0, r < rlim && c < clim && r >= c);
-      acc[cg][2 * h + 1] = keep_f64(v[1], shift == 0 && r + 1 < rlim && c < clim && r + 1 >= c);
+      for (int h = 0; h < 2; ++h) {
+        const int rr = rbase + 2 * l15 + 32 * h;
+        __builtin_memcpy(&raw[cg][h], colp + min(rr, f - 2), 16);
+      }
     }
-  }
-  asm volatile("" ::: "memory");
+  };
+  double acc[NCG][4];
+  auto mask_c = [&](int r) {
+    const int rbase = df_block_lo(i + r, KB, k, f) + (wv & 1) * 64;
+    const int rlim = df_block_lo(i + r + 1, KB, k, f);
 #pragma unroll
-  for (int qq = 0; qq < STAGES - 1; ++qq) if (qq < nchunk) issue(qq);
-  for (int ch = 0; ch < nchunk; ++ch) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (int cg = 0; cg < NCG; ++cg) {
+      const int c = cbase + cg * 4 + l4;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int rr = rbase + 2 * l15 + 32 * h;
+        const int shift = rr - min(rr, f - 2);      // 0 in the interior, 1 when rr is the last row, >= 2 outside
+        const double e0 = shift == 0 ? raw[cg][h][0] : raw[cg][h][1];
+        acc[cg][2 * h] = keep_f64(e0, rr < rlim && c < clim && rr >= c);
+        acc[cg][2 * h + 1] = keep_f64(raw[cg][h][1], shift == 0 && rr + 1 < rlim && c < clim && rr + 1 >= c);
+      }
+    }
+  };
+  load_c(0);
+  asm volatile("" ::: "memory");
+  mask_c(0);
+#pragma unroll
+  for (int g = 0; g < STAGES - 1; ++g) if (g < total) issue(g);
+  int plain_until = 0;                     // chunks up to this one are waited for with vmcnt(0): ordinary loads / stores sit between the operand requests
+  const int pre = min(2, nchunk - 1);      // chunk of a tile behind whose operand request the next tile's C is requested
+  int r = 0, ch = 0;
+  for (int g = 0; g < total; ++g) {
+    {
+      // chunk g has landed once only the chunks requested after it (at most STAGES - 2) are still outstanding
+      const int later = g < plain_until ? 0 : min(STAGES - 2, total - 1 - g);
+      if (later >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DMA) : "memory");
+      else if (later == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();
-    if (ch + STAGES - 1 < nchunk) issue(ch + STAGES - 1);
+    // the slot written next was last read one iteration ago; everyone is past that barrier
+    if (g + STAGES - 1 < total) issue(g + STAGES - 1);
+    if (ch == pre && r + 1 < R) { load_c(r + 1); plain_until = g + STAGES; }
+    const int rt0 = df_block_lo(i + r, KB, k, f), rlim = df_block_lo(i + r + 1, KB, k, f);
+    const int rbase = rt0 + (wv & 1) * 64;
+    const bool active = !(rbase + 63 < cbase) && rbase < rlim && cbase < clim;
     if (active) {
-      const double* slot = sm + (size_t)(ch % STAGES) * 2 * kSyrkKC * kSyrkLd;
+      const double* slot = sm + (size_t)(g % STAGES) * 2 * kSyrkKC * kSyrkLd;
       const double* bw = slot + (wv & 1) * 64 + 2 * l15;
       const double* bl = slot + kSyrkKC * kSyrkLd + (wv >> 1) * WCW + (lane & 3);
 #pragma unroll
@@ -382,30 +440,36 @@ __device__ __forceinline__ void df_syrk_tile(const DevPlan& P, int s, int j0, in
         }
       }
     }
-  }
-  if (active) {
+    if (++ch == nchunk) {
+      // the row tile is done: store it (write-through, not waited for here) and switch to the next one's accumulators
+      if (active) {
 #pragma unroll
-    for (int cg = 0; cg < NCG; ++cg) {
-      const int c = cbase + cg * 4 + l4;
-      if (c >= clim) continue;
-      double* colp = F + (size_t)c * f;
+        for (int cg = 0; cg < NCG; ++cg) {
+          const int c = cbase + cg * 4 + l4;
+          if (c >= clim) continue;
+          double* colp = F + (size_t)c * f;
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int r = rbase + 2 * l15 + 32 * h;
-        if (r + 1 < rlim && r >= c) {
-          st_sc1_f64x2(colp + r, (d2_t){acc[cg][2 * h], acc[cg][2 * h + 1]});
-        } else {
-          if (r < rlim && r >= c) st_agent_f64(colp + r, acc[cg][2 * h]);
-          if (r + 1 < rlim && r + 1 >= c) st_agent_f64(colp + r + 1, acc[cg][2 * h + 1]);
+          for (int h = 0; h < 2; ++h) {
+            const int rr = rbase + 2 * l15 + 32 * h;
+            if (rr + 1 < rlim && rr >= c) {
+              st_sc1_f64x2(colp + rr, (d2_t){acc[cg][2 * h], acc[cg][2 * h + 1]});
+            } else {
+              if (rr < rlim && rr >= c) st_agent_f64(colp + rr, acc[cg][2 * h]);
+              if (rr + 1 < rlim && rr + 1 >= c) st_agent_f64(colp + rr + 1, acc[cg][2 * h + 1]);
+            }
+          }
         }
       }
+      ch = 0;
+      plain_until = g + STAGES;
+      if (++r < R) mask_c(r);
     }
   }
   // the ring's slots are reused by the next task of this workgroup: every wave is done reading them behind the caller's barrier
 }
 
-constexpr int kDfThreads = 512;
-constexpr size_t kDfLds = std::max(((size_t)5 * kMW * kPLD + (size_t)2 * 4 * 32 * kXld) * sizeof(double), kDfTuLds);   // diag2_body's and df_tu_tile's; the other roles need less
+constexpr int kDfThreads = kDfThreadsC;
+constexpr size_t kDfLds = std::max(std::max(((size_t)5 * kMW * kPLD + (size_t)2 * 4 * 32 * kXld) * sizeof(double), kDfTuLds), (size_t)kDfStages * 2 * kSyrkKC * kSyrkLd * sizeof(double));   // diag2_body's and df_tu_tile's; the other roles need less
 
 // counters[5] = a wait ran into its bound (or another worker's did): every worker leaves, the factorisation reports a wrong
 // inertia ("pivot counts do not add up") and the solves return NaN -- never numbers computed from tiles that had not arrived
@@ -427,35 +491,40 @@ __global__ __launch_bounds__(kDfThreads, 1) void k_front_dataflow(DevPlan P, con
       if (t < ntasks) {
         const DfTask tk = tasks[t];
         const int s = __builtin_amdgcn_readfirstlane(tk.front), type_nq = __builtin_amdgcn_readfirstlane(tk.type_nq), ij = __builtin_amdgcn_readfirstlane(tk.ij), q0 = __builtin_amdgcn_readfirstlane(tk.q0);
-        const int type = type_nq & 255, nq = type_nq >> 8, i = ij & 0xffff, j = ij >> 16;
+        const int type = type_nq & 255, nq = (type_nq >> 8) & 255, rows = max(type_nq >> 16, 1), i = ij & 0xffff, j = ij >> 16;
         const int k = P.sn_col0[s + 1] - P.sn_col0[s];
         const int f = (int)(P.row_ptr[s + 1] - P.row_ptr[s]);
         const int KB = (k + 127) >> 7;
         const int TB = KB + ((f - k + 127) >> 7);
         const int* st = P.df_state + P.df_state_pos[s];
-        // up to three states to wait for: (address, least value)
-        const int* a0; const int* a1; const int* a2;
-        int v0, v1, v2;
-        if (type == kDfD) { a0 = a1 = a2 = st + (size_t)i * TB + i; v0 = v1 = v2 = i; }
-        else if (type == kDfT) { a0 = st + (size_t)j * TB + j; v0 = j + 1; a1 = a2 = st + (size_t)i * TB + j; v1 = v2 = j; }
-        else if (type == kDfTU) { a0 = a1 = st + (size_t)i * TB + j; v0 = v1 = j; a2 = st + (size_t)i * TB + i; v2 = j; }      // the tiles (q + 1, q) and (q + 1, q + 1), q = j; D(q) is awaited inside the task
-        else {
+        // the tile states the task waits for, one per lane of the wave: (address, least value); the other lanes hold a condition
+        // that is always true
+        const int ln = tid & 63;
+        const int* addr = st;
+        int need = -(1 << 30);
+        if (type == kDfD) { if (ln == 0) { addr = st + (size_t)i * TB + i; need = i; } }
+        else if (type == kDfT) {
+          if (ln == 0) { addr = st + (size_t)j * TB + j; need = j + 1; }
+          if (ln == 1) { addr = st + (size_t)i * TB + j; need = j; }
+        } else if (type == kDfTU) {      // the tiles (q + 1, q) and (q + 1, q + 1), q = j; D(q) is awaited inside the task
+          if (ln == 0) { addr = st + (size_t)i * TB + j; need = j; }
+          if (ln == 1) { addr = st + (size_t)i * TB + i; need = j; }
+        } else {
           const int ql = q0 + nq - 1;
-          a0 = st + (size_t)i * TB + ql; v0 = ql + 1;
-          a1 = st + (size_t)j * TB + ql; v1 = ql + 1;
-          a2 = st + (size_t)i * TB + j; v2 = q0;
+          if (ln < rows) { addr = st + (size_t)(i + ln) * TB + ql; need = ql + 1; }                   // row operands
+          else if (ln < 2 * rows) { addr = st + (size_t)(i + ln - rows) * TB + j; need = q0; }        // the tiles themselves
+          else if (ln == 2 * rows) { addr = st + (size_t)j * TB + ql; need = ql + 1; }                // column operand
         }
-        if (drop) v2 += 1 << 20;      // tests: a hand-off that never comes
+        if (drop && ln == 0) need += 1 << 20;      // tests: a hand-off that never comes
         int spins = 0;
         for (;;) {
-          const int c0 = __builtin_amdgcn_readfirstlane(ld_state(a0)), c1 = __builtin_amdgcn_readfirstlane(ld_state(a1)), c2 = __builtin_amdgcn_readfirstlane(ld_state(a2));
-          if (c0 >= v0 && c1 >= v1 && c2 >= v2) break;
+          if (__builtin_amdgcn_ballot_w64(ld_state(addr) >= need) == ~0ull) break;
           // the stop flag of the delta loop (retries only) and the time-out word end every wait
           const int stop = P.want_neg >= 0 ? __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&P.counters[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : 0;
           const int dead = __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&P.counters[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
           if (stop | dead) { ok = 0; break; }
           if (++spins >= (1 << 21)) {
-            if ((tid & 63) == 0) { atomicAdd(&P.counters[3], 1ull); atomicExch(&P.counters[5], 1ull); }
+            if (ln == 0) { atomicAdd(&P.counters[3], 1ull); atomicExch(&P.counters[5], 1ull); }
             ok = 0;
             break;
           }
@@ -475,15 +544,14 @@ __global__ __launch_bounds__(kDfThreads, 1) void k_front_dataflow(DevPlan P, con
     const int type_nq = __builtin_amdgcn_readfirstlane(tk.type_nq);
     const int ij = __builtin_amdgcn_readfirstlane(tk.ij);
     const int q0 = __builtin_amdgcn_readfirstlane(tk.q0);
-    const int type = type_nq & 255, nq = type_nq >> 8, i = ij & 0xffff, j = ij >> 16;
+    const int type = type_nq & 255, nq = (type_nq >> 8) & 255, rows = max(type_nq >> 16, 1), i = ij & 0xffff, j = ij >> 16;
     const int k = P.sn_col0[s + 1] - P.sn_col0[s];
     const int f = (int)(P.row_ptr[s + 1] - P.row_ptr[s]);
     const int KB = (k + 127) >> 7;
     const int TB = KB + ((f - k + 127) >> 7);
     int* st = P.df_state + P.df_state_pos[s];
     int* mine;
-    int* mine2 = nullptr;      // TU publishes two tiles (the same new value)
-    int newv;
+    int newv, npub = 1;
     if (type == kDfD) {
       if (!(dbg & 1)) diag2_body<true>(P, s, i, 128, tol, sm);
       mine = st + (size_t)i * TB + i; newv = i + 1;
@@ -491,20 +559,19 @@ __global__ __launch_bounds__(kDfThreads, 1) void k_front_dataflow(DevPlan P, con
       if (!(dbg & 2)) df_trsm_tile(P, s, j, df_block_lo(i, KB, k, f), df_block_lo(i + 1, KB, k, f), sm);
       mine = st + (size_t)i * TB + j; newv = j + 1;
     } else if (type == kDfTU) {
-      if (!df_tu_tile(P, s, j, df_block_lo(i, KB, k, f), df_block_lo(i + 1, KB, k, f), st + (size_t)j * TB + j, j + 1, &s_ctl[2], sm, tlog ? tlog + (size_t)t * 8 + 4 : nullptr)) return;
+      if (!df_tu_tile(P, s, j, df_block_lo(i, KB, k, f), df_block_lo(i + 1, KB, k, f), st + (size_t)j * TB + j, j + 1, st + (size_t)i * TB + i, &s_ctl[2], sm, tlog ? tlog + (size_t)t * 8 + 4 : nullptr)) return;
       mine = st + (size_t)i * TB + j; newv = j + 1;
-      mine2 = st + (size_t)i * TB + i;
     } else {
       const int j0 = q0 * 128;
-      if (!(dbg & 4)) df_syrk_tile(P, s, j0, min(nq * 128, k - j0), df_block_lo(i, KB, k, f), df_block_lo(j, KB, k, f), df_block_lo(i + 1, KB, k, f), df_block_lo(j + 1, KB, k, f), sm);
-      mine = st + (size_t)i * TB + j; newv = q0 + nq;
+      if (!(dbg & 4)) df_syrk_tiles(P, s, j0, min(nq * 128, k - j0), i, rows, j, KB, k, sm);
+      mine = st + (size_t)i * TB + j; newv = q0 + nq; npub = rows;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every storing wave: its sc1 stores have been acknowledged
     __syncthreads();                                      // ... and every wave is done with the LDS of this task and with s_ctl
     if (tlog && tid == 0) tlog[(size_t)t * 8 + 2] = wall_clock64();
-    if (wave == 0) {
-      __hip_atomic_store(mine, newv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // the same word from every lane of the wave
-      if (mine2) __hip_atomic_store(mine2, newv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (wave == 0) {      // lane r publishes row tile r of the task (one tile for every kind but the bulk updates)
+      const int ln = tid & 63;
+      if (ln < npub) __hip_atomic_store(mine + (size_t)ln * TB, newv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }
@@ -525,7 +592,8 @@ std::string df_setup(Numeric& N) {
   int dev = 0, ncu = 256;
   if (hipGetDevice(&dev) == hipSuccess) { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ncu = pr.multiProcessorCount; }
   N.df_workers = getenv("OKKT_DF_WORKERS") ? std::max(1, atoi(getenv("OKKT_DF_WORKERS"))) : ncu;
-  N.df_group = getenv("OKKT_DF_GROUP") ? std::max(1, std::min(atoi(getenv("OKKT_DF_GROUP")), 4)) : 2;
+  N.df_group = getenv("OKKT_DF_GROUP") ? std::max(1, std::min(atoi(getenv("OKKT_DF_GROUP")), 4)) : 4;
+  N.df_rows = getenv("OKKT_DF_ROWS") ? std::max(1, std::min(atoi(getenv("OKKT_DF_ROWS")), 8)) : 1;
   auto do_sched = [&](std::vector<LevelSchedule>& levels) {
     for (LevelSchedule& L : levels) {
       Segment& g = L.seg[3];
@@ -544,7 +612,7 @@ std::string df_setup(Numeric& N) {
         g.df_flops += (double)k * f * f - (double)k * k * f + (double)k * k * k / 3.0;
       }
       double model = 0;
-      df_build_queue(fronts, N.df_workers, N.df_group, q, &model);
+      df_build_queue(fronts, N.df_workers, N.df_group, N.df_rows, q, &model);
       g.df_off = (int64_t)all.size();
       g.df_cnt = (int)q.size();
       g.df_head = nheads++;

@@ -21,6 +21,7 @@
 // together with D(q): its worker has the rows of its tiles in flight while the diagonal block is being factored.
 #include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 #include <functional>
 #include <queue>
 #include <vector>
@@ -31,11 +32,13 @@ namespace okkt {
 
 namespace {
 
+constexpr int kLonePanels = 2;
+
 struct FrontGrid {
   int f, k, KB, TB;
   int64_t offD, offT, offTU, offU;   // first task index of each kind
   std::vector<int> tq;               // [KB] prefix of the T tasks per panel
-  std::vector<int64_t> uoff;         // [TB * TB] first U task of tile (i, j)
+  std::vector<std::vector<std::vector<int64_t>>> unode;   // [column j][group c][row i]: the U task that holds tile (i, j) for that group
   std::vector<std::vector<int>> gstart;   // [TB] first panel of every update group of tile column j, plus the end
   int npanels(int j) const { return std::min(j, KB); }                      // panels tile column j receives
   // index of the group of column j that ENDS with panel q, or -1
@@ -48,10 +51,18 @@ struct FrontGrid {
 
 }  // namespace
 
-void df_build_queue(const std::vector<DfFront>& fronts, int workers, int group, std::vector<DfTask>& out, double* model_us) {
+void df_build_queue(const std::vector<DfFront>& fronts, int workers, int group, int rows_per_task, std::vector<DfTask>& out, double* model_us) {
   const int G = std::max(1, group);
+  const int RT = std::max(1, std::min(rows_per_task, 8));
+  // Time model (us, measured on MI355X with one workgroup per CU: D 39-45, T 25-32, U 25-30 at K = 128 and 45-52 at K = 256, TU 40
+  // behind its D).  The chain tasks D and TU enter the model SHORTER than they are (chain_scale): a chain task that sits in the
+  // queue behind bulk tasks of the same readiness is popped late and the whole chain slips (priority inversion, seen as 75-105 us
+  // between diagonal blocks instead of 45 in the bulk-bound phase of the S-metric root); one that is popped early only costs a
+  // waiting workgroup.
+  static const float chain_scale = getenv("OKKT_DF_MODEL_CHAIN") ? (float)atof(getenv("OKKT_DF_MODEL_CHAIN")) : 0.6f;
+  static const float bulk_scale = getenv("OKKT_DF_MODEL_BULK") ? (float)atof(getenv("OKKT_DF_MODEL_BULK")) : 1.0f;
   std::vector<FrontGrid> grids(fronts.size());
-  struct Node { int front; int type; int i, j, q0, nq; int ndep; float dur; int64_t key; };
+  struct Node { int front; int type; int i, j, q0, nq; int ndep; float dur; int64_t key; int rows; };
   std::vector<Node> nodes;
   for (size_t a = 0; a < fronts.size(); ++a) {
     FrontGrid& g = grids[a];
@@ -63,10 +74,14 @@ void df_build_queue(const std::vector<DfFront>& fronts, int workers, int group, 
     g.gstart.assign(TB, std::vector<int>());
     for (int j = 0; j < TB; ++j) {
       const int np = g.npanels(j);
-      const int paired = j < KB ? std::max(np - 1, 0) : np;     // a pivot column takes its last panel alone
+      // a pivot column takes its last panels alone (K = 128): the last one is what the next diagonal block / panel tile waits
+      // for, the one before it becomes available one step earlier and must be done by then; everything older comes `group` panels
+      // at a time (K = 512 at the default: 64 us of MFMA work for the 20 us a task pays around it)
+      const int lone = j < KB ? std::min(np, kLonePanels) : 0;
+      const int grouped = np - lone;
       std::vector<int>& gs = g.gstart[j];
-      for (int q0 = 0; q0 < paired; q0 += G) gs.push_back(q0);
-      if (j < KB && np > 0) gs.push_back(np - 1);
+      for (int q0 = 0; q0 < grouped; q0 += G) gs.push_back(q0);
+      for (int q0 = grouped; q0 < np; ++q0) gs.push_back(q0);
       gs.push_back(np);
     }
     // priority: target column relative to the end of the pivot block (a front with a longer chain ahead of it goes first), then
@@ -75,30 +90,41 @@ void df_build_queue(const std::vector<DfFront>& fronts, int workers, int group, 
     g.offD = (int64_t)nodes.size();
     for (int q = 0; q < KB; ++q) {
       const int nb = std::min(128, g.k - 128 * q);
-      nodes.push_back({(int)a, kDfD, q, q, q, 1, q > 0 ? 1 : 0, 5.0f + 2.3f * (float)((nb + 7) / 8), key(q, 0, q, q)});
+      nodes.push_back({(int)a, kDfD, q, q, q, 1, q > 0 ? 1 : 0, chain_scale * (5.0f + 2.3f * (float)((nb + 7) / 8)), key(q, 0, q, q), 1});
     }
     g.offTU = (int64_t)nodes.size();
     for (int q = 0; q + 1 < KB; ++q)     // needs D(q) [released when D(q) STARTS], the updates of (q + 1, q) and the earlier updates of (q + 1, q + 1)
-      nodes.push_back({(int)a, kDfTU, q + 1, q, q, 1, 1 + (q > 0 ? 2 : 0), 0.0f, key(q, 1, q + 1, q)});
+      nodes.push_back({(int)a, kDfTU, q + 1, q, q, 1, 1 + (q > 0 ? 2 : 0), 0.0f, key(q, 1, q + 1, q), 1});
     g.offT = (int64_t)nodes.size();
     g.tq.assign(KB + 1, 0);
     for (int q = 0; q < KB; ++q) {
       const int first = q + 1 < KB ? q + 2 : q + 1;             // block row q + 1 belongs to TU(q)
       g.tq[q + 1] = g.tq[q] + std::max(TB - first, 0);
-      for (int i = first; i < TB; ++i) nodes.push_back({(int)a, kDfT, i, q, q, 1, 1 + (q > 0 ? 1 : 0), 26.0f, key(q, 2, i, q)});
+      for (int i = first; i < TB; ++i) nodes.push_back({(int)a, kDfT, i, q, q, 1, 1 + (q > 0 ? 1 : 0), bulk_scale * 28.0f, key(q, 2, i, q), 1});
     }
-    g.offU = (int64_t)nodes.size();
-    g.uoff.assign((size_t)TB * TB, -1);
-    for (int i = 0; i < TB; ++i)
-      for (int j = 0; j <= i; ++j) {
-        g.uoff[(size_t)i * TB + j] = (int64_t)nodes.size();
-        const std::vector<int>& gs = g.gstart[j];
-        for (size_t c = 0; c + 1 < gs.size(); ++c) {
-          const int q0 = gs[c], nq = gs[c + 1] - gs[c];
-          const bool in_tu = i == j && j < KB && c + 2 == gs.size();       // the last panel of a diagonal pivot tile: part of TU(j - 1)
-          nodes.push_back({(int)a, in_tu ? -1 : kDfU, i, j, q0, nq, (i != j ? 2 : 1) + (q0 > 0 ? 1 : 0), 7.0f + 0.165f * 128.0f * (float)nq, key(j, 3, i, q0)});
+    // Update tasks.  The groups of a column that are not the lone last panel of a pivot column are bulk work: the tiles below the
+    // diagonal tile are taken `rows_per_task` at a time (one pop, one wait, one acquire and one drain per task, and the C tile of
+    // the next row block is in flight while the current one is computed: dataflow.hip, df_syrk_tiles).  The last panel of a pivot
+    // column stays one tile per task: the panel tile below it (or the next diagonal block) waits for exactly that tile.
+    g.unode.assign(TB, std::vector<std::vector<int64_t>>());
+    for (int j = 0; j < TB; ++j) {
+      const std::vector<int>& gs = g.gstart[j];
+      const int ng = (int)gs.size() - 1;
+      g.unode[j].assign(ng, std::vector<int64_t>(TB, -1));
+      for (int c = 0; c < ng; ++c) {
+        const int q0 = gs[c], nq = gs[c + 1] - gs[c];
+        const bool lone_last = j < KB && c + 1 == ng;
+        const int R = (j < KB && c + kLonePanels >= ng) ? 1 : RT;
+        for (int i = j; i < TB;) {
+          const int rows = i == j ? 1 : std::min(R, TB - i);
+          const bool in_tu = i == j && lone_last;                  // the last panel of a diagonal pivot tile: part of TU(j - 1)
+          const int ndep = (i != j ? rows + 1 : 1) + (c > 0 ? 1 : 0);
+          for (int r = 0; r < rows; ++r) g.unode[j][c][i + r] = (int64_t)nodes.size();
+          nodes.push_back({(int)a, in_tu ? -1 : kDfU, i, j, q0, nq, ndep, bulk_scale * (6.0f + 0.16f * 128.0f * (float)nq * (float)rows + 4.0f * (float)(rows - 1)), key(j, 3, i, q0), rows});
+          i += rows;
         }
       }
+    }
   }
   auto t_index = [&](const FrontGrid& g, int i, int q) -> int64_t {       // T(i, q) or, for i == q + 1 < KB, TU(q)
     if (q + 1 < g.KB) return i == q + 1 ? g.offTU + q : g.offT + g.tq[q] + (i - q - 2);
@@ -120,12 +146,12 @@ void df_build_queue(const std::vector<DfFront>& fronts, int workers, int group, 
       const int64_t x = ready.top().second;
       ready.pop();
       Node& nd = nodes[x];
-      out.push_back({fronts[nd.front].s, nd.type | (nd.nq << 8), nd.i | (nd.j << 16), nd.q0});
+      out.push_back({fronts[nd.front].s, nd.type | (nd.nq << 8) | (nd.rows << 16), nd.i | (nd.j << 16), nd.q0});
       running.push({now + nd.dur, x});
       --idle;
       if (nd.type == kDfD && nd.i + 1 < grids[nd.front].KB) {      // TU(q) starts beside D(q) and ends 24 us behind it
         const int64_t tu = grids[nd.front].offTU + nd.i;
-        nodes[tu].dur = nd.dur + 24.0f;
+        nodes[tu].dur = nd.dur + chain_scale * 40.0f;
         release(tu);
       }
     }
@@ -142,23 +168,38 @@ void df_build_queue(const std::vector<DfFront>& fronts, int workers, int group, 
       for (int i = (q + 1 < KB ? q + 2 : q + 1); i < TB; ++i) release(t_index(g, i, q));
     } else if (nd.type == kDfT || nd.type == kDfTU) {
       // block row i of panel q is done: the update groups whose LAST panel is q and that read block row i as the row operand
-      // (tiles (i, j), q < j <= i) or as the column operand (tiles (i2, i), i2 >= i)
+      // (tiles (i, j), q < j <= i) or as the column operand (tiles (i2, i), i2 > i: once per task)
       const int i = nd.i, q = nd.j;
       for (int j = q + 1; j <= i; ++j) {
         if (nd.type == kDfTU && j == i) continue;                 // its own diagonal tile: updated inside the task
         const int gq = g.group_ending(j, q);
-        if (gq >= 0) release(g.uoff[(size_t)i * TB + j] + gq);
+        if (gq >= 0) release(g.unode[j][gq][i]);
       }
-      { const int gq = g.group_ending(i, q); if (gq >= 0) for (int i2 = i + 1; i2 < TB; ++i2) release(g.uoff[(size_t)i2 * TB + i] + gq); }
+      {
+        const int gq = g.group_ending(i, q);
+        if (gq >= 0) {
+          int64_t last = -1;
+          for (int i2 = i + 1; i2 < TB; ++i2) { const int64_t x2 = g.unode[i][gq][i2]; if (x2 != last) { release(x2); last = x2; } }
+        }
+      }
       if (nd.type == kDfTU) release(g.offD + i);                  // tile (q + 1, q + 1) has received panel q
     } else {
-      const int i = nd.i, j = nd.j;
-      const int np = g.npanels(j);
-      if (nd.q0 + nd.nq < np) {
-        const int64_t nxt = x + 1;                               // the next group of the same tile
-        if (nodes[nxt].type >= 0) release(nxt);
-        else release(g.offTU + (j - 1));                          // ... which is the one inside TU(j - 1)
-      } else if (j < KB) release(i == j ? g.offD + j : t_index(g, i, j));
+      // an update task: the next group of its tiles (one task with the same rows, or one task per tile when the next group is the
+      // lone last panel of a pivot column), or what waits for the finished tiles
+      const int j = nd.j;
+      const int ng = (int)g.gstart[j].size() - 1;
+      const int c = g.group_ending(j, nd.q0 + nd.nq - 1);
+      if (c + 1 < ng) {
+        int64_t last = -1;
+        for (int r = 0; r < nd.rows; ++r) {
+          const int64_t x2 = g.unode[j][c + 1][nd.i + r];
+          if (x2 == last) continue;
+          last = x2;
+          if (nodes[x2].type >= 0) release(x2); else release(g.offTU + (j - 1));      // ... the one inside TU(j - 1)
+        }
+      } else if (j < KB) {
+        for (int r = 0; r < nd.rows; ++r) release(nd.i + r == j ? g.offD + j : t_index(g, nd.i + r, j));
+      }
     }
   }
   if (model_us) *model_us = now;

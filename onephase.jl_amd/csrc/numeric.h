@@ -85,11 +85,11 @@ struct DevPlan {
 
 // one task of the dataflow factorisation (dataflow_sched.cpp builds the queues, dataflow.hip runs them)
 enum { kDfD = 0, kDfT = 1, kDfU = 2, kDfTU = 3 };
-struct DfTask { int front; int type_nq; int ij; int q0; };     // type | nq << 8, i | j << 16
+struct DfTask { int front; int type_nq; int ij; int q0; };     // type | nq << 8 | rows << 16 (update tasks: tiles (i .. i + rows - 1, j)), i | j << 16
 struct DfFront { int s, f, k; };
 // queue of the fronts of one level in the start order of a simulated list schedule on `workers` workers; `group` panels per
 // update task where the tile allows it; model_us = the simulated makespan
-void df_build_queue(const std::vector<DfFront>& fronts, int workers, int group, std::vector<DfTask>& out, double* model_us);
+void df_build_queue(const std::vector<DfFront>& fronts, int workers, int group, int rows_per_task, std::vector<DfTask>& out, double* model_us);
 
 constexpr int kCountSlots = 64, kCountStride = 16;
 #ifndef OKKT_SOLVE_BLOCK
@@ -191,7 +191,8 @@ struct Numeric {
   // big fronts of a level as ONE persistent launch (dataflow.hip): tasks on 128 x 128 tiles popped from a queue in a precomputed order,
   // hand-offs through per-tile states.  OKKT_DATAFLOW=0 switches back to the per-step launches of factor_sched.
   int dataflow = 1;
-  int df_group = 2;                    // panels per update task (K = 128 * group) where the column allows it
+  int df_group = 4;                    // panels per update task (K = 128 * group) where the column allows it (OKKT_DF_GROUP; S-metric 19.1 / 18.3 / 18.2 ms at 2 / 3 / 4)
+  int df_rows = 1;                     // row tiles per bulk update task (OKKT_DF_ROWS; 2 and 4 measured slower: the coarser tasks cost the schedule more than the shared prologue saves)
   int df_workers = 256;                // workers of the simulated schedule (and the grid of the launch): one workgroup per CU
   DfTask* df_tasks = nullptr;
   int* df_heads = nullptr;

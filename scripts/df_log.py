@@ -28,6 +28,8 @@ for n_, l_ in enumerate(launches):
 which = int(sys.argv[2]) if len(sys.argv) > 2 else int(np.argmax([len(l) for l in launches]))
 L = np.array(launches[which], dtype=np.int64)
 idx, front, typ, ti, tj, q0, nq, worker, pop, ready, end = L.T[:11]
+nrows = np.maximum(nq >> 8, 1)
+nq = nq & 255
 marks = L[:, 11:15] if L.shape[1] >= 15 else None
 t0 = pop.min()
 pop = (pop - t0) / 100.0
@@ -40,7 +42,7 @@ for k in (0, 1, 2, 3):
     m = typ == k
     if not m.any():
         continue
-    for sel, label in ((m, names[k]),) if k != 2 else ((m & (nq == 1), "U K=128"), (m & (nq == 2), "U K=256"), (m & (nq > 2), "U K>256")):
+    for sel, label in ((m, names[k]),) if k != 2 else ((m & (nq == 1), "U K=128"), (m & (nq == 2), "U K=256"), (m & (nq == 3), "U K=384"), (m & (nq >= 4), "U K=512")):
         if not sel.any():
             continue
         body = end[sel] - ready[sel]
@@ -77,7 +79,7 @@ for q in qs:
 if marks is not None and (typ == 3).any():
     m = typ == 3
     mk = (marks[m] - t0) / 100.0
-    print(f"  TU phases (us, mean): ready -> D arrived {np.mean(mk[:, 0] - ready[m]):.1f}, rows solved +{np.mean(mk[:, 1] - mk[:, 0]):.1f}, stored + W in LDS +{np.mean(mk[:, 2] - mk[:, 1]):.1f}, tile updated +{np.mean(mk[:, 3] - mk[:, 2]):.1f}, C stored + drained +{np.mean(end[m] - mk[:, 3]):.1f}")
+    print(f"  TU phases (us, mean): ready -> D arrived {np.mean(mk[:, 0] - ready[m]):.1f}, rows solved +{np.mean(mk[:, 1] - mk[:, 0]):.1f}, W in LDS +{np.mean(mk[:, 2] - mk[:, 1]):.1f}, tile updated, stored and published +{np.mean(mk[:, 3] - mk[:, 2]):.1f}, W and L stored + drained +{np.mean(end[m] - mk[:, 3]):.1f}")
 if len(qs) > 1:
     per = (D[qs[-1]][2] - D[qs[0]][1]) / (len(qs) - 1)
     print(f"  mean distance between diagonal blocks {per:.1f} us")

@@ -14,18 +14,19 @@ from onephase_jl_amd import _lib
 D, T, U, TU = 0, 1, 2, 3
 
 
-def build_queue(fronts, workers=256, group=2):
+def build_queue(fronts, workers=256, group=2, rows=1):
     lib = _lib.load()
     n = len(fronts)
     f = (C.c_int32 * n)(*[a for a, _ in fronts])
     k = (C.c_int32 * n)(*[b for _, b in fronts])
     model = C.c_double(0)
+    group = group | (rows << 8)
     cnt = lib.okkt_debug_dataflow_queue(n, f, k, workers, group, None, 0, C.byref(model))
     assert cnt >= 0
     buf = (C.c_int32 * (4 * max(cnt, 1)))()
     assert lib.okkt_debug_dataflow_queue(n, f, k, workers, group, buf, cnt, C.byref(model)) == cnt
     q = np.frombuffer(buf, dtype=np.int32).reshape(-1, 4)[:cnt]
-    tasks = [(int(a), int(b) & 255, int(b) >> 8, int(c) & 0xFFFF, int(c) >> 16, int(d)) for a, b, c, d in q]
+    tasks = [(int(a), int(b) & 255, (int(b) >> 8) & 255, int(c) & 0xFFFF, int(c) >> 16, int(d), max(int(b) >> 16, 1)) for a, b, c, d in q]
     return tasks, model.value
 
 
@@ -63,47 +64,49 @@ def replay(fronts, tasks, group):
         grids.append((KB, TB, b))
         states.append(np.zeros((TB, TB), dtype=int))
         Ws.append(np.zeros((f, k)))
-    for (a, typ, nq, i, j, q0) in tasks:
-        f, k = fronts[a]
-        KB, TB, b = grids[a]
-        st, A, W = states[a], mats[a], Ws[a]
-        ri = slice(b[i], b[i + 1])
-        if typ == D:
-            assert i == j and i < KB and st[i, i] == i, ("D out of order", a, i, st[i, i])
-            blk = A[ri, ri]
-            nb = blk.shape[0]
-            for c in range(nb):
-                d = blk[c, c]
-                l = blk[c + 1:, c] / d
-                blk[c + 1:, c + 1:] -= np.outer(l, blk[c + 1:, c])
-                blk[c + 1:, c] = l
-            st[i, i] = i + 1
-        elif typ in (T, TU):
-            q = j
-            assert i > q and q < KB and st[q, q] >= q + 1 and st[i, q] == q, ("T out of order", a, i, q)
-            if typ == TU:
-                assert i == q + 1 and i < KB and st[i, i] == q, ("TU out of order", a, i, q, st[i, i])
-            cq = slice(b[q], b[q + 1])
-            Lqq = np.tril(A[cq, cq], -1) + np.eye(b[q + 1] - b[q])
-            d = np.diag(A[cq, cq])
-            Wt = np.linalg.solve(Lqq, A[ri, cq].T).T
-            W[ri, cq] = Wt
-            A[ri, cq] = Wt / d
-            st[i, q] = q + 1
-            if typ == TU:      # ... and the diagonal tile of block row i receives panel q
-                A[ri, ri] -= np.tril(W[ri, cq] @ A[ri, cq].T)
-                st[i, i] = q + 1
-        else:
-            ql = q0 + nq - 1
-            assert 1 <= nq <= group and i >= j > ql and ql < KB, ("U shape", a, i, j, q0, nq)
-            assert st[i, ql] >= ql + 1 and st[j, ql] >= ql + 1 and st[i, j] == q0, ("U out of order", a, i, j, q0, nq, st[i, j])
-            cj = slice(b[j], b[j + 1])
-            kk = slice(b[q0], b[ql + 1])
-            upd = W[ri, kk] @ A[cj, kk].T
-            if i == j:
-                upd = np.tril(upd)
-            A[ri, cj] -= upd
-            st[i, j] = q0 + nq
+    for (a, typ, nq, i0, j, q0, R) in tasks:
+      assert R == 1 or (typ == U and i0 > j), (typ, i0, j, R)
+      for i in range(i0, i0 + R):
+          f, k = fronts[a]
+          KB, TB, b = grids[a]
+          st, A, W = states[a], mats[a], Ws[a]
+          ri = slice(b[i], b[i + 1])
+          if typ == D:
+              assert i == j and i < KB and st[i, i] == i, ("D out of order", a, i, st[i, i])
+              blk = A[ri, ri]
+              nb = blk.shape[0]
+              for c in range(nb):
+                  d = blk[c, c]
+                  l = blk[c + 1:, c] / d
+                  blk[c + 1:, c + 1:] -= np.outer(l, blk[c + 1:, c])
+                  blk[c + 1:, c] = l
+              st[i, i] = i + 1
+          elif typ in (T, TU):
+              q = j
+              assert i > q and q < KB and st[q, q] >= q + 1 and st[i, q] == q, ("T out of order", a, i, q)
+              if typ == TU:
+                  assert i == q + 1 and i < KB and st[i, i] == q, ("TU out of order", a, i, q, st[i, i])
+              cq = slice(b[q], b[q + 1])
+              Lqq = np.tril(A[cq, cq], -1) + np.eye(b[q + 1] - b[q])
+              d = np.diag(A[cq, cq])
+              Wt = np.linalg.solve(Lqq, A[ri, cq].T).T
+              W[ri, cq] = Wt
+              A[ri, cq] = Wt / d
+              st[i, q] = q + 1
+              if typ == TU:      # ... and the diagonal tile of block row i receives panel q
+                  A[ri, ri] -= np.tril(W[ri, cq] @ A[ri, cq].T)
+                  st[i, i] = q + 1
+          else:
+              ql = q0 + nq - 1
+              assert 1 <= nq <= max(group, 1) and i >= j > ql and ql < KB, ("U shape", a, i, j, q0, nq)
+              assert st[i, ql] >= ql + 1 and st[j, ql] >= ql + 1 and st[i, j] == q0, ("U out of order", a, i, j, q0, nq, st[i, j])
+              cj = slice(b[j], b[j + 1])
+              kk = slice(b[q0], b[ql + 1])
+              upd = W[ri, kk] @ A[cj, kk].T
+              if i == j:
+                  upd = np.tril(upd)
+              A[ri, cj] -= upd
+              st[i, j] = q0 + nq
     for a, (f, k) in enumerate(fronts):
         KB, TB, b = grids[a]
         for i in range(TB):
@@ -128,9 +131,9 @@ CASES = [
 
 
 @pytest.mark.parametrize("fronts", CASES)
-@pytest.mark.parametrize("group", [1, 2, 3])
-def test_queue_replays_to_the_partial_factorisation(fronts, group):
-    tasks, model = build_queue(fronts, workers=16, group=group)
+@pytest.mark.parametrize("group,rows", [(1, 1), (2, 1), (3, 2), (2, 4)])
+def test_queue_replays_to_the_partial_factorisation(fronts, group, rows):
+    tasks, model = build_queue(fronts, workers=16, group=group, rows=rows)
     assert model > 0
     replay(fronts, tasks, group)
 
@@ -148,20 +151,20 @@ def test_queue_is_the_same_every_time_and_scales():
     nTU = sum(1 for t in a if t[0] == 0 and t[1] == TU)
     assert nD == KB and nTU == KB - 1 and nT == sum(TB - 1 - q for q in range(KB))
     # the last panel of a pivot column comes alone (K = 128): it is what the next diagonal block / panel tile waits for
-    for (fr, typ, nq, i, j, q0) in a:
-        if fr == 0 and typ == U and j < KB and q0 + nq == j:
+    for (fr, typ, nq, i, j, q0, R) in a:
+        if fr == 0 and typ == U and j < KB and q0 + nq >= j - 1:
             assert nq == 1
 
 
 def test_chain_is_woven_into_the_bulk():
     """On a front with many tiles the next diagonal block must not sit behind the whole trailing update of the previous
     panel: its position in the queue is early among that panel's update tasks."""
-    tasks, _ = build_queue([(6000, 6000)], workers=256, group=2)
+    tasks, _ = build_queue([(6000, 6000)], workers=256, group=2, rows=4)
     pos = {}
-    for p, (a, typ, nq, i, j, q0) in enumerate(tasks):
+    for p, (a, typ, nq, i, j, q0, R) in enumerate(tasks):
         pos.setdefault((typ, i, j, q0), p)
     for q in (2, 10, 20):
         d_next = pos[(D, q + 1, q + 1, q + 1)]
         assert pos[(D, q, q, q)] < pos[(TU, q + 1, q, q)] < d_next      # TU(q) is popped while D(q) runs (its loads are in flight by the time D(q) is done)
-        ups = [p for p, (a, typ, nq, i, j, q0) in enumerate(tasks) if typ == U and q0 <= q < q0 + nq and j > q + 1]
+        ups = [p for p, (a, typ, nq, i, j, q0, R) in enumerate(tasks) if typ == U and q0 <= q < q0 + nq and j > q + 1]
         assert ups and d_next < np.percentile(ups, 60), (q, d_next, np.percentile(ups, [10, 50, 90]))
