@@ -160,10 +160,11 @@ int okkt_dev_download(okkt_handle h, void* dst, const void* d_src, int64_t bytes
 int okkt_set_early_exit(okkt_handle h, int enable);
 /* the handle's HIP stream (hipStream_t as void*), for callers that time with their own events */
 void* okkt_get_stream(okkt_handle h);
-/* per-launch timing of the dominant kernel (the FP64-MFMA trailing update k_big_syrk): HIP events are
- * recorded around every launch on the handle's stream while enabled; okkt_get_profile returns the
- * number of launches since enabling, their summed duration and their summed algorithmic flops
- * (rem * (rem + 1) * nb per front and block column, DESIGN.md "Kernels") */
+/* per-launch timing of the dominant kernel (k_front_dataflow, the persistent launch that factors the big fronts of one level;
+ * with OKKT_DATAFLOW=0 the FP64-MFMA trailing update k_big_syrk of the per-step schedule): HIP events are recorded around
+ * every launch on the handle's stream while enabled; okkt_get_profile returns the number of launches since enabling, their
+ * summed duration and their summed algorithmic flops (k f^2 - k^2 f + k^3 / 3 per front of a dataflow launch; rem * (rem + 1) * nb
+ * per front and block column of a trailing update, DESIGN.md "Kernels") */
 int okkt_profile_dominant(okkt_handle h, int enable);
 int okkt_get_profile(okkt_handle h, int64_t* n_launches, double* total_ms, double* total_flops);
 /* Test hook, host only (no device, no handle): the task queue of the dataflow launch (csrc/dataflow.hip) for one level of

@@ -40,15 +40,11 @@ int solver_ensure_numeric(okkt_solver_s* h) {
   if (const char* df = getenv("OKKT_DATAFLOW")) h->N.dataflow = atoi(df);
   std::string e = numeric_setup(h->S, h->sopts, h->stream, h->N);
   if (const char* sh = getenv("OKKT_SPLIT_HEAD")) h->N.split_head = atoi(sh);
-  if (const char* dc = getenv("OKKT_DECOUPLE")) h->N.decouple = atoi(dc);
-  if (const char* af = getenv("OKKT_AHEAD_FIRST")) h->N.ahead_first = atoi(af);
   if (const char* d2 = getenv("OKKT_DIAG2")) h->N.diag2 = atoi(d2);
   if (const char* fd = getenv("OKKT_FUSE_DIAG_TRSM")) h->N.fuse_diag_trsm = atoi(fd);
-  if (const char* sf = getenv("OKKT_SOLVE_FORK")) h->N.solve_fork = atoi(sf);
   if (const char* ss = getenv("OKKT_SOLVE_SPLIT_SMALL")) h->N.solve_split_small = atoi(ss);
   if (const char* su = getenv("OKKT_SOLVE_FUSE")) h->N.solve_fuse = atoi(su);
   if (const char* sw = getenv("OKKT_SOLVE_FUSE_WIDE_MAX")) h->N.solve_fuse_wide_max = atoi(sw);
-  if (const char* dr = getenv("OKKT_DECOUPLE_MIN_ROWS")) h->N.decouple_min_rows = atoi(dr);
   if (const char* mt = getenv("OKKT_LA_MIN_TILES")) h->N.la_min_tiles = atoi(mt);
   if (!e.empty()) { numeric_release(h->N); return solver_set_error(h, OKKT_ERR_HIP, e); }
   h->numeric_ready = true;

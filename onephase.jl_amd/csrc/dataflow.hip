@@ -622,7 +622,6 @@ std::string df_setup(Numeric& N) {
   };
   do_sched(N.levels);
   do_sched(N.levels_top);
-  for (LaneSched& X : N.xlanes) do_sched(X.levels);
   N.n_df_heads = nheads;
   N.df_state_ints = total;
   auto up = [&](const void* src, size_t bytes, void** out) -> std::string {

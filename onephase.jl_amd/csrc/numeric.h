@@ -122,18 +122,10 @@ struct SolveLevel {
   int wide_off = 0, wide_cnt = 0, wide_maxf = 0, wide_maxk = 0;
 };
 
-// Lanes: independent subtrees of ONE factorisation that run side by side on separate streams of the same GPU (the two halves
-// below the top separator of a nested-dissection tree); lane 0 is `levels` / `slevels`, the others live here, the part of the
-// tree above them is `levels_top`.  Empty when the tree has no two substantial independent subtrees or the plan is partitioned
-// over several GPUs.
-struct LaneSched { std::vector<LevelSchedule> levels; std::vector<SolveLevel> slevels; hipStream_t stream = nullptr; };
 struct LaneStreams { hipStream_t main = nullptr, masked = nullptr, panel = nullptr, aux = nullptr; };
 
 struct Numeric {
   DevPlan d;
-  std::vector<LaneSched> xlanes;         // lanes 1, 2, ...
-  std::vector<hipEvent_t> solve_events;  // per-level fork / join of the sweeps (thin fronts beside wide fronts)
-  size_t solve_ev_used = 0;
   int solve_fuse = 1;                    // thin fronts: the two dependent launches of a level and sweep fused into one (in-launch hand-offs); OKKT_SOLVE_FUSE=0 switches back
   int solve_fuse_wide_max = 0;           // wide fronts: fused while the partial block products of a launch are at most this many workgroups (OKKT_SOLVE_FUSE_WIDE_MAX; 0 = never: measured neutral to slower, the consumers cannot start their panel loads before the hand-off)
   int* solve_flags = nullptr;            // [nsuper] monotonic y flags of the fused forward launches
@@ -142,12 +134,6 @@ struct Numeric {
   unsigned long long* solve_counters64 = nullptr;   // [nsuper] epoch-based arrival counters of the fused wide-front launches
   unsigned long long solve_epoch64 = 0;
   int solve_split_small = 400;           // panel GEMVs of the wide fronts: launches of fewer 64-row / 64-column workgroups than this use 32 rows / 16 columns per workgroup (OKKT_SOLVE_SPLIT_SMALL; 0 = never)
-  int solve_fork = 0;                    // OKKT_SOLVE_FORK=1: the wide fronts of a level on the auxiliary stream beside the thin ones
-  std::vector<hipEvent_t> lane_events;   // fork / join of the lanes
-  size_t lane_ev_used = 0;
-  bool early_before_top = false;         // lanes: the pivot counts are read once, between the lanes and the top of the tree
-  std::vector<double> lane_flops;        // dense-front flops per lane (statistics)
-  double lanes_top_flops = 0;
   std::vector<SolveLevel> slevels, slevels_top;
   hipEvent_t inv_event = nullptr;        // recorded behind the block inversions that the factorisation started on the auxiliary stream
   bool inv_wait = false;                 // ... which the next solve has to wait for
@@ -177,7 +163,6 @@ struct Numeric {
   hipStream_t stream_panel = nullptr;
   hipStream_t stream_aux = nullptr;     // off-critical-path part of the in-group panel updates
   int split_head = 1;
-  int ahead_first = 0;                   // OKKT_AHEAD_FIRST=1: look-ahead columns on the trailing update's stream ahead of it instead of beside it on the panel stream (measured slower: 23.1 -> 23.7 ms, the delayed trailing update costs more than the chain gains)
   int fuse_diag_trsm = 3;                // k_diag_trsm_fused, the diagonal block and the rows below it in one launch.  OKKT_FUSE_DIAG_TRSM: 0 never; 1 always (S-metric 23.7 -> 24.1 ms: the waiting trsm workgroups hold CUs the trailing update wants); 2 wherever the panels run in order (S-C5 +5 %: with many fronts per level they hold the CUs of the other fronts' diagonal blocks); 3 (default) in order AND at most OKKT_FUSE_MAX_FRONTS (8) fronts in the level: S-C3 3.53 -> 3.47 ms, S-C5 4.70 -> 4.67, S-metric unchanged
   int* chain_flags = nullptr;            // [nsuper] monotonic flags of those launches
   int chain_epoch = 0;
@@ -199,8 +184,6 @@ struct Numeric {
   int n_df_heads = 0;
   int64_t df_state_ints = 0;
   int diag2 = 1;                         // k_big_diag2 (role-split, pipelined) instead of k_big_diag; OKKT_DIAG2=0 switches back
-  int decouple = 0;                      // OKKT_DECOUPLE=1: single-block steps with the diagonal chain ahead of the wide trsm / trailing update (aux stream); measured slower
-  int decouple_min_rows = 256;           // ... while at least this many rows are left below the step
   int lookahead = 1;
   int sb_tail_rows = 4000;               // the inversion of the finished diagonal blocks starts once fewer rows than this remain
   int la_min_tiles = 600;                // rest triangle must hold at least this many 128 x 128 tiles

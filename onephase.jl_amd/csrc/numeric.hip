@@ -724,8 +724,7 @@ __global__ __launch_bounds__(256) void k_big_invert(DevPlan P, const int* __rest
 
 template <int NBLK>
 __global__ __launch_bounds__(256) void k_big_trsm(DevPlan P, const int* __restrict__ list, int step, int wcol0, int blk_lo) {
-  // blk_lo: first 64-row block of the panel this launch handles (the grid covers blocks blk_lo, blk_lo + 1, ...): the decoupled
-  // schedule solves the first 128 rows on the critical path and the rest beside the next diagonal block
+  // blk_lo: first 64-row block of the panel this launch handles (the grid covers blocks blk_lo, blk_lo + 1, ...)
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int s = list[blockIdx.y];
   if (stop_requested_wg(P)) return;
@@ -775,9 +774,7 @@ __global__ __launch_bounds__(384) void k_diag_trsm_fused(DevPlan P, const int* _
 // staged 128 rows deep (the DMA shape stays), only the first 64 are read.
 template <int DBG, int HEAD, int TC = 128>
 __global__ __launch_bounds__(kSyrkNW * 64, kSyrkNW / 2) void k_big_syrk(DevPlan P, const int* __restrict__ list, int stepA, int npan,
-                                                                        int tstep, int NB, int wofs, int csplit, int sub0) {
-  // sub0 (kSyrkTrail only): 0 the whole region, 1 only its first 128 x 128 tile (the next diagonal block: critical path of the
-  // decoupled schedule), 2 everything but that tile
+                                                                        int tstep, int NB, int wofs, int csplit) {
   static_assert(TC == 128 || (TC == 64 && HEAD == kSyrkTrail), "64-column tiles exist for the trailing triangle only");
   // Applies the panels [stepA, stepA + npan) (K = up to npan * NB columns, W panels side by side in wbuf from
   // column wofs) to the region that starts at block column tstep; K = GS * NB halves the C traffic per flop.
@@ -808,14 +805,10 @@ __global__ __launch_bounds__(kSyrkNW * 64, kSyrkNW / 2) void k_big_syrk(DevPlan 
   // XCD-aware order: consecutive tile indices (which share operand panels) stay on one XCD and its L2
   // `per` from THIS front's tile count, not from the grid (which is sized for the largest front of the level):
   // otherwise a smaller front of a batched launch runs on the first one or two XCDs only
-  int skip = 0;
-  if (HEAD == kSyrkTrail && sub0 == 1) ntiles = min(ntiles, TC == 128 ? 1 : 2);
-  else if (HEAD == kSyrkTrail && sub0 == 2) { skip = TC == 128 ? 1 : 2; ntiles = max(ntiles - skip, 0); }
   const int per = (ntiles + 7) >> 3;
   if ((int)(blockIdx.x >> 3) >= per) return;
   int idx = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
   if (idx >= ntiles) return;
-  idx += skip;
   int ti, tj;
   if (HEAD == kSyrkPanel) { ti = idx + (csplit == 2 ? 1 : 0); tj = 0; }
   else if (HEAD == kSyrkAhead) {
@@ -1050,29 +1043,6 @@ std::string numeric_setup(const Symbolic& S, const SymbolicOptions& opts, hipStr
   int64_t wtotal = 0;
   N.n_small = N.n_big = 0;
   const bool parted = S.nparts > 1 && (int)S.sn_owner.size() == ns;
-  // lanes (see numeric.h): only for an unpartitioned plan with the extra streams at hand
-  std::vector<int> lane_of;
-  N.xlanes.clear(); N.lane_flops.clear(); N.lanes_top_flops = 0; N.early_before_top = false;
-  {
-    const int want = getenv("OKKT_LANES") ? atoi(getenv("OKKT_LANES")) : 1;   // off by default: measured neutral
-    const int avail = 1 + (N.stream_aux ? 1 : 0) + (N.stream_aux && N.stream_panel ? 1 : 0);
-    const int nl = std::min(std::min(want, avail), 3);
-    if (!parted && nl >= 2) {
-      const double own_frac = getenv("OKKT_LANE_OWN_FRAC") ? atof(getenv("OKKT_LANE_OWN_FRAC")) : 0.08;
-      const double min_frac = getenv("OKKT_LANE_MIN_FRAC") ? atof(getenv("OKKT_LANE_MIN_FRAC")) : 0.05;
-      lane_cut(S, nl, own_frac, min_frac, lane_of, N.lane_flops, N.lanes_top_flops);
-      if (!lane_of.empty()) {
-        N.xlanes.resize(nl - 1);
-        for (int i = 1; i < nl; ++i) N.xlanes[i - 1].stream = i == 1 ? N.stream_aux : N.stream_panel;
-        if (getenv("OKKT_DEBUG_FRONTS")) {
-          fprintf(stderr, "okkt: %d lanes, flops", nl);
-          for (double x : N.lane_flops) fprintf(stderr, " %.3g", x);
-          fprintf(stderr, ", top %.3g\n", N.lanes_top_flops);
-        }
-      }
-    }
-  }
-  const bool laned = !lane_of.empty();
   // Tasks: a workgroup runs a whole subtree of small fronts, children before parents (the supernodes are numbered
   // in postorder, so a subtree is the index range [first descendant, root]); one launch per LEVEL OF TASKS instead of
   // one per level of fronts.  A banded KKT (the hanging chain of BASELINE config 2) has an elimination tree that is
@@ -1157,7 +1127,6 @@ std::string numeric_setup(const Symbolic& S, const SymbolicOptions& opts, hipStr
       std::vector<int> cls[kNumClasses];
       for (int s : units_at[l]) {
         if (parted) { if (S.sn_owner[s] != want_owner) continue; }
-        else if (laned) { if (lane_of[s] != want_owner) continue; }
         else if (want_owner != 0) continue;
         int f = 0;                                            // largest front of the unit decides the class
         for (int t = task_lo[s]; t <= s; ++t) f = std::max(f, (int)(S.row_ptr[t + 1] - S.row_ptr[t]));
@@ -1201,19 +1170,12 @@ std::string numeric_setup(const Symbolic& S, const SymbolicOptions& opts, hipStr
     }
   };
   build(N.levels, parted ? N.part_id : 0);
-  for (size_t i = 0; i < N.xlanes.size(); ++i) build(N.xlanes[i].levels, (int)i + 1);
-  if ((parted && N.part_id == 0) || laned) build(N.levels_top, -1); else N.levels_top.clear();
-  if (laned) {
-    double tot = N.lanes_top_flops;
-    for (double x : N.lane_flops) tot += x;
-    N.early_before_top = N.lanes_top_flops >= 0.3 * tot;
-    N.early_level = -1;    // the in-loop check belongs to the single-schedule plan
-  }
+  if (parted && N.part_id == 0) build(N.levels_top, -1); else N.levels_top.clear();
   if (!(e = upload(N, sched, &d.sched)).empty()) return e;
   if (!(e = upload(N, task_lo, &d.task_lo)).empty()) return e;
   // the leading levels without a big front run as one launch (k_front_small<.., FLOW>, the flow kernels of solve.hip)
   N.flow_levels = N.flow_off = N.flow_cnt = N.flow_maxf = N.flow_maxk = 0;
-  if (!laned && N.flow && (!parted || parted_tasks)) {
+  if (N.flow && (!parted || parted_tasks)) {
     int nl = 0;
     while (nl < (int)N.levels.size() && N.levels[nl].seg[3].cnt == 0) ++nl;
     if (nl >= 2) {
@@ -1392,17 +1354,10 @@ void numeric_release(Numeric& N) {
   N.allocations.clear();
   N.levels.clear();
   N.levels_top.clear();
-  N.xlanes.clear();
-  for (hipEvent_t ev : N.lane_events) (void)hipEventDestroy(ev);
-  N.lane_events.clear();
-  for (hipEvent_t ev : N.solve_events) (void)hipEventDestroy(ev);
-  N.solve_events.clear();
-  N.solve_ev_used = 0;
   N.chain_flags = nullptr; N.chain_epoch = 0;
   N.df_tasks = nullptr; N.df_heads = nullptr; N.n_df_heads = 0; N.df_state_ints = 0;
   N.flow_flags = nullptr; N.flow_epoch = 0; N.flow_levels = 0;
   N.solve_flags = nullptr; N.solve_counters = nullptr; N.solve_epoch = 0; N.solve_counters64 = nullptr; N.solve_epoch64 = 0;
-  N.lane_ev_used = 0;
   N.slevels.clear();
   N.slevels_top.clear();
   N.d = DevPlan();
@@ -1421,37 +1376,7 @@ std::string numeric_read_counts(Numeric& N, hipStream_t stream, unsigned long lo
   return "";
 }
 
-namespace {
-hipEvent_t lane_event(Numeric& N) {
-  if (N.lane_ev_used >= N.lane_events.size()) {
-    hipEvent_t e2 = nullptr;
-    if (hipEventCreateWithFlags(&e2, hipEventDisableTiming) != hipSuccess) return nullptr;
-    N.lane_events.push_back(e2);
-  }
-  return N.lane_events[N.lane_ev_used++];
-}
-}  // namespace
-
-// `from` -> every lane stream (fork) or every lane stream -> `to` (join)
-std::string lanes_fork(Numeric& N, hipStream_t from) {
-  if (N.xlanes.empty()) return "";
-  hipEvent_t ev = lane_event(N);
-  if (!ev) return "hipEventCreate failed";
-  OKKT_HIP_TRY(hipEventRecord(ev, from));
-  for (LaneSched& X : N.xlanes) OKKT_HIP_TRY(hipStreamWaitEvent(X.stream, ev, 0));
-  return "";
-}
-std::string lanes_join(Numeric& N, hipStream_t to) {
-  for (LaneSched& X : N.xlanes) {
-    hipEvent_t ev = lane_event(N);
-    if (!ev) return "hipEventCreate failed";
-    OKKT_HIP_TRY(hipEventRecord(ev, X.stream));
-    OKKT_HIP_TRY(hipStreamWaitEvent(to, ev, 0));
-  }
-  return "";
-}
-
-// one schedule (a lane, the local subtrees of a part, or the top of the tree) on the streams of `ss`
+// one schedule (the local subtrees of a part, or the top of the tree) on the streams of `ss`
 static std::string factor_sched(Numeric& N, DevPlan P, const std::vector<LevelSchedule>& levels, const std::vector<SolveLevel>& slevels,
                                 const LaneStreams& ss, double tol, bool in_loop_check, bool& inv_on_aux, size_t l_begin = 0, size_t l_end = (size_t)-1);
 
@@ -1459,47 +1384,20 @@ std::string numeric_factor_enqueue(Numeric& N, const double* d_vals, double tol,
   DevPlan P = N.d;
   P.vals = d_vals;
   hipStream_t st = N.stream;
-  const bool laned = which == 0 && !N.xlanes.empty();
   if (reset_counters) OKKT_HIP_TRY(hipMemsetAsync(P.counters, 0, (size_t)kCountSlots * kCountStride * sizeof(unsigned long long), st));
   if (N.dataflow && P.df_state) OKKT_HIP_TRY(hipMemsetAsync(P.df_state, 0, ((size_t)N.df_state_ints + (size_t)N.n_df_heads) * sizeof(int), st));   // tile states and queue heads
-  if (N.early_check && N.early_device && which == 0 && (N.levels_top.empty() || laned) && reset_counters) { P.want_pos = N.early_n; P.want_neg = N.early_m; }
+  if (N.early_check && N.early_device && which == 0 && N.levels_top.empty() && reset_counters) { P.want_pos = N.early_n; P.want_neg = N.early_m; }
   N.la_used = 0;
   if (which == 0) N.inv_wait = false;   // the block inverses belong to the previous factorisation (the top phase of a partitioned
                                         // plan keeps the wait its local phase has set up)
   bool inv_on_aux = false;
   N.early_exited = false;
   std::string e;
-  if (!laned) {
+  {
     const LaneStreams ss{N.stream, N.stream_masked, N.stream_panel, N.stream_aux};
     e = factor_sched(N, P, which == 0 ? N.levels : N.levels_top, which == 0 ? N.slevels : N.slevels_top, ss, tol,
                      which == 0 && N.levels_top.empty(), inv_on_aux);
     if (!e.empty()) return e;
-  } else {
-    // lanes side by side (lane 0 keeps the look-ahead streams, the others are single streams), then the top of the tree
-    N.lane_ev_used = 0;
-    if (!(e = lanes_fork(N, st)).empty()) return e;
-    bool dummy = false;
-    const LaneStreams s0{N.stream, N.stream_masked, N.xlanes.size() >= 2 ? nullptr : N.stream_panel, nullptr};
-    // enqueued level by level in turn: a stream's launches reach the GPU in host order, and a lane whose launches are all
-    // queued behind the whole of another lane starts when that one is nearly done
-    for (size_t l = 0; l < N.levels.size(); ++l) {
-      if (!(e = factor_sched(N, P, N.levels, N.slevels, s0, tol, false, dummy, l, l + 1)).empty()) return e;
-      for (LaneSched& X : N.xlanes) {
-        const LaneStreams sx{X.stream, nullptr, nullptr, nullptr};
-        if (!(e = factor_sched(N, P, X.levels, X.slevels, sx, tol, false, dummy, l, l + 1)).empty()) return e;
-      }
-    }
-    if (!(e = lanes_join(N, st)).empty()) return e;
-    if (N.early_check && N.early_before_top) {
-      unsigned long long cnt[5] = {0, 0, 0, 0, 0};
-      if (!(e = numeric_read_counts(N, st, cnt)).empty()) return e;
-      if (cnt[4] != 0 || cnt[3] > 0 || cnt[2] > 0 || cnt[1] > (unsigned long long)N.early_m || cnt[0] > (unsigned long long)N.early_n) {
-        N.early_exited = true;
-        return "";
-      }
-    }
-    const LaneStreams ss{N.stream, N.stream_masked, N.stream_panel, N.stream_aux};
-    if (!(e = factor_sched(N, P, N.levels_top, N.slevels_top, ss, tol, false, inv_on_aux)).empty()) return e;
   }
   if (inv_on_aux) {    // the next solve waits for the block inversions that are still running on the auxiliary stream
     if (!N.inv_event) OKKT_HIP_TRY(hipEventCreateWithFlags(&N.inv_event, hipEventDisableTiming));
@@ -1629,12 +1527,8 @@ static std::string factor_sched(Numeric& N, DevPlan P, const std::vector<LevelSc
         if (ntile == 0) return "";
         // few tiles: 128 x 64 tiles (see k_big_syrk); decided on the largest front of the launch
         static const int small_max = getenv("OKKT_SYRK_SMALL_TILES") ? atoi(getenv("OKKT_SYRK_SMALL_TILES")) : 1500;
-        static const int lds_pad = getenv("OKKT_DEBUG_SYRK_LDS_PAD") ? atoi(getenv("OKKT_DEBUG_SYRK_LDS_PAD")) : 0;   // experiment: extra dynamic LDS of the 128 x 64 trailing update (caps its workgroups per CU)
-        const int sub0 = head == 0 ? (sub == 11 ? 1 : (sub == 12 ? 2 : 0)) : 0;     // decoupled schedule: the next diagonal tile / the rest
-        const bool narrow = (head == 0 || head == 3) && dbg_syrk == 0 && sub0 != 1 && (int64_t)ntile * g.cnt <= small_max;
+        const bool narrow = (head == 0 || head == 3) && dbg_syrk == 0 && (int64_t)ntile * g.cnt <= small_max;
         if (narrow) ntile = head == 0 ? T * (T + 1) : Tr * (Tr + 1);
-        if (sub0 == 1) ntile = 1;
-        else if (sub0 == 2) ntile -= narrow ? 2 : 1;
         if (ntile <= 0) return "";
         const dim3 grid((ntile + 7) / 8 * 8, g.cnt);
         const int wofs = par * GS * NB;
@@ -1656,24 +1550,19 @@ static std::string factor_sched(Numeric& N, DevPlan P, const std::vector<LevelSc
             if (head == 1) { const double w = std::min<double>(t0 + NB, kk) - t0; fl += 2.0 * K * (w * remq - w * (w - 1.0) / 2.0); }
             else if (head == 2) fl += 2.0 * K * (w2 * remq - w2 * (w2 - 1.0) / 2.0);
             else if (head == 3) fl += K * remr * (remr + 1.0);
-            else {
-              const double tw = std::min(128.0, remq);
-              const double first = K * tw * (tw + 1.0);
-              fl += sub0 == 1 ? first : (sub0 == 2 ? K * remq * (remq + 1.0) - first : K * remq * (remq + 1.0));
-            }
+            else fl += K * remq * (remq + 1.0);
           }
           if (N.prof_used + 2 > N.prof_events.size())
             for (int q = 0; q < 512; ++q) { hipEvent_t ev; OKKT_HIP_TRY(hipEventCreate(&ev)); N.prof_events.push_back(ev); }
           N.prof_flops.push_back(fl);
           OKKT_HIP_TRY(hipEventRecord(N.prof_events[N.prof_used++], sst));
         }
-#define OKKT_SYRK(D, H) hipLaunchKernelGGL((k_big_syrk<D, H>), grid, dim3(kSyrkNW * 64), syrk_lds_bytes(kSyrkStages), sst, P, list, stepA, npan, tstep, NB, wofs, csplit, sub0)
+#define OKKT_SYRK(D, H) hipLaunchKernelGGL((k_big_syrk<D, H>), grid, dim3(kSyrkNW * 64), syrk_lds_bytes(kSyrkStages), sst, P, list, stepA, npan, tstep, NB, wofs, csplit)
         const int csplit = head == 1 ? sub : (head == 0 ? 0 : cs);
         if (head == 1) OKKT_SYRK(0, kSyrkPanel);
         else if (head == 2) OKKT_SYRK(0, kSyrkAhead);
-        else if (narrow && lds_pad > 0) hipLaunchKernelGGL((k_big_syrk<0, kSyrkTrail, 64>), grid, dim3(kSyrkNW * 64), syrk_lds_bytes(kSyrkStages) + (size_t)lds_pad, sst, P, list, stepA, npan, tstep, NB, wofs, csplit, sub0);
-        else if (narrow && dbg_syrk == 96) hipLaunchKernelGGL((k_big_syrk<16, kSyrkTrail, 64>), grid, dim3(kSyrkNW * 64), syrk_lds_bytes(kSyrkStages), sst, P, list, stepA, npan, tstep, NB, wofs, csplit, sub0);
-        else if (narrow) hipLaunchKernelGGL((k_big_syrk<0, kSyrkTrail, 64>), grid, dim3(kSyrkNW * 64), syrk_lds_bytes(kSyrkStages), sst, P, list, stepA, npan, tstep, NB, wofs, csplit, sub0);
+        else if (narrow && dbg_syrk == 96) hipLaunchKernelGGL((k_big_syrk<16, kSyrkTrail, 64>), grid, dim3(kSyrkNW * 64), syrk_lds_bytes(kSyrkStages), sst, P, list, stepA, npan, tstep, NB, wofs, csplit);
+        else if (narrow) hipLaunchKernelGGL((k_big_syrk<0, kSyrkTrail, 64>), grid, dim3(kSyrkNW * 64), syrk_lds_bytes(kSyrkStages), sst, P, list, stepA, npan, tstep, NB, wofs, csplit);
         else switch (dbg_syrk) {   // timing-only ablations of the trailing update (OKKT_DEBUG_SYRK): wrong outputs
           case 81: OKKT_SYRK(1, kSyrkTrail); break;    // no C load
           case 82: OKKT_SYRK(2, kSyrkTrail); break;    // no MFMA
@@ -1760,9 +1649,7 @@ static std::string factor_sched(Numeric& N, DevPlan P, const std::vector<LevelSc
       // A front of at least two such blocks starts early: the blocks that are final when it enters its chain-bound tail
       // (fewer than sb_tail_rows rows left, idle CUs) are inverted during the tail, the rest behind the last panel.
       const SolveLevel& SL = slevels[l];
-      // (with the decoupled schedule the auxiliary stream carries the wide trsm / trailing updates of the tail, and the panel
-      // stream is idle there: the inversions go to the panel stream)
-      hipStream_t inv_st = (N.decouple && ss.aux && ss.panel) ? ss.panel : (ss.aux ? ss.aux : st);
+      hipStream_t inv_st = ss.aux ? ss.aux : st;
       const bool inv_early = ss.aux != nullptr && SL.wide_cnt > 0 && g.maxk >= 2 * kSolveBlock && N.sb_tail_rows >= 0;
       int inv_steps_done = 0, inv_blocks_done = 0;
       const size_t lds_inv = ((size_t)(NB + 2) * NB + 3 * kTld * kIB) * sizeof(double);
@@ -1816,7 +1703,6 @@ static std::string factor_sched(Numeric& N, DevPlan P, const std::vector<LevelSc
       std::string e = launch_panels(st, 0, gs_cur, par);
       if (!e.empty()) return e;
       hipEvent_t ev_panel = nullptr;   // set while the panels of the current super-step are on the panel stream
-      bool dec_partial = false;        // decoupled schedule: only the first 128 rows of the current panel's trsm have been done
       for (int stepA = 0; stepA < nsteps;) {
         const int stepB = stepA + gs_cur;                          // first block column of the next super-step
         const bool more = stepB < nsteps;
@@ -1825,20 +1711,6 @@ static std::string factor_sched(Numeric& N, DevPlan P, const std::vector<LevelSc
         if (la) {
           hipEvent_t eva, evp;
           if (!(e = next_event(&eva)).empty() || !(e = next_event(&evp)).empty()) return e;
-          if (N.ahead_first) {
-            // round 3: the look-ahead columns go FIRST on the trailing update's own stream -- 136 tiles alone on 248 CUs take
-            // 45 us, beside a queued trailing update (2 000 workgroups ahead of them on every CU but the reserved ones) 85 - 150 us,
-            // and the panel chain waits for them either way; the trailing update starts that much later and is not the
-            // critical path while the chain is
-            if (ev_panel) OKKT_HIP_TRY(hipStreamWaitEvent(st, ev_panel, 0));       // Panel(q) (its W panels) is behind this
-            if (!(e = launch_syrk(st, stepA, gs_cur, stepB, 2, par, gs_next)).empty()) return e;
-            OKKT_HIP_TRY(hipEventRecord(eva, st));
-            OKKT_HIP_TRY(hipStreamWaitEvent(ss.panel, eva, 0));
-            if (!(e = launch_panels(ss.panel, stepB, gs_next, par ^ 1)).empty()) return e;
-            OKKT_HIP_TRY(hipEventRecord(evp, ss.panel));
-            if (!(e = launch_syrk(st, stepA, gs_cur, stepB, 3, par, gs_next)).empty()) return e;
-            ev_panel = evp;
-          } else {
           OKKT_HIP_TRY(hipEventRecord(eva, st));                     // rest(q - 1) (and Panel(0)) are behind this
           OKKT_HIP_TRY(hipStreamWaitEvent(ss.panel, eva, 0));
           if (!(e = launch_syrk(ss.panel, stepA, gs_cur, stepB, 2, par, gs_next)).empty()) return e;
@@ -1847,37 +1719,8 @@ static std::string factor_sched(Numeric& N, DevPlan P, const std::vector<LevelSc
           if (ev_panel) OKKT_HIP_TRY(hipStreamWaitEvent(st, ev_panel, 0));
           if (!(e = launch_syrk(st, stepA, gs_cur, stepB, 3, par, gs_next)).empty()) return e;
           ev_panel = evp;
-          }
-        } else if (N.decouple && ss.aux != nullptr && gs_cur == 1 && (!more || gs_next == 1) && rem_rows(stepB) >= N.decouple_min_rows && dbg_syrk == 0) {
-          // Decoupled single-block steps (round 3): the chain  diag(q) -> first 128 rows of trsm(q) -> update of the next
-          // diagonal tile -> diag(q + 1)  runs on `st`; the rest of trsm(q) and the rest of the trailing update follow one
-          // step behind on the auxiliary stream.  Every tile still receives its updates in the same order as in the
-          // in-order schedule (bitwise the same factor): the next diagonal tile gets panel q - 1 from the auxiliary stream
-          // before panel q from the chain (the chain waited for it before the tile solve of step q).
-          if (ev_panel) { OKKT_HIP_TRY(hipStreamWaitEvent(st, ev_panel, 0)); ev_panel = nullptr; }
-          hipEvent_t evT, evR;
-          if (!(e = next_event(&evT)).empty() || !(e = next_event(&evR)).empty()) return e;
-          OKKT_HIP_TRY(hipEventRecord(evT, st));                        // diag(stepA) and the first tile of its trsm are behind this
-          OKKT_HIP_TRY(hipStreamWaitEvent(ss.aux, evT, 0));
-          // panels before stepA are final behind this point of `st` (it waited for their wide trsm): block inversions for the solves
-          if (inv_early && rem_rows(stepB) < N.sb_tail_rows && !(e = inv_range(stepA, false)).empty()) return e;
-          if (dec_partial) launch_trsm(ss.aux, stepA, par, 0, 2, -1);    // the rows below the first 128
-          if (!(e = launch_syrk(ss.aux, stepA, 1, stepB, 0, par, 0, more ? 12 : 0)).empty()) return e;
-          OKKT_HIP_TRY(hipEventRecord(evR, ss.aux));
-          dec_partial = false;
-          if (more) {
-            if (!(e = launch_syrk(st, stepA, 1, stepB, 0, par, 0, 11)).empty()) return e;      // the next diagonal tile
-            if (N.diag2 && dbg_stop == 0) hipLaunchKernelGGL(k_big_diag2, dim3(g.cnt), dim3(384), lds_diag2, st, P, list, stepB, NB, tol);
-            else hipLaunchKernelGGL(k_big_diag, dim3(g.cnt), dim3(256), lds_diag, st, P, list, stepB, NB, tol, dbg_stop);
-            OKKT_HIP_TRY(hipStreamWaitEvent(st, evR, 0));               // column stepB is up to date
-            launch_trsm(st, stepB, par ^ 1, 0, 0, 2);
-            dec_partial = true;
-          } else {
-            OKKT_HIP_TRY(hipStreamWaitEvent(st, evR, 0));
-          }
         } else {
           if (ev_panel) { OKKT_HIP_TRY(hipStreamWaitEvent(st, ev_panel, 0)); ev_panel = nullptr; }
-          if (dec_partial) { launch_trsm(st, stepA, par, 0, 2, -1); dec_partial = false; }   // leaving the decoupled schedule: finish the panel
           // columns below stepB * NB are final behind this point of `st`: once the front is in its chain-bound tail, the
           // inversion of the finished super-blocks starts on the auxiliary stream
           // (every block that has become final since the last call: in the tail the CUs are idle anyway, and the first solve
@@ -1905,14 +1748,13 @@ static std::string factor_sched(Numeric& N, DevPlan P, const std::vector<LevelSc
 std::string numeric_solve_enqueue(Numeric& N, int R) {
   std::string e;
   static const int dbg_phase = getenv("OKKT_DEBUG_SOLVE_PHASE") ? atoi(getenv("OKKT_DEBUG_SOLVE_PHASE")) : 0;   // 1: forward sweep only (z = D^-1 L^-1 P b)
-  const bool laned = !N.xlanes.empty();    // then which = 0 covers the lanes AND the top of the tree
   if (!(e = solve_fwd_enqueue(N, 0, R)).empty()) return e;
-  if (!laned && !(e = solve_fwd_enqueue(N, 1, R)).empty()) return e;
+  if (!(e = solve_fwd_enqueue(N, 1, R)).empty()) return e;
   if (dbg_phase == 1) {   // the caller reads the sweep's result where it expects the solution
     OKKT_HIP_TRY(hipMemcpyAsync(N.d.xwork, N.d.zwork, (size_t)N.d.n * kMaxRhs * sizeof(double), hipMemcpyDeviceToDevice, N.stream));
     return "";
   }
-  if (!laned && !(e = solve_bwd_enqueue(N, 1, R)).empty()) return e;
+  if (!(e = solve_bwd_enqueue(N, 1, R)).empty()) return e;
   return solve_bwd_enqueue(N, 0, R);
 }
 

@@ -1068,7 +1068,6 @@ std::string solve_setup(const Symbolic& S, Numeric& N) {
     }
   };
   build(N.levels, N.slevels);
-  for (LaneSched& X : N.xlanes) build(X.levels, X.slevels);
   build(N.levels_top, N.slevels_top);
   std::string e;
   if (!(e = up(N, ssched, &d.ssched)).empty()) return e;
@@ -1124,16 +1123,6 @@ std::string solve_invert_enqueue(Numeric& N, hipStream_t st, const SolveLevel& L
   return "";
 }
 
-// events of the per-level fork of the sweeps (a pool on the handle, reused by every solve)
-static hipEvent_t solve_event(Numeric& N) {
-  if (N.solve_ev_used >= N.solve_events.size()) {
-    hipEvent_t e2 = nullptr;
-    if (hipEventCreateWithFlags(&e2, hipEventDisableTiming) != hipSuccess) return nullptr;
-    N.solve_events.push_back(e2);
-  }
-  return N.solve_events[N.solve_ev_used++];
-}
-
 template <int R>
 static std::string fwd_enqueue_r(Numeric& N, const std::vector<LevelSchedule>& levels, const std::vector<SolveLevel>& sl, hipStream_t st, int l_lo, int l_hi) {
   DevPlan P = N.d;
@@ -1159,19 +1148,6 @@ static std::string fwd_enqueue_r(Numeric& N, const std::vector<LevelSchedule>& l
       else hipLaunchKernelGGL((k_fs_small<256, R>), dim3(g.cnt), dim3(256), lds, st, P, P.sched + g.off, g.maxf, (int*)nullptr, 0, 0);
     }
     const SolveLevel& S = sl[l];
-    // the thin and the wide fronts of a level are independent: with both present the wide chain runs on the auxiliary stream
-    // beside the thin pair (OKKT_SOLVE_FORK, measured in DESIGN section 6)
-    hipStream_t wst = st;
-    hipEvent_t ev_join = nullptr;
-    if (S.thin_cnt && S.wide_cnt && N.solve_fork && N.stream_aux && N.stream_aux != st) {
-      hipEvent_t ev_fork = solve_event(N);
-      ev_join = solve_event(N);
-      if (ev_fork && ev_join) {
-        OKKT_HIP_TRY(hipEventRecord(ev_fork, st));
-        OKKT_HIP_TRY(hipStreamWaitEvent(N.stream_aux, ev_fork, 0));
-        wst = N.stream_aux;
-      } else ev_join = nullptr;
-    }
     if (S.thin_cnt && N.solve_fuse && N.solve_flags) {
       // one launch: workgroup 0 of a front computes y and raises its flag, the others apply the panel rows behind it
       hipLaunchKernelGGL(k_fwd_thin_fused<R>, dim3((S.thin_maxr + 127) / 128 + 1, S.thin_cnt), dim3(256), 0, st, P, P.ssched + S.thin_off, N.nb, N.solve_flags, N.solve_epoch);
@@ -1180,7 +1156,6 @@ static std::string fwd_enqueue_r(Numeric& N, const std::vector<LevelSchedule>& l
       if (S.thin_maxr > 0) hipLaunchKernelGGL(k_fwd_thin_upd<R>, dim3((S.thin_maxr + 127) / 128, S.thin_cnt), dim3(256), 0, st, P, P.ssched + S.thin_off);
     }
     if (S.wide_cnt) {
-      hipStream_t st = wst;
       const int* list = P.ssched + S.wide_off;
       const int nblk = (S.wide_maxk + kSB - 1) / kSB;
       const size_t lds = ((size_t)R * kSB + (size_t)8 * R * kUpdRows) * sizeof(double);
@@ -1197,10 +1172,6 @@ static std::string fwd_enqueue_r(Numeric& N, const std::vector<LevelSchedule>& l
           else hipLaunchKernelGGL(k_fwd_upd<R>, dim3(nupd, S.wide_cnt), dim3(256), lds, st, P, list, b);
         }
       }
-    }
-    if (ev_join) {
-      OKKT_HIP_TRY(hipEventRecord(ev_join, wst));
-      OKKT_HIP_TRY(hipStreamWaitEvent(st, ev_join, 0));
     }
   }
   OKKT_HIP_TRY(hipGetLastError());
@@ -1222,19 +1193,7 @@ static std::string bwd_enqueue_r(Numeric& N, const std::vector<LevelSchedule>& l
       break;
     }
     const SolveLevel& S = sl[l];
-    hipStream_t wst = st;
-    hipEvent_t ev_join = nullptr;
-    if (S.thin_cnt && S.wide_cnt && N.solve_fork && N.stream_aux && N.stream_aux != st) {
-      hipEvent_t ev_fork = solve_event(N);
-      ev_join = solve_event(N);
-      if (ev_fork && ev_join) {
-        OKKT_HIP_TRY(hipEventRecord(ev_fork, st));
-        OKKT_HIP_TRY(hipStreamWaitEvent(N.stream_aux, ev_fork, 0));
-        wst = N.stream_aux;
-      } else ev_join = nullptr;
-    }
     if (S.wide_cnt) {
-      hipStream_t st = wst;
       const int* list = P.ssched + S.wide_off;
       if (S.wide_maxf > 0) hipLaunchKernelGGL(k_bwd_pre<R>, dim3((S.wide_maxk + 3) / 4, S.wide_cnt), dim3(256), 0, st, P, list);
       const int nblk = (S.wide_maxk + kSB - 1) / kSB;
@@ -1258,10 +1217,6 @@ static std::string bwd_enqueue_r(Numeric& N, const std::vector<LevelSchedule>& l
       if (S.thin_maxr > 0) hipLaunchKernelGGL(k_bwd_pre<R>, dim3((S.thin_maxk + 3) / 4, S.thin_cnt), dim3(256), 0, st, P, list);
       hipLaunchKernelGGL(k_bwd_thin<R>, dim3(S.thin_cnt), dim3(256), 0, st, P, list, N.nb);
     }
-    if (ev_join) {
-      OKKT_HIP_TRY(hipEventRecord(ev_join, wst));
-      OKKT_HIP_TRY(hipStreamWaitEvent(st, ev_join, 0));
-    }
     for (int c = 0; c < 3; ++c) {
       const Segment& g = L.seg[c];
       if (!g.cnt) continue;
@@ -1283,30 +1238,14 @@ static std::string sweep(Numeric& N, bool fwd, const std::vector<LevelSchedule>&
   return R == 1 ? bwd_enqueue_r<1>(N, levels, sl, st, l_lo, l_hi) : (R == 2 ? bwd_enqueue_r<2>(N, levels, sl, st, l_lo, l_hi) : bwd_enqueue_r<4>(N, levels, sl, st, l_lo, l_hi));
 }
 
-// which = 0: the local subtrees -- with lanes, every lane on its own stream (forked from / joined into the handle's stream)
-// followed (forward) or preceded (backward) by the top of the tree; which = 1: the top schedule of a partitioned plan
+// which = 0: the local subtrees (everything when the plan is not partitioned); which = 1: the top schedule of a partitioned plan
 static std::string sweep_which(Numeric& N, bool fwd, int which, int R) {
-  std::string e;
   if (which != 0) return sweep(N, fwd, N.levels_top, N.slevels_top, N.stream, R);
-  if (N.xlanes.empty()) return sweep(N, fwd, N.levels, N.slevels, N.stream, R);
-  if (!fwd && !(e = sweep(N, false, N.levels_top, N.slevels_top, N.stream, R)).empty()) return e;
-  if (!(e = lanes_fork(N, N.stream)).empty()) return e;
-  // level by level in turn (host order = submission order: see numeric_factor_enqueue)
-  const int nl = (int)N.levels.size();
-  for (int q = 0; q < nl; ++q) {
-    const int l = fwd ? q : nl - 1 - q;
-    if (!(e = sweep(N, fwd, N.levels, N.slevels, N.stream, R, l, l + 1)).empty()) return e;
-    for (LaneSched& X : N.xlanes)
-      if (!(e = sweep(N, fwd, X.levels, X.slevels, X.stream, R, l, l + 1)).empty()) return e;
-  }
-  if (!(e = lanes_join(N, N.stream)).empty()) return e;
-  if (fwd && !(e = sweep(N, true, N.levels_top, N.slevels_top, N.stream, R)).empty()) return e;
-  return "";
+  return sweep(N, fwd, N.levels, N.slevels, N.stream, R);
 }
 
 std::string solve_fwd_enqueue(Numeric& N, int which, int R) {
   if (which == 0 && N.inv_wait) { OKKT_HIP_TRY(hipStreamWaitEvent(N.stream, N.inv_event, 0)); N.inv_wait = false; }   // inversions started by the factorisation
-  if (which == 0) { N.lane_ev_used = 0; N.solve_ev_used = 0; }
   ++N.solve_epoch;          // the y flags of the fused forward launches are monotonic: one value per forward sweep
   return sweep_which(N, true, which, R);
 }

@@ -630,61 +630,6 @@ std::string analyze_pattern(int64_t n64, const int64_t* colptr, const int64_t* r
 }
 
 
-// Lanes of ONE GPU (numeric.hip): independent subtrees that are factored and solved side by side on separate streams, the
-// rest of the tree ("top", -1) behind them.  A nested-dissection tree has exactly this shape: the two halves below the top
-// separator never touch.  Greedy descent from the roots: the heaviest candidate subtree is opened (its root joins the top)
-// while that root is cheap (< own_frac of all flops) or nothing can run beside it yet; the candidates are then packed into
-// nlanes bins, longest first.  lane_of stays empty when no second lane of at least min_frac of the flops exists.
-void lane_cut(const Symbolic& S, int nlanes, double own_frac, double min_frac, std::vector<int>& lane_of, std::vector<double>& lane_flops, double& top_flops) {
-  const int ns = S.nsuper;
-  lane_of.clear(); lane_flops.clear(); top_flops = 0;
-  if (nlanes < 2 || ns < 2) return;
-  std::vector<double> own(ns, 0.0), sub(ns, 0.0);
-  double total = 0;
-  for (int s = 0; s < ns; ++s) {
-    const double f = (double)(S.row_ptr[s + 1] - S.row_ptr[s]), k = (double)(S.sn_col0[s + 1] - S.sn_col0[s]);
-    own[s] = k * f * f - k * k * f + k * k * k / 3.0;
-    total += own[s];
-  }
-  for (int s = 0; s < ns; ++s) { sub[s] += own[s]; if (S.sn_parent[s] >= 0) sub[S.sn_parent[s]] += sub[s]; }
-  std::vector<char> is_top(ns, 0);
-  std::vector<int> cand;
-  for (int s = 0; s < ns; ++s) if (S.sn_parent[s] < 0) cand.push_back(s);
-  auto second_heaviest = [&]() { double a = 0, b = 0; for (int c : cand) { if (sub[c] > a) { b = a; a = sub[c]; } else if (sub[c] > b) b = sub[c]; } return b; };
-  for (int iter = 0; iter < ns; ++iter) {
-    int best = -1;
-    for (size_t q = 0; q < cand.size(); ++q)
-      if (S.child_ptr[cand[q] + 1] > S.child_ptr[cand[q]] && (best < 0 || sub[cand[q]] > sub[cand[best]])) best = (int)q;
-    if (best < 0) break;
-    const int s = cand[best];
-    // open it?  Always while there is nothing substantial to run beside it; otherwise only cheap roots
-    const bool alone = second_heaviest() < min_frac * total;
-    if (!alone && own[s] >= own_frac * total) break;
-    if (sub[s] < 2.0 * min_frac * total) break;      // nothing worth splitting is left
-    cand[best] = cand.back(); cand.pop_back();
-    for (int64_t q = S.child_ptr[s]; q < S.child_ptr[s + 1]; ++q) cand.push_back(S.children[q]);
-    is_top[s] = 1;
-    top_flops += own[s];
-  }
-  std::sort(cand.begin(), cand.end(), [&](int a, int b) { return sub[a] > sub[b] || (sub[a] == sub[b] && a < b); });
-  lane_flops.assign(nlanes, 0.0);
-  std::vector<int> root_lane(ns, -2);
-  for (int c : cand) {
-    int p = 0;
-    for (int q = 1; q < nlanes; ++q) if (lane_flops[q] < lane_flops[p]) p = q;
-    root_lane[c] = p;
-    lane_flops[p] += sub[c];
-  }
-  double smallest = lane_flops[0];
-  for (double x : lane_flops) smallest = std::min(smallest, x);
-  if (smallest < min_frac * total) { lane_flops.clear(); top_flops = 0; return; }
-  lane_of.assign(ns, -1);
-  for (int s = ns - 1; s >= 0; --s) {
-    if (is_top[s]) continue;
-    lane_of[s] = root_lane[s] >= 0 ? root_lane[s] : lane_of[S.sn_parent[s]];
-  }
-}
-
 void partition_tree(Symbolic& S, int nparts) {
   const int ns = S.nsuper;
   S.nparts = std::max(1, nparts);

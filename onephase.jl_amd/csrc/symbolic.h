@@ -116,8 +116,6 @@ struct Symbolic {
 // pieces are small enough to balance, then longest-processing-time bin packing); deterministic
 void partition_tree(Symbolic& S, int nparts);
 
-// lanes of one GPU: lane_of[s] = lane of supernode s, -1 = top; empty when the tree has no two substantial independent subtrees
-void lane_cut(const Symbolic& S, int nlanes, double own_frac, double min_frac, std::vector<int>& lane_of, std::vector<double>& lane_flops, double& top_flops);
 
 // colptr/rowval: CSC of a square matrix in either index base; only row >= col is used.
 // user_perm (size n, perm[new]=old, 0-based) is read when opts.ordering == 2.

@@ -1,0 +1,73 @@
+"""GPU tests of the dataflow factorisation of the big fronts (csrc/dataflow.hip: one persistent launch per level, tasks on
+128 x 128 tiles handed over through per-tile states) against the per-step launches of csrc/numeric.hip (OKKT_DATAFLOW=0), which
+the other GPU tests pin against the oracle.  Both run the same operations per entry in the same order, so D, the stored factor
+and the solution must agree BIT FOR BIT -- any hand-off that delivered a stale tile would show up here.  The reference reaches
+this arithmetic through CHOLMOD (src/linear_system_solvers/julia.jl:34,52,72)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_case(case, env, tmp_path, tag):
+    out = str(tmp_path / f"{case}_{tag}.npz")
+    e = dict(os.environ)
+    e.update(env)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "dataflow_case.py"), case, out], cwd=ROOT, env=e, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "CASE_OK" in r.stdout, (case, env, r.stdout[-400:], r.stderr[-1500:])
+    return dict(np.load(out))
+
+
+# one block column and one row more (a 1 x 1 last block), a short last pivot block, several whole blocks, 21 block columns with
+# the look-ahead chain, and BASELINE config 3 (every front shape of a real elimination tree, contribution blocks included)
+@pytest.mark.parametrize("case", ["dense129", "dense300", "dense640", "dense2600", "S-C3"])
+def test_dataflow_equals_the_per_step_launches_bit_for_bit(case, tmp_path):
+    a = run_case(case, {"OKKT_DATAFLOW": "0"}, tmp_path, "steps")
+    b = run_case(case, {"OKKT_DATAFLOW": "1"}, tmp_path, "flow")
+    assert int(a["rc"]) == 1 and int(b["rc"]) == 1
+    assert a["inertia"].tolist() == b["inertia"].tolist() == [int(a["want"][0]), int(a["want"][1]), 0, 0]
+    assert np.array_equal(a["d"], b["d"])
+    assert np.array_equal(a["Lidx"], b["Lidx"]) and np.array_equal(a["Ldata"], b["Ldata"])
+    assert np.array_equal(a["x"], b["x"])
+
+
+@pytest.mark.parametrize("env", [{"OKKT_DF_GROUP": "1"}, {"OKKT_DF_GROUP": "2"}, {"OKKT_DF_GROUP": "3", "OKKT_DF_ROWS": "2"}, {"OKKT_DF_ROWS": "4"},
+                                 {"OKKT_DF_WORKERS": "7"}, {"OKKT_DF_WORKERS": "64", "OKKT_DF_MODEL_CHAIN": "2.0"}],
+                         ids=lambda e: ",".join(f"{k[8:]}={v}" for k, v in e.items()))
+def test_every_queue_shape_gives_the_same_factor(env, tmp_path):
+    """The grouping of the panels, the number of row tiles per task, the number of workers and the time model only change the ORDER
+    of the queue; the factor does not depend on it."""
+    a = run_case("dense2600", {"OKKT_DATAFLOW": "1"}, tmp_path, "default")
+    e = {"OKKT_DATAFLOW": "1"}
+    e.update(env)
+    b = run_case("dense2600", e, tmp_path, "variant")
+    assert np.array_equal(a["d"], b["d"]) and np.array_equal(a["Ldata"], b["Ldata"]) and np.array_equal(a["x"], b["x"])
+
+
+def test_a_lost_hand_off_of_the_dataflow_launch_is_loud():
+    """Every wait of the launch is bounded.  One that runs into its bound (forced: the first wait condition of every task asks for a
+    state nobody publishes) raises the time-out word, every worker leaves, and the factorisation fails with an error instead of
+    returning a factor computed from tiles that had not arrived."""
+    code = (
+        "import sys, numpy as np, scipy.sparse as sp\n"
+        "sys.path.insert(0, '.')\n"
+        "from onephase_jl_amd.linear_system_solvers import OkktError, finalize_b, initialize_b, linear_solver_HIP\n"
+        "rng = np.random.default_rng(3); n = 400\n"
+        "B = rng.normal(size=(n, n)); M = B + B.T + np.diag(np.full(n, 3.0 * np.sqrt(n)))\n"
+        "h = linear_solver_HIP('symmetric'); initialize_b(h)\n"
+        "try:\n"
+        "    rc = h.ls_factor_b(sp.csc_matrix(np.tril(M)), n, 0)\n"
+        "except OkktError as e:\n"
+        "    print('FACTOR_ERROR', e); sys.exit(0)\n"
+        "print('RC', rc)\n")
+    e = dict(os.environ)
+    e["OKKT_DATAFLOW"] = "1"
+    e["OKKT_DEBUG_DROP_HANDOFF"] = "4"
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=e, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-1200:]
+    assert "FACTOR_ERROR" in r.stdout and "pivot counts" in r.stdout, r.stdout[-400:]

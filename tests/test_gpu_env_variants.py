@@ -1,5 +1,6 @@
 """GPU tests: every schedule the tuning switches of DESIGN.md section 9 can select gives the same answers
-(look-ahead on / off / everywhere, super-step widths, split in-group updates, when the block inversions of the solves start)."""
+(the dataflow launch and the per-step schedule with look-ahead on / off / everywhere, super-step widths, split in-group updates,
+when the block inversions of the solves start)."""
 import os
 import subprocess
 import sys
@@ -9,38 +10,34 @@ import pytest
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
+# The per-step schedule of csrc/numeric.hip (OKKT_DATAFLOW=0: the round-3 path, kept as the cross-check of the dataflow launch)
+# with its own switches, then the switches that both paths share.
+STEPS = {"OKKT_DATAFLOW": "0"}
 VARIANTS = [
     {},
-    {"OKKT_LOOKAHEAD": "0"},
-    {"OKKT_LA_MIN_TILES": "1"},                                   # look-ahead on every big front, masked twin stream everywhere
-    {"OKKT_LA_MIN_TILES": "1", "OKKT_SPLIT_MIN_ROWS": "0", "OKKT_GROUP": "4", "OKKT_GROUP_ONE_ROWS": "0"},
-    {"OKKT_GROUP": "1"},
-    {"OKKT_GROUP_BIG": "4", "OKKT_GROUP_BIG_MINF": "0", "OKKT_GROUP_SWITCH_ROWS": "0", "OKKT_GROUP_ONE_ROWS": "0"},
-    {"OKKT_GROUP_ONE_ROWS": "100000"},
-    {"OKKT_RESERVED_CUS": "32", "OKKT_LA_MIN_TILES": "64"},
-    {"OKKT_SB_TAIL_ROWS": "100000"},                              # block inversions start as early as a block is final (needs a front of >= 4 blocks)
-    {"OKKT_SB_TAIL_ROWS": "-1"},                                  # ... or only behind the last panel
+    dict(STEPS),
+    dict(STEPS, OKKT_LOOKAHEAD="0"),
+    dict(STEPS, OKKT_LA_MIN_TILES="1"),                            # look-ahead on every big front, masked twin stream everywhere
+    dict(STEPS, OKKT_LA_MIN_TILES="1", OKKT_SPLIT_MIN_ROWS="0", OKKT_GROUP="4", OKKT_GROUP_ONE_ROWS="0"),
+    dict(STEPS, OKKT_GROUP="1"),
+    dict(STEPS, OKKT_GROUP_BIG="4", OKKT_GROUP_BIG_MINF="0", OKKT_GROUP_SWITCH_ROWS="0", OKKT_GROUP_ONE_ROWS="0"),
+    dict(STEPS, OKKT_RESERVED_CUS="32", OKKT_LA_MIN_TILES="64"),
+    dict(STEPS, OKKT_SB_TAIL_ROWS="100000"),                       # block inversions start as early as a block is final (needs a front of >= 4 blocks)
+    dict(STEPS, OKKT_SYRK_SMALL_TILES="0"),                        # 128 x 128 tiles everywhere
+    dict(STEPS, OKKT_SYRK_SMALL_TILES="100000000"),                # 128 x 64 tiles everywhere
+    dict(STEPS, OKKT_DIAG2="0"),                                   # the round-2 diagonal-block kernel
+    dict(STEPS, OKKT_FUSE_DIAG_TRSM="0"),                          # diagonal block and the rows below it always in two launches
+    dict(STEPS, OKKT_FUSE_DIAG_TRSM="1", OKKT_LA_MIN_TILES="1", OKKT_SPLIT_MIN_ROWS="0"),      # ... in one launch everywhere
+    {"OKKT_SB_TAIL_ROWS": "-1"},
     {"OKKT_ASM_CHUNKED": "0"},
     {"OKKT_ASM_LCOL": "0"},
     {"OKKT_TASKS": "0"},                                          # one launch per level of small fronts
     {"OKKT_TASK_ABS": "1e9"},                                     # every all-small subtree is one workgroup's task
-    # round 3
-    {"OKKT_SYRK_SMALL_TILES": "0"},                               # 128 x 128 tiles everywhere
-    {"OKKT_SYRK_SMALL_TILES": "100000000"},                       # 128 x 64 tiles everywhere
-    {"OKKT_DIAG2": "0"},                                          # the round-2 diagonal-block kernel
-    {"OKKT_LANES": "2"},                                          # independent subtrees as lanes on two streams
-    {"OKKT_LANES": "3", "OKKT_LANE_MIN_FRAC": "0.01", "OKKT_LANE_OWN_FRAC": "0.5"},
-    {"OKKT_DECOUPLE": "1", "OKKT_GROUP": "1"},                    # diagonal chain one step ahead of the wide kernels, on every step
-    {"OKKT_DECOUPLE": "1", "OKKT_DECOUPLE_MIN_ROWS": "0"},
-    {"OKKT_FUSE_DIAG_TRSM": "0"},                                 # diagonal block and the rows below it always in two launches
-    {"OKKT_FUSE_DIAG_TRSM": "1"},                                 # ... in one launch everywhere (default: only in-order panels of levels with few fronts)
-    {"OKKT_FUSE_DIAG_TRSM": "2"},
-    {"OKKT_FUSE_DIAG_TRSM": "1", "OKKT_LA_MIN_TILES": "1", "OKKT_SPLIT_MIN_ROWS": "0"},
     {"OKKT_SOLVE_FUSE": "0"},                                     # the sweeps with two launches per level of thin fronts
     {"OKKT_SOLVE_FUSE_WIDE_MAX": "100000000"},                    # the wide fronts fused as well
-    {"OKKT_SOLVE_FORK": "1"},
     {"OKKT_SOLVE_SPLIT_SMALL": "0"},                              # panel GEMVs of the wide fronts always with 64 rows / columns per workgroup
     {"OKKT_FLOW": "0"},                                           # small-front tasks: one launch per level instead of one for all levels
+    {"OKKT_DF_GROUP": "2", "OKKT_DF_WORKERS": "48"},              # the dataflow launch with pairs of panels on 48 workers
     {"OKKT_ORDERING_TEST": "3"},                                  # (read by the case) AMD instead of the automatic choice
 ]
 
