@@ -326,8 +326,11 @@ __device__ __forceinline__ void trsm_body(const DevPlan& P, int s, int step, int
   }
   if (AG) {
     if (tid == 0) {
+      // bounded like every in-launch wait; a wait that runs into its bound is counted as a non-finite pivot and raises the time-out
+      // word (flow_wait does the same): the factorisation fails on its pivot counts instead of solving with a block that never came
       int spins = 0;
       while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(2);
+      if (spins >= (1 << 22)) { atomicAdd(&P.counters[3], 1ull); atomicExch(&P.counters[5], 1ull); }
     }
     __syncthreads();
   }

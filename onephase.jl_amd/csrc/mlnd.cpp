@@ -25,6 +25,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <stdexcept>
 #include <thread>
 #include <chrono>
 
@@ -583,6 +584,9 @@ struct NdCtx {
   int ntrial_top;
   std::atomic<int> threads_free;
   bool dbg;
+  // a helper thread never lets an exception escape (that would be std::terminate for the host process): it sets this flag, and the
+  // thread that spawned it throws once every helper has been joined -- the caller (symbolic.cpp) then drops the dissection candidate
+  std::atomic<bool> failed{false};
 };
 
 void amd_leaf(const Graph& g, const std::vector<int>& label, int* out) {
@@ -615,12 +619,21 @@ void nd_rec(NdCtx& cx, Graph g, std::vector<int> label, int* out, int depth, uin
   std::vector<std::vector<int8_t>> cand(ntrial);
   {
     std::vector<std::thread> th;
+    th.reserve(ntrial);
     for (int t = 1; t < ntrial; ++t) {
-      if (cx.threads_free.fetch_sub(1) > 0) th.emplace_back([&, t] { ml_separator(g, seed * 31 + t, max_frac, cand[t]); });
-      else { cx.threads_free.fetch_add(1); ml_separator(g, seed * 31 + t, max_frac, cand[t]); }
+      bool spawned = false;
+      if (cx.threads_free.fetch_sub(1) > 0) {
+        try {
+          th.emplace_back([&, t] { try { ml_separator(g, seed * 31 + t, max_frac, cand[t]); } catch (...) { cx.failed.store(true); } });
+          spawned = true;
+        } catch (...) { spawned = false; }       // no thread to be had (pid / thread limit): this trial runs here
+      }
+      if (!spawned) { cx.threads_free.fetch_add(1); ml_separator(g, seed * 31 + t, max_frac, cand[t]); }
     }
-    ml_separator(g, seed * 31, max_frac, cand[0]);
+    bool own_failed = false;
+    try { ml_separator(g, seed * 31, max_frac, cand[0]); } catch (...) { own_failed = true; }
     for (auto& t : th) { t.join(); cx.threads_free.fetch_add(1); }
+    if (own_failed || cx.failed.load()) { cx.failed.store(true); throw std::runtime_error("multilevel dissection: a bisection trial failed"); }
   }
   // one more candidate: the level-structure bisection (deterministic, no seed)
   static const bool use_bfs = !(getenv("OKKT_MLND_BFS") && atoi(getenv("OKKT_MLND_BFS")) == 0);
@@ -658,13 +671,27 @@ void nd_rec(NdCtx& cx, Graph g, std::vector<int> label, int* out, int depth, uin
   std::vector<std::vector<int8_t>>().swap(cand);
   int* outa = out;
   int* outb = out + cnt[0];
-  if (ga.n > 2000 && cx.threads_free.fetch_sub(1) > 0) {
-    std::thread th([&cx, &ga, &la, outa, depth, seed]() mutable { nd_rec(cx, std::move(ga), std::move(la), outa, depth + 1, seed * 2 + 1); });
-    nd_rec(cx, std::move(gb), std::move(lb), outb, depth + 1, seed * 2 + 2);
-    th.join();
-    cx.threads_free.fetch_add(1);
-  } else {
-    if (ga.n > 2000) cx.threads_free.fetch_add(1);
+  bool forked = false;
+  if (ga.n > 2000) {
+    if (cx.threads_free.fetch_sub(1) > 0) {
+      std::thread th;
+      try {
+        th = std::thread([&cx, &ga, &la, outa, depth, seed]() mutable {
+          try { nd_rec(cx, std::move(ga), std::move(la), outa, depth + 1, seed * 2 + 1); } catch (...) { cx.failed.store(true); }
+        });
+        forked = true;
+      } catch (...) { forked = false; }          // no thread to be had: both halves on this thread
+      if (forked) {
+        bool own_failed = false;
+        try { nd_rec(cx, std::move(gb), std::move(lb), outb, depth + 1, seed * 2 + 2); } catch (...) { own_failed = true; }
+        th.join();
+        cx.threads_free.fetch_add(1);
+        if (own_failed || cx.failed.load()) { cx.failed.store(true); throw std::runtime_error("multilevel dissection: a sub-problem failed"); }
+      }
+    }
+    if (!forked) cx.threads_free.fetch_add(1);
+  }
+  if (!forked) {
     nd_rec(cx, std::move(ga), std::move(la), outa, depth + 1, seed * 2 + 1);
     nd_rec(cx, std::move(gb), std::move(lb), outb, depth + 1, seed * 2 + 2);
   }

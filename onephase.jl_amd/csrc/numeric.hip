@@ -734,19 +734,24 @@ __global__ __launch_bounds__(256) void k_big_trsm(DevPlan P, const int* __restri
 // and raises the front's flag; the others have their panel rows in flight by then, wait, stage the block and solve.  What
 // crosses workgroups inside the launch (L11, its 32 x 32 inverses, D) is written and read with agent-scope accesses.
 __global__ __launch_bounds__(384) void k_diag_trsm_fused(DevPlan P, const int* __restrict__ list, int step, int NB, double tol, int wcol0,
-                                                         int* __restrict__ flags, int epoch, int cnt, int ntr) {
+                                                         int* __restrict__ flags, int epoch, int cnt, int ntr, int drop) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   // one-dimensional grid, the diagonal blocks of ALL fronts first (cnt workgroups), then the trsm workgroups front by front: with
   // (1 + ntr, cnt) the waiting trsm workgroups of the first fronts filled the CUs before the other fronts' diagonal blocks were
   // dispatched (one 110-KB workgroup per CU) and a level of 50 fronts took three rounds
   const int x = (int)blockIdx.x;
   const int s = list[x < cnt ? x : (x - cnt) / ntr];
-  if (stop_requested_wg(P)) return;
+  if (stop_requested_wg(P)) {
+    // the trsm workgroups of this front may have passed their own test before the flag was raised: they must not wait for a block
+    // that will never be factored (advisor, round 3)
+    if (x < cnt && threadIdx.x == 0) __hip_atomic_store(flags + s, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
   if (x < cnt) {
     diag2_body<true>(P, s, step, NB, tol, sm);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every storing wave: its agent-scope stores have been acknowledged
     __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(flags + s, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) __hip_atomic_store(flags + s, epoch - drop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   } else {
     trsm_body<4, true>(P, s, step, wcol0, (x - cnt) % ntr, sm, flags + s, epoch);
   }
@@ -1385,6 +1390,9 @@ std::string numeric_factor_enqueue(Numeric& N, const double* d_vals, double tol,
   P.vals = d_vals;
   hipStream_t st = N.stream;
   if (reset_counters) OKKT_HIP_TRY(hipMemsetAsync(P.counters, 0, (size_t)kCountSlots * kCountStride * sizeof(unsigned long long), st));
+  // the arrival counters of the fused backward launches are reset by their consumer; a sweep that was cut short (a wait that ran into
+  // its bound) leaves a residue that would let the next solve's consumer start early: cleared with the time-out word (advisor, round 3)
+  if (reset_counters && N.solve_counters) OKKT_HIP_TRY(hipMemsetAsync(N.solve_counters, 0, (size_t)N.d.nsuper * sizeof(int), st));
   if (N.dataflow && P.df_state) OKKT_HIP_TRY(hipMemsetAsync(P.df_state, 0, ((size_t)N.df_state_ints + (size_t)N.n_df_heads) * sizeof(int), st));   // tile states and queue heads
   if (N.early_check && N.early_device && which == 0 && N.levels_top.empty() && reset_counters) { P.want_pos = N.early_n; P.want_neg = N.early_m; }
   N.la_used = 0;
@@ -1626,8 +1634,9 @@ static std::string factor_sched(Numeric& N, DevPlan P, const std::vector<LevelSc
             const int ntr = rem_f > 0 ? (rem_f + 63) / 64 : 0;
             if (N.diag2 && (N.fuse_diag_trsm == 1 || (N.fuse_diag_trsm == 2 && pst == st) || (N.fuse_diag_trsm == 3 && pst == st && g.cnt <= fuse_max_fronts)) && N.chain_flags && dbg_stop == 0 && NB == 128 && ev_rest == nullptr && ntr > 0) {
               const int wc = (par * GS + i) * NB;
+              static const int drop_fused = getenv("OKKT_DEBUG_DROP_HANDOFF") ? atoi(getenv("OKKT_DEBUG_DROP_HANDOFF")) : 0;   // bit 3 (tests): the diagonal workgroups raise the flags to an epoch below the one the others wait for
               hipLaunchKernelGGL(k_diag_trsm_fused, dim3((1 + ntr) * g.cnt), dim3(384), std::max(lds_diag2, lds_trsm_max), pst, P, list, step, NB, tol, wc,
-                                 N.chain_flags, ++N.chain_epoch, g.cnt, ntr);
+                                 N.chain_flags, ++N.chain_epoch, g.cnt, ntr, (drop_fused & 8) ? 1 : 0);
               continue;
             }
           }

@@ -571,20 +571,40 @@ std::string analyze_pattern(int64_t n64, const int64_t* colptr, const int64_t* r
     // are the grid planes: 40^3 grid 1.0e10 flops against 2.1e10 (multilevel dissection) and 4.6e10 (minimum degree), 400^2 grid
     // 6.1e8 against 1.2e9 and 1.0e9; on graphs with long-range edges it is hopeless (S-metric: 50 x more flops) and loses the
     // comparison.  It costs 0.1 s of one more thread, statistics only.
-    std::thread tc([&] { ec = analyze_one(n64, colptr, rowval, index_base, oc, user_perm, Sc, nullptr, true); });
+    // The candidate threads never let an exception escape (a std::system_error from thread creation under a pid / thread limit, a
+    // bad_alloc inside a thread would otherwise end the host process through std::terminate): a candidate that fails is simply not a
+    // candidate, minimum degree on the calling thread is the fall-back, and the joins run whatever happens (advisor, round 3).
+    // OKKT_ANALYZE_THREADS=1 runs the candidates one after the other on the calling thread.
+    auto run_c = [&] {
+      try { ec = analyze_one(n64, colptr, rowval, index_base, oc, user_perm, Sc, nullptr, true); }
+      catch (const std::exception& ex) { ec = std::string("level-structure candidate: ") + ex.what(); }
+      catch (...) { ec = "level-structure candidate failed"; }
+    };
     // The dissection is the faster of the two on many-core hosts (its pieces are ordered in parallel, minimum degree is one
     // thread): its thread goes on with the FULL analysis of its own ordering while minimum degree is still running -- the plan
     // is ready when the comparison is decided, and is thrown away when minimum degree wins
-    std::thread tb([&] {
-      eb = analyze_one(n64, colptr, rowval, index_base, ob, user_perm, Sb, nullptr, true);
-      if (eb.empty() && Sb.ordering_used == 5 && Sb.flops_exact >= 1e9) {
-        const std::vector<int> ord = Sb.perm;
-        espec = analyze_one(n64, colptr, rowval, index_base, ob, user_perm, Sspec, &ord, false);
-      }
-    });
-    ea = analyze_one(n64, colptr, rowval, index_base, oa, user_perm, Sa, nullptr, true);
-    tb.join();
-    tc.join();
+    auto run_b = [&] {
+      try {
+        eb = analyze_one(n64, colptr, rowval, index_base, ob, user_perm, Sb, nullptr, true);
+        if (eb.empty() && Sb.ordering_used == 5 && Sb.flops_exact >= 1e9) {
+          const std::vector<int> ord = Sb.perm;
+          espec = analyze_one(n64, colptr, rowval, index_base, ob, user_perm, Sspec, &ord, false);
+        }
+      } catch (const std::exception& ex) { eb = std::string("dissection candidate: ") + ex.what(); espec = eb; }
+      catch (...) { eb = "dissection candidate failed"; espec = eb; }
+    };
+    const bool serial = getenv("OKKT_ANALYZE_THREADS") && atoi(getenv("OKKT_ANALYZE_THREADS")) <= 1;
+    std::thread tb, tc;
+    bool b_started = false, c_started = false;
+    if (!serial) {
+      try { tc = std::thread(run_c); c_started = true; } catch (...) { c_started = false; }
+      try { tb = std::thread(run_b); b_started = true; } catch (...) { b_started = false; }
+    }
+    try { ea = analyze_one(n64, colptr, rowval, index_base, oa, user_perm, Sa, nullptr, true); }
+    catch (const std::exception& ex) { ea = std::string("minimum-degree analysis: ") + ex.what(); }
+    catch (...) { ea = "minimum-degree analysis failed"; }
+    if (b_started) tb.join(); else run_b();
+    if (c_started) tc.join(); else run_c();
     if (!ea.empty()) return ea;
     const bool b_ok = eb.empty() && Sb.ordering_used == 5 && Sb.flops_exact < 0.9 * Sa.flops_exact && Sa.flops_exact >= 1e9;
     const bool c_ok = ec.empty() && Sc.ordering_used == 4 && Sc.flops_exact < 0.9 * Sa.flops_exact && Sa.flops_exact >= 1e9;

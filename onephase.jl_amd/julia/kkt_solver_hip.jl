@@ -185,6 +185,12 @@ end
 # candidates of take_step2! (take_step.jl:34-66) are right-hand sides of one factorised system.  Returns [(dir, kkt_err_norm)];
 # kkt_associate_rhs!(k, iter, ...) must have told the library the current iterate.
 function compute_directions!(k::HIP_KKT_solver, etas::Vector{Class_reduction_factors})
+    # the same guards as compute_direction_implementation!: the BigFloat refinement of the Schur solvers ends in a MethodError in
+    # the reference (schur.jl:167, eval.jl:232), and every returned direction goes through check_for_nan (IPM_tools.jl:32-49).
+    # k.dir and k.kkt_err_norm are NOT updated: the caller picks one of the candidates.
+    if k.pars.kkt.ItRefine_BigFloat && (k.kind == 0 || k.kind == 3)       # :schur, :schur_direct
+        error("MethodError: no method matching hess_product(::Class_iterate, ::Array{BigFloat,1}) (schur.jl:167 with pars.kkt.ItRefine_BigFloat = true)")
+    end
     n = dim(k.factor_it); m = ncon(k.factor_it); q = length(etas)
     e = zeros(3 * q)
     for i in 1:q
@@ -199,6 +205,7 @@ function compute_directions!(k::HIP_KKT_solver, etas::Vector{Class_reduction_fac
         d = Class_point(); d.x = dx[(i - 1) * n + 1:i * n]; d.y = dy[(i - 1) * m + 1:i * m]; d.s = ds[(i - 1) * m + 1:i * m]
         d.mu = -(1.0 - etas[i].mu) * get_mu(k.current_it)
         d.primal_scale = -(1.0 - etas[i].P) * k.current_it.point.primal_scale
+        check_for_nan(d)
         r = err[6 * (i - 1) + 1:6 * i]
         push!(out, (d, Class_kkt_error(r[1], r[2], r[3], r[4], r[5], r[6])))
     end

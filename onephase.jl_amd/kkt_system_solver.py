@@ -303,9 +303,14 @@ class HIP_KKT_solver:
     # ---- several directions of the same factor in one pass (probe + candidates of take_step2!, take_step.jl:2-66)
     def compute_directions_b(self, etas):
         """[(dir, kkt_err_norm)] for the reduction factors `etas` at the iterate of the last kkt_associate_rhs_b: System_rhs on
-        the device per triple, the solves batched (up to four right-hand sides per sweep over L)."""
+        the device per triple, the solves batched (up to four right-hand sides per sweep over L).  Every returned direction passes
+        the checks of compute_direction_b (the BigFloat guard of the Schur solvers, check_for_nan of IPM_tools.jl:32-49); self.dir and
+        self.kkt_err_norm are NOT updated -- the caller picks one of the candidates."""
         if self.ready != "factored":
             raise OkktError("kkt solver not ready to compute direction!")
+        if self.pars.kkt.ItRefine_BigFloat and self.kind in ("schur", "schur_direct"):
+            raise OkktError("MethodError: no method matching hess_product(::Class_iterate, ::Array{BigFloat,1}) "
+                            "(schur.jl:167 with pars.kkt.ItRefine_BigFloat = true; eval.jl:232 only accepts Array{Float64,1})")
         n, m = self.factor_it.dim(), self.factor_it.ncon()
         q = len(etas)
         e = L.f64(np.array([[t.P, t.D, t.mu] for t in etas], dtype=float).ravel())
@@ -318,6 +323,9 @@ class HIP_KKT_solver:
             d = Class_point(x=dx[i].copy(), y=dy[i].copy(), s=ds[i].copy())
             d.mu = -(1.0 - etas[i].mu) * self.current_it.mu
             d.primal_scale = -(1.0 - etas[i].P) * self.current_it.primal_scale
+            for name, v in (("x", d.x), ("y", d.y), ("s", d.s)):       # check_for_nan, IPM_tools.jl:32-49 -- as the single-rhs path
+                if not np.all(np.isfinite(v)):
+                    raise OkktError(f"NaN in {name} (candidate {i})")
             ke = err[i]
             out.append((d, Class_kkt_error(ke.error_D, ke.error_P, ke.error_mu, ke.overall, ke.rhs_norm, ke.ratio)))
         return out
