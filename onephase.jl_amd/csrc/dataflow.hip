@@ -487,8 +487,11 @@ __global__ __launch_bounds__(kDfThreads, 1) void k_front_dataflow(DevPlan P, con
       if ((tid & 63) == 0) t = atomicAdd(head, 1);
       t = __builtin_amdgcn_readfirstlane(t);
       int ok = 1;
+      // a retry of the delta loop whose pivot counts already decide a wrong inertia: nothing more is started (the workers leave
+      // within one task's time; the launches of the levels above return at their first pop)
+      if (P.want_neg >= 0 && __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&P.counters[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0) ok = 0;
       if (tlog && t < ntasks && (tid & 63) == 0) { tlog[(size_t)t * 8] = wall_clock64(); tlog[(size_t)t * 8 + 3] = blockIdx.x; }
-      if (t < ntasks) {
+      if (t < ntasks && ok) {
         const DfTask tk = tasks[t];
         const int s = __builtin_amdgcn_readfirstlane(tk.front), type_nq = __builtin_amdgcn_readfirstlane(tk.type_nq), ij = __builtin_amdgcn_readfirstlane(tk.ij), q0 = __builtin_amdgcn_readfirstlane(tk.q0);
         const int type = type_nq & 255, nq = (type_nq >> 8) & 255, rows = max(type_nq >> 16, 1), i = ij & 0xffff, j = ij >> 16;

@@ -15,6 +15,11 @@ CONFIGS = {
     # name: n, m, J nnz/row, tril(H) nnz/col (incl. diagonal)
     "S-metric": dict(n=40_000, m=60_000, j_per_row=24, h_per_col=10),
     "S-C3": dict(n=10_000, m=20_000, j_per_row=20, h_per_col=8),
+    # the fully random variant of BASELINE config 3 ("random sparse", SURVEY 8d: p_far = 1): no locality, no separators for a
+    # dissection to find, near-dense fronts -- the case where the ordering gain vanishes and the MFMA kernels carry the number;
+    # the small one is what the scalar oracle affords in a test
+    "S-C3-random": dict(n=10_000, m=20_000, j_per_row=20, h_per_col=8, p_far=1.0),
+    "S-C3-random-small": dict(n=1_000, m=2_000, j_per_row=20, h_per_col=8, p_far=1.0),
     "S-small": dict(n=400, m=600, j_per_row=6, h_per_col=4),
     "S-tiny": dict(n=40, m=60, j_per_row=4, h_per_col=3),
 }
