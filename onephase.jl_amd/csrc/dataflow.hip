@@ -35,8 +35,12 @@ namespace okkt {
 typedef double d2_t __attribute__((ext_vector_type(2)));
 constexpr int kDfThreadsC = 512;   // threads of a worker
 #ifndef OKKT_DF_STAGES
-#define OKKT_DF_STAGES 4
+#define OKKT_DF_STAGES 2
 #endif
+#ifndef OKKT_DF_KC
+#define OKKT_DF_KC 32
+#endif
+constexpr int kDfKC = OKKT_DF_KC;           // panel columns per ring slot of the update tasks
 constexpr int kDfStages = OKKT_DF_STAGES;   // operand ring of the update tasks: 16-column chunks in LDS (one workgroup per CU: nobody else covers a chunk that is late)
 
 // 16-byte write-through store (global_store_dwordx4 ... sc1): the C tiles leave the CU at the rate of plain stores and are
@@ -331,9 +335,9 @@ __device__ __forceinline__ bool df_tu_tile(const DevPlan& P, int s, int q, int r
 // chunks: the C tile of the next row block is requested while the current one is in its main loop (raw pairs in registers, masked
 // when the accumulators switch), its first operand chunk follows the last chunk of the current tile through the ring, and the
 // stores of a finished tile drain behind the next tile's first chunk.
-__device__ __forceinline__ void df_syrk_tiles(const DevPlan& P, int s, int j0, int nb, int i, int R, int j, int KB, int k, double* sm) {
+__device__ __forceinline__ void df_syrk_tiles(const DevPlan& P, int s, int j0, int nb, int i, int R, int j, int KB, int k, double* sm, long long* marks) {
   constexpr int NW = kSyrkNW, STAGES = kDfStages;
-  constexpr int DMA = 2 * (kSyrkKC / NW);   // LDS-DMA instructions per wave and chunk
+  constexpr int DMA = 2 * (kDfKC / NW);   // LDS-DMA instructions per wave and chunk
   constexpr int WCW = 128 / (NW / 2);   // columns per wave
   constexpr int NCG = WCW / 4;          // 4-column groups per wave
   int tid_ = threadIdx.x;
@@ -346,21 +350,21 @@ __device__ __forceinline__ void df_syrk_tiles(const DevPlan& P, int s, int j0, i
   const double* Wcol = P.wbuf + P.wbuf_pos[s] + (size_t)j0 * f + lane * 2;
   const double* Lg = F + (size_t)j0 * f + ct0 + lane * 2;
   const int l15 = lane & 15, l4 = lane >> 4;
-  const int nchunk = (nb + kSyrkKC - 1) / kSyrkKC;
+  const int nchunk = (nb + kDfKC - 1) / kDfKC;
   const int total = R * nchunk;
   // operand chunk g of the stream: chunk g % nchunk of row tile g / nchunk
   auto issue = [&](int g) {
     const int r = g / nchunk, ch = g - r * nchunk;
     const double* Wg = Wcol + df_block_lo(i + r, KB, k, f);
-    double* slot = sm + (size_t)(g % STAGES) * 2 * kSyrkKC * kSyrkLd;
+    double* slot = sm + (size_t)(g % STAGES) * 2 * kDfKC * kSyrkLd;
 #pragma unroll
-    for (int qq = 0; qq < kSyrkKC / NW; ++qq) {
+    for (int qq = 0; qq < kDfKC / NW; ++qq) {
       const int prow = qq * NW + wv;
-      const int p = ch * kSyrkKC + prow;
+      const int p = ch * kDfKC + prow;
       const double* wsrc = p < nb ? Wg + (size_t)p * f : P.zero_page + lane * 2;
       const double* lsrc = p < nb ? Lg + (size_t)p * f : P.zero_page + lane * 2;
       __builtin_amdgcn_global_load_lds(wsrc, (lds_void_t*)(slot + prow * kSyrkLd), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds(lsrc, (lds_void_t*)(slot + (kSyrkKC + prow) * kSyrkLd), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(lsrc, (lds_void_t*)(slot + (kDfKC + prow) * kSyrkLd), 16, 0, 0);
     }
   };
   // raw C pairs of a row tile (clamped addresses, no branches) and the masks that turn them into accumulators
@@ -412,6 +416,7 @@ __device__ __forceinline__ void df_syrk_tiles(const DevPlan& P, int s, int j0, i
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
+    if (marks && g == 0 && tid == 0) marks[0] = wall_clock64();       // C tile and the first operand chunk have landed
     // the slot written next was last read one iteration ago; everyone is past that barrier
     if (g + STAGES - 1 < total) issue(g + STAGES - 1);
     if (ch == pre && r + 1 < R) { load_c(r + 1); plain_until = g + STAGES; }
@@ -419,11 +424,11 @@ __device__ __forceinline__ void df_syrk_tiles(const DevPlan& P, int s, int j0, i
     const int rbase = rt0 + (wv & 1) * 64;
     const bool active = !(rbase + 63 < cbase) && rbase < rlim && cbase < clim;
     if (active) {
-      const double* slot = sm + (size_t)(g % STAGES) * 2 * kSyrkKC * kSyrkLd;
+      const double* slot = sm + (size_t)(g % STAGES) * 2 * kDfKC * kSyrkLd;
       const double* bw = slot + (wv & 1) * 64 + 2 * l15;
-      const double* bl = slot + kSyrkKC * kSyrkLd + (wv >> 1) * WCW + (lane & 3);
+      const double* bl = slot + kDfKC * kSyrkLd + (wv >> 1) * WCW + (lane & 3);
 #pragma unroll
-      for (int kk = 0; kk < kSyrkKC / 4; ++kk) {
+      for (int kk = 0; kk < kDfKC / 4; ++kk) {
         double bv[4];
 #pragma unroll
         for (int rb = 0; rb < 4; ++rb) bv[rb] = bw[(kk * 4 + l4) * kSyrkLd + (rb & 1) + 32 * (rb >> 1)];
@@ -441,6 +446,7 @@ __device__ __forceinline__ void df_syrk_tiles(const DevPlan& P, int s, int j0, i
       }
     }
     if (++ch == nchunk) {
+      if (marks && g == total - 1 && tid == 0) marks[1] = wall_clock64();      // main loop done
       // the row tile is done: store it (write-through, not waited for here) and switch to the next one's accumulators
       if (active) {
 #pragma unroll
@@ -465,11 +471,12 @@ __device__ __forceinline__ void df_syrk_tiles(const DevPlan& P, int s, int j0, i
       if (++r < R) mask_c(r);
     }
   }
+  if (marks && tid == 0) marks[2] = wall_clock64();        // stores issued
   // the ring's slots are reused by the next task of this workgroup: every wave is done reading them behind the caller's barrier
 }
 
 constexpr int kDfThreads = kDfThreadsC;
-constexpr size_t kDfLds = std::max(std::max(((size_t)5 * kMW * kPLD + (size_t)2 * 4 * 32 * kXld) * sizeof(double), kDfTuLds), (size_t)kDfStages * 2 * kSyrkKC * kSyrkLd * sizeof(double));   // diag2_body's and df_tu_tile's; the other roles need less
+constexpr size_t kDfLds = std::max(std::max(((size_t)5 * kMW * kPLD + (size_t)2 * 4 * 32 * kXld) * sizeof(double), kDfTuLds), (size_t)kDfStages * 2 * kDfKC * kSyrkLd * sizeof(double));   // diag2_body's and df_tu_tile's; the other roles need less
 
 // counters[5] = a wait ran into its bound (or another worker's did): every worker leaves, the factorisation reports a wrong
 // inertia ("pivot counts do not add up") and the solves return NaN -- never numbers computed from tiles that had not arrived
@@ -566,7 +573,7 @@ __global__ __launch_bounds__(kDfThreads, 1) void k_front_dataflow(DevPlan P, con
       mine = st + (size_t)i * TB + j; newv = j + 1;
     } else {
       const int j0 = q0 * 128;
-      if (!(dbg & 4)) df_syrk_tiles(P, s, j0, min(nq * 128, k - j0), i, rows, j, KB, k, sm);
+      if (!(dbg & 4)) df_syrk_tiles(P, s, j0, min(nq * 128, k - j0), i, rows, j, KB, k, sm, tlog ? tlog + (size_t)t * 8 + 4 : nullptr);
       mine = st + (size_t)i * TB + j; newv = q0 + nq; npub = rows;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every storing wave: its sc1 stores have been acknowledged
@@ -595,7 +602,7 @@ std::string df_setup(Numeric& N) {
   int dev = 0, ncu = 256;
   if (hipGetDevice(&dev) == hipSuccess) { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ncu = pr.multiProcessorCount; }
   N.df_workers = getenv("OKKT_DF_WORKERS") ? std::max(1, atoi(getenv("OKKT_DF_WORKERS"))) : ncu;
-  N.df_group = getenv("OKKT_DF_GROUP") ? std::max(1, std::min(atoi(getenv("OKKT_DF_GROUP")), 4)) : 4;
+  N.df_group = getenv("OKKT_DF_GROUP") ? std::max(1, std::min(atoi(getenv("OKKT_DF_GROUP")), 16)) : 4;
   N.df_rows = getenv("OKKT_DF_ROWS") ? std::max(1, std::min(atoi(getenv("OKKT_DF_ROWS")), 8)) : 1;
   auto do_sched = [&](std::vector<LevelSchedule>& levels) {
     for (LevelSchedule& L : levels) {

@@ -99,9 +99,15 @@ constexpr int kXld = 33;
 __device__ __forceinline__ void st_agent_f64(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ double ld_agent_f64(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-template <bool AG>
+#ifndef OKKT_DIAG2_MW
+#define OKKT_DIAG2_MW 8
+#endif
+constexpr int kDiag2MW = OKKT_DIAG2_MW;     // columns per micro-step of diag2_body (8: round 3; 4 halves the redundant block factorisation of the row threads for twice the barriers)
+template <bool AG, int MW = kDiag2MW>
 __device__ __forceinline__ void diag2_body(const DevPlan& P, int s, int step, int NB, double tol, double* sm) {
-  static_assert(kMW == 8, "micro-panels of 8 columns");
+  static_assert(MW == 8 || MW == 4, "micro-panels of 4 or 8 columns");
+  constexpr int NE = MW / 4;                   // MFMA k-steps (4 columns each) per micro-panel
+  constexpr int PER = 16 / MW;                 // micro-panels per 16-column tile
   int tid_ = threadIdx.x;
   asm volatile("" : "+v"(tid_));      // opaque: inside a persistent loop (dataflow.hip) nothing derived from the lane id is hoisted out of the body and kept live across the other roles
   const int tid = tid_, lane = tid & 63;
@@ -114,9 +120,9 @@ __device__ __forceinline__ void diag2_body(const DevPlan& P, int s, int step, in
   if (j0 >= k) return;
   const int nb = min(NB, k - j0);
   double* Praw = sm;                           // 8 x kPLD: raw micro-panel (columns as rows of the array)
-  double* LpB = Praw + kMW * kPLD;             // -L of the micro-panel, two buffers
-  double* WpB = LpB + 2 * kMW * kPLD;          // W = L * D, two buffers
-  double* Ld = WpB + 2 * kMW * kPLD;           // 4 diagonal 32 x 32 blocks of L, leading dimension 33
+  double* LpB = Praw + MW * kPLD;             // -L of the micro-panel, two buffers
+  double* WpB = LpB + 2 * MW * kPLD;          // W = L * D, two buffers
+  double* Ld = WpB + 2 * MW * kPLD;           // 4 diagonal 32 x 32 blocks of L, leading dimension 33
   double* Xs = Ld + 4 * 32 * kXld;             // their inverses
   double* F = P.arena + P.front_pos[s];
   const bool mm = wave >= 2 && wave < 6;       // MFMA wave (four of them: one per SIMD; the two row waves share two of the SIMDs); waves 6, 7 of a
@@ -155,11 +161,11 @@ __device__ __forceinline__ void diag2_body(const DevPlan& P, int s, int step, in
     }
   }
   double my_d = 1.0;
-  const int nms = (nb + kMW - 1) / kMW;        // micro-steps
+  const int nms = (nb + MW - 1) / MW;        // micro-steps
   for (int ms = 0; ms < nms; ++ms) {
-    const int p8 = ms * kMW, pp = ms >> 1, h = ms & 1;
-    const double* Lprev = LpB + ((ms + 1) & 1) * kMW * kPLD;    // panels of micro-step ms - 1
-    const double* Wprev = WpB + ((ms + 1) & 1) * kMW * kPLD;
+    const int p8 = ms * MW, pp = ms / PER, h = ms % PER;
+    const double* Lprev = LpB + ((ms + 1) & 1) * MW * kPLD;    // panels of micro-step ms - 1
+    const double* Wprev = WpB + ((ms + 1) & 1) * MW * kPLD;
     if (mm) {
       // head: update of step ms - 1 on the tile column of panel ms, then the copy-out of panel ms
       if (ms > 0) {
@@ -167,11 +173,11 @@ __device__ __forceinline__ void diag2_body(const DevPlan& P, int s, int step, in
         for (int q = 0; q < 9; ++q)
           if (tj_s[q] == pp) {
             const int rr = 16 * ti_s[q] + l15, cc = 16 * tj_s[q] + l15;
-            double av[2], bv[2];
+            double av[NE], bv[NE];
 #pragma unroll
-            for (int e = 0; e < 2; ++e) { av[e] = Wprev[(4 * e + l4) * kPLD + cc]; bv[e] = Lprev[(4 * e + l4) * kPLD + rr]; }
+            for (int e = 0; e < NE; ++e) { av[e] = Wprev[(4 * e + l4) * kPLD + cc]; bv[e] = Lprev[(4 * e + l4) * kPLD + rr]; }
 #pragma unroll
-            for (int e = 0; e < 2; ++e) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[e], bv[e], acc[q], 0, 0, 0);
+            for (int e = 0; e < NE; ++e) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[e], bv[e], acc[q], 0, 0, 0);
           }
       }
 #pragma unroll
@@ -179,7 +185,13 @@ __device__ __forceinline__ void diag2_body(const DevPlan& P, int s, int step, in
         if (tj_s[q] == pp) {
           const int r = 16 * ti_s[q] + l15;
 #pragma unroll
-          for (int e = 0; e < 2; ++e) Praw[(4 * e + l4) * kPLD + r] = h == 0 ? acc[q][e] : acc[q][2 + e];
+          for (int e = 0; e < NE; ++e) {
+            // register h * NE + e of the tile (no dynamic register index: selects)
+            double v;
+            if constexpr (MW == 8) v = h == 0 ? acc[q][e] : acc[q][2 + e];
+            else v = h == 0 ? acc[q][0] : (h == 1 ? acc[q][1] : (h == 2 ? acc[q][2] : acc[q][3]));
+            Praw[(4 * e + l4) * kPLD + r] = v;
+          }
         }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -187,35 +199,35 @@ __device__ __forceinline__ void diag2_body(const DevPlan& P, int s, int step, in
     asm volatile("" ::: "memory");
     if (!mm) {
       // row threads: 8 x 8 diagonal LDL^T redundantly in registers, own row solved, panels and final entries written
-      double* Lp = LpB + (ms & 1) * kMW * kPLD;
-      double* Wp = WpB + (ms & 1) * kMW * kPLD;
+      double* Lp = LpB + (ms & 1) * MW * kPLD;
+      double* Wp = WpB + (ms & 1) * MW * kPLD;
       if (tid >= p8 && tid < 128) {
         const int r = tid;
-        double A[kMW][kMW], a[kMW], rd[kMW], w[kMW], lr[kMW];
+        double A[MW][MW], a[MW], rd[MW], w[MW], lr[MW];
 #pragma unroll
-        for (int c = 0; c < kMW; ++c) {
+        for (int c = 0; c < MW; ++c) {
           a[c] = Praw[c * kPLD + r];
 #pragma unroll
-          for (int i = c; i < kMW; ++i) A[i][c] = Praw[c * kPLD + p8 + i];
+          for (int i = c; i < MW; ++i) A[i][c] = Praw[c * kPLD + p8 + i];
         }
 #pragma unroll
-        for (int c = 0; c < kMW; ++c) {
+        for (int c = 0; c < MW; ++c) {
           rd[c] = fast_rcp_f64(A[c][c]);
           w[c] = a[c];
           lr[c] = w[c] * rd[c];
 #pragma unroll
-          for (int i = c + 1; i < kMW; ++i) {
+          for (int i = c + 1; i < MW; ++i) {
             const double lic = A[i][c] * rd[c];
 #pragma unroll
             for (int j = c + 1; j <= i; ++j) A[i][j] = __builtin_fma(-lic, A[j][c], A[i][j]);
           }
 #pragma unroll
-          for (int j = c + 1; j < kMW; ++j) a[j] = __builtin_fma(-lr[c], A[j][c], a[j]);
+          for (int j = c + 1; j < MW; ++j) a[j] = __builtin_fma(-lr[c], A[j][c], a[j]);
         }
         const int i = r - p8;
         double* Fr = F + (size_t)(j0 + p8) * f + j0 + r;
 #pragma unroll
-        for (int c = 0; c < kMW; ++c) {
+        for (int c = 0; c < MW; ++c) {
           Lp[c * kPLD + r] = -lr[c];
           Wp[c * kPLD + r] = w[c];
           const double val = i == c ? w[c] : lr[c];
@@ -224,9 +236,9 @@ __device__ __forceinline__ void diag2_body(const DevPlan& P, int s, int step, in
             if ((r >> 5) == ((p8 + c) >> 5)) Ld[(r >> 5) * 32 * kXld + (r & 31) + ((p8 + c) & 31) * kXld] = val;
           }
         }
-        if (i < kMW) {
+        if (i < MW) {
 #pragma unroll
-          for (int c = 0; c < kMW; ++c) my_d = i == c ? w[c] : my_d;
+          for (int c = 0; c < MW; ++c) my_d = i == c ? w[c] : my_d;
         }
       }
     } else if (ms > 0) {
@@ -235,11 +247,11 @@ __device__ __forceinline__ void diag2_body(const DevPlan& P, int s, int step, in
       for (int q = 0; q < 9; ++q)
         if (tj_s[q] > pp) {
           const int rr = 16 * ti_s[q] + l15, cc = 16 * tj_s[q] + l15;
-          double av[2], bv[2];
+          double av[NE], bv[NE];
 #pragma unroll
-          for (int e = 0; e < 2; ++e) { av[e] = Wprev[(4 * e + l4) * kPLD + cc]; bv[e] = Lprev[(4 * e + l4) * kPLD + rr]; }
+          for (int e = 0; e < NE; ++e) { av[e] = Wprev[(4 * e + l4) * kPLD + cc]; bv[e] = Lprev[(4 * e + l4) * kPLD + rr]; }
 #pragma unroll
-          for (int e = 0; e < 2; ++e) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[e], bv[e], acc[q], 0, 0, 0);
+          for (int e = 0; e < NE; ++e) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[e], bv[e], acc[q], 0, 0, 0);
         }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

@@ -4,7 +4,11 @@ and how busy the workers were.
 usage: python scripts/df_log.py <log> [launch index, default: the one with most tasks]"""
 import sys
 
+import os
+
 import numpy as np
+
+CHUNK = int(os.environ.get("OKKT_DF_KC", "32"))      # panel columns per operand chunk of the build that wrote the log
 
 path = sys.argv[1]
 launches = []
@@ -80,6 +84,13 @@ if marks is not None and (typ == 3).any():
     m = typ == 3
     mk = (marks[m] - t0) / 100.0
     print(f"  TU phases (us, mean): ready -> D arrived {np.mean(mk[:, 0] - ready[m]):.1f}, rows solved +{np.mean(mk[:, 1] - mk[:, 0]):.1f}, W in LDS +{np.mean(mk[:, 2] - mk[:, 1]):.1f}, tile updated, stored and published +{np.mean(mk[:, 3] - mk[:, 2]):.1f}, W and L stored + drained +{np.mean(end[m] - mk[:, 3]):.1f}")
+if marks is not None and (typ == 2).any():
+    for kq in sorted(set(nq[typ == 2])):
+        m = (typ == 2) & (nq == kq) & (marks[:, 2] > 0)
+        if not m.any():
+            continue
+        mk = (marks[m] - t0) / 100.0
+        print(f"  U K={128 * kq} phases (us, median): ready -> C tile + first chunk landed {np.median(mk[:, 0] - ready[m]):.1f}, main loop +{np.median(mk[:, 1] - mk[:, 0]):.1f} ({np.median(mk[:, 1] - mk[:, 0]) / (128 * kq / CHUNK):.2f} per {CHUNK}-column chunk), stores issued +{np.median(mk[:, 2] - mk[:, 1]):.1f}, drained + barrier +{np.median(end[m] - mk[:, 2]):.1f}; pop -> ready {np.median(ready[m] - pop[m]):.1f}")
 if len(qs) > 1:
     per = (D[qs[-1]][2] - D[qs[0]][1]) / (len(qs) - 1)
     print(f"  mean distance between diagonal blocks {per:.1f} us")
