@@ -141,7 +141,8 @@ __device__ __forceinline__ void df_trsm_tile(const DevPlan& P, int s, int q, int
 // slots; L = W * (1 / d) is formed on the fly, the very product that is stored) and applies it to the diagonal tile with the
 // trailing update's MFMA loop.  Same operations per entry in the same order as T followed by U: bitwise the same numbers.
 constexpr size_t kDfTuLds = ((size_t)128 * kSyrkLd + 128) * sizeof(double);
-__device__ __forceinline__ bool df_tu_tile(const DevPlan& P, int s, int q, int r0, int rlim, const int* dstate, int dval, int* diag_state, int* s_flag, double* sm, long long* marks) {
+constexpr int kDfTileLd = 130;       // leading dimension of the diagonal tile handed from TU to D through LDS (even: 16-byte rows pairs stay aligned)
+__device__ __forceinline__ bool df_tu_tile(const DevPlan& P, int s, int q, int r0, int rlim, const int* dstate, int dval, int* diag_state, int* row_state, bool with_d, int* s_flag, double* sm, long long* marks) {
   constexpr int NBLK = 4, NB = 128, NPAIR = NBLK * (NBLK + 1) / 2;
   constexpr int NW = kSyrkNW, WCW = 128 / (NW / 2), NCG = WCW / 4;
   int tid_ = threadIdx.x;
@@ -263,6 +264,26 @@ __device__ __forceinline__ bool df_tu_tile(const DevPlan& P, int s, int q, int r
   if (tid < NB) rd2[tid] = myrd;
   __syncthreads();
   if (marks && tid == 0) marks[2] = wall_clock64();        // W in LDS
+  // W and L = W D^-1 of the block row leave from LDS: 16-byte write-through stores of two consecutive rows, 1 KiB of one column
+  // per wave instruction (the 8-byte sc1 stores straight from the solve's register layout took 9 us of the 42 between two diagonal
+  // blocks).  With D(q + 1) in the task they go out BEFORE the tile update, which covers their drain: the other rows' updates of
+  // block column q + 1 wait for them (publishing them from inside the factorisation, 4 us later, cost S-C3 1.5 %).
+  auto store_wl = [&]() {
+    const int nrow = rlim - r0;
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+      const int idx = it * kDfThreadsC + tid;
+      const int p = idx >> 6, x2 = (idx & 63) * 2;
+      d2_t w;
+      __builtin_memcpy(&w, Wl + (size_t)p * kSyrkLd + x2, 16);
+      const double rp = rd2[p];
+      const d2_t l = (d2_t){w[0] * rp, w[1] * rp};
+      double* wdst = Wb + (size_t)p * f + r0 + x2;
+      double* ldst = F + (size_t)(j0 + p) * f + r0 + x2;
+      if (x2 + 1 < nrow) { st_sc1_f64x2(wdst, w); st_sc1_f64x2(ldst, l); }
+      else if (x2 < nrow) { st_agent_f64(wdst, w[0]); st_agent_f64(ldst, l[0]); }
+    }
+  };
   if (active) {
     const double* bw = Wl + (wv & 1) * 64 + 2 * l15;
     const double* bl = Wl + (wv >> 1) * WCW + (lane & 3);
@@ -284,45 +305,57 @@ __device__ __forceinline__ bool df_tu_tile(const DevPlan& P, int s, int q, int r
             acc[half * 4 + qq][rb] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[qq], bv[rb], acc[half * 4 + qq][rb], 0, 0, 1 /* neg A */);
       }
     }
+    if (!with_d) {
 #pragma unroll
-    for (int cg = 0; cg < NCG; ++cg) {
-      const int c = cbase + cg * 4 + l4;
-      if (c >= rlim) continue;
-      double* colp = F + (size_t)c * f;
+      for (int cg = 0; cg < NCG; ++cg) {
+        const int c = cbase + cg * 4 + l4;
+        if (c >= rlim) continue;
+        double* colp = F + (size_t)c * f;
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int r = rbase + 2 * l15 + 32 * h;
-        if (r + 1 < rlim && r >= c) {
-          st_sc1_f64x2(colp + r, (d2_t){acc[cg][2 * h], acc[cg][2 * h + 1]});
-        } else {
-          if (r < rlim && r >= c) st_agent_f64(colp + r, acc[cg][2 * h]);
-          if (r + 1 < rlim && r + 1 >= c) st_agent_f64(colp + r + 1, acc[cg][2 * h + 1]);
+        for (int h = 0; h < 2; ++h) {
+          const int r = rbase + 2 * l15 + 32 * h;
+          if (r + 1 < rlim && r >= c) {
+            st_sc1_f64x2(colp + r, (d2_t){acc[cg][2 * h], acc[cg][2 * h + 1]});
+          } else {
+            if (r < rlim && r >= c) st_agent_f64(colp + r, acc[cg][2 * h]);
+            if (r + 1 < rlim && r + 1 >= c) st_agent_f64(colp + r + 1, acc[cg][2 * h + 1]);
+          }
         }
       }
     }
   }
-  // the diagonal tile first: it is what D(q + 1) waits for.  Every storing wave drains, the workgroup meets, one wave publishes.
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (wave == 0) __hip_atomic_store(diag_state, dval, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // tile (q + 1, q + 1) has received panel q (= q + 1 tasks)
-  if (marks && tid == 0) marks[3] = wall_clock64();        // diagonal tile published
-  // W and L = W D^-1 of the block row leave from LDS: 16-byte write-through stores of two consecutive rows, 1 KiB of one column
-  // per wave instruction (the 8-byte sc1 stores straight from the solve's register layout took 9 us of the 42 between two diagonal blocks)
-  {
-    const int nrow = rlim - r0;
-#pragma unroll 4
-    for (int it = 0; it < 16; ++it) {
-      const int idx = it * kDfThreadsC + tid;
-      const int p = idx >> 6, x2 = (idx & 63) * 2;
-      d2_t w;
-      __builtin_memcpy(&w, Wl + (size_t)p * kSyrkLd + x2, 16);
-      const double rp = rd2[p];
-      const d2_t l = (d2_t){w[0] * rp, w[1] * rp};
-      double* wdst = Wb + (size_t)p * f + r0 + x2;
-      double* ldst = F + (size_t)(j0 + p) * f + r0 + x2;
-      if (x2 + 1 < nrow) { st_sc1_f64x2(wdst, w); st_sc1_f64x2(ldst, l); }
-      else if (x2 < nrow) { st_agent_f64(wdst, w[0]); st_agent_f64(ldst, l[0]); }
+  if (!with_d) {
+    // the diagonal tile first: it is what D(q + 1) waits for.  Every storing wave drains, the workgroup meets, one wave publishes.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (wave == 0) __hip_atomic_store(diag_state, dval, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // tile (q + 1, q + 1) has received panel q (= q + 1 tasks)
+    if (marks && tid == 0) marks[3] = wall_clock64();      // diagonal tile updated and published
+    store_wl();
+  } else {
+    // TU(q) + D(q + 1) in one task: the block row's W and L go out (the other rows' updates of block column q + 1 wait for them:
+    // stored ahead of the tile update they delayed it by 10 us, published from inside the factorisation they came 4 us late --
+    // both measured slower on S-C3), then the updated diagonal tile is handed to the diagonal-block factorisation through LDS
+    // (column-major, leading dimension kDfTileLd, over the W image) -- no trip through HBM, no hand-off
+    if (marks && tid == 0) marks[3] = wall_clock64();      // diagonal tile updated
+    store_wl();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();                     // every wave has read its part of the W image
+    if (active) {
+      double* Tl = sm;
+#pragma unroll
+      for (int cg = 0; cg < NCG; ++cg) {
+        const int c = cbase + cg * 4 + l4 - r0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int r = rbase + 2 * l15 + 32 * h - r0;
+          const d2_t v = (d2_t){acc[cg][2 * h], acc[cg][2 * h + 1]};
+          __builtin_memcpy(Tl + (size_t)c * kDfTileLd + r, &v, 16);
+        }
+      }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (wave == 0) __hip_atomic_store(row_state, dval, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // tile (q + 1, q): W and L of the block row are in memory
   }
   return true;
 }
@@ -569,8 +602,16 @@ __global__ __launch_bounds__(kDfThreads, 1) void k_front_dataflow(DevPlan P, con
       if (!(dbg & 2)) df_trsm_tile(P, s, j, df_block_lo(i, KB, k, f), df_block_lo(i + 1, KB, k, f), sm);
       mine = st + (size_t)i * TB + j; newv = j + 1;
     } else if (type == kDfTU) {
-      if (!df_tu_tile(P, s, j, df_block_lo(i, KB, k, f), df_block_lo(i + 1, KB, k, f), st + (size_t)j * TB + j, j + 1, st + (size_t)i * TB + i, &s_ctl[2], sm, tlog ? tlog + (size_t)t * 8 + 4 : nullptr)) return;
-      mine = st + (size_t)i * TB + j; newv = j + 1;
+      // nq == 2: D(q + 1) is part of the task (the updated diagonal tile reaches it through LDS)
+      const bool with_d = nq == 2;
+      if (!df_tu_tile(P, s, j, df_block_lo(i, KB, k, f), df_block_lo(i + 1, KB, k, f), st + (size_t)j * TB + j, j + 1, st + (size_t)i * TB + i, st + (size_t)i * TB + j, with_d,
+                      &s_ctl[2], sm, tlog ? tlog + (size_t)t * 8 + 4 : nullptr)) return;
+      if (with_d) {
+        diag2_body<true>(P, s, i, 128, tol, sm, sm, kDfTileLd);
+        mine = st + (size_t)i * TB + i; newv = i + 1;          // tile (q + 1, q) was published inside the task
+      } else {
+        mine = st + (size_t)i * TB + j; newv = j + 1;
+      }
     } else {
       const int j0 = q0 * 128;
       if (!(dbg & 4)) df_syrk_tiles(P, s, j0, min(nq * 128, k - j0), i, rows, j, KB, k, sm, tlog ? tlog + (size_t)t * 8 + 4 : nullptr);
@@ -603,6 +644,7 @@ std::string df_setup(Numeric& N) {
   if (hipGetDevice(&dev) == hipSuccess) { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ncu = pr.multiProcessorCount; }
   N.df_workers = getenv("OKKT_DF_WORKERS") ? std::max(1, atoi(getenv("OKKT_DF_WORKERS"))) : ncu;
   N.df_group = getenv("OKKT_DF_GROUP") ? std::max(1, std::min(atoi(getenv("OKKT_DF_GROUP")), 16)) : 4;
+  N.df_fuse_d = getenv("OKKT_DF_FUSE_D") ? atoi(getenv("OKKT_DF_FUSE_D")) : 1;
   N.df_rows = getenv("OKKT_DF_ROWS") ? std::max(1, std::min(atoi(getenv("OKKT_DF_ROWS")), 8)) : 1;
   auto do_sched = [&](std::vector<LevelSchedule>& levels) {
     for (LevelSchedule& L : levels) {
@@ -622,7 +664,7 @@ std::string df_setup(Numeric& N) {
         g.df_flops += (double)k * f * f - (double)k * k * f + (double)k * k * k / 3.0;
       }
       double model = 0;
-      df_build_queue(fronts, N.df_workers, N.df_group, N.df_rows, q, &model);
+      df_build_queue(fronts, N.df_workers, N.df_group, N.df_rows, N.df_fuse_d != 0, q, &model);
       g.df_off = (int64_t)all.size();
       g.df_cnt = (int)q.size();
       g.df_head = nheads++;

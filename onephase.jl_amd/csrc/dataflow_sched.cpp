@@ -51,7 +51,7 @@ struct FrontGrid {
 
 }  // namespace
 
-void df_build_queue(const std::vector<DfFront>& fronts, int workers, int group, int rows_per_task, std::vector<DfTask>& out, double* model_us) {
+void df_build_queue(const std::vector<DfFront>& fronts, int workers, int group, int rows_per_task, bool fuse_d, std::vector<DfTask>& out, double* model_us) {
   const int G = std::max(1, group);
   const int RT = std::max(1, std::min(rows_per_task, 8));
   // Time model (us, measured on MI355X with one workgroup per CU: D 39-45, T 25-32, U 25-30 at K = 128 and 45-52 at K = 256, TU 40
@@ -146,7 +146,10 @@ void df_build_queue(const std::vector<DfFront>& fronts, int workers, int group, 
       const int64_t x = ready.top().second;
       ready.pop();
       Node& nd = nodes[x];
-      out.push_back({fronts[nd.front].s, nd.type | (nd.nq << 8) | (nd.rows << 16), nd.i | (nd.j << 16), nd.q0});
+      // fuse_d: D(q), q >= 1, is carried out by the worker of TU(q - 1) right behind the update of its tile (no task of its own; it stays
+      // in this simulation, where it starts on some worker the moment TU(q - 1) ends -- the same thing for the model)
+      if (!(fuse_d && nd.type == kDfD && nd.i > 0))
+        out.push_back({fronts[nd.front].s, nd.type | ((nd.type == kDfTU && fuse_d ? 2 : nd.nq) << 8) | (nd.rows << 16), nd.i | (nd.j << 16), nd.q0});
       running.push({now + nd.dur, x});
       --idle;
       if (nd.type == kDfD && nd.i + 1 < grids[nd.front].KB) {      // TU(q) starts beside D(q) and ends 24 us behind it

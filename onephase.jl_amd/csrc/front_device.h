@@ -103,8 +103,10 @@ __device__ __forceinline__ double ld_agent_f64(const double* p) { return __hip_a
 #define OKKT_DIAG2_MW 8
 #endif
 constexpr int kDiag2MW = OKKT_DIAG2_MW;     // columns per micro-step of diag2_body (8: round 3; 4 halves the redundant block factorisation of the row threads for twice the barriers)
+// tile_lds != nullptr (dataflow.hip, TU + D in one task): the block comes from LDS (column-major, leading dimension tile_ld, written
+// by the same workgroup) instead of the front in HBM; it overlaps this function's own LDS areas, hence the barrier behind the loads
 template <bool AG, int MW = kDiag2MW>
-__device__ __forceinline__ void diag2_body(const DevPlan& P, int s, int step, int NB, double tol, double* sm) {
+__device__ __forceinline__ void diag2_body(const DevPlan& P, int s, int step, int NB, double tol, double* sm, const double* tile_lds = nullptr, int tile_ld = 0) {
   static_assert(MW == 8 || MW == 4, "micro-panels of 4 or 8 columns");
   constexpr int NE = MW / 4;                   // MFMA k-steps (4 columns each) per micro-panel
   constexpr int PER = 16 / MW;                 // micro-panels per 16-column tile
@@ -146,7 +148,7 @@ __device__ __forceinline__ void diag2_body(const DevPlan& P, int s, int step, in
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
         const int c = 16 * tj_s[q] + 4 * v + l4;
-        raw[q][v] = F[(size_t)(j0 + min(c, nb - 1)) * f + j0 + min(r, nb - 1)];
+        raw[q][v] = tile_lds ? tile_lds[(size_t)min(c, nb - 1) * tile_ld + min(r, nb - 1)] : F[(size_t)(j0 + min(c, nb - 1)) * f + j0 + min(r, nb - 1)];
       }
     }
 #pragma unroll
@@ -160,6 +162,7 @@ __device__ __forceinline__ void diag2_body(const DevPlan& P, int s, int step, in
       }
     }
   }
+  if (tile_lds) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __syncthreads(); }      // every MFMA wave holds its tiles: the LDS below may be written
   double my_d = 1.0;
   const int nms = (nb + MW - 1) / MW;        // micro-steps
   for (int ms = 0; ms < nms; ++ms) {

@@ -14,13 +14,13 @@ from onephase_jl_amd import _lib
 D, T, U, TU = 0, 1, 2, 3
 
 
-def build_queue(fronts, workers=256, group=2, rows=1):
+def build_queue(fronts, workers=256, group=2, rows=1, fuse_d=False):
     lib = _lib.load()
     n = len(fronts)
     f = (C.c_int32 * n)(*[a for a, _ in fronts])
     k = (C.c_int32 * n)(*[b for _, b in fronts])
     model = C.c_double(0)
-    group = group | (rows << 8)
+    group = group | (rows << 8) | ((1 if fuse_d else 0) << 16)
     cnt = lib.okkt_debug_dataflow_queue(n, f, k, workers, group, None, 0, C.byref(model))
     assert cnt >= 0
     buf = (C.c_int32 * (4 * max(cnt, 1)))()
@@ -51,7 +51,7 @@ def dense_partial_ldlt(A, k):
     return A
 
 
-def replay(fronts, tasks, group):
+def replay(fronts, tasks, group, fused=False):
     rng = np.random.default_rng(7)
     mats, refs, states, Ws, grids = [], [], [], [], []
     for f, k in fronts:
@@ -73,6 +73,7 @@ def replay(fronts, tasks, group):
           ri = slice(b[i], b[i + 1])
           if typ == D:
               assert i == j and i < KB and st[i, i] == i, ("D out of order", a, i, st[i, i])
+              assert not (fused and i > 0), "D(q >= 1) must ride in TU(q - 1)"
               blk = A[ri, ri]
               nb = blk.shape[0]
               for c in range(nb):
@@ -96,6 +97,14 @@ def replay(fronts, tasks, group):
               if typ == TU:      # ... and the diagonal tile of block row i receives panel q
                   A[ri, ri] -= np.tril(W[ri, cq] @ A[ri, cq].T)
                   st[i, i] = q + 1
+                  if nq == 2:    # ... and is factored by the same task (D(q + 1) is not a task of its own)
+                      blk = A[ri, ri]
+                      for c in range(blk.shape[0]):
+                          dd = blk[c, c]
+                          l = blk[c + 1:, c] / dd
+                          blk[c + 1:, c + 1:] -= np.outer(l, blk[c + 1:, c])
+                          blk[c + 1:, c] = l
+                      st[i, i] = i + 1
           else:
               ql = q0 + nq - 1
               assert 1 <= nq <= max(group, 1) and i >= j > ql and ql < KB, ("U shape", a, i, j, q0, nq)
@@ -131,11 +140,11 @@ CASES = [
 
 
 @pytest.mark.parametrize("fronts", CASES)
-@pytest.mark.parametrize("group,rows", [(1, 1), (2, 1), (3, 2), (2, 4)])
-def test_queue_replays_to_the_partial_factorisation(fronts, group, rows):
-    tasks, model = build_queue(fronts, workers=16, group=group, rows=rows)
+@pytest.mark.parametrize("group,rows,fused", [(1, 1, False), (2, 1, True), (3, 2, False), (2, 4, True), (4, 1, True)])
+def test_queue_replays_to_the_partial_factorisation(fronts, group, rows, fused):
+    tasks, model = build_queue(fronts, workers=16, group=group, rows=rows, fuse_d=fused)
     assert model > 0
-    replay(fronts, tasks, group)
+    replay(fronts, tasks, group, fused)
 
 
 def test_queue_is_the_same_every_time_and_scales():
