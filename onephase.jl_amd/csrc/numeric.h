@@ -138,6 +138,10 @@ struct Numeric {
   hipEvent_t inv_event = nullptr;        // recorded behind the block inversions that the factorisation started on the auxiliary stream
   bool inv_wait = false;                 // ... which the next solve has to wait for
   hipStream_t inv_stream = nullptr;      // the stream those inversions were put on
+  // one event per level of `levels` behind that level's inversions: the forward sweep waits for a level's inverses when it gets
+  // there, not for the root's before its first launch (the root's 0.7 ms of inversions hide behind the lower levels of the sweep)
+  std::vector<hipEvent_t> inv_level_events;
+  std::vector<char> inv_level_pending;
   std::vector<LevelSchedule> levels;      // subtrees owned by this part (everything when unpartitioned)
   std::vector<LevelSchedule> levels_top;  // top of the tree (part 0 of a partitioned plan only)
   int part_id = 0;

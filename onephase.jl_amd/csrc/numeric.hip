@@ -1351,6 +1351,8 @@ void numeric_release(Numeric& N) {
   N.prof_used = 0;
   N.prof_flops.clear();
   if (N.inv_event) { (void)hipEventDestroy(N.inv_event); N.inv_event = nullptr; }
+  for (hipEvent_t ev : N.inv_level_events) if (ev) (void)hipEventDestroy(ev);
+  N.inv_level_events.clear(); N.inv_level_pending.clear();
   N.inv_wait = false;
   for (hipEvent_t ev : N.la_events) (void)hipEventDestroy(ev);
   N.la_events.clear();
@@ -1396,6 +1398,7 @@ std::string numeric_factor_enqueue(Numeric& N, const double* d_vals, double tol,
   if (N.dataflow && P.df_state) OKKT_HIP_TRY(hipMemsetAsync(P.df_state, 0, ((size_t)N.df_state_ints + (size_t)N.n_df_heads) * sizeof(int), st));   // tile states and queue heads
   if (N.early_check && N.early_device && which == 0 && N.levels_top.empty() && reset_counters) { P.want_pos = N.early_n; P.want_neg = N.early_m; }
   N.la_used = 0;
+  if (which == 0) std::fill(N.inv_level_pending.begin(), N.inv_level_pending.end(), 0);
   if (which == 0) N.inv_wait = false;   // the block inverses belong to the previous factorisation (the top phase of a partitioned
                                         // plan keeps the wait its local phase has set up)
   bool inv_on_aux = false;
@@ -1407,7 +1410,8 @@ std::string numeric_factor_enqueue(Numeric& N, const double* d_vals, double tol,
                      which == 0 && N.levels_top.empty(), inv_on_aux);
     if (!e.empty()) return e;
   }
-  if (inv_on_aux) {    // the next solve waits for the block inversions that are still running on the auxiliary stream
+  const bool per_level = which == 0 && N.levels_top.empty() && !N.inv_level_pending.empty();
+  if (inv_on_aux && !per_level) {    // the next solve waits for the block inversions that are still running on the auxiliary stream
     if (!N.inv_event) OKKT_HIP_TRY(hipEventCreateWithFlags(&N.inv_event, hipEventDisableTiming));
     OKKT_HIP_TRY(hipEventRecord(N.inv_event, N.inv_stream ? N.inv_stream : N.stream_aux));
     N.inv_wait = true;
@@ -1658,7 +1662,8 @@ static std::string factor_sched(Numeric& N, DevPlan P, const std::vector<LevelSc
       // A front of at least two such blocks starts early: the blocks that are final when it enters its chain-bound tail
       // (fewer than sb_tail_rows rows left, idle CUs) are inverted during the tail, the rest behind the last panel.
       const SolveLevel& SL = slevels[l];
-      hipStream_t inv_st = ss.aux ? ss.aux : st;
+      static const int inv_main = getenv("OKKT_INV_MAIN") ? atoi(getenv("OKKT_INV_MAIN")) : 0;    // experiment: the block inversions of a dataflow level on the handle's stream behind the launch
+      hipStream_t inv_st = (ss.aux && !(inv_main && N.dataflow)) ? ss.aux : st;
       const bool inv_early = ss.aux != nullptr && SL.wide_cnt > 0 && g.maxk >= 2 * kSolveBlock && N.sb_tail_rows >= 0;
       int inv_steps_done = 0, inv_blocks_done = 0;
       const size_t lds_inv = ((size_t)(NB + 2) * NB + 3 * kTld * kIB) * sizeof(double);
@@ -1694,6 +1699,16 @@ static std::string factor_sched(Numeric& N, DevPlan P, const std::vector<LevelSc
         }
         return "";
       };
+      // the level's inversions are all enqueued on inv_st: the forward sweep of the next solve waits for THIS event when it reaches this
+      // level (single-schedule plans; the top schedule of a partitioned plan keeps the one event of numeric_factor_enqueue)
+      auto level_inv_event = [&]() -> std::string {
+        if (&levels != &N.levels || !N.levels_top.empty() || inv_st == st) return "";
+        if (N.inv_level_events.size() < levels.size()) { N.inv_level_events.resize(levels.size(), nullptr); N.inv_level_pending.resize(levels.size(), 0); }
+        if (!N.inv_level_events[l]) OKKT_HIP_TRY(hipEventCreateWithFlags(&N.inv_level_events[l], hipEventDisableTiming));
+        OKKT_HIP_TRY(hipEventRecord(N.inv_level_events[l], inv_st));
+        N.inv_level_pending[l] = 1;
+        return "";
+      };
       if (use_df) {
         const bool prof = N.profile;
         if (prof) {
@@ -1706,6 +1721,7 @@ static std::string factor_sched(Numeric& N, DevPlan P, const std::vector<LevelSc
         if (!e.empty()) return e;
         if (prof) OKKT_HIP_TRY(hipEventRecord(N.prof_events[N.prof_used++], st));
         if (!(e = inv_range(nsteps, true)).empty()) return e;
+        if (!(e = level_inv_event()).empty()) return e;
         continue;
       }
       int gs_cur = gs_at(0), par = 0;
@@ -1742,6 +1758,7 @@ static std::string factor_sched(Numeric& N, DevPlan P, const std::vector<LevelSc
       }
       // full inverses of the diagonal blocks (for the solves): the remaining block columns of the level in one launch
       if (!(e = inv_range(nsteps, true)).empty()) return e;
+      if (!(e = level_inv_event()).empty()) return e;
       if (seg_la) {   // join the handle's stream
         hipEvent_t evj;
         if (!(e = next_event(&evj)).empty()) return e;

@@ -1147,6 +1147,10 @@ static std::string fwd_enqueue_r(Numeric& N, const std::vector<LevelSchedule>& l
       if (c == 0) hipLaunchKernelGGL((k_fs_small<64, R>), dim3(g.cnt), dim3(64), lds, st, P, P.sched + g.off, g.maxf, (int*)nullptr, 0, 0);
       else hipLaunchKernelGGL((k_fs_small<256, R>), dim3(g.cnt), dim3(256), lds, st, P, P.sched + g.off, g.maxf, (int*)nullptr, 0, 0);
     }
+    if (&levels == &N.levels && (size_t)l < N.inv_level_pending.size() && N.inv_level_pending[l]) {      // this level's block inverses (enqueued by the factorisation on the auxiliary stream)
+      OKKT_HIP_TRY(hipStreamWaitEvent(st, N.inv_level_events[l], 0));
+      N.inv_level_pending[l] = 0;
+    }
     const SolveLevel& S = sl[l];
     if (S.thin_cnt && N.solve_fuse && N.solve_flags) {
       // one launch: workgroup 0 of a front computes y and raises its flag, the others apply the panel rows behind it

@@ -18,7 +18,8 @@ work, out, rnd = sys.argv[1], sys.argv[2], sys.argv[3]
 CUS = 256
 # kernels of interest: (substring, label, reads are 16 B / lane ("wide": FETCH_SIZE doubled))
 KERNELS = [
-    ("k_big_syrk<0, 0,", "k_big_syrk<0,0> trailing update (dominant)", True),
+    ("k_front_dataflow", "k_front_dataflow (dominant: one persistent launch per level of big fronts)", True),
+    ("k_big_syrk<0, 0,", "k_big_syrk<0,0> trailing update (per-step schedule, OKKT_DATAFLOW=0)", True),
     ("k_big_syrk<0, 1,", "k_big_syrk<0,1> in-group update", True),
     ("k_big_syrk<0, 2,", "k_big_syrk<0,2> look-ahead columns", True),
     ("k_big_trsm", "k_big_trsm", False),
@@ -76,7 +77,7 @@ for sub, label, wide in KERNELS:
     if "dispatches" not in rec:
         continue
     n = rec["dispatches"]
-    for table in (dur_bench if "syrk" in sub or "trsm" in sub or "diag" in sub or "assemble" in sub else dur, dur, dur_bench):
+    for table in (dur_bench if "syrk" in sub or "trsm" in sub or "diag" in sub or "assemble" in sub or "dataflow" in sub else dur, dur, dur_bench):
         hit = [v for k, v in table.items() if sub in k]
         if hit:
             rec["avg_duration_us_unprofiled"] = sum(c * a for c, a in hit) / max(sum(c for c, a in hit), 1) / 1e3
@@ -99,13 +100,13 @@ for sub, label, wide in KERNELS:
             rec["hbm_GBps_at_unprofiled_duration"] = rec["hbm_bytes_per_launch"] / (rec["avg_duration_us_unprofiled"] * 1e-6) / 1e9
     summary["kernels"].append(rec)
 json.dump(summary, open(f"{out}/{rnd}_pmc_summary.json", "w"), indent=1)
-syrk = next((r for r in summary["kernels"] if r["kernel"].startswith("k_big_syrk<0,0>")), None)
+syrk = next((r for r in summary["kernels"] if r["kernel"].startswith("k_front_dataflow")), None) or next((r for r in summary["kernels"] if r["kernel"].startswith("k_big_syrk<0,0>")), None)
 if syrk:
-    rec = {"kernel": "k_big_syrk<0, 0>", "launches": syrk["dispatches"], "fetch_kib_total": syrk.get("FETCH_SIZE"), "write_kib_total": syrk.get("WRITE_SIZE"),
+    rec = {"kernel": syrk["kernel"], "launches": syrk["dispatches"], "fetch_kib_total": syrk.get("FETCH_SIZE"), "write_kib_total": syrk.get("WRITE_SIZE"),
            "hbm_bytes_per_launch": syrk.get("hbm_bytes_per_launch"),
            "hbm_bytes_per_launch_raw": ((syrk.get("FETCH_SIZE", 0.0) + syrk.get("WRITE_SIZE", 0.0)) * 1024.0 / syrk["dispatches"]),
            "mfma_util_pct": syrk.get("mfma_util_pct"), "lds_bank_conflict_ratio": syrk.get("lds_bank_conflict_ratio"),
            "note": "hbm_bytes_per_launch doubles FETCH_SIZE (16-byte-per-lane C tile reads and LDS-DMA operand streams, MI355X guide); raw keeps it as reported"}
-    json.dump(rec, open(f"{out}/{rnd}_syrk_pmc.json", "w"), indent=1)
+    json.dump(rec, open(f"{out}/{rnd}_dataflow_pmc.json" if "dataflow" in syrk["kernel"] else f"{out}/{rnd}_syrk_pmc.json", "w"), indent=1)
 for r in summary["kernels"]:
     print({k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items() if k in ("kernel", "dispatches", "mfma_util_pct", "lds_bank_conflict_ratio", "hbm_bytes_per_launch", "hbm_GBps_at_unprofiled_duration", "avg_duration_us_unprofiled", "SQ_WAIT_ANY_frac_of_wave_cycles", "SQ_WAIT_INST_ANY_frac_of_wave_cycles", "SQ_ACTIVE_INST_ANY_frac_of_wave_cycles")})
