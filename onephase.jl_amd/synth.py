@@ -81,6 +81,11 @@ def make_problem(n, m, j_per_row=8, h_per_col=4, w=50.0, p_far=0.01, seed=0, con
 def make_config(name, seed=0, **over):
     if name == "S-C5":   # block-angular: 8 independent blocks + 200 linking columns (wide elimination tree)
         return block_angular(seed=seed, **over)
+    if name == "S-C5-wide":   # the same tree shape with blocks of the S-C3 size (n + m = 240 200): a part of the sharded run is
+        # throughput-bound instead of a chain of small fronts (round-3 review, item 3; labelled: NOT BASELINE's config 5)
+        cfg = dict(n_b=10_000, m_b=20_000, j_per_row=20, h_per_col=8)
+        cfg.update(over)
+        return block_angular(seed=seed, **cfg)
     cfg = dict(CONFIGS[name])
     cfg.update(over)
     return make_problem(seed=seed, **cfg)
