@@ -64,8 +64,28 @@ T = {(int(i), int(j)): (pop[a], ready[a], end[a]) for a, i, j in zip(np.where(se
 U = {}
 for a in np.where(sel & (typ == 2))[0]:
     U[(int(ti[a]), int(tj[a]), int(q0[a]) + int(nq[a]))] = (pop[a], ready[a], end[a])
-print(f"chain of front {big}: step | D pop ready end (body) | T(q+1,q) ready end | U(q+1,q+1,->q+1) ready end | D(q+1) ready - D(q) end")
-qs = sorted(D)
+TUt = {int(j): (pop[a], ready[a], end[a], int(nq[a])) for a, j in zip(np.where(sel & (typ == 3))[0], tj[sel & (typ == 3)])}
+fused = any(v[3] == 2 for v in TUt.values())
+if fused:
+    # D(q + 1) rides in TU(q): the end of TU(q) is the end of the diagonal block of block column q + 1
+    print(f"chain of front {big} (TU(q) + D(q + 1) in one task): q | TU pop ready end | end - end of the previous diagonal block")
+    prev = D[0][2] if 0 in D else None
+    ends = [prev] if prev is not None else []
+    for q in sorted(TUt):
+        t = TUt[q]
+        row = f"  {q:3d} | {t[0]:8.1f} {t[1]:8.1f} {t[2]:8.1f}"
+        if prev is not None:
+            row += f" | {t[2] - prev:6.1f}"
+        prev = t[2]
+        ends.append(prev)
+        if q < 5 or q % 8 == 0 or q >= max(TUt) - 2:
+            print(row)
+    if len(ends) > 1:
+        print(f"  mean distance between diagonal blocks {(ends[-1] - ends[0]) / (len(ends) - 1):.1f} us")
+    qs = []
+else:
+    print(f"chain of front {big}: step | D pop ready end (body) | T(q+1,q) ready end | U(q+1,q+1,->q+1) ready end | D(q+1) ready - D(q) end")
+    qs = sorted(D)
 for q in qs:
     d = D[q]
     t = T.get((q + 1, q))
