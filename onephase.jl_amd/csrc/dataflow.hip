@@ -40,6 +40,14 @@ constexpr int kDfThreadsC = 512;   // threads of a worker
 #ifndef OKKT_DF_KC
 #define OKKT_DF_KC 32
 #endif
+#ifndef OKKT_DF_STAGGER
+#define OKKT_DF_STAGGER 1
+#endif
+#ifndef OKKT_DF_STAGGER_KK
+#define OKKT_DF_STAGGER_KK (OKKT_DF_KC / 8)
+#endif
+constexpr int kDfStaggerKK = OKKT_DF_STAGGER_KK;   // ... at this k-step (4 panel columns each) of the chunk
+constexpr bool kDfStagger = OKKT_DF_STAGGER != 0;   // waves 4 - 7 of a worker request the next operand chunk half a chunk behind waves 0 - 3
 constexpr int kDfKC = OKKT_DF_KC;           // panel columns per ring slot of the update tasks
 constexpr int kDfStages = OKKT_DF_STAGES;   // operand ring of the update tasks: 16-column chunks in LDS (one workgroup per CU: nobody else covers a chunk that is late)
 
@@ -449,9 +457,14 @@ __device__ __forceinline__ void df_syrk_tiles(const DevPlan& P, int s, int j0, i
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
-    if (marks && g == 0 && tid == 0) marks[0] = wall_clock64();       // C tile and the first operand chunk have landed
-    // the slot written next was last read one iteration ago; everyone is past that barrier
-    if (g + STAGES - 1 < total) issue(g + STAGES - 1);
+    if (marks && g == 0 && tid == 0) { marks[0] = wall_clock64(); marks[3] = -(long long)clock64(); }       // C tile and the first operand chunk have landed; shader clock at the start of the main loop
+    // the slot written next was last read one iteration ago; everyone is past that barrier.  Waves k and k + 4 share a SIMD and run
+    // the same program: waves 0 - 3 request the next chunk right here, waves 4 - 7 in the middle of their MFMAs, so that one wave's
+    // LDS-DMA issue (8 requests with their address arithmetic: ~ 1 200 cycles of a 10 500-cycle chunk) falls into its partner's
+    // matrix work instead of both stalling the SIMD's matrix pipe at the same time (MI355X guide, two waves per SIMD, item 9)
+    const bool late = kDfStagger && wv >= 4;
+    const bool more = g + STAGES - 1 < total;
+    if (more && !late) issue(g + STAGES - 1);
     if (ch == pre && r + 1 < R) { load_c(r + 1); plain_until = g + STAGES; }
     const int rt0 = df_block_lo(i + r, KB, k, f), rlim = df_block_lo(i + r + 1, KB, k, f);
     const int rbase = rt0 + (wv & 1) * 64;
@@ -462,6 +475,7 @@ __device__ __forceinline__ void df_syrk_tiles(const DevPlan& P, int s, int j0, i
       const double* bl = slot + kDfKC * kSyrkLd + (wv >> 1) * WCW + (lane & 3);
 #pragma unroll
       for (int kk = 0; kk < kDfKC / 4; ++kk) {
+        if (kk == kDfStaggerKK && more && late) issue(g + STAGES - 1);
         double bv[4];
 #pragma unroll
         for (int rb = 0; rb < 4; ++rb) bv[rb] = bw[(kk * 4 + l4) * kSyrkLd + (rb & 1) + 32 * (rb >> 1)];
@@ -477,9 +491,9 @@ __device__ __forceinline__ void df_syrk_tiles(const DevPlan& P, int s, int j0, i
               acc[half * 4 + qq][rb] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[qq], bv[rb], acc[half * 4 + qq][rb], 0, 0, 1 /* neg A */);
         }
       }
-    }
+    } else if (more && late) issue(g + STAGES - 1);      // a wave without a piece of this tile still stages its rows
     if (++ch == nchunk) {
-      if (marks && g == total - 1 && tid == 0) marks[1] = wall_clock64();      // main loop done
+      if (marks && g == total - 1 && tid == 0) { marks[1] = wall_clock64(); marks[3] += (long long)clock64(); }      // main loop done: marks[3] = shader cycles of the main loop
       // the row tile is done: store it (write-through, not waited for here) and switch to the next one's accumulators
       if (active) {
 #pragma unroll

@@ -110,7 +110,7 @@ if marks is not None and (typ == 2).any():
         if not m.any():
             continue
         mk = (marks[m] - t0) / 100.0
-        print(f"  U K={128 * kq} phases (us, median): ready -> C tile + first chunk landed {np.median(mk[:, 0] - ready[m]):.1f}, main loop +{np.median(mk[:, 1] - mk[:, 0]):.1f} ({np.median(mk[:, 1] - mk[:, 0]) / (128 * kq / CHUNK):.2f} per {CHUNK}-column chunk), stores issued +{np.median(mk[:, 2] - mk[:, 1]):.1f}, drained + barrier +{np.median(end[m] - mk[:, 2]):.1f}; pop -> ready {np.median(ready[m] - pop[m]):.1f}")
+        print(f"  U K={128 * kq} phases (us, median): ready -> C tile + first chunk landed {np.median(mk[:, 0] - ready[m]):.1f}, main loop +{np.median(mk[:, 1] - mk[:, 0]):.1f} ({np.median(mk[:, 1] - mk[:, 0]) / (128 * kq / CHUNK):.2f} per {CHUNK}-column chunk), stores issued +{np.median(mk[:, 2] - mk[:, 1]):.1f}, drained + barrier +{np.median(end[m] - mk[:, 2]):.1f}; pop -> ready {np.median(ready[m] - pop[m]):.1f}; shader clock in the main loop {np.median(marks[m][:, 3] / np.maximum(marks[m][:, 1] - marks[m][:, 0], 1)) / 10:.2f} GHz ({np.median(marks[m][:, 3]) / (128 * kq / CHUNK):.0f} cycles per chunk)")
 if len(qs) > 1:
     per = (D[qs[-1]][2] - D[qs[0]][1]) / (len(qs) - 1)
     print(f"  mean distance between diagonal blocks {per:.1f} us")
