@@ -20,6 +20,7 @@
 #include "front_device.h"
 
 #include <algorithm>
+#include <type_traits>
 #include <cstdio>
 #include <cstdlib>
 
@@ -148,11 +149,26 @@ __device__ __forceinline__ void df_trsm_tile(const DevPlan& P, int s, int q, int
 // worker's), solves its 128 rows like df_trsm_tile, keeps W in LDS (128 x 128, the layout of the trailing update's operand
 // slots; L = W * (1 / d) is formed on the fly, the very product that is stored) and applies it to the diagonal tile with the
 // trailing update's MFMA loop.  Same operations per entry in the same order as T followed by U: bitwise the same numbers.
+//
+// Both steps run at the FP64 matrix rate of ONE CU (7 us for the rows, 9 - 11 us for the ten 32 x 32 sub-tiles of the lower
+// triangle), so the block row may be split between two workers (`part`):
+//   part 1 (task TA): rows [r0, r0 + 64) -- solves them, stores their W and L (half state 1), updates the sub-tiles that need
+//                     nothing else ((0,0), (1,0), (1,1) of the 4 x 4 grid), stores them (half state 2: published by the worker);
+//   part 2 (task TU): rows [r0 + 64, rlim) -- solves them, fetches the W of the upper rows once half state 1 is seen, updates the
+//                     seven sub-tiles of its rows, takes the three of part 1 from memory (half state 2) and goes on as the
+//                     unsplit task does (the diagonal block's factorisation from LDS, or the tile's publication);
+//   part 0: everything in one task (block rows of at most 64 rows, OKKT_DF_SPLIT_TU=0).
+// The half state lives in the unused upper slot (q, q + 1) of the front's tile states.
+// units (row block | column half-block << 2 of the 4 x 8 grid of 32 x 16 units; 255 = none) per part, wave and slot: see df_tu_tile
+__device__ const unsigned char kTuUnits[3][8][3] = {
+    {{0, 10, 19}, {4, 14, 23}, {1, 18, 27}, {5, 22, 31}, {9, 3, 255}, {13, 7, 255}, {2, 11, 255}, {6, 15, 255}},
+    {{0, 255, 255}, {4, 255, 255}, {1, 255, 255}, {5, 255, 255}, {9, 255, 255}, {13, 255, 255}, {255, 255, 255}, {255, 255, 255}},
+    {{18, 2, 255}, {22, 6, 255}, {19, 10, 255}, {23, 14, 255}, {27, 3, 255}, {31, 7, 255}, {255, 11, 255}, {255, 15, 255}}};
 constexpr size_t kDfTuLds = ((size_t)128 * kSyrkLd + 128) * sizeof(double);
 constexpr int kDfTileLd = 130;       // leading dimension of the diagonal tile handed from TU to D through LDS (even: 16-byte rows pairs stay aligned)
-__device__ __forceinline__ bool df_tu_tile(const DevPlan& P, int s, int q, int r0, int rlim, const int* dstate, int dval, int* diag_state, int* row_state, bool with_d, int* s_flag, double* sm, long long* marks) {
+__device__ __forceinline__ bool df_tu_tile(const DevPlan& P, int s, int q, int r0, int rlim, const int* dstate, int dval, int* diag_state, int* row_state, int* half_state, int part,
+                                           bool with_d, int* s_flag, double* sm, long long* marks) {
   constexpr int NBLK = 4, NB = 128, NPAIR = NBLK * (NBLK + 1) / 2;
-  constexpr int NW = kSyrkNW, WCW = 128 / (NW / 2), NCG = WCW / 4;
   int tid_ = threadIdx.x;
   asm volatile("" : "+v"(tid_));
   const int tid = tid_, lane = tid & 63, wv = tid >> 6;
@@ -165,59 +181,84 @@ __device__ __forceinline__ bool df_tu_tile(const DevPlan& P, int s, int q, int r
   double* Wb = P.wbuf + P.wbuf_pos[s] + (size_t)j0 * f;
   const double* X = P.invl + P.invl_pos[s] + (size_t)q * NB * NB;
   double* rdv = sm + NPAIR * kIB * kIB;
-  const int row = r0 + wv * 16 + (lane & 15);
+  // the rows this task solves: sixteen per wave, eight waves for a whole block row, four for a half
+  const int roff = part == 2 ? 64 : 0;
+  const int hrows = part == 0 ? 128 : 64;
+  const bool solver = part == 0 || wave < 4;
+  const int trow = roff + (part == 0 ? wv : (wv & 3)) * 16 + (lane & 15);      // row of the tile
+  const int row = r0 + trow;
   const int rowc = min(row, f - 1);
-  const bool valid = row < rlim;
+  const bool valid = solver && row < rlim;
   const int lk = lane >> 4, li = lane & 3;
   const int l15 = lane & 15, l4 = lane >> 4;
   double t[NBLK * 8];
 #pragma unroll
-  for (int qq = 0; qq < NBLK * 8; ++qq) {
-    const int c = 4 * qq + lk;
-    t[qq] = keep_f64(F[(size_t)(j0 + c) * f + rowc], valid);
+  for (int qq = 0; qq < NBLK * 8; ++qq) t[qq] = 0.0;
+  if (solver) {
+#pragma unroll
+    for (int qq = 0; qq < NBLK * 8; ++qq) {
+      const int c = 4 * qq + lk;
+      t[qq] = keep_f64(F[(size_t)(j0 + c) * f + rowc], valid);
+    }
   }
-  // the wave's 64 x 32 piece of the diagonal tile (rows and columns [r0, rlim))
-  const int rbase = r0 + (wv & 1) * 64;
-  const int cbase = r0 + (wv >> 1) * WCW;
-  const bool active = !(rbase + 63 < cbase) && rbase < rlim && cbase < rlim;
-  double acc[NCG][4];
+  // The diagonal tile (rows and columns [r0, rlim)) is updated in UNITS of 32 rows x 16 columns -- 8 MFMAs per k-step of four
+  // panel columns, 4096 cycles of the SIMD's matrix pipe (1.75 us).  Only the lower triangle counts: 20 units of 32, dealt over the
+  // waves so that every SIMD (waves w and w + 4 share one: scripts/simd_probe.hip) has TWO waves issuing -- one wave alone gets an
+  // FP64 MFMA through every 32 cycles instead of every 16 (measured here: 512 MFMAs of one wave 6.9 us; the 64 x 32 pieces of the
+  // first version, one or two per SIMD, took 10.7 us for the tile):
+  //   part 0: 3, 3, 3, 3, 2, 2, 2, 2 units per wave (five per SIMD);
+  //   part 1: its six units (row blocks 0 and 1) on waves 0-5;
+  //   part 2: the six units of its own rows and columns on waves 0-5 (slot 0: they run while the workgroup waits for the other
+  //           half's W), the eight left of them on waves 0-7 (slot 1).
+  constexpr int NU = 3;
+  int ucode[NU];
 #pragma unroll
-  for (int cg = 0; cg < NCG; ++cg) {
-    const int c = cbase + cg * 4 + l4;
-    const double* colp = F + (size_t)min(c, f - 1) * f;
+  for (int u = 0; u < NU; ++u) ucode[u] = __builtin_amdgcn_readfirstlane((int)kTuUnits[part][wave][u]);
+  auto unit_on = [&](int u) { return ucode[u] != 255 && r0 + 32 * (ucode[u] & 3) < rlim && r0 + 16 * (ucode[u] >> 2) < rlim; };
+  double acc[NU][4][2];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int r = rbase + 2 * l15 + 32 * h;
-      const int rcl = min(r, f - 2);
-      const int shift = r - rcl;
+  for (int u = 0; u < NU; ++u) {
+#pragma unroll
+    for (int cg = 0; cg < 4; ++cg) { acc[u][cg][0] = 0.0; acc[u][cg][1] = 0.0; }
+    if (!unit_on(u)) continue;
+    const int r = r0 + 32 * (ucode[u] & 3) + 2 * l15;
+    const int rcl = min(r, f - 2);
+    const int shift = r - rcl;
+#pragma unroll
+    for (int cg = 0; cg < 4; ++cg) {
+      const int c = r0 + 16 * (ucode[u] >> 2) + cg * 4 + l4;
+      const double* colp = F + (size_t)min(c, f - 1) * f;
       d2_t v;
       __builtin_memcpy(&v, colp + rcl, 16);
       const double e0 = shift == 0 ? v[0] : v[1];
-      acc[cg][2 * h] = keep_f64(e0, r < rlim && c < rlim && r >= c);
-      acc[cg][2 * h + 1] = keep_f64(v[1], shift == 0 && r + 1 < rlim && c < rlim && r + 1 >= c);
+      acc[u][cg][0] = keep_f64(e0, r < rlim && c < rlim && r >= c);
+      acc[u][cg][1] = keep_f64(v[1], shift == 0 && r + 1 < rlim && c < rlim && r + 1 >= c);
     }
   }
-  // second wait: the diagonal block of panel q
-  if (wave == 0) {
-    int ok = 1, spins = 0;
-    for (;;) {
-      if (__builtin_amdgcn_readfirstlane(ld_state(dstate)) >= dval) break;
-      const int stop = P.want_neg >= 0 ? __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&P.counters[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : 0;
-      const int dead = __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&P.counters[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-      if (stop | dead) { ok = 0; break; }
-      if (++spins >= (1 << 21)) {
-        if (lane == 0) { atomicAdd(&P.counters[3], 1ull); atomicExch(&P.counters[5], 1ull); }
-        ok = 0;
-        break;
+  // a wait inside the task (the diagonal block of panel q; the other half's states): the worker's protocol, one flag word per wait
+  auto await = [&](const int* state, int least, int* flag, int poller) -> bool {
+    if (wave == poller) {
+      int ok = 1, spins = 0;
+      for (;;) {
+        if (__builtin_amdgcn_readfirstlane(ld_state(state)) >= least) break;
+        const int stop = P.want_neg >= 0 ? __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&P.counters[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : 0;
+        const int dead = __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&P.counters[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        if (stop | dead) { ok = 0; break; }
+        if (++spins >= (1 << 21)) {
+          if (lane == 0) { atomicAdd(&P.counters[3], 1ull); atomicExch(&P.counters[5], 1ull); }
+          ok = 0;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
       }
-      __builtin_amdgcn_s_sleep(1);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      *flag = ok;
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    *s_flag = ok;
-  }
-  __syncthreads();
-  if (__builtin_amdgcn_readfirstlane(*s_flag) == 0) return false;
+    __syncthreads();
+    return __builtin_amdgcn_readfirstlane(*flag) != 0;
+  };
+  if (!await(dstate, dval, s_flag, 0)) return false;
   if (marks && tid == 0) marks[0] = wall_clock64();        // D(q) has arrived
   {
     const int e = tid * 2;
@@ -239,49 +280,52 @@ __device__ __forceinline__ bool df_tu_tile(const DevPlan& P, int s, int q, int r
     if (tid < NB) rdv[tid] = 1.0 / P.dvals[col0 + j0 + tid];
   }
   __syncthreads();
+  if (solver) {
 #pragma unroll
-  for (int bi = 0; bi < NBLK; ++bi) {
+    for (int bi = 0; bi < NBLK; ++bi) {
 #pragma unroll
-    for (int bp = 0; bp < bi; ++bp) {
-      const double* Lb = sm + (bi * (bi + 1) / 2 + bp) * kIB * kIB;
+      for (int bp = 0; bp < bi; ++bp) {
+        const double* Lb = sm + (bi * (bi + 1) / 2 + bp) * kIB * kIB;
 #pragma unroll
-      for (int gp = 0; gp < 8; ++gp)
+        for (int gp = 0; gp < 8; ++gp)
 #pragma unroll
-        for (int g = 0; g < 8; ++g)
-          t[bi * 8 + gp] = __builtin_amdgcn_mfma_f64_4x4x4f64(Lb[(gp * 4 + li) + (g * 4 + lk) * kIB], t[bp * 8 + g], t[bi * 8 + gp], 0, 0, 1 /* neg A */);
+          for (int g = 0; g < 8; ++g)
+            t[bi * 8 + gp] = __builtin_amdgcn_mfma_f64_4x4x4f64(Lb[(gp * 4 + li) + (g * 4 + lk) * kIB], t[bp * 8 + g], t[bi * 8 + gp], 0, 0, 1 /* neg A */);
+      }
+      const double* Xb = sm + (bi * (bi + 1) / 2 + bi) * kIB * kIB;
+      double wt[8];
+#pragma unroll
+      for (int gp = 0; gp < 8; ++gp) {
+        wt[gp] = 0.0;
+#pragma unroll
+        for (int g = 0; g <= gp; ++g)
+          wt[gp] = __builtin_amdgcn_mfma_f64_4x4x4f64(Xb[(gp * 4 + li) + (g * 4 + lk) * kIB], t[bi * 8 + g], wt[gp], 0, 0, 0);
+      }
+#pragma unroll
+      for (int gp = 0; gp < 8; ++gp) t[bi * 8 + gp] = wt[gp];
     }
-    const double* Xb = sm + (bi * (bi + 1) / 2 + bi) * kIB * kIB;
-    double wt[8];
-#pragma unroll
-    for (int gp = 0; gp < 8; ++gp) {
-      wt[gp] = 0.0;
-#pragma unroll
-      for (int g = 0; g <= gp; ++g)
-        wt[gp] = __builtin_amdgcn_mfma_f64_4x4x4f64(Xb[(gp * 4 + li) + (g * 4 + lk) * kIB], t[bi * 8 + g], wt[gp], 0, 0, 0);
-    }
-#pragma unroll
-    for (int gp = 0; gp < 8; ++gp) t[bi * 8 + gp] = wt[gp];
   }
   if (marks && tid == 0) marks[1] = wall_clock64();        // rows solved
   const double myrd = tid < NB ? rdv[tid] : 0.0;
   __syncthreads();                       // every wave is done with the staged blocks and the reciprocals
   double* Wl = sm;                       // [128 panel columns][kSyrkLd]: W(r0 + r, j0 + p) at p * kSyrkLd + r
   double* rd2 = sm + (size_t)128 * kSyrkLd;
+  if (solver) {
 #pragma unroll
-  for (int qq = 0; qq < NBLK * 8; ++qq) Wl[(size_t)(4 * qq + lk) * kSyrkLd + wv * 16 + l15] = t[qq];      // rows past the block are zero
+    for (int qq = 0; qq < NBLK * 8; ++qq) Wl[(size_t)(4 * qq + lk) * kSyrkLd + trow] = t[qq];      // rows past the block are zero
+  }
   if (tid < NB) rd2[tid] = myrd;
   __syncthreads();
-  if (marks && tid == 0) marks[2] = wall_clock64();        // W in LDS
-  // W and L = W D^-1 of the block row leave from LDS: 16-byte write-through stores of two consecutive rows, 1 KiB of one column
-  // per wave instruction (the 8-byte sc1 stores straight from the solve's register layout took 9 us of the 42 between two diagonal
-  // blocks).  With D(q + 1) in the task they go out BEFORE the tile update, which covers their drain: the other rows' updates of
-  // block column q + 1 wait for them (publishing them from inside the factorisation, 4 us later, cost S-C3 1.5 %).
-  auto store_wl = [&]() {
-    const int nrow = rlim - r0;
-#pragma unroll 4
-    for (int it = 0; it < 16; ++it) {
-      const int idx = it * kDfThreadsC + tid;
-      const int p = idx >> 6, x2 = (idx & 63) * 2;
+  if (marks && tid == 0 && part == 0) marks[2] = wall_clock64();        // W in LDS (a split task: the hand-over of the upper rows' W, below)
+  // W and L = W D^-1 of the task's rows leave from LDS: 16-byte write-through stores of two consecutive rows, 1 KiB (512 B for
+  // a half) of one column per wave instruction (the 8-byte sc1 stores straight from the solve's register layout took 9 us of the 42
+  // between two diagonal blocks).
+  auto store_wl = [&](int first_thread, int nthreads) {
+    const int nrow = min(rlim - r0, roff + hrows);
+    const int sh = part == 0 ? 6 : 5;                      // log2 of the row pairs per column
+    if (tid < first_thread || tid >= first_thread + nthreads) return;
+    for (int idx = tid - first_thread; idx < (128 << sh); idx += nthreads) {
+      const int p = idx >> sh, x2 = roff + (idx & ((1 << sh) - 1)) * 2;
       d2_t w;
       __builtin_memcpy(&w, Wl + (size_t)p * kSyrkLd + x2, 16);
       const double rp = rd2[p];
@@ -292,73 +336,140 @@ __device__ __forceinline__ bool df_tu_tile(const DevPlan& P, int s, int q, int r
       else if (x2 < nrow) { st_agent_f64(wdst, w[0]); st_agent_f64(ldst, l[0]); }
     }
   };
-  if (active) {
-    const double* bw = Wl + (wv & 1) * 64 + 2 * l15;
-    const double* bl = Wl + (wv >> 1) * WCW + (lane & 3);
+  // the update of unit u: the operand fragments of the next k-step are requested before the products of the current one are issued
+  auto update_unit = [&](auto uc) {
+    constexpr int u = decltype(uc)::value;
+    if (!unit_on(u)) return;
+    const double* bw = Wl + 32 * (ucode[u] & 3) + 2 * l15;
+    const double* bl = Wl + 16 * (ucode[u] >> 2) + (lane & 3);
+    double nrd, nav[4];
+    d2_t nbv;
+    auto fetch = [&](int kk) {
+      nrd = rd2[kk * 4 + l4];
+      __builtin_memcpy(&nbv, bw + (kk * 4 + l4) * kSyrkLd, 16);
+#pragma unroll
+      for (int cg = 0; cg < 4; ++cg) nav[cg] = bl[(kk * 4 + l4) * kSyrkLd + cg * 4];
+    };
+    fetch(0);
 #pragma unroll 4
     for (int kk = 0; kk < NB / 4; ++kk) {
-      const double rdp = rd2[kk * 4 + l4];
-      double bv[4];
+      double av[4];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const d2_t bv = nbv;
 #pragma unroll
-      for (int rb = 0; rb < 4; ++rb) bv[rb] = bw[(kk * 4 + l4) * kSyrkLd + (rb & 1) + 32 * (rb >> 1)];
+      for (int cg = 0; cg < 4; ++cg) av[cg] = nav[cg] * nrd;
+      fetch(min(kk + 1, NB / 4 - 1));
 #pragma unroll
-      for (int half = 0; half < NCG / 4; ++half) {
-        double av[4];
-#pragma unroll
-        for (int qq = 0; qq < 4; ++qq) av[qq] = bl[(kk * 4 + l4) * kSyrkLd + (half * 4 + qq) * 4] * rdp;
-#pragma unroll
-        for (int qq = 0; qq < 4; ++qq)
-#pragma unroll
-          for (int rb = 0; rb < 4; ++rb)
-            acc[half * 4 + qq][rb] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[qq], bv[rb], acc[half * 4 + qq][rb], 0, 0, 1 /* neg A */);
+      for (int cg = 0; cg < 4; ++cg) {
+        acc[u][cg][0] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[cg], bv[0], acc[u][cg][0], 0, 0, 1 /* neg A */);
+        acc[u][cg][1] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[cg], bv[1], acc[u][cg][1], 0, 0, 1 /* neg A */);
       }
     }
-    if (!with_d) {
+  };
+  if (part == 1) {
+    // the other half waits for these rows: out, drained, published
+    store_wl(0, kDfThreadsC);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (wave == 0) __hip_atomic_store(half_state, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (marks && tid == 0) marks[2] = wall_clock64();      // W and L of the upper rows stored, drained, published
+    update_unit(std::integral_constant<int, 0>());
+  } else if (part == 2) {
+    // W and L of these rows to memory (every wave its share: one wave alone has 64 stores in flight at most and took 8 us over
+    // them); then waves 0-5 the units of its own rows and columns, wave 7 the wait for the other half's W
+    store_wl(6 * 64, 128);
+    update_unit(std::integral_constant<int, 0>());
+    if (!await(half_state, 1, s_flag + 1, 0)) return false;
+    if (marks && tid == 0) marks[2] = wall_clock64();      // ... and seen by the other half
+    // W of the upper 64 rows (the column operand of this half's sub-tiles left of the diagonal) from memory into the image
+#pragma unroll 4
+    for (int it = 0; it < 8; ++it) {
+      const int idx = it * kDfThreadsC + tid;
+      const int p = idx >> 5, x2 = (idx & 31) * 2;
+      d2_t w;
+      __builtin_memcpy(&w, Wb + (size_t)p * f + r0 + x2, 16);
+      __builtin_memcpy(Wl + (size_t)p * kSyrkLd + x2, &w, 16);
+    }
+    __syncthreads();
+    update_unit(std::integral_constant<int, 1>());
+  } else {
+    update_unit(std::integral_constant<int, 0>());
+    update_unit(std::integral_constant<int, 1>());
+    update_unit(std::integral_constant<int, 2>());
+  }
+  // the wave's units to memory (write-through) ...
+  auto store_piece = [&]() {
 #pragma unroll
-      for (int cg = 0; cg < NCG; ++cg) {
-        const int c = cbase + cg * 4 + l4;
+    for (int u = 0; u < NU; ++u) {
+      if (!unit_on(u)) continue;
+      const int r = r0 + 32 * (ucode[u] & 3) + 2 * l15;
+#pragma unroll
+      for (int cg = 0; cg < 4; ++cg) {
+        const int c = r0 + 16 * (ucode[u] >> 2) + cg * 4 + l4;
         if (c >= rlim) continue;
         double* colp = F + (size_t)c * f;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int r = rbase + 2 * l15 + 32 * h;
-          if (r + 1 < rlim && r >= c) {
-            st_sc1_f64x2(colp + r, (d2_t){acc[cg][2 * h], acc[cg][2 * h + 1]});
-          } else {
-            if (r < rlim && r >= c) st_agent_f64(colp + r, acc[cg][2 * h]);
-            if (r + 1 < rlim && r + 1 >= c) st_agent_f64(colp + r + 1, acc[cg][2 * h + 1]);
-          }
+        if (r + 1 < rlim && r >= c) {
+          st_sc1_f64x2(colp + r, (d2_t){acc[u][cg][0], acc[u][cg][1]});
+        } else {
+          if (r < rlim && r >= c) st_agent_f64(colp + r, acc[u][cg][0]);
+          if (r + 1 < rlim && r + 1 >= c) st_agent_f64(colp + r + 1, acc[u][cg][1]);
         }
       }
     }
+  };
+  // ... or into the LDS tile the diagonal-block factorisation reads (column-major, leading dimension kDfTileLd, over the W image)
+  auto piece_to_lds = [&]() {
+    double* Tl = sm;
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      if (!unit_on(u)) continue;
+      const int r = 32 * (ucode[u] & 3) + 2 * l15;
+#pragma unroll
+      for (int cg = 0; cg < 4; ++cg) {
+        const int c = 16 * (ucode[u] >> 2) + cg * 4 + l4;
+        const d2_t v = (d2_t){acc[u][cg][0], acc[u][cg][1]};
+        __builtin_memcpy(Tl + (size_t)c * kDfTileLd + r, &v, 16);
+      }
+    }
+  };
+  if (part == 1) {
+    // sub-tiles (0,0), (1,0), (1,1): to memory; the worker drains, meets and publishes half state 2
+    if (marks && tid == 0) marks[3] = wall_clock64();
+    store_piece();
+    return true;
   }
   if (!with_d) {
     // the diagonal tile first: it is what D(q + 1) waits for.  Every storing wave drains, the workgroup meets, one wave publishes.
+    store_piece();
+    if (part == 2 && !await(half_state, 2, s_flag + 2, 0)) return false;      // ... the other half's sub-tiles are part of the tile
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (wave == 0) __hip_atomic_store(diag_state, dval, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // tile (q + 1, q + 1) has received panel q (= q + 1 tasks)
     if (marks && tid == 0) marks[3] = wall_clock64();      // diagonal tile updated and published
-    store_wl();
+    if (part == 0) store_wl(0, kDfThreadsC);
   } else {
     // TU(q) + D(q + 1) in one task: the block row's W and L go out (the other rows' updates of block column q + 1 wait for them:
     // stored ahead of the tile update they delayed it by 10 us, published from inside the factorisation they came 4 us late --
     // both measured slower on S-C3), then the updated diagonal tile is handed to the diagonal-block factorisation through LDS
-    // (column-major, leading dimension kDfTileLd, over the W image) -- no trip through HBM, no hand-off
+    // -- no trip through HBM, no hand-off
     if (marks && tid == 0) marks[3] = wall_clock64();      // diagonal tile updated
-    store_wl();
+    if (part == 0) store_wl(0, kDfThreadsC);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();                     // every wave has read its part of the W image
-    if (active) {
+    piece_to_lds();
+    if (part == 2) {
+      if (!await(half_state, 2, s_flag + 2, 0)) return false;
+      // the other half's sub-tiles: rows and columns [0, 64) of the tile, from memory
       double* Tl = sm;
 #pragma unroll
-      for (int cg = 0; cg < NCG; ++cg) {
-        const int c = cbase + cg * 4 + l4 - r0;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int r = rbase + 2 * l15 + 32 * h - r0;
-          const d2_t v = (d2_t){acc[cg][2 * h], acc[cg][2 * h + 1]};
-          __builtin_memcpy(Tl + (size_t)c * kDfTileLd + r, &v, 16);
-        }
+      for (int it = 0; it < 4; ++it) {
+        const int idx = it * kDfThreadsC + tid;
+        const int c = idx >> 5, x2 = (idx & 31) * 2;
+        d2_t v;
+        __builtin_memcpy(&v, F + (size_t)(r0 + c) * f + r0 + x2, 16);
+        v[0] = keep_f64(v[0], x2 >= c);
+        v[1] = keep_f64(v[1], x2 + 1 >= c);
+        __builtin_memcpy(Tl + (size_t)c * kDfTileLd + x2, &v, 16);
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -563,7 +674,7 @@ __global__ __launch_bounds__(kDfThreads, 1) void k_front_dataflow(DevPlan P, con
         else if (type == kDfT) {
           if (ln == 0) { addr = st + (size_t)j * TB + j; need = j + 1; }
           if (ln == 1) { addr = st + (size_t)i * TB + j; need = j; }
-        } else if (type == kDfTU) {      // the tiles (q + 1, q) and (q + 1, q + 1), q = j; D(q) is awaited inside the task
+        } else if (type == kDfTU || type == kDfTA) {      // the tiles (q + 1, q) and (q + 1, q + 1), q = j; D(q) is awaited inside the task
           if (ln == 0) { addr = st + (size_t)i * TB + j; need = j; }
           if (ln == 1) { addr = st + (size_t)i * TB + i; need = j; }
         } else {
@@ -615,12 +726,17 @@ __global__ __launch_bounds__(kDfThreads, 1) void k_front_dataflow(DevPlan P, con
     } else if (type == kDfT) {
       if (!(dbg & 2)) df_trsm_tile(P, s, j, df_block_lo(i, KB, k, f), df_block_lo(i + 1, KB, k, f), sm);
       mine = st + (size_t)i * TB + j; newv = j + 1;
-    } else if (type == kDfTU) {
-      // nq == 2: D(q + 1) is part of the task (the updated diagonal tile reaches it through LDS)
-      const bool with_d = nq == 2;
-      if (!df_tu_tile(P, s, j, df_block_lo(i, KB, k, f), df_block_lo(i + 1, KB, k, f), st + (size_t)j * TB + j, j + 1, st + (size_t)i * TB + i, st + (size_t)i * TB + j, with_d,
+    } else if (type == kDfTU || type == kDfTA) {
+      // nq & 2: D(q + 1) is part of the task (the updated diagonal tile reaches it through LDS); nq & 4: the lower half of a split block
+      // row (the upper half is the TA task right before it in the queue)
+      const bool with_d = type == kDfTU && (nq & 2);
+      const int part = type == kDfTA ? 1 : ((nq & 4) ? 2 : 0);
+      int* hs = st + (size_t)j * TB + i;          // the unused upper slot (q, q + 1): the state of the upper half
+      if (!df_tu_tile(P, s, j, df_block_lo(i, KB, k, f), df_block_lo(i + 1, KB, k, f), st + (size_t)j * TB + j, j + 1, st + (size_t)i * TB + i, st + (size_t)i * TB + j, hs, part, with_d,
                       &s_ctl[2], sm, tlog ? tlog + (size_t)t * 8 + 4 : nullptr)) return;
-      if (with_d) {
+      if (type == kDfTA) {
+        mine = hs; newv = 2;
+      } else if (with_d) {
         diag2_body<true>(P, s, i, 128, tol, sm, sm, kDfTileLd);
         mine = st + (size_t)i * TB + i; newv = i + 1;          // tile (q + 1, q) was published inside the task
       } else {
@@ -659,6 +775,7 @@ std::string df_setup(Numeric& N) {
   N.df_workers = getenv("OKKT_DF_WORKERS") ? std::max(1, atoi(getenv("OKKT_DF_WORKERS"))) : ncu;
   N.df_group = getenv("OKKT_DF_GROUP") ? std::max(1, std::min(atoi(getenv("OKKT_DF_GROUP")), 16)) : 4;
   N.df_fuse_d = getenv("OKKT_DF_FUSE_D") ? atoi(getenv("OKKT_DF_FUSE_D")) : 1;
+  N.df_split_tu = getenv("OKKT_DF_SPLIT_TU") ? atoi(getenv("OKKT_DF_SPLIT_TU")) : 1;
   N.df_rows = getenv("OKKT_DF_ROWS") ? std::max(1, std::min(atoi(getenv("OKKT_DF_ROWS")), 8)) : 1;
   auto do_sched = [&](std::vector<LevelSchedule>& levels) {
     for (LevelSchedule& L : levels) {
@@ -678,7 +795,7 @@ std::string df_setup(Numeric& N) {
         g.df_flops += (double)k * f * f - (double)k * k * f + (double)k * k * k / 3.0;
       }
       double model = 0;
-      df_build_queue(fronts, N.df_workers, N.df_group, N.df_rows, N.df_fuse_d != 0, q, &model);
+      df_build_queue(fronts, N.df_workers, N.df_group, N.df_rows, N.df_fuse_d != 0, N.df_split_tu != 0, q, &model);
       g.df_off = (int64_t)all.size();
       g.df_cnt = (int)q.size();
       g.df_head = nheads++;

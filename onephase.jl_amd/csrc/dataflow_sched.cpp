@@ -9,6 +9,8 @@
 //   U(i, j, q0, nq)  A(i, j) -= sum_{q0 <= q < q0 + nq} W(i, q) L(j, q)^T             after T(i, q), T(j, q) and the previous update of (i, j)
 //   TU(q)            T(q + 1, q) and U(q + 1, q + 1, q, 1) in one task (q + 1 < KB): the two steps between the diagonal blocks of
 //                    consecutive block columns -- the critical path -- without a hand-off and without a trip through memory
+//   TA(q)            the upper 64 rows of TU(q)'s block row, when it has more than 64 (split_tu): both steps run at the FP64 matrix rate
+//                    of one CU, two workers halve them.  Emitted right before TU(q), which waits for TA's two states inside the task
 // A tile receives the panels in ascending order (the same sequence of operations per entry as the per-step kernels: bitwise the
 // same factor).  Panels are applied `group` at a time (K = 128 * group) except that the LAST panel of a pivot column comes alone:
 // it is the one the next diagonal block (or panel tile) waits for.
@@ -51,7 +53,7 @@ struct FrontGrid {
 
 }  // namespace
 
-void df_build_queue(const std::vector<DfFront>& fronts, int workers, int group, int rows_per_task, bool fuse_d, std::vector<DfTask>& out, double* model_us) {
+void df_build_queue(const std::vector<DfFront>& fronts, int workers, int group, int rows_per_task, bool fuse_d, bool split_tu, std::vector<DfTask>& out, double* model_us) {
   const int G = std::max(1, group);
   const int RT = std::max(1, std::min(rows_per_task, 8));
   // Time model (us, measured on MI355X with one workgroup per CU: D 39-45, T 25-32, U 25-30 at K = 128 and 45-52 at K = 256, TU 40
@@ -148,8 +150,16 @@ void df_build_queue(const std::vector<DfFront>& fronts, int workers, int group, 
       Node& nd = nodes[x];
       // fuse_d: D(q), q >= 1, is carried out by the worker of TU(q - 1) right behind the update of its tile (no task of its own; it stays
       // in this simulation, where it starts on some worker the moment TU(q - 1) ends -- the same thing for the model)
-      if (!(fuse_d && nd.type == kDfD && nd.i > 0))
-        out.push_back({fronts[nd.front].s, nd.type | ((nd.type == kDfTU && fuse_d ? 2 : nd.nq) << 8) | (nd.rows << 16), nd.i | (nd.j << 16), nd.q0});
+      if (nd.type == kDfTU) {
+        // a block row of more than 64 rows is split between two workers: TA (the upper 64 rows) goes into the queue right before
+        // TU (the rest, and everything behind the tile update) -- TU waits for TA's two states, so TA has to be the earlier pop
+        const FrontGrid& gg = grids[nd.front];
+        const int lo = std::min(nd.i * 128, gg.k), hi = std::min(lo + 128, gg.k);      // nd.i = q + 1 < KB: a pivot block
+        const bool split = split_tu && hi - lo > 64;
+        if (split) out.push_back({fronts[nd.front].s, kDfTA | (1 << 8) | (1 << 16), nd.i | (nd.j << 16), nd.q0});
+        out.push_back({fronts[nd.front].s, kDfTU | (((fuse_d ? 2 : 1) | (split ? 4 : 0)) << 8) | (nd.rows << 16), nd.i | (nd.j << 16), nd.q0});
+      } else if (!(fuse_d && nd.type == kDfD && nd.i > 0))
+        out.push_back({fronts[nd.front].s, nd.type | (nd.nq << 8) | (nd.rows << 16), nd.i | (nd.j << 16), nd.q0});
       running.push({now + nd.dur, x});
       --idle;
       if (nd.type == kDfD && nd.i + 1 < grids[nd.front].KB) {      // TU(q) starts beside D(q) and ends 24 us behind it

@@ -84,12 +84,12 @@ struct DevPlan {
 };
 
 // one task of the dataflow factorisation (dataflow_sched.cpp builds the queues, dataflow.hip runs them)
-enum { kDfD = 0, kDfT = 1, kDfU = 2, kDfTU = 3 };
+enum { kDfD = 0, kDfT = 1, kDfU = 2, kDfTU = 3, kDfTA = 4 };
 struct DfTask { int front; int type_nq; int ij; int q0; };     // type | nq << 8 | rows << 16 (update tasks: tiles (i .. i + rows - 1, j)), i | j << 16
 struct DfFront { int s, f, k; };
 // queue of the fronts of one level in the start order of a simulated list schedule on `workers` workers; `group` panels per
 // update task where the tile allows it; model_us = the simulated makespan
-void df_build_queue(const std::vector<DfFront>& fronts, int workers, int group, int rows_per_task, bool fuse_d, std::vector<DfTask>& out, double* model_us);
+void df_build_queue(const std::vector<DfFront>& fronts, int workers, int group, int rows_per_task, bool fuse_d, bool split_tu, std::vector<DfTask>& out, double* model_us);
 
 constexpr int kCountSlots = 64, kCountStride = 16;
 #ifndef OKKT_SOLVE_BLOCK
@@ -182,6 +182,7 @@ struct Numeric {
   int dataflow = 1;
   int df_group = 4;                    // panels per update task (K = 128 * group) where the column allows it (OKKT_DF_GROUP; S-metric 19.1 / 18.3 / 18.2 ms at 2 / 3 / 4)
   int df_fuse_d = 1;                   // D(q + 1) in the task of TU(q): the diagonal tile passes through LDS (OKKT_DF_FUSE_D=0: a task of its own)
+  int df_split_tu = 1;                 // block rows of more than 64 rows: TU(q) as two tasks on two workers, TA(q) (upper 64 rows) and TU(q) (OKKT_DF_SPLIT_TU=0: one)
   int df_rows = 1;                     // row tiles per bulk update task (OKKT_DF_ROWS; 2 and 4 measured slower: the coarser tasks cost the schedule more than the shared prologue saves)
   int df_workers = 256;                // workers of the simulated schedule (and the grid of the launch): one workgroup per CU
   DfTask* df_tasks = nullptr;

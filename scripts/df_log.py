@@ -41,8 +41,8 @@ ready = (ready - t0) / 100.0
 end = (end - t0) / 100.0
 span = end.max()
 print(f"launch {which}: {len(L)} tasks, {len(set(worker))} workers, span {span:.1f} us")
-names = {0: "D", 1: "T", 2: "U", 3: "TU"}
-for k in (0, 1, 2, 3):
+names = {0: "D", 1: "T", 2: "U", 3: "TU", 4: "TA"}
+for k in (0, 1, 2, 3, 4):
     m = typ == k
     if not m.any():
         continue
@@ -65,7 +65,7 @@ U = {}
 for a in np.where(sel & (typ == 2))[0]:
     U[(int(ti[a]), int(tj[a]), int(q0[a]) + int(nq[a]))] = (pop[a], ready[a], end[a])
 TUt = {int(j): (pop[a], ready[a], end[a], int(nq[a])) for a, j in zip(np.where(sel & (typ == 3))[0], tj[sel & (typ == 3)])}
-fused = any(v[3] == 2 for v in TUt.values())
+fused = any(v[3] & 2 for v in TUt.values())
 if fused:
     # D(q + 1) rides in TU(q): the end of TU(q) is the end of the diagonal block of block column q + 1
     print(f"chain of front {big} (TU(q) + D(q + 1) in one task): q | TU pop ready end | end - end of the previous diagonal block")
@@ -100,10 +100,27 @@ for q in qs:
         row += f" | {dn[1] - d[2]:6.1f}"
     if q < 6 or q % 8 == 0 or q >= qs[-1] - 2:
         print(row)
-if marks is not None and (typ == 3).any():
-    m = typ == 3
+if marks is not None and ((typ == 3) & ((nq & 4) != 0)).any():
+    # split block rows: absolute times of the hand-over, relative to the arrival of D(q) at the lower half
+    ta = {(int(f_), int(j_)): a for a, (f_, j_) in enumerate(zip(front, tj)) if typ[a] == 4}
+    rows_ = []
+    for a in np.where((typ == 3) & ((nq & 4) != 0))[0]:
+        b_ = ta.get((int(front[a]), int(tj[a])))
+        if b_ is None:
+            continue
+        mb, ma = (marks[a] - t0) / 100.0, (marks[b_] - t0) / 100.0
+        rows_.append([ma[0] - mb[0], ma[1] - mb[0], ma[2] - mb[0], ma[3] - mb[0], end[b_] - mb[0], mb[1] - mb[0], mb[2] - mb[0], mb[3] - mb[0]])
+    if rows_:
+        r_ = np.mean(np.array(rows_), axis=0)
+        print(f"  split block rows (us after D(q) reached the lower half, mean): upper half: D seen {r_[0]:.1f}, rows solved {r_[1]:.1f}, W / L out and published {r_[2]:.1f}, sub-tiles updated {r_[3]:.1f}, stored and drained {r_[4]:.1f} | lower half: rows solved {r_[5]:.1f}, upper W published seen {r_[6]:.1f}, tile updated {r_[7]:.1f}")
+if marks is not None and ((typ == 3) & ((nq & 4) == 0)).any():
+    m = (typ == 3) & ((nq & 4) == 0)
     mk = (marks[m] - t0) / 100.0
     print(f"  TU phases (us, mean): ready -> D arrived {np.mean(mk[:, 0] - ready[m]):.1f}, rows solved +{np.mean(mk[:, 1] - mk[:, 0]):.1f}, W in LDS +{np.mean(mk[:, 2] - mk[:, 1]):.1f}, tile updated, stored and published +{np.mean(mk[:, 3] - mk[:, 2]):.1f}, W and L stored + drained +{np.mean(end[m] - mk[:, 3]):.1f}")
+if marks is not None and (typ == 4).any():
+    m = typ == 4
+    mk = (marks[m] - t0) / 100.0
+    print(f"  TA phases (us, mean): ready -> D arrived {np.mean(mk[:, 0] - ready[m]):.1f}, rows solved +{np.mean(mk[:, 1] - mk[:, 0]):.1f}, W in LDS +{np.mean(mk[:, 2] - mk[:, 1]):.1f}, W and L out + published, sub-tiles updated +{np.mean(mk[:, 3] - mk[:, 2]):.1f}, stored + drained +{np.mean(end[m] - mk[:, 3]):.1f}")
 if marks is not None and (typ == 2).any():
     for kq in sorted(set(nq[typ == 2])):
         m = (typ == 2) & (nq == kq) & (marks[:, 2] > 0)

@@ -11,16 +11,16 @@ import pytest
 
 from onephase_jl_amd import _lib
 
-D, T, U, TU = 0, 1, 2, 3
+D, T, U, TU, TA = 0, 1, 2, 3, 4
 
 
-def build_queue(fronts, workers=256, group=2, rows=1, fuse_d=False):
+def build_queue(fronts, workers=256, group=2, rows=1, fuse_d=False, split=False):
     lib = _lib.load()
     n = len(fronts)
     f = (C.c_int32 * n)(*[a for a, _ in fronts])
     k = (C.c_int32 * n)(*[b for _, b in fronts])
     model = C.c_double(0)
-    group = group | (rows << 8) | ((1 if fuse_d else 0) << 16)
+    group = group | (rows << 8) | ((1 if fuse_d else 0) << 16) | ((1 if split else 0) << 17)
     cnt = lib.okkt_debug_dataflow_queue(n, f, k, workers, group, None, 0, C.byref(model))
     assert cnt >= 0
     buf = (C.c_int32 * (4 * max(cnt, 1)))()
@@ -51,8 +51,9 @@ def dense_partial_ldlt(A, k):
     return A
 
 
-def replay(fronts, tasks, group, fused=False):
+def replay(fronts, tasks, group, fused=False, split=False):
     rng = np.random.default_rng(7)
+    halves = set()
     mats, refs, states, Ws, grids = [], [], [], [], []
     for f, k in fronts:
         B = rng.normal(size=(f, f))
@@ -82,22 +83,48 @@ def replay(fronts, tasks, group, fused=False):
                   blk[c + 1:, c + 1:] -= np.outer(l, blk[c + 1:, c])
                   blk[c + 1:, c] = l
               st[i, i] = i + 1
-          elif typ in (T, TU):
+          elif typ == TA:
+              # the upper 64 rows of block row q + 1: solved, their part of the diagonal tile updated (sub-tiles that need no other row)
               q = j
-              assert i > q and q < KB and st[q, q] >= q + 1 and st[i, q] == q, ("T out of order", a, i, q)
-              if typ == TU:
-                  assert i == q + 1 and i < KB and st[i, i] == q, ("TU out of order", a, i, q, st[i, i])
+              assert i == q + 1 and i < KB and st[q, q] >= q + 1 and st[i, q] == q and st[i, i] == q, ("TA out of order", a, i, q)
+              assert b[i + 1] - b[i] > 64 and (a, q) not in halves
+              ra = slice(b[i], b[i] + 64)
               cq = slice(b[q], b[q + 1])
               Lqq = np.tril(A[cq, cq], -1) + np.eye(b[q + 1] - b[q])
               d = np.diag(A[cq, cq])
-              Wt = np.linalg.solve(Lqq, A[ri, cq].T).T
-              W[ri, cq] = Wt
-              A[ri, cq] = Wt / d
+              Wt = np.linalg.solve(Lqq, A[ra, cq].T).T
+              W[ra, cq] = Wt
+              A[ra, cq] = Wt / d
+              A[ra, ra] -= np.tril(W[ra, cq] @ A[ra, cq].T)
+              halves.add((a, q))
+          elif typ in (T, TU):
+              q = j
+              assert i > q and q < KB and st[q, q] >= q + 1 and st[i, q] == q, ("T out of order", a, i, q)
+              rows_t = ri
+              if typ == TU:
+                  assert i == q + 1 and i < KB and st[i, i] == q, ("TU out of order", a, i, q, st[i, i])
+                  assert bool(nq & 4) == (split and b[i + 1] - b[i] > 64), ("TU split flag", a, i, q, nq)
+                  if nq & 4:     # the lower half of a split block row: the upper one must have been popped before
+                      assert (a, q) in halves, ("TU before its TA", a, q)
+                      rows_t = slice(b[i] + 64, b[i + 1])
+              else:
+                  assert nq == 1
+              cq = slice(b[q], b[q + 1])
+              Lqq = np.tril(A[cq, cq], -1) + np.eye(b[q + 1] - b[q])
+              d = np.diag(A[cq, cq])
+              Wt = np.linalg.solve(Lqq, A[rows_t, cq].T).T
+              W[rows_t, cq] = Wt
+              A[rows_t, cq] = Wt / d
               st[i, q] = q + 1
               if typ == TU:      # ... and the diagonal tile of block row i receives panel q
-                  A[ri, ri] -= np.tril(W[ri, cq] @ A[ri, cq].T)
+                  if nq & 4:
+                      ra = slice(b[i], b[i] + 64)
+                      A[rows_t, ra] -= W[rows_t, cq] @ A[ra, cq].T
+                      A[rows_t, rows_t] -= np.tril(W[rows_t, cq] @ A[rows_t, cq].T)
+                  else:
+                      A[ri, ri] -= np.tril(W[ri, cq] @ A[ri, cq].T)
                   st[i, i] = q + 1
-                  if nq == 2:    # ... and is factored by the same task (D(q + 1) is not a task of its own)
+                  if nq & 2:     # ... and is factored by the same task (D(q + 1) is not a task of its own)
                       blk = A[ri, ri]
                       for c in range(blk.shape[0]):
                           dd = blk[c, c]
@@ -140,11 +167,11 @@ CASES = [
 
 
 @pytest.mark.parametrize("fronts", CASES)
-@pytest.mark.parametrize("group,rows,fused", [(1, 1, False), (2, 1, True), (3, 2, False), (2, 4, True), (4, 1, True)])
-def test_queue_replays_to_the_partial_factorisation(fronts, group, rows, fused):
-    tasks, model = build_queue(fronts, workers=16, group=group, rows=rows, fuse_d=fused)
+@pytest.mark.parametrize("group,rows,fused,split", [(1, 1, False, False), (2, 1, True, False), (3, 2, False, True), (2, 4, True, False), (4, 1, True, True)])
+def test_queue_replays_to_the_partial_factorisation(fronts, group, rows, fused, split):
+    tasks, model = build_queue(fronts, workers=16, group=group, rows=rows, fuse_d=fused, split=split)
     assert model > 0
-    replay(fronts, tasks, group, fused)
+    replay(fronts, tasks, group, fused, split)
 
 
 def test_queue_is_the_same_every_time_and_scales():
@@ -159,6 +186,13 @@ def test_queue_is_the_same_every_time_and_scales():
     nT = sum(1 for t in a if t[0] == 0 and t[1] in (T, TU))
     nTU = sum(1 for t in a if t[0] == 0 and t[1] == TU)
     assert nD == KB and nTU == KB - 1 and nT == sum(TB - 1 - q for q in range(KB))
+    assert not any(t[1] == TA for t in a)
+    c, _ = build_queue([(2000, 900), (600, 200)], workers=256, group=2, split=True)
+    # 900 = 7 * 128 + 4: the last pivot block row has 4 rows and stays whole, the six before it are split; 200 = 128 + 72: split
+    assert sum(1 for t in c if t[0] == 0 and t[1] == TA) == 6 and sum(1 for t in c if t[0] == 1 and t[1] == TA) == 1
+    for p, t in enumerate(c):
+        if t[1] == TA:
+            assert c[p + 1][1] == TU and c[p + 1][0] == t[0] and c[p + 1][3:5] == t[3:5] and c[p + 1][2] & 4
     # the last panel of a pivot column comes alone (K = 128): it is what the next diagonal block / panel tile waits for
     for (fr, typ, nq, i, j, q0, R) in a:
         if fr == 0 and typ == U and j < KB and q0 + nq >= j - 1:
