@@ -63,6 +63,8 @@ struct DevPlan {
   double* ythin = nullptr;       // [kMaxRhs][128] per thin front: y = X w_K between the two forward launches of a level
   int64_t* ythin_pos = nullptr;
   int* ssched = nullptr;         // big fronts per level, thin (k <= NB) then wide
+  unsigned long long* sver = nullptr;   // flow sweeps of the wide fronts: per 32-row (forward) / 64-column (backward) tile, (epoch << 12) + blocks applied
+  int64_t* sver_pos = nullptr;          // [nsuper] first tile word of a wide front, -1 otherwise
   int64_t xw_stride = 0, cv_stride = 0;   // distance between the right-hand sides of a batch in xwork / cv
   double* invl = nullptr;          // inverse of the unit-lower diagonal blocks, NB x NB each
   int64_t* invl_pos = nullptr;     // [nsuper]
@@ -127,6 +129,7 @@ struct LaneStreams { hipStream_t main = nullptr, masked = nullptr, panel = nullp
 struct Numeric {
   DevPlan d;
   int solve_fuse = 1;                    // thin fronts: the two dependent launches of a level and sweep fused into one (in-launch hand-offs); OKKT_SOLVE_FUSE=0 switches back
+  int solve_flow = 0;                    // experiment (OKKT_SOLVE_FLOW=1): the forward sweep over the wide fronts of a level as ONE launch, block products and panel GEMVs handing their vectors on through tile states.  Correct, slower: 650 us instead of 534 per S-metric solve
   int solve_fuse_wide_max = 0;           // wide fronts: fused while the partial block products of a launch are at most this many workgroups (OKKT_SOLVE_FUSE_WIDE_MAX; 0 = never: measured neutral to slower, the consumers cannot start their panel loads before the hand-off)
   int* solve_flags = nullptr;            // [nsuper] monotonic y flags of the fused forward launches
   int* solve_counters = nullptr;         // [nsuper] arrival counters of the fused backward launches

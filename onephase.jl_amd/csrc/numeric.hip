@@ -1669,6 +1669,8 @@ static std::string factor_sched(Numeric& N, DevPlan P, const std::vector<LevelSc
       const size_t lds_inv = ((size_t)(NB + 2) * NB + 3 * kTld * kIB) * sizeof(double);
       auto inv_range = [&](int steps_final, bool last) -> std::string {
         std::string e2;
+        static const int skip_inv = getenv("OKKT_DEBUG_SKIP_INV") ? atoi(getenv("OKKT_DEBUG_SKIP_INV")) : 0;   // experiment: no block inverses (the solves are then wrong): what do they cost the factorisation?
+        if (skip_inv) return "";
         if (!last) {
           const int blocks_upto = (int)((int64_t)steps_final * NB / kSolveBlock);
           if (blocks_upto <= inv_blocks_done) return "";

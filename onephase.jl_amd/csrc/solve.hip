@@ -272,6 +272,35 @@ __device__ __forceinline__ void front_wait(const int* flag, int value, unsigned 
   __syncthreads();
 }
 
+// Flow sweeps of the wide fronts (k_fwd_wide_flow / k_bwd_wide_flow): wave 0 waits until the tile words ver[t0 .. t0 + nt) have
+// reached `want` (nt <= 62) and, with a counter, until the arrival counter has reached `cwant` -- one condition per lane, one
+// ballot per poll; bounded like the other waits.  The payload travels with agent-scope accesses only (no fences, see above).
+__device__ __forceinline__ void flow_wait(const unsigned long long* ver, int t0, int nt, unsigned long long want, const unsigned long long* counter, unsigned long long cwant,
+                                          unsigned long long* tmo) {
+  if (threadIdx.x < 64) {
+    const int ln = threadIdx.x;
+    const unsigned long long* addr = ln < nt ? ver + t0 + ln : ((ln == 63 && counter) ? counter : nullptr);
+    const unsigned long long need = ln < nt ? want : cwant;
+    int spins = 0;
+    for (;;) {
+      const bool ok = addr == nullptr || __hip_atomic_load(addr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need;
+      if (__builtin_amdgcn_ballot_w64(ok) == ~0ull) break;
+      if (++spins >= (1 << 22)) {
+        if (ln == 0 && tmo) atomicExch(tmo, 1ull);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(2);
+    }
+  }
+  __syncthreads();
+}
+// ... and publishes tile words once every wave's agent-scope stores have been acknowledged
+__device__ __forceinline__ void flow_publish(unsigned long long* ver, int t0, int nt, unsigned long long value) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if ((int)threadIdx.x < nt) __hip_atomic_store(ver + t0 + threadIdx.x, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // small fronts (one workgroup per task of fronts, the front's vector in LDS), R right-hand sides
 // ------------------------------------------------------------------------------------------------------------------
@@ -539,8 +568,10 @@ __global__ __launch_bounds__(256) void k_fwd_thin_fused(DevPlan P, const int* __
 // [cq * kSB / kCS, +kSB / kCS); X_b is lower triangular, so a workgroup stops at its last row.  The kCS partial vectors are
 // summed by the consumer (k_fwd_upd).  In block 0 the right-hand side is assembled on the fly (children's contributions).
 // returns false when the workgroup has no row of the block (it then takes no part in the hand-off of the fused launch)
+// ver != NULL (flow launch): the right-hand side rows of block b > 0 were written by workgroups of the same launch -- their 32-row
+// tiles are awaited (vwant = blocks applied to them) and read with agent-scope loads
 template <int R, bool AG>
-__device__ __forceinline__ bool fwd_y_body(const DevPlan& P, int s, int b, int bx, int cq) {
+__device__ __forceinline__ bool fwd_y_body(const DevPlan& P, int s, int b, int bx, int cq, const unsigned long long* ver = nullptr, unsigned long long vwant = 0) {
   constexpr int CW = kSB / kCS;
   __shared__ double wj[R][CW], part[4][R][64];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -552,7 +583,7 @@ __device__ __forceinline__ bool fwd_y_body(const DevPlan& P, int s, int b, int b
   const int i0 = bx * 64;
   if (i0 >= kb) return false;
   const int i = i0 + lane;
-  double* yp = P.ypart + P.ypart_pos[s] + (size_t)cq * kSB;          // [R][kCS][kSB]
+  double* yp = P.ypart + P.ypart_pos[s] + (ver ? (size_t)b * kMaxRhs * kCS * kSB : 0) + (size_t)cq * kSB;          // [R][kCS][kSB]; a flow launch: one such buffer per block (block b + 1's products run beside block b's far rows)
   const int pend = min(kb, i0 + 64);              // no row of this workgroup reaches beyond its last row
   const int q0 = cq * CW;
   if (q0 >= pend) {
@@ -565,6 +596,7 @@ __device__ __forceinline__ bool fwd_y_body(const DevPlan& P, int s, int b, int b
   const double* X = P.xinv + P.xinv_pos[s] + off + (size_t)q0 * ld;
   const int ic = min(i, kb - 1);
   const int64_t gcb = P.bigcol_base[s];
+  if (ver && b > 0) flow_wait(ver, (c0 + q0) >> 5, ((c0 + q0 + kq - 1) >> 5) - ((c0 + q0) >> 5) + 1, vwant, nullptr, 0ull, P.counters + 5);
   for (int c = tid; c < CW; c += 256) {
     double w[R];
 #pragma unroll
@@ -573,7 +605,7 @@ __device__ __forceinline__ bool fwd_y_body(const DevPlan& P, int s, int b, int b
       if (b == 0) fwd_gather<R>(P, gcb, col0, k, q0 + c, w);
       else {
 #pragma unroll
-        for (int r = 0; r < R; ++r) w[r] = P.xwork[(size_t)r * P.xw_stride + col0 + c0 + q0 + c];
+        for (int r = 0; r < R; ++r) w[r] = ver ? ld_agent(&P.xwork[(size_t)r * P.xw_stride + col0 + c0 + q0 + c]) : P.xwork[(size_t)r * P.xw_stride + col0 + c0 + q0 + c];
       }
     }
 #pragma unroll
@@ -618,8 +650,13 @@ constexpr int kUpdRows = 64;
 // counter != NULL: a workgroup of the fused launch -- it waits for the partial products of its front before it sums them
 // ROWS = rows per workgroup: 64 (two per lane, eight groups of 32 lanes share the columns) or 32 (sixteen groups of 16 lanes) for
 // launches that would otherwise leave most CUs idle (the later blocks of a front: rows / 64 workgroups)
+// ver != NULL: a workgroup of the flow launch (all blocks of a level's wide fronts in one launch): its rows start at the absolute row
+// rb_abs (a multiple of 32), `first` marks the workgroup that stores z, the arrival counter is the block's own (yexp arrivals), the
+// 32-row tiles it owns are awaited (vbase + b: the updates of the blocks before b) before the running vector is read, everything
+// another workgroup of the launch reads or wrote travels with agent-scope accesses, and the tiles are published (vbase + b + 1)
 template <int R, int ROWS = kUpdRows>
-__device__ __forceinline__ void fwd_upd_body(const DevPlan& P, int s, int b, int bx, double* sm, const unsigned long long* counter, unsigned long long epoch) {
+__device__ __forceinline__ void fwd_upd_body(const DevPlan& P, int s, int b, int bx, double* sm, const unsigned long long* counter, unsigned long long epoch,
+                                             unsigned long long* ver = nullptr, unsigned long long vbase = 0, int rb_abs = -1, int first = -1, long long yexp = -1) {
   constexpr int GW = ROWS / 2, NG = 256 / GW;      // lanes per group, groups
   double* yj = sm;                                 // y[R][kSB], then part[NG][R][ROWS]
   double* part = sm + (size_t)R * kSB;
@@ -631,17 +668,20 @@ __device__ __forceinline__ void fwd_upd_body(const DevPlan& P, int s, int b, int
   xblock(k, b, c0, kb, ld, off);
   if (kb <= 0) return;
   const int rbeg = c0 + kb;                       // first row below the block
-  const int rb = rbeg + bx * ROWS;
-  if (bx > 0 && rb >= f) return;
-  if (counter) front_wait64(counter, epoch, ((kb + 63) / 64) * kCS, P.counters + 5);
-  const double* yp = P.ypart + P.ypart_pos[s];
+  const int rb = rb_abs >= 0 ? rb_abs : rbeg + bx * ROWS;
+  const bool is_first = first >= 0 ? first != 0 : bx == 0;
+  if (!is_first && rb >= f) return;
+  const int vt0 = rb >> 5, vnt = rb < f ? min(ROWS / 32, (f - rb + 31) >> 5) : 0;
+  if (ver) flow_wait(ver, vt0, b > 0 ? vnt : 0, vbase + (unsigned long long)b, counter, (epoch << 20) + (unsigned long long)yexp, P.counters + 5);
+  else if (counter) front_wait64(counter, epoch, ((kb + 63) / 64) * kCS, P.counters + 5);
+  const double* yp = P.ypart + P.ypart_pos[s] + (ver ? (size_t)b * kMaxRhs * kCS * kSB : 0);
   for (int p = tid; p < kSB; p += 256) {
     const int pc = min(p, kb - 1);
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const double y = counter ? sum_splits_agent(yp + (size_t)r * kCS * kSB + pc) : sum_splits(yp + (size_t)r * kCS * kSB + pc);
       yj[r * kSB + p] = p < kb ? y : 0.0;
-      if (bx == 0 && p < kb) P.zwork[(size_t)r * P.xw_stride + col0 + c0 + p] = y / P.dvals[col0 + c0 + p];
+      if (is_first && p < kb) P.zwork[(size_t)r * P.xw_stride + col0 + c0 + p] = y / P.dvals[col0 + c0 + p];
     }
   }
   __syncthreads();
@@ -691,17 +731,18 @@ __device__ __forceinline__ void fwd_upd_body(const DevPlan& P, int s, int b, int
       if (b == 0) fwd_gather<R>(P, gcb, col0, k, rowv, w);
       else {
 #pragma unroll
-        for (int r = 0; r < R; ++r) w[r] = *fwd_slot<R>(P, s, col0, k, rowv, r);
+        for (int r = 0; r < R; ++r) w[r] = ver ? ld_agent(fwd_slot<R>(P, s, col0, k, rowv, r)) : *fwd_slot<R>(P, s, col0, k, rowv, r);
       }
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         double sum = 0.0;
 #pragma unroll
         for (int h = 0; h < NG; ++h) sum += part[((size_t)h * R + r) * ROWS + tid];
-        *fwd_slot<R>(P, s, col0, k, rowv, r) = w[r] - sum;
+        if (ver) st_agent(fwd_slot<R>(P, s, col0, k, rowv, r), w[r] - sum); else *fwd_slot<R>(P, s, col0, k, rowv, r) = w[r] - sum;
       }
     }
   }
+  if (ver) flow_publish(ver, vt0, vnt, vbase + (unsigned long long)b + 1ull);
 }
 
 template <int R, int ROWS = kUpdRows>
@@ -721,6 +762,55 @@ __global__ __launch_bounds__(256) void k_fwd_wide_fused(DevPlan P, const int* __
   } else {
     fwd_upd_body<R>(P, s, b, x - ny * kCS, sm, counters + s, epoch);
   }
+}
+
+// Flow launch, forward: EVERY block of the wide fronts of a level in one launch.  blockIdx.x = front, blockIdx.y = task; the tasks
+// are laid out block by block -- the partial block products of block b (row tile x column split), then the panel rows below it:
+// 32 workgroups of 32 rows (the rows the NEXT block product waits for: short tasks), then workgroups of 64 rows -- so that every
+// task depends on tasks with SMALLER indices only (workgroups are dispatched in index order: whatever a waiting workgroup waits
+// for is resident or done).  The block product of block b + 1 starts when the 32-row tiles of its rows carry b + 1 updates, while
+// the far rows of block b (and b - 1, ...) are still streaming their panels: the chain of a front is block product -> near rows,
+// the bulk of L streams beside it.
+// MEASURED SLOWER than the two launches per block (k_fwd_y, k_fwd_upd) it was meant to replace -- 65 us per level instead of 53 at
+// S-metric (650 / 534 us per solve) -- and therefore off (OKKT_SOLVE_FLOW=1 enables it; tests keep it correct): a dependent kernel
+// boundary costs 1.5 - 2 us on this GPU, a hand-off through a flag with an agent-scope payload (drain, atomics, poll, payload
+// loads that bypass the L1) 3 - 4 us, and the chain of a block -- product, then the 32-row panel tasks, each a 256 KB stream in four
+// dependent rounds -- is the same length in both forms; what the flow launch adds is spinning workgroups beside the working ones.
+constexpr int kFlowBlocks = 96;        // blocks of a wide front per flow launch (fronts with more pivot columns take the two-launch path)
+constexpr int kFlowNear = 32;          // 32-row workgroups behind a block
+struct SweepFlow {
+  int nblk;
+  int base[kFlowBlocks + 1];           // first task of block b
+  short nprod[kFlowBlocks];            // block-product tasks of block b (tiles x kCS)
+};
+template <int R>
+__global__ __launch_bounds__(256) void k_fwd_wide_flow(DevPlan P, const int* __restrict__ list, SweepFlow T, unsigned long long* __restrict__ counters, unsigned long long epoch) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int s = list[blockIdx.x];
+  const int t = (int)blockIdx.y;
+  int b = 0;
+  while (b + 1 < T.nblk && t >= T.base[b + 1]) ++b;
+  const int idx = t - T.base[b];
+  const int k = P.sn_col0[s + 1] - P.sn_col0[s];
+  int c0, kb, ld; int64_t off;
+  xblock(k, b, c0, kb, ld, off);
+  if (kb <= 0) return;
+  unsigned long long* ver = P.sver + P.sver_pos[s];
+  const unsigned long long vbase = epoch << 12;
+  const int nprod = T.nprod[b];
+  // the block's own arrival counter (behind the tile words): products of later blocks that are all zero arrive at once
+  const int f = (int)(P.row_ptr[s + 1] - P.row_ptr[s]);
+  unsigned long long* ycnt = ver + ((f + 31) >> 5) + 2 + b;
+  if (idx < nprod) {
+    const int ny = nprod / kCS;
+    if (fwd_y_body<R, true>(P, s, b, idx % ny, idx / ny, ver, vbase + (unsigned long long)b)) front_arrive64(ycnt, epoch);
+    return;
+  }
+  const int j = idx - nprod;
+  const int t0 = (c0 + kb) >> 5;                                         // the 32-row tile that holds the first row below the block
+  const long long yexp = (long long)((kb + 63) / 64) * kCS;
+  if (j < kFlowNear) fwd_upd_body<R, 32>(P, s, b, j, sm, ycnt, epoch, ver, vbase, 32 * (t0 + j), j == 0, yexp);
+  else fwd_upd_body<R, 64>(P, s, b, j, sm, ycnt, epoch, ver, vbase, 32 * (t0 + kFlowNear) + 64 * (j - kFlowNear), 0, yexp);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1038,8 +1128,8 @@ std::string solve_setup(const Symbolic& S, Numeric& N) {
   DevPlan& d = N.d;
   const int ns = S.nsuper;
   std::vector<int> ssched;
-  std::vector<int64_t> xinv_pos(ns, -1), ypart_pos(ns, -1), ythin_pos(ns, -1);
-  int64_t xtot = 0, ytot = 0, ttot = 0;
+  std::vector<int64_t> xinv_pos(ns, -1), ypart_pos(ns, -1), ythin_pos(ns, -1), sver_pos(ns, -1);
+  int64_t xtot = 0, ytot = 0, ttot = 0, vtot = 0;
   auto build = [&](const std::vector<LevelSchedule>& levels, std::vector<SolveLevel>& out) {
     out.assign(levels.size(), SolveLevel());
     for (size_t l = 0; l < levels.size(); ++l) {
@@ -1062,7 +1152,9 @@ std::string solve_setup(const Symbolic& S, Numeric& N) {
           xinv_pos[s] = xtot;
           xtot += nfull * (int64_t)kSB * kSB + lastp * lastp;
           ypart_pos[s] = ytot;
-          ytot += (int64_t)kMaxRhs * kCS * kSB;
+          ytot += (int64_t)kMaxRhs * kCS * kSB * ((k + kSB - 1) / kSB);      // one buffer of partial products per block (flow launches)
+          sver_pos[s] = vtot;
+          vtot += (N.sn_f[s] + 31) / 32 + 2 + (k + kSB - 1) / kSB;      // tile words, then one arrival counter per block
         }
       }
     }
@@ -1078,6 +1170,12 @@ std::string solve_setup(const Symbolic& S, Numeric& N) {
   if (!(e = dz(N, (size_t)xtot, &d.xinv)).empty()) return e;
   if (!(e = dz(N, (size_t)xtot, &d.xtmp)).empty()) return e;
   if (!(e = dz(N, (size_t)ytot, &d.ypart)).empty()) return e;
+  if (!(e = up(N, sver_pos, &d.sver_pos)).empty()) return e;
+  {
+    double* rawv = nullptr;
+    if (!(e = dz(N, (size_t)vtot + 1, &rawv)).empty()) return e;      // zero-filled once: the words carry the epoch of the launch that wrote them
+    d.sver = (unsigned long long*)rawv;
+  }
   {
     // hand-off words of the fused sweeps: a monotonic y flag and an arrival counter per supernode (zero-filled once)
     double* raw = nullptr;
@@ -1163,7 +1261,25 @@ static std::string fwd_enqueue_r(Numeric& N, const std::vector<LevelSchedule>& l
       const int* list = P.ssched + S.wide_off;
       const int nblk = (S.wide_maxk + kSB - 1) / kSB;
       const size_t lds = ((size_t)R * kSB + (size_t)8 * R * kUpdRows) * sizeof(double);
-      for (int b = 0; b < nblk; ++b) {
+      bool flow_done = false;
+      if (N.solve_flow && N.solve_counters64 && P.sver && nblk <= kFlowBlocks) {
+        SweepFlow T;
+        T.nblk = nblk;
+        int64_t tot = 0;
+        for (int b = 0; b < nblk; ++b) {
+          const int kbmax = std::min(kSB, S.wide_maxk - b * kSB);
+          const int rem = std::max(S.wide_maxf - b * kSB, 0);      // upper bound on the rows below the START of block b
+          T.base[b] = (int)tot;
+          T.nprod[b] = (short)(((kbmax + 63) / 64) * kCS);
+          tot += T.nprod[b] + kFlowNear + std::max(0, (rem + 32 - 32 * kFlowNear + 63) / 64);
+        }
+        T.base[nblk] = (int)tot;
+        if (tot <= 65535) {
+          hipLaunchKernelGGL(k_fwd_wide_flow<R>, dim3(S.wide_cnt, (unsigned)tot), dim3(256), lds, st, P, list, T, N.solve_counters64, ++N.solve_epoch64);
+          flow_done = true;
+        }
+      }
+      for (int b = 0; b < nblk && !flow_done; ++b) {
         const int kbmax = std::min(kSB, S.wide_maxk - b * kSB);
         const int rem = std::max(S.wide_maxf - b * kSB, 0);        // upper bound on the rows below the start of block b (a narrower last block leaves more rows than maxf - (b + 1) kSB)
         const int ny = (kbmax + 63) / 64, nupd = std::max(1, (rem + kUpdRows - 1) / kUpdRows);
