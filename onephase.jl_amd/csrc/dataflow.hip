@@ -634,7 +634,7 @@ __device__ __forceinline__ void df_syrk_tiles(const DevPlan& P, int s, int j0, i
 }
 
 constexpr int kDfThreads = kDfThreadsC;
-constexpr size_t kDfLds = std::max(std::max(((size_t)5 * kMW * kPLD + (size_t)2 * 4 * 32 * kXld) * sizeof(double), kDfTuLds), (size_t)kDfStages * 2 * kDfKC * kSyrkLd * sizeof(double));   // diag2_body's and df_tu_tile's; the other roles need less
+constexpr size_t kDfLds = std::max(std::max(OKKT_DIAG2_LDS_DOUBLES(kMW) * sizeof(double), kDfTuLds), (size_t)kDfStages * 2 * kDfKC * kSyrkLd * sizeof(double));   // diag2_body's and df_tu_tile's; the other roles need less
 
 // counters[5] = a wait ran into its bound (or another worker's did): every worker leaves, the factorisation reports a wrong
 // inertia ("pivot counts do not add up") and the solves return NaN -- never numbers computed from tiles that had not arrived
@@ -721,7 +721,7 @@ __global__ __launch_bounds__(kDfThreads, 1) void k_front_dataflow(DevPlan P, con
     int* mine;
     int newv, npub = 1;
     if (type == kDfD) {
-      if (!(dbg & 1)) diag2_body<true>(P, s, i, 128, tol, sm);
+      if (!(dbg & 1)) diag2_body<true, kDiag2MW, 6>(P, s, i, 128, tol, sm, nullptr, 0, tlog ? tlog + (size_t)t * 8 + 4 : nullptr);
       mine = st + (size_t)i * TB + i; newv = i + 1;
     } else if (type == kDfT) {
       if (!(dbg & 2)) df_trsm_tile(P, s, j, df_block_lo(i, KB, k, f), df_block_lo(i + 1, KB, k, f), sm);
@@ -737,7 +737,7 @@ __global__ __launch_bounds__(kDfThreads, 1) void k_front_dataflow(DevPlan P, con
       if (type == kDfTA) {
         mine = hs; newv = 2;
       } else if (with_d) {
-        diag2_body<true>(P, s, i, 128, tol, sm, sm, kDfTileLd);
+        diag2_body<true, kDiag2MW, 6>(P, s, i, 128, tol, sm, sm, kDfTileLd);
         mine = st + (size_t)i * TB + i; newv = i + 1;          // tile (q + 1, q) was published inside the task
       } else {
         mine = st + (size_t)i * TB + j; newv = j + 1;

@@ -40,6 +40,15 @@ __device__ __forceinline__ void flush_counts(const DevPlan& P, int slot, unsigne
   unsigned long long* counters = P.counters + (size_t)slot * kCountStride;
   pos = wave_sum(pos); neg = wave_sum(neg); zer = wave_sum(zer); bad = wave_sum(bad);
   if ((threadIdx.x & 63) == 0) {
+    if (P.want_pos < 0 && P.want_neg < 0) {
+      // no limits to test: atomics without a return value (the returning form kept the wave waiting for the memory side's answer:
+      // 2 us at the end of every diagonal block)
+      if (pos) atomicAdd(&counters[0], (unsigned long long)pos);
+      if (neg) atomicAdd(&counters[1], (unsigned long long)neg);
+      if (zer) atomicAdd(&counters[2], (unsigned long long)zer);
+      if (bad) atomicAdd(&counters[3], (unsigned long long)bad);
+      return;
+    }
     bool fail = false;
     if (pos) { const unsigned long long o = atomicAdd(&counters[0], (unsigned long long)pos); fail |= P.want_pos >= 0 && o + pos > (unsigned long long)P.want_pos; }
     if (neg) { const unsigned long long o = atomicAdd(&counters[1], (unsigned long long)neg); fail |= P.want_neg >= 0 && o + neg > (unsigned long long)P.want_neg; }
@@ -99,14 +108,16 @@ constexpr int kXld = 33;
 __device__ __forceinline__ void st_agent_f64(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ double ld_agent_f64(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+// LDS of diag2_body in doubles: raw micro-panel, two buffers each of -L and W, the four 32 x 32 diagonal blocks of L, their inverses, the pivots
+#define OKKT_DIAG2_LDS_DOUBLES(MWc) ((size_t)5 * (MWc) * kPLD + (size_t)2 * 4 * 32 * kXld + 128)
 #ifndef OKKT_DIAG2_MW
 #define OKKT_DIAG2_MW 8
 #endif
 constexpr int kDiag2MW = OKKT_DIAG2_MW;     // columns per micro-step of diag2_body (8: round 3; 4 halves the redundant block factorisation of the row threads for twice the barriers)
 // tile_lds != nullptr (dataflow.hip, TU + D in one task): the block comes from LDS (column-major, leading dimension tile_ld, written
 // by the same workgroup) instead of the front in HBM; it overlaps this function's own LDS areas, hence the barrier behind the loads
-template <bool AG, int MW = kDiag2MW>
-__device__ __forceinline__ void diag2_body(const DevPlan& P, int s, int step, int NB, double tol, double* sm, const double* tile_lds = nullptr, int tile_ld = 0) {
+template <bool AG, int MW = kDiag2MW, int NMM = 4>
+__device__ __forceinline__ void diag2_body(const DevPlan& P, int s, int step, int NB, double tol, double* sm, const double* tile_lds = nullptr, int tile_ld = 0, long long* marks = nullptr) {
   static_assert(MW == 8 || MW == 4, "micro-panels of 4 or 8 columns");
   constexpr int NE = MW / 4;                   // MFMA k-steps (4 columns each) per micro-panel
   constexpr int PER = 16 / MW;                 // micro-panels per 16-column tile
@@ -126,24 +137,32 @@ __device__ __forceinline__ void diag2_body(const DevPlan& P, int s, int step, in
   double* WpB = LpB + 2 * MW * kPLD;          // W = L * D, two buffers
   double* Ld = WpB + 2 * MW * kPLD;           // 4 diagonal 32 x 32 blocks of L, leading dimension 33
   double* Xs = Ld + 4 * 32 * kXld;             // their inverses
+  double* dpiv = Xs + 4 * 32 * kXld;           // the 128 pivots, for the waves that count them behind the loop
   double* F = P.arena + P.front_pos[s];
-  const bool mm = wave >= 2 && wave < 6;       // MFMA wave (four of them: one per SIMD; the two row waves share two of the SIMDs); waves 6, 7 of a
-                                               // 512-thread workgroup (dataflow.hip) only meet the barriers
+  // MFMA waves: NMM of them from wave 2 on.  Four in a 384-thread workgroup (k_big_diag2: one per SIMD, the two row waves share two of the
+  // SIMDs); six in the 512-thread workers of the dataflow launch, whose waves 6 and 7 would otherwise only meet the barriers -- a wave
+  // gets a v_mfma_f64_16x16x4 through at the same rate whether it is alone on its SIMD or shares it with one more, so six waves finish
+  // the 36 tiles in two thirds of the time (the rest of the update, not the row phase, was what a micro-step waited for: 9 of 38 us).
+  // (Waves 2, 3, 6, 7 -- two SIMDs with two MFMA waves each, the row waves' SIMDs left alone -- was slower than waves 2 .. 5: 39.9 us.)
+  static_assert(NMM == 4 || NMM == 6, "36 tiles over four or six MFMA waves");
+  constexpr int NT = 36 / NMM;                 // tiles per MFMA wave
+  const bool mm = wave >= 2 && wave < 2 + NMM;
+  const int mmi = wave >= 2 ? wave - 2 : 0;    // 0 .. NMM - 1 among the MFMA waves
   // tiles of an MFMA wave: t = 4 q + (wave - 2), column-major over the lower triangle of the 8 x 8 tile grid
-  int ti_s[9], tj_s[9];
+  int ti_s[NT], tj_s[NT];
 #pragma unroll
-  for (int q = 0; q < 9; ++q) {
-    const int t = 4 * q + ((wave + 2) & 3);
+  for (int q = 0; q < NT; ++q) {
+    const int t = NMM * q + mmi;
     const int tj = (t >= 8) + (t >= 15) + (t >= 21) + (t >= 26) + (t >= 30) + (t >= 33) + (t >= 35);
     const int start = tj * 8 - tj * (tj - 1) / 2;
     tj_s[q] = tj;
     ti_s[q] = tj + (t - start);
   }
-  d4_t acc[9];
+  d4_t acc[NT];
   if (mm) {
-    double raw[9][4];
+    double raw[NT][4];
 #pragma unroll
-    for (int q = 0; q < 9; ++q) {
+    for (int q = 0; q < NT; ++q) {
       const int r = 16 * ti_s[q] + l15;
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
@@ -152,7 +171,7 @@ __device__ __forceinline__ void diag2_body(const DevPlan& P, int s, int step, in
       }
     }
 #pragma unroll
-    for (int q = 0; q < 9; ++q) {
+    for (int q = 0; q < NT; ++q) {
       const int r = 16 * ti_s[q] + l15;
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
@@ -165,6 +184,9 @@ __device__ __forceinline__ void diag2_body(const DevPlan& P, int s, int step, in
   if (tile_lds) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __syncthreads(); }      // every MFMA wave holds its tiles: the LDS below may be written
   double my_d = 1.0;
   const int nms = (nb + MW - 1) / MW;        // micro-steps
+  // marks (task log of the dataflow launch, wave 0 = a row wave): time spent waiting for the head (barrier 1), in the row phase,
+  // waiting for the rest of the update (barrier 2), and the start of the tail behind the loop
+  long long tk = marks ? wall_clock64() : 0, t_head = 0, t_row = 0, t_rest = 0;
   for (int ms = 0; ms < nms; ++ms) {
     const int p8 = ms * MW, pp = ms / PER, h = ms % PER;
     const double* Lprev = LpB + ((ms + 1) & 1) * MW * kPLD;    // panels of micro-step ms - 1
@@ -173,7 +195,7 @@ __device__ __forceinline__ void diag2_body(const DevPlan& P, int s, int step, in
       // head: update of step ms - 1 on the tile column of panel ms, then the copy-out of panel ms
       if (ms > 0) {
 #pragma unroll
-        for (int q = 0; q < 9; ++q)
+        for (int q = 0; q < NT; ++q)
           if (tj_s[q] == pp) {
             const int rr = 16 * ti_s[q] + l15, cc = 16 * tj_s[q] + l15;
             double av[NE], bv[NE];
@@ -184,7 +206,7 @@ __device__ __forceinline__ void diag2_body(const DevPlan& P, int s, int step, in
           }
       }
 #pragma unroll
-      for (int q = 0; q < 9; ++q)
+      for (int q = 0; q < NT; ++q)
         if (tj_s[q] == pp) {
           const int r = 16 * ti_s[q] + l15;
 #pragma unroll
@@ -200,6 +222,7 @@ __device__ __forceinline__ void diag2_body(const DevPlan& P, int s, int step, in
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    if (marks && tid == 0) { const long long tn = wall_clock64(); t_head += tn - tk; tk = tn; }
     if (!mm) {
       // row threads: 8 x 8 diagonal LDL^T redundantly in registers, own row solved, panels and final entries written
       double* Lp = LpB + (ms & 1) * MW * kPLD;
@@ -242,12 +265,13 @@ __device__ __forceinline__ void diag2_body(const DevPlan& P, int s, int step, in
         if (i < MW) {
 #pragma unroll
           for (int c = 0; c < MW; ++c) my_d = i == c ? w[c] : my_d;
+          dpiv[r] = my_d;
         }
       }
     } else if (ms > 0) {
       // rest of the update of step ms - 1: the tile columns to the right of panel ms's
 #pragma unroll
-      for (int q = 0; q < 9; ++q)
+      for (int q = 0; q < NT; ++q)
         if (tj_s[q] > pp) {
           const int rr = 16 * ti_s[q] + l15, cc = 16 * tj_s[q] + l15;
           double av[NE], bv[NE];
@@ -258,40 +282,92 @@ __device__ __forceinline__ void diag2_body(const DevPlan& P, int s, int step, in
         }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (marks && tid == 0) { const long long tn = wall_clock64(); t_row += tn - tk; tk = tn; }
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    if (marks && tid == 0) { const long long tn = wall_clock64(); t_rest += tn - tk; tk = tn; }
   }
-  {
+  if (marks && tid == 0) { marks[0] = t_head; marks[1] = t_row; marks[2] = t_rest; marks[3] = wall_clock64(); }
+  (void)my_d;
+  if (wave == 4 || wave == 5) {
+    // the pivots are stored and counted by two waves that have nothing else to do here (MFMA waves), from the copies the row threads
+    // left in LDS: the row waves go straight on to the inverses below (1.2 us of the 38 of a diagonal block)
     unsigned pos = 0, neg = 0, zer = 0, bad = 0;
-    if (tid < nb) {
-      if (AG) st_agent_f64(&P.dvals[col0 + j0 + tid], my_d); else P.dvals[col0 + j0 + tid] = my_d;
-      classify_pivot(my_d, tol, pos, neg, zer, bad);
+    const int t = tid - 256;
+    if (t < nb) {
+      const double d = dpiv[t];
+      if (AG) st_agent_f64(&P.dvals[col0 + j0 + t], d); else P.dvals[col0 + j0 + t] = d;
+      classify_pivot(d, tol, pos, neg, zer, bad);
     }
     flush_counts(P, 0, pos, neg, zer, bad);
   }
+#ifdef OKKT_D_TAIL_MARKS
+  if (marks && tid == 0) marks[0] = wall_clock64();
+#endif
   // X_bb = inv(L_bb): wave b, one column per lane (Ld is complete behind the last barrier of the loop)
   const int off = wave * 32;
   if (wave < 4 && off < nb) {
     const int w = min(32, nb - off);
     const double* Lb = Ld + wave * 32 * kXld;
     double* Xb = Xs + wave * 32 * kXld;
-    if (lane < 32) {
-      const int c = lane;
-      double x[32];
+    {
+      // Column c = lane & 31 of the inverse by forward substitution, COLUMN-oriented: once x[p] is final it is applied to every row
+      // below it -- independent FMAs -- so the dependent chain is 32 long, not 496 (row-oriented dot products, the first form: 4.8 us
+      // of the 38 of a diagonal block, every FMA behind the one before it).  The two halves of the wave share a column: lane c keeps the
+      // even rows, lane c + 32 the odd ones (16 values each), x[p] crosses with v_permlane32_swap.  Every entry still receives its
+      // terms in ascending p: the same numbers bit for bit.  hipcc would wait for every pair of LDS values in front of the two FMAs that
+      // use them (8.8 us): column p + 1 of L is requested before the FMAs of column p.
+      const int c = lane & 31, hf = lane >> 5;
+      const double* Lh = Lb + hf;                     // row 2 j + hf of column p at Lh[2 j + p * kXld]
+      double v[16], la[16], lb[16];
 #pragma unroll
-      for (int r = 0; r < 32; ++r) {
-        double v = (r == c) ? 1.0 : 0.0;
-        if (r < w) {
+      for (int j = 0; j < 16; ++j) v[j] = (2 * j + hf == c) ? 1.0 : 0.0;
+      // x[p] from the half that owns row p to both halves
+      auto both = [&](double x, int owner) {
+        const unsigned lo = (unsigned)__double2loint(x), hi = (unsigned)__double2hiint(x);
+        const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+        const auto bq = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+        return owner == 0 ? __hiloint2double((int)bq[0], (int)a[0]) : __hiloint2double((int)bq[1], (int)a[1]);
+      };
+      // rows of column p below the diagonal: j >= (p + 1) / 2 (p even: j = p / 2 is row p itself in the even half: its multiplier is zero)
 #pragma unroll
-          for (int p = 0; p < r; ++p) v = __builtin_fma(-Lb[r + p * kXld], x[p], v);
+      for (int j = 0; j < 16; ++j) la[j] = Lh[2 * j];
+#pragma unroll
+      for (int p = 0; p < 32; p += 2) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int j = (p + 2) / 2; j < 16; ++j) lb[j] = Lh[2 * j + (p + 1) * kXld];
+        {
+          // p even: owned by the even half, v[p / 2]
+          const double mine = (p < w && c < w && p >= c) ? v[p / 2] : 0.0;
+          const double xp = both(mine, 0);
+          v[p / 2] = hf == 0 ? xp : __builtin_fma(-la[p / 2], xp, v[p / 2]);      // even half: x[p] itself; odd half: row p + 1
+#pragma unroll
+          for (int j = p / 2 + 1; j < 16; ++j) v[j] = __builtin_fma(-la[j], xp, v[j]);
         }
-        x[r] = (r < w && c < w && r >= c) ? v : 0.0;
-      }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (p + 2 < 32) {
 #pragma unroll
-      for (int r = 0; r < 32; ++r) Xb[r + c * kXld] = x[r];
+          for (int j = (p + 2) / 2; j < 16; ++j) la[j] = Lh[2 * j + (p + 2) * kXld];
+        }
+        {
+          // p + 1 odd: owned by the odd half, v[p / 2]; the rows below it: j >= p / 2 + 1 in both halves
+          const double mine = (p + 1 < w && c < w && p + 1 >= c) ? v[p / 2] : 0.0;
+          const double xp = both(mine, 1);
+          v[p / 2] = hf == 1 ? xp : v[p / 2];
+#pragma unroll
+          for (int j = p / 2 + 1; j < 16; ++j) v[j] = __builtin_fma(-lb[j], xp, v[j]);
+        }
+      }
+      // the masks of the entries that were never anybody's x[p] at the point of use are already in: v[j] IS the masked x[2 j + hf]
+#pragma unroll
+      for (int j = 0; j < 16; ++j) Xb[(2 * j + hf) + c * kXld] = v[j];
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
+#ifdef OKKT_D_TAIL_MARKS
+    if (marks && tid == 0) marks[1] = wall_clock64();
+#endif
     double* Xg = P.invl + P.invl_pos[s] + (size_t)step * NB * NB;
     const int r = lane & 31;
 #pragma unroll
@@ -299,6 +375,9 @@ __device__ __forceinline__ void diag2_body(const DevPlan& P, int s, int step, in
       const int c = (lane >> 5) + 2 * q;
       if (AG) st_agent_f64(&Xg[(off + r) + (size_t)(off + c) * NB], Xb[r + c * kXld]); else Xg[(off + r) + (size_t)(off + c) * NB] = Xb[r + c * kXld];
     }
+#ifdef OKKT_D_TAIL_MARKS
+    if (marks && tid == 0) { marks[2] = wall_clock64(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); marks[2] = wall_clock64() * 0 + marks[2]; }
+#endif
   }
 }
 

@@ -1468,7 +1468,7 @@ static std::string factor_sched(Numeric& N, DevPlan P, const std::vector<LevelSc
       const int* list = P.sched + g.off;
       const int nsteps = (g.maxk + NB - 1) / NB;
       const size_t lds_diag = ((size_t)3 * kMW * kPLD + (size_t)2 * 4 * 32 * kXld) * sizeof(double);
-      const size_t lds_diag2 = ((size_t)5 * kMW * kPLD + (size_t)2 * 4 * 32 * kXld) * sizeof(double);
+      const size_t lds_diag2 = OKKT_DIAG2_LDS_DOUBLES(kMW) * sizeof(double);
       const size_t lds_trsm_max = ((size_t)10 * kIB * kIB + 128) * sizeof(double);
       // every front of the segment must own a W buffer for this group size: decided on the smallest front
       const int GS = g.minf >= N.group_big_minf ? N.group_big : N.group;     // widest super-step of this segment (sizes wbuf)

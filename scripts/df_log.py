@@ -117,6 +117,12 @@ if marks is not None and ((typ == 3) & ((nq & 4) == 0)).any():
     m = (typ == 3) & ((nq & 4) == 0)
     mk = (marks[m] - t0) / 100.0
     print(f"  TU phases (us, mean): ready -> D arrived {np.mean(mk[:, 0] - ready[m]):.1f}, rows solved +{np.mean(mk[:, 1] - mk[:, 0]):.1f}, W in LDS +{np.mean(mk[:, 2] - mk[:, 1]):.1f}, tile updated, stored and published +{np.mean(mk[:, 3] - mk[:, 2]):.1f}, W and L stored + drained +{np.mean(end[m] - mk[:, 3]):.1f}")
+if marks is not None and (typ == 0).any():
+    m = (typ == 0) & (marks[:, 3] > 0)
+    if m.any():
+        mk = marks[m].astype(float) / 100.0
+        tail = end[m] - (marks[m][:, 3] - t0) / 100.0
+        print(f"  D phases (us, mean over {int(m.sum())} stand-alone diagonal blocks, seen by a row wave): before the loop {np.mean(end[m] - ready[m] - mk[:, 0] - mk[:, 1] - mk[:, 2] - tail):.1f}, waiting for the head of the update + panel copy {np.mean(mk[:, 0]):.1f}, row phase {np.mean(mk[:, 1]):.1f}, waiting for the rest of the update {np.mean(mk[:, 2]):.1f}, tail (pivot counts, 32 x 32 inverses, stores, drain) {np.mean(tail):.1f}")
 if marks is not None and (typ == 4).any():
     m = typ == 4
     mk = (marks[m] - t0) / 100.0
