@@ -280,6 +280,10 @@ __device__ __forceinline__ bool df_tu_tile(const DevPlan& P, int s, int q, int r
     if (tid < NB) rdv[tid] = 1.0 / P.dvals[col0 + j0 + tid];
   }
   __syncthreads();
+#ifdef OKKT_TU_STAGE_MARK
+  if (marks && tid == 0) marks[1] = wall_clock64();        // (variant build) the staged blocks are in LDS
+#define OKKT_TU_SKIP_MARK1 1
+#endif
   if (solver) {
 #pragma unroll
     for (int bi = 0; bi < NBLK; ++bi) {
@@ -305,7 +309,9 @@ __device__ __forceinline__ bool df_tu_tile(const DevPlan& P, int s, int q, int r
       for (int gp = 0; gp < 8; ++gp) t[bi * 8 + gp] = wt[gp];
     }
   }
+#ifndef OKKT_TU_SKIP_MARK1
   if (marks && tid == 0) marks[1] = wall_clock64();        // rows solved
+#endif
   const double myrd = tid < NB ? rdv[tid] : 0.0;
   __syncthreads();                       // every wave is done with the staged blocks and the reciprocals
   double* Wl = sm;                       // [128 panel columns][kSyrkLd]: W(r0 + r, j0 + p) at p * kSyrkLd + r
@@ -646,11 +652,14 @@ __global__ __launch_bounds__(kDfThreads, 1) void k_front_dataflow(DevPlan P, con
   // around it hipcc threads the branch through the loop header, the structurizer turns the worker's loop into two nested loops and
   // lanes 1 .. 63 of wave 0 run ahead into the next s_barrier while lane 0 is masked off -- the workgroup hangs (round 4, first run)
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int t_ahead = -1;      // wave 0: the queue position taken while the previous task's stores were draining
   for (;;) {
     if (wave == 0) {
-      int t = 0;
-      if ((tid & 63) == 0) t = atomicAdd(head, 1);
-      t = __builtin_amdgcn_readfirstlane(t);
+      int t = t_ahead;
+      if (t_ahead < 0) {
+        if ((tid & 63) == 0) t = atomicAdd(head, 1);
+        t = __builtin_amdgcn_readfirstlane(t);
+      }
       int ok = 1;
       // a retry of the delta loop whose pivot counts already decide a wrong inertia: nothing more is started (the workers leave
       // within one task's time; the launches of the levels above return at their first pop)
@@ -747,12 +756,16 @@ __global__ __launch_bounds__(kDfThreads, 1) void k_front_dataflow(DevPlan P, con
       if (!(dbg & 4)) df_syrk_tiles(P, s, j0, min(nq * 128, k - j0), i, rows, j, KB, k, sm, tlog ? tlog + (size_t)t * 8 + 4 : nullptr);
       mine = st + (size_t)i * TB + j; newv = q0 + nq; npub = rows;
     }
+    // the next queue position is requested now: the atomic's round trip (1 us) runs beside the drain of this task's stores
+    int t_pre = 0;
+    if (wave == 0 && (tid & 63) == 0) t_pre = atomicAdd(head, 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every storing wave: its sc1 stores have been acknowledged
     __syncthreads();                                      // ... and every wave is done with the LDS of this task and with s_ctl
     if (tlog && tid == 0) tlog[(size_t)t * 8 + 2] = wall_clock64();
     if (wave == 0) {      // lane r publishes row tile r of the task (one tile for every kind but the bulk updates)
       const int ln = tid & 63;
       if (ln < npub) __hip_atomic_store(mine + (size_t)ln * TB, newv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      t_ahead = __builtin_amdgcn_readfirstlane(t_pre);
     }
   }
 }
