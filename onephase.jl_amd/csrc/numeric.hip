@@ -322,7 +322,10 @@ __global__ __launch_bounds__(256) void k_big_assemble(DevPlan P, const int* __re
 // child entry read once (the in-HBM path zero-fills, then reads and writes the column once per contributing item).
 // Per child a small table gives the position in its rel list where each chunk boundary falls (the list is sorted),
 // and per front column the range of its A entries is precomputed: no searches on the device.
-constexpr int kAsmChunk = 1024;
+#ifndef OKKT_ASM_CHUNK
+#define OKKT_ASM_CHUNK 1024
+#endif
+constexpr int kAsmChunk = OKKT_ASM_CHUNK;
 __global__ __launch_bounds__(256) void k_big_assemble_chunked(DevPlan P, const int* __restrict__ list) {
   __shared__ double sm[4 * kAsmChunk];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
