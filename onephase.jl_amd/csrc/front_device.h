@@ -307,22 +307,31 @@ __device__ __forceinline__ void diag2_body(const DevPlan& P, int s, int step, in
             for (int j = c + 1; j < MW; ++j) a[j] = __builtin_fma(-lr[c], A[j][c], a[j]);
           }
         }
+        // outputs.  The entries below the diagonal are L; a diagonal row also stores its pivot at its own column (one store at a
+        // per-lane address instead of a select per column in every row thread); the columns of a micro-step lie in ONE 32-column
+        // block (p8 is a multiple of MW), so whether the row belongs to that diagonal 32 x 32 block is decided once.
         const int i = r - p8;
         double* Fr = F + (size_t)(j0 + p8) * f + j0 + r;
+        const bool rv = r < nb;
+        const bool inblk = (r >> 5) == (p8 >> 5);
+        double* Ldr = Ld + (r >> 5) * 32 * kXld + (r & 31) + (p8 & 31) * kXld;
 #pragma unroll
         for (int c = 0; c < MW; ++c) {
           Lp[c * kPLD + r] = -lr[c];
           Wp[c * kPLD + r] = w[c];
-          const double val = i == c ? w[c] : lr[c];
-          if (i >= c && r < nb && p8 + c < nb) {
-            if (AG) st_agent_f64(&Fr[(size_t)c * f], val); else Fr[(size_t)c * f] = val;
-            if ((r >> 5) == ((p8 + c) >> 5)) Ld[(r >> 5) * 32 * kXld + (r & 31) + ((p8 + c) & 31) * kXld] = val;
+          if (i > c && rv && p8 + c < nb) {
+            if (AG) st_agent_f64(&Fr[(size_t)c * f], lr[c]); else Fr[(size_t)c * f] = lr[c];
+            if (inblk) Ldr[c * kXld] = lr[c];
           }
         }
         if (i < MW) {
 #pragma unroll
           for (int c = 0; c < MW; ++c) my_d = i == c ? w[c] : my_d;
           dpiv[r] = my_d;
+          if (rv) {
+            if (AG) st_agent_f64(&Fr[(size_t)i * f], my_d); else Fr[(size_t)i * f] = my_d;
+            Ldr[i * kXld] = my_d;
+          }
         }
       }
     } else if (ms > 0) {
