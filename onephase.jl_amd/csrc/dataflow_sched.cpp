@@ -26,6 +26,7 @@
 #include <cstdlib>
 #include <functional>
 #include <queue>
+#include <unordered_map>
 #include <vector>
 
 #include "numeric.h"
@@ -143,6 +144,8 @@ void df_build_queue(const std::vector<DfFront>& fronts, int workers, int group, 
   double now = 0;
   int idle = std::max(1, workers);
   auto release = [&](int64_t x) { if (--nodes[x].ndep == 0) ready.push({nodes[x].key, x}); };
+  // only with D(q + 1) inside TU(q): as a task of its own it would come BEHIND the panel tile that waits for it
+  const bool early_feeder = fuse_d && rows_per_task == 1 && getenv("OKKT_DF_HOIST") && atoi(getenv("OKKT_DF_HOIST")) != 0;
   while (!ready.empty() || !running.empty()) {
     while (idle > 0 && !ready.empty()) {
       const int64_t x = ready.top().second;
@@ -166,6 +169,14 @@ void df_build_queue(const std::vector<DfFront>& fronts, int workers, int group, 
         const int64_t tu = grids[nd.front].offTU + nd.i;
         nodes[tu].dur = nd.dur + chain_scale * 40.0f;
         release(tu);
+        // ... and the panel tile that feeds the NEXT chain step, T(q + 3, q + 1), counts D(q + 1) -- which TU(q) carries -- as done
+        // already: it goes into the queue a chain step ahead of the model's time and waits there (the model's clock runs behind the
+        // real chain while updates are plentiful: the feeder was popped 10 - 40 us after it could have started).  T(2, 0) beside D(0).
+        if (early_feeder) {
+          const FrontGrid& gg = grids[nd.front];
+          if (nd.i == 0 && 2 < gg.TB) release(t_index(gg, 2, 0));
+          if (nd.i + 2 < gg.KB && nd.i + 3 < gg.TB) release(t_index(gg, nd.i + 3, nd.i + 1));
+        }
       }
     }
     if (running.empty()) break;
@@ -178,7 +189,10 @@ void df_build_queue(const std::vector<DfFront>& fronts, int workers, int group, 
     const int KB = g.KB, TB = g.TB;
     if (nd.type == kDfD) {
       const int q = nd.i;
-      for (int i = (q + 1 < KB ? q + 2 : q + 1); i < TB; ++i) release(t_index(g, i, q));
+      for (int i = (q + 1 < KB ? q + 2 : q + 1); i < TB; ++i) {
+        if (early_feeder && i == q + 2 && q + 1 < KB && (q == 0 || q - 1 + 2 < KB)) continue;      // released when D(q - 1) (D(0)) was dispatched
+        release(t_index(g, i, q));
+      }
     } else if (nd.type == kDfT || nd.type == kDfTU) {
       // block row i of panel q is done: the update groups whose LAST panel is q and that read block row i as the row operand
       // (tiles (i, j), q < j <= i) or as the column operand (tiles (i2, i), i2 > i: once per task)
@@ -216,6 +230,93 @@ void df_build_queue(const std::vector<DfFront>& fronts, int workers, int group, 
     }
   }
   if (model_us) *model_us = now;
+
+  // ---- the feeders of the chain, hoisted ---------------------------------------------------------------------------------------
+  // TU(q) needs the tiles (q + 1, q) and (q + 1, q + 1) with panel q - 1 applied: two single-panel update tasks that wait for
+  // T(q + 1, q - 1).  The simulation dispatches them when T(q + 1, q - 1) ends, i.e. BEHIND everything else that became ready in
+  // those 28 us (the other 50 panel tiles of the step and the updates they release: 280 tasks at the root of the metric workload).
+  // With every worker busy the queue advances 2.8 tasks per us, so the two tasks -- and TU(q) behind them -- were popped 30 - 100 us
+  // after they could have run: the root's diagonal blocks came every 87 us instead of every 63 while updates were plentiful, and
+  // its last 17 block columns were left over as a chain-bound tail.  With OKKT_DF_HOIST=1 they are moved up to right behind
+  // T(q + 1, q - 1), TA(q) and TU(q) right behind them (their workers wait).  A task is never moved in front of one it depends on (the
+  // dependencies are looked up; tests/test_dataflow_queue.py replays the result).  MEASURED: the two tasks then start the moment their
+  // panel tile is done -- and the panel tile T(q + 1, q - 1) is what comes late (10 - 45 us behind D(q - 1)); moved up as well
+  // (OKKT_DF_HOIST_LEAD), it waits for ITS last update, U(q + 1, q - 1; q - 2): the chain is gated by a widening cone of single-panel
+  // tasks next to the diagonal, each of which queues behind bulk work, and the root takes 6.4 ms either way.  Off.  What the cone
+  // needs is a priority the in-order queue cannot give it: a second queue for the tasks within a few block rows of the chain.
+  static const bool hoist = getenv("OKKT_DF_HOIST") && atoi(getenv("OKKT_DF_HOIST")) != 0;      // experiment, off: see below
+  if (hoist && rows_per_task == 1) {
+    auto key_of = [](const DfTask& t) {
+      const int type = t.type_nq & 255, nq = (t.type_nq >> 8) & 255, i = t.ij & 0xffff, j = t.ij >> 16;
+      const int endp = type == kDfU ? t.q0 + nq : j + 1;          // panels applied to tile (i, j) once the task is done
+      return ((int64_t)type << 48) | ((int64_t)i << 32) | ((int64_t)j << 16) | (int64_t)endp;
+    };
+    for (size_t a = 0; a < fronts.size(); ++a) {
+      const FrontGrid& g = grids[a];
+      if (g.KB < 3) continue;
+      const int sfront = fronts[a].s;
+      // positions by key for this front, kept up to date across the moves (a move shifts a short range of the queue)
+      std::unordered_map<int64_t, int64_t> where;
+      where.reserve(out.size() / fronts.size() * 2 + 16);
+      for (int64_t p = 0; p < (int64_t)out.size(); ++p)
+        if (out[p].front == sfront) where[key_of(out[p])] = p;
+      auto find = [&](int type, int i, int j, int endp) -> int64_t {
+        const auto it = where.find(((int64_t)type << 48) | ((int64_t)i << 32) | ((int64_t)j << 16) | (int64_t)endp);
+        return it == where.end() ? -1 : it->second;
+      };
+      // task at position `from` to position anchor + 1 when that is earlier (everything in between moves one place back)
+      auto hoist_to = [&](int64_t from, int64_t anchor) {
+        const int64_t to = anchor + 1;
+        if (from < 0 || from <= to) return;
+        const DfTask t = out[from];
+        for (int64_t p = from; p > to; --p) {
+          out[p] = out[p - 1];
+          if (out[p].front == sfront) where[key_of(out[p])] = p;
+        }
+        out[to] = t;
+        where[key_of(t)] = to;
+      };
+      auto single = [&](int64_t p) { return p >= 0 && ((out[p].type_nq >> 8) & 255) == 1; };
+      static const int near = getenv("OKKT_DF_HOIST_NEAR") ? atoi(getenv("OKKT_DF_HOIST_NEAR")) : 3;
+      for (int q = 1; q + 1 < g.KB; ++q) {
+        if (find(kDfT, q + 1, q - 1, q) < 0 || find(kDfTU, q, q - 1, q) < 0) continue;
+        // the chain row's panel tile T(q + 1, q - 1) itself: `lead` places ahead of where the model dispatched it (it waits for D(q - 1),
+        // which TU(q - 2) carries, and for its own last update) -- never in front of those
+        static const int lead = getenv("OKKT_DF_HOIST_LEAD") ? atoi(getenv("OKKT_DF_HOIST_LEAD")) : 0;
+        if (lead > 0) {
+          const int64_t pt = find(kDfT, q + 1, q - 1, q);
+          int64_t anchor = std::max(pt - 1 - lead, q >= 2 ? std::max(find(kDfTU, q - 1, q - 2, q - 1), find(kDfU, q + 1, q - 1, q - 1)) : find(kDfD, 0, 0, 1));
+          if (q >= 2 && (find(kDfTU, q - 1, q - 2, q - 1) < 0 || find(kDfU, q + 1, q - 1, q - 1) < 0)) anchor = pt;      // unknown dependency position: stay
+          anchor = std::max(anchor, find(kDfD, q - 1, q - 1, q));      // D(q - 1) as a task of its own
+          hoist_to(pt, anchor);
+        }
+        // U(i, q; panel q - 1) right behind T(i, q - 1) for the chain row i = q + 1 and the rows next to it (they gate T(i, q), which
+        // feeds the chain one and two steps later): needs that panel tile, the block row of TU(q - 1) and its own previous update
+        for (int i = q + 1; i <= q + near && i < g.TB; ++i) {
+          const int64_t pu = find(kDfU, i, q, q);
+          if (!single(pu) || find(kDfT, i, q - 1, q) < 0) continue;
+          if (q >= 2 && find(kDfU, i, q, q - 1) < 0) continue;
+          const int64_t anchor = std::max(std::max(find(kDfT, i, q - 1, q), find(kDfTU, q, q - 1, q)), q >= 2 ? find(kDfU, i, q, q - 1) : (int64_t)-1);
+          hoist_to(pu, anchor);
+        }
+        // U(q + 1, q + 1; panel q - 1): both operands are block row q + 1 of panel q - 1
+        {
+          const int64_t pu = find(kDfU, q + 1, q + 1, q);
+          if (single(pu) && !(q >= 2 && find(kDfU, q + 1, q + 1, q - 1) < 0))
+            hoist_to(pu, std::max(std::max(find(kDfT, q + 1, q - 1, q), find(kDfU, q + 1, q, q)), q >= 2 ? find(kDfU, q + 1, q + 1, q - 1) : (int64_t)-1));
+        }
+        // TA(q) and TU(q) behind both, behind TU(q - 1) (which carries D(q)) and behind D(q) where it is a task of its own
+        {
+          const int64_t pu1 = find(kDfU, q + 1, q, q), pu2 = find(kDfU, q + 1, q + 1, q);
+          if (pu1 < 0 || pu2 < 0) continue;
+          int64_t anchor = std::max(std::max(pu1, pu2), std::max(find(kDfTU, q, q - 1, q), find(kDfD, q, q, q + 1)));
+          const int64_t pta = find(kDfTA, q + 1, q, q + 1);
+          if (pta >= 0) { hoist_to(pta, anchor); anchor = std::max(anchor, find(kDfTA, q + 1, q, q + 1)); }
+          hoist_to(find(kDfTU, q + 1, q, q + 1), anchor);
+        }
+      }
+    }
+  }
 }
 
 }  // namespace okkt
