@@ -38,7 +38,8 @@ def test_dataflow_equals_the_per_step_launches_bit_for_bit(case, tmp_path):
 
 @pytest.mark.parametrize("env", [{"OKKT_DF_GROUP": "1"}, {"OKKT_DF_GROUP": "2"}, {"OKKT_DF_GROUP": "3", "OKKT_DF_ROWS": "2"}, {"OKKT_DF_ROWS": "4"},
                                  {"OKKT_DF_WORKERS": "7"}, {"OKKT_DF_WORKERS": "64", "OKKT_DF_MODEL_CHAIN": "2.0"}, {"OKKT_DF_SPLIT_TU": "0"},
-                                 {"OKKT_DF_SPLIT_TU": "0", "OKKT_DF_FUSE_D": "0"}, {"OKKT_DF_FUSE_D": "0"}],
+                                 {"OKKT_DF_SPLIT_TU": "0", "OKKT_DF_FUSE_D": "0"}, {"OKKT_DF_FUSE_D": "0"},
+                                 {"OKKT_DF_HOIST": "1"}, {"OKKT_DF_HOIST": "1", "OKKT_DF_HOIST_LEAD": "150", "OKKT_DF_HOIST_NEAR": "6"}, {"OKKT_DF_TAPER": "2"}],
                          ids=lambda e: ",".join(f"{k[8:]}={v}" for k, v in e.items()))
 def test_every_queue_shape_gives_the_same_factor(env, tmp_path):
     """The grouping of the panels, the number of row tiles per task, the number of workers, the time model, one or two workers for
