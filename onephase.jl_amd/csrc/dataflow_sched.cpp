@@ -37,6 +37,20 @@ namespace {
 
 constexpr int kLonePanels = 2;
 
+// Two-kernel form: does a panel tile / update belong to the chain kernel's queue?  The chain D(q) -> TU(q) -> D(q + 1) is fed by the
+// block rows right below the diagonal: TU(q) needs the tiles (q + 1, q) and (q + 1, q + 1) with panel q - 1 applied, i.e. T(q + 1, q - 1)
+// and two single-panel updates behind D(q - 1) -- 57 us of work against the 63 us between two diagonal blocks, with no slack for a
+// place in a bulk queue or for a CU shared with another workgroup (measured: the root of the metric workload fell from 94 to 111 us
+// per block column with every T and U in the bulk queues).  So the panel tiles of the `near` block rows below TU's, and the
+// single-panel updates of the last two panels of a pivot column on tiles within `near` rows of the diagonal, run on the chain
+// kernel's workers (a whole CU each, nothing queued in front of them).
+inline bool near_chain_task(int type, int i, int j, int q0, int nq, int KB, int near) {
+  if (near <= 0) return false;
+  if (type == kDfT) return i - j <= near + 1;
+  if (type == kDfU) return nq == 1 && j < KB && q0 + kLonePanels >= j && i - j <= near;
+  return false;
+}
+
 struct FrontGrid {
   int f, k, KB, TB;
   int64_t offD, offT, offTU, offU;   // first task index of each kind
@@ -54,7 +68,14 @@ struct FrontGrid {
 
 }  // namespace
 
-void df_build_queue(const std::vector<DfFront>& fronts, int workers, int group, int rows_per_task, bool fuse_d, bool split_tu, std::vector<DfTask>& out, double* model_us) {
+int df_near_rows() {
+  static const int near = getenv("OKKT_DF_NEAR") ? atoi(getenv("OKKT_DF_NEAR")) : 2;
+  return near;
+}
+
+void df_build_queue(const std::vector<DfFront>& fronts, int workers, int group, int rows_per_task, bool fuse_d, bool split_tu, std::vector<DfTask>& out, double* model_us,
+                    int chain_workers, float bulk_mul) {
+  const int near = chain_workers > 0 ? df_near_rows() : 0;
   const int G = std::max(1, group);
   const int RT = std::max(1, std::min(rows_per_task, 8));
   // Time model (us, measured on MI355X with one workgroup per CU: D 39-45, T 25-32, U 25-30 at K = 128 and 45-52 at K = 256, TU 40
@@ -63,7 +84,8 @@ void df_build_queue(const std::vector<DfFront>& fronts, int workers, int group, 
   // between diagonal blocks instead of 45 in the bulk-bound phase of the S-metric root); one that is popped early only costs a
   // waiting workgroup.
   static const float chain_scale = getenv("OKKT_DF_MODEL_CHAIN") ? (float)atof(getenv("OKKT_DF_MODEL_CHAIN")) : 0.6f;
-  static const float bulk_scale = getenv("OKKT_DF_MODEL_BULK") ? (float)atof(getenv("OKKT_DF_MODEL_BULK")) : 1.0f;
+  static const float bulk_env = getenv("OKKT_DF_MODEL_BULK") ? (float)atof(getenv("OKKT_DF_MODEL_BULK")) : 1.0f;
+  const float bulk_scale = bulk_env * bulk_mul;
   std::vector<FrontGrid> grids(fronts.size());
   struct Node { int front; int type; int i, j, q0, nq; int ndep; float dur; int64_t key; int rows; };
   std::vector<Node> nodes;
@@ -83,19 +105,7 @@ void df_build_queue(const std::vector<DfFront>& fronts, int workers, int group, 
       const int lone = j < KB ? std::min(np, kLonePanels) : 0;
       const int grouped = np - lone;
       std::vector<int>& gs = g.gstart[j];
-      // OKKT_DF_TAPER = t > 0: the group right in front of the lone panels holds at most t panels and the full groups are aligned to
-      // IT (the short group comes first): behind D(q - 3) the tile (q + 1, q) then needs T, a K = 128 t update and the two lone ones
-      // (28 + 47 + 28 + 28 us at t = 2) within three chain steps (189 us) instead of T + a K = 512 update + the lone ones (181 us)
-      static const int taper_env = getenv("OKKT_DF_TAPER") ? atoi(getenv("OKKT_DF_TAPER")) : 0;
-      const int taper = std::min(taper_env, G - 1);      // (a group of G panels is not a taper)
-      if (taper > 0 && j < KB && grouped > taper) {
-        const int head_part = (grouped - taper) % G;
-        if (head_part > 0) gs.push_back(0);
-        for (int q0 = head_part; q0 < grouped - taper; q0 += G) gs.push_back(q0);
-        gs.push_back(grouped - taper);
-      } else {
-        for (int q0 = 0; q0 < grouped; q0 += G) gs.push_back(q0);
-      }
+      for (int q0 = 0; q0 < grouped; q0 += G) gs.push_back(q0);
       for (int q0 = grouped; q0 < np; ++q0) gs.push_back(q0);
       gs.push_back(np);
     }
@@ -115,7 +125,8 @@ void df_build_queue(const std::vector<DfFront>& fronts, int workers, int group, 
     for (int q = 0; q < KB; ++q) {
       const int first = q + 1 < KB ? q + 2 : q + 1;             // block row q + 1 belongs to TU(q)
       g.tq[q + 1] = g.tq[q] + std::max(TB - first, 0);
-      for (int i = first; i < TB; ++i) nodes.push_back({(int)a, kDfT, i, q, q, 1, 1 + (q > 0 ? 1 : 0), bulk_scale * 28.0f, key(q, 2, i, q), 1});
+      for (int i = first; i < TB; ++i)
+        nodes.push_back({(int)a, kDfT, i, q, q, 1, 1 + (q > 0 ? 1 : 0), (near_chain_task(kDfT, i, q, q, 1, KB, near) ? bulk_env : bulk_scale) * 28.0f, key(q, 2, i, q), 1});
     }
     // Update tasks.  The groups of a column that are not the lone last panel of a pivot column are bulk work: the tiles below the
     // diagonal tile are taken `rows_per_task` at a time (one pop, one wait, one acquire and one drain per task, and the C tile of
@@ -135,7 +146,8 @@ void df_build_queue(const std::vector<DfFront>& fronts, int workers, int group, 
           const bool in_tu = i == j && lone_last;                  // the last panel of a diagonal pivot tile: part of TU(j - 1)
           const int ndep = (i != j ? rows + 1 : 1) + (c > 0 ? 1 : 0);
           for (int r = 0; r < rows; ++r) g.unode[j][c][i + r] = (int64_t)nodes.size();
-          nodes.push_back({(int)a, in_tu ? -1 : kDfU, i, j, q0, nq, ndep, bulk_scale * (6.0f + 0.16f * 128.0f * (float)nq * (float)rows + 4.0f * (float)(rows - 1)), key(j, 3, i, q0), rows});
+          nodes.push_back({(int)a, in_tu ? -1 : kDfU, i, j, q0, nq, ndep,
+                           (near_chain_task(kDfU, i, j, q0, nq, KB, near) ? bulk_env : bulk_scale) * (6.0f + 0.16f * 128.0f * (float)nq * (float)rows + 4.0f * (float)(rows - 1)), key(j, 3, i, q0), rows});
           i += rows;
         }
       }
@@ -145,23 +157,34 @@ void df_build_queue(const std::vector<DfFront>& fronts, int workers, int group, 
     if (q + 1 < g.KB) return i == q + 1 ? g.offTU + q : g.offT + g.tq[q] + (i - q - 2);
     return g.offT + g.tq[q] + (i - q - 1);
   };
-  // list schedule: `workers` identical workers, a ready task with the smallest key starts as soon as a worker is free
+  // list schedule: `workers` identical workers, a ready task with the smallest key starts as soon as a worker is free.  With
+  // chain_workers > 0 (the two-kernel form of dataflow.hip) the chain tasks D / TU have a pool of their own and the panel tiles and
+  // updates share `workers` bulk workers; the emitted order is still ONE sequence, which df_split_queue cuts into the kernels' queues
   typedef std::pair<int64_t, int64_t> KI;   // (key, node)
-  std::priority_queue<KI, std::vector<KI>, std::greater<KI>> ready;
+  std::priority_queue<KI, std::vector<KI>, std::greater<KI>> ready_pool[2];
   typedef std::pair<double, int64_t> TI;    // (finish time, node)
   std::priority_queue<TI, std::vector<TI>, std::greater<TI>> running;
-  for (int64_t x = 0; x < (int64_t)nodes.size(); ++x) if (nodes[x].type >= 0 && nodes[x].ndep == 0) ready.push({nodes[x].key, x});
+  auto pool_of = [&](const Node& nd) {
+    if (chain_workers <= 0) return 0;
+    return (nd.type == kDfD || nd.type == kDfTU || near_chain_task(nd.type, nd.i, nd.j, nd.q0, nd.nq, grids[nd.front].KB, near)) ? 1 : 0;
+  };
+  for (int64_t x = 0; x < (int64_t)nodes.size(); ++x) if (nodes[x].type >= 0 && nodes[x].ndep == 0) ready_pool[pool_of(nodes[x])].push({nodes[x].key, x});
   out.clear();
   out.reserve(nodes.size());
   double now = 0;
-  int idle = std::max(1, workers);
-  auto release = [&](int64_t x) { if (--nodes[x].ndep == 0) ready.push({nodes[x].key, x}); };
-  // only with D(q + 1) inside TU(q): as a task of its own it would come BEHIND the panel tile that waits for it
-  const bool early_feeder = fuse_d && rows_per_task == 1 && getenv("OKKT_DF_HOIST") && atoi(getenv("OKKT_DF_HOIST")) != 0;
-  while (!ready.empty() || !running.empty()) {
-    while (idle > 0 && !ready.empty()) {
-      const int64_t x = ready.top().second;
-      ready.pop();
+  int idle_pool[2] = {std::max(1, workers), std::max(0, chain_workers)};
+  auto release = [&](int64_t x) { if (--nodes[x].ndep == 0) ready_pool[pool_of(nodes[x])].push({nodes[x].key, x}); };
+  auto any_ready = [&]() { return !ready_pool[0].empty() || !ready_pool[1].empty(); };
+  while (any_ready() || !running.empty()) {
+    for (;;) {
+      // the more urgent of the two pools' heads that has a free worker
+      int pl = -1;
+      for (int c = 0; c < 2; ++c)
+        if (idle_pool[c] > 0 && !ready_pool[c].empty() && (pl < 0 || ready_pool[c].top().first < ready_pool[pl].top().first)) pl = c;
+      if (pl < 0) break;
+      int& idle = idle_pool[pl];
+      const int64_t x = ready_pool[pl].top().second;
+      ready_pool[pl].pop();
       Node& nd = nodes[x];
       // fuse_d: D(q), q >= 1, is carried out by the worker of TU(q - 1) right behind the update of its tile (no task of its own; it stays
       // in this simulation, where it starts on some worker the moment TU(q - 1) ends -- the same thing for the model)
@@ -181,30 +204,19 @@ void df_build_queue(const std::vector<DfFront>& fronts, int workers, int group, 
         const int64_t tu = grids[nd.front].offTU + nd.i;
         nodes[tu].dur = nd.dur + chain_scale * 40.0f;
         release(tu);
-        // ... and the panel tile that feeds the NEXT chain step, T(q + 3, q + 1), counts D(q + 1) -- which TU(q) carries -- as done
-        // already: it goes into the queue a chain step ahead of the model's time and waits there (the model's clock runs behind the
-        // real chain while updates are plentiful: the feeder was popped 10 - 40 us after it could have started).  T(2, 0) beside D(0).
-        if (early_feeder) {
-          const FrontGrid& gg = grids[nd.front];
-          if (nd.i == 0 && 2 < gg.TB) release(t_index(gg, 2, 0));
-          if (nd.i + 2 < gg.KB && nd.i + 3 < gg.TB) release(t_index(gg, nd.i + 3, nd.i + 1));
-        }
       }
     }
     if (running.empty()) break;
     const int64_t x = running.top().second;
     now = running.top().first;
     running.pop();
-    ++idle;
     const Node nd = nodes[x];
+    ++idle_pool[pool_of(nd)];
     const FrontGrid& g = grids[nd.front];
     const int KB = g.KB, TB = g.TB;
     if (nd.type == kDfD) {
       const int q = nd.i;
-      for (int i = (q + 1 < KB ? q + 2 : q + 1); i < TB; ++i) {
-        if (early_feeder && i == q + 2 && q + 1 < KB && (q == 0 || q - 1 + 2 < KB)) continue;      // released when D(q - 1) (D(0)) was dispatched
-        release(t_index(g, i, q));
-      }
+      for (int i = (q + 1 < KB ? q + 2 : q + 1); i < TB; ++i) release(t_index(g, i, q));
     } else if (nd.type == kDfT || nd.type == kDfTU) {
       // block row i of panel q is done: the update groups whose LAST panel is q and that read block row i as the row operand
       // (tiles (i, j), q < j <= i) or as the column operand (tiles (i2, i), i2 > i: once per task)
@@ -242,92 +254,36 @@ void df_build_queue(const std::vector<DfFront>& fronts, int workers, int group, 
     }
   }
   if (model_us) *model_us = now;
+}
 
-  // ---- the feeders of the chain, hoisted ---------------------------------------------------------------------------------------
-  // TU(q) needs the tiles (q + 1, q) and (q + 1, q + 1) with panel q - 1 applied: two single-panel update tasks that wait for
-  // T(q + 1, q - 1).  The simulation dispatches them when T(q + 1, q - 1) ends, i.e. BEHIND everything else that became ready in
-  // those 28 us (the other 50 panel tiles of the step and the updates they release: 280 tasks at the root of the metric workload).
-  // With every worker busy the queue advances 2.8 tasks per us, so the two tasks -- and TU(q) behind them -- were popped 30 - 100 us
-  // after they could have run: the root's diagonal blocks came every 87 us instead of every 63 while updates were plentiful, and
-  // its last 17 block columns were left over as a chain-bound tail.  With OKKT_DF_HOIST=1 they are moved up to right behind
-  // T(q + 1, q - 1), TA(q) and TU(q) right behind them (their workers wait).  A task is never moved in front of one it depends on (the
-  // dependencies are looked up; tests/test_dataflow_queue.py replays the result).  MEASURED: the two tasks then start the moment their
-  // panel tile is done -- and the panel tile T(q + 1, q - 1) is what comes late (10 - 45 us behind D(q - 1)); moved up as well
-  // (OKKT_DF_HOIST_LEAD), it waits for ITS last update, U(q + 1, q - 1; q - 2): the chain is gated by a widening cone of single-panel
-  // tasks next to the diagonal, each of which queues behind bulk work, and the root takes 6.4 ms either way.  Off.  What the cone
-  // needs is a priority the in-order queue cannot give it: a second queue for the tasks within a few block rows of the chain.
-  static const bool hoist = getenv("OKKT_DF_HOIST") && atoi(getenv("OKKT_DF_HOIST")) != 0;      // experiment, off: see below
-  if (hoist && rows_per_task == 1) {
-    auto key_of = [](const DfTask& t) {
-      const int type = t.type_nq & 255, nq = (t.type_nq >> 8) & 255, i = t.ij & 0xffff, j = t.ij >> 16;
-      const int endp = type == kDfU ? t.q0 + nq : j + 1;          // panels applied to tile (i, j) once the task is done
-      return ((int64_t)type << 48) | ((int64_t)i << 32) | ((int64_t)j << 16) | (int64_t)endp;
-    };
-    for (size_t a = 0; a < fronts.size(); ++a) {
-      const FrontGrid& g = grids[a];
-      if (g.KB < 3) continue;
-      const int sfront = fronts[a].s;
-      // positions by key for this front, kept up to date across the moves (a move shifts a short range of the queue)
-      std::unordered_map<int64_t, int64_t> where;
-      where.reserve(out.size() / fronts.size() * 2 + 16);
-      for (int64_t p = 0; p < (int64_t)out.size(); ++p)
-        if (out[p].front == sfront) where[key_of(out[p])] = p;
-      auto find = [&](int type, int i, int j, int endp) -> int64_t {
-        const auto it = where.find(((int64_t)type << 48) | ((int64_t)i << 32) | ((int64_t)j << 16) | (int64_t)endp);
-        return it == where.end() ? -1 : it->second;
-      };
-      // task at position `from` to position anchor + 1 when that is earlier (everything in between moves one place back)
-      auto hoist_to = [&](int64_t from, int64_t anchor) {
-        const int64_t to = anchor + 1;
-        if (from < 0 || from <= to) return;
-        const DfTask t = out[from];
-        for (int64_t p = from; p > to; --p) {
-          out[p] = out[p - 1];
-          if (out[p].front == sfront) where[key_of(out[p])] = p;
-        }
-        out[to] = t;
-        where[key_of(t)] = to;
-      };
-      auto single = [&](int64_t p) { return p >= 0 && ((out[p].type_nq >> 8) & 255) == 1; };
-      static const int near = getenv("OKKT_DF_HOIST_NEAR") ? atoi(getenv("OKKT_DF_HOIST_NEAR")) : 3;
-      for (int q = 1; q + 1 < g.KB; ++q) {
-        if (find(kDfT, q + 1, q - 1, q) < 0 || find(kDfTU, q, q - 1, q) < 0) continue;
-        // the chain row's panel tile T(q + 1, q - 1) itself: `lead` places ahead of where the model dispatched it (it waits for D(q - 1),
-        // which TU(q - 2) carries, and for its own last update) -- never in front of those
-        static const int lead = getenv("OKKT_DF_HOIST_LEAD") ? atoi(getenv("OKKT_DF_HOIST_LEAD")) : 0;
-        if (lead > 0) {
-          const int64_t pt = find(kDfT, q + 1, q - 1, q);
-          int64_t anchor = std::max(pt - 1 - lead, q >= 2 ? std::max(find(kDfTU, q - 1, q - 2, q - 1), find(kDfU, q + 1, q - 1, q - 1)) : find(kDfD, 0, 0, 1));
-          if (q >= 2 && (find(kDfTU, q - 1, q - 2, q - 1) < 0 || find(kDfU, q + 1, q - 1, q - 1) < 0)) anchor = pt;      // unknown dependency position: stay
-          anchor = std::max(anchor, find(kDfD, q - 1, q - 1, q));      // D(q - 1) as a task of its own
-          hoist_to(pt, anchor);
-        }
-        // U(i, q; panel q - 1) right behind T(i, q - 1) for the chain row i = q + 1 and the rows next to it (they gate T(i, q), which
-        // feeds the chain one and two steps later): needs that panel tile, the block row of TU(q - 1) and its own previous update
-        for (int i = q + 1; i <= q + near && i < g.TB; ++i) {
-          const int64_t pu = find(kDfU, i, q, q);
-          if (!single(pu) || find(kDfT, i, q - 1, q) < 0) continue;
-          if (q >= 2 && find(kDfU, i, q, q - 1) < 0) continue;
-          const int64_t anchor = std::max(std::max(find(kDfT, i, q - 1, q), find(kDfTU, q, q - 1, q)), q >= 2 ? find(kDfU, i, q, q - 1) : (int64_t)-1);
-          hoist_to(pu, anchor);
-        }
-        // U(q + 1, q + 1; panel q - 1): both operands are block row q + 1 of panel q - 1
-        {
-          const int64_t pu = find(kDfU, q + 1, q + 1, q);
-          if (single(pu) && !(q >= 2 && find(kDfU, q + 1, q + 1, q - 1) < 0))
-            hoist_to(pu, std::max(std::max(find(kDfT, q + 1, q - 1, q), find(kDfU, q + 1, q, q)), q >= 2 ? find(kDfU, q + 1, q + 1, q - 1) : (int64_t)-1));
-        }
-        // TA(q) and TU(q) behind both, behind TU(q - 1) (which carries D(q)) and behind D(q) where it is a task of its own
-        {
-          const int64_t pu1 = find(kDfU, q + 1, q, q), pu2 = find(kDfU, q + 1, q + 1, q);
-          if (pu1 < 0 || pu2 < 0) continue;
-          int64_t anchor = std::max(std::max(pu1, pu2), std::max(find(kDfTU, q, q - 1, q), find(kDfD, q, q, q + 1)));
-          const int64_t pta = find(kDfTA, q + 1, q, q + 1);
-          if (pta >= 0) { hoist_to(pta, anchor); anchor = std::max(anchor, find(kDfTA, q + 1, q, q + 1)); }
-          hoist_to(find(kDfTU, q + 1, q, q + 1), anchor);
-        }
-      }
-    }
+// The two-kernel form (dataflow.hip: k_front_bulk beside k_front_dataflow): the chain tasks D / TA / TU keep their relative order in
+// `chain`; the panel tiles and the updates go to one queue per XCD.  Every queue is a subsequence of the one topological order, so
+// the earliest unfinished task is always at the head of its queue or running: the in-order pop rule keeps the launch deadlock-free
+// as long as every queue has a resident worker.  Which XCD: the rows of tile column j are cut into eight contiguous chunks counted
+// from the bottom of the front -- a chunk keeps its rows while the column moves to the right, so the updates of one row band by
+// consecutive tile columns share the W panel in that XCD's L2, and the ~8 rows x ~8 columns an XCD has in flight share their L
+// panels -- rotated by the update group (different groups read different panels anyway) so that the short chunk at the diagonal
+// does not always fall on the same XCD.
+void df_split_queue(const std::vector<DfFront>& fronts, const std::vector<DfTask>& q, std::vector<DfTask>& chain, std::vector<DfTask> bulk[8]) {
+  chain.clear();
+  for (int x = 0; x < 8; ++x) bulk[x].clear();
+  std::vector<std::pair<int, int>> byfront;      // (supernode, index in fronts), sorted
+  for (size_t a = 0; a < fronts.size(); ++a) byfront.push_back({fronts[a].s, (int)a});
+  std::sort(byfront.begin(), byfront.end());
+  for (const DfTask& t : q) {
+    const int type = t.type_nq & 255;
+    if (type == kDfD || type == kDfTU || type == kDfTA) { chain.push_back(t); continue; }
+    const auto it = std::lower_bound(byfront.begin(), byfront.end(), std::make_pair(t.front, -1));
+    const int a = it->second;
+    const int f = fronts[a].f, k = fronts[a].k;
+    const int KB = (k + 127) / 128;
+    const int TB = KB + (f - k + 127) / 128;
+    const int i = t.ij & 0xffff, j = t.ij >> 16;
+    if (near_chain_task(type, i, j, t.q0, (t.type_nq >> 8) & 255, KB, df_near_rows())) { chain.push_back(t); continue; }
+    const int col = type == kDfT ? j + 1 : j;                 // first row of the column's range
+    const int cs = std::max(1, (TB - col + 7) / 8);
+    const int c = std::min(7, (TB - 1 - i) / cs);
+    bulk[(c + (t.q0 >> 2) + a) & 7].push_back(t);
   }
 }
 

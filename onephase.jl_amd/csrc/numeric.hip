@@ -1398,7 +1398,10 @@ std::string numeric_factor_enqueue(Numeric& N, const double* d_vals, double tol,
   // the arrival counters of the fused backward launches are reset by their consumer; a sweep that was cut short (a wait that ran into
   // its bound) leaves a residue that would let the next solve's consumer start early: cleared with the time-out word (advisor, round 3)
   if (reset_counters && N.solve_counters) OKKT_HIP_TRY(hipMemsetAsync(N.solve_counters, 0, (size_t)N.d.nsuper * sizeof(int), st));
-  if (N.dataflow && P.df_state) OKKT_HIP_TRY(hipMemsetAsync(P.df_state, 0, ((size_t)N.df_state_ints + (size_t)N.n_df_heads) * sizeof(int), st));   // tile states and queue heads
+  if (N.dataflow && P.df_state) {
+    OKKT_HIP_TRY(hipMemsetAsync(P.df_state, 0, ((size_t)N.df_state_ints + (size_t)N.n_df_heads * kDfHeadStride + (size_t)N.df_ntasks) * sizeof(int), st));   // tile states, queue heads, claim words
+    ++N.df_epoch;      // the assembly flags of the two-kernel levels are monotonic: a new value per factorisation instead of a fill
+  }
   if (N.early_check && N.early_device && which == 0 && N.levels_top.empty() && reset_counters) { P.want_pos = N.early_n; P.want_neg = N.early_m; }
   N.la_used = 0;
   if (which == 0) std::fill(N.inv_level_pending.begin(), N.inv_level_pending.end(), 0);
@@ -1408,7 +1411,7 @@ std::string numeric_factor_enqueue(Numeric& N, const double* d_vals, double tol,
   N.early_exited = false;
   std::string e;
   {
-    const LaneStreams ss{N.stream, N.stream_masked, N.stream_panel, N.stream_aux};
+    const LaneStreams ss{N.stream, N.stream_masked, N.stream_panel, N.stream_aux, N.stream_chain};
     e = factor_sched(N, P, which == 0 ? N.levels : N.levels_top, which == 0 ? N.slevels : N.slevels_top, ss, tol,
                      which == 0 && N.levels_top.empty(), inv_on_aux);
     if (!e.empty()) return e;
@@ -1425,7 +1428,40 @@ std::string numeric_factor_enqueue(Numeric& N, const double* d_vals, double tol,
 
 static std::string factor_sched(Numeric& N, DevPlan P, const std::vector<LevelSchedule>& levels, const std::vector<SolveLevel>& slevels,
                                 const LaneStreams& ss, double tol, bool in_loop_check, bool& inv_on_aux, size_t l_begin, size_t l_end) {
-  hipStream_t st = ss.main;
+  // `cur`: the stream the schedule is on.  The levels that run in the two-kernel form of the dataflow launch (dataflow.hip) sit on the
+  // CU-masked twin of the handle's stream, their chain kernels on the chain stream (the reserved CUs); everything else on the handle's
+  // stream.  A change of stream is one event; the chain stream is tied to the start of the factorisation (the fill of the tile states
+  // must not overtake a chain kernel that finds the previous factorisation's states) and joined at the end.
+  hipStream_t cur = ss.main;
+  bool chain_used = false;
+  auto next_event_top = [&](hipEvent_t* ev) -> std::string {
+    if (N.la_used >= N.la_events.size())
+      for (int q = 0; q < 64; ++q) { hipEvent_t e2; OKKT_HIP_TRY(hipEventCreateWithFlags(&e2, hipEventDisableTiming)); N.la_events.push_back(e2); }
+    *ev = N.la_events[N.la_used++];
+    return "";
+  };
+  auto move_to = [&](hipStream_t to) -> std::string {
+    if (to == cur || to == nullptr) return "";
+    hipEvent_t ev;
+    std::string e2 = next_event_top(&ev);
+    if (!e2.empty()) return e2;
+    OKKT_HIP_TRY(hipEventRecord(ev, cur));
+    OKKT_HIP_TRY(hipStreamWaitEvent(to, ev, 0));
+    cur = to;
+    return "";
+  };
+  auto finish = [&]() -> std::string {
+    std::string e2 = move_to(ss.main);
+    if (!e2.empty()) return e2;
+    if (chain_used) {
+      hipEvent_t ev;
+      if (!(e2 = next_event_top(&ev)).empty()) return e2;
+      OKKT_HIP_TRY(hipEventRecord(ev, ss.chain));
+      OKKT_HIP_TRY(hipStreamWaitEvent(ss.main, ev, 0));
+      chain_used = false;
+    }
+    return "";
+  };
   const int NB = N.nb;
   static const int dbg_syrk = getenv("OKKT_DEBUG_SYRK") ? atoi(getenv("OKKT_DEBUG_SYRK")) : 0;
   static const int split_min_rows = getenv("OKKT_SPLIT_MIN_ROWS") ? atoi(getenv("OKKT_SPLIT_MIN_ROWS")) : 5000;
@@ -1437,11 +1473,11 @@ static std::string factor_sched(Numeric& N, DevPlan P, const std::vector<LevelSc
       // the pivots counted so far already decide a wrong inertia?  Then the (expensive) rest of the tree is skipped:
       // one synchronisation per factorisation, 35 of 49 ms saved per failed attempt of the delta loop at S-metric
       unsigned long long cnt[5] = {0, 0, 0, 0, 0};
-      std::string ec = numeric_read_counts(N, st, cnt);
+      std::string ec = numeric_read_counts(N, cur, cnt);
       if (!ec.empty()) return ec;
       if (cnt[4] != 0 || cnt[3] > 0 || cnt[2] > 0 || cnt[1] > (unsigned long long)N.early_m || cnt[0] > (unsigned long long)N.early_n) {
         N.early_exited = true;
-        return "";
+        return finish();
       }
     }
     if (l == 0 && &levels == &N.levels && N.flow_levels >= 2 && l_end >= (size_t)N.flow_levels && N.flow_flags) {
@@ -1450,22 +1486,22 @@ static std::string factor_sched(Numeric& N, DevPlan P, const std::vector<LevelSc
       // OKKT_DEBUG_DROP_HANDOFF=1 (tests): the consumers wait for an epoch nobody raises -- every wait runs into its bound
       static const int drop = getenv("OKKT_DEBUG_DROP_HANDOFF") ? atoi(getenv("OKKT_DEBUG_DROP_HANDOFF")) : 0;
       const int wep = ep + ((drop & 1) ? (1 << 20) : 0);
-      if (N.flow_maxf <= 32) hipLaunchKernelGGL((k_front_small<64, true>), dim3(N.flow_cnt), dim3(64), lds_small(N.flow_maxf), st, P, P.sched + N.flow_off, tol, N.flow_flags, ep, wep);
-      else hipLaunchKernelGGL((k_front_small<256, true>), dim3(N.flow_cnt), dim3(256), lds_small(N.flow_maxf), st, P, P.sched + N.flow_off, tol, N.flow_flags, ep, wep);
-      if (P.want_neg >= 0) hipLaunchKernelGGL(k_fold_counts, dim3(1), dim3(64), 0, st, P);
+      if (N.flow_maxf <= 32) hipLaunchKernelGGL((k_front_small<64, true>), dim3(N.flow_cnt), dim3(64), lds_small(N.flow_maxf), cur, P, P.sched + N.flow_off, tol, N.flow_flags, ep, wep);
+      else hipLaunchKernelGGL((k_front_small<256, true>), dim3(N.flow_cnt), dim3(256), lds_small(N.flow_maxf), cur, P, P.sched + N.flow_off, tol, N.flow_flags, ep, wep);
+      if (P.want_neg >= 0) hipLaunchKernelGGL(k_fold_counts, dim3(1), dim3(64), 0, cur, P);
       l = (size_t)N.flow_levels - 1;
       continue;
     }
     if (L.seg[0].cnt) {
       const Segment& g = L.seg[0];
-      hipLaunchKernelGGL(k_front_small<64>, dim3(g.cnt), dim3(64), lds_small(g.maxf), st, P, P.sched + g.off, tol, (int*)nullptr, 0, 0);
+      hipLaunchKernelGGL(k_front_small<64>, dim3(g.cnt), dim3(64), lds_small(g.maxf), cur, P, P.sched + g.off, tol, (int*)nullptr, 0, 0);
     }
     for (int c = 1; c <= 2; ++c)
       if (L.seg[c].cnt) {
         const Segment& g = L.seg[c];
-        hipLaunchKernelGGL(k_front_small<256>, dim3(g.cnt), dim3(256), lds_small(g.maxf), st, P, P.sched + g.off, tol, (int*)nullptr, 0, 0);
+        hipLaunchKernelGGL(k_front_small<256>, dim3(g.cnt), dim3(256), lds_small(g.maxf), cur, P, P.sched + g.off, tol, (int*)nullptr, 0, 0);
       }
-    if (P.want_neg >= 0 && (L.seg[0].cnt || L.seg[1].cnt || L.seg[2].cnt)) hipLaunchKernelGGL(k_fold_counts, dim3(1), dim3(64), 0, st, P);
+    if (P.want_neg >= 0 && (L.seg[0].cnt || L.seg[1].cnt || L.seg[2].cnt)) hipLaunchKernelGGL(k_fold_counts, dim3(1), dim3(64), 0, cur, P);
     if (L.seg[3].cnt) {
       const Segment& g = L.seg[3];
       const int* list = P.sched + g.off;
@@ -1501,8 +1537,13 @@ static std::string factor_sched(Numeric& N, DevPlan P, const std::vector<LevelSc
       // to the panel streams); every other level keeps all CUs
       // the level's big fronts as one persistent dataflow launch (dataflow.hip) instead of the per-step launches below
       const bool use_df = N.dataflow && g.df_cnt > 0 && NB == 128 && dbg_syrk == 0 && dbg_stop == 0 && P.df_state != nullptr;
+      const bool use_split = use_df && g.df_split && ss.masked && ss.chain;
+      {
+        std::string em = move_to(use_split ? ss.masked : ss.main);
+        if (!em.empty()) return em;
+      }
       const bool seg_la = !use_df && la_at(0, gs_at(0));
-      hipStream_t st = ss.main;
+      hipStream_t st = cur;
       if (seg_la) {
         hipEvent_t evf;
         std::string e = next_event(&evf);
@@ -1722,9 +1763,25 @@ static std::string factor_sched(Numeric& N, DevPlan P, const std::vector<LevelSc
           N.prof_flops.push_back(g.df_flops);
           OKKT_HIP_TRY(hipEventRecord(N.prof_events[N.prof_used++], st));
         }
-        std::string e = df_launch(N, P, g, st, tol);
+        std::string e;
+        if (use_split) {
+          if (!chain_used) {      // first chain kernel of this factorisation: behind the fill of the tile states (and whatever the handle's stream has done since)
+            hipEvent_t evc;
+            if (!(e = next_event(&evc)).empty()) return e;
+            OKKT_HIP_TRY(hipEventRecord(evc, st));
+            OKKT_HIP_TRY(hipStreamWaitEvent(ss.chain, evc, 0));
+            chain_used = true;
+          }
+          e = df_launch_split(N, P, g, st, ss.chain, tol);
+        } else e = df_launch(N, P, g, st, tol);
         if (!e.empty()) return e;
         if (prof) OKKT_HIP_TRY(hipEventRecord(N.prof_events[N.prof_used++], st));
+        if (use_split) {      // the block inversions read what the chain kernel wrote as well
+          hipEvent_t evc;
+          if (!(e = next_event(&evc)).empty()) return e;
+          OKKT_HIP_TRY(hipEventRecord(evc, ss.chain));
+          OKKT_HIP_TRY(hipStreamWaitEvent(inv_st, evc, 0));
+        }
         if (!(e = inv_range(nsteps, true)).empty()) return e;
         if (!(e = level_inv_event()).empty()) return e;
         continue;
@@ -1772,7 +1829,7 @@ static std::string factor_sched(Numeric& N, DevPlan P, const std::vector<LevelSc
       }
     }
   }
-  return "";
+  return finish();
 }
 
 

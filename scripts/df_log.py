@@ -32,6 +32,16 @@ for n_, l_ in enumerate(launches):
 which = int(sys.argv[2]) if len(sys.argv) > 2 else int(np.argmax([len(l) for l in launches]))
 L = np.array(launches[which], dtype=np.int64)
 idx, front, typ, ti, tj, q0, nq, worker, pop, ready, end = L.T[:11]
+place = worker >> 16              # two-kernel form: XCC id | HW_ID << 4 of the bulk workers
+worker = worker & 0xffff
+if place.any():
+    xcc = place & 15
+    hw = place >> 4
+    cu = ((hw >> 8) & 15) | (((hw >> 12) & 1) << 4) | (((hw >> 13) & 7) << 5) | (xcc << 8)      # cu_id, sh_id, se_id, xcc
+    m = worker >= 1000
+    wk = np.unique(np.stack([worker[m], cu[m]], axis=1), axis=0)
+    per_cu = np.bincount(np.unique(wk[:, 1], return_inverse=True)[1])
+    print(f"  bulk workers seen: {len(wk)} on {len(per_cu)} CUs; CUs with 1 / 2 / more workers: {(per_cu == 1).sum()} / {(per_cu == 2).sum()} / {(per_cu > 2).sum()}; per XCD: {np.bincount(wk[:, 1] >> 8, minlength=8).tolist()}")
 nrows = np.maximum(nq >> 8, 1)
 nq = nq & 255
 marks = L[:, 11:15] if L.shape[1] >= 15 else None
@@ -52,6 +62,21 @@ for k in (0, 1, 2, 3, 4):
         body = end[sel] - ready[sel]
         wait = ready[sel] - pop[sel]
         print(f"  {label:8s} n {sel.sum():6d}  body us: mean {body.mean():6.1f} med {np.median(body):6.1f} max {body.max():6.1f} | wait us: mean {wait.mean():6.1f} med {np.median(wait):6.1f} max {wait.max():7.1f} | sum body {body.sum() / 1e3:8.2f} ms")
+if os.environ.get("OKKT_DF_LOG_SAVE"):
+    np.savez_compressed(os.environ["OKKT_DF_LOG_SAVE"], L=L)
+# time line: per twentieth of the span the share of the workers inside a task body / waiting in a popped task, the update work
+# started and the block column the chain has reached
+nbk = 20
+edges = np.linspace(0.0, span, nbk + 1)
+nwk = len(set(worker))
+print("  time line (us from | body % | wait % | U tasks started | diagonal blocks done by then)")
+dends = np.sort(end[(typ == 0) | ((typ == 3) & ((nq & 2) != 0))])
+for b in range(nbk):
+    lo, hi = edges[b], edges[b + 1]
+    inb = np.clip(np.minimum(end, hi) - np.maximum(ready, lo), 0, None).sum()
+    inw = np.clip(np.minimum(ready, hi) - np.maximum(pop, lo), 0, None).sum()
+    nu = int(((typ == 2) & (ready >= lo) & (ready < hi)).sum())
+    print(f"    {lo:8.0f} | {inb / (nwk * (hi - lo)) * 100:5.1f} | {inw / (nwk * (hi - lo)) * 100:5.1f} | {nu:5d} | {int((dends <= hi).sum()):3d}")
 busy = (end - ready).sum()
 waits = (ready - pop).sum()
 nw = len(set(worker))
