@@ -169,7 +169,7 @@ int okkt_profile_dominant(okkt_handle h, int enable);
 int okkt_get_profile(okkt_handle h, int64_t* n_launches, double* total_ms, double* total_flops);
 /* Test hook, host only (no device, no handle): the task queue of the dataflow launch (csrc/dataflow.hip) for one level of
  * nfronts big fronts of orders f[] with k[] pivot columns each, as it would be uploaded for `workers` workers, `group & 255` panels
- * and `(group >> 8) & 255` row tiles (0 = 1) per bulk update task; bit 16 of `group`: D(q + 1) rides in TU(q) (bit 1 of nq in its task); bit 17: a block row of more than 64 rows is split between TA(q) (type 4, its upper 64 rows) right before TU(q) (bit 2 of nq).  tasks receives 4 ints per task: front index, type | nq << 8 | rows << 16 (type 0 = D diagonal tile, 1 = T panel tile,
+ * and `(group >> 8) & 255` row tiles (0 = 1) per bulk update task; bit 16 of `group`: D(q + 1) rides in TU(q) (bit 1 of nq in its task); bit 17: a block row of more than 64 rows is split between TA(q) (type 4, its upper 64 rows) right before TU(q) (bit 2 of nq); bit 18: the panel tiles from panel 1 on carry the last update of their tile (type 5 = TL(i, q): U(i, q, q - 1, 1) then T(i, q); that update is not a task of its own).  tasks receives 4 ints per task: front index, type | nq << 8 | rows << 16 (type 0 = D diagonal tile, 1 = T panel tile,
  * 2 = U update of the tiles (i .. i + rows - 1, j), 3 = TU: panel tile (i, j) and the diagonal tile (i, i), i = j + 1), i | j << 16 (tile row / column; for T: j = the panel), q0 (first panel of an update).  Returns the number of
  * tasks (also when it exceeds cap; only cap tasks are written), or a negative error code.  tests/test_dataflow_queue.py replays
  * the queue on a dense matrix with numpy and checks the dependency order. */

@@ -245,7 +245,11 @@ int okkt_create(okkt_handle* out, const okkt_opts* opts) {
     const char* ela = getenv("OKKT_LOOKAHEAD");
     const char* ercu = getenv("OKKT_RESERVED_CUS");
     const int la = ela ? atoi(ela) : 1;
-    int reserved = ercu ? atoi(ercu) : 8;   // one per XCD: a lone workgroup always lands on XCD 0, several fronts spread
+    // 32 = one CU of every shader engine of every XCD (mask bit b = CU index b / 8 of XCD b % 8, CU index c in shader engine c % 4:
+    // scripts/cumask_map.hip).  The hardware deals workgroups to the shader engines round-robin and IN ORDER: with an uneven mask
+    // (round 4: 8 = one CU per XCD) the engine that lost a CU fills up first and the dispatch stalls behind it -- 460 of 496 workgroups
+    // resident in scripts/occ_probe.hip, as few as 393 in situ -- so reserving one CU per engine costs the masked stream nothing more
+    int reserved = ercu ? atoi(ercu) : 32;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, dev) != hipSuccess) { delete h; return OKKT_ERR_HIP; }
     const int ncu = prop.multiProcessorCount;
@@ -632,7 +636,7 @@ int64_t okkt_debug_dataflow_queue(int32_t nfronts, const int32_t* f, const int32
     }
     std::vector<okkt::DfTask> q;
     double model = 0;
-    okkt::df_build_queue(fronts, workers, group & 255, std::max(1, (group >> 8) & 255), (group >> 16) & 1, (group >> 17) & 1, q, &model);
+    okkt::df_build_queue(fronts, workers, group & 255, std::max(1, (group >> 8) & 255), (group >> 16) & 1, (group >> 17) & 1, q, &model, 0, 1.0f, (group >> 18) & 1);
     if (model_us) *model_us = model;
     for (int64_t t = 0; t < (int64_t)q.size() && t < cap; ++t) {
       tasks[4 * t] = q[t].front; tasks[4 * t + 1] = q[t].type_nq; tasks[4 * t + 2] = q[t].ij; tasks[4 * t + 3] = q[t].q0;
@@ -652,7 +656,7 @@ int64_t okkt_debug_dataflow_split(int32_t nfronts, const int32_t* f, const int32
     }
     std::vector<okkt::DfTask> q, chain, bulk[8];
     double model = 0;
-    okkt::df_build_queue(fronts, workers, group & 255, 1, (group >> 16) & 1, (group >> 17) & 1, q, &model, chain_workers, 1.7f);
+    okkt::df_build_queue(fronts, workers, group & 255, 1, (group >> 16) & 1, (group >> 17) & 1, q, &model, chain_workers, 1.7f, (group >> 18) & 1);
     okkt::df_split_queue(fronts, q, chain, bulk);
     int64_t t = 0;
     auto put = [&](const std::vector<okkt::DfTask>& v) {

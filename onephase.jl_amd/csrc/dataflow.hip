@@ -144,6 +144,168 @@ __device__ __forceinline__ void df_trsm_tile(const DevPlan& P, int s, int q, int
   }
 }
 
+// a wait inside a task (the diagonal block a TL task solves against): the worker's protocol -- wave 0 polls (bounded), acquires, the
+// workgroup meets.  false: the launch is stopping (delta loop) or a wait has run into its bound
+__device__ __forceinline__ bool df_await(const DevPlan& P, const int* state, int least, int* flag) {
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  if (wave == 0) {
+    int ok = 1, spins = 0;
+    for (;;) {
+      if (__builtin_amdgcn_readfirstlane(ld_state(state)) >= least) break;
+      const int stop = P.want_neg >= 0 ? __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&P.counters[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : 0;
+      const int dead = __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&P.counters[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      if (stop | dead) { ok = 0; break; }
+      if (++spins >= (1 << 21)) {
+        if ((threadIdx.x & 63) == 0) { atomicAdd(&P.counters[3], 1ull); atomicExch(&P.counters[5], 1ull); }
+        ok = 0;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    *flag = ok;
+  }
+  __syncthreads();
+  return __builtin_amdgcn_readfirstlane(*flag) != 0;
+}
+
+// ---- TL: the last update of tile (i, q) (panel q - 1) and T(i, q) in one task, q >= 1 ------------------------------------------------
+// A block row below the chain's advances one block column per chain step: T(i, q - 1) -> U(i, q; panel q - 1) -> T(i, q), two tasks and two
+// hand-offs (30 + 27 + 2 x 3 us) per 63-us step -- every row was as slow as the chain itself, any queueing made it slower, and the chain
+// waits for the rows that enter its cone: the root of the metric workload ran at 87 - 94 us per block column while updates were
+// plentiful.  Here the update runs in the panel solve's own register layout (a wave owns 16 rows x 128 columns: the 16 x 4 strips are
+// the accumulators, W(i, q - 1) in the same layout is the B operand, L(q, q - 1) staged in LDS the A operand: 1024 MFMAs per wave) and
+// BEFORE D(q) has arrived -- the task is popped when its tile has received panel q - 2 and block rows i and q of panel q - 1 are there,
+// waits for D(q) inside like TU, stages the diagonal block's pieces over the L image and solves.  The products reach every entry in
+// ascending panel order, k ascending within the panel, as in the update task: bitwise the same tile, then df_trsm_tile's solve.
+// W and L leave through LDS as 16-byte write-through stores (the 8-byte ones of df_trsm_tile cost 9 us per tile).
+constexpr int kTlLd = 132;           // leading dimension of the L(q, q - 1) image: the four k-slices of an A fragment on disjoint banks
+constexpr size_t kDfTlLds = std::max((size_t)128 * kTlLd * sizeof(double), (size_t)(128 * kSyrkLd + 128) * sizeof(double));
+__device__ __forceinline__ bool df_tl_tile(const DevPlan& P, int s, int q, int r0, int rlim, const int* dstate, int* s_flag, double* sm, long long* marks) {
+  constexpr int NBLK = 4, NB = 128, NPAIR = NBLK * (NBLK + 1) / 2;
+  int tid_ = threadIdx.x;
+  asm volatile("" : "+v"(tid_));
+  const int tid = tid_, lane = tid & 63, wv = tid >> 6;
+  const int col0 = P.sn_col0[s];
+  const int k = P.sn_col0[s + 1] - col0;
+  const int f = (int)(P.row_ptr[s + 1] - P.row_ptr[s]);
+  const int j0 = q * NB;
+  const int nb = min(NB, k - j0);
+  double* F = P.arena + P.front_pos[s];
+  double* Wb = P.wbuf + P.wbuf_pos[s] + (size_t)j0 * f;
+  const double* Wprev = Wb - (size_t)NB * f;              // W of panel q - 1 (a whole block column)
+  const double* X = P.invl + P.invl_pos[s] + (size_t)q * NB * NB;
+  const int trow = wv * 16 + (lane & 15);
+  const int row = r0 + trow;
+  const int rowc = min(row, f - 1);
+  const bool valid = row < rlim;
+  const int lk = lane >> 4, li = lane & 3;
+  double t[NBLK * 8], w[NBLK * 8];
+#pragma unroll
+  for (int qq = 0; qq < NBLK * 8; ++qq) {
+    const int c = 4 * qq + lk;
+    t[qq] = keep_f64(F[(size_t)(j0 + min(c, nb - 1)) * f + rowc], c < nb && valid);
+    w[qq] = keep_f64(Wprev[(size_t)c * f + rowc], valid);
+  }
+  // L(q, q - 1): rows [j0, j0 + nb) of panel q - 1, entry (c, kk) at c + kk * kTlLd
+  {
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+      const int idx = it * kDfThreadsC + tid;
+      const int kk = idx >> 6, c2 = (idx & 63) * 2;
+      const double* src = F + (size_t)(j0 - NB + kk) * f + j0;
+      d2_t v;
+      v[0] = keep_f64(src[min(c2, nb - 1)], c2 < nb);
+      v[1] = keep_f64(src[min(c2 + 1, nb - 1)], c2 + 1 < nb);
+      __builtin_memcpy(sm + (size_t)kk * kTlLd + c2, &v, 16);
+    }
+  }
+  __syncthreads();
+  if (marks && tid == 0) marks[0] = wall_clock64();        // operands in registers and LDS
+  // t(rows, c) -= sum_kk W(rows, kk) L(c, kk): k-strips ascending, the order of the update task's k-steps
+  // (fully unrolled: a rolled loop over g indexes w[] dynamically, which puts the array into scratch memory -- a scratch load and a
+  // vmcnt(0) per 64 MFMAs)
+#pragma unroll
+  for (int g = 0; g < NBLK * 8; ++g) {
+#pragma unroll
+    for (int gp = 0; gp < NBLK * 8; ++gp)
+      t[gp] = __builtin_amdgcn_mfma_f64_4x4x4f64(sm[(gp * 4 + li) + (size_t)(g * 4 + lk) * kTlLd], w[g], t[gp], 0, 0, 1 /* neg A */);
+  }
+  if (marks && tid == 0) marks[1] = wall_clock64();        // tile updated
+  if (!df_await(P, dstate, q + 1, s_flag)) return false;   // D(q); the barrier inside: every wave is done with the L image
+  if (marks && tid == 0) marks[2] = wall_clock64();        // D(q) has arrived
+  double* rdv = sm + NPAIR * kIB * kIB;
+  {
+    const int e = tid * 2;
+    const int cc = e / kIB, rr = e - cc * kIB;
+#pragma unroll
+    for (int bi = 0; bi < NBLK; ++bi)
+#pragma unroll
+      for (int bp = 0; bp <= bi; ++bp) {
+        double v[2];
+        const int gr = bi * kIB + rr, gc = bp * kIB + cc;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const double* src = bp == bi ? X + (gr + u) + (size_t)gc * NB
+                                       : F + (size_t)(j0 + min(gc, nb - 1)) * f + j0 + min(gr + u, nb - 1);
+          v[u] = keep_f64(*src, gr + u < nb && gc < nb);
+        }
+        double* dst = sm + (bi * (bi + 1) / 2 + bp) * kIB * kIB + e;
+        dst[0] = v[0]; dst[1] = v[1];
+      }
+    if (tid < NB) rdv[tid] = tid < nb ? 1.0 / P.dvals[col0 + j0 + tid] : 0.0;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int bi = 0; bi < NBLK; ++bi) {
+#pragma unroll
+    for (int bp = 0; bp < bi; ++bp) {
+      const double* Lb = sm + (bi * (bi + 1) / 2 + bp) * kIB * kIB;
+#pragma unroll
+      for (int gp = 0; gp < 8; ++gp)
+#pragma unroll
+        for (int g = 0; g < 8; ++g)
+          t[bi * 8 + gp] = __builtin_amdgcn_mfma_f64_4x4x4f64(Lb[(gp * 4 + li) + (g * 4 + lk) * kIB], t[bp * 8 + g], t[bi * 8 + gp], 0, 0, 1 /* neg A */);
+    }
+    const double* Xb = sm + (bi * (bi + 1) / 2 + bi) * kIB * kIB;
+    double wt[8];
+#pragma unroll
+    for (int gp = 0; gp < 8; ++gp) {
+      wt[gp] = 0.0;
+#pragma unroll
+      for (int g = 0; g <= gp; ++g)   // X_ii is lower triangular
+        wt[gp] = __builtin_amdgcn_mfma_f64_4x4x4f64(Xb[(gp * 4 + li) + (g * 4 + lk) * kIB], t[bi * 8 + g], wt[gp], 0, 0, 0);
+    }
+#pragma unroll
+    for (int gp = 0; gp < 8; ++gp) t[bi * 8 + gp] = wt[gp];
+  }
+  const double myrd = tid < NB ? rdv[tid] : 0.0;
+  __syncthreads();                       // every wave is done with the staged blocks and the reciprocals
+  double* Wl = sm;                       // [128 panel columns][kSyrkLd]: W(r0 + r, j0 + p) at p * kSyrkLd + r
+  double* rd2 = sm + (size_t)128 * kSyrkLd;
+#pragma unroll
+  for (int qq = 0; qq < NBLK * 8; ++qq) Wl[(size_t)(4 * qq + lk) * kSyrkLd + trow] = t[qq];      // rows past the block are zero
+  if (tid < NB) rd2[tid] = myrd;
+  __syncthreads();
+  if (marks && tid == 0) marks[3] = wall_clock64();        // solved, W in LDS
+  {
+    const int nrow = min(rlim - r0, 128);
+    for (int idx = tid; idx < (nb << 6); idx += kDfThreadsC) {
+      const int p = idx >> 6, x2 = (idx & 63) * 2;
+      d2_t wv2;
+      __builtin_memcpy(&wv2, Wl + (size_t)p * kSyrkLd + x2, 16);
+      const double rp = rd2[p];
+      const d2_t l = (d2_t){wv2[0] * rp, wv2[1] * rp};
+      double* wdst = Wb + (size_t)p * f + r0 + x2;
+      double* ldst = F + (size_t)(j0 + p) * f + r0 + x2;
+      if (x2 + 1 < nrow) { st_sc1_f64x2(wdst, wv2); st_sc1_f64x2(ldst, l); }
+      else if (x2 < nrow) { st_agent_f64(wdst, wv2[0]); st_agent_f64(ldst, l[0]); }
+    }
+  }
+  return true;
+}
+
 // ---- TU: T(q + 1, q) and the update of the diagonal tile (q + 1, q + 1) by panel q in one task -------------------------------
 // The two steps between the diagonal blocks of consecutive block columns.  The task is popped beside D(q): the rows of tile
 // (q + 1, q) and the diagonal tile are in flight while D(q) runs; then the task waits for D(q) (second wait, same protocol as the
@@ -888,12 +1050,17 @@ __global__ __launch_bounds__(kDfThreadsC, 4) void k_front_bulk(DevPlan P, const 
     const int k = P.sn_col0[s + 1] - P.sn_col0[s];
     const int f = (int)(P.row_ptr[s + 1] - P.row_ptr[s]);
     const int KB = (k + 127) >> 7;
+    // a panel tile or a single-panel update is a link of its block row's chain (one block column per chain step): its waves take the CU's
+    // issue slots ahead of the partner workgroup's K = 512 update, which has the slack
+    const bool urgent = (dbg & 64) == 0 && (type == kDfT || nq == 1);
+    if (urgent) __builtin_amdgcn_s_setprio(3);
     if (type == kDfT) {
       if (!(dbg & 2)) df_trsm_tile_packed(P, s, j, df_block_lo(i, KB, k, f), df_block_lo(i + 1, KB, k, f), sm);
     } else {
       const int j0 = q0 * 128;
       if (!(dbg & 4)) df_syrk_tiles<kBulkKC, kBulkStages, false, false>(P, s, j0, min(nq * 128, k - j0), i, 1, j, KB, k, sm, tlog ? tlog + (size_t)gt * 8 + 4 : nullptr);
     }
+    if (urgent) __builtin_amdgcn_s_setprio(0);
     // the next task is looked for now: the scan's round trips run beside the drain of this task's stores (wave 0's own loads come back
     // behind its stores).  What this task enables is not ready yet in that scan -- another worker takes it.
     if (wave == 0) gt_next = bulk_claim(P, deps, qinfo, claim, xcc, s_cur, tid & 63, &mine_next, &newv_next, false, (dbg & 32) != 0);
@@ -905,7 +1072,7 @@ __global__ __launch_bounds__(kDfThreadsC, 4) void k_front_bulk(DevPlan P, const 
 }
 
 constexpr int kDfThreads = kDfThreadsC;
-constexpr size_t kDfLds = std::max(std::max(OKKT_DIAG2_LDS_DOUBLES(kMW) * sizeof(double), kDfTuLds), (size_t)kDfStages * 2 * kDfKC * kSyrkLd * sizeof(double));   // diag2_body's and df_tu_tile's; the other roles need less
+constexpr size_t kDfLds = std::max(std::max(std::max(OKKT_DIAG2_LDS_DOUBLES(kMW) * sizeof(double), kDfTuLds), (size_t)kDfStages * 2 * kDfKC * kSyrkLd * sizeof(double)), kDfTlLds);   // diag2_body's and df_tu_tile's; the other roles need less
 
 // counters[5] = a wait ran into its bound (or another worker's did): every worker leaves, the factorisation reports a wrong
 // inertia ("pivot counts do not add up") and the solves return NaN -- never numbers computed from tiles that had not arrived
@@ -947,11 +1114,15 @@ __global__ __launch_bounds__(kDfThreads, 1) void k_front_dataflow(DevPlan P, con
         const int ln = tid & 63;
         const int* addr = st;
         int need = -(1 << 30);
-        if (asm_flags && j == 0 && type != kDfT && type != kDfU && ln == 3) { addr = asm_flags + s; need = epoch; }
+        if (asm_flags && j == 0 && type != kDfT && type != kDfU && type != kDfTL && ln == 3) { addr = asm_flags + s; need = epoch; }
         if (type == kDfD) { if (ln == 0) { addr = st + (size_t)i * TB + i; need = i; } }
         else if (type == kDfT) {
           if (ln == 0) { addr = st + (size_t)j * TB + j; need = j + 1; }
           if (ln == 1) { addr = st + (size_t)i * TB + j; need = j; }
+        } else if (type == kDfTL) {      // tile (i, q) with panel q - 2 applied, block rows i and q of panel q - 1; D(q) is awaited inside the task
+          if (ln == 0) { addr = st + (size_t)i * TB + j; need = j - 1; }
+          if (ln == 1) { addr = st + (size_t)i * TB + (j - 1); need = j; }
+          if (ln == 2) { addr = st + (size_t)j * TB + (j - 1); need = j; }
         } else if (type == kDfTU || type == kDfTA) {      // the tiles (q + 1, q) and (q + 1, q + 1), q = j; D(q) is awaited inside the task
           if (ln == 0) { addr = st + (size_t)i * TB + j; need = j; }
           if (ln == 1) { addr = st + (size_t)i * TB + i; need = j; }
@@ -1003,6 +1174,9 @@ __global__ __launch_bounds__(kDfThreads, 1) void k_front_dataflow(DevPlan P, con
       mine = st + (size_t)i * TB + i; newv = i + 1;
     } else if (type == kDfT) {
       if (!(dbg & 2)) df_trsm_tile(P, s, j, df_block_lo(i, KB, k, f), df_block_lo(i + 1, KB, k, f), sm);
+      mine = st + (size_t)i * TB + j; newv = j + 1;
+    } else if (type == kDfTL) {
+      if (!df_tl_tile(P, s, j, df_block_lo(i, KB, k, f), df_block_lo(i + 1, KB, k, f), st + (size_t)j * TB + j, &s_ctl[2], sm, tlog ? tlog + (size_t)t * 8 + 4 : nullptr)) return;
       mine = st + (size_t)i * TB + j; newv = j + 1;
     } else if (type == kDfTU || type == kDfTA) {
       // nq & 2: D(q + 1) is part of the task (the updated diagonal tile reaches it through LDS); nq & 4: the lower half of a split block
@@ -1060,6 +1234,7 @@ std::string df_setup(Numeric& N) {
   N.df_group = getenv("OKKT_DF_GROUP") ? std::max(1, std::min(atoi(getenv("OKKT_DF_GROUP")), 16)) : 4;
   N.df_fuse_d = getenv("OKKT_DF_FUSE_D") ? atoi(getenv("OKKT_DF_FUSE_D")) : 1;
   N.df_split_tu = getenv("OKKT_DF_SPLIT_TU") ? atoi(getenv("OKKT_DF_SPLIT_TU")) : 1;
+  N.df_fuse_tl = getenv("OKKT_DF_FUSE_TL") ? atoi(getenv("OKKT_DF_FUSE_TL")) : 1;
   N.df_rows = getenv("OKKT_DF_ROWS") ? std::max(1, std::min(atoi(getenv("OKKT_DF_ROWS")), 8)) : 1;
   // the two-kernel form needs the CU-masked stream pair of the handle (bulk kernel on every CU but the reserved ones, chain kernel on those)
   N.df_split_fronts = getenv("OKKT_DF_SPLIT_FRONTS") ? atoi(getenv("OKKT_DF_SPLIT_FRONTS")) : 0;
@@ -1093,9 +1268,9 @@ std::string df_setup(Numeric& N) {
       }
       double model = 0;
       const bool split = N.df_split_fronts > 0 && g.cnt <= N.df_split_fronts;
-      if (split) df_build_queue(fronts, N.df_bulk_workers, N.df_group, 1, N.df_fuse_d != 0, N.df_split_tu != 0, q, &model, N.df_chain_workers, split_mul);
+      if (split) df_build_queue(fronts, N.df_bulk_workers, N.df_group, 1, N.df_fuse_d != 0, N.df_split_tu != 0, q, &model, N.df_chain_workers, split_mul, N.df_fuse_tl != 0);
       if (!split || (int)q.size() < split_min_tasks) {
-        df_build_queue(fronts, N.df_workers, N.df_group, N.df_rows, N.df_fuse_d != 0, N.df_split_tu != 0, q, &model);
+        df_build_queue(fronts, N.df_workers, N.df_group, N.df_rows, N.df_fuse_d != 0, N.df_split_tu != 0, q, &model, 0, 1.0f, N.df_fuse_tl != 0);
         g.df_split = 0;
       } else g.df_split = 1;
       g.df_off = (int64_t)all.size();

@@ -9,6 +9,10 @@
 //   U(i, j, q0, nq)  A(i, j) -= sum_{q0 <= q < q0 + nq} W(i, q) L(j, q)^T             after T(i, q), T(j, q) and the previous update of (i, j)
 //   TU(q)            T(q + 1, q) and U(q + 1, q + 1, q, 1) in one task (q + 1 < KB): the two steps between the diagonal blocks of
 //                    consecutive block columns -- the critical path -- without a hand-off and without a trip through memory
+//   TL(i, q)         (fuse_tl) T(i, q) with the LAST update of its tile, U(i, q, q - 1, 1), inside the task, for every block row below TU's and
+//                    q >= 1: the row's per-column chain T -> single-panel update -> T (two tasks and two hand-offs per block column: as
+//                    long as the 63 us between two diagonal blocks, so every row held the chain back) becomes one task whose update runs
+//                    BEFORE D(q) has arrived (released when D(q) starts, like TU)
 //   TA(q)            the upper 64 rows of TU(q)'s block row, when it has more than 64 (split_tu): both steps run at the FP64 matrix rate
 //                    of one CU, two workers halve them.  Emitted right before TU(q), which waits for TA's two states inside the task
 // A tile receives the panels in ascending order (the same sequence of operations per entry as the per-step kernels: bitwise the
@@ -69,12 +73,12 @@ struct FrontGrid {
 }  // namespace
 
 int df_near_rows() {
-  static const int near = getenv("OKKT_DF_NEAR") ? atoi(getenv("OKKT_DF_NEAR")) : 2;
+  static const int near = getenv("OKKT_DF_NEAR") ? atoi(getenv("OKKT_DF_NEAR")) : 6;
   return near;
 }
 
 void df_build_queue(const std::vector<DfFront>& fronts, int workers, int group, int rows_per_task, bool fuse_d, bool split_tu, std::vector<DfTask>& out, double* model_us,
-                    int chain_workers, float bulk_mul) {
+                    int chain_workers, float bulk_mul, bool fuse_tl) {
   const int near = chain_workers > 0 ? df_near_rows() : 0;
   const int G = std::max(1, group);
   const int RT = std::max(1, std::min(rows_per_task, 8));
@@ -87,7 +91,7 @@ void df_build_queue(const std::vector<DfFront>& fronts, int workers, int group, 
   static const float bulk_env = getenv("OKKT_DF_MODEL_BULK") ? (float)atof(getenv("OKKT_DF_MODEL_BULK")) : 1.0f;
   const float bulk_scale = bulk_env * bulk_mul;
   std::vector<FrontGrid> grids(fronts.size());
-  struct Node { int front; int type; int i, j, q0, nq; int ndep; float dur; int64_t key; int rows; };
+  struct Node { int front; int type; int i, j, q0, nq; int ndep; float dur; int64_t key; int rows; int64_t fwd; };      // type -1: a placeholder (an update that runs inside the task `fwd`)
   std::vector<Node> nodes;
   for (size_t a = 0; a < fronts.size(); ++a) {
     FrontGrid& g = grids[a];
@@ -115,18 +119,21 @@ void df_build_queue(const std::vector<DfFront>& fronts, int workers, int group, 
     g.offD = (int64_t)nodes.size();
     for (int q = 0; q < KB; ++q) {
       const int nb = std::min(128, g.k - 128 * q);
-      nodes.push_back({(int)a, kDfD, q, q, q, 1, q > 0 ? 1 : 0, chain_scale * (5.0f + 2.3f * (float)((nb + 7) / 8)), key(q, 0, q, q), 1});
+      nodes.push_back({(int)a, kDfD, q, q, q, 1, q > 0 ? 1 : 0, chain_scale * (5.0f + 2.3f * (float)((nb + 7) / 8)), key(q, 0, q, q), 1, -1});
     }
     g.offTU = (int64_t)nodes.size();
     for (int q = 0; q + 1 < KB; ++q)     // needs D(q) [released when D(q) STARTS], the updates of (q + 1, q) and the earlier updates of (q + 1, q + 1)
-      nodes.push_back({(int)a, kDfTU, q + 1, q, q, 1, 1 + (q > 0 ? 2 : 0), 0.0f, key(q, 1, q + 1, q), 1});
+      nodes.push_back({(int)a, kDfTU, q + 1, q, q, 1, 1 + (q > 0 ? 2 : 0), 0.0f, key(q, 1, q + 1, q), 1, -1});
     g.offT = (int64_t)nodes.size();
     g.tq.assign(KB + 1, 0);
     for (int q = 0; q < KB; ++q) {
       const int first = q + 1 < KB ? q + 2 : q + 1;             // block row q + 1 belongs to TU(q)
       g.tq[q + 1] = g.tq[q] + std::max(TB - first, 0);
+      // fuse_tl: from panel 1 on the panel tile carries the last update of its tile (TL): it waits for that update's operands (the
+      // placeholder below forwards them) and for the START of D(q)
+      // (two-kernel form: only the rows near the chain -- the bulk kernel has no TL body, and the far rows have the slack for two tasks)
       for (int i = first; i < TB; ++i)
-        nodes.push_back({(int)a, kDfT, i, q, q, 1, 1 + (q > 0 ? 1 : 0), (near_chain_task(kDfT, i, q, q, 1, KB, near) ? bulk_env : bulk_scale) * 28.0f, key(q, 2, i, q), 1});
+        nodes.push_back({(int)a, (fuse_tl && q > 0 && (chain_workers <= 0 || i - q <= near + 1)) ? kDfTL : kDfT, i, q, q, 1, 1 + (q > 0 ? 1 : 0), (near_chain_task(kDfT, i, q, q, 1, KB, near) ? bulk_env : bulk_scale) * 28.0f, key(q, 2, i, q), 1, -1});
     }
     // Update tasks.  The groups of a column that are not the lone last panel of a pivot column are bulk work: the tiles below the
     // diagonal tile are taken `rows_per_task` at a time (one pop, one wait, one acquire and one drain per task, and the C tile of
@@ -144,10 +151,12 @@ void df_build_queue(const std::vector<DfFront>& fronts, int workers, int group, 
         for (int i = j; i < TB;) {
           const int rows = i == j ? 1 : std::min(R, TB - i);
           const bool in_tu = i == j && lone_last;                  // the last panel of a diagonal pivot tile: part of TU(j - 1)
+          const bool in_tl = fuse_tl && lone_last && i > j && !(i == j + 1 && j + 1 < KB) && (chain_workers <= 0 || i - j <= near + 1);      // ... of a tile below the TU row: part of TL(i, j)
           const int ndep = (i != j ? rows + 1 : 1) + (c > 0 ? 1 : 0);
           for (int r = 0; r < rows; ++r) g.unode[j][c][i + r] = (int64_t)nodes.size();
-          nodes.push_back({(int)a, in_tu ? -1 : kDfU, i, j, q0, nq, ndep,
-                           (near_chain_task(kDfU, i, j, q0, nq, KB, near) ? bulk_env : bulk_scale) * (6.0f + 0.16f * 128.0f * (float)nq * (float)rows + 4.0f * (float)(rows - 1)), key(j, 3, i, q0), rows});
+          nodes.push_back({(int)a, in_tu ? -1 : (in_tl ? -2 : kDfU), i, j, q0, nq, ndep,
+                           (near_chain_task(kDfU, i, j, q0, nq, KB, near) ? bulk_env : bulk_scale) * (6.0f + 0.16f * 128.0f * (float)nq * (float)rows + 4.0f * (float)(rows - 1)), key(j, 3, i, q0), rows,
+                           in_tl ? g.offT + g.tq[j] + (i - (j + 1 < KB ? j + 2 : j + 1)) : -1});      // in_tl (type -2): once its operands are there it releases TL(i, j)
           i += rows;
         }
       }
@@ -166,14 +175,20 @@ void df_build_queue(const std::vector<DfFront>& fronts, int workers, int group, 
   std::priority_queue<TI, std::vector<TI>, std::greater<TI>> running;
   auto pool_of = [&](const Node& nd) {
     if (chain_workers <= 0) return 0;
-    return (nd.type == kDfD || nd.type == kDfTU || near_chain_task(nd.type, nd.i, nd.j, nd.q0, nd.nq, grids[nd.front].KB, near)) ? 1 : 0;
+    return (nd.type == kDfD || nd.type == kDfTU || nd.type == kDfTL || near_chain_task(nd.type, nd.i, nd.j, nd.q0, nd.nq, grids[nd.front].KB, near)) ? 1 : 0;
   };
   for (int64_t x = 0; x < (int64_t)nodes.size(); ++x) if (nodes[x].type >= 0 && nodes[x].ndep == 0) ready_pool[pool_of(nodes[x])].push({nodes[x].key, x});
   out.clear();
   out.reserve(nodes.size());
   double now = 0;
   int idle_pool[2] = {std::max(1, workers), std::max(0, chain_workers)};
-  auto release = [&](int64_t x) { if (--nodes[x].ndep == 0) ready_pool[pool_of(nodes[x])].push({nodes[x].key, x}); };
+  std::function<void(int64_t)> release = [&](int64_t x) {
+    if (--nodes[x].ndep != 0) return;
+    if (nodes[x].type == -2) release(nodes[x].fwd);      // an update inside TL: its operands are what the task waits for
+    else ready_pool[pool_of(nodes[x])].push({nodes[x].key, x});
+  };
+  std::vector<std::vector<double>> dend(fronts.size());      // [front][q]: end of D(q) in the model (TL tasks start before it)
+  for (size_t a = 0; a < fronts.size(); ++a) dend[a].assign(grids[a].KB, 0.0);
   auto any_ready = [&]() { return !ready_pool[0].empty() || !ready_pool[1].empty(); };
   while (any_ready() || !running.empty()) {
     for (;;) {
@@ -198,12 +213,25 @@ void df_build_queue(const std::vector<DfFront>& fronts, int workers, int group, 
         out.push_back({fronts[nd.front].s, kDfTU | (((fuse_d ? 2 : 1) | (split ? 4 : 0)) << 8) | (nd.rows << 16), nd.i | (nd.j << 16), nd.q0});
       } else if (!(fuse_d && nd.type == kDfD && nd.i > 0))
         out.push_back({fronts[nd.front].s, nd.type | (nd.nq << 8) | (nd.rows << 16), nd.i | (nd.j << 16), nd.q0});
+      if (nd.type == kDfTL)      // the update (14 us) runs ahead of D(q); the solve, the stores and the hand-off behind it
+        nd.dur = (float)(std::max(now + 14.0 * bulk_env, dend[nd.front][nd.j]) + 22.0 * bulk_env - now);
       running.push({now + nd.dur, x});
       --idle;
-      if (nd.type == kDfD && nd.i + 1 < grids[nd.front].KB) {      // TU(q) starts beside D(q) and ends 24 us behind it
-        const int64_t tu = grids[nd.front].offTU + nd.i;
-        nodes[tu].dur = nd.dur + chain_scale * 40.0f;
-        release(tu);
+      if (nd.type == kDfD) {
+        dend[nd.front][nd.i] = now + nd.dur;
+        if (nd.i + 1 < grids[nd.front].KB) {      // TU(q) starts beside D(q) and ends 24 us behind it
+          const int64_t tu = grids[nd.front].offTU + nd.i;
+          nodes[tu].dur = nd.dur + chain_scale * 40.0f;
+          release(tu);
+        }
+        if (fuse_tl && nd.i > 0) {                // ... and so do the TL tasks of the block rows below
+          const FrontGrid& gg = grids[nd.front];
+          const int q = nd.i;
+          for (int i = (q + 1 < gg.KB ? q + 2 : q + 1); i < gg.TB; ++i) {
+            const int64_t x2 = gg.offT + gg.tq[q] + (i - (q + 1 < gg.KB ? q + 2 : q + 1));
+            if (nodes[x2].type == kDfTL) release(x2);
+          }
+        }
       }
     }
     if (running.empty()) break;
@@ -216,8 +244,9 @@ void df_build_queue(const std::vector<DfFront>& fronts, int workers, int group, 
     const int KB = g.KB, TB = g.TB;
     if (nd.type == kDfD) {
       const int q = nd.i;
-      for (int i = (q + 1 < KB ? q + 2 : q + 1); i < TB; ++i) release(t_index(g, i, q));
-    } else if (nd.type == kDfT || nd.type == kDfTU) {
+      for (int i = (q + 1 < KB ? q + 2 : q + 1); i < TB; ++i)
+        if (nodes[t_index(g, i, q)].type != kDfTL) release(t_index(g, i, q));      // (the TL tasks were released when D(q) started)
+    } else if (nd.type == kDfT || nd.type == kDfTU || nd.type == kDfTL) {
       // block row i of panel q is done: the update groups whose LAST panel is q and that read block row i as the row operand
       // (tiles (i, j), q < j <= i) or as the column operand (tiles (i2, i), i2 > i: once per task)
       const int i = nd.i, q = nd.j;
@@ -246,7 +275,7 @@ void df_build_queue(const std::vector<DfFront>& fronts, int workers, int group, 
           const int64_t x2 = g.unode[j][c + 1][nd.i + r];
           if (x2 == last) continue;
           last = x2;
-          if (nodes[x2].type >= 0) release(x2); else release(g.offTU + (j - 1));      // ... the one inside TU(j - 1)
+          if (nodes[x2].type != -1) release(x2); else release(g.offTU + (j - 1));      // ... the one inside TU(j - 1)
         }
       } else if (j < KB) {
         for (int r = 0; r < nd.rows; ++r) release(nd.i + r == j ? g.offD + j : t_index(g, nd.i + r, j));
@@ -272,7 +301,7 @@ void df_split_queue(const std::vector<DfFront>& fronts, const std::vector<DfTask
   std::sort(byfront.begin(), byfront.end());
   for (const DfTask& t : q) {
     const int type = t.type_nq & 255;
-    if (type == kDfD || type == kDfTU || type == kDfTA) { chain.push_back(t); continue; }
+    if (type == kDfD || type == kDfTU || type == kDfTA || type == kDfTL) { chain.push_back(t); continue; }
     const auto it = std::lower_bound(byfront.begin(), byfront.end(), std::make_pair(t.front, -1));
     const int a = it->second;
     const int f = fronts[a].f, k = fronts[a].k;

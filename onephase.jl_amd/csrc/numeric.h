@@ -86,7 +86,7 @@ struct DevPlan {
 };
 
 // one task of the dataflow factorisation (dataflow_sched.cpp builds the queues, dataflow.hip runs them)
-enum { kDfD = 0, kDfT = 1, kDfU = 2, kDfTU = 3, kDfTA = 4 };
+enum { kDfD = 0, kDfT = 1, kDfU = 2, kDfTU = 3, kDfTA = 4, kDfTL = 5 };
 struct DfTask { int front; int type_nq; int ij; int q0; };     // type | nq << 8 | rows << 16 (update tasks: tiles (i .. i + rows - 1, j)), i | j << 16
 struct DfFront { int s, f, k; };
 // what a bulk task of the two-kernel form waits for and publishes: three (index into the tile states, least value) pairs, then the index and
@@ -97,7 +97,7 @@ struct DfDep { int a0, n0, a1, n1, a2, n2, mine, newv; };
 // chain_workers > 0: the model of the two-kernel form -- D / TU run on a pool of their own, the panel tiles and updates on `workers`
 // bulk workers whose task durations are scaled by bulk_mul (two workgroups share a CU's matrix pipes)
 void df_build_queue(const std::vector<DfFront>& fronts, int workers, int group, int rows_per_task, bool fuse_d, bool split_tu, std::vector<DfTask>& out, double* model_us,
-                    int chain_workers = 0, float bulk_mul = 1.0f);
+                    int chain_workers = 0, float bulk_mul = 1.0f, bool fuse_tl = false);
 // the queue cut into the chain kernel's queue (D, TA, TU) and one queue of panel tiles and updates per XCD, each in the order of `q`
 void df_split_queue(const std::vector<DfFront>& fronts, const std::vector<DfTask>& q, std::vector<DfTask>& chain, std::vector<DfTask> bulk[8]);
 
@@ -198,6 +198,7 @@ struct Numeric {
   int df_group = 4;                    // panels per update task (K = 128 * group) where the column allows it (OKKT_DF_GROUP; S-metric 19.1 / 18.3 / 18.2 ms at 2 / 3 / 4)
   int df_fuse_d = 1;                   // D(q + 1) in the task of TU(q): the diagonal tile passes through LDS (OKKT_DF_FUSE_D=0: a task of its own)
   int df_split_tu = 1;                 // block rows of more than 64 rows: TU(q) as two tasks on two workers, TA(q) (upper 64 rows) and TU(q) (OKKT_DF_SPLIT_TU=0: one)
+  int df_fuse_tl = 1;                  // T(i, q) with the last update of its tile inside the task (TL), q >= 1 (OKKT_DF_FUSE_TL=0: separate tasks)
   int df_rows = 1;                     // row tiles per bulk update task (OKKT_DF_ROWS; 2 and 4 measured slower: the coarser tasks cost the schedule more than the shared prologue saves)
   int df_workers = 256;                // workers of the simulated schedule (and the grid of the launch): one workgroup per CU
   int df_split_fronts = 0;             // levels of at most this many big fronts run in the two-kernel form (OKKT_DF_SPLIT_FRONTS; 0: never)

@@ -51,8 +51,8 @@ ready = (ready - t0) / 100.0
 end = (end - t0) / 100.0
 span = end.max()
 print(f"launch {which}: {len(L)} tasks, {len(set(worker))} workers, span {span:.1f} us")
-names = {0: "D", 1: "T", 2: "U", 3: "TU", 4: "TA"}
-for k in (0, 1, 2, 3, 4):
+names = {0: "D", 1: "T", 2: "U", 3: "TU", 4: "TA", 5: "TL"}
+for k in (0, 1, 2, 3, 4, 5):
     m = typ == k
     if not m.any():
         continue

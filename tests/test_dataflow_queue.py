@@ -11,16 +11,16 @@ import pytest
 
 from onephase_jl_amd import _lib
 
-D, T, U, TU, TA = 0, 1, 2, 3, 4
+D, T, U, TU, TA, TL = 0, 1, 2, 3, 4, 5
 
 
-def build_queue(fronts, workers=256, group=2, rows=1, fuse_d=False, split=False):
+def build_queue(fronts, workers=256, group=2, rows=1, fuse_d=False, split=False, fuse_tl=False):
     lib = _lib.load()
     n = len(fronts)
     f = (C.c_int32 * n)(*[a for a, _ in fronts])
     k = (C.c_int32 * n)(*[b for _, b in fronts])
     model = C.c_double(0)
-    group = group | (rows << 8) | ((1 if fuse_d else 0) << 16) | ((1 if split else 0) << 17)
+    group = group | (rows << 8) | ((1 if fuse_d else 0) << 16) | ((1 if split else 0) << 17) | ((1 if fuse_tl else 0) << 18)
     cnt = lib.okkt_debug_dataflow_queue(n, f, k, workers, group, None, 0, C.byref(model))
     assert cnt >= 0
     buf = (C.c_int32 * (4 * max(cnt, 1)))()
@@ -30,13 +30,13 @@ def build_queue(fronts, workers=256, group=2, rows=1, fuse_d=False, split=False)
     return tasks, model.value
 
 
-def build_split(fronts, workers=496, chain_workers=8, group=4, fuse_d=True, split=True):
+def build_split(fronts, workers=496, chain_workers=8, group=4, fuse_d=True, split=True, fuse_tl=False):
     lib = _lib.load()
     n = len(fronts)
     f = (C.c_int32 * n)(*[a for a, _ in fronts])
     k = (C.c_int32 * n)(*[b for _, b in fronts])
     qlen = (C.c_int32 * 9)()
-    g = group | ((1 if fuse_d else 0) << 16) | ((1 if split else 0) << 17)
+    g = group | ((1 if fuse_d else 0) << 16) | ((1 if split else 0) << 17) | ((1 if fuse_tl else 0) << 18)
     cnt = lib.okkt_debug_dataflow_split(n, f, k, workers, chain_workers, g, None, 0, qlen)
     assert cnt >= 0
     buf = (C.c_int32 * (4 * max(cnt, 1)))()
@@ -72,7 +72,7 @@ def dense_partial_ldlt(A, k):
     return A
 
 
-def replay(fronts, tasks, group, fused=False, split=False, queues=None, policy=0):
+def replay(fronts, tasks, group, fused=False, split=False, queues=None, policy=0, fuse_tl=False):
     rng = np.random.default_rng(7)
     halves = set()
     mats, refs, states, Ws, grids = [], [], [], [], []
@@ -94,6 +94,8 @@ def replay(fronts, tasks, group, fused=False, split=False, queues=None, policy=0
             return st[i0, i0] >= i0
         if typ == T:
             return st[j, j] >= j + 1 and st[i0, j] >= j
+        if typ == TL:      # popped on the update's operands; D(q) is awaited inside the task
+            return st[i0, j] >= j - 1 and st[i0, j - 1] >= j and st[j, j - 1] >= j and st[j, j] >= j + 1
         if typ in (TU, TA):
             if typ == TU and (nq & 4) and (a, j) not in halves:
                 return False
@@ -134,8 +136,13 @@ def replay(fronts, tasks, group, fused=False, split=False, queues=None, policy=0
               A[ra, cq] = Wt / d
               A[ra, ra] -= np.tril(W[ra, cq] @ A[ra, cq].T)
               halves.add((a, q))
-          elif typ in (T, TU):
+          elif typ in (T, TU, TL):
               q = j
+              if typ == TL:      # the last update of the tile first: panel q - 1
+                  assert q >= 1 and not (i == q + 1 and q + 1 < KB) and st[i, q] == q - 1 and st[i, q - 1] >= q and st[q, q - 1] >= q, ("TL out of order", a, i, q, st[i, q])
+                  kq = slice(b[q - 1], b[q])
+                  A[ri, b[q]:b[q + 1]] -= W[ri, kq] @ A[b[q]:b[q + 1], kq].T
+                  st[i, q] = q
               assert i > q and q < KB and st[q, q] >= q + 1 and st[i, q] == q, ("T out of order", a, i, q)
               rows_t = ri
               if typ == TU:
@@ -146,6 +153,7 @@ def replay(fronts, tasks, group, fused=False, split=False, queues=None, policy=0
                       rows_t = slice(b[i] + 64, b[i + 1])
               else:
                   assert nq == 1
+                  assert not (fuse_tl and typ == T and q >= 1), "T(i, q >= 1) must be a TL task"
               cq = slice(b[q], b[q + 1])
               Lqq = np.tril(A[cq, cq], -1) + np.eye(b[q + 1] - b[q])
               d = np.diag(A[cq, cq])
@@ -172,6 +180,7 @@ def replay(fronts, tasks, group, fused=False, split=False, queues=None, policy=0
           else:
               ql = q0 + nq - 1
               assert 1 <= nq <= max(group, 1) and i >= j > ql and ql < KB, ("U shape", a, i, j, q0, nq)
+              assert not (fuse_tl and j < KB and ql == j - 1 and i > j and not (i == j + 1 and j + 1 < KB)), ("this update belongs inside TL", a, i, j, q0, nq)
               assert st[i, ql] >= ql + 1 and st[j, ql] >= ql + 1 and st[i, j] == q0, ("U out of order", a, i, j, q0, nq, st[i, j])
               cj = slice(b[j], b[j + 1])
               kk = slice(b[q0], b[ql + 1])
@@ -236,26 +245,26 @@ CASES = [
 
 
 @pytest.mark.parametrize("fronts", CASES)
-@pytest.mark.parametrize("group,rows,fused,split", [(1, 1, False, False), (2, 1, True, False), (3, 2, False, True), (2, 4, True, False), (4, 1, True, True)])
-def test_queue_replays_to_the_partial_factorisation(fronts, group, rows, fused, split):
-    tasks, model = build_queue(fronts, workers=16, group=group, rows=rows, fuse_d=fused, split=split)
+@pytest.mark.parametrize("group,rows,fused,split,tl", [(1, 1, False, False, False), (2, 1, True, False, False), (3, 2, False, True, False), (2, 4, True, False, True), (4, 1, True, True, True), (2, 1, False, False, True)])
+def test_queue_replays_to_the_partial_factorisation(fronts, group, rows, fused, split, tl):
+    tasks, model = build_queue(fronts, workers=16, group=group, rows=rows, fuse_d=fused, split=split, fuse_tl=tl)
     assert model > 0
-    replay(fronts, tasks, group, fused, split)
+    replay(fronts, tasks, group, fused, split, fuse_tl=tl)
 
 
 @pytest.mark.parametrize("fronts", CASES + [[(2600, 2600)], [(1800, 700), (1500, 1500)]])
-@pytest.mark.parametrize("group,fused,split,policy", [(4, True, True, 0), (4, True, True, 1), (4, True, True, 7), (2, False, False, 3), (3, True, False, 11)])
-def test_two_kernel_queues_finish_under_any_interleaving(fronts, group, fused, split, policy):
+@pytest.mark.parametrize("group,fused,split,policy,tl", [(4, True, True, 0, True), (4, True, True, 1, False), (4, True, True, 7, True), (2, False, False, 3, False), (3, True, False, 11, True)])
+def test_two_kernel_queues_finish_under_any_interleaving(fronts, group, fused, split, policy, tl):
     """The two-kernel form: the chain queue (D / TA / TU) and the eight per-XCD queues of panel tiles and updates, each popped in order
     by a worker of its own -- some held task is always ready (no deadlock) and the result is the partial factorisation."""
-    queues = build_split(fronts, workers=48, chain_workers=4, group=group, fuse_d=fused, split=split)
+    queues = build_split(fronts, workers=48, chain_workers=4, group=group, fuse_d=fused, split=split, fuse_tl=tl)
     # the chain kernel's queue: the chain itself and its feeders -- the panel tiles of the block rows right below TU's and the single-panel
     # updates within two rows of the diagonal; everything else in the bulk queues
-    assert all(t[1] in (D, TU, TA) or (t[1] == T and t[3] - t[4] <= 3) or (t[1] == U and t[2] == 1 and t[3] - t[4] <= 2) for t in queues[0])
+    assert all(t[1] in (D, TU, TA, TL) or (t[1] == T and t[3] - t[4] <= 3) or (t[1] == U and t[2] == 1 and t[3] - t[4] <= 2) for t in queues[0])
     assert all(t[1] in (T, U) for q in queues[1:] for t in q)
-    single, _ = build_queue(fronts, workers=48, group=group, fuse_d=fused, split=split)
+    single, _ = build_queue(fronts, workers=48, group=group, fuse_d=fused, split=split, fuse_tl=tl)
     assert sorted(t for q in queues for t in q) == sorted(single) or len(single) == sum(len(q) for q in queues)
-    replay(fronts, None, group, fused, split, queues=queues, policy=policy)
+    replay(fronts, None, group, fused, split, queues=queues, policy=policy, fuse_tl=tl)
 
 
 def test_two_kernel_queues_keep_row_bands_together():
