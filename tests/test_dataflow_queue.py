@@ -264,7 +264,8 @@ def test_two_kernel_queues_finish_under_any_interleaving(fronts, group, fused, s
     assert all(t[1] in (D, TU, TA, TL) or (t[1] == T and t[3] - t[4] <= NEAR + 1) or (t[1] == U and t[2] == 1 and t[3] - t[4] <= NEAR) for t in queues[0])
     assert all(t[1] in (T, U) for q in queues[1:] for t in q)
     single, _ = build_queue(fronts, workers=48, group=group, fuse_d=fused, split=split, fuse_tl=tl)
-    assert sorted(t for q in queues for t in q) == sorted(single) or len(single) == sum(len(q) for q in queues)
+    if not tl:      # (with TL tasks the two forms differ: the one-kernel form fuses every block row, the two-kernel form the near ones)
+        assert sorted(t for q in queues for t in q) == sorted(single) or len(single) == sum(len(q) for q in queues)
     replay(fronts, None, group, fused, split, queues=queues, policy=policy, fuse_tl=tl)
 
 
