@@ -87,6 +87,8 @@ def replay(fronts, tasks, group, fused=False, split=False, queues=None, policy=0
         grids.append((KB, TB, b))
         states.append(np.zeros((TB, TB), dtype=int))
         Ws.append(np.zeros((f, k)))
+    tl_tiles = {(t[0], t[3], t[4]) for t in (tasks if queues is None else [x for q in queues for x in q]) if t[1] == TL}
+
     def ready(task):
         """the tile states the kernels wait for before a popped task starts (dataflow.hip: the worker's poll, and D(q) inside TU / TA)"""
         (a, typ, nq, i0, j, q0, R) = task
@@ -154,7 +156,7 @@ def replay(fronts, tasks, group, fused=False, split=False, queues=None, policy=0
                       rows_t = slice(b[i] + 64, b[i + 1])
               else:
                   assert nq == 1
-                  assert not (fuse_tl and typ == T and q >= 1), "T(i, q >= 1) must be a TL task"
+                  assert not (fuse_tl and queues is None and typ == T and q >= 1), "T(i, q >= 1) must be a TL task"
               cq = slice(b[q], b[q + 1])
               Lqq = np.tril(A[cq, cq], -1) + np.eye(b[q + 1] - b[q])
               d = np.diag(A[cq, cq])
@@ -181,7 +183,8 @@ def replay(fronts, tasks, group, fused=False, split=False, queues=None, policy=0
           else:
               ql = q0 + nq - 1
               assert 1 <= nq <= max(group, 1) and i >= j > ql and ql < KB, ("U shape", a, i, j, q0, nq)
-              assert not (fuse_tl and j < KB and ql == j - 1 and i > j and not (i == j + 1 and j + 1 < KB)), ("this update belongs inside TL", a, i, j, q0, nq)
+              assert not (ql == j - 1 and (a, i, j) in tl_tiles), ("this update belongs inside TL", a, i, j, q0, nq)
+              assert not (fuse_tl and queues is None and j < KB and ql == j - 1 and i > j and not (i == j + 1 and j + 1 < KB)), ("one-kernel form: every block row below TU's is fused", a, i, j)
               assert st[i, ql] >= ql + 1 and st[j, ql] >= ql + 1 and st[i, j] == q0, ("U out of order", a, i, j, q0, nq, st[i, j])
               cj = slice(b[j], b[j + 1])
               kk = slice(b[q0], b[ql + 1])
