@@ -40,6 +40,7 @@ int solver_ensure_numeric(okkt_solver_s* h) {
   h->N.df_chain_workers = h->stream_reserved;
   if (const char* fl = getenv("OKKT_FLOW")) h->N.flow = atoi(fl);   // read by the set-up
   if (const char* df = getenv("OKKT_DATAFLOW")) h->N.dataflow = atoi(df);
+  if (const char* sf = getenv("OKKT_SOLVE_FLOW")) h->N.solve_flow = atoi(sf);   // read by the set-up (it sizes the partial-product buffers)
   std::string e = numeric_setup(h->S, h->sopts, h->stream, h->N);
   if (const char* sh = getenv("OKKT_SPLIT_HEAD")) h->N.split_head = atoi(sh);
   if (const char* d2 = getenv("OKKT_DIAG2")) h->N.diag2 = atoi(d2);
@@ -47,7 +48,6 @@ int solver_ensure_numeric(okkt_solver_s* h) {
   if (const char* ss = getenv("OKKT_SOLVE_SPLIT_SMALL")) h->N.solve_split_small = atoi(ss);
   if (const char* su = getenv("OKKT_SOLVE_FUSE")) h->N.solve_fuse = atoi(su);
   if (const char* sw = getenv("OKKT_SOLVE_FUSE_WIDE_MAX")) h->N.solve_fuse_wide_max = atoi(sw);
-  if (const char* sf = getenv("OKKT_SOLVE_FLOW")) h->N.solve_flow = atoi(sf);
   if (const char* mt = getenv("OKKT_LA_MIN_TILES")) h->N.la_min_tiles = atoi(mt);
   if (!e.empty()) { numeric_release(h->N); return solver_set_error(h, OKKT_ERR_HIP, e); }
   h->numeric_ready = true;
@@ -71,9 +71,11 @@ int solver_factor_device(okkt_solver_s* h, const double* d_vals, int64_t n, int6
   std::string e = numeric_factor_enqueue(h->N, d_vals, tol);
   if (!e.empty()) return solver_set_error(h, OKKT_ERR_HIP, e);
   (void)hipEventRecord(h->ev1, h->stream);
-  unsigned long long cnt[5];
+  unsigned long long cnt[6];
   e = numeric_read_counts(h->N, h->stream, cnt);
   if (!e.empty()) return solver_set_error(h, OKKT_ERR_HIP, std::string("numeric factorisation failed: ") + e);
+  if (cnt[5] != 0)      // distinct from an inertia failure: callers of the delta loop must not shift and retry on it
+    return solver_set_error(h, OKKT_ERR_INTERNAL, "a hand-off inside a launch timed out: the pivot counts are incomplete and there is no factor");
   float ms = 0;
   if (hipEventElapsedTime(&ms, h->ev0, h->ev1) == hipSuccess) h->last_factor_ms = ms;
   okkt_inertia in;

@@ -150,13 +150,14 @@ __device__ __forceinline__ bool df_await(const DevPlan& P, const int* state, int
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   if (wave == 0) {
     int ok = 1, spins = 0;
+    long long t0w = 0;
     for (;;) {
       if (__builtin_amdgcn_readfirstlane(ld_state(state)) >= least) break;
       const int stop = P.want_neg >= 0 ? __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&P.counters[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : 0;
       const int dead = __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&P.counters[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
       if (stop | dead) { ok = 0; break; }
-      if (++spins >= (1 << 21)) {
-        if ((threadIdx.x & 63) == 0) { atomicAdd(&P.counters[3], 1ull); atomicExch(&P.counters[5], 1ull); }
+      if (wait_expired(spins, t0w)) {
+        if ((threadIdx.x & 63) == 0) atomicExch(&P.counters[5], 1ull);
         ok = 0;
         break;
       }
@@ -402,13 +403,14 @@ __device__ __forceinline__ bool df_tu_tile(const DevPlan& P, int s, int q, int r
   auto await = [&](const int* state, int least, int* flag, int poller) -> bool {
     if (wave == poller) {
       int ok = 1, spins = 0;
+      long long t0w = 0;
       for (;;) {
         if (__builtin_amdgcn_readfirstlane(ld_state(state)) >= least) break;
         const int stop = P.want_neg >= 0 ? __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&P.counters[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : 0;
         const int dead = __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&P.counters[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
         if (stop | dead) { ok = 0; break; }
-        if (++spins >= (1 << 21)) {
-          if (lane == 0) { atomicAdd(&P.counters[3], 1ull); atomicExch(&P.counters[5], 1ull); }
+        if (wait_expired(spins, t0w)) {
+          if (lane == 0) atomicExch(&P.counters[5], 1ull);
           ok = 0;
           break;
         }
@@ -936,6 +938,7 @@ constexpr int kBulkLook = 4;
 __device__ __forceinline__ int bulk_claim(const DevPlan& P, const DfDep* __restrict__ deps, const int* __restrict__ qinfo, int* __restrict__ claim, int my, volatile int* s_cur, int lane,
                                           int* mine_out, int* newv_out, bool block, bool inorder) {
   int spins = 0;
+  long long t0w = 0;
   for (;;) {
     bool all_done = true, all_done_own = true;
     for (int dq = 0; dq < 8; ++dq) {
@@ -982,7 +985,7 @@ __device__ __forceinline__ int bulk_claim(const DevPlan& P, const DfDep* __restr
                 if (ld_state(P.df_state + a0) >= n0 && ld_state(P.df_state + a1) >= n1 && ld_state(P.df_state + a2) >= n2) break;
                 const int dead = __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&P.counters[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
                 if (dead) return -2;
-                if (++spins >= (1 << 21)) { if (lane == 0) { atomicAdd(&P.counters[3], 1ull); atomicExch(&P.counters[5], 1ull); } return -2; }
+                if (wait_expired(spins, t0w)) { if (lane == 0) atomicExch(&P.counters[5], 1ull); return -2; }
                 __builtin_amdgcn_s_sleep(2);
               }
             }
@@ -997,8 +1000,8 @@ __device__ __forceinline__ int bulk_claim(const DevPlan& P, const DfDep* __restr
     const int stop = P.want_neg >= 0 ? __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&P.counters[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : 0;
     const int dead = __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&P.counters[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     if (stop | dead) return -2;
-    if (++spins >= (1 << 20)) {      // bounded like every in-launch wait: nothing became ready for seconds
-      if (lane == 0) { atomicAdd(&P.counters[3], 1ull); atomicExch(&P.counters[5], 1ull); }
+    if (wait_expired(spins, t0w)) {      // bounded like every in-launch wait: nothing became ready for seconds
+      if (lane == 0) atomicExch(&P.counters[5], 1ull);
       return -2;
     }
     __builtin_amdgcn_s_sleep(8);
@@ -1074,8 +1077,8 @@ __global__ __launch_bounds__(kDfThreadsC, 4) void k_front_bulk(DevPlan P, const 
 constexpr int kDfThreads = kDfThreadsC;
 constexpr size_t kDfLds = std::max(std::max(std::max(OKKT_DIAG2_LDS_DOUBLES(kMW) * sizeof(double), kDfTuLds), (size_t)kDfStages * 2 * kDfKC * kSyrkLd * sizeof(double)), kDfTlLds);   // diag2_body's and df_tu_tile's; the other roles need less
 
-// counters[5] = a wait ran into its bound (or another worker's did): every worker leaves, the factorisation reports a wrong
-// inertia ("pivot counts do not add up") and the solves return NaN -- never numbers computed from tiles that had not arrived
+// counters[5] = a wait ran into its bound, three seconds of wall clock (or another worker's did): every worker leaves, the factorisation
+// fails with "a hand-off timed out" and the solves return NaN -- never numbers computed from tiles that had not arrived
 // asm_flags != nullptr: the chain kernel of the two-kernel form (k_front_bulk above) -- it runs on a stream of its own and may be resident
 // before the level's fronts are assembled: a task that waits for no other task (block column 0) waits for its front's flag instead
 __global__ __launch_bounds__(kDfThreads, 1) void k_front_dataflow(DevPlan P, const DfTask* __restrict__ tasks, int ntasks, int* __restrict__ head, double tol, int drop, int dbg, long long* __restrict__ tlog,
@@ -1134,14 +1137,15 @@ __global__ __launch_bounds__(kDfThreads, 1) void k_front_dataflow(DevPlan P, con
         }
         if (drop && ln == 0) need += 1 << 20;      // tests: a hand-off that never comes
         int spins = 0;
+        long long t0w = 0;
         for (;;) {
           if (__builtin_amdgcn_ballot_w64(ld_state(addr) >= need) == ~0ull) break;
           // the stop flag of the delta loop (retries only) and the time-out word end every wait
           const int stop = P.want_neg >= 0 ? __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&P.counters[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : 0;
           const int dead = __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&P.counters[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
           if (stop | dead) { ok = 0; break; }
-          if (++spins >= (1 << 21)) {
-            if (ln == 0) { atomicAdd(&P.counters[3], 1ull); atomicExch(&P.counters[5], 1ull); }
+          if (wait_expired(spins, t0w)) {
+            if (ln == 0) atomicExch(&P.counters[5], 1ull);
             ok = 0;
             break;
           }

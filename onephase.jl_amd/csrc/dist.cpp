@@ -119,7 +119,7 @@ int okkt_dist_counts(okkt_handle h, int64_t out[4]) {
   if (!h || !out) return OKKT_ERR_INVALID;
   int rc = need_dist(h);
   if (rc != OKKT_OK) return rc;
-  unsigned long long cnt[5];
+  unsigned long long cnt[6];
   if (!numeric_read_counts(h->N, h->stream, cnt).empty())
     return solver_set_error(h, OKKT_ERR_HIP, "download of the pivot counts failed");
   for (int i = 0; i < 4; ++i) out[i] = (int64_t)cnt[i];

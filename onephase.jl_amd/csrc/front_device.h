@@ -87,6 +87,17 @@ __device__ __forceinline__ double readlane_f64(double v, int src_lane) {
   return __hiloint2double(hi, lo);
 }
 
+// Bound of the waits inside the dataflow launches: wall-clock time, not a number of polls (advisor, round 4: a launch slowed far below
+// normal -- counter collection, several processes on one GPU -- must not turn a legitimate wait into an error).  The time-out word
+// counters[5] is raised alone: the host reports "a hand-off timed out", not a pivot-count failure.
+constexpr long long kWaitTicks = 300000000LL;      // 3 s of the 100-MHz counter
+__device__ __forceinline__ bool wait_expired(int& spins, long long& t0) {
+  if ((++spins & 127) != 0) return false;
+  const long long now = wall_clock64();
+  if (t0 == 0) { t0 = now; return false; }
+  return now - t0 > kWaitTicks;
+}
+
 constexpr int kIB = 32;  // inner block width of the diagonal-block kernel
 constexpr int kTld = 33; // leading dimension of the 32 x 32 scratch blocks (odd: conflict-free column access)
 

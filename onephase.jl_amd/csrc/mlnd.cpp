@@ -620,6 +620,7 @@ void nd_rec(NdCtx& cx, Graph g, std::vector<int> label, int* out, int depth, uin
   {
     std::vector<std::thread> th;
     th.reserve(ntrial);
+    bool inline_failed = false;
     for (int t = 1; t < ntrial; ++t) {
       bool spawned = false;
       if (cx.threads_free.fetch_sub(1) > 0) {
@@ -628,9 +629,11 @@ void nd_rec(NdCtx& cx, Graph g, std::vector<int> label, int* out, int depth, uin
           spawned = true;
         } catch (...) { spawned = false; }       // no thread to be had (pid / thread limit): this trial runs here
       }
-      if (!spawned) { cx.threads_free.fetch_add(1); ml_separator(g, seed * 31 + t, max_frac, cand[t]); }
+      // the trial runs here: inside a try block too -- an exception that unwound through `th` with joinable threads in it would end in
+      // std::terminate (advisor, round 4); every thread is joined below before anything is thrown
+      if (!spawned) { cx.threads_free.fetch_add(1); try { ml_separator(g, seed * 31 + t, max_frac, cand[t]); } catch (...) { inline_failed = true; } }
     }
-    bool own_failed = false;
+    bool own_failed = inline_failed;
     try { ml_separator(g, seed * 31, max_frac, cand[0]); } catch (...) { own_failed = true; }
     for (auto& t : th) { t.join(); cx.threads_free.fetch_add(1); }
     if (own_failed || cx.failed.load()) { cx.failed.store(true); throw std::runtime_error("multilevel dissection: a bisection trial failed"); }

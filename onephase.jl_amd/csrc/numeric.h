@@ -114,8 +114,8 @@ constexpr int kCountSlots = 64, kCountStride = 16;
 constexpr int kSolveBlock = OKKT_SOLVE_BLOCK;
 static_assert(kSolveBlock == 1024 || kSolveBlock == 2048, "solve.hip is validated for 1024- and 2048-column inverse blocks only");
 constexpr int kMaxRhs = 4;                      // right-hand sides carried through one pass over L
-// sums the slots: out[0..3] = pos, neg, zero, nonfinite, out[4] = stop flag (synchronises `stream`)
-std::string numeric_read_counts(struct Numeric& N, hipStream_t stream, unsigned long long out[5]);
+// sums the slots: out[0..3] = pos, neg, zero, nonfinite, out[4] = stop flag, out[5] = time-out word of the in-launch waits (synchronises `stream`)
+std::string numeric_read_counts(struct Numeric& N, hipStream_t stream, unsigned long long out[6]);
 
 // front classes by order f: 0: f<=32 (one wave), 1: f<=64, 2: f<=small_max (256 threads, LDS), 3: big
 constexpr int kNumClasses = 4;

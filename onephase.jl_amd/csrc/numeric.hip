@@ -1047,8 +1047,14 @@ std::string numeric_setup(const Symbolic& S, const SymbolicOptions& opts, hipStr
   // partition there are two schedules: the subtrees this part owns and (part 0 only) the top of the tree.
   std::vector<int> sched;
   sched.reserve(ns);
+  // W = L21 D of the big fronts' panels is dead once its level's launches have finished (the block inversions and the solves read F,
+  // invl and xinv only), so a level's fronts take their W from one of TWO regions by the parity of the level: consecutive levels never
+  // share one (a chain kernel of the two-kernel form may still be in its last diagonal block when the next level starts), and the
+  // buffer is max over the even levels + max over the odd levels instead of the sum over all fronts (advisor, round 4: a second copy
+  // of every pivot column, growing with nnz(L)).  wbuf_pos is relative to the region; the region's base is added below.
   std::vector<int64_t> wpos(ns, -1);
-  int64_t wtotal = 0;
+  std::vector<char> wparity(ns, 0);
+  int64_t wregion[2] = {0, 0};
   N.n_small = N.n_big = 0;
   const bool parted = S.nparts > 1 && (int)S.sn_owner.size() == ns;
   // Tasks: a workgroup runs a whole subtree of small fronts, children before parents (the supernodes are numbered
@@ -1129,9 +1135,11 @@ std::string numeric_setup(const Symbolic& S, const SymbolicOptions& opts, hipStr
   }
   N.n_tasks = 0;
   N.max_task_len = 0;
+  int wlevel_seq = 0;      // levels that hold big fronts, counted over both schedules (the top of a partitioned plan runs behind the local part)
   auto build = [&](std::vector<LevelSchedule>& levels, int want_owner) {
     levels.assign(nulev, LevelSchedule());
     for (int l = 0; l < nulev; ++l) {
+      int64_t wlevel = 0;      // W doubles of this level's big fronts
       std::vector<int> cls[kNumClasses];
       for (int s : units_at[l]) {
         if (parted) { if (S.sn_owner[s] != want_owner) continue; }
@@ -1171,10 +1179,11 @@ std::string numeric_setup(const Symbolic& S, const SymbolicOptions& opts, hipStr
             // two super-steps of W (look-ahead double buffer of the per-step schedule); the dataflow launch keeps the W of EVERY panel of
             // the front (a task may still read panel q while the chain is several block columns ahead: no slot is ever reused)
             const int64_t wcols = std::max<int64_t>((int64_t)N.nb * (f >= N.group_big_minf ? std::max(N.group, N.group_big) : N.group) * 2, N.dataflow ? ((int64_t)k + N.nb - 1) / N.nb * N.nb : 0);
-            wpos[s] = wtotal; wtotal += (int64_t)f * wcols; ++N.n_big;
+            wpos[s] = wlevel; wparity[s] = (char)(wlevel_seq & 1); wlevel += (int64_t)f * wcols; ++N.n_big;
           }
         }
       }
+      if (wlevel > 0) { wregion[wlevel_seq & 1] = std::max(wregion[wlevel_seq & 1], wlevel); ++wlevel_seq; }
     }
   };
   build(N.levels, parted ? N.part_id : 0);
@@ -1206,6 +1215,8 @@ std::string numeric_setup(const Symbolic& S, const SymbolicOptions& opts, hipStr
     if (!(e = upload(N, unit_parent, &d.unit_parent)).empty()) return e;
   }
   if (getenv("OKKT_DEBUG_FRONTS")) fprintf(stderr, "okkt: %d levels of units (%d levels of fronts), %lld tasks of small fronts, longest %d\n", nulev, S.nlevels, (long long)N.n_tasks, N.max_task_len);
+  for (int s2 = 0; s2 < ns; ++s2) if (wpos[s2] >= 0 && wparity[s2]) wpos[s2] += wregion[0];
+  const int64_t wtotal = wregion[0] + wregion[1];
   if (!(e = upload(N, wpos, &d.wbuf_pos)).empty()) return e;
   N.sched_host = sched;
   {
@@ -1374,7 +1385,7 @@ void numeric_release(Numeric& N) {
   N.vals_owned = nullptr;
 }
 
-std::string numeric_read_counts(Numeric& N, hipStream_t stream, unsigned long long out[5]) {
+std::string numeric_read_counts(Numeric& N, hipStream_t stream, unsigned long long out[6]) {
   unsigned long long raw[kCountSlots * kCountStride];
   OKKT_HIP_TRY(hipMemcpyAsync(raw, N.d.counters, sizeof(raw), hipMemcpyDeviceToHost, stream));
   OKKT_HIP_TRY(hipStreamSynchronize(stream));
@@ -1383,6 +1394,7 @@ std::string numeric_read_counts(Numeric& N, hipStream_t stream, unsigned long lo
     for (int q = 0; q < kCountSlots; ++q) out[c] += raw[q * kCountStride + c];
   }
   out[4] = raw[4];
+  out[5] = raw[5];
   return "";
 }
 
@@ -1404,6 +1416,14 @@ std::string numeric_factor_enqueue(Numeric& N, const double* d_vals, double tol,
   }
   if (N.early_check && N.early_device && which == 0 && N.levels_top.empty() && reset_counters) { P.want_pos = N.early_n; P.want_neg = N.early_m; }
   N.la_used = 0;
+  // A factorisation right behind another one (a retry of the delta loop: no solve in between): the previous factor's block inversions may
+  // still be running on the auxiliary stream and read the arena and invl that the new assembly overwrites -- the handle's stream waits for
+  // them (no cost when a solve ran in between: it has waited already)
+  if (which == 0) {
+    for (size_t l = 0; l < N.inv_level_pending.size(); ++l)
+      if (N.inv_level_pending[l] && N.inv_level_events[l]) OKKT_HIP_TRY(hipStreamWaitEvent(st, N.inv_level_events[l], 0));
+    if (N.inv_wait && N.inv_event) OKKT_HIP_TRY(hipStreamWaitEvent(st, N.inv_event, 0));
+  }
   if (which == 0) std::fill(N.inv_level_pending.begin(), N.inv_level_pending.end(), 0);
   if (which == 0) N.inv_wait = false;   // the block inverses belong to the previous factorisation (the top phase of a partitioned
                                         // plan keeps the wait its local phase has set up)
@@ -1472,7 +1492,7 @@ static std::string factor_sched(Numeric& N, DevPlan P, const std::vector<LevelSc
     if (N.early_check && in_loop_check && (int)l == N.early_level) {
       // the pivots counted so far already decide a wrong inertia?  Then the (expensive) rest of the tree is skipped:
       // one synchronisation per factorisation, 35 of 49 ms saved per failed attempt of the delta loop at S-metric
-      unsigned long long cnt[5] = {0, 0, 0, 0, 0};
+      unsigned long long cnt[6] = {0, 0, 0, 0, 0, 0};
       std::string ec = numeric_read_counts(N, cur, cnt);
       if (!ec.empty()) return ec;
       if (cnt[4] != 0 || cnt[3] > 0 || cnt[2] > 0 || cnt[1] > (unsigned long long)N.early_m || cnt[0] > (unsigned long long)N.early_n) {

@@ -1152,7 +1152,7 @@ std::string solve_setup(const Symbolic& S, Numeric& N) {
           xinv_pos[s] = xtot;
           xtot += nfull * (int64_t)kSB * kSB + lastp * lastp;
           ypart_pos[s] = ytot;
-          ytot += (int64_t)kMaxRhs * kCS * kSB * ((k + kSB - 1) / kSB);      // one buffer of partial products per block (flow launches)
+          ytot += (int64_t)kMaxRhs * kCS * kSB * (N.solve_flow ? (k + kSB - 1) / kSB : 1);      // one buffer of partial products (the flow experiment: one per block)
           sver_pos[s] = vtot;
           vtot += (N.sn_f[s] + 31) / 32 + 2 + (k + kSB - 1) / kSB;      // tile words, then one arrival counter per block
         }
@@ -1349,8 +1349,6 @@ static std::string bwd_enqueue_r(Numeric& N, const std::vector<LevelSchedule>& l
   return "";
 }
 
-std::string lanes_fork(Numeric& N, hipStream_t from);
-std::string lanes_join(Numeric& N, hipStream_t to);
 
 static std::string sweep(Numeric& N, bool fwd, const std::vector<LevelSchedule>& levels, const std::vector<SolveLevel>& sl, hipStream_t st, int R,
                          int l_lo = 0, int l_hi = 1 << 30) {
