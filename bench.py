@@ -198,7 +198,7 @@ def main():
     M = synth.symmetrize_lower(K)
     resid = float(np.max(np.abs(M @ x - rhs)) / np.max(np.abs(rhs)))
     st = hip.stats()
-    ok = (rc == 1) and hip.inertia == (n, m, 0, 0) and resid < 1e-5
+    ok = (rc == 1) and hip.inertia == (n, m, 0, 0) and resid < 2e-6      # the run reaches 4.6e-7 (oracle: 1.8e-7): a regression of 5 x fails the line
 
     if rank == 0:
         value = world * args.steps / elapsed
