@@ -113,6 +113,9 @@ typedef struct {
   int64_t n_analyze_calls; /* how many times a new pattern forced a re-analysis */
   int64_t ordering_used;   /* 0 AMD, 1 natural, 2 user, 4 level-structure nested dissection, 5 multilevel nested dissection */
   int64_t critical_pivots; /* pivots on the longest leaf-to-root path of the supernodal elimination tree */
+  int64_t top_separator;   /* multilevel dissection: vertices of the top-level separator (-1: none) */
+  int64_t amd_skipped;     /* automatic ordering: 1 = minimum degree was abandoned (small top separator), no flop comparison was made */
+  double flops_other;      /* automatic ordering: factor flops of the candidate that lost the comparison (0: none, or skipped) */
 } okkt_stats;
 
 /* ---- level 1: linear solver ------------------------------------------------------------ */

@@ -77,6 +77,9 @@ class OkktStats(C.Structure):
         ("n_analyze_calls", C.c_int64),
         ("ordering_used", C.c_int64),
         ("critical_pivots", C.c_int64),
+        ("top_separator", C.c_int64),
+        ("amd_skipped", C.c_int64),
+        ("flops_other", C.c_double),
     ]
 
     def as_dict(self):

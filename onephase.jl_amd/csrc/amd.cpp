@@ -18,6 +18,7 @@
 #include "symbolic.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <chrono>
 #include <cstdint>
@@ -34,7 +35,7 @@ enum : uint8_t { ST_VAR = 0, ST_ELEM = 1, ST_DEAD = 2, ST_ABSORBED = 3, ST_DENSE
 }  // namespace
 
 void amd_order(int n, const std::vector<int64_t>& ap, const std::vector<int>& ai,
-               std::vector<int>& order) {
+               std::vector<int>& order, const std::atomic<bool>* cancel) {
   order.clear();
   order.reserve(n);
   if (n == 0) return;
@@ -111,6 +112,8 @@ void amd_order(int n, const std::vector<int64_t>& ap, const std::vector<int>& ai
   auto t_start = std::chrono::steady_clock::now();
   int dbg_next = 0; int64_t work_scan = 0;
   while (eliminated < nleft) {
+    // the caller no longer needs this ordering (symbolic.cpp: the dissection candidate finished with a small top separator)
+    if (cancel && cancel->load(std::memory_order_relaxed)) { order.clear(); return; }
     if (dbg && eliminated >= dbg_next) {
       fprintf(stderr, "okkt: amd %8d of %d eliminated, %zu pivots, %.3f s, mindeg %d, scanned %ld\n", eliminated, nleft, pivots.size(),
               std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count(), mindeg, (long)work_scan);

@@ -445,6 +445,9 @@ int okkt_get_stats(okkt_handle h, okkt_stats* out) {
   out->n_analyze_calls = h->n_analyze_calls;
   out->ordering_used = h->S.ordering_used;
   out->critical_pivots = h->S.critical_pivots;
+  out->top_separator = h->S.top_separator;
+  out->amd_skipped = h->S.amd_skipped ? 1 : 0;
+  out->flops_other = h->S.flops_other;
   return OKKT_OK;
 }
 

@@ -587,6 +587,7 @@ struct NdCtx {
   // a helper thread never lets an exception escape (that would be std::terminate for the host process): it sets this flag, and the
   // thread that spawned it throws once every helper has been joined -- the caller (symbolic.cpp) then drops the dissection candidate
   std::atomic<bool> failed{false};
+  int top_sep = -1;      // separator of the depth-0 bisection (written by that call alone)
 };
 
 void amd_leaf(const Graph& g, const std::vector<int>& label, int* out) {
@@ -655,6 +656,7 @@ void nd_rec(NdCtx& cx, Graph g, std::vector<int> label, int* out, int depth, uin
   std::vector<int8_t>& where = cand[bestt];
   int cnt[3] = {0, 0, 0};
   for (int v = 0; v < g.n; ++v) ++cnt[where[v]];
+  if (depth == 0) cx.top_sep = cnt[2];
   if (cx.dbg && depth < 4) fprintf(stderr, "okkt: nd depth %d: %d vertices -> %d | %d | separator %d\n", depth, g.n, cnt[0], cnt[1], cnt[2]);
   // a useless split (everything in the separator or on one side): minimum degree on the whole piece
   if (cnt[0] == 0 || cnt[1] == 0 || cnt[2] * 2 > g.n) { amd_leaf(g, label, out); return; }
@@ -702,7 +704,8 @@ void nd_rec(NdCtx& cx, Graph g, std::vector<int> label, int* out, int depth, uin
 
 }  // namespace
 
-void ml_nd_order(int n, const std::vector<int64_t>& gp, const std::vector<int>& gi, int leaf, int ntrial_top, std::vector<int>& order) {
+void ml_nd_order(int n, const std::vector<int64_t>& gp, const std::vector<int>& gi, int leaf, int ntrial_top, std::vector<int>& order, int* top_sep) {
+  if (top_sep) *top_sep = -1;
   order.assign(n, -1);
   if (n == 0) return;
   if (gi.size() > 0x7ffffff0u) { order.clear(); return; }   // 32-bit adjacency offsets below: the caller keeps minimum degree
@@ -734,6 +737,7 @@ void ml_nd_order(int n, const std::vector<int64_t>& gp, const std::vector<int>& 
   cx.dbg = getenv("OKKT_DEBUG_ANALYZE") != nullptr;
   const int ng = g.n;
   nd_rec(cx, std::move(g), std::move(label), order.data(), 0, 1);
+  if (top_sep) *top_sep = cx.top_sep < 0 ? -1 : cx.top_sep + (int)last.size();      // the dense rows are eliminated with the top separator
   for (size_t k = 0; k < last.size(); ++k) order[ng + k] = last[k];
 }
 

@@ -10,6 +10,11 @@
 
 namespace okkt {
 
+// one extend-add item of a big front's column (numeric.hip: k_big_assemble*): the child's contribution-block column in the arena, its rel
+// list, the rows of its contribution block, the local column, its chunk-boundary table
+struct EaRec { int64_t src; int64_t rel; int rc; int jj; int64_t cut; };
+static_assert(sizeof(EaRec) == 32, "two 16-byte loads per record");
+
 // Everything the kernels need, resident in HBM for the life of a pattern.
 struct DevPlan {
   int n = 0, nsuper = 0;
@@ -51,6 +56,7 @@ struct DevPlan {
   int64_t* ea_src = nullptr;     // per item: arena offset of the child's contribution-block column
   int64_t* ea_rel = nullptr;     // per item: start of the child's rel list
   int64_t* ea_cut = nullptr;     // per item: start of the child's chunk-boundary table in cutv
+  const struct EaRec* ea_rec = nullptr;   // per item: the five fields above in one 32-byte record (two 16-byte loads instead of five scattered ones)
   int* cutv = nullptr;           // per child of a big front: positions of the parent's 1024-row boundaries in its rel list
   int64_t* acol_lo = nullptr;    // [n_bigcols + 1] first A entry of each big-front column
   // solves (solve.hip): explicit inverses of the kSolveBlock-column diagonal blocks of the fronts with more than NB pivot

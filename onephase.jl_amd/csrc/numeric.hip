@@ -192,6 +192,15 @@ __device__ __forceinline__ int lower_bound_dev(const int* a, int n, int key) {
 // deterministic, no atomics, no workgroup barriers.
 // column pc of front s accumulated in `buf` (buf[0] = row pc): zero, A entries, delta, children's contributions in
 // their fixed order.  LDS = true: buf is the wave's LDS column; false: the HBM column itself.
+// extend-add items whose records and first rows are in flight together (round 5: packed 32-byte records, 4 / 8 / 16 items measured: 2047 / 2058 /
+// 2485 us of assembly per S-metric factorisation -- the kernels are not bound by the record fetches)
+#ifndef OKKT_ASM_BATCH
+#define OKKT_ASM_BATCH 4
+#endif
+#ifndef OKKT_ASM_BATCH_CHUNKED
+#define OKKT_ASM_BATCH_CHUNKED 4
+#endif
+constexpr int kAsmBatch = OKKT_ASM_BATCH, kAsmBatchChunked = OKKT_ASM_BATCH_CHUNKED;
 template <bool LDS, bool BATCH>
 __device__ __forceinline__ void assemble_column(const DevPlan& P, int s, int pc, int f, int k, int col0, double* __restrict__ buf) {
   const int lane = threadIdx.x & 63;
@@ -224,17 +233,17 @@ __device__ __forceinline__ void assemble_column(const DevPlan& P, int s, int pc,
   // Items are applied strictly in order (same destination column), but their loads need not wait for each other:
   // four items at a time have their records, and then the first 64 rows of their index and source columns, in
   // flight together (clamped addresses, no branches); most items of the lower levels are no longer than that.
-  constexpr int NB4 = 4;
+  constexpr int NB4 = kAsmBatch;
   if constexpr (!BATCH) {
     // long columns (upper levels, bandwidth-bound): one item after the other, the next record fetched meanwhile
     int64_t src_n = 0, rel_n = 0;
     int rc_n = 0, jj_n = 0;
-    if (q0 < q1) { src_n = P.ea_src[q0]; rel_n = P.ea_rel[q0]; rc_n = P.ea_rc[q0]; jj_n = P.ea_jj[q0]; }
+    if (q0 < q1) { const EaRec r = P.ea_rec[q0]; src_n = r.src; rel_n = r.rel; rc_n = r.rc; jj_n = r.jj; }
     for (int64_t q = q0; q < q1; ++q) {
       const int rc = rc_n, jj = jj_n;
       const int* rl = P.rel + rel_n;
       const double* Ccol = P.arena + src_n;
-      if (q + 1 < q1) { src_n = P.ea_src[q + 1]; rel_n = P.ea_rel[q + 1]; rc_n = P.ea_rc[q + 1]; jj_n = P.ea_jj[q + 1]; }
+      if (q + 1 < q1) { const EaRec r = P.ea_rec[q + 1]; src_n = r.src; rel_n = r.rel; rc_n = r.rc; jj_n = r.jj; }
       int ii = jj + lane;
       for (; ii + 192 < rc; ii += 256) {
         int d[4];
@@ -256,8 +265,8 @@ __device__ __forceinline__ void assemble_column(const DevPlan& P, int s, int pc,
     int rc[NB4], jj[NB4];
 #pragma unroll
     for (int u = 0; u < NB4; ++u) {
-      const int64_t qq = min(q + u, q1 - 1);
-      src[u] = P.ea_src[qq]; rel[u] = P.ea_rel[qq]; rc[u] = P.ea_rc[qq]; jj[u] = P.ea_jj[qq];
+      const EaRec r = P.ea_rec[min(q + u, q1 - 1)];
+      src[u] = r.src; rel[u] = r.rel; rc[u] = r.rc; jj[u] = r.jj;
     }
     int d[NB4];
     double v[NB4];
@@ -369,14 +378,14 @@ __global__ __launch_bounds__(256) void k_big_assemble_chunked(DevPlan P, const i
   // but four at a time have their records, then their chunk boundaries, then the first 64 rows of their index and value
   // columns in flight together (clamped addresses, no branches around the loads): three dependent round trips per four
   // items instead of two per item -- the kernel is pure memory latency (SQ_WAIT_ANY 85 % of the wave cycles).
-  constexpr int NB4 = 4;
+  constexpr int NB4 = kAsmBatchChunked;
   for (int64_t q = q0; q < q1; q += NB4) {
     int64_t src[NB4], rel[NB4], cutp[NB4];
     int rc[NB4], jj[NB4], lo[NB4], hi[NB4];
 #pragma unroll
     for (int u = 0; u < NB4; ++u) {
-      const int64_t qq = min(q + u, q1 - 1);
-      src[u] = P.ea_src[qq]; rel[u] = P.ea_rel[qq]; rc[u] = P.ea_rc[qq]; jj[u] = P.ea_jj[qq]; cutp[u] = P.ea_cut[qq];
+      const EaRec r = P.ea_rec[min(q + u, q1 - 1)];
+      src[u] = r.src; rel[u] = r.rel; rc[u] = r.rc; jj[u] = r.jj; cutp[u] = r.cut;
     }
 #pragma unroll
     for (int u = 0; u < NB4; ++u) {
@@ -1312,6 +1321,13 @@ std::string numeric_setup(const Symbolic& S, const SymbolicOptions& opts, hipStr
     if (!(e = upload(N, ea_src, &d.ea_src)).empty()) return e;
     if (!(e = upload(N, ea_rel, &d.ea_rel)).empty()) return e;
     if (!(e = upload(N, ea_cut, &d.ea_cut)).empty()) return e;
+    {
+      std::vector<EaRec> recs(ea_src.size());
+      for (size_t t = 0; t < recs.size(); ++t) recs[t] = EaRec{ea_src[t], ea_rel[t], ea_rc[t], ea_jj[t], ea_cut[t]};
+      EaRec* dr = nullptr;
+      if (!(e = upload(N, recs, &dr)).empty()) return e;
+      d.ea_rec = dr;
+    }
     if (!(e = upload(N, cutv, &d.cutv)).empty()) return e;
     if (!(e = upload(N, acol_lo, &d.acol_lo)).empty()) return e;
     // zero-filled once: the parts of a block beyond a front's last pivot column are never written and are read as zeros

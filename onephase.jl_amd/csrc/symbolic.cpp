@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <chrono>
 #include <algorithm>
+#include <atomic>
 #include <functional>
 #include <cstring>
 #include <numeric>
@@ -71,7 +72,8 @@ static std::string parallel_pieces(int64_t n, int want, F fn) {
 static std::string analyze_one(int64_t n64, const int64_t* colptr, const int64_t* rowval,
                                int index_base, const SymbolicOptions& opts,
                                const int64_t* user_perm, Symbolic& S,
-                               const std::vector<int>* forced_order = nullptr, bool stats_only = false) {
+                               const std::vector<int>* forced_order = nullptr, bool stats_only = false,
+                               const std::atomic<bool>* cancel = nullptr) {
   if (n64 < 0 || n64 > 0x7ffffff0) return "matrix order out of range";
   if (index_base != 0 && index_base != 1) return "index_base must be 0 or 1";
   const int n = (int)n64;
@@ -151,10 +153,12 @@ static std::string analyze_one(int64_t n64, const int64_t* colptr, const int64_t
     order = *forced_order;
     S.ordering_used = opts.ordering == 3 ? 0 : opts.ordering;
   } else if (opts.ordering == 0 || opts.ordering == 3) {
-    amd_order(n, gp, gi, order);
+    amd_order(n, gp, gi, order, cancel);
+    if (cancel && (int)order.size() != n) return "cancelled";
   } else if (opts.ordering == 5) {
-    ml_nd_order(n, gp, gi, opts.mlnd_leaf, opts.mlnd_trials, order);
-    if ((int)order.size() != n) amd_order(n, gp, gi, order); else S.ordering_used = 5;
+    int top_sep = -1;
+    ml_nd_order(n, gp, gi, opts.mlnd_leaf, opts.mlnd_trials, order, &top_sep);
+    if ((int)order.size() != n) amd_order(n, gp, gi, order); else { S.ordering_used = 5; S.top_separator = top_sep; }
   } else if (opts.ordering == 4) {
     level_nd_order(n, gp, gi, opts.nd_leaf, order);
     S.ordering_used = 4;
@@ -628,10 +632,17 @@ std::string analyze_pattern(int64_t n64, const int64_t* colptr, const int64_t* r
     // is ready when the comparison is decided, and is thrown away when minimum degree wins
     // (round 4: ONE pass -- the candidate's statistics are the first half of the full analysis; the second pass over the graph, the
     // elimination tree, the column counts and the postorder cost 0.05 s of the 0.6)
+    // (round 5) Minimum degree (0.47 - 0.51 s on one thread at S-metric) was the critical path of the analysis only to be COMPARED with:
+    // when the dissection's plan is ready and its top separator is small -- at most trust_frac of the graph: the graph has the
+    // separators the method lives on (S-metric 7 %, S-C5 0.2 %; the fully random S-C3 variant, where minimum degree wins: above 25 %) --
+    // the minimum-degree candidate is abandoned where it stands and the dissection is taken without a flop comparison.
+    static const double trust_frac = getenv("OKKT_MLND_TRUST_FRAC") ? atof(getenv("OKKT_MLND_TRUST_FRAC")) : 0.12;
+    std::atomic<bool> cancel_amd{false};
     auto run_b = [&] {
       try {
         eb = analyze_one(n64, colptr, rowval, index_base, ob, user_perm, Sb, nullptr, false);
         espec = eb.empty() && Sb.ordering_used == 5 ? "" : "no dissection plan";
+        if (espec.empty() && Sb.top_separator >= 0 && (double)Sb.top_separator <= trust_frac * (double)n64 && Sb.flops_exact >= 1e9) cancel_amd.store(true);
       } catch (const std::exception& ex) { eb = std::string("dissection candidate: ") + ex.what(); espec = eb; }
       catch (...) { eb = "dissection candidate failed"; espec = eb; }
     };
@@ -642,11 +653,30 @@ std::string analyze_pattern(int64_t n64, const int64_t* colptr, const int64_t* r
       try { tc = std::thread(run_c); c_started = true; } catch (...) { c_started = false; }
       try { tb = std::thread(run_b); b_started = true; } catch (...) { b_started = false; }
     }
-    try { ea = analyze_one(n64, colptr, rowval, index_base, oa, user_perm, Sa, nullptr, true); }
+    // (serial mode: the dissection first, so that minimum degree can be skipped altogether)
+    if (!b_started) run_b();
+    try { ea = analyze_one(n64, colptr, rowval, index_base, oa, user_perm, Sa, nullptr, true, &cancel_amd); }
     catch (const std::exception& ex) { ea = std::string("minimum-degree analysis: ") + ex.what(); }
     catch (...) { ea = "minimum-degree analysis failed"; }
-    if (b_started) tb.join(); else run_b();
+    if (b_started) tb.join();
     if (c_started) tc.join(); else run_c();
+    const bool skipped = ea == "cancelled" && cancel_amd.load() && espec.empty();
+    if (skipped) {
+      // the level-structure candidate still has a say (mesh-like graphs): it must beat the dissection by 10 %
+      const bool lv = ec.empty() && Sc.ordering_used == 4 && Sc.flops_exact < 0.9 * Sb.flops_exact;
+      if (dbg)
+        fprintf(stderr, "okkt: analyze candidates: AMD abandoned (top separator %ld of %ld) | nested dissection flops %.4g nnz(L) %ld | level-structure dissection flops %.4g -> %s\n",
+                (long)Sb.top_separator, (long)n64, Sb.flops_exact, (long)Sb.nnzL, Sc.flops_exact, lv ? "level-structure dissection" : "nested dissection");
+      if (lv) {
+        const std::vector<int> ord = Sc.perm;
+        std::string e2 = analyze_one(n64, colptr, rowval, index_base, oc, user_perm, S, &ord, false);
+        S.amd_skipped = true; S.flops_other = Sb.flops_exact;
+        return e2;
+      }
+      S = std::move(Sb);
+      S.amd_skipped = true;
+      return "";
+    }
     if (!ea.empty()) return ea;
     const bool b_ok = eb.empty() && Sb.ordering_used == 5 && Sb.flops_exact < 0.9 * Sa.flops_exact && Sa.flops_exact >= 1e9;
     const bool c_ok = ec.empty() && Sc.ordering_used == 4 && Sc.flops_exact < 0.9 * Sa.flops_exact && Sa.flops_exact >= 1e9;
@@ -660,7 +690,7 @@ std::string analyze_pattern(int64_t n64, const int64_t* colptr, const int64_t* r
       return analyze_one(n64, colptr, rowval, index_base, oc, user_perm, S, &ord, false);
     }
     if (nd_wins) {
-      if (espec.empty()) { S = std::move(Sb); return ""; }
+      if (espec.empty()) { const double fa = Sa.flops_exact; S = std::move(Sb); S.flops_other = fa; return ""; }
       const std::vector<int> ord = Sb.perm;
       return analyze_one(n64, colptr, rowval, index_base, ob, user_perm, S, &ord, false);
     }
@@ -668,6 +698,7 @@ std::string analyze_pattern(int64_t n64, const int64_t* colptr, const int64_t* r
     const std::vector<int> ord = Sa.perm;
     std::string e = analyze_one(n64, colptr, rowval, index_base, oa, user_perm, S, &ord, false);
     if (!e.empty()) return e;
+    if (eb.empty() && Sb.ordering_used == 5) S.flops_other = Sb.flops_exact;
   } else {
     std::string e = analyze_one(n64, colptr, rowval, index_base, opts, user_perm, S);
     if (!e.empty() || opts.ordering != 0) return e;

@@ -7,14 +7,16 @@
 // (front layout in HBM, scatter maps, extend-add index lists, level schedule) that the
 // HIP numeric kernels replay for every delta-shift refactorisation.
 #pragma once
+#include <atomic>
 #include <cstdint>
 #include <string>
 #include <vector>
 
 namespace okkt {
 
+// cancel != nullptr: checked at every pivot; when it is set the ordering is abandoned and `order` comes back empty
 void amd_order(int n, const std::vector<int64_t>& ap, const std::vector<int>& ai,
-               std::vector<int>& order);
+               std::vector<int>& order, const std::atomic<bool>* cancel = nullptr);
 
 // level-structure nested dissection (nd.cpp): the parallel ordering for path-like graphs
 void level_nd_order(int n, const std::vector<int64_t>& gp, const std::vector<int>& gi, int leaf, std::vector<int>& order);
@@ -22,7 +24,8 @@ void level_nd_order(int n, const std::vector<int64_t>& gp, const std::vector<int
 // multilevel nested dissection (mlnd.cpp): heavy-edge coarsening, FM-refined bisections, minimum-vertex-cover separators,
 // minimum degree on the pieces of at most `leaf` vertices; the top two levels keep the best of `ntrial_top` bisections.
 // Leaves `order` empty when the graph is beyond its 32-bit offsets (the caller keeps minimum degree).
-void ml_nd_order(int n, const std::vector<int64_t>& gp, const std::vector<int>& gi, int leaf, int ntrial_top, std::vector<int>& order);
+// top_sep != nullptr: receives the size of the top-level separator (-1 when the graph was not bisected)
+void ml_nd_order(int n, const std::vector<int64_t>& gp, const std::vector<int>& gi, int leaf, int ntrial_top, std::vector<int>& order, int* top_sep = nullptr);
 
 struct SymbolicOptions {
   int ordering = 0;        // 0 = AMD, switching to level-structure nested dissection when the AMD tree is a path of small
@@ -56,6 +59,10 @@ struct Symbolic {
   int64_t nnz_in = 0;     // entries in the caller's CSC (all, incl. ignored upper ones)
   int64_t nnz_lower = 0;  // entries with row >= col (the ones that are used)
   bool has_duplicates = false;
+
+  int64_t top_separator = -1;   // multilevel dissection: vertices of the top-level separator (-1: no bisection)
+  bool amd_skipped = false;     // automatic ordering: minimum degree was abandoned because the dissection's top separator is small (no flop comparison)
+  double flops_other = 0;       // automatic ordering: factor flops of the candidate that lost the comparison (0: none / skipped)
 
   std::vector<int> perm;   // perm[new] = old
   std::vector<int> iperm;  // iperm[old] = new
