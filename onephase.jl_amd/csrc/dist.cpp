@@ -203,11 +203,15 @@ RcclApi& rccl() {
   std::call_once(once, [] {
     RcclApi& a = *api;
     const char* names[] = {getenv("OKKT_RCCL_PATH"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-    for (const char* nm : names) {
-      if (!nm) continue;
-      a.lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
-      if (a.lib) break;
-    }
+    // A copy that is in the process already (torch brings its own librccl) is taken first: two RCCL libraries in one process ended in
+    // "double free or corruption" at exit on the ROCm 7.2 boxes (this library had opened /opt/rocm's copy with RTLD_GLOBAL, a later
+    // `import torch` loaded the bundled one on top of its symbols).  RTLD_LOCAL: nothing of RCCL is exported to later loads.
+    for (int pass = 0; pass < 2 && !a.lib; ++pass)
+      for (const char* nm : names) {
+        if (!nm) continue;
+        a.lib = dlopen(nm, RTLD_NOW | RTLD_LOCAL | (pass == 0 ? RTLD_NOLOAD : 0));
+        if (a.lib) break;
+      }
     if (!a.lib) { a.err = std::string("librccl not found: ") + (dlerror() ? dlerror() : ""); return; }
 #define OKKT_SYM(field, name) a.field = (decltype(a.field))dlsym(a.lib, name); if (!a.field) a.err = std::string("librccl lacks ") + name
     OKKT_SYM(GetUniqueId, "ncclGetUniqueId");
@@ -360,7 +364,8 @@ int okkt_dist_solve(okkt_handle h, const double* d_rhs, double* d_sol) {
     if (e.empty()) e = numeric_dist_x(h->N, 0, h->dist_x);
     if (!e.empty()) return solver_set_error(h, OKKT_ERR_HIP, e);
   }
-  if (multi) OKKT_NCCL(h, "ncclBroadcast(separator solution)", a.Broadcast(h->dist_x, h->dist_x, (size_t)h->S.n, ncclDouble, 0, comm, st));
+  // only the top's columns travel (round 4 sent all n doubles for a separator of a few hundred)
+  if (multi && h->N.n_top_cols > 0) OKKT_NCCL(h, "ncclBroadcast(separator solution)", a.Broadcast(h->dist_x, h->dist_x, (size_t)h->N.n_top_cols, ncclDouble, 0, comm, st));
   if (multi || h->rccl_rank != 0) e = numeric_dist_x(h->N, 1, h->dist_x);
   if (e.empty()) e = solve_bwd_enqueue(h->N, 0, 1);
   if (e.empty()) e = numeric_dist_x(h->N, 2, d_sol);

@@ -76,6 +76,7 @@ struct DevPlan {
   int64_t* invl_pos = nullptr;     // [nsuper]
   int* sn_owner = nullptr;     // multi-GPU partition: owner part of each supernode (-1 = top)
   int* col_owner = nullptr;    // the same per permuted column
+  int* top_cols = nullptr;     // the permuted columns of the top (owner -1), ascending: what the separator-solution broadcast carries
   int* bnd = nullptr;          // boundary fronts (subtree roots under a top node)
   int64_t* bnd_cb = nullptr;   // their offsets in the contribution-block exchange buffer
   int64_t* bnd_cv = nullptr;   // ... and in the contribution-vector exchange buffer
@@ -167,6 +168,7 @@ struct Numeric {
   std::vector<LevelSchedule> levels_top;  // top of the tree (part 0 of a partitioned plan only)
   int part_id = 0;
   int n_boundary = 0;
+  int n_top_cols = 0;                    // columns of the top of a partitioned plan
   std::vector<void*> allocations;
   int nb = 64;
   int group = 2;   // block columns per super-step: the trailing update runs with K = group * nb
@@ -258,7 +260,8 @@ void solve_permute_in(const Numeric& N, const double* d_rhs, int64_t stride, int
 void solve_permute_out(const Numeric& N, double* d_sol, int64_t stride, int nr, int R, bool accumulate);
 // what = 0 contribution blocks, 1 contribution vectors; unpack = 0: mine -> buffer, 1: buffer -> the others' slots
 std::string numeric_dist_pack(Numeric& N, int what, int unpack, double* d_buf);
-// mode 0: xwork -> buf; 1: buf -> xwork on top columns; 2: owned part of the solution, original order -> buf
+// mode 0: the top's columns of xwork -> buf, packed (n_top_cols doubles); 1: buf -> xwork on the top's columns; 2: owned part of the solution,
+// original order -> buf (n doubles, zeros elsewhere)
 std::string numeric_dist_x(Numeric& N, int mode, double* d_buf);
 // out[0..3] = pos, neg, zero, nonfinite summed over the counter slots, on the device (no synchronisation)
 void numeric_sum_counts_device(Numeric& N, long long* d_out4);

@@ -1235,6 +1235,12 @@ std::string numeric_setup(const Symbolic& S, const SymbolicOptions& opts, hipStr
       for (int j = S.sn_col0[sn]; j < S.sn_col0[sn + 1]; ++j) col_owner[j] = owner[sn];
     if (!(e = upload(N, owner, &d.sn_owner)).empty()) return e;
     if (!(e = upload(N, col_owner, &d.col_owner)).empty()) return e;
+    {
+      std::vector<int> top_cols;
+      if (parted) for (int j = 0; j < (int)S.n; ++j) if (col_owner[j] == -1) top_cols.push_back(j);
+      N.n_top_cols = (int)top_cols.size();
+      if (!(e = upload(N, top_cols, &d.top_cols)).empty()) return e;
+    }
     N.n_boundary = parted ? (int)S.boundary.size() : 0;
     if (parted) {
       if (!(e = upload(N, S.boundary, &d.bnd)).empty()) return e;
@@ -1915,12 +1921,13 @@ __global__ void k_pack_cv(DevPlan P, const int* __restrict__ bnd, const int64_t*
 // mode 0: buf[col] = xwork[col] (all);  1: xwork[col] = buf[col] for top columns only;
 // mode 2: sol[perm[col]] = owned(col) ? xwork[col] : 0  (owned: my part, or top when I am part 0)
 __global__ void k_exchange_x(int n, const int* __restrict__ col_owner, const int* __restrict__ perm, int part, int mode,
-                             double* __restrict__ xwork, double* __restrict__ buf) {
+                             double* __restrict__ xwork, double* __restrict__ buf, const int* __restrict__ top_cols, int ntop) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (mode == 0) { if (c < ntop) buf[c] = xwork[top_cols[c]]; return; }      // the separator solution, packed: only the top's columns travel
+  if (mode == 1) { if (c < ntop) xwork[top_cols[c]] = buf[c]; return; }
   if (c >= n) return;
-  if (mode == 0) buf[c] = xwork[c];
-  else if (mode == 1) { if (col_owner[c] == -1) xwork[c] = buf[c]; }
-  else { const int o = col_owner[c]; buf[perm[c]] = (o == part || (o == -1 && part == 0)) ? xwork[c] : 0.0; }
+  const int o = col_owner[c];
+  buf[perm[c]] = (o == part || (o == -1 && part == 0)) ? xwork[c] : 0.0;
 }
 
 __global__ void k_sum_counts(const unsigned long long* __restrict__ counters, long long* __restrict__ out) {
@@ -1943,7 +1950,8 @@ std::string numeric_dist_pack(Numeric& N, int what, int unpack, double* d_buf) {
 }
 std::string numeric_dist_x(Numeric& N, int mode, double* d_buf) {
   const int n = N.d.n;
-  if (n) hipLaunchKernelGGL(k_exchange_x, dim3((n + 255) / 256), dim3(256), 0, N.stream, n, N.d.col_owner, N.d.perm, N.part_id, mode, N.d.xwork, d_buf);
+  const int cnt = mode == 2 ? n : N.n_top_cols;
+  if (cnt) hipLaunchKernelGGL(k_exchange_x, dim3((cnt + 255) / 256), dim3(256), 0, N.stream, n, N.d.col_owner, N.d.perm, N.part_id, mode, N.d.xwork, d_buf, N.d.top_cols, N.n_top_cols);
   OKKT_HIP_TRY(hipGetLastError());
   return "";
 }
