@@ -45,11 +45,7 @@ constexpr int kDfThreadsC = 512;   // threads of a worker
 #define OKKT_DF_STAGGER 1
 #endif
 constexpr bool kDfStagger = OKKT_DF_STAGGER != 0;   // waves 4 - 7 of a worker request the next operand chunk half a chunk behind waves 0 - 3
-#ifndef OKKT_DIAG2_PIPE
-#define OKKT_DIAG2_PIPE 0
-#endif
-constexpr bool kDfDiagPipe = OKKT_DIAG2_PIPE != 0;   // experiment: the 8 x 8 block factorisation of a micro-step once, by wave 6, handed on column by column through LDS (slower: 50.6 against 34.5 us per diagonal block)
-constexpr int kDfDiagMfmaWaves = kDfDiagPipe ? 4 : 6;   // MFMA waves of the diagonal-block factorisation in a worker (four or six: the same time)
+constexpr int kDfDiagMfmaWaves = 6;   // MFMA waves of the diagonal-block factorisation in a worker (four or six: the same time)
 constexpr int kDfKC = OKKT_DF_KC;           // panel columns per ring slot of the update tasks
 constexpr int kDfStages = OKKT_DF_STAGES;   // operand ring of the update tasks: 16-column chunks in LDS (one workgroup per CU: nobody else covers a chunk that is late)
 
@@ -1174,7 +1170,7 @@ __global__ __launch_bounds__(kDfThreads, 1) void k_front_dataflow(DevPlan P, con
     int* mine;
     int newv, npub = 1;
     if (type == kDfD) {
-      if (!(dbg & 1)) diag2_body<true, kDiag2MW, kDfDiagMfmaWaves, kDfDiagPipe>(P, s, i, 128, tol, sm, nullptr, 0, tlog ? tlog + (size_t)t * 8 + 4 : nullptr);
+      if (!(dbg & 1)) diag2_body<true, kDiag2MW, kDfDiagMfmaWaves>(P, s, i, 128, tol, sm, nullptr, 0, tlog ? tlog + (size_t)t * 8 + 4 : nullptr);
       mine = st + (size_t)i * TB + i; newv = i + 1;
     } else if (type == kDfT) {
       if (!(dbg & 2)) df_trsm_tile(P, s, j, df_block_lo(i, KB, k, f), df_block_lo(i + 1, KB, k, f), sm);
@@ -1193,7 +1189,7 @@ __global__ __launch_bounds__(kDfThreads, 1) void k_front_dataflow(DevPlan P, con
       if (type == kDfTA) {
         mine = hs; newv = 2;
       } else if (with_d) {
-        diag2_body<true, kDiag2MW, kDfDiagMfmaWaves, kDfDiagPipe>(P, s, i, 128, tol, sm, sm, kDfTileLd);
+        diag2_body<true, kDiag2MW, kDfDiagMfmaWaves>(P, s, i, 128, tol, sm, sm, kDfTileLd);
         mine = st + (size_t)i * TB + i; newv = i + 1;          // tile (q + 1, q) was published inside the task
       } else {
         mine = st + (size_t)i * TB + j; newv = j + 1;

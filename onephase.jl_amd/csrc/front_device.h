@@ -127,7 +127,7 @@ __device__ __forceinline__ double ld_agent_f64(const double* p) { return __hip_a
 constexpr int kDiag2MW = OKKT_DIAG2_MW;     // columns per micro-step of diag2_body (8: round 3; 4 halves the redundant block factorisation of the row threads for twice the barriers)
 // tile_lds != nullptr (dataflow.hip, TU + D in one task): the block comes from LDS (column-major, leading dimension tile_ld, written
 // by the same workgroup) instead of the front in HBM; it overlaps this function's own LDS areas, hence the barrier behind the loads
-template <bool AG, int MW = kDiag2MW, int NMM = 4, bool PIPE = false>
+template <bool AG, int MW = kDiag2MW, int NMM = 4>
 __device__ __forceinline__ void diag2_body(const DevPlan& P, int s, int step, int NB, double tol, double* sm, const double* tile_lds = nullptr, int tile_ld = 0, long long* marks = nullptr) {
   static_assert(MW == 8 || MW == 4, "micro-panels of 4 or 8 columns");
   constexpr int NE = MW / 4;                   // MFMA k-steps (4 columns each) per micro-panel
@@ -149,20 +149,12 @@ __device__ __forceinline__ void diag2_body(const DevPlan& P, int s, int step, in
   double* Ld = WpB + 2 * MW * kPLD;           // 4 diagonal 32 x 32 blocks of L, leading dimension 33
   double* Xs = Ld + 4 * 32 * kXld;             // their inverses
   double* dpiv = Xs + 4 * 32 * kXld;           // the 128 pivots, for the waves that count them behind the loop
-  // PIPE (experiment, -DOKKT_DIAG2_PIPE=1, 512-thread workers of the dataflow launch): the 8 x 8 diagonal factorisation of a micro-step
-  // is done ONCE, by wave 6, and handed to the row threads column by column through LDS -- reciprocal and multipliers of column c, then
-  // a flag word -- instead of being repeated by every row thread (188 of the 460 instructions of its micro-step).  Same operations on
-  // the same numbers, bitwise the same factor -- and SLOWER: 50.6 us per diagonal block against 34.5.  Every column costs the consumers
-  // two LDS round trips (flag, then operands) behind the producer's write, 8 x 300 cycles per micro-step: repeating the block
-  // factorisation in every row thread is the latency-optimal form.
-  double* fac_rd = dpiv + 128;                 // [MW] reciprocals
-  double* fac_a = fac_rd + MW;                 // [MW][MW]: entry (j, c), j > c, as the row solve of column c needs it
-  // the flag word: MW * ms + c + 1 once column c of micro-step ms is there.  Read and written with explicit LDS instructions on its
-  // LDS offset (the low half of the generic address): a volatile access through the generic pointer makes hipcc emit an illegal
-  // compare against src_shared_base
-  const unsigned fac_flag = (unsigned)(uintptr_t)(fac_a + MW * MW);
-  auto flag_store = [&](int v) { asm volatile("ds_write_b32 %0, %1" : : "v"(fac_flag), "v"(v) : "memory"); };
-  auto flag_load = [&]() { int v; asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(fac_flag) : "memory"); return v; };
+  // The 8 x 8 diagonal block of a micro-step is factored by EVERY row thread (188 of the 460 instructions of its micro-step).  Doing it
+  // once was tried twice and is slower both ways: handed on column by column through LDS flags (round 4: 50.6 us per diagonal block
+  // against 34.5; scripts/experiments/r04_diag2_pipe.patch) and as a whole behind one flag (round 5: wave 0 factors, wave 1 waits and
+  // solves with 36 multiply-adds -- 71 us between two diagonal blocks against 63; r05_diag2_factor_once.patch).  The factorisation is a
+  // dependent chain of eight reciprocals (about 1 us on a wave that has nothing else to issue); a row thread that repeats it interleaves
+  // the chain with its own row's independent work, which is what hides it.
   double* F = P.arena + P.front_pos[s];
   // MFMA waves: NMM of them from wave 2 on.  Four in a 384-thread workgroup (k_big_diag2: one per SIMD, the two row waves share two of the
   // SIMDs); six in the 512-thread workers of the dataflow launch, whose waves 6 and 7 would otherwise only meet the barriers -- a wave
@@ -207,7 +199,6 @@ __device__ __forceinline__ void diag2_body(const DevPlan& P, int s, int step, in
     }
   }
   if (tile_lds) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __syncthreads(); }      // every MFMA wave holds its tiles: the LDS below may be written
-  if (PIPE && tid == 0) flag_store(0);         // ordered before its first reader by the first barrier of the loop
   double my_d = 1.0;
   const int nms = (nb + MW - 1) / MW;        // micro-steps
   // marks (task log of the dataflow launch, wave 0 = a row wave): time spent waiting for the head (barrier 1), in the row phase,
@@ -253,70 +244,29 @@ __device__ __forceinline__ void diag2_body(const DevPlan& P, int s, int step, in
       // row threads: 8 x 8 diagonal LDL^T redundantly in registers, own row solved, panels and final entries written
       double* Lp = LpB + (ms & 1) * MW * kPLD;
       double* Wp = WpB + (ms & 1) * MW * kPLD;
-      if (PIPE && wave == 6) {
-        // the factor wave: every lane holds the whole block (broadcast reads), lane 0 publishes
-        double A[MW][MW];
-#pragma unroll
-        for (int c = 0; c < MW; ++c)
-#pragma unroll
-          for (int i = c; i < MW; ++i) A[i][c] = Praw[c * kPLD + p8 + i];
-#pragma unroll
-        for (int c = 0; c < MW; ++c) {
-          const double rdc = fast_rcp_f64(A[c][c]);
-          if (lane == 0) {
-#pragma unroll
-            for (int j = c + 1; j < MW; ++j) fac_a[j * MW + c] = A[j][c];
-            fac_rd[c] = rdc;
-          }
-          asm volatile("" ::: "memory");          // the flag is written after the column (LDS executes a wave's operations in order)
-          if (lane == 0) flag_store(MW * ms + c + 1);
-          asm volatile("" ::: "memory");
-#pragma unroll
-          for (int i = c + 1; i < MW; ++i) {
-            const double lic = A[i][c] * rdc;
-#pragma unroll
-            for (int j = c + 1; j <= i; ++j) A[i][j] = __builtin_fma(-lic, A[j][c], A[i][j]);
-          }
-        }
-      }
       if (tid >= p8 && tid < 128) {
         const int r = tid;
         double a[MW], w[MW], lr[MW];
-        if constexpr (PIPE) {
+        double A[MW][MW], rd[MW];
 #pragma unroll
-          for (int c = 0; c < MW; ++c) a[c] = Praw[c * kPLD + r];
+        for (int c = 0; c < MW; ++c) {
+          a[c] = Praw[c * kPLD + r];
 #pragma unroll
-          for (int c = 0; c < MW; ++c) {
-            while (flag_load() < MW * ms + c + 1) {}      // column c of this micro-step has been published
-            asm volatile("" ::: "memory");
-            const double rdc = fac_rd[c];
-            w[c] = a[c];
-            lr[c] = w[c] * rdc;
+          for (int i = c; i < MW; ++i) A[i][c] = Praw[c * kPLD + p8 + i];
+        }
 #pragma unroll
-            for (int j = c + 1; j < MW; ++j) a[j] = __builtin_fma(-lr[c], fac_a[j * MW + c], a[j]);
-          }
-        } else {
-          double A[MW][MW], rd[MW];
+        for (int c = 0; c < MW; ++c) {
+          rd[c] = fast_rcp_f64(A[c][c]);
+          w[c] = a[c];
+          lr[c] = w[c] * rd[c];
 #pragma unroll
-          for (int c = 0; c < MW; ++c) {
-            a[c] = Praw[c * kPLD + r];
+          for (int i = c + 1; i < MW; ++i) {
+            const double lic = A[i][c] * rd[c];
 #pragma unroll
-            for (int i = c; i < MW; ++i) A[i][c] = Praw[c * kPLD + p8 + i];
+            for (int j = c + 1; j <= i; ++j) A[i][j] = __builtin_fma(-lic, A[j][c], A[i][j]);
           }
 #pragma unroll
-          for (int c = 0; c < MW; ++c) {
-            rd[c] = fast_rcp_f64(A[c][c]);
-            w[c] = a[c];
-            lr[c] = w[c] * rd[c];
-#pragma unroll
-            for (int i = c + 1; i < MW; ++i) {
-              const double lic = A[i][c] * rd[c];
-#pragma unroll
-              for (int j = c + 1; j <= i; ++j) A[i][j] = __builtin_fma(-lic, A[j][c], A[i][j]);
-            }
-#pragma unroll
-            for (int j = c + 1; j < MW; ++j) a[j] = __builtin_fma(-lr[c], A[j][c], a[j]);
-          }
+          for (int j = c + 1; j < MW; ++j) a[j] = __builtin_fma(-lr[c], A[j][c], a[j]);
         }
         // outputs.  The entries below the diagonal are L; a diagonal row also stores its pivot at its own column (one store at a
         // per-lane address instead of a select per column in every row thread); the columns of a micro-step lie in ONE 32-column
