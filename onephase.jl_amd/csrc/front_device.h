@@ -154,7 +154,10 @@ __device__ __forceinline__ void diag2_body(const DevPlan& P, int s, int step, in
   // against 34.5; scripts/experiments/r04_diag2_pipe.patch) and as a whole behind one flag (round 5: wave 0 factors, wave 1 waits and
   // solves with 36 multiply-adds -- 71 us between two diagonal blocks against 63; r05_diag2_factor_once.patch).  The factorisation is a
   // dependent chain of eight reciprocals (about 1 us on a wave that has nothing else to issue); a row thread that repeats it interleaves
-  // the chain with its own row's independent work, which is what hides it.
+  // the chain with its own row's independent work, which is what hides it.  The multipliers as scalar operands through v_readlane
+  // from copies of the diagonal rows in the finished lanes of both row waves (r05_diag2_readlane.patch: 72 readlanes instead of the 188
+  // instructions) is bitwise equal and time-neutral: the row solve is 0.41 us of a 1.8 us micro-step, the rest is two barriers and
+  // four LDS round trips.
   double* F = P.arena + P.front_pos[s];
   // MFMA waves: NMM of them from wave 2 on.  Four in a 384-thread workgroup (k_big_diag2: one per SIMD, the two row waves share two of the
   // SIMDs); six in the 512-thread workers of the dataflow launch, whose waves 6 and 7 would otherwise only meet the barriers -- a wave

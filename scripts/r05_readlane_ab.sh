@@ -1,0 +1,17 @@
+#!/bin/bash
+# GPU box: the diagonal block's row solve with v_readlane multipliers against the private 8 x 8 factorisation per row thread (lib_rl0.so):
+# D, L and x bit for bit, then the step times.
+for c in dense700 dense2600 S-C3; do
+  OKKT_LIB_PATH=scripts/_bin/lib_rl0.so timeout 300 python scripts/df_check.py --run $c /tmp/rl0_$c.npz > /dev/null 2>&1
+  timeout 300 python scripts/df_check.py --run $c /tmp/rl1_$c.npz > /dev/null 2>&1
+  python3 - $c <<'PY'
+import sys, numpy as np
+c = sys.argv[1]
+a, b = np.load(f"/tmp/rl0_{c}.npz"), np.load(f"/tmp/rl1_{c}.npz")
+print(c, "D equal", np.array_equal(a["d"], b["d"]), "x equal", np.array_equal(a["x"], b["x"]), "L equal", ("Ldata" in a.files and np.array_equal(a["Ldata"], b["Ldata"])), "factor ms", a["tf"].min().round(3), "->", b["tf"].min().round(3), "resid", float(b["res"]))
+PY
+done
+for c in S-metric S-C3 S-C5; do
+  echo -n "private 8x8: "; OKKT_LIB_PATH=scripts/_bin/lib_rl0.so timeout 300 python scripts/step_probe.py $c 2>&1 | tail -1
+  echo -n "readlane   : "; timeout 300 python scripts/step_probe.py $c 2>&1 | tail -1
+done
