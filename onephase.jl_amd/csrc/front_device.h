@@ -207,8 +207,41 @@ __device__ __forceinline__ void diag2_body(const DevPlan& P, int s, int step, in
   // marks (task log of the dataflow launch, wave 0 = a row wave): time spent waiting for the head (barrier 1), in the row phase,
   // waiting for the rest of the update (barrier 2), and the start of the tail behind the loop
   long long tk = marks ? wall_clock64() : 0, t_head = 0, t_row = 0, t_rest = 0;
+  // row threads: the multipliers and W values of the last micro-step, kept in registers until its outputs are written
+  double lr_keep[MW], w_keep[MW];
+  int p8_keep = -1;
+  auto row_outputs = [&]() {
+    // The entries below the diagonal are L; a diagonal row also stores its pivot at its own column (one store at a per-lane address
+    // instead of a select per column in every row thread); the columns of a micro-step lie in ONE 32-column block (p8 is a multiple
+    // of MW), so whether the row belongs to that diagonal 32 x 32 block is decided once.
+    const int p8 = p8_keep;
+    if (p8 < 0 || mm || tid < p8 || tid >= 128) return;
+    const int r = tid;
+    const int i = r - p8;
+    double* Fr = F + (size_t)(j0 + p8) * f + j0 + r;
+    const bool rv = r < nb;
+    const bool inblk = (r >> 5) == (p8 >> 5);
+    double* Ldr = Ld + (r >> 5) * 32 * kXld + (r & 31) + (p8 & 31) * kXld;
+#pragma unroll
+    for (int c = 0; c < MW; ++c) {
+      if (i > c && rv && p8 + c < nb) {
+        if (AG) st_agent_f64(&Fr[(size_t)c * f], lr_keep[c]); else Fr[(size_t)c * f] = lr_keep[c];
+        if (inblk) Ldr[c * kXld] = lr_keep[c];
+      }
+    }
+    if (i < MW) {
+#pragma unroll
+      for (int c = 0; c < MW; ++c) my_d = i == c ? w_keep[c] : my_d;
+      dpiv[r] = my_d;
+      if (rv) {
+        if (AG) st_agent_f64(&Fr[(size_t)i * f], my_d); else Fr[(size_t)i * f] = my_d;
+        Ldr[i * kXld] = my_d;
+      }
+    }
+  };
   for (int ms = 0; ms < nms; ++ms) {
     const int p8 = ms * MW, pp = ms / PER, h = ms % PER;
+    row_outputs();      // of micro-step ms - 1, beside the MFMA waves' head of this one
     const double* Lprev = LpB + ((ms + 1) & 1) * MW * kPLD;    // panels of micro-step ms - 1
     const double* Wprev = WpB + ((ms + 1) & 1) * MW * kPLD;
     if (mm) {
@@ -244,12 +277,14 @@ __device__ __forceinline__ void diag2_body(const DevPlan& P, int s, int step, in
     asm volatile("" ::: "memory");
     if (marks && tid == 0) { const long long tn = wall_clock64(); t_head += tn - tk; tk = tn; }
     if (!mm) {
-      // row threads: 8 x 8 diagonal LDL^T redundantly in registers, own row solved, panels and final entries written
+      // row threads: 8 x 8 diagonal LDL^T redundantly in registers, own row solved, the panels -L and W written for the MFMA waves.
+      // The entries nobody waits for inside the loop (L to memory, the block's copy for the inverses, the pivots) are written
+      // BEHIND the barrier, while the MFMA waves work on the head of the next micro-step (row_outputs, called at the top of the loop).
       double* Lp = LpB + (ms & 1) * MW * kPLD;
       double* Wp = WpB + (ms & 1) * MW * kPLD;
       if (tid >= p8 && tid < 128) {
         const int r = tid;
-        double a[MW], w[MW], lr[MW];
+        double a[MW];
         double A[MW][MW], rd[MW];
 #pragma unroll
         for (int c = 0; c < MW; ++c) {
@@ -260,8 +295,8 @@ __device__ __forceinline__ void diag2_body(const DevPlan& P, int s, int step, in
 #pragma unroll
         for (int c = 0; c < MW; ++c) {
           rd[c] = fast_rcp_f64(A[c][c]);
-          w[c] = a[c];
-          lr[c] = w[c] * rd[c];
+          w_keep[c] = a[c];
+          lr_keep[c] = w_keep[c] * rd[c];
 #pragma unroll
           for (int i = c + 1; i < MW; ++i) {
             const double lic = A[i][c] * rd[c];
@@ -269,35 +304,15 @@ __device__ __forceinline__ void diag2_body(const DevPlan& P, int s, int step, in
             for (int j = c + 1; j <= i; ++j) A[i][j] = __builtin_fma(-lic, A[j][c], A[i][j]);
           }
 #pragma unroll
-          for (int j = c + 1; j < MW; ++j) a[j] = __builtin_fma(-lr[c], A[j][c], a[j]);
+          for (int j = c + 1; j < MW; ++j) a[j] = __builtin_fma(-lr_keep[c], A[j][c], a[j]);
         }
-        // outputs.  The entries below the diagonal are L; a diagonal row also stores its pivot at its own column (one store at a
-        // per-lane address instead of a select per column in every row thread); the columns of a micro-step lie in ONE 32-column
-        // block (p8 is a multiple of MW), so whether the row belongs to that diagonal 32 x 32 block is decided once.
-        const int i = r - p8;
-        double* Fr = F + (size_t)(j0 + p8) * f + j0 + r;
-        const bool rv = r < nb;
-        const bool inblk = (r >> 5) == (p8 >> 5);
-        double* Ldr = Ld + (r >> 5) * 32 * kXld + (r & 31) + (p8 & 31) * kXld;
 #pragma unroll
         for (int c = 0; c < MW; ++c) {
-          Lp[c * kPLD + r] = -lr[c];
-          Wp[c * kPLD + r] = w[c];
-          if (i > c && rv && p8 + c < nb) {
-            if (AG) st_agent_f64(&Fr[(size_t)c * f], lr[c]); else Fr[(size_t)c * f] = lr[c];
-            if (inblk) Ldr[c * kXld] = lr[c];
-          }
-        }
-        if (i < MW) {
-#pragma unroll
-          for (int c = 0; c < MW; ++c) my_d = i == c ? w[c] : my_d;
-          dpiv[r] = my_d;
-          if (rv) {
-            if (AG) st_agent_f64(&Fr[(size_t)i * f], my_d); else Fr[(size_t)i * f] = my_d;
-            Ldr[i * kXld] = my_d;
-          }
+          Lp[c * kPLD + r] = -lr_keep[c];
+          Wp[c * kPLD + r] = w_keep[c];
         }
       }
+      p8_keep = p8;
     } else if (ms > 0) {
       // rest of the update of step ms - 1: the tile columns to the right of panel ms's
 #pragma unroll
@@ -317,6 +332,10 @@ __device__ __forceinline__ void diag2_body(const DevPlan& P, int s, int step, in
     asm volatile("" ::: "memory");
     if (marks && tid == 0) { const long long tn = wall_clock64(); t_rest += tn - tk; tk = tn; }
   }
+  row_outputs();        // of the last micro-step; the inverses below read the block's copy, the pivot counts read dpiv
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
   if (marks && tid == 0) { marks[0] = t_head; marks[1] = t_row; marks[2] = t_rest; marks[3] = wall_clock64(); }
   (void)my_d;
   if (wave == 4 || wave == 5) {

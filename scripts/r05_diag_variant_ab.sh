@@ -1,5 +1,5 @@
 #!/bin/bash
-# GPU box: the diagonal block's row solve with v_readlane multipliers against the private 8 x 8 factorisation per row thread (lib_rl0.so):
+# GPU box: A/B of a diagonal-block variant (the tree) against an older build (scripts/_bin/lib_rl0.so = the round-4 row phase):
 # D, L and x bit for bit, then the step times.
 for c in dense700 dense2600 S-C3; do
   OKKT_LIB_PATH=scripts/_bin/lib_rl0.so timeout 300 python scripts/df_check.py --run $c /tmp/rl0_$c.npz > /dev/null 2>&1
@@ -12,6 +12,6 @@ print(c, "D equal", np.array_equal(a["d"], b["d"]), "x equal", np.array_equal(a[
 PY
 done
 for c in S-metric S-C3 S-C5; do
-  echo -n "private 8x8: "; OKKT_LIB_PATH=scripts/_bin/lib_rl0.so timeout 300 python scripts/step_probe.py $c 2>&1 | tail -1
-  echo -n "readlane   : "; timeout 300 python scripts/step_probe.py $c 2>&1 | tail -1
+  echo -n "old build  : "; OKKT_LIB_PATH=scripts/_bin/lib_rl0.so timeout 300 python scripts/step_probe.py $c 2>&1 | tail -1
+  echo -n "this tree  : "; timeout 300 python scripts/step_probe.py $c 2>&1 | tail -1
 done
