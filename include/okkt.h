@@ -178,13 +178,7 @@ int okkt_get_profile(okkt_handle h, int64_t* n_launches, double* total_ms, doubl
  * the queue on a dense matrix with numpy and checks the dependency order. */
 int64_t okkt_debug_dataflow_queue(int32_t nfronts, const int32_t* f, const int32_t* k, int32_t workers, int32_t group,
                                   int32_t* tasks, int64_t cap, double* model_us);
-/* The same level in the two-kernel form (csrc/dataflow.hip: k_front_bulk beside the chain kernel): the queue built for `workers` bulk
- * workers and `chain_workers` chain workers and cut by df_split_queue.  tasks receives the chain queue (D / TA / TU) followed by the
- * eight per-XCD queues of panel tiles and updates; qlen[0] = length of the chain queue, qlen[1 .. 8] = lengths of the eight bulk
- * queues.  Returns the total number of tasks.  tests/test_dataflow_queue.py replays the nine queues under the kernels' pop rule
- * (each queue in order, any interleaving between queues) and checks that some queue's head is always runnable. */
-int64_t okkt_debug_dataflow_split(int32_t nfronts, const int32_t* f, const int32_t* k, int32_t workers, int32_t chain_workers, int32_t group,
-                                  int32_t* tasks, int64_t cap, int32_t* qlen);
+
 
 /* ---- multi-GPU: subtree-to-GPU sharding of ONE factorisation (one process per GPU) -------------------
  * No reference counterpart (the reference is single-process).  Every rank analyses the same

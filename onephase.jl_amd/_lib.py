@@ -159,7 +159,6 @@ SIGNATURES = {
     "okkt_profile_dominant": (C.c_int, [_vp, C.c_int]),
     "okkt_get_profile": (C.c_int, [_vp, _i64p, _f64p, _f64p]),
     "okkt_debug_dataflow_queue": (C.c_int64, [C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.c_int64, _f64p]),
-    "okkt_debug_dataflow_split": (C.c_int64, [C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.c_int64, C.POINTER(C.c_int32)]),
     "okkt_dist_set_partition": (C.c_int, [_vp, C.c_int, C.c_int]),
     "okkt_dist_info": (C.c_int, [_vp, _i64p, _i64p, _i64p, _f64p, _f64p]),
     "okkt_dist_get_owner": (C.c_int, [_vp, _i64p, _i64p, _i64p]),

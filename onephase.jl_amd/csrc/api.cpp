@@ -36,8 +36,6 @@ int solver_ensure_numeric(okkt_solver_s* h) {
   h->N.stream_masked = h->stream_masked;     // before the set-up: the lanes of the plan are given streams there
   h->N.stream_panel = h->stream_panel;
   h->N.stream_aux = h->stream_aux;
-  h->N.stream_chain = h->stream_chain;
-  h->N.df_chain_workers = h->stream_reserved;
   if (const char* fl = getenv("OKKT_FLOW")) h->N.flow = atoi(fl);   // read by the set-up
   if (const char* df = getenv("OKKT_DATAFLOW")) h->N.dataflow = atoi(df);
   if (const char* sf = getenv("OKKT_SOLVE_FLOW")) h->N.solve_flow = atoi(sf);   // read by the set-up (it sizes the partial-product buffers)
@@ -155,7 +153,7 @@ int okkt_default_opts(okkt_opts* o) {
 // -- the runtime's hardware-queue assignment of later streams differs -- while a reused set keeps the first timing.
 struct StreamSet {
   int device = -1, la = 0, reserved = 0, seq = 0;   // seq: order of creation in this process (1, 2, ...)
-  hipStream_t stream = nullptr, masked = nullptr, panel = nullptr, aux = nullptr, chain = nullptr;   // chain: CU mask of exactly the reserved CUs (the chain kernel of the dataflow levels' two-kernel form)
+  hipStream_t stream = nullptr, masked = nullptr, panel = nullptr, aux = nullptr;
 };
 // heap objects that are never destructed: no static-destruction order to get wrong at process exit
 static std::mutex& pool_mutex() { static std::mutex* m = new std::mutex; return *m; }
@@ -171,7 +169,7 @@ static void pool_close() {
   g_pool_closed = true;
   for (const StreamSet& set : pool_all()) {
     if (hipSetDevice(set.device) != hipSuccess) continue;
-    for (hipStream_t q : {set.chain, set.aux, set.panel, set.masked, set.stream})
+    for (hipStream_t q : {set.aux, set.panel, set.masked, set.stream})
       if (q) { (void)hipStreamSynchronize(q); (void)hipStreamDestroy(q); }
   }
   pool_all().clear();
@@ -259,14 +257,12 @@ int okkt_create(okkt_handle* out, const okkt_opts* opts) {
     if (reserved > ncu / 2) reserved = ncu / 2;
     StreamSet set;
     if (take_stream_set(dev, la ? 1 : 0, reserved, &set)) {
-      h->stream = set.stream; h->stream_masked = set.masked; h->stream_panel = set.panel; h->stream_aux = set.aux; h->stream_chain = set.chain;
+      h->stream = set.stream; h->stream_masked = set.masked; h->stream_panel = set.panel; h->stream_aux = set.aux;
       h->stream_seq = set.seq;
     } else if (la) {
       std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
       for (int b = reserved; b < ncu; ++b) mask[(size_t)b >> 5] |= 1u << (b & 31);
       int lo = 0, hi = 0;
-      std::vector<uint32_t> cmask((size_t)(ncu + 31) / 32, 0u);     // the complement: the reserved CUs (one per XCD at the default)
-      for (int b = 0; b < reserved; ++b) cmask[(size_t)b >> 5] |= 1u << (b & 31);
       if (hipExtStreamCreateWithCUMask(&h->stream_masked, (uint32_t)mask.size(), mask.data()) != hipSuccess ||
           hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess ||
           hipStreamCreateWithPriority(&h->stream_panel, hipStreamNonBlocking, hi) != hipSuccess ||
@@ -276,14 +272,11 @@ int okkt_create(okkt_handle* out, const okkt_opts* opts) {
         if (h->stream_panel) { (void)hipStreamDestroy(h->stream_panel); }
         h->stream_panel = nullptr;
         h->stream_aux = nullptr;
-      } else if (hipExtStreamCreateWithCUMask(&h->stream_chain, (uint32_t)cmask.size(), cmask.data()) != hipSuccess) {
-        (void)hipGetLastError();
-        h->stream_chain = nullptr;      // the dataflow levels then keep their one-kernel form
       }
     }
     if (!h->stream && hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
       // nothing of this set is registered yet: destroy the look-ahead streams that were created above
-      for (hipStream_t q : {h->stream_masked, h->stream_panel, h->stream_aux, h->stream_chain}) if (q) (void)hipStreamDestroy(q);
+      for (hipStream_t q : {h->stream_masked, h->stream_panel, h->stream_aux}) if (q) (void)hipStreamDestroy(q);
       delete h;
       return OKKT_ERR_HIP;
     }
@@ -291,7 +284,7 @@ int okkt_create(okkt_handle* out, const okkt_opts* opts) {
     h->stream_reserved = reserved;
     if (set.device < 0) {   // a new set: the pool owns its streams from now on
       set.device = dev; set.la = h->stream_la; set.reserved = reserved;
-      set.stream = h->stream; set.masked = h->stream_masked; set.panel = h->stream_panel; set.aux = h->stream_aux; set.chain = h->stream_chain;
+      set.stream = h->stream; set.masked = h->stream_masked; set.panel = h->stream_panel; set.aux = h->stream_aux;
       register_stream_set(set);
       h->stream_seq = pool_size();
     }
@@ -327,12 +320,12 @@ int okkt_destroy(okkt_handle h) {
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     // the streams go back to the pool (idle: everything on them was synchronised above or joined into h->stream)
-    for (hipStream_t q : {h->stream_masked, h->stream_panel, h->stream_aux, h->stream_chain})
+    for (hipStream_t q : {h->stream_masked, h->stream_panel, h->stream_aux})
       if (q) (void)hipStreamSynchronize(q);
     if (h->stream) {
       StreamSet set;
       set.device = h->device; set.la = h->stream_la; set.reserved = h->stream_reserved;
-      set.stream = h->stream; set.masked = h->stream_masked; set.panel = h->stream_panel; set.aux = h->stream_aux; set.chain = h->stream_chain;
+      set.stream = h->stream; set.masked = h->stream_masked; set.panel = h->stream_panel; set.aux = h->stream_aux;
       set.seq = h->stream_seq;
       give_stream_set(set);
     }
@@ -641,39 +634,12 @@ int64_t okkt_debug_dataflow_queue(int32_t nfronts, const int32_t* f, const int32
     }
     std::vector<okkt::DfTask> q;
     double model = 0;
-    okkt::df_build_queue(fronts, workers, group & 255, std::max(1, (group >> 8) & 255), (group >> 16) & 1, (group >> 17) & 1, q, &model, 0, 1.0f, (group >> 18) & 1);
+    okkt::df_build_queue(fronts, workers, group & 255, std::max(1, (group >> 8) & 255), (group >> 16) & 1, (group >> 17) & 1, q, &model, (group >> 18) & 1);
     if (model_us) *model_us = model;
     for (int64_t t = 0; t < (int64_t)q.size() && t < cap; ++t) {
       tasks[4 * t] = q[t].front; tasks[4 * t + 1] = q[t].type_nq; tasks[4 * t + 2] = q[t].ij; tasks[4 * t + 3] = q[t].q0;
     }
     return (int64_t)q.size();
-  } catch (...) { return OKKT_ERR_ALLOC; }
-}
-
-int64_t okkt_debug_dataflow_split(int32_t nfronts, const int32_t* f, const int32_t* k, int32_t workers, int32_t chain_workers, int32_t group,
-                                  int32_t* tasks, int64_t cap, int32_t* qlen) {
-  if (nfronts < 0 || !f || !k || !qlen || (cap > 0 && !tasks) || chain_workers < 1) return OKKT_ERR_INVALID;
-  try {
-    std::vector<okkt::DfFront> fronts;
-    for (int a = 0; a < nfronts; ++a) {
-      if (k[a] < 1 || f[a] < k[a]) return OKKT_ERR_INVALID;
-      fronts.push_back({a, f[a], k[a]});
-    }
-    std::vector<okkt::DfTask> q, chain, bulk[8];
-    double model = 0;
-    okkt::df_build_queue(fronts, workers, group & 255, 1, (group >> 16) & 1, (group >> 17) & 1, q, &model, chain_workers, 1.7f, (group >> 18) & 1);
-    okkt::df_split_queue(fronts, q, chain, bulk);
-    int64_t t = 0;
-    auto put = [&](const std::vector<okkt::DfTask>& v) {
-      for (const okkt::DfTask& x : v) {
-        if (t < cap) { tasks[4 * t] = x.front; tasks[4 * t + 1] = x.type_nq; tasks[4 * t + 2] = x.ij; tasks[4 * t + 3] = x.q0; }
-        ++t;
-      }
-    };
-    put(chain);
-    qlen[0] = (int32_t)chain.size();
-    for (int x = 0; x < 8; ++x) { put(bulk[x]); qlen[1 + x] = (int32_t)bulk[x].size(); }
-    return t;
   } catch (...) { return OKKT_ERR_ALLOC; }
 }
 

@@ -654,9 +654,9 @@ __device__ __forceinline__ bool df_tu_tile(const DevPlan& P, int s, int q, int r
 // chunks: the C tile of the next row block is requested while the current one is in its main loop (raw pairs in registers, masked
 // when the accumulators switch), its first operand chunk follows the last chunk of the current tile through the ring, and the
 // stores of a finished tile drain behind the next tile's first chunk.
-// KC / STAGES: panel columns per ring slot and slots (32 x 2 for the one-workgroup-per-CU worker, 16 x 2 = 72 KB for the bulk kernel that
-// runs two workgroups per CU); MULTI: a task may carry several row tiles (the next C tile in a second register set: the bulk kernel's
-// 128-VGPR budget has no room for it and its partner workgroup covers the prologue instead); STAGGER: see below.
+// KC / STAGES: panel columns per ring slot and slots (32 x 2 for the one-workgroup-per-CU worker; 16 x 2 = 72 KB was the 128-VGPR
+// bulk kernel's of the two-kernel form, scripts/experiments/r05_two_kernel_form.patch); MULTI: a task may carry several row tiles
+// (the next C tile in a second register set); STAGGER: see below.
 template <int KC, int STAGES, bool MULTI, bool STAGGER>
 __device__ __forceinline__ void df_syrk_tiles(const DevPlan& P, int s, int j0, int nb, int i, int R_, int j, int KB, int k, double* sm, long long* marks) {
   constexpr int NW = kSyrkNW;
@@ -807,278 +807,12 @@ __device__ __forceinline__ void df_syrk_tiles(const DevPlan& P, int s, int j0, i
   // the ring's slots are reused by the next task of this workgroup: every wave is done reading them behind the caller's barrier
 }
 
-// ---- the bulk kernel's T: df_trsm_tile in 67 KB of LDS ---------------------------------------------------------------------------
-// Two workgroups of the bulk kernel share a CU (below), so a task has 80 KB of LDS, and the ten staged 32 x 32 blocks of df_trsm_tile
-// take 83.  The four diagonal blocks are inverses of unit-lower blocks: only the rows from the diagonal's 4-row group on are ever
-// read, so they are staged PACKED -- the four columns of column group g keep their rows 4 g .. 31 (576 doubles instead of 1024).
-// Same products in the same order as df_trsm_tile: bitwise the same W and L.
-constexpr int kBulkXPack = 576;                                        // doubles of a packed diagonal inverse
-constexpr int kBulkTDoubles = 6 * kIB * kIB + 4 * kBulkXPack + 128;   // six blocks below the diagonal, four packed inverses, the reciprocals
-__device__ __forceinline__ constexpr int xpack_start(int g) { return 136 * g - 8 * g * g; }
-__device__ __forceinline__ void df_trsm_tile_packed(const DevPlan& P, int s, int q, int r0, int rlim, double* sm) {
-  constexpr int NBLK = 4, NB = 128;
-  int tid_ = threadIdx.x;
-  asm volatile("" : "+v"(tid_));
-  const int tid = tid_, lane = tid & 63, wv = tid >> 6;
-  const int col0 = P.sn_col0[s];
-  const int k = P.sn_col0[s + 1] - col0;
-  const int f = (int)(P.row_ptr[s + 1] - P.row_ptr[s]);
-  const int j0 = q * NB;
-  const int nb = min(NB, k - j0);
-  double* F = P.arena + P.front_pos[s];
-  double* Wb = P.wbuf + P.wbuf_pos[s] + (size_t)j0 * f;
-  const double* X = P.invl + P.invl_pos[s] + (size_t)q * NB * NB;
-  double* xs = sm + 6 * kIB * kIB;
-  double* rdv = xs + 4 * kBulkXPack;
-  const int row = r0 + wv * 16 + (lane & 15);
-  const int rowc = min(row, f - 1);
-  const bool valid = row < rlim;
-  const int lk = lane >> 4, li = lane & 3;
-  double t[NBLK * 8];
-#pragma unroll
-  for (int qq = 0; qq < NBLK * 8; ++qq) {
-    const int c = 4 * qq + lk;
-    t[qq] = keep_f64(F[(size_t)(j0 + min(c, nb - 1)) * f + rowc], c < nb && valid);
-  }
-  {
-    const int e = tid * 2;                 // 2 consecutive rows of one column per thread and block
-    const int cc = e / kIB, rr = e - cc * kIB;
-    const int g4 = cc >> 2;
-#pragma unroll
-    for (int bi = 0; bi < NBLK; ++bi)
-#pragma unroll
-      for (int bp = 0; bp <= bi; ++bp) {
-        double v[2];
-        const int gr = bi * kIB + rr, gc = bp * kIB + cc;
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const double* src = bp == bi ? X + (gr + u) + (size_t)gc * NB
-                                       : F + (size_t)(j0 + min(gc, nb - 1)) * f + j0 + min(gr + u, nb - 1);
-          v[u] = keep_f64(*src, gr + u < nb && gc < nb);
-        }
-        if (bp == bi) {
-          if (rr >= 4 * g4) {
-            double* dst = xs + bi * kBulkXPack + (136 * g4 - 8 * g4 * g4) + (cc & 3) * (32 - 4 * g4) + (rr - 4 * g4);
-            dst[0] = v[0]; dst[1] = v[1];
-          }
-        } else {
-          double* dst = sm + (bi * (bi - 1) / 2 + bp) * kIB * kIB + e;
-          dst[0] = v[0]; dst[1] = v[1];
-        }
-      }
-    if (tid < NB) rdv[tid] = tid < nb ? 1.0 / P.dvals[col0 + j0 + tid] : 0.0;
-  }
-  __syncthreads();
-#pragma unroll
-  for (int bi = 0; bi < NBLK; ++bi) {
-#pragma unroll
-    for (int bp = 0; bp < bi; ++bp) {
-      const double* Lb = sm + (bi * (bi - 1) / 2 + bp) * kIB * kIB;
-#pragma unroll
-      for (int gp = 0; gp < 8; ++gp)
-#pragma unroll
-        for (int g = 0; g < 8; ++g)
-          t[bi * 8 + gp] = __builtin_amdgcn_mfma_f64_4x4x4f64(Lb[(gp * 4 + li) + (g * 4 + lk) * kIB], t[bp * 8 + g], t[bi * 8 + gp], 0, 0, 1 /* neg A */);
-    }
-    const double* Xb = xs + bi * kBulkXPack;
-    double wt[8];
-#pragma unroll
-    for (int gp = 0; gp < 8; ++gp) {
-      wt[gp] = 0.0;
-#pragma unroll
-      for (int g = 0; g <= gp; ++g)   // X_ii is lower triangular
-        wt[gp] = __builtin_amdgcn_mfma_f64_4x4x4f64(Xb[xpack_start(g) + lk * (32 - 4 * g) + (gp * 4 + li - 4 * g)], t[bi * 8 + g], wt[gp], 0, 0, 0);
-    }
-#pragma unroll
-    for (int gp = 0; gp < 8; ++gp) t[bi * 8 + gp] = wt[gp];
-  }
-  if (valid) {
-#pragma unroll
-    for (int qq = 0; qq < NBLK * 8; ++qq) {
-      const int c = 4 * qq + lk;
-      if (c < nb) {
-        st_agent_f64(&Wb[(size_t)c * f + row], t[qq]);
-        st_agent_f64(&F[(size_t)(j0 + c) * f + row], t[qq] * rdv[c]);
-      }
-    }
-  }
-}
-
-// ---- the bulk kernel: panel tiles and updates at four waves per SIMD --------------------------------------------------------------
-// One 512-thread worker per CU (k_front_dataflow) gives an update task two waves per SIMD, and two waves get a v_mfma_f64_4x4x4
-// through every 20 - 22 cycles where the pipe takes one every 16.  For the levels whose time is the updates (few
-// fronts: the top of the tree) the launch is therefore split in two kernels that share the tile states:
-//   k_front_bulk      T and U tasks, <= 128 VGPRs and 72 KB of LDS: TWO workgroups per CU = four waves per SIMD, the partner's main
-//                     loop covers a task's prologue and epilogue; on the CU-masked stream (every CU but the reserved ones);
-//   k_front_dataflow  the chain tasks D / TA / TU (236 VGPRs, 150 KB) on the reserved CUs, from its own queue.
-// The bulk tasks come from one queue per XCD (dataflow_sched.cpp: df_split_queue): a worker pops the queue of the XCD it runs on
-// (HW_REG_XCC_ID) in order and moves on to the next queue only when its own is exhausted.  Every queue is a subsequence of the one
-// topological order and keeps its own workers until it is empty, so the earliest unfinished task is running or at the head of a
-// queue whose workers are free: no deadlock as long as every XCD has a resident worker (the grid is sized from the occupancy query).
-// qinfo: offset (relative to `tasks`) and length of the eight queues; heads: their eight counters.
-constexpr int kBulkKC = 16, kBulkStages = 2;
-constexpr size_t kBulkLds = std::max((size_t)kBulkStages * 2 * kBulkKC * kSyrkLd * sizeof(double), (size_t)kBulkTDoubles * sizeof(double));
-static_assert(2 * (kBulkLds + 64) <= 160 * 1024, "two bulk workers per CU");
-// How a bulk worker takes a task: FIRST READY, not in order.  The in-order pop of the one-kernel form blocks a worker on a task whose
-// inputs are not there yet; with 496 workers on eight static queues 30 % of the worker time went into such waits (tasks popped up to a
-// millisecond early wherever the host's time model was off, the root of the metric workload 7.0 ms instead of 6.3).  Here every task
-// has a claim word and a precomputed record of the (at most three) tile states it waits for (DfDep); a worker's wave 0 looks at a
-// window of 64 tasks of its queue at a time -- lane l: claim word and record of task cursor + l, then its states -- and claims the
-// first task that is unclaimed AND ready with a compare-and-swap.  A claimed task never waits, so no worker ever holds a task it
-// cannot run: the launch cannot deadlock whatever the order of the queues, the number of resident workers or the placement; the
-// queue order (the simulated schedule) is only the priority among the ready tasks.  A worker keeps a cursor per queue (the first
-// task it has not seen claimed), looks up to kBulkLook windows ahead in the queue of its own XCD and then one window into each
-// of the others (work stealing: only when nothing of its own is ready), and leaves when every queue is claimed to its end.
-constexpr int kBulkLook = 4;
-// block = false: one pass, -3 when nothing is ready (the caller still has a result to publish: it must not wait here)
-__device__ __forceinline__ int bulk_claim(const DevPlan& P, const DfDep* __restrict__ deps, const int* __restrict__ qinfo, int* __restrict__ claim, int my, volatile int* s_cur, int lane,
-                                          int* mine_out, int* newv_out, bool block, bool inorder) {
-  int spins = 0;
-  long long t0w = 0;
-  for (;;) {
-    bool all_done = true, all_done_own = true;
-    for (int dq = 0; dq < 8; ++dq) {
-      const int q = (my + dq) & 7;
-      const int cnt = __builtin_amdgcn_readfirstlane(qinfo[8 + q]), off = __builtin_amdgcn_readfirstlane(qinfo[q]);
-      const int base = __builtin_amdgcn_readfirstlane(s_cur[q]);
-      if (base >= cnt) continue;
-      all_done = false;
-      if (dq == 0) all_done_own = false;
-      const int nwin = (dq == 0 && !inorder) ? kBulkLook : 1;
-      if (inorder && dq > 0 && !all_done_own) break;      // the other queues only once the own one is exhausted
-      for (int w = 0; w < nwin; ++w) {
-        const int idx = base + w * 64 + lane;
-        if (__builtin_amdgcn_readfirstlane(base + w * 64) >= cnt) break;
-        const bool valid = idx < cnt;
-        const int g = off + min(idx, cnt - 1);
-        const int c = valid ? ld_state(claim + g) : 1;
-        const unsigned long long cm = __builtin_amdgcn_ballot_w64(c != 0);
-        if (w == 0) {
-          // leading tasks that are claimed (or past the end): the cursor moves over them for good
-          const int lead = cm == ~0ull ? 64 : (int)__builtin_ctzll(~cm);
-          if (lead > 0 && lane == 0) s_cur[q] = min(base + lead, cnt);
-        }
-        bool r = false;
-        DfDep d;
-        if (c == 0) {
-          d = deps[g];
-          r = inorder || (ld_state(P.df_state + d.a0) >= d.n0 && ld_state(P.df_state + d.a1) >= d.n1 && ld_state(P.df_state + d.a2) >= d.n2);
-        } else { d.mine = 0; d.newv = 0; d.a0 = d.a1 = d.a2 = 0; d.n0 = d.n1 = d.n2 = 0; }
-        unsigned long long rm = __builtin_amdgcn_ballot_w64(r);
-        while (rm) {
-          const int pl = (int)__builtin_ctzll(rm);
-          int old = 1;
-          if (lane == pl) old = atomicCAS(claim + g, 0, 1);
-          old = __builtin_amdgcn_readlane(old, pl);
-          if (old == 0) {
-            *mine_out = __builtin_amdgcn_readlane(d.mine, pl);
-            *newv_out = __builtin_amdgcn_readlane(d.newv, pl);
-            const int got = __builtin_amdgcn_readlane(g, pl);
-            if (inorder) {      // (experiment) the one-kernel form's rule: the head of the queue is taken whatever its state and waited for
-              const int a0 = __builtin_amdgcn_readlane(d.a0, pl), a1 = __builtin_amdgcn_readlane(d.a1, pl), a2 = __builtin_amdgcn_readlane(d.a2, pl);
-              const int n0 = __builtin_amdgcn_readlane(d.n0, pl), n1 = __builtin_amdgcn_readlane(d.n1, pl), n2 = __builtin_amdgcn_readlane(d.n2, pl);
-              for (;;) {
-                if (ld_state(P.df_state + a0) >= n0 && ld_state(P.df_state + a1) >= n1 && ld_state(P.df_state + a2) >= n2) break;
-                const int dead = __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&P.counters[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                if (dead) return -2;
-                if (wait_expired(spins, t0w)) { if (lane == 0) atomicExch(&P.counters[5], 1ull); return -2; }
-                __builtin_amdgcn_s_sleep(2);
-              }
-            }
-            return got;
-          }
-          rm &= rm - 1;
-        }
-      }
-    }
-    if (all_done) return -1;
-    if (!block) return -3;
-    const int stop = P.want_neg >= 0 ? __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&P.counters[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : 0;
-    const int dead = __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&P.counters[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    if (stop | dead) return -2;
-    if (wait_expired(spins, t0w)) {      // bounded like every in-launch wait: nothing became ready for seconds
-      if (lane == 0) atomicExch(&P.counters[5], 1ull);
-      return -2;
-    }
-    __builtin_amdgcn_s_sleep(8);
-  }
-}
-
-__global__ __launch_bounds__(kDfThreadsC, 4) void k_front_bulk(DevPlan P, const DfTask* __restrict__ tasks, const DfDep* __restrict__ deps, const int* __restrict__ qinfo, int* __restrict__ claim, int dbg,
-                                                              const int* __restrict__ fronts, int nfronts, int* __restrict__ asm_flags, int epoch, long long* __restrict__ tlog) {
-  extern __shared__ __attribute__((aligned(16))) double sm[];
-  __shared__ int s_ctl[4];
-  __shared__ int s_cur[8];
-  const int tid = threadIdx.x;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // this launch sits behind the level's assembly on its stream: the chain kernel (another stream) may touch the fronts now
-  if (blockIdx.x == 0 && asm_flags)
-    for (int a = tid; a < nfronts; a += kDfThreadsC) __hip_atomic_store(asm_flags + fronts[a], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  int xcc;
-  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-  xcc &= 7;
-  if (tid < 8) s_cur[tid] = 0;
-  __syncthreads();
-  int gt_next = -3, mine_next = 0, newv_next = 0;      // wave 0: the task claimed while the previous one's stores were draining (-3: none yet)
-  for (;;) {
-    if (wave == 0) {
-      int gt = gt_next, mi = mine_next, nv = newv_next;
-      if (gt == -3) gt = bulk_claim(P, deps, qinfo, claim, xcc, s_cur, tid & 63, &mi, &nv, true, (dbg & 32) != 0);
-      if (gt >= 0) {
-        if (tlog && (tid & 63) == 0) {
-          int hwid;
-          asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-          tlog[(size_t)gt * 8] = wall_clock64(); tlog[(size_t)gt * 8 + 3] = (long long)blockIdx.x | ((long long)xcc << 16) | ((long long)(hwid & 0xffff) << 20);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (tlog && (tid & 63) == 0) tlog[(size_t)gt * 8 + 1] = wall_clock64();
-      }
-      s_ctl[0] = gt; s_ctl[1] = mi; s_ctl[2] = nv;
-    }
-    __syncthreads();
-    const int gt = __builtin_amdgcn_readfirstlane(s_ctl[0]);
-    if (gt < 0) return;
-    const int mine_idx = __builtin_amdgcn_readfirstlane(s_ctl[1]), newv = __builtin_amdgcn_readfirstlane(s_ctl[2]);
-    const DfTask tk = tasks[gt];
-    const int s = __builtin_amdgcn_readfirstlane(tk.front);
-    const int type_nq = __builtin_amdgcn_readfirstlane(tk.type_nq);
-    const int ij = __builtin_amdgcn_readfirstlane(tk.ij);
-    const int q0 = __builtin_amdgcn_readfirstlane(tk.q0);
-    const int type = type_nq & 255, nq = (type_nq >> 8) & 255, i = ij & 0xffff, j = ij >> 16;
-    const int k = P.sn_col0[s + 1] - P.sn_col0[s];
-    const int f = (int)(P.row_ptr[s + 1] - P.row_ptr[s]);
-    const int KB = (k + 127) >> 7;
-    // a panel tile or a single-panel update is a link of its block row's chain (one block column per chain step): its waves take the CU's
-    // issue slots ahead of the partner workgroup's K = 512 update, which has the slack
-    const bool urgent = (dbg & 64) == 0 && (type == kDfT || nq == 1);
-    if (urgent) __builtin_amdgcn_s_setprio(3);
-    if (type == kDfT) {
-      if (!(dbg & 2)) df_trsm_tile_packed(P, s, j, df_block_lo(i, KB, k, f), df_block_lo(i + 1, KB, k, f), sm);
-    } else {
-      const int j0 = q0 * 128;
-      if (!(dbg & 4)) df_syrk_tiles<kBulkKC, kBulkStages, false, false>(P, s, j0, min(nq * 128, k - j0), i, 1, j, KB, k, sm, tlog ? tlog + (size_t)gt * 8 + 4 : nullptr);
-    }
-    if (urgent) __builtin_amdgcn_s_setprio(0);
-    // the next task is looked for now: the scan's round trips run beside the drain of this task's stores (wave 0's own loads come back
-    // behind its stores).  What this task enables is not ready yet in that scan -- another worker takes it.
-    if (wave == 0) gt_next = bulk_claim(P, deps, qinfo, claim, xcc, s_cur, tid & 63, &mine_next, &newv_next, false, (dbg & 32) != 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every storing wave: its sc1 stores have been acknowledged
-    __syncthreads();                                      // ... and every wave is done with the LDS of this task and with s_ctl
-    if (tlog && tid == 0) tlog[(size_t)gt * 8 + 2] = wall_clock64();
-    if (wave == 0 && (tid & 63) == 0) __hip_atomic_store(P.df_state + mine_idx, newv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-}
-
 constexpr int kDfThreads = kDfThreadsC;
 constexpr size_t kDfLds = std::max(std::max(std::max(OKKT_DIAG2_LDS_DOUBLES(kMW) * sizeof(double), kDfTuLds), (size_t)kDfStages * 2 * kDfKC * kSyrkLd * sizeof(double)), kDfTlLds);   // diag2_body's and df_tu_tile's; the other roles need less
 
 // counters[5] = a wait ran into its bound, three seconds of wall clock (or another worker's did): every worker leaves, the factorisation
 // fails with "a hand-off timed out" and the solves return NaN -- never numbers computed from tiles that had not arrived
-// asm_flags != nullptr: the chain kernel of the two-kernel form (k_front_bulk above) -- it runs on a stream of its own and may be resident
-// before the level's fronts are assembled: a task that waits for no other task (block column 0) waits for its front's flag instead
-__global__ __launch_bounds__(kDfThreads, 1) void k_front_dataflow(DevPlan P, const DfTask* __restrict__ tasks, int ntasks, int* __restrict__ head, double tol, int drop, int dbg, long long* __restrict__ tlog,
-                                                                 const int* __restrict__ asm_flags, int epoch) {
+__global__ __launch_bounds__(kDfThreads, 1) void k_front_dataflow(DevPlan P, const DfTask* __restrict__ tasks, int ntasks, int* __restrict__ head, double tol, int drop, int dbg, long long* __restrict__ tlog) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   __shared__ int s_ctl[8];
   const int tid = threadIdx.x;
@@ -1113,7 +847,6 @@ __global__ __launch_bounds__(kDfThreads, 1) void k_front_dataflow(DevPlan P, con
         const int ln = tid & 63;
         const int* addr = st;
         int need = -(1 << 30);
-        if (asm_flags && j == 0 && type != kDfT && type != kDfU && type != kDfTL && ln == 3) { addr = asm_flags + s; need = epoch; }
         if (type == kDfD) { if (ln == 0) { addr = st + (size_t)i * TB + i; need = i; } }
         else if (type == kDfT) {
           if (ln == 0) { addr = st + (size_t)j * TB + j; need = j + 1; }
@@ -1218,15 +951,13 @@ __global__ __launch_bounds__(kDfThreads, 1) void k_front_dataflow(DevPlan P, con
 std::string df_setup(Numeric& N) {
   DevPlan& d = N.d;
   const int ns = d.nsuper;
-  N.df_tasks = nullptr; N.df_heads = nullptr; N.n_df_heads = 0; N.df_state_ints = 0; N.df_qinfo = nullptr; N.df_asm_flags = nullptr; N.df_deps = nullptr; N.df_claim = nullptr; N.df_ntasks = 0;
+  N.df_tasks = nullptr; N.df_heads = nullptr; N.n_df_heads = 0; N.df_state_ints = 0;
   d.df_state = nullptr; d.df_state_pos = nullptr;
   if (!N.dataflow || N.nb != 128) return "";
   std::vector<int64_t> spos(ns, -1);
   int64_t total = 0;
   std::vector<DfTask> all;
-  std::vector<DfDep> alldeps;       // parallel to `all`: filled for the bulk tasks of the two-kernel levels
   std::vector<DfTask> q;
-  std::vector<int> qinfo;
   int nheads = 0;
   int dev = 0, ncu = 256;
   if (hipGetDevice(&dev) == hipSuccess) { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ncu = pr.multiProcessorCount; }
@@ -1236,23 +967,11 @@ std::string df_setup(Numeric& N) {
   N.df_split_tu = getenv("OKKT_DF_SPLIT_TU") ? atoi(getenv("OKKT_DF_SPLIT_TU")) : 1;
   N.df_fuse_tl = getenv("OKKT_DF_FUSE_TL") ? atoi(getenv("OKKT_DF_FUSE_TL")) : 1;
   N.df_rows = getenv("OKKT_DF_ROWS") ? std::max(1, std::min(atoi(getenv("OKKT_DF_ROWS")), 8)) : 1;
-  // the two-kernel form needs the CU-masked stream pair of the handle (bulk kernel on every CU but the reserved ones, chain kernel on those)
-  N.df_split_fronts = getenv("OKKT_DF_SPLIT_FRONTS") ? atoi(getenv("OKKT_DF_SPLIT_FRONTS")) : 0;
-  if (!N.stream_masked || !N.stream_chain || N.df_chain_workers < 2) N.df_split_fronts = 0;
   OKKT_HIP_TRY(hipFuncSetAttribute((const void*)k_front_dataflow, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
-  OKKT_HIP_TRY(hipFuncSetAttribute((const void*)k_front_bulk, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-  if (N.df_split_fronts > 0) {
-    int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k_front_bulk, kDfThreadsC, kBulkLds) != hipSuccess || per_cu < 1) { (void)hipGetLastError(); N.df_split_fronts = 0; }
-    else N.df_bulk_workers = std::min(per_cu, 2) * std::max(1, ncu - N.df_chain_workers);
-    if (getenv("OKKT_DEBUG_FRONTS")) fprintf(stderr, "okkt: bulk kernel: %d workgroups per CU, %d workers beside %d chain workers\n", per_cu, N.df_bulk_workers, N.df_chain_workers);
-  }
-  static const float split_mul = getenv("OKKT_DF_SPLIT_BULK_MUL") ? (float)atof(getenv("OKKT_DF_SPLIT_BULK_MUL")) : 1.7f;   // a bulk task's duration in the model: two workgroups share a CU
-  static const int split_min_tasks = getenv("OKKT_DF_SPLIT_MIN_TASKS") ? atoi(getenv("OKKT_DF_SPLIT_MIN_TASKS")) : 2000;
   auto do_sched = [&](std::vector<LevelSchedule>& levels) {
     for (LevelSchedule& L : levels) {
       Segment& g = L.seg[3];
-      g.df_off = -1; g.df_cnt = 0; g.df_head = -1; g.df_flops = 0; g.df_split = 0; g.dfc_cnt = 0; g.dfb_cnt = 0;
+      g.df_off = -1; g.df_cnt = 0; g.df_head = -1; g.df_flops = 0;
       if (g.cnt == 0) continue;
       std::vector<DfFront> fronts;
       for (int a = 0; a < g.cnt; ++a) {
@@ -1267,44 +986,12 @@ std::string df_setup(Numeric& N) {
         g.df_flops += (double)k * f * f - (double)k * k * f + (double)k * k * k / 3.0;
       }
       double model = 0;
-      const bool split = N.df_split_fronts > 0 && g.cnt <= N.df_split_fronts;
-      if (split) df_build_queue(fronts, N.df_bulk_workers, N.df_group, 1, N.df_fuse_d != 0, N.df_split_tu != 0, q, &model, N.df_chain_workers, split_mul, N.df_fuse_tl != 0);
-      if (!split || (int)q.size() < split_min_tasks) {
-        df_build_queue(fronts, N.df_workers, N.df_group, N.df_rows, N.df_fuse_d != 0, N.df_split_tu != 0, q, &model, 0, 1.0f, N.df_fuse_tl != 0);
-        g.df_split = 0;
-      } else g.df_split = 1;
+      df_build_queue(fronts, N.df_workers, N.df_group, N.df_rows, N.df_fuse_d != 0, N.df_split_tu != 0, q, &model, N.df_fuse_tl != 0);
       g.df_off = (int64_t)all.size();
       g.df_cnt = (int)q.size();
       g.df_head = nheads++;
-      qinfo.resize((size_t)nheads * 16, 0);
-      if (g.df_split) {
-        std::vector<DfTask> chain, bulk[8];
-        df_split_queue(fronts, q, chain, bulk);
-        g.dfc_cnt = (int)chain.size();
-        all.insert(all.end(), chain.begin(), chain.end());
-        int off = 0;
-        for (int x = 0; x < 8; ++x) {
-          qinfo[(size_t)g.df_head * 16 + x] = off;
-          qinfo[(size_t)g.df_head * 16 + 8 + x] = (int)bulk[x].size();
-          off += (int)bulk[x].size();
-          all.insert(all.end(), bulk[x].begin(), bulk[x].end());
-        }
-        g.dfb_cnt = off;
-        // what each bulk task waits for and publishes, as indices into the tile states (k_front_bulk: bulk_claim)
-        alldeps.resize(all.size(), DfDep{0, 0, 0, 0, 0, 0, 0, 0});
-        for (size_t t = (size_t)g.df_off + (size_t)g.dfc_cnt; t < all.size(); ++t) {
-          const DfTask& tk = all[t];
-          const int s = tk.front, type = tk.type_nq & 255, nq = (tk.type_nq >> 8) & 255, i = tk.ij & 0xffff, j = tk.ij >> 16;
-          const int f = N.sn_f[s], k = N.sn_k[s];
-          const int64_t TB = (k + 127) / 128 + (f - k + 127) / 128;
-          auto at = [&](int x, int y) { return (int)(spos[s] + (int64_t)x * TB + y); };
-          DfDep d;
-          if (type == kDfT) { d = {at(j, j), j + 1, at(i, j), j, at(j, j), j + 1, at(i, j), j + 1}; }
-          else { const int ql = tk.q0 + nq - 1; d = {at(i, ql), ql + 1, at(i, j), tk.q0, at(j, ql), ql + 1, at(i, j), tk.q0 + nq}; }
-          alldeps[t] = d;
-        }
-      } else all.insert(all.end(), q.begin(), q.end());
-      if (getenv("OKKT_DEBUG_FRONTS")) fprintf(stderr, "okkt: dataflow level: %d fronts (largest %d x %d), %d tasks%s, model %.0f us\n", g.cnt, g.maxf, g.maxk, g.df_cnt, g.df_split ? " (bulk + chain kernels)" : "", model);
+      all.insert(all.end(), q.begin(), q.end());
+      if (getenv("OKKT_DEBUG_FRONTS")) fprintf(stderr, "okkt: dataflow level: %d fronts (largest %d x %d), %d tasks, model %.0f us\n", g.cnt, g.maxf, g.maxk, g.df_cnt, model);
     }
   };
   do_sched(N.levels);
@@ -1322,27 +1009,15 @@ std::string df_setup(Numeric& N) {
   std::string e;
   if (!(e = up(spos.data(), spos.size() * sizeof(int64_t), (void**)&d.df_state_pos)).empty()) return e;
   if (!(e = up(all.data(), all.size() * sizeof(DfTask), (void**)&N.df_tasks)).empty()) return e;
-  if (!(e = up(qinfo.data(), qinfo.size() * sizeof(int), (void**)&N.df_qinfo)).empty()) return e;
-  if (total + (int64_t)nheads * kDfHeadStride + (int64_t)all.size() >= (int64_t)1 << 31) return "dataflow: tile states beyond 2^31";
-  alldeps.resize(all.size(), DfDep{0, 0, 0, 0, 0, 0, 0, 0});
-  if (!(e = up(alldeps.data(), alldeps.size() * sizeof(DfDep), (void**)&N.df_deps)).empty()) return e;
-  N.df_ntasks = (int64_t)all.size();
+  if (total + (int64_t)nheads * kDfHeadStride >= (int64_t)1 << 31) return "dataflow: tile states beyond 2^31";
   {
     void* p = nullptr;      // tile states, then the queue heads: one fill per factorisation clears both
-    const size_t bytes = ((size_t)total + (size_t)nheads * kDfHeadStride + all.size() + 16) * sizeof(int);      // ... and the claim words of the bulk tasks
+    const size_t bytes = ((size_t)total + (size_t)nheads * kDfHeadStride + 16) * sizeof(int);
     OKKT_HIP_TRY(hipMalloc(&p, bytes));
     N.allocations.push_back(p);
     OKKT_HIP_TRY(hipMemset(p, 0, bytes));
     d.df_state = (int*)p;
     N.df_heads = d.df_state + total;
-    N.df_claim = N.df_heads + (size_t)nheads * kDfHeadStride;
-    p = nullptr;            // per front: the epoch of the factorisation whose assembly is complete (monotonic, never cleared)
-    OKKT_HIP_TRY(hipMalloc(&p, ((size_t)ns + 16) * sizeof(int)));
-    N.allocations.push_back(p);
-    OKKT_HIP_TRY(hipMemset(p, 0, ((size_t)ns + 16) * sizeof(int)));
-    OKKT_HIP_TRY(hipStreamSynchronize(nullptr));
-    N.df_asm_flags = (int*)p;
-    N.df_epoch = 0;
   }
   return "";
 }
@@ -1354,8 +1029,7 @@ std::string df_launch(Numeric& N, const DevPlan& P, const Segment& g, hipStream_
   const int grid = std::min(g.df_cnt, N.df_workers);
   long long* tlog = nullptr;
   if (dbg & 16) { OKKT_HIP_TRY(hipMalloc((void**)&tlog, (size_t)g.df_cnt * 8 * sizeof(long long))); OKKT_HIP_TRY(hipMemsetAsync(tlog, 0, (size_t)g.df_cnt * 8 * sizeof(long long), st)); }   // debug only: per task pop / ready / end ticks (10 ns) and the worker
-  hipLaunchKernelGGL(k_front_dataflow, dim3(grid), dim3(kDfThreads), kDfLds, st, P, N.df_tasks + g.df_off, g.df_cnt, N.df_heads + g.df_head * kDfHeadStride, tol, (drop & 4) ? 1 : 0, dbg, tlog,
-                     (const int*)nullptr, 0);
+  hipLaunchKernelGGL(k_front_dataflow, dim3(grid), dim3(kDfThreads), kDfLds, st, P, N.df_tasks + g.df_off, g.df_cnt, N.df_heads + g.df_head * kDfHeadStride, tol, (drop & 4) ? 1 : 0, dbg, tlog);
   if (dbg & 24) {
     hipError_t e2 = hipStreamSynchronize(st);
     fprintf(stderr, "okkt: dataflow launch of %d tasks on %d workers: %s\n", g.df_cnt, grid, hipGetErrorString(e2));
@@ -1372,47 +1046,6 @@ std::string df_launch(Numeric& N, const DevPlan& P, const Segment& g, hipStream_
       for (int t = 0; t < g.df_cnt; ++t)
         fprintf(fp, "%d %d %d %d %d %d %d %lld %lld %lld %lld %lld %lld %lld %lld\n", t, ht[t].front, ht[t].type_nq & 255, ht[t].ij & 0xffff, ht[t].ij >> 16, ht[t].q0, ht[t].type_nq >> 8,
                 hl[(size_t)t * 8 + 3], hl[(size_t)t * 8], hl[(size_t)t * 8 + 1], hl[(size_t)t * 8 + 2], hl[(size_t)t * 8 + 4], hl[(size_t)t * 8 + 5], hl[(size_t)t * 8 + 6], hl[(size_t)t * 8 + 7]);
-      fclose(fp);
-    }
-  }
-  OKKT_HIP_TRY(hipGetLastError());
-  return "";
-}
-
-// The two-kernel form of a level: the chain kernel (k_front_dataflow on the level's D / TA / TU queue) on st_chain -- it waits for the
-// fronts' assembly flags, so it needs no stream dependency on the assembly launch -- and the bulk kernel on st_bulk behind the
-// assembly.  The caller joins both streams before anything reads the level's results.
-std::string df_launch_split(Numeric& N, const DevPlan& P, const Segment& g, hipStream_t st_bulk, hipStream_t st_chain, double tol) {
-  if (g.df_cnt <= 0) return "";
-  static const int drop = getenv("OKKT_DEBUG_DROP_HANDOFF") ? atoi(getenv("OKKT_DEBUG_DROP_HANDOFF")) : 0;
-  static const int dbg = getenv("OKKT_DEBUG_DATAFLOW") ? atoi(getenv("OKKT_DEBUG_DATAFLOW")) : 0;
-  int* heads = N.df_heads + (size_t)g.df_head * kDfHeadStride;
-  const DfTask* chain = N.df_tasks + g.df_off;
-  const DfTask* bulk = chain + g.dfc_cnt;
-  long long* tlog = nullptr;
-  if (dbg & 16) { OKKT_HIP_TRY(hipMalloc((void**)&tlog, (size_t)g.df_cnt * 8 * sizeof(long long))); OKKT_HIP_TRY(hipMemset(tlog, 0, (size_t)g.df_cnt * 8 * sizeof(long long))); }
-  if (g.dfc_cnt > 0)
-    hipLaunchKernelGGL(k_front_dataflow, dim3(std::min(g.dfc_cnt, N.df_chain_workers)), dim3(kDfThreads), kDfLds, st_chain, P, chain, g.dfc_cnt, heads + 8, tol, (drop & 4) ? 1 : 0, dbg, tlog,
-                       (const int*)N.df_asm_flags, N.df_epoch);
-  hipLaunchKernelGGL(k_front_bulk, dim3(std::max(1, std::min(g.dfb_cnt, N.df_bulk_workers))), dim3(kDfThreadsC), kBulkLds, st_bulk, P, bulk, N.df_deps + g.df_off + g.dfc_cnt,
-                     N.df_qinfo + (size_t)g.df_head * 16, N.df_claim + g.df_off + g.dfc_cnt, dbg, P.sched + g.off, g.cnt, N.df_asm_flags, N.df_epoch, tlog ? tlog + (size_t)g.dfc_cnt * 8 : nullptr);
-  if (dbg & 24) {
-    hipError_t e2 = hipStreamSynchronize(st_bulk);
-    hipError_t e3 = hipStreamSynchronize(st_chain);
-    fprintf(stderr, "okkt: dataflow launch of %d chain + %d bulk tasks: %s / %s\n", g.dfc_cnt, g.dfb_cnt, hipGetErrorString(e2), hipGetErrorString(e3));
-  }
-  if (tlog) {
-    std::vector<long long> hl((size_t)g.df_cnt * 8);
-    std::vector<DfTask> ht((size_t)g.df_cnt);
-    OKKT_HIP_TRY(hipMemcpy(hl.data(), tlog, hl.size() * sizeof(long long), hipMemcpyDeviceToHost));
-    OKKT_HIP_TRY(hipMemcpy(ht.data(), N.df_tasks + g.df_off, ht.size() * sizeof(DfTask), hipMemcpyDeviceToHost));
-    (void)hipFree(tlog);
-    const char* path = getenv("OKKT_DF_LOG");
-    if (FILE* fp = fopen(path ? path : "/tmp/okkt_df_log.txt", "a")) {
-      fprintf(fp, "# launch %d tasks %d workers (index front type i j q0 nq worker pop ready end [10 ns ticks])\n", g.df_cnt, N.df_bulk_workers + N.df_chain_workers);
-      for (int t = 0; t < g.df_cnt; ++t)
-        fprintf(fp, "%d %d %d %d %d %d %d %lld %lld %lld %lld %lld %lld %lld %lld\n", t, ht[t].front, ht[t].type_nq & 255, ht[t].ij & 0xffff, ht[t].ij >> 16, ht[t].q0, ht[t].type_nq >> 8,
-                (hl[(size_t)t * 8 + 3] & 0xffff) + (t >= g.dfc_cnt ? 1000 : 0) + ((hl[(size_t)t * 8 + 3] >> 16) << 16), hl[(size_t)t * 8], hl[(size_t)t * 8 + 1], hl[(size_t)t * 8 + 2], hl[(size_t)t * 8 + 4], hl[(size_t)t * 8 + 5], hl[(size_t)t * 8 + 6], hl[(size_t)t * 8 + 7]);
       fclose(fp);
     }
   }

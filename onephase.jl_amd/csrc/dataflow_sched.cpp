@@ -41,20 +41,6 @@ namespace {
 
 constexpr int kLonePanels = 2;
 
-// Two-kernel form: does a panel tile / update belong to the chain kernel's queue?  The chain D(q) -> TU(q) -> D(q + 1) is fed by the
-// block rows right below the diagonal: TU(q) needs the tiles (q + 1, q) and (q + 1, q + 1) with panel q - 1 applied, i.e. T(q + 1, q - 1)
-// and two single-panel updates behind D(q - 1) -- 57 us of work against the 63 us between two diagonal blocks, with no slack for a
-// place in a bulk queue or for a CU shared with another workgroup (measured: the root of the metric workload fell from 94 to 111 us
-// per block column with every T and U in the bulk queues).  So the panel tiles of the `near` block rows below TU's, and the
-// single-panel updates of the last two panels of a pivot column on tiles within `near` rows of the diagonal, run on the chain
-// kernel's workers (a whole CU each, nothing queued in front of them).
-inline bool near_chain_task(int type, int i, int j, int q0, int nq, int KB, int near) {
-  if (near <= 0) return false;
-  if (type == kDfT) return i - j <= near + 1;
-  if (type == kDfU) return nq == 1 && j < KB && q0 + kLonePanels >= j && i - j <= near;
-  return false;
-}
-
 struct FrontGrid {
   int f, k, KB, TB;
   int64_t offD, offT, offTU, offU;   // first task index of each kind
@@ -72,14 +58,8 @@ struct FrontGrid {
 
 }  // namespace
 
-int df_near_rows() {
-  static const int near = getenv("OKKT_DF_NEAR") ? atoi(getenv("OKKT_DF_NEAR")) : 6;
-  return near;
-}
-
 void df_build_queue(const std::vector<DfFront>& fronts, int workers, int group, int rows_per_task, bool fuse_d, bool split_tu, std::vector<DfTask>& out, double* model_us,
-                    int chain_workers, float bulk_mul, bool fuse_tl) {
-  const int near = chain_workers > 0 ? df_near_rows() : 0;
+                    bool fuse_tl) {
   const int G = std::max(1, group);
   const int RT = std::max(1, std::min(rows_per_task, 8));
   // Time model (us, measured on MI355X with one workgroup per CU: D 39-45, T 25-32, U 25-30 at K = 128 and 45-52 at K = 256, TU 40
@@ -88,8 +68,7 @@ void df_build_queue(const std::vector<DfFront>& fronts, int workers, int group, 
   // between diagonal blocks instead of 45 in the bulk-bound phase of the S-metric root); one that is popped early only costs a
   // waiting workgroup.
   static const float chain_scale = getenv("OKKT_DF_MODEL_CHAIN") ? (float)atof(getenv("OKKT_DF_MODEL_CHAIN")) : 0.6f;
-  static const float bulk_env = getenv("OKKT_DF_MODEL_BULK") ? (float)atof(getenv("OKKT_DF_MODEL_BULK")) : 1.0f;
-  const float bulk_scale = bulk_env * bulk_mul;
+  static const float bulk_scale = getenv("OKKT_DF_MODEL_BULK") ? (float)atof(getenv("OKKT_DF_MODEL_BULK")) : 1.0f;
   std::vector<FrontGrid> grids(fronts.size());
   struct Node { int front; int type; int i, j, q0, nq; int ndep; float dur; int64_t key; int rows; int64_t fwd; };      // type -1: a placeholder (an update that runs inside the task `fwd`)
   std::vector<Node> nodes;
@@ -131,9 +110,8 @@ void df_build_queue(const std::vector<DfFront>& fronts, int workers, int group, 
       g.tq[q + 1] = g.tq[q] + std::max(TB - first, 0);
       // fuse_tl: from panel 1 on the panel tile carries the last update of its tile (TL): it waits for that update's operands (the
       // placeholder below forwards them) and for the START of D(q)
-      // (two-kernel form: only the rows near the chain -- the bulk kernel has no TL body, and the far rows have the slack for two tasks)
       for (int i = first; i < TB; ++i)
-        nodes.push_back({(int)a, (fuse_tl && q > 0 && (chain_workers <= 0 || i - q <= near + 1)) ? kDfTL : kDfT, i, q, q, 1, 1 + (q > 0 ? 1 : 0), (near_chain_task(kDfT, i, q, q, 1, KB, near) ? bulk_env : bulk_scale) * 28.0f, key(q, 2, i, q), 1, -1});
+        nodes.push_back({(int)a, (fuse_tl && q > 0) ? kDfTL : kDfT, i, q, q, 1, 1 + (q > 0 ? 1 : 0), bulk_scale * 28.0f, key(q, 2, i, q), 1, -1});
     }
     // Update tasks.  The groups of a column that are not the lone last panel of a pivot column are bulk work: the tiles below the
     // diagonal tile are taken `rows_per_task` at a time (one pop, one wait, one acquire and one drain per task, and the C tile of
@@ -151,11 +129,11 @@ void df_build_queue(const std::vector<DfFront>& fronts, int workers, int group, 
         for (int i = j; i < TB;) {
           const int rows = i == j ? 1 : std::min(R, TB - i);
           const bool in_tu = i == j && lone_last;                  // the last panel of a diagonal pivot tile: part of TU(j - 1)
-          const bool in_tl = fuse_tl && lone_last && i > j && !(i == j + 1 && j + 1 < KB) && (chain_workers <= 0 || i - j <= near + 1);      // ... of a tile below the TU row: part of TL(i, j)
+          const bool in_tl = fuse_tl && lone_last && i > j && !(i == j + 1 && j + 1 < KB);      // ... of a tile below the TU row: part of TL(i, j)
           const int ndep = (i != j ? rows + 1 : 1) + (c > 0 ? 1 : 0);
           for (int r = 0; r < rows; ++r) g.unode[j][c][i + r] = (int64_t)nodes.size();
           nodes.push_back({(int)a, in_tu ? -1 : (in_tl ? -2 : kDfU), i, j, q0, nq, ndep,
-                           (near_chain_task(kDfU, i, j, q0, nq, KB, near) ? bulk_env : bulk_scale) * (6.0f + 0.16f * 128.0f * (float)nq * (float)rows + 4.0f * (float)(rows - 1)), key(j, 3, i, q0), rows,
+                           bulk_scale * (6.0f + 0.16f * 128.0f * (float)nq * (float)rows + 4.0f * (float)(rows - 1)), key(j, 3, i, q0), rows,
                            in_tl ? g.offT + g.tq[j] + (i - (j + 1 < KB ? j + 2 : j + 1)) : -1});      // in_tl (type -2): once its operands are there it releases TL(i, j)
           i += rows;
         }
@@ -166,40 +144,27 @@ void df_build_queue(const std::vector<DfFront>& fronts, int workers, int group, 
     if (q + 1 < g.KB) return i == q + 1 ? g.offTU + q : g.offT + g.tq[q] + (i - q - 2);
     return g.offT + g.tq[q] + (i - q - 1);
   };
-  // list schedule: `workers` identical workers, a ready task with the smallest key starts as soon as a worker is free.  With
-  // chain_workers > 0 (the two-kernel form of dataflow.hip) the chain tasks D / TU have a pool of their own and the panel tiles and
-  // updates share `workers` bulk workers; the emitted order is still ONE sequence, which df_split_queue cuts into the kernels' queues
+  // list schedule: `workers` identical workers, a ready task with the smallest key starts as soon as a worker is free
   typedef std::pair<int64_t, int64_t> KI;   // (key, node)
-  std::priority_queue<KI, std::vector<KI>, std::greater<KI>> ready_pool[2];
+  std::priority_queue<KI, std::vector<KI>, std::greater<KI>> ready;
   typedef std::pair<double, int64_t> TI;    // (finish time, node)
   std::priority_queue<TI, std::vector<TI>, std::greater<TI>> running;
-  auto pool_of = [&](const Node& nd) {
-    if (chain_workers <= 0) return 0;
-    return (nd.type == kDfD || nd.type == kDfTU || nd.type == kDfTL || near_chain_task(nd.type, nd.i, nd.j, nd.q0, nd.nq, grids[nd.front].KB, near)) ? 1 : 0;
-  };
-  for (int64_t x = 0; x < (int64_t)nodes.size(); ++x) if (nodes[x].type >= 0 && nodes[x].ndep == 0) ready_pool[pool_of(nodes[x])].push({nodes[x].key, x});
+  for (int64_t x = 0; x < (int64_t)nodes.size(); ++x) if (nodes[x].type >= 0 && nodes[x].ndep == 0) ready.push({nodes[x].key, x});
   out.clear();
   out.reserve(nodes.size());
   double now = 0;
-  int idle_pool[2] = {std::max(1, workers), std::max(0, chain_workers)};
+  int idle = std::max(1, workers);
   std::function<void(int64_t)> release = [&](int64_t x) {
     if (--nodes[x].ndep != 0) return;
     if (nodes[x].type == -2) release(nodes[x].fwd);      // an update inside TL: its operands are what the task waits for
-    else ready_pool[pool_of(nodes[x])].push({nodes[x].key, x});
+    else ready.push({nodes[x].key, x});
   };
   std::vector<std::vector<double>> dend(fronts.size());      // [front][q]: end of D(q) in the model (TL tasks start before it)
   for (size_t a = 0; a < fronts.size(); ++a) dend[a].assign(grids[a].KB, 0.0);
-  auto any_ready = [&]() { return !ready_pool[0].empty() || !ready_pool[1].empty(); };
-  while (any_ready() || !running.empty()) {
-    for (;;) {
-      // the more urgent of the two pools' heads that has a free worker
-      int pl = -1;
-      for (int c = 0; c < 2; ++c)
-        if (idle_pool[c] > 0 && !ready_pool[c].empty() && (pl < 0 || ready_pool[c].top().first < ready_pool[pl].top().first)) pl = c;
-      if (pl < 0) break;
-      int& idle = idle_pool[pl];
-      const int64_t x = ready_pool[pl].top().second;
-      ready_pool[pl].pop();
+  while (!ready.empty() || !running.empty()) {
+    while (idle > 0 && !ready.empty()) {
+      const int64_t x = ready.top().second;
+      ready.pop();
       Node& nd = nodes[x];
       // fuse_d: D(q), q >= 1, is carried out by the worker of TU(q - 1) right behind the update of its tile (no task of its own; it stays
       // in this simulation, where it starts on some worker the moment TU(q - 1) ends -- the same thing for the model)
@@ -214,7 +179,7 @@ void df_build_queue(const std::vector<DfFront>& fronts, int workers, int group, 
       } else if (!(fuse_d && nd.type == kDfD && nd.i > 0))
         out.push_back({fronts[nd.front].s, nd.type | (nd.nq << 8) | (nd.rows << 16), nd.i | (nd.j << 16), nd.q0});
       if (nd.type == kDfTL)      // the update (14 us) runs ahead of D(q); the solve, the stores and the hand-off behind it
-        nd.dur = (float)(std::max(now + 14.0 * bulk_env, dend[nd.front][nd.j]) + 22.0 * bulk_env - now);
+        nd.dur = (float)(std::max(now + 14.0 * bulk_scale, dend[nd.front][nd.j]) + 22.0 * bulk_scale - now);
       running.push({now + nd.dur, x});
       --idle;
       if (nd.type == kDfD) {
@@ -239,7 +204,7 @@ void df_build_queue(const std::vector<DfFront>& fronts, int workers, int group, 
     now = running.top().first;
     running.pop();
     const Node nd = nodes[x];
-    ++idle_pool[pool_of(nd)];
+    ++idle;
     const FrontGrid& g = grids[nd.front];
     const int KB = g.KB, TB = g.TB;
     if (nd.type == kDfD) {
@@ -283,37 +248,6 @@ void df_build_queue(const std::vector<DfFront>& fronts, int workers, int group, 
     }
   }
   if (model_us) *model_us = now;
-}
-
-// The two-kernel form (dataflow.hip: k_front_bulk beside k_front_dataflow): the chain tasks D / TA / TU keep their relative order in
-// `chain`; the panel tiles and the updates go to one queue per XCD.  Every queue is a subsequence of the one topological order, so
-// the earliest unfinished task is always at the head of its queue or running: the in-order pop rule keeps the launch deadlock-free
-// as long as every queue has a resident worker.  Which XCD: the rows of tile column j are cut into eight contiguous chunks counted
-// from the bottom of the front -- a chunk keeps its rows while the column moves to the right, so the updates of one row band by
-// consecutive tile columns share the W panel in that XCD's L2, and the ~8 rows x ~8 columns an XCD has in flight share their L
-// panels -- rotated by the update group (different groups read different panels anyway) so that the short chunk at the diagonal
-// does not always fall on the same XCD.
-void df_split_queue(const std::vector<DfFront>& fronts, const std::vector<DfTask>& q, std::vector<DfTask>& chain, std::vector<DfTask> bulk[8]) {
-  chain.clear();
-  for (int x = 0; x < 8; ++x) bulk[x].clear();
-  std::vector<std::pair<int, int>> byfront;      // (supernode, index in fronts), sorted
-  for (size_t a = 0; a < fronts.size(); ++a) byfront.push_back({fronts[a].s, (int)a});
-  std::sort(byfront.begin(), byfront.end());
-  for (const DfTask& t : q) {
-    const int type = t.type_nq & 255;
-    if (type == kDfD || type == kDfTU || type == kDfTA || type == kDfTL) { chain.push_back(t); continue; }
-    const auto it = std::lower_bound(byfront.begin(), byfront.end(), std::make_pair(t.front, -1));
-    const int a = it->second;
-    const int f = fronts[a].f, k = fronts[a].k;
-    const int KB = (k + 127) / 128;
-    const int TB = KB + (f - k + 127) / 128;
-    const int i = t.ij & 0xffff, j = t.ij >> 16;
-    if (near_chain_task(type, i, j, t.q0, (t.type_nq >> 8) & 255, KB, df_near_rows())) { chain.push_back(t); continue; }
-    const int col = type == kDfT ? j + 1 : j;                 // first row of the column's range
-    const int cs = std::max(1, (TB - col + 7) / 8);
-    const int c = std::min(7, (TB - 1 - i) / cs);
-    bulk[(c + (t.q0 >> 2) + a) & 7].push_back(t);
-  }
 }
 
 }  // namespace okkt

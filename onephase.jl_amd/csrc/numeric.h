@@ -96,19 +96,12 @@ struct DevPlan {
 enum { kDfD = 0, kDfT = 1, kDfU = 2, kDfTU = 3, kDfTA = 4, kDfTL = 5 };
 struct DfTask { int front; int type_nq; int ij; int q0; };     // type | nq << 8 | rows << 16 (update tasks: tiles (i .. i + rows - 1, j)), i | j << 16
 struct DfFront { int s, f, k; };
-// what a bulk task of the two-kernel form waits for and publishes: three (index into the tile states, least value) pairs, then the index and
-// the value of its own tile (dataflow.hip: bulk_claim looks at these instead of decoding the task)
-struct DfDep { int a0, n0, a1, n1, a2, n2, mine, newv; };
 // queue of the fronts of one level in the start order of a simulated list schedule on `workers` workers; `group` panels per
 // update task where the tile allows it; model_us = the simulated makespan
-// chain_workers > 0: the model of the two-kernel form -- D / TU run on a pool of their own, the panel tiles and updates on `workers`
-// bulk workers whose task durations are scaled by bulk_mul (two workgroups share a CU's matrix pipes)
 void df_build_queue(const std::vector<DfFront>& fronts, int workers, int group, int rows_per_task, bool fuse_d, bool split_tu, std::vector<DfTask>& out, double* model_us,
-                    int chain_workers = 0, float bulk_mul = 1.0f, bool fuse_tl = false);
-// the queue cut into the chain kernel's queue (D, TA, TU) and one queue of panel tiles and updates per XCD, each in the order of `q`
-void df_split_queue(const std::vector<DfFront>& fronts, const std::vector<DfTask>& q, std::vector<DfTask>& chain, std::vector<DfTask> bulk[8]);
+                    bool fuse_tl = false);
 
-constexpr int kDfHeadStride = 16;   // queue counters of a level: words 0 .. 7 the per-XCD queues of the bulk kernel (word 0: the single queue of an unsplit level), word 8 the chain queue
+constexpr int kDfHeadStride = 16;   // queue counter of a level (word 0; one cache line per level)
 constexpr int kCountSlots = 64, kCountStride = 16;
 #ifndef OKKT_SOLVE_BLOCK
 #define OKKT_SOLVE_BLOCK 1024
@@ -131,9 +124,6 @@ struct Segment {
   int64_t df_off = -1;     // class 3 (big fronts): the level's task queue in Numeric::df_tasks, its length, its head counters (kDfHeadStride words), its flops
   int df_cnt = 0, df_head = -1;
   double df_flops = 0;
-  // two-kernel form of the level (dataflow.hip: k_front_bulk + k_front_dataflow as the chain kernel): the chain queue [df_off, df_off + dfc_cnt),
-  // behind it the eight per-XCD queues of panel tiles and updates (offsets / lengths in Numeric::df_qinfo + df_head * 16)
-  int df_split = 0, dfc_cnt = 0, dfb_cnt = 0;
 };
 struct LevelSchedule { Segment seg[kNumClasses]; };
 
@@ -143,7 +133,7 @@ struct SolveLevel {
   int wide_off = 0, wide_cnt = 0, wide_maxf = 0, wide_maxk = 0;
 };
 
-struct LaneStreams { hipStream_t main = nullptr, masked = nullptr, panel = nullptr, aux = nullptr, chain = nullptr; };
+struct LaneStreams { hipStream_t main = nullptr, masked = nullptr, panel = nullptr, aux = nullptr; };
 
 struct Numeric {
   DevPlan d;
@@ -209,18 +199,6 @@ struct Numeric {
   int df_fuse_tl = 1;                  // T(i, q) with the last update of its tile inside the task (TL), q >= 1 (OKKT_DF_FUSE_TL=0: separate tasks)
   int df_rows = 1;                     // row tiles per bulk update task (OKKT_DF_ROWS; 2 and 4 measured slower: the coarser tasks cost the schedule more than the shared prologue saves)
   int df_workers = 256;                // workers of the simulated schedule (and the grid of the launch): one workgroup per CU
-  int df_split_fronts = 0;             // levels of at most this many big fronts run in the two-kernel form (OKKT_DF_SPLIT_FRONTS; 0: never)
-  int df_chain_workers = 8;            // workgroups of the chain kernel = the CUs the masked stream leaves free
-  int df_bulk_workers = 496;           // workgroups of the bulk kernel: two per CU of the masked stream
-  int* df_qinfo = nullptr;             // [levels][16]: offset and length of the eight bulk queues
-  DfDep* df_deps = nullptr;            // [tasks] parallel to df_tasks (bulk tasks of the two-kernel levels)
-  int* df_claim = nullptr;             // [tasks] claim words of the bulk tasks (behind the queue heads: cleared with them)
-  int64_t df_ntasks = 0;
-  int* df_asm_flags = nullptr;         // [nsuper] epoch of the factorisation whose assembly of the front is complete (set by the bulk kernel)
-  int df_epoch = 0;
-  hipStream_t stream_chain = nullptr;  // CU-masked to the reserved CUs: the chain kernel
-  hipEvent_t df_ev_chain = nullptr;    // recorded behind the last chain kernel of a factorisation
-  bool df_chain_pending = false;
   DfTask* df_tasks = nullptr;
   int* df_heads = nullptr;
   int n_df_heads = 0;
@@ -272,7 +250,5 @@ void launch_set_shift(const Numeric& N, double delta, int64_t nshift);
 // dataflow.hip: the big fronts of one level (class-3 segment g, already assembled) as one persistent launch on `st`
 std::string df_setup(Numeric& N);
 std::string df_launch(Numeric& N, const DevPlan& P, const Segment& g, hipStream_t st, double tol);
-// the two-kernel form: the bulk kernel on st_bulk (behind the level's assembly), the chain kernel on st_chain
-std::string df_launch_split(Numeric& N, const DevPlan& P, const Segment& g, hipStream_t st_bulk, hipStream_t st_chain, double tol);
 
 }  // namespace okkt

@@ -1058,7 +1058,7 @@ std::string numeric_setup(const Symbolic& S, const SymbolicOptions& opts, hipStr
   sched.reserve(ns);
   // W = L21 D of the big fronts' panels is dead once its level's launches have finished (the block inversions and the solves read F,
   // invl and xinv only), so a level's fronts take their W from one of TWO regions by the parity of the level: consecutive levels never
-  // share one (a chain kernel of the two-kernel form may still be in its last diagonal block when the next level starts), and the
+  // share one (the two-kernel form, now a patch, could still be in a level's last diagonal block when the next level started), and the
   // buffer is max over the even levels + max over the odd levels instead of the sum over all fronts (advisor, round 4: a second copy
   // of every pivot column, growing with nnz(L)).  wbuf_pos is relative to the region; the region's base is added below.
   std::vector<int64_t> wpos(ns, -1);
@@ -1433,8 +1433,7 @@ std::string numeric_factor_enqueue(Numeric& N, const double* d_vals, double tol,
   // its bound) leaves a residue that would let the next solve's consumer start early: cleared with the time-out word (advisor, round 3)
   if (reset_counters && N.solve_counters) OKKT_HIP_TRY(hipMemsetAsync(N.solve_counters, 0, (size_t)N.d.nsuper * sizeof(int), st));
   if (N.dataflow && P.df_state) {
-    OKKT_HIP_TRY(hipMemsetAsync(P.df_state, 0, ((size_t)N.df_state_ints + (size_t)N.n_df_heads * kDfHeadStride + (size_t)N.df_ntasks) * sizeof(int), st));   // tile states, queue heads, claim words
-    ++N.df_epoch;      // the assembly flags of the two-kernel levels are monotonic: a new value per factorisation instead of a fill
+    OKKT_HIP_TRY(hipMemsetAsync(P.df_state, 0, ((size_t)N.df_state_ints + (size_t)N.n_df_heads * kDfHeadStride) * sizeof(int), st));   // tile states, queue heads
   }
   if (N.early_check && N.early_device && which == 0 && N.levels_top.empty() && reset_counters) { P.want_pos = N.early_n; P.want_neg = N.early_m; }
   N.la_used = 0;
@@ -1453,7 +1452,7 @@ std::string numeric_factor_enqueue(Numeric& N, const double* d_vals, double tol,
   N.early_exited = false;
   std::string e;
   {
-    const LaneStreams ss{N.stream, N.stream_masked, N.stream_panel, N.stream_aux, N.stream_chain};
+    const LaneStreams ss{N.stream, N.stream_masked, N.stream_panel, N.stream_aux};
     e = factor_sched(N, P, which == 0 ? N.levels : N.levels_top, which == 0 ? N.slevels : N.slevels_top, ss, tol,
                      which == 0 && N.levels_top.empty(), inv_on_aux);
     if (!e.empty()) return e;
@@ -1470,40 +1469,7 @@ std::string numeric_factor_enqueue(Numeric& N, const double* d_vals, double tol,
 
 static std::string factor_sched(Numeric& N, DevPlan P, const std::vector<LevelSchedule>& levels, const std::vector<SolveLevel>& slevels,
                                 const LaneStreams& ss, double tol, bool in_loop_check, bool& inv_on_aux, size_t l_begin, size_t l_end) {
-  // `cur`: the stream the schedule is on.  The levels that run in the two-kernel form of the dataflow launch (dataflow.hip) sit on the
-  // CU-masked twin of the handle's stream, their chain kernels on the chain stream (the reserved CUs); everything else on the handle's
-  // stream.  A change of stream is one event; the chain stream is tied to the start of the factorisation (the fill of the tile states
-  // must not overtake a chain kernel that finds the previous factorisation's states) and joined at the end.
-  hipStream_t cur = ss.main;
-  bool chain_used = false;
-  auto next_event_top = [&](hipEvent_t* ev) -> std::string {
-    if (N.la_used >= N.la_events.size())
-      for (int q = 0; q < 64; ++q) { hipEvent_t e2; OKKT_HIP_TRY(hipEventCreateWithFlags(&e2, hipEventDisableTiming)); N.la_events.push_back(e2); }
-    *ev = N.la_events[N.la_used++];
-    return "";
-  };
-  auto move_to = [&](hipStream_t to) -> std::string {
-    if (to == cur || to == nullptr) return "";
-    hipEvent_t ev;
-    std::string e2 = next_event_top(&ev);
-    if (!e2.empty()) return e2;
-    OKKT_HIP_TRY(hipEventRecord(ev, cur));
-    OKKT_HIP_TRY(hipStreamWaitEvent(to, ev, 0));
-    cur = to;
-    return "";
-  };
-  auto finish = [&]() -> std::string {
-    std::string e2 = move_to(ss.main);
-    if (!e2.empty()) return e2;
-    if (chain_used) {
-      hipEvent_t ev;
-      if (!(e2 = next_event_top(&ev)).empty()) return e2;
-      OKKT_HIP_TRY(hipEventRecord(ev, ss.chain));
-      OKKT_HIP_TRY(hipStreamWaitEvent(ss.main, ev, 0));
-      chain_used = false;
-    }
-    return "";
-  };
+  const hipStream_t cur = ss.main;      // the stream the schedule is on
   const int NB = N.nb;
   static const int dbg_syrk = getenv("OKKT_DEBUG_SYRK") ? atoi(getenv("OKKT_DEBUG_SYRK")) : 0;
   static const int split_min_rows = getenv("OKKT_SPLIT_MIN_ROWS") ? atoi(getenv("OKKT_SPLIT_MIN_ROWS")) : 5000;
@@ -1519,7 +1485,7 @@ static std::string factor_sched(Numeric& N, DevPlan P, const std::vector<LevelSc
       if (!ec.empty()) return ec;
       if (cnt[4] != 0 || cnt[3] > 0 || cnt[2] > 0 || cnt[1] > (unsigned long long)N.early_m || cnt[0] > (unsigned long long)N.early_n) {
         N.early_exited = true;
-        return finish();
+        return "";
       }
     }
     if (l == 0 && &levels == &N.levels && N.flow_levels >= 2 && l_end >= (size_t)N.flow_levels && N.flow_flags) {
@@ -1579,11 +1545,6 @@ static std::string factor_sched(Numeric& N, DevPlan P, const std::vector<LevelSc
       // to the panel streams); every other level keeps all CUs
       // the level's big fronts as one persistent dataflow launch (dataflow.hip) instead of the per-step launches below
       const bool use_df = N.dataflow && g.df_cnt > 0 && NB == 128 && dbg_syrk == 0 && dbg_stop == 0 && P.df_state != nullptr;
-      const bool use_split = use_df && g.df_split && ss.masked && ss.chain;
-      {
-        std::string em = move_to(use_split ? ss.masked : ss.main);
-        if (!em.empty()) return em;
-      }
       const bool seg_la = !use_df && la_at(0, gs_at(0));
       hipStream_t st = cur;
       if (seg_la) {
@@ -1806,24 +1767,9 @@ static std::string factor_sched(Numeric& N, DevPlan P, const std::vector<LevelSc
           OKKT_HIP_TRY(hipEventRecord(N.prof_events[N.prof_used++], st));
         }
         std::string e;
-        if (use_split) {
-          if (!chain_used) {      // first chain kernel of this factorisation: behind the fill of the tile states (and whatever the handle's stream has done since)
-            hipEvent_t evc;
-            if (!(e = next_event(&evc)).empty()) return e;
-            OKKT_HIP_TRY(hipEventRecord(evc, st));
-            OKKT_HIP_TRY(hipStreamWaitEvent(ss.chain, evc, 0));
-            chain_used = true;
-          }
-          e = df_launch_split(N, P, g, st, ss.chain, tol);
-        } else e = df_launch(N, P, g, st, tol);
+        e = df_launch(N, P, g, st, tol);
         if (!e.empty()) return e;
         if (prof) OKKT_HIP_TRY(hipEventRecord(N.prof_events[N.prof_used++], st));
-        if (use_split) {      // the block inversions read what the chain kernel wrote as well
-          hipEvent_t evc;
-          if (!(e = next_event(&evc)).empty()) return e;
-          OKKT_HIP_TRY(hipEventRecord(evc, ss.chain));
-          OKKT_HIP_TRY(hipStreamWaitEvent(inv_st, evc, 0));
-        }
         if (!(e = inv_range(nsteps, true)).empty()) return e;
         if (!(e = level_inv_event()).empty()) return e;
         continue;
@@ -1871,7 +1817,7 @@ static std::string factor_sched(Numeric& N, DevPlan P, const std::vector<LevelSc
       }
     }
   }
-  return finish();
+  return "";
 }
 
 

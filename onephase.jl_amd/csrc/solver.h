@@ -27,7 +27,6 @@ struct okkt_solver_s {
   int stream_seq = 0;                       // its order of creation in the process
   hipStream_t stream_panel = nullptr;  // look-ahead panel stream (high priority, all CUs)
   hipStream_t stream_aux = nullptr;    // second panel stream: the part of the in-group updates that k_big_diag does not wait for
-  hipStream_t stream_chain = nullptr;  // CU mask of exactly the reserved CUs: the chain kernel of the two-kernel dataflow levels
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::vector<int64_t> user_perm;
   std::vector<int64_t> pat_colptr, pat_rowval;   // the analysed pattern as the caller passed it (exact re-use test in okkt_analyze)

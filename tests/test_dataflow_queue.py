@@ -12,7 +12,6 @@ import pytest
 from onephase_jl_amd import _lib
 
 D, T, U, TU, TA, TL = 0, 1, 2, 3, 4, 5
-NEAR = 6      # dataflow_sched.cpp: df_near_rows()
 
 
 def build_queue(fronts, workers=256, group=2, rows=1, fuse_d=False, split=False, fuse_tl=False):
@@ -29,27 +28,6 @@ def build_queue(fronts, workers=256, group=2, rows=1, fuse_d=False, split=False,
     q = np.frombuffer(buf, dtype=np.int32).reshape(-1, 4)[:cnt]
     tasks = [(int(a), int(b) & 255, (int(b) >> 8) & 255, int(c) & 0xFFFF, int(c) >> 16, int(d), max(int(b) >> 16, 1)) for a, b, c, d in q]
     return tasks, model.value
-
-
-def build_split(fronts, workers=496, chain_workers=8, group=4, fuse_d=True, split=True, fuse_tl=False):
-    lib = _lib.load()
-    n = len(fronts)
-    f = (C.c_int32 * n)(*[a for a, _ in fronts])
-    k = (C.c_int32 * n)(*[b for _, b in fronts])
-    qlen = (C.c_int32 * 9)()
-    g = group | ((1 if fuse_d else 0) << 16) | ((1 if split else 0) << 17) | ((1 if fuse_tl else 0) << 18)
-    cnt = lib.okkt_debug_dataflow_split(n, f, k, workers, chain_workers, g, None, 0, qlen)
-    assert cnt >= 0
-    buf = (C.c_int32 * (4 * max(cnt, 1)))()
-    assert lib.okkt_debug_dataflow_split(n, f, k, workers, chain_workers, g, buf, cnt, qlen) == cnt
-    q = np.frombuffer(buf, dtype=np.int32).reshape(-1, 4)[:cnt]
-    tasks = [(int(a), int(b) & 255, (int(b) >> 8) & 255, int(c) & 0xFFFF, int(c) >> 16, int(d), max(int(b) >> 16, 1)) for a, b, c, d in q]
-    queues, pos = [], 0
-    for x in range(9):
-        queues.append(tasks[pos:pos + qlen[x]])
-        pos += qlen[x]
-    assert pos == cnt
-    return queues
 
 
 def bounds(f, k):
@@ -73,7 +51,7 @@ def dense_partial_ldlt(A, k):
     return A
 
 
-def replay(fronts, tasks, group, fused=False, split=False, queues=None, policy=0, fuse_tl=False):
+def replay(fronts, tasks, group, fused=False, split=False, fuse_tl=False):
     rng = np.random.default_rng(7)
     halves = set()
     mats, refs, states, Ws, grids = [], [], [], [], []
@@ -87,7 +65,7 @@ def replay(fronts, tasks, group, fused=False, split=False, queues=None, policy=0
         grids.append((KB, TB, b))
         states.append(np.zeros((TB, TB), dtype=int))
         Ws.append(np.zeros((f, k)))
-    tl_tiles = {(t[0], t[3], t[4]) for t in (tasks if queues is None else [x for q in queues for x in q]) if t[1] == TL}
+    tl_tiles = {(t[0], t[3], t[4]) for t in tasks if t[1] == TL}
 
     def ready(task):
         """the tile states the kernels wait for before a popped task starts (dataflow.hip: the worker's poll, and D(q) inside TU / TA)"""
@@ -156,7 +134,7 @@ def replay(fronts, tasks, group, fused=False, split=False, queues=None, policy=0
                       rows_t = slice(b[i] + 64, b[i + 1])
               else:
                   assert nq == 1
-                  assert not (fuse_tl and queues is None and typ == T and q >= 1), "T(i, q >= 1) must be a TL task"
+                  assert not (fuse_tl and typ == T and q >= 1), "T(i, q >= 1) must be a TL task"
               cq = slice(b[q], b[q + 1])
               Lqq = np.tril(A[cq, cq], -1) + np.eye(b[q + 1] - b[q])
               d = np.diag(A[cq, cq])
@@ -184,7 +162,7 @@ def replay(fronts, tasks, group, fused=False, split=False, queues=None, policy=0
               ql = q0 + nq - 1
               assert 1 <= nq <= max(group, 1) and i >= j > ql and ql < KB, ("U shape", a, i, j, q0, nq)
               assert not (ql == j - 1 and (a, i, j) in tl_tiles), ("this update belongs inside TL", a, i, j, q0, nq)
-              assert not (fuse_tl and queues is None and j < KB and ql == j - 1 and i > j and not (i == j + 1 and j + 1 < KB)), ("one-kernel form: every block row below TU's is fused", a, i, j)
+              assert not (fuse_tl and j < KB and ql == j - 1 and i > j and not (i == j + 1 and j + 1 < KB)), ("every block row below TU's is fused", a, i, j)
               assert st[i, ql] >= ql + 1 and st[j, ql] >= ql + 1 and st[i, j] == q0, ("U out of order", a, i, j, q0, nq, st[i, j])
               cj = slice(b[j], b[j + 1])
               kk = slice(b[q0], b[ql + 1])
@@ -193,38 +171,9 @@ def replay(fronts, tasks, group, fused=False, split=False, queues=None, policy=0
                   upd = np.tril(upd)
               A[ri, cj] -= upd
               st[i, j] = q0 + nq
-    if queues is None:
-        for task in tasks:
-            assert ready(task), ("dependency later in the queue", task)
-            run(task)
-    else:
-        # the kernels' pop rule with ONE worker per queue (the fewest the launch may have): a worker pops the head of its queue, holds the
-        # task until it is ready, runs it; a bulk worker whose queue is exhausted moves on to the next bulk queue.  Queue 0 is the chain
-        # kernel's, queues 1 .. 8 the bulk kernel's.  `policy` picks among the ready workers: any interleaving must finish.
-        rng2 = np.random.default_rng(policy)
-        heads = [0] * len(queues)
-        serving = list(range(len(queues)))        # queue a worker currently pops from
-        holding = [None] * len(queues)
-        left = sum(len(q) for q in queues)
-        while left:
-            for w in range(len(queues)):
-                moved = 0
-                while holding[w] is None and moved < 8:
-                    qx = serving[w]
-                    if heads[qx] < len(queues[qx]):
-                        holding[w] = queues[qx][heads[qx]]
-                        heads[qx] += 1
-                    elif w == 0:
-                        break
-                    else:
-                        serving[w] = 1 + (qx % 8)      # next bulk queue
-                        moved += 1
-            can = [w for w in range(len(queues)) if holding[w] is not None and ready(holding[w])]
-            assert can, ("deadlock: no held task is ready", [holding[w] for w in range(len(queues))], left)
-            w = can[0] if policy == 0 else (can[-1] if policy == 1 else can[int(rng2.integers(len(can)))])
-            run(holding[w])
-            holding[w] = None
-            left -= 1
+    for task in tasks:
+        assert ready(task), ("dependency later in the queue", task)
+        run(task)
     for a, (f, k) in enumerate(fronts):
         KB, TB, b = grids[a]
         for i in range(TB):
@@ -254,40 +203,6 @@ def test_queue_replays_to_the_partial_factorisation(fronts, group, rows, fused, 
     tasks, model = build_queue(fronts, workers=16, group=group, rows=rows, fuse_d=fused, split=split, fuse_tl=tl)
     assert model > 0
     replay(fronts, tasks, group, fused, split, fuse_tl=tl)
-
-
-@pytest.mark.parametrize("fronts", CASES + [[(2600, 2600)], [(1800, 700), (1500, 1500)]])
-@pytest.mark.parametrize("group,fused,split,policy,tl", [(4, True, True, 0, True), (4, True, True, 1, False), (4, True, True, 7, True), (2, False, False, 3, False), (3, True, False, 11, True)])
-def test_two_kernel_queues_finish_under_any_interleaving(fronts, group, fused, split, policy, tl):
-    """The two-kernel form: the chain queue (D / TA / TU) and the eight per-XCD queues of panel tiles and updates, each popped in order
-    by a worker of its own -- some held task is always ready (no deadlock) and the result is the partial factorisation."""
-    queues = build_split(fronts, workers=48, chain_workers=4, group=group, fuse_d=fused, split=split, fuse_tl=tl)
-    # the chain kernel's queue: the chain itself and its feeders -- the panel tiles of the block rows right below TU's and the single-panel
-    # updates within NEAR rows of the diagonal; everything else in the bulk queues
-    assert all(t[1] in (D, TU, TA, TL) or (t[1] == T and t[3] - t[4] <= NEAR + 1) or (t[1] == U and t[2] == 1 and t[3] - t[4] <= NEAR) for t in queues[0])
-    assert all(t[1] in (T, U) for q in queues[1:] for t in q)
-    single, _ = build_queue(fronts, workers=48, group=group, fuse_d=fused, split=split, fuse_tl=tl)
-    if not tl:      # (with TL tasks the two forms differ: the one-kernel form fuses every block row, the two-kernel form the near ones)
-        assert sorted(t for q in queues for t in q) == sorted(single) or len(single) == sum(len(q) for q in queues)
-    replay(fronts, None, group, fused, split, queues=queues, policy=policy, fuse_tl=tl)
-
-
-def test_two_kernel_queues_keep_row_bands_together():
-    """the updates of one tile row by neighbouring tile columns (same panels) sit in the same XCD's queue: they share the W panel"""
-    queues = build_split([(6000, 6000)], workers=496, chain_workers=8, group=4)
-    where = {}
-    for x, q in enumerate(queues[1:]):
-        for (a, typ, nq, i, j, q0, R) in q:
-            if typ == U:
-                where[(i, j, q0)] = x
-    same = tot = 0
-    for (i, j, q0), x in where.items():
-        if (i, j + 1, q0) in where and i > j + 1:
-            tot += 1
-            same += where[(i, j + 1, q0)] == x
-    assert tot > 500 and same / tot > 0.8, (same, tot)
-    sizes = [len(q) for q in queues[1:]]
-    assert max(sizes) < 1.25 * min(sizes), sizes
 
 
 def test_queue_is_the_same_every_time_and_scales():

@@ -39,32 +39,16 @@ def test_dataflow_equals_the_per_step_launches_bit_for_bit(case, tmp_path):
 @pytest.mark.parametrize("env", [{"OKKT_DF_GROUP": "1"}, {"OKKT_DF_GROUP": "2"}, {"OKKT_DF_GROUP": "3", "OKKT_DF_ROWS": "2"}, {"OKKT_DF_ROWS": "4"},
                                  {"OKKT_DF_WORKERS": "7"}, {"OKKT_DF_WORKERS": "64", "OKKT_DF_MODEL_CHAIN": "2.0"}, {"OKKT_DF_SPLIT_TU": "0"},
                                  {"OKKT_DF_SPLIT_TU": "0", "OKKT_DF_FUSE_D": "0"}, {"OKKT_DF_FUSE_D": "0"},
-                                 {"OKKT_DF_FUSE_TL": "0"}, {"OKKT_DF_FUSE_TL": "0", "OKKT_DF_FUSE_D": "0", "OKKT_DF_GROUP": "2"},
-                                 # the two-kernel form (bulk kernel with first-ready claims beside the chain kernel), forced on a level of any size;
-                                 # with a near zone of two rows; without TL tasks.  (Its in-order emulation, OKKT_DEBUG_DATAFLOW=32, is not a
-                                 # test case: with the in-order pop rule a bulk queue whose workers are not all resident -- the masked launch never
-                                 # is, DESIGN.md section 4 -- can wait for a task that no resident worker will pop, and the launch ends in its
-                                 # time-out; that is what the first-ready claims are for.)
-                                 {"OKKT_DF_SPLIT_FRONTS": "4", "OKKT_DF_SPLIT_MIN_TASKS": "0"}, {"OKKT_DF_SPLIT_FRONTS": "4", "OKKT_DF_SPLIT_MIN_TASKS": "0", "OKKT_DF_NEAR": "2"},
-                                 {"OKKT_DF_SPLIT_FRONTS": "4", "OKKT_DF_SPLIT_MIN_TASKS": "0", "OKKT_DF_FUSE_TL": "0", "OKKT_RESERVED_CUS": "8"}],
+                                 {"OKKT_DF_FUSE_TL": "0"}, {"OKKT_DF_FUSE_TL": "0", "OKKT_DF_FUSE_D": "0", "OKKT_DF_GROUP": "2"}],
                          ids=lambda e: ",".join(f"{k[8:]}={v}" for k, v in e.items()))
 def test_every_queue_shape_gives_the_same_factor(env, tmp_path):
     """The grouping of the panels, the number of row tiles per task, the number of workers, the time model, one or two workers for
-    the block row behind a diagonal block, the diagonal block as a task of its own, the last update of a tile inside its panel task
-    (TL) and the two-kernel form only change the ORDER of the queue(s) and who computes what; the factor does not depend on it."""
+    the block row behind a diagonal block, the diagonal block as a task of its own and the last update of a tile inside its panel task
+    (TL) only change the ORDER of the queue and who computes what; the factor does not depend on it."""
     a = run_case("dense2600", {"OKKT_DATAFLOW": "1"}, tmp_path, "default")
     e = {"OKKT_DATAFLOW": "1"}
     e.update(env)
     b = run_case("dense2600", e, tmp_path, "variant")
-    assert np.array_equal(a["d"], b["d"]) and np.array_equal(a["Ldata"], b["Ldata"]) and np.array_equal(a["x"], b["x"])
-
-
-def test_two_kernel_form_on_a_real_tree_bit_for_bit(tmp_path):
-    """BASELINE config 3 with every level of at most four big fronts in the two-kernel form (k_front_bulk beside the chain kernel on the
-    CU-masked stream pair): the same factor, bit for bit, as the per-step launches."""
-    a = run_case("S-C3", {"OKKT_DATAFLOW": "0"}, tmp_path, "steps")
-    b = run_case("S-C3", {"OKKT_DATAFLOW": "1", "OKKT_DF_SPLIT_FRONTS": "4", "OKKT_DF_SPLIT_MIN_TASKS": "0"}, tmp_path, "split")
-    assert int(a["rc"]) == 1 and int(b["rc"]) == 1 and a["inertia"].tolist() == b["inertia"].tolist()
     assert np.array_equal(a["d"], b["d"]) and np.array_equal(a["Ldata"], b["Ldata"]) and np.array_equal(a["x"], b["x"])
 
 
