@@ -36,12 +36,11 @@ static int run(const char* name, int n, const std::set<std::pair<int, int>>& e, 
   }
   size_t ntask = 0;
   if (!fronts.empty()) {
-    std::vector<DfTask> q, chain, bulk[8];
+    std::vector<DfTask> q;
     double model = 0;
-    df_build_queue(fronts, 64, 4, 1, true, true, q, &model, 0, 1.0f, true);
+    df_build_queue(fronts, 64, 4, 1, true, true, q, &model, true);
     ntask = q.size();
-    df_build_queue(fronts, 96, 4, 1, true, true, q, &model, 8, 1.7f, true);
-    df_split_queue(fronts, q, chain, bulk);
+    df_build_queue(fronts, 96, 2, 2, false, false, q, &model, false);
   }
   printf("%-12s ordering %d: n %d nnz(L) %lld supernodes %zu, %zu dataflow tasks\n", name, ordering, n, (long long)S.nnzL, S.sn_col0.size() - 1, ntask);
   return 0;
