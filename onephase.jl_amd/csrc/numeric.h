@@ -66,6 +66,7 @@ struct DevPlan {
   int64_t* xinv_pos = nullptr;   // [nsuper] offset into xinv / xtmp, -1 for fronts with k <= NB (they use invl) and small fronts
   double* ypart = nullptr;       // [kMaxRhs][4][kSolveBlock] per wide front
   int64_t* ypart_pos = nullptr;
+  int solve_mid = 0;             // fronts of NB + 1 .. solve_mid (<= kSolveBlock) pivot columns: block substitution in 64-column steps (k_fwd_mid / k_bwd_mid) instead of the product with the block's explicit inverse; 0 = none
   double* ythin = nullptr;       // [kMaxRhs][128] per thin front: y = X w_K between the two forward launches of a level
   int64_t* ythin_pos = nullptr;
   int* ssched = nullptr;         // big fronts per level, thin (k <= NB) then wide
@@ -130,7 +131,7 @@ struct LevelSchedule { Segment seg[kNumClasses]; };
 // big fronts of one level for the solves: thin (k <= NB: one fused forward launch) and wide (block products with X_b)
 struct SolveLevel {
   int thin_off = 0, thin_cnt = 0, thin_maxf = 0, thin_maxk = 0, thin_maxr = 0;
-  int wide_off = 0, wide_cnt = 0, wide_maxf = 0, wide_maxk = 0;
+  int wide_off = 0, wide_cnt = 0, wide_maxf = 0, wide_maxk = 0, wide_mink = 1 << 30;
 };
 
 struct LaneStreams { hipStream_t main = nullptr, masked = nullptr, panel = nullptr, aux = nullptr; };

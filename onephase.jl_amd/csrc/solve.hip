@@ -639,6 +639,7 @@ __device__ __forceinline__ bool fwd_y_body(const DevPlan& P, int s, int b, int b
 }
 template <int R>
 __global__ __launch_bounds__(256) void k_fwd_y(DevPlan P, const int* __restrict__ list, int b) {
+  if (P.solve_mid) { const int s = list[blockIdx.y]; if (P.sn_col0[s + 1] - P.sn_col0[s] <= P.solve_mid) return; }      // k_fwd_mid's fronts
   (void)fwd_y_body<R, false>(P, list[blockIdx.y], b, (int)blockIdx.x, (int)blockIdx.z);
 }
 
@@ -977,6 +978,7 @@ __device__ __forceinline__ bool bwd_x_body(const DevPlan& P, int s, int b, int b
 }
 template <int R>
 __global__ __launch_bounds__(256) void k_bwd_x(DevPlan P, const int* __restrict__ list, int b) {
+  if (P.solve_mid) { const int s = list[blockIdx.y]; if (P.sn_col0[s + 1] - P.sn_col0[s] <= P.solve_mid) return; }      // k_bwd_mid's fronts
   (void)bwd_x_body<R, false>(P, list[blockIdx.y], b, (int)blockIdx.x, (int)blockIdx.z);
 }
 
@@ -1071,6 +1073,249 @@ __global__ __launch_bounds__(256) void k_bwd_wide_fused(DevPlan P, const int* __
   }
 }
 
+// ---- fronts of NB + 1 .. kSB pivot columns: the pivot block by BLOCK SUBSTITUTION in 64-column steps --------------------------------
+// An explicit inverse is as accurate as substitution for blocks of up to 64 columns and 5 - 40 x worse from 128 columns on (measured on
+// BASELINE configs 3 and 5 with the HIP factor: scripts/solve_emulation.py).  These fronts have ONE block product
+// per sweep (k <= kSB): one workgroup per front takes its place -- y_s = X64_s w_s with the 64 x 64 diagonal blocks of the 128-column
+// inverses the factorisation leaves in `invl`, then the rest of the pivot block's rows minus L y_s, step by step -- and hands the result
+// over where the block product's partial vectors go (split 0; the other splits zero), so that k_fwd_upd / k_bwd_upd stay as they are.
+// The fronts of more than kSB pivot columns (launch chains of kSB-column inverses) are not touched.
+constexpr int kMidThreads = 1024;
+// the 64 x 64 diagonal block of a 128-column inverse: four values per thread, requested a step ahead (registers), stored with leading dimension 65
+__device__ __forceinline__ void mid_load_x(const double* Xb, int o, int NB, double (&xr)[4]) {
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int idx = tid + kMidThreads * u, i = idx & 63, j = idx >> 6;
+    xr[u] = Xb[(o + i) + (size_t)(o + j) * NB];
+  }
+}
+__device__ __forceinline__ void mid_store_x(const double (&xr)[4], double* xb) {
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int idx = tid + kMidThreads * u, i = idx & 63, j = idx >> 6;
+    xb[i + j * 65] = xr[u];
+  }
+}
+template <int R>
+__global__ __launch_bounds__(kMidThreads) void k_fwd_mid(DevPlan P, const int* __restrict__ list, int NB) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];      // w[R][kSB], then the partial sums of the row update [4][R][512]
+  __shared__ double xb[64 * 65], ys[R][64];
+  double* upd = sm + (size_t)R * kSB;
+  double (*part)[R][64] = (double (*)[R][64])upd;      // [16][R][64]: the product's partial sums (the row update's buffer is idle then)
+  const int s = list[blockIdx.x];
+  const int tid = threadIdx.x;
+  const int col0 = P.sn_col0[s];
+  const int k = P.sn_col0[s + 1] - col0;
+  const int f = (int)(P.row_ptr[s + 1] - P.row_ptr[s]);
+  if (k <= NB || k > P.solve_mid) return;
+  const double* F = P.arena + P.front_pos[s];
+  const double* X = P.invl + P.invl_pos[s];
+  const int pr = tid & 255, q = tid >> 8;
+  // the L entries of a step's row update: rows (p, p + 1) below the step, columns 16 q .. 16 q + 15 of it; requested a step ahead (they do
+  // not depend on the step's solution), so that a step waits for LDS only
+  auto load_panel = [&](int c0, int pbase, d2_t (&v)[16]) {
+    const int nb = min(64, k - c0);
+    const int p = pbase + 2 * pr;
+    if (c0 < k && p < k) {
+      const bool two = p + 1 < k;
+      const double* Lr = F + (size_t)(c0 + 16 * q) * f + (two ? p : p - 1);      // a lone last row is the second value of the pair before it
+#pragma unroll
+      for (int u = 0; u < 16; ++u) __builtin_memcpy(&v[u], Lr + (size_t)min(u, max(nb - 1 - 16 * q, 0)) * f, 16);
+    }
+  };
+  double xr[4];
+  d2_t pv[16];
+  mid_load_x(X, 0, NB, xr);
+  load_panel(0, 64, pv);
+  const int64_t gcb = P.bigcol_base[s];
+  for (int p = tid; p < k; p += kMidThreads) {
+    double t[R];
+    fwd_gather<R>(P, gcb, col0, k, p, t);
+#pragma unroll
+    for (int r = 0; r < R; ++r) sm[r * kSB + p] = t[r];
+  }
+  for (int c0 = 0; c0 < k; c0 += 64) {
+    const int nb = min(64, k - c0);
+    mid_store_x(xr, xb);
+    __syncthreads();
+    if (c0 + 64 < k) mid_load_x(X + (size_t)((c0 + 64) >> 7) * NB * NB, (c0 + 64) & 127, NB, xr);      // the next step's block, beside this step's work
+    {
+      // y_s = X64 w_s: row i = tid & 63, sixteen column groups of four
+      const int i = tid & 63, g = tid >> 6;
+      double a[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) a[r] = 0.0;
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const int j = 4 * g + jj;
+        const double x = (j <= i && i < nb) ? xb[i + j * 65] : 0.0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) a[r] += x * sm[r * kSB + min(c0 + j, k - 1)];
+      }
+#pragma unroll
+      for (int r = 0; r < R; ++r) part[g][r][i] = a[r];
+    }
+    __syncthreads();
+    if (tid < 64)
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        double v = 0.0;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) v += part[g][r][tid];
+        ys[r][tid] = tid < nb ? v : 0.0;
+        if (tid < nb) sm[r * kSB + c0 + tid] = v;
+      }
+    __syncthreads();
+    // the rows of the pivot block below this step: a thread takes a row pair and sixteen of the 64 columns; the four column groups of a pair meet in LDS
+    for (int pbase = c0 + 64; pbase < k; pbase += 512) {
+      if (pbase > c0 + 64) load_panel(c0, pbase, pv);      // (only the first 512 rows were requested ahead)
+      const int p = pbase + 2 * pr;
+      if (p < k) {
+        const bool two = p + 1 < k;
+        double a0[R], a1[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) { a0[r] = 0.0; a1[r] = 0.0; }
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+          if (16 * q + u < nb) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) { const double y = ys[r][16 * q + u]; a0[r] += pv[u][0] * y; a1[r] += pv[u][1] * y; }
+          }
+#pragma unroll
+        for (int r = 0; r < R; ++r) { upd[((size_t)q * R + r) * 512 + 2 * pr] = two ? a0[r] : a1[r]; upd[((size_t)q * R + r) * 512 + 2 * pr + 1] = two ? a1[r] : 0.0; }
+      }
+      __syncthreads();
+      if (tid < 512 && pbase + tid < k)
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+          sm[r * kSB + pbase + tid] -= (upd[((size_t)0 * R + r) * 512 + tid] + upd[((size_t)1 * R + r) * 512 + tid]) + (upd[((size_t)2 * R + r) * 512 + tid] + upd[((size_t)3 * R + r) * 512 + tid]);
+      __syncthreads();
+    }
+    load_panel(c0 + 64, c0 + 128, pv);      // the next step's first 512 rows
+  }
+  double* yp = P.ypart + P.ypart_pos[s];
+  for (int p = tid; p < k; p += kMidThreads)
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      yp[(size_t)r * kCS * kSB + p] = sm[r * kSB + p];
+#pragma unroll
+      for (int q2 = 1; q2 < kCS; ++q2) yp[(size_t)r * kCS * kSB + (size_t)q2 * kSB + p] = 0.0;
+    }
+}
+// backward: x_K = L_KK^-T z_K from the last 64 columns to the first (z_K already holds the products with the rows below: k_bwd_pre).
+// The columns before a step are updated with the step's solution, t[c] -= sum_p L[c0 + p][c] x[p]: the 64 rows of a step are contiguous in a
+// column, so HALF A WAVE takes a column (32 lanes x one row pair = one 512-byte run), 32 columns per pass of the workgroup; the row sums
+// meet by five shuffles.  (A thread per column with sixteen scalar loads each -- 16 000 uncoalesced requests per step -- took 10 us per step.)
+template <int R>
+__global__ __launch_bounds__(kMidThreads) void k_bwd_mid(DevPlan P, const int* __restrict__ list, int NB) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];      // t[R][kSB], then the product's partial sums [16][R][64]
+  __shared__ double xb[64 * 65], xs[R][64];
+  double (*part)[R][64] = (double (*)[R][64])(sm + (size_t)R * kSB);
+  const int s = list[blockIdx.x];
+  const int tid = threadIdx.x;
+  const int col0 = P.sn_col0[s];
+  const int k = P.sn_col0[s + 1] - col0;
+  const int f = (int)(P.row_ptr[s + 1] - P.row_ptr[s]);
+  if (k <= NB || k > P.solve_mid) return;
+  const double* F = P.arena + P.front_pos[s];
+  const double* X = P.invl + P.invl_pos[s];
+  const int clast = ((k - 1) >> 6) << 6;
+  const int hl = tid & 31, hw = tid >> 5;      // lane of the half-wave (row pair 2 hl), half-wave 0 .. 31
+  constexpr int NPF = 8;                        // columns per thread requested a step ahead: 32 half-waves x 8 = the first 256 columns
+  auto load_cols = [&](int c0, int cfirst, d2_t (&v)[NPF]) {
+    if (c0 < 0) return;
+    const int nb = min(64, k - c0);
+    const int pp = min(2 * hl, max(nb - 2, 0));      // a short last step: clamped pair (masked when used)
+#pragma unroll
+    for (int u = 0; u < NPF; ++u) {
+      const int c = cfirst + hw + 32 * u;
+      if (c < c0) __builtin_memcpy(&v[u], F + (size_t)c * f + c0 + pp, 16);
+    }
+  };
+  double xr[4];
+  d2_t cv[NPF];
+  mid_load_x(X + (size_t)(clast >> 7) * NB * NB, clast & 127, NB, xr);
+  load_cols(clast, 0, cv);
+  for (int p = tid; p < k; p += kMidThreads)
+#pragma unroll
+    for (int r = 0; r < R; ++r) sm[r * kSB + p] = P.zwork[(size_t)r * P.xw_stride + col0 + p];
+  for (int c0 = clast; c0 >= 0; c0 -= 64) {
+    const int nb = min(64, k - c0);
+    mid_store_x(xr, xb);
+    __syncthreads();
+    if (c0 >= 64) mid_load_x(X + (size_t)((c0 - 64) >> 7) * NB * NB, (c0 - 64) & 127, NB, xr);
+    {
+      // x_s = X64' t_s: column j = tid & 63, sixteen row groups of four
+      const int j = tid & 63, g = tid >> 6;
+      double a[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) a[r] = 0.0;
+#pragma unroll
+      for (int ii = 0; ii < 4; ++ii) {
+        const int i = 4 * g + ii;
+        const double x = (i >= j && i < nb) ? xb[i + j * 65] : 0.0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) a[r] += x * sm[r * kSB + min(c0 + i, k - 1)];
+      }
+#pragma unroll
+      for (int r = 0; r < R; ++r) part[g][r][j] = a[r];
+    }
+    __syncthreads();
+    if (tid < 64)
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        double v = 0.0;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) v += part[g][r][tid];
+        xs[r][tid] = tid < nb ? v : 0.0;
+        if (tid < nb) sm[r * kSB + c0 + tid] = v;
+      }
+    __syncthreads();
+    {
+      // the step's solution at this lane's row pair (zero beyond a short last step; a clamped pair reads its own rows)
+      const int pp = min(2 * hl, max(nb - 2, 0));
+      double x0[R], x1[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        x0[r] = (pp == 2 * hl && pp < nb) ? xs[r][pp] : 0.0;
+        x1[r] = (pp == 2 * hl && pp + 1 < nb) ? xs[r][pp + 1] : ((pp != 2 * hl && 2 * hl < nb) ? 0.0 : 0.0);
+      }
+      // (an odd nb: its last row 2 hl = nb - 1 is the SECOND value of the clamped pair nb - 2)
+      if (pp != 2 * hl && 2 * hl == nb - 1) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) { x0[r] = 0.0; x1[r] = xs[r][nb - 1]; }
+      }
+      for (int cfirst = 0; cfirst < c0; cfirst += 32 * NPF) {
+        if (cfirst > 0) load_cols(c0, cfirst, cv);
+#pragma unroll
+        for (int u = 0; u < NPF; ++u) {
+          const int c = cfirst + hw + 32 * u;
+          if (c < c0) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+              double a = cv[u][0] * x0[r] + cv[u][1] * x1[r];
+              for (int o = 16; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+              if (hl == 0) sm[r * kSB + c] -= a;
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+    load_cols(c0 - 64, 0, cv);      // the next step's first 256 columns
+  }
+  double* xp = P.ypart + P.ypart_pos[s];
+  for (int p = tid; p < k; p += kMidThreads)
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      xp[(size_t)r * kCS * kSB + p] = sm[r * kSB + p];
+#pragma unroll
+      for (int q2 = 1; q2 < kCS; ++q2) xp[(size_t)r * kCS * kSB + (size_t)q2 * kSB + p] = 0.0;
+    }
+}
+
 template <int R>
 __global__ void k_permute_in_r(int n, int nr, int64_t stride_in, const int* __restrict__ perm, const double* __restrict__ rhs, double* __restrict__ x, int64_t xs) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1126,6 +1371,12 @@ std::string dz(Numeric& N, size_t count, double** out) {
 // per level: the big fronts split by the width of the pivot block (thin: k <= NB, wide: k > NB), device lists + host segments
 std::string solve_setup(const Symbolic& S, Numeric& N) {
   DevPlan& d = N.d;
+  // the widest pivot block that goes through block substitution (0: none).  Measured (S-C5 / S-metric, forward error of the worse of two
+  // vectors and solve time; the CPU restatement: 6.9e-10 / 9.7e-9): none 1.2e-8, 1.04 ms / 2.0e-8, 1.54 ms; 256: 1.2e-9, 1.26 / 9.2e-9, 1.75;
+  // 384: 9.3e-10, 1.26 / 8.4e-9, 1.76; 512: 9.3e-10, 1.26 / 1.3e-8, 1.89; 1024: 1.6e-9, 1.78 / 9.6e-9, 2.05 -- the many fronts of
+  // 129 .. 256 columns carry the error, the few wide ones the time
+  d.solve_mid = std::min(getenv("OKKT_SOLVE_MID") ? atoi(getenv("OKKT_SOLVE_MID")) : 384, kSB);
+  if (N.solve_flow || N.nb != 128) d.solve_mid = 0;      // (the flow experiment has its own block products; the 64-column inverses are read out of 128-column blocks)
   const int ns = S.nsuper;
   std::vector<int> ssched;
   std::vector<int64_t> xinv_pos(ns, -1), ypart_pos(ns, -1), ythin_pos(ns, -1), sver_pos(ns, -1);
@@ -1145,7 +1396,7 @@ std::string solve_setup(const Symbolic& S, Numeric& N) {
       L.wide_off = (int)ssched.size(); L.wide_cnt = (int)wide.size();
       for (int s : wide) {
         ssched.push_back(s);
-        L.wide_maxf = std::max(L.wide_maxf, N.sn_f[s]); L.wide_maxk = std::max(L.wide_maxk, N.sn_k[s]);
+        L.wide_maxf = std::max(L.wide_maxf, N.sn_f[s]); L.wide_maxk = std::max(L.wide_maxk, N.sn_k[s]); L.wide_mink = std::min(L.wide_mink, N.sn_k[s]);
         if (xinv_pos[s] < 0) {
           const int64_t k = N.sn_k[s];
           const int64_t nfull = k / kSB, last = k - nfull * kSB, lastp = (last + 127) / 128 * 128;
@@ -1191,6 +1442,8 @@ std::string solve_setup(const Symbolic& S, Numeric& N) {
   for (const void* fn : {(const void*)k_fwd_wide_fused<1>, (const void*)k_fwd_wide_fused<2>, (const void*)k_fwd_wide_fused<4>, (const void*)k_bwd_wide_fused<1>,
                          (const void*)k_bwd_wide_fused<2>, (const void*)k_bwd_wide_fused<4>})
     OKKT_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096 - 16 * 1024));
+  for (const void* fn : {(const void*)k_fwd_mid<1>, (const void*)k_fwd_mid<2>, (const void*)k_fwd_mid<4>, (const void*)k_bwd_mid<1>, (const void*)k_bwd_mid<2>, (const void*)k_bwd_mid<4>})
+    OKKT_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024));
   for (const void* fn : {(const void*)k_fwd_upd<1>, (const void*)k_fwd_upd<2>, (const void*)k_fwd_upd<4>, (const void*)k_bwd_upd<1>,
                          (const void*)k_bwd_upd<2>, (const void*)k_bwd_upd<4>, (const void*)k_fwd_upd<1, 32>, (const void*)k_fwd_upd<2, 32>, (const void*)k_fwd_upd<4, 32>, (const void*)k_bwd_upd<1, 16>, (const void*)k_bwd_upd<2, 16>, (const void*)k_bwd_upd<4, 16>, (const void*)k_fs_small<256, 1>, (const void*)k_fs_small<256, 2>,
                          (const void*)k_fs_small<256, 4>, (const void*)k_bs_small<256, 1>, (const void*)k_bs_small<256, 2>, (const void*)k_bs_small<256, 4>})
@@ -1286,7 +1539,8 @@ static std::string fwd_enqueue_r(Numeric& N, const std::vector<LevelSchedule>& l
         if (N.solve_fuse && N.solve_counters64 && ny * kCS * S.wide_cnt <= N.solve_fuse_wide_max) {
           hipLaunchKernelGGL(k_fwd_wide_fused<R>, dim3(ny * kCS + nupd, S.wide_cnt), dim3(256), lds, st, P, list, b, ny, N.solve_counters64, ++N.solve_epoch64);
         } else {
-          hipLaunchKernelGGL(k_fwd_y<R>, dim3(ny, S.wide_cnt, kCS), dim3(256), 0, st, P, list, b);
+          if (P.solve_mid && b == 0 && S.wide_mink <= P.solve_mid) hipLaunchKernelGGL(k_fwd_mid<R>, dim3(S.wide_cnt), dim3(kMidThreads), (size_t)R * (kSB + 4 * 512) * sizeof(double), st, P, list, N.nb);
+          if (!P.solve_mid || S.wide_maxk > P.solve_mid) hipLaunchKernelGGL(k_fwd_y<R>, dim3(ny, S.wide_cnt, kCS), dim3(256), 0, st, P, list, b);
           // few workgroups of 64 rows (the later blocks of a front): 32 rows each, so that the launch reaches more CUs
           if (N.solve_split_small && nupd * S.wide_cnt < N.solve_split_small) hipLaunchKernelGGL((k_fwd_upd<R, 32>), dim3(std::max(1, (rem + 31) / 32), S.wide_cnt), dim3(256), lds, st, P, list, b);
           else hipLaunchKernelGGL(k_fwd_upd<R>, dim3(nupd, S.wide_cnt), dim3(256), lds, st, P, list, b);
@@ -1324,7 +1578,8 @@ static std::string bwd_enqueue_r(Numeric& N, const std::vector<LevelSchedule>& l
         if (N.solve_fuse && N.solve_counters64 && nx * kCS * S.wide_cnt <= N.solve_fuse_wide_max) {
           hipLaunchKernelGGL(k_bwd_wide_fused<R>, dim3(nx * kCS + nupd, S.wide_cnt), dim3(256), lds, st, P, list, b, nx, N.solve_counters64, ++N.solve_epoch64);
         } else {
-          hipLaunchKernelGGL(k_bwd_x<R>, dim3(nx, S.wide_cnt, kCS), dim3(256), 0, st, P, list, b);
+          if (P.solve_mid && b == 0 && S.wide_mink <= P.solve_mid) hipLaunchKernelGGL(k_bwd_mid<R>, dim3(S.wide_cnt), dim3(kMidThreads), (size_t)R * (kSB + 16 * 64) * sizeof(double), st, P, list, N.nb);
+          if (!P.solve_mid || S.wide_maxk > P.solve_mid) hipLaunchKernelGGL(k_bwd_x<R>, dim3(nx, S.wide_cnt, kCS), dim3(256), 0, st, P, list, b);
           if (N.solve_split_small && nupd * S.wide_cnt < N.solve_split_small) hipLaunchKernelGGL((k_bwd_upd<R, 16>), dim3((b * kSB + 15) / 16 + 1, S.wide_cnt), dim3(256), lds, st, P, list, b);
           else hipLaunchKernelGGL(k_bwd_upd<R>, dim3(nupd, S.wide_cnt), dim3(256), lds, st, P, list, b);
         }

@@ -11,7 +11,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 tot = 0
 for r in rows:
     n = r["Name"]
-    if any(x in n for x in ("k_fwd", "k_bwd", "k_fs_", "k_bs_", "permute")):
+    if any(x in n for x in ("k_fwd", "k_bwd", "k_fs_", "k_bs_", "permute", "_mid")):
         tot += float(r["TotalDurationNs"])
         print("%9.1f us total  %6d calls  avg %8.2f us  %s" % (float(r["TotalDurationNs"]) / 1e3, int(r["Calls"]), float(r["AverageNs"]) / 1e3, n[:80]))
 print("solve kernels total %.1f us over 13 solves = %.1f us per solve" % (tot / 1e3, tot / 1e3 / 13))

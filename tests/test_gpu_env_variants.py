@@ -37,6 +37,8 @@ VARIANTS = [
     {"OKKT_SOLVE_FUSE_WIDE_MAX": "100000000"},                    # the wide fronts fused as well
     {"OKKT_SOLVE_FLOW": "1"},                                     # forward sweep of the wide fronts: one launch per level, vectors handed on through tile states
     {"OKKT_DF_SPLIT_TU": "0"},                                    # the block row behind a diagonal block as one task
+    {"OKKT_SOLVE_MID": "0"},                                      # every pivot block of more than 128 columns through its explicit inverse (rounds 2 - 4)
+    {"OKKT_SOLVE_MID": "1024"},                                   # ... through block substitution in 64-column steps up to 1024 columns (default: 384)
     {"OKKT_SOLVE_SPLIT_SMALL": "0"},                              # panel GEMVs of the wide fronts always with 64 rows / columns per workgroup
     {"OKKT_FLOW": "0"},                                           # small-front tasks: one launch per level instead of one for all levels
     {"OKKT_DF_GROUP": "2", "OKKT_DF_WORKERS": "48"},              # the dataflow launch with pairs of panels on 48 workers

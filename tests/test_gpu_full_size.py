@@ -166,19 +166,17 @@ def test_smetric_forward_error_against_the_extended_precision_solution():
 
 
 def test_sc5_forward_error_against_the_extended_precision_solution():
-    """BASELINE config 5 (round-4 review: it had no forward-error test).  Its fronts of 129 - 1024 pivot columns take the solves through
-    explicit inverses built by recursive doubling, the least accurate part of the HIP solve, and the gap to the CPU restatement is
-    LARGER here than on S-metric and S-C3 and depends on the right-hand side: measured on the two vectors of this test 1.18e-8 and
-    3.4e-9 against 3.7e-10 and 6.9e-10 for the restatement (32 x and 5 x; `scripts/forward_error.py`'s vectors in round 4: 2.4e-9 and
-    6.4e-9 against 1.6e-9 and 7.3e-10).  So S-C5 does NOT meet the 8 x bound of the two tests beside this one, and its worst vector
-    is just outside the 1e-8 that the comparisons against the oracle's solution use (what would close the gap is
-    block substitution for these fronts instead of explicit inverses).  Asserted, so that the gap cannot grow unnoticed: 2e-8 per
-    vector and 40 x the restatement's worst error."""
+    """BASELINE config 5 (round-4 review: it had no forward-error test).  Its many fronts of 129 - 384 pivot columns used to take the
+    solves through explicit inverses of the whole pivot block (recursive doubling): 1.18e-8 and 3.4e-9 on the two vectors of this test
+    against 3.7e-10 and 6.9e-10 for the CPU restatement -- outside the 1e-8 of the other comparisons.  `scripts/solve_emulation.py`
+    located the loss (explicit inverses are as good as substitution up to 64 columns and 5 - 40 x worse from 128 on), and these fronts
+    now go through block substitution in 64-column steps (csrc/solve.hip, k_fwd_mid / k_bwd_mid): measured 4.4e-10 and 9.3e-10.
+    Asserted: the stated tolerance on x for every vector, and at most 4 x the restatement's error (worst against worst)."""
     errs = _forward_errors("S-C5", 8)
     worst_o = max(e_o for e_o, _ in errs)
     for e_o, e_h in errs:
-        assert e_h <= 2.0 * TOL_X, (e_h, e_o)
-    assert max(e_h for _, e_h in errs) <= 40.0 * worst_o + 1e-12, errs
+        assert e_h <= TOL_X, (e_h, e_o)
+    assert max(e_h for _, e_h in errs) <= 4.0 * worst_o + 1e-12, errs
 
 
 def test_sc3_forward_error_against_the_extended_precision_solution():
