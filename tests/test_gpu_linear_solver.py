@@ -343,7 +343,29 @@ def test_early_exit_of_a_failed_factorisation_is_opt_in():
     finalize_b(full); finalize_b(early)
 
 
-@pytest.mark.parametrize("case", ["S-small", "dense-700", "dense-2600", "S-C3"])
+@pytest.mark.parametrize("n", [129, 130, 191, 192, 193, 255, 256, 257, 320, 383, 384, 385, 449])
+def test_one_front_of_every_mid_size_against_lapack(n):
+    """A single dense front whose pivot block takes the solves through block substitution in 64-column steps (129 .. 384 columns: csrc/solve.hip,
+    k_fwd_mid / k_bwd_mid -- every count of full and partial steps, odd and even row counts below a step) and, from 385 on, through the
+    explicit inverse again: the solution of a well-conditioned indefinite system against LAPACK's to 1e-11, one and four right-hand sides."""
+    rng = np.random.default_rng(1000 + n)
+    B = rng.normal(size=(n, n))
+    M = B + B.T + np.diag(np.where(rng.random(n) < 0.5, 1.0, -1.0) * (3.0 * np.sqrt(n)))
+    w = np.linalg.eigvalsh(M)
+    h = hip_solver("symmetric")
+    assert h.ls_factor_b(sp.csc_matrix(np.tril(M)), int((w > 0).sum()), int((w < 0).sum())) == 1
+    from onephase_jl_amd import _lib as L
+    Bm = rng.normal(size=(4, n))
+    X = np.zeros_like(Bm)
+    h._check(h._lib.okkt_solve(h._h, L.p_f64(Bm), L.p_f64(X), 4), "okkt_solve")
+    for r in range(4):
+        xt = np.linalg.solve(M, Bm[r])
+        assert np.max(np.abs(X[r] - xt)) <= 1e-11 * np.max(np.abs(xt)), (n, r)
+        assert np.max(np.abs(h.ls_solve(Bm[r]) - xt)) <= 1e-11 * np.max(np.abs(xt)), (n, r)
+    finalize_b(h)
+
+
+@pytest.mark.parametrize("case", ["S-small", "dense-257", "dense-700", "dense-2600", "S-C3"])
 def test_batched_right_hand_sides(case):
     # okkt_solve with nrhs > 1 carries up to four right-hand sides through one pass over L (solve.hip): every column of
     # the batch must equal the single solve of that column (same summation order: to rounding of the compiler's FMA
