@@ -1306,10 +1306,13 @@ __global__ __launch_bounds__(kMidThreads) void k_bwd_mid(DevPlan P, const int* _
     __syncthreads();
     load_cols(c0 - 64, 0, cv);      // the next step's first 256 columns
   }
+  // x_K itself (what k_bwd_upd would copy out of the partial vectors: a level whose wide fronts all come through here skips that launch),
+  // and the partial vectors for the levels that still run it
   double* xp = P.ypart + P.ypart_pos[s];
   for (int p = tid; p < k; p += kMidThreads)
 #pragma unroll
     for (int r = 0; r < R; ++r) {
+      P.xwork[(size_t)r * P.xw_stride + col0 + p] = sm[r * kSB + p];
       xp[(size_t)r * kCS * kSB + p] = sm[r * kSB + p];
 #pragma unroll
       for (int q2 = 1; q2 < kCS; ++q2) xp[(size_t)r * kCS * kSB + (size_t)q2 * kSB + p] = 0.0;
@@ -1580,6 +1583,7 @@ static std::string bwd_enqueue_r(Numeric& N, const std::vector<LevelSchedule>& l
         } else {
           if (P.solve_mid && b == 0 && S.wide_mink <= P.solve_mid) hipLaunchKernelGGL(k_bwd_mid<R>, dim3(S.wide_cnt), dim3(kMidThreads), (size_t)R * (kSB + 16 * 64) * sizeof(double), st, P, list, N.nb);
           if (!P.solve_mid || S.wide_maxk > P.solve_mid) hipLaunchKernelGGL(k_bwd_x<R>, dim3(nx, S.wide_cnt, kCS), dim3(256), 0, st, P, list, b);
+          if (P.solve_mid && S.wide_maxk <= P.solve_mid) continue;      // k_bwd_mid has stored x_K of every front of this level
           if (N.solve_split_small && nupd * S.wide_cnt < N.solve_split_small) hipLaunchKernelGGL((k_bwd_upd<R, 16>), dim3((b * kSB + 15) / 16 + 1, S.wide_cnt), dim3(256), lds, st, P, list, b);
           else hipLaunchKernelGGL(k_bwd_upd<R>, dim3(nupd, S.wide_cnt), dim3(256), lds, st, P, list, b);
         }
