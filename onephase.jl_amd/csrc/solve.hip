@@ -1098,12 +1098,15 @@ __device__ __forceinline__ void mid_store_x(const double (&xr)[4], double* xb) {
     xb[i + j * 65] = xr[u];
   }
 }
+// Three barriers per step: the 64 x 64 block of the NEXT step goes into the other of two LDS buffers while this step's rows are updated,
+// and the four column quarters of a row pair sit in neighbouring lanes and meet by two shuffles.  (A form with one buffer, the quarters'
+// partial sums in LDS and five barriers per step took the same 17 us per level and sweep; so did 256 and 512 threads per workgroup:
+// what a step costs, about 2 us, is its chain of dependent LDS round trips, not the barriers.)
 template <int R>
 __global__ __launch_bounds__(kMidThreads) void k_fwd_mid(DevPlan P, const int* __restrict__ list, int NB) {
-  extern __shared__ __attribute__((aligned(16))) double sm[];      // w[R][kSB], then the partial sums of the row update [4][R][512]
-  __shared__ double xb[64 * 65], ys[R][64];
-  double* upd = sm + (size_t)R * kSB;
-  double (*part)[R][64] = (double (*)[R][64])upd;      // [16][R][64]: the product's partial sums (the row update's buffer is idle then)
+  extern __shared__ __attribute__((aligned(16))) double sm[];      // w[R][kSB], then the product's partial sums [16][R][64]
+  __shared__ double xb[2][64 * 65], ys[R][64];
+  double (*part)[R][64] = (double (*)[R][64])(sm + (size_t)R * kSB);
   const int s = list[blockIdx.x];
   const int tid = threadIdx.x;
   const int col0 = P.sn_col0[s];
@@ -1112,7 +1115,7 @@ __global__ __launch_bounds__(kMidThreads) void k_fwd_mid(DevPlan P, const int* _
   if (k <= NB || k > P.solve_mid) return;
   const double* F = P.arena + P.front_pos[s];
   const double* X = P.invl + P.invl_pos[s];
-  const int pr = tid & 255, q = tid >> 8;
+  const int q = tid & 3, pr = tid >> 2;      // column quarter (neighbouring lanes) and row pair of the row update
   // the L entries of a step's row update: rows (p, p + 1) below the step, columns 16 q .. 16 q + 15 of it; requested a step ahead (they do
   // not depend on the step's solution), so that a step waits for LDS only
   auto load_panel = [&](int c0, int pbase, d2_t (&v)[16]) {
@@ -1136,11 +1139,12 @@ __global__ __launch_bounds__(kMidThreads) void k_fwd_mid(DevPlan P, const int* _
 #pragma unroll
     for (int r = 0; r < R; ++r) sm[r * kSB + p] = t[r];
   }
-  for (int c0 = 0; c0 < k; c0 += 64) {
+  mid_store_x(xr, xb[0]);
+  if (64 < k) mid_load_x(X + (size_t)(64 >> 7) * NB * NB, 64 & 127, NB, xr);
+  __syncthreads();
+  for (int c0 = 0, st = 0; c0 < k; c0 += 64, ++st) {
     const int nb = min(64, k - c0);
-    mid_store_x(xr, xb);
-    __syncthreads();
-    if (c0 + 64 < k) mid_load_x(X + (size_t)((c0 + 64) >> 7) * NB * NB, (c0 + 64) & 127, NB, xr);      // the next step's block, beside this step's work
+    const double* xc = xb[st & 1];
     {
       // y_s = X64 w_s: row i = tid & 63, sixteen column groups of four
       const int i = tid & 63, g = tid >> 6;
@@ -1150,7 +1154,7 @@ __global__ __launch_bounds__(kMidThreads) void k_fwd_mid(DevPlan P, const int* _
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) {
         const int j = 4 * g + jj;
-        const double x = (j <= i && i < nb) ? xb[i + j * 65] : 0.0;
+        const double x = (j <= i && i < nb) ? xc[i + j * 65] : 0.0;
 #pragma unroll
         for (int r = 0; r < R; ++r) a[r] += x * sm[r * kSB + min(c0 + j, k - 1)];
       }
@@ -1168,32 +1172,38 @@ __global__ __launch_bounds__(kMidThreads) void k_fwd_mid(DevPlan P, const int* _
         if (tid < nb) sm[r * kSB + c0 + tid] = v;
       }
     __syncthreads();
-    // the rows of the pivot block below this step: a thread takes a row pair and sixteen of the 64 columns; the four column groups of a pair meet in LDS
+    // the rows of the pivot block below this step
     for (int pbase = c0 + 64; pbase < k; pbase += 512) {
       if (pbase > c0 + 64) load_panel(c0, pbase, pv);      // (only the first 512 rows were requested ahead)
       const int p = pbase + 2 * pr;
-      if (p < k) {
-        const bool two = p + 1 < k;
-        double a0[R], a1[R];
+      const bool have = p < k, two = p + 1 < k;
+      double a0[R], a1[R];
 #pragma unroll
-        for (int r = 0; r < R; ++r) { a0[r] = 0.0; a1[r] = 0.0; }
+      for (int r = 0; r < R; ++r) { a0[r] = 0.0; a1[r] = 0.0; }
+      if (have) {
 #pragma unroll
         for (int u = 0; u < 16; ++u)
           if (16 * q + u < nb) {
 #pragma unroll
             for (int r = 0; r < R; ++r) { const double y = ys[r][16 * q + u]; a0[r] += pv[u][0] * y; a1[r] += pv[u][1] * y; }
           }
-#pragma unroll
-        for (int r = 0; r < R; ++r) { upd[((size_t)q * R + r) * 512 + 2 * pr] = two ? a0[r] : a1[r]; upd[((size_t)q * R + r) * 512 + 2 * pr + 1] = two ? a1[r] : 0.0; }
       }
-      __syncthreads();
-      if (tid < 512 && pbase + tid < k)
 #pragma unroll
-        for (int r = 0; r < R; ++r)
-          sm[r * kSB + pbase + tid] -= (upd[((size_t)0 * R + r) * 512 + tid] + upd[((size_t)1 * R + r) * 512 + tid]) + (upd[((size_t)2 * R + r) * 512 + tid] + upd[((size_t)3 * R + r) * 512 + tid]);
-      __syncthreads();
+      for (int r = 0; r < R; ++r) {
+        a0[r] += __shfl_xor(a0[r], 1, 64); a1[r] += __shfl_xor(a1[r], 1, 64);
+        a0[r] += __shfl_xor(a0[r], 2, 64); a1[r] += __shfl_xor(a1[r], 2, 64);
+        if (have && q == 0) {
+          if (two) { sm[r * kSB + p] -= a0[r]; sm[r * kSB + p + 1] -= a1[r]; }
+          else sm[r * kSB + p] -= a1[r];
+        }
+      }
     }
-    load_panel(c0 + 64, c0 + 128, pv);      // the next step's first 512 rows
+    if (c0 + 64 < k) {
+      mid_store_x(xr, xb[(st + 1) & 1]);
+      if (c0 + 128 < k) mid_load_x(X + (size_t)((c0 + 128) >> 7) * NB * NB, (c0 + 128) & 127, NB, xr);
+      load_panel(c0 + 64, c0 + 128, pv);      // the next step's first 512 rows
+    }
+    __syncthreads();
   }
   double* yp = P.ypart + P.ypart_pos[s];
   for (int p = tid; p < k; p += kMidThreads)
@@ -1211,7 +1221,7 @@ __global__ __launch_bounds__(kMidThreads) void k_fwd_mid(DevPlan P, const int* _
 template <int R>
 __global__ __launch_bounds__(kMidThreads) void k_bwd_mid(DevPlan P, const int* __restrict__ list, int NB) {
   extern __shared__ __attribute__((aligned(16))) double sm[];      // t[R][kSB], then the product's partial sums [16][R][64]
-  __shared__ double xb[64 * 65], xs[R][64];
+  __shared__ double xb[2][64 * 65], xs[R][64];
   double (*part)[R][64] = (double (*)[R][64])(sm + (size_t)R * kSB);
   const int s = list[blockIdx.x];
   const int tid = threadIdx.x;
@@ -1241,11 +1251,12 @@ __global__ __launch_bounds__(kMidThreads) void k_bwd_mid(DevPlan P, const int* _
   for (int p = tid; p < k; p += kMidThreads)
 #pragma unroll
     for (int r = 0; r < R; ++r) sm[r * kSB + p] = P.zwork[(size_t)r * P.xw_stride + col0 + p];
-  for (int c0 = clast; c0 >= 0; c0 -= 64) {
+  mid_store_x(xr, xb[0]);
+  if (clast >= 64) mid_load_x(X + (size_t)((clast - 64) >> 7) * NB * NB, (clast - 64) & 127, NB, xr);
+  __syncthreads();
+  for (int c0 = clast, st = 0; c0 >= 0; c0 -= 64, ++st) {
     const int nb = min(64, k - c0);
-    mid_store_x(xr, xb);
-    __syncthreads();
-    if (c0 >= 64) mid_load_x(X + (size_t)((c0 - 64) >> 7) * NB * NB, (c0 - 64) & 127, NB, xr);
+    const double* xc = xb[st & 1];
     {
       // x_s = X64' t_s: column j = tid & 63, sixteen row groups of four
       const int j = tid & 63, g = tid >> 6;
@@ -1255,7 +1266,7 @@ __global__ __launch_bounds__(kMidThreads) void k_bwd_mid(DevPlan P, const int* _
 #pragma unroll
       for (int ii = 0; ii < 4; ++ii) {
         const int i = 4 * g + ii;
-        const double x = (i >= j && i < nb) ? xb[i + j * 65] : 0.0;
+        const double x = (i >= j && i < nb) ? xc[i + j * 65] : 0.0;
 #pragma unroll
         for (int r = 0; r < R; ++r) a[r] += x * sm[r * kSB + min(c0 + i, k - 1)];
       }
@@ -1274,15 +1285,14 @@ __global__ __launch_bounds__(kMidThreads) void k_bwd_mid(DevPlan P, const int* _
       }
     __syncthreads();
     {
-      // the step's solution at this lane's row pair (zero beyond a short last step; a clamped pair reads its own rows)
+      // the step's solution at this lane's row pair (zero beyond a short last step; an odd nb: its last row is the SECOND value of the clamped pair)
       const int pp = min(2 * hl, max(nb - 2, 0));
       double x0[R], x1[R];
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         x0[r] = (pp == 2 * hl && pp < nb) ? xs[r][pp] : 0.0;
-        x1[r] = (pp == 2 * hl && pp + 1 < nb) ? xs[r][pp + 1] : ((pp != 2 * hl && 2 * hl < nb) ? 0.0 : 0.0);
+        x1[r] = (pp == 2 * hl && pp + 1 < nb) ? xs[r][pp + 1] : 0.0;
       }
-      // (an odd nb: its last row 2 hl = nb - 1 is the SECOND value of the clamped pair nb - 2)
       if (pp != 2 * hl && 2 * hl == nb - 1) {
 #pragma unroll
         for (int r = 0; r < R; ++r) { x0[r] = 0.0; x1[r] = xs[r][nb - 1]; }
@@ -1303,8 +1313,12 @@ __global__ __launch_bounds__(kMidThreads) void k_bwd_mid(DevPlan P, const int* _
         }
       }
     }
+    if (c0 >= 64) {
+      mid_store_x(xr, xb[(st + 1) & 1]);
+      if (c0 >= 128) mid_load_x(X + (size_t)((c0 - 128) >> 7) * NB * NB, (c0 - 128) & 127, NB, xr);
+      load_cols(c0 - 64, 0, cv);      // the next step's first 256 columns
+    }
     __syncthreads();
-    load_cols(c0 - 64, 0, cv);      // the next step's first 256 columns
   }
   // x_K itself (what k_bwd_upd would copy out of the partial vectors: a level whose wide fronts all come through here skips that launch),
   // and the partial vectors for the levels that still run it
@@ -1446,7 +1460,7 @@ std::string solve_setup(const Symbolic& S, Numeric& N) {
                          (const void*)k_bwd_wide_fused<2>, (const void*)k_bwd_wide_fused<4>})
     OKKT_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096 - 16 * 1024));
   for (const void* fn : {(const void*)k_fwd_mid<1>, (const void*)k_fwd_mid<2>, (const void*)k_fwd_mid<4>, (const void*)k_bwd_mid<1>, (const void*)k_bwd_mid<2>, (const void*)k_bwd_mid<4>})
-    OKKT_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024));
+    OKKT_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
   for (const void* fn : {(const void*)k_fwd_upd<1>, (const void*)k_fwd_upd<2>, (const void*)k_fwd_upd<4>, (const void*)k_bwd_upd<1>,
                          (const void*)k_bwd_upd<2>, (const void*)k_bwd_upd<4>, (const void*)k_fwd_upd<1, 32>, (const void*)k_fwd_upd<2, 32>, (const void*)k_fwd_upd<4, 32>, (const void*)k_bwd_upd<1, 16>, (const void*)k_bwd_upd<2, 16>, (const void*)k_bwd_upd<4, 16>, (const void*)k_fs_small<256, 1>, (const void*)k_fs_small<256, 2>,
                          (const void*)k_fs_small<256, 4>, (const void*)k_bs_small<256, 1>, (const void*)k_bs_small<256, 2>, (const void*)k_bs_small<256, 4>})
@@ -1542,7 +1556,7 @@ static std::string fwd_enqueue_r(Numeric& N, const std::vector<LevelSchedule>& l
         if (N.solve_fuse && N.solve_counters64 && ny * kCS * S.wide_cnt <= N.solve_fuse_wide_max) {
           hipLaunchKernelGGL(k_fwd_wide_fused<R>, dim3(ny * kCS + nupd, S.wide_cnt), dim3(256), lds, st, P, list, b, ny, N.solve_counters64, ++N.solve_epoch64);
         } else {
-          if (P.solve_mid && b == 0 && S.wide_mink <= P.solve_mid) hipLaunchKernelGGL(k_fwd_mid<R>, dim3(S.wide_cnt), dim3(kMidThreads), (size_t)R * (kSB + 4 * 512) * sizeof(double), st, P, list, N.nb);
+          if (P.solve_mid && b == 0 && S.wide_mink <= P.solve_mid) hipLaunchKernelGGL(k_fwd_mid<R>, dim3(S.wide_cnt), dim3(kMidThreads), (size_t)R * (kSB + 16 * 64) * sizeof(double), st, P, list, N.nb);
           if (!P.solve_mid || S.wide_maxk > P.solve_mid) hipLaunchKernelGGL(k_fwd_y<R>, dim3(ny, S.wide_cnt, kCS), dim3(256), 0, st, P, list, b);
           // few workgroups of 64 rows (the later blocks of a front): 32 rows each, so that the launch reaches more CUs
           if (N.solve_split_small && nupd * S.wide_cnt < N.solve_split_small) hipLaunchKernelGGL((k_fwd_upd<R, 32>), dim3(std::max(1, (rem + 31) / 32), S.wide_cnt), dim3(256), lds, st, P, list, b);
