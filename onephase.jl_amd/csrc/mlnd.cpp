@@ -89,58 +89,126 @@ struct Heap {
   void clear() { for (int v : heap) pos[v] = -1; heap.clear(); }
 };
 
+// ---- helper threads for the loops inside one bisection ---------------------------------------------------------------
+// `run_parts(tf, want, f)` calls f(t, T) for t = 0 .. T-1 on T <= want threads (this one included), T as many as the budget of the
+// analysis (`tf`, NdCtx::threads_free) has to lend; the loops that use it produce the same result for every T.  A helper never lets
+// an exception escape; the caller throws once all are joined.
+template <class F>
+void run_parts(std::atomic<int>* tf, int want, F&& f) {
+  int got = 0;
+  if (tf) while (got < want - 1) { if (tf->fetch_sub(1) > 0) ++got; else { tf->fetch_add(1); break; } }
+  const int T = got + 1;
+  std::atomic<bool> failed{false};
+  std::vector<std::thread> th;
+  th.reserve(got);
+  bool inline_failed = false;
+  for (int t = 1; t < T; ++t) {
+    bool spawned = false;
+    try { th.emplace_back([&, t] { try { f(t, T); } catch (...) { failed.store(true); } }); spawned = true; } catch (...) { spawned = false; }
+    if (!spawned) { try { f(t, T); } catch (...) { inline_failed = true; } }
+  }
+  try { f(0, T); } catch (...) { inline_failed = true; }
+  for (auto& t : th) t.join();
+  if (tf) tf->fetch_add(got);
+  if (inline_failed || failed.load()) throw std::runtime_error("multilevel dissection: a helper thread failed");
+}
+
 // ---- coarsening: heavy-edge matching ---------------------------------------------------------
-void coarsen(const Graph& g, Graph& c, std::vector<int>& cmap, Rng& rng, int maxvw) {
+// The matching is one greedy sweep (serial by nature); the contraction builds every coarse vertex's list on its own and is dealt to
+// helper threads in contiguous ranges of coarse vertices, concatenated in order: the coarse graph does not depend on the thread count.
+void coarsen(const Graph& g, Graph& c, std::vector<int>& cmap, Rng& rng, int maxvw, std::atomic<int>* tf) {
   const int n = g.n;
   std::vector<int> match(n, -1), perm(n);
   for (int i = 0; i < n; ++i) perm[i] = i;
   for (int i = n - 1; i > 0; --i) std::swap(perm[i], perm[rng.below(i + 1)]);
   cmap.assign(n, -1);
   int nc = 0;
+  // coarse vertices in the order of their ids: the first fine vertex of id k in `perm` order defines it
+  std::vector<int> rep;
+  rep.reserve(n);
   for (int q = 0; q < n; ++q) {
     const int v = perm[q];
     if (match[v] >= 0) continue;
     // heaviest edge to an unmatched neighbour -- but never an edge much lighter than v's heaviest one: when the
     // neighbours v belongs with are taken, matching it across a stray long-range edge would glue two distant regions into
     // one coarse vertex (seen on the metric workload: coarse vertices with 40 % foreign content, seven-piece "bisections");
-    // v stays single at this level instead
+    // v stays single at this level instead.  One pass: the heaviest edge among the neighbours that can be matched is
+    // compared with the floor afterwards (below it, no neighbour qualifies).
     int best = -1, bw = -1, heaviest = 0;
-    for (int p = g.xadj[v]; p < g.xadj[v + 1]; ++p) heaviest = std::max(heaviest, g.ew[p]);
-    const int floor_w = (heaviest + 3) / 4;
-    for (int p = g.xadj[v]; p < g.xadj[v + 1]; ++p) {
-      const int u = g.adj[p];
-      if (match[u] >= 0 || g.vw[v] + g.vw[u] > maxvw || g.ew[p] < floor_w) continue;
-      if (g.ew[p] > bw || (g.ew[p] == bw && g.vw[u] < g.vw[best])) { best = u; bw = g.ew[p]; }
+    const int vwv = g.vw[v];
+    for (int p = g.xadj[v], pe = g.xadj[v + 1]; p < pe; ++p) {
+      const int w = g.ew[p], u = g.adj[p];
+      heaviest = std::max(heaviest, w);
+      if (w < bw || match[u] >= 0 || vwv + g.vw[u] > maxvw) continue;
+      if (w > bw || g.vw[u] < g.vw[best]) { best = u; bw = w; }
     }
+    if (best >= 0 && bw < (heaviest + 3) / 4) best = -1;
     if (best >= 0) { match[v] = best; match[best] = v; cmap[v] = cmap[best] = nc++; }
     else { match[v] = v; cmap[v] = nc++; }
+    rep.push_back(v);
   }
   c.n = nc;
   c.xadj.assign(nc + 1, 0);
   c.vw.assign(nc, 0);
   c.tvw = g.tvw;
-  c.adj.clear(); c.ew.clear();
-  c.adj.reserve(g.adj.size()); c.ew.reserve(g.adj.size());
-  std::vector<int> slot(nc, -1);
-  // coarse vertices in the order of their ids: the first fine vertex of id k in `perm` order defines it
-  std::vector<int> rep(nc, -1);
-  for (int q = 0; q < n; ++q) { const int v = perm[q]; if (rep[cmap[v]] < 0) rep[cmap[v]] = v; }
+  // ranges of coarse vertices with equal shares of the fine lists
+  const int want = n >= 6000 ? (n >= 40000 ? 6 : 4) : 1;
+  std::vector<int64_t> wsum(nc + 1, 0);
   for (int k = 0; k < nc; ++k) {
     const int v = rep[k], u = match[v];
-    const int start = (int)c.adj.size();
-    for (int pass = 0; pass < 2; ++pass) {
-      const int x = pass == 0 ? v : u;
-      if (pass == 1 && u == v) break;
-      c.vw[k] += g.vw[x];
-      for (int p = g.xadj[x]; p < g.xadj[x + 1]; ++p) {
-        const int ck = cmap[g.adj[p]];
-        if (ck == k) continue;
-        if (slot[ck] < start) { slot[ck] = (int)c.adj.size(); c.adj.push_back(ck); c.ew.push_back(g.ew[p]); }
-        else c.ew[slot[ck]] += g.ew[p];
-      }
-    }
-    c.xadj[k + 1] = (int)c.adj.size();
+    wsum[k + 1] = wsum[k] + (g.xadj[v + 1] - g.xadj[v]) + (u != v ? g.xadj[u + 1] - g.xadj[u] : 0);
   }
+  struct Part { std::vector<int> adj, ew; int k0 = 0, k1 = 0; };
+  std::vector<Part> parts;
+  int T_used = 1;
+  auto contract = [&](int t, int T) {
+    Part& P = parts[t];
+    P.k0 = (int)(std::lower_bound(wsum.begin(), wsum.end(), wsum[nc] * t / T) - wsum.begin());
+    P.k1 = t + 1 == T ? nc : (int)(std::lower_bound(wsum.begin(), wsum.end(), wsum[nc] * (t + 1) / T) - wsum.begin());
+    if (t == 0) P.k0 = 0;
+    P.k0 = std::min(P.k0, nc); P.k1 = std::min(std::max(P.k1, P.k0), nc);
+    const size_t cap = (size_t)(wsum[P.k1] - wsum[P.k0]);
+    P.adj.resize(cap); P.ew.resize(cap);
+    int* pa = P.adj.data();
+    int* pw = P.ew.data();
+    std::vector<int> slot(nc, -1);
+    int out = 0;
+    for (int k = P.k0; k < P.k1; ++k) {
+      const int v = rep[k], u = match[v];
+      const int start = out;
+      int vw = 0;
+      for (int pass = 0; pass < 2; ++pass) {
+        const int x = pass == 0 ? v : u;
+        if (pass == 1 && u == v) break;
+        vw += g.vw[x];
+        for (int p = g.xadj[x], pe = g.xadj[x + 1]; p < pe; ++p) {
+          const int ck = cmap[g.adj[p]];
+          if (ck == k) continue;
+          const int sl = slot[ck];
+          if (sl < start) { slot[ck] = out; pa[out] = ck; pw[out] = g.ew[p]; ++out; }
+          else pw[sl] += g.ew[p];
+        }
+      }
+      c.vw[k] = vw;
+      c.xadj[k + 1] = out - start;          // the length for now
+    }
+    P.adj.resize(out); P.ew.resize(out);
+  };
+  {
+    // the part count is fixed before the parts are dealt: run_parts tells every call its T
+    parts.resize(want);
+    run_parts(tf, want, [&](int t, int T) { if (t == 0) T_used = T; contract(t, T); });
+  }
+  // the ranges of the T parts tile [0, nc) when every part used the same T; run_parts guarantees that
+  for (int k = 0; k < nc; ++k) c.xadj[k + 1] += c.xadj[k];
+  c.adj.resize(c.xadj[nc]); c.ew.resize(c.xadj[nc]);
+  auto gather = [&](int t, int) {
+    const Part& P = parts[t];
+    if (P.adj.empty()) return;
+    std::copy(P.adj.begin(), P.adj.end(), c.adj.begin() + c.xadj[P.k0]);
+    std::copy(P.ew.begin(), P.ew.end(), c.ew.begin() + c.xadj[P.k0]);
+  };
+  for (int t = 0; t < T_used; ++t) gather(t, T_used);
 }
 
 // ---- 2-way edge-cut FM refinement --------------------------------------------------------------
@@ -459,7 +527,7 @@ void fm_node(const Graph& g, std::vector<int8_t>& where, int64_t maxw, int npass
 }
 
 // ---- one multilevel bisection -> vertex separator ----------------------------------------------------------
-void ml_separator(const Graph& g0, uint64_t seed, double max_frac, std::vector<int8_t>& where) {
+void ml_separator(const Graph& g0, uint64_t seed, double max_frac, std::vector<int8_t>& where, std::atomic<int>* tf) {
   Rng rng(seed);
   const bool tdbg = getenv("OKKT_DEBUG_MLND") != nullptr && g0.n > 50000;
   auto t0 = std::chrono::steady_clock::now();
@@ -477,7 +545,7 @@ void ml_separator(const Graph& g0, uint64_t seed, double max_frac, std::vector<i
     Graph c;
     std::vector<int> cmap;
     const int maxvw = (int)std::max<int64_t>(1, (3 * g->tvw) / (2 * coarsen_to));
-    coarsen(*g, c, cmap, rng, maxvw);
+    coarsen(*g, c, cmap, rng, maxvw, tf);
     if (c.n > 0.97 * g->n) { if (c.n < g->n) { levels.push_back(std::move(c)); cmaps.push_back(std::move(cmap)); g = &levels.back(); } break; }
     levels.push_back(std::move(c));
     cmaps.push_back(std::move(cmap));
@@ -618,6 +686,14 @@ void nd_rec(NdCtx& cx, Graph g, std::vector<int> label, int* out, int depth, uin
   static const double max_frac = getenv("OKKT_MLND_FRAC") ? atof(getenv("OKKT_MLND_FRAC")) : 0.6;
   const int ntrial = depth < 2 ? cx.ntrial_top : 1;
   std::vector<std::vector<int8_t>> cand(ntrial);
+  const bool tdbg = depth < 3 && getenv("OKKT_DEBUG_MLND") != nullptr;
+  auto t0 = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (!tdbg) return;
+    auto t = std::chrono::steady_clock::now();
+    fprintf(stderr, "okkt: nd depth %d n %d %-12s %.3f s\n", depth, g.n, what, std::chrono::duration<double>(t - t0).count());
+    t0 = t;
+  };
   {
     std::vector<std::thread> th;
     th.reserve(ntrial);
@@ -626,25 +702,27 @@ void nd_rec(NdCtx& cx, Graph g, std::vector<int> label, int* out, int depth, uin
       bool spawned = false;
       if (cx.threads_free.fetch_sub(1) > 0) {
         try {
-          th.emplace_back([&, t] { try { ml_separator(g, seed * 31 + t, max_frac, cand[t]); } catch (...) { cx.failed.store(true); } });
+          th.emplace_back([&, t] { try { ml_separator(g, seed * 31 + t, max_frac, cand[t], &cx.threads_free); } catch (...) { cx.failed.store(true); } });
           spawned = true;
         } catch (...) { spawned = false; }       // no thread to be had (pid / thread limit): this trial runs here
       }
       // the trial runs here: inside a try block too -- an exception that unwound through `th` with joinable threads in it would end in
       // std::terminate (advisor, round 4); every thread is joined below before anything is thrown
-      if (!spawned) { cx.threads_free.fetch_add(1); try { ml_separator(g, seed * 31 + t, max_frac, cand[t]); } catch (...) { inline_failed = true; } }
+      if (!spawned) { cx.threads_free.fetch_add(1); try { ml_separator(g, seed * 31 + t, max_frac, cand[t], &cx.threads_free); } catch (...) { inline_failed = true; } }
     }
     bool own_failed = inline_failed;
-    try { ml_separator(g, seed * 31, max_frac, cand[0]); } catch (...) { own_failed = true; }
+    try { ml_separator(g, seed * 31, max_frac, cand[0], &cx.threads_free); } catch (...) { own_failed = true; }
     for (auto& t : th) { t.join(); cx.threads_free.fetch_add(1); }
     if (own_failed || cx.failed.load()) { cx.failed.store(true); throw std::runtime_error("multilevel dissection: a bisection trial failed"); }
   }
+  lap("trials");
   // one more candidate: the level-structure bisection (deterministic, no seed)
   static const bool use_bfs = !(getenv("OKKT_MLND_BFS") && atoi(getenv("OKKT_MLND_BFS")) == 0);
   if (use_bfs) {
     std::vector<int8_t> wb;
     if (bfs_separator(g, max_frac, wb)) cand.push_back(std::move(wb));
   }
+  lap("level cand");
   int bestt = 0;
   int64_t bests = -1, bestimb = 0;
   for (int t = 0; t < (int)cand.size(); ++t) {
@@ -671,6 +749,7 @@ void nd_rec(NdCtx& cx, Graph g, std::vector<int> label, int* out, int depth, uin
   std::vector<int> la, lb;
   induced(g, label, where, 0, ga, la);
   induced(g, label, where, 1, gb, lb);
+  lap("induced");
   g = Graph();
   std::vector<int>().swap(label);
   std::vector<std::vector<int8_t>>().swap(cand);
@@ -733,7 +812,7 @@ void ml_nd_order(int n, const std::vector<int64_t>& gp, const std::vector<int>& 
   cx.ntrial_top = std::max(1, getenv("OKKT_MLND_TRIALS") ? atoi(getenv("OKKT_MLND_TRIALS")) : ntrial_top);
   int hw = (int)std::thread::hardware_concurrency();
   if (getenv("OKKT_ANALYZE_THREADS")) hw = atoi(getenv("OKKT_ANALYZE_THREADS"));
-  cx.threads_free.store(std::max(0, std::min(hw, 32) - 1));
+  cx.threads_free.store(std::max(0, std::min(hw, 64) - 1));
   cx.dbg = getenv("OKKT_DEBUG_ANALYZE") != nullptr;
   const int ng = g.n;
   nd_rec(cx, std::move(g), std::move(label), order.data(), 0, 1);

@@ -330,12 +330,30 @@ static std::string analyze_one(int64_t n64, const int64_t* colptr, const int64_t
   S.perm.resize(n);
   S.iperm.resize(n);
   for (int k = 0; k < n; ++k) { S.perm[k] = order[post[k]]; S.iperm[S.perm[k]] = k; }
-  build_lower(S.iperm, rp, ri, &cp, &ci);
-  etree_of(rp, ri, S.parent);
+  // The postorder is a relabelling along the tree: the elimination tree and the column counts of the renumbered matrix are the
+  // relabelled ones (no second pass over the pattern for them); only the column lists are built again, in the new numbering.
   {
-    std::vector<int> ident(n);                                 // the new numbering is a postorder of its own tree
-    std::iota(ident.begin(), ident.end(), 0);
-    column_counts(S.parent, ident, cp, ci, S.colcount);
+    std::vector<int> inv_post(n);
+    for (int k = 0; k < n; ++k) inv_post[post[k]] = k;
+    S.parent.resize(n);
+    S.colcount.resize(n);
+    for (int k = 0; k < n; ++k) {
+      const int j = post[k];
+      S.parent[k] = parent0[j] >= 0 ? inv_post[parent0[j]] : -1;
+      S.colcount[k] = count0[j];
+    }
+    cp.assign(n + 1, 0);
+    for (int i = 0; i < n; ++i) {
+      const int a = S.iperm[i];
+      for (int64_t p = gp[i]; p < gp[i + 1]; ++p) { const int j = gi[p]; if (j < i) ++cp[std::min(a, S.iperm[j]) + 1]; }
+    }
+    for (int i = 0; i < n; ++i) cp[i + 1] += cp[i];
+    ci.resize(cp[n]);
+    std::vector<int64_t> f2(cp.begin(), cp.end() - 1);
+    for (int i = 0; i < n; ++i) {
+      const int a = S.iperm[i];
+      for (int64_t p = gp[i]; p < gp[i + 1]; ++p) { const int j = gi[p]; if (j < i) { const int b = S.iperm[j]; ci[f2[std::min(a, b)]++] = std::max(a, b); } }
+    }
   }
   const std::vector<int>& parent = S.parent;
   const std::vector<int>& cc = S.colcount;
