@@ -118,11 +118,16 @@ void run_parts(std::atomic<int>* tf, int want, F&& f) {
 // helper threads in contiguous ranges of coarse vertices, concatenated in order: the coarse graph does not depend on the thread count.
 void coarsen(const Graph& g, Graph& c, std::vector<int>& cmap, Rng& rng, int maxvw, std::atomic<int>* tf) {
   const int n = g.n;
+  static const bool cdbg_on = getenv("OKKT_DEBUG_COARSEN") != nullptr;
+  const bool cdbg = cdbg_on && n > 50000;
+  auto tc0 = std::chrono::steady_clock::now();
+  auto clap = [&](const char* what) { if (!cdbg) return; auto t = std::chrono::steady_clock::now(); fprintf(stderr, "okkt: coarsen n %d %-10s %.4f s\n", n, what, std::chrono::duration<double>(t - tc0).count()); tc0 = t; };
   std::vector<int> match(n, -1), perm(n);
   for (int i = 0; i < n; ++i) perm[i] = i;
   for (int i = n - 1; i > 0; --i) std::swap(perm[i], perm[rng.below(i + 1)]);
   cmap.assign(n, -1);
   int nc = 0;
+  clap("shuffle");
   // coarse vertices in the order of their ids: the first fine vertex of id k in `perm` order defines it
   std::vector<int> rep;
   rep.reserve(n);
@@ -147,12 +152,13 @@ void coarsen(const Graph& g, Graph& c, std::vector<int>& cmap, Rng& rng, int max
     else { match[v] = v; cmap[v] = nc++; }
     rep.push_back(v);
   }
+  clap("match");
   c.n = nc;
   c.xadj.assign(nc + 1, 0);
   c.vw.assign(nc, 0);
   c.tvw = g.tvw;
   // ranges of coarse vertices with equal shares of the fine lists
-  const int want = n >= 6000 ? (n >= 40000 ? 6 : 4) : 1;
+  const int want = n >= 6000 ? std::min(12, std::max(2, n / 8000)) : 1;
   std::vector<int64_t> wsum(nc + 1, 0);
   for (int k = 0; k < nc; ++k) {
     const int v = rep[k], u = match[v];
@@ -199,6 +205,7 @@ void coarsen(const Graph& g, Graph& c, std::vector<int>& cmap, Rng& rng, int max
     parts.resize(want);
     run_parts(tf, want, [&](int t, int T) { if (t == 0) T_used = T; contract(t, T); });
   }
+  clap("contract");
   // the ranges of the T parts tile [0, nc) when every part used the same T; run_parts guarantees that
   for (int k = 0; k < nc; ++k) c.xadj[k + 1] += c.xadj[k];
   c.adj.resize(c.xadj[nc]); c.ew.resize(c.xadj[nc]);
@@ -208,7 +215,8 @@ void coarsen(const Graph& g, Graph& c, std::vector<int>& cmap, Rng& rng, int max
     std::copy(P.adj.begin(), P.adj.end(), c.adj.begin() + c.xadj[P.k0]);
     std::copy(P.ew.begin(), P.ew.end(), c.ew.begin() + c.xadj[P.k0]);
   };
-  for (int t = 0; t < T_used; ++t) gather(t, T_used);
+  run_parts(c.xadj[nc] >= 400000 ? tf : nullptr, T_used, [&](int t, int T) { for (int part = t; part < T_used; part += T) gather(part, T_used); });
+  clap("gather");
 }
 
 // ---- 2-way edge-cut FM refinement --------------------------------------------------------------
@@ -218,25 +226,35 @@ struct Bisection {
   int64_t cut = 0;
 };
 
-void compute_cut(const Graph& g, Bisection& b, std::vector<int64_t>& id, std::vector<int64_t>& ed) {
+void compute_cut(const Graph& g, Bisection& b, std::vector<int64_t>& id, std::vector<int64_t>& ed, std::atomic<int>* tf = nullptr) {
   const int n = g.n;
   id.assign(n, 0); ed.assign(n, 0);
-  b.pw[0] = b.pw[1] = 0; b.cut = 0;
-  for (int v = 0; v < n; ++v) {
-    b.pw[b.where[v]] += g.vw[v];
-    for (int p = g.xadj[v]; p < g.xadj[v + 1]; ++p) {
-      if (b.where[g.adj[p]] == b.where[v]) id[v] += g.ew[p]; else ed[v] += g.ew[p];
+  const int want = n >= 16000 ? std::min(8, n / 8000) : 1;
+  int64_t pw[8][2], cut[8];
+  for (int t = 0; t < 8; ++t) { pw[t][0] = pw[t][1] = 0; cut[t] = 0; }
+  run_parts(tf, want, [&](int t, int T) {                   // integer sums: the same for every T
+    const int v0 = (int)((int64_t)n * t / T), v1 = (int)((int64_t)n * (t + 1) / T);
+    int64_t w0 = 0, w1 = 0, c = 0;
+    for (int v = v0; v < v1; ++v) {
+      const int8_t wv = b.where[v];
+      (wv ? w1 : w0) += g.vw[v];
+      int64_t i_ = 0, e_ = 0;
+      for (int p = g.xadj[v], pe = g.xadj[v + 1]; p < pe; ++p) { if (b.where[g.adj[p]] == wv) i_ += g.ew[p]; else e_ += g.ew[p]; }
+      id[v] = i_; ed[v] = e_;
+      c += e_;
     }
-    b.cut += ed[v];
-  }
+    pw[t][0] = w0; pw[t][1] = w1; cut[t] = c;
+  });
+  b.pw[0] = b.pw[1] = 0; b.cut = 0;
+  for (int t = 0; t < 8; ++t) { b.pw[0] += pw[t][0]; b.pw[1] += pw[t][1]; b.cut += cut[t]; }
   b.cut /= 2;
 }
 
 // boundary FM; maxw = largest admissible part weight.  Returns true when the cut or the balance improved.
-bool fm_edge(const Graph& g, Bisection& b, int64_t maxw, int npass, Heap hp[2]) {
+bool fm_edge(const Graph& g, Bisection& b, int64_t maxw, int npass, Heap hp[2], std::atomic<int>* tf = nullptr) {
   const int n = g.n;
   std::vector<int64_t> id, ed;
-  compute_cut(g, b, id, ed);
+  compute_cut(g, b, id, ed, tf);
   std::vector<char> locked(n, 0);
   std::vector<int> moved;
   bool any = false;
@@ -574,7 +592,7 @@ void ml_separator(const Graph& g0, uint64_t seed, double max_frac, std::vector<i
     bf.where.resize(gf.n);
     const std::vector<int>& cm = cmaps[l];
     for (int v = 0; v < gf.n; ++v) bf.where[v] = b.where[cm[v]];
-    fm_edge(gf, bf, (int64_t)std::ceil(max_frac * (double)gf.tvw), 6, hp);
+    fm_edge(gf, bf, (int64_t)std::ceil(max_frac * (double)gf.tvw), 6, hp, tf);
     b = std::move(bf);
     if (tdbg) fprintf(stderr, "okkt: mlnd level %d n %d cut %ld parts %ld | %ld\n", l, gf.n, (long)b.cut, (long)b.pw[0], (long)b.pw[1]);
   }
@@ -694,6 +712,23 @@ void nd_rec(NdCtx& cx, Graph g, std::vector<int> label, int* out, int depth, uin
     fprintf(stderr, "okkt: nd depth %d n %d %-12s %.3f s\n", depth, g.n, what, std::chrono::duration<double>(t - t0).count());
     t0 = t;
   };
+  // one more candidate: the level-structure bisection (deterministic, no seed) -- on a thread of its own beside the trials when the
+  // budget has one, after them otherwise
+  static const bool use_bfs = !(getenv("OKKT_MLND_BFS") && atoi(getenv("OKKT_MLND_BFS")) == 0);
+  std::vector<int8_t> wb;
+  bool have_wb = false, bfs_spawned = false;
+  std::thread bfs_th;
+  struct JoinOnExit { std::thread& t; ~JoinOnExit() { if (t.joinable()) t.join(); } } bfs_join{bfs_th};   // nothing may unwind past a running thread
+  if (use_bfs && g.n >= 4000) {
+    if (cx.threads_free.fetch_sub(1) > 0) {
+      try {
+        bfs_th = std::thread([&] { try { have_wb = bfs_separator(g, max_frac, wb); } catch (...) { cx.failed.store(true); } });
+        bfs_spawned = true;
+      } catch (...) { bfs_spawned = false; }
+    }
+    if (!bfs_spawned) cx.threads_free.fetch_add(1);
+  }
+  bool trial_failed = false;
   {
     std::vector<std::thread> th;
     th.reserve(ntrial);
@@ -713,15 +748,13 @@ void nd_rec(NdCtx& cx, Graph g, std::vector<int> label, int* out, int depth, uin
     bool own_failed = inline_failed;
     try { ml_separator(g, seed * 31, max_frac, cand[0], &cx.threads_free); } catch (...) { own_failed = true; }
     for (auto& t : th) { t.join(); cx.threads_free.fetch_add(1); }
-    if (own_failed || cx.failed.load()) { cx.failed.store(true); throw std::runtime_error("multilevel dissection: a bisection trial failed"); }
+    trial_failed = own_failed;
   }
   lap("trials");
-  // one more candidate: the level-structure bisection (deterministic, no seed)
-  static const bool use_bfs = !(getenv("OKKT_MLND_BFS") && atoi(getenv("OKKT_MLND_BFS")) == 0);
-  if (use_bfs) {
-    std::vector<int8_t> wb;
-    if (bfs_separator(g, max_frac, wb)) cand.push_back(std::move(wb));
-  }
+  if (bfs_spawned) { bfs_th.join(); cx.threads_free.fetch_add(1); }
+  if (trial_failed || cx.failed.load()) { cx.failed.store(true); throw std::runtime_error("multilevel dissection: a bisection trial failed"); }
+  if (use_bfs && !bfs_spawned) have_wb = bfs_separator(g, max_frac, wb);
+  if (have_wb) cand.push_back(std::move(wb));
   lap("level cand");
   int bestt = 0;
   int64_t bests = -1, bestimb = 0;
@@ -747,8 +780,13 @@ void nd_rec(NdCtx& cx, Graph g, std::vector<int> label, int* out, int depth, uin
   }
   Graph ga, gb;
   std::vector<int> la, lb;
-  induced(g, label, where, 0, ga, la);
-  induced(g, label, where, 1, gb, lb);
+  {
+    std::atomic<int>* tf = g.n >= 20000 ? &cx.threads_free : nullptr;
+    run_parts(tf, 2, [&](int t, int T) {
+      if (t == 0) induced(g, label, where, 0, ga, la);
+      if (t == 1 || T == 1) induced(g, label, where, 1, gb, lb);
+    });
+  }
   lap("induced");
   g = Graph();
   std::vector<int>().swap(label);

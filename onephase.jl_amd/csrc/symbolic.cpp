@@ -18,16 +18,16 @@
 namespace okkt {
 
 uint64_t hash_pattern(int64_t n, const int64_t* colptr, const int64_t* rowval) {
-  // FNV-1a over (n, colptr, rowval): identifies a sparsity pattern so that the
-  // reference-shaped ls_factor!(A, ...) call can skip re-analysis when only values changed.
+  // A 64-bit digest of (n, colptr, rowval): an identifier of the sparsity pattern for logs and statistics (the decision to skip a
+  // re-analysis is an exact comparison in api.cpp, not this).  One multiply-rotate step per 64-bit word -- the byte-wise FNV-1a of
+  // rounds 1-4 was 20 ms at S-metric, in every candidate thread of the analysis.
   uint64_t h = 1469598103934665603ull;
-  auto mix = [&h](uint64_t v) {
-    for (int b = 0; b < 8; ++b) { h ^= (v >> (8 * b)) & 0xffu; h *= 1099511628211ull; }
-  };
+  auto mix = [&h](uint64_t v) { h = (h ^ v) * 0x9E3779B97F4A7C15ull; h = (h << 29) | (h >> 35); };
   mix((uint64_t)n);
   for (int64_t j = 0; j <= n; ++j) mix((uint64_t)colptr[j]);
   const int64_t nnz = colptr[n] - colptr[0];
   for (int64_t p = 0; p < nnz; ++p) mix((uint64_t)rowval[p]);
+  h ^= h >> 31; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 29;
   return h;
 }
 
@@ -342,6 +342,7 @@ static std::string analyze_one(int64_t n64, const int64_t* colptr, const int64_t
       S.parent[k] = parent0[j] >= 0 ? inv_post[parent0[j]] : -1;
       S.colcount[k] = count0[j];
     }
+    // column lists with the rows ascending (the row-structure pass below reads them in that order): by new row number
     cp.assign(n + 1, 0);
     for (int i = 0; i < n; ++i) {
       const int a = S.iperm[i];
@@ -350,9 +351,9 @@ static std::string analyze_one(int64_t n64, const int64_t* colptr, const int64_t
     for (int i = 0; i < n; ++i) cp[i + 1] += cp[i];
     ci.resize(cp[n]);
     std::vector<int64_t> f2(cp.begin(), cp.end() - 1);
-    for (int i = 0; i < n; ++i) {
-      const int a = S.iperm[i];
-      for (int64_t p = gp[i]; p < gp[i + 1]; ++p) { const int j = gi[p]; if (j < i) { const int b = S.iperm[j]; ci[f2[std::min(a, b)]++] = std::max(a, b); } }
+    for (int r = 0; r < n; ++r) {
+      const int i = S.perm[r];
+      for (int64_t p = gp[i]; p < gp[i + 1]; ++p) { const int b = S.iperm[gi[p]]; if (b < r) ci[f2[b]++] = r; }
     }
   }
   const std::vector<int>& parent = S.parent;
@@ -476,20 +477,26 @@ static std::string analyze_one(int64_t n64, const int64_t* colptr, const int64_t
   }
   S.arena_doubles = S.front_pos[ns];
   S.rel.resize(S.rel_ptr[ns]);
-  for (int s = 0; s < ns; ++s) {
-    int p = S.sn_parent[s];
-    if (p < 0) continue;
-    int k = col0[s + 1] - col0[s];
-    const int* mine = &S.rows[S.row_ptr[s] + k];
-    int64_t r = S.row_ptr[s + 1] - S.row_ptr[s] - k;
-    const int* theirs = &S.rows[S.row_ptr[p]];
-    int64_t fp = S.row_ptr[p + 1] - S.row_ptr[p];
-    int64_t q = 0;
-    for (int64_t i = 0; i < r; ++i) {
-      while (q < fp && theirs[q] < mine[i]) ++q;
-      if (q >= fp || theirs[q] != mine[i]) return "internal error: child row missing from parent front";
-      S.rel[S.rel_ptr[s] + i] = (int)q;
-    }
+  {
+    // every supernode's list on its own: pieces of the supernode range on host threads
+    const std::string perr = parallel_pieces(ns, S.rel_ptr[ns] >= 200000 ? 8 : 1, [&](int64_t slo, int64_t shi, int) {
+      for (int64_t s = slo; s < shi; ++s) {
+        int p = S.sn_parent[s];
+        if (p < 0) continue;
+        int k = col0[s + 1] - col0[s];
+        const int* mine = &S.rows[S.row_ptr[s] + k];
+        int64_t r = S.row_ptr[s + 1] - S.row_ptr[s] - k;
+        const int* theirs = &S.rows[S.row_ptr[p]];
+        int64_t fp = S.row_ptr[p + 1] - S.row_ptr[p];
+        int64_t q = 0;
+        for (int64_t i = 0; i < r; ++i) {
+          while (q < fp && theirs[q] < mine[i]) ++q;
+          if (q >= fp || theirs[q] != mine[i]) throw std::runtime_error("internal error: child row missing from parent front");
+          S.rel[S.rel_ptr[s] + i] = (int)q;
+        }
+      }
+    });
+    if (!perr.empty()) return perr;
   }
 
   lap("layout");
@@ -537,18 +544,42 @@ static std::string analyze_one(int64_t n64, const int64_t* colptr, const int64_t
       });
       if (!perr.empty()) return perr;
     }
-    for (int64_t p = 0; p < nnz_in; ++p) if (ent_sn[p] >= 0) ++cnt[ent_sn[p] + 1];
-    S.aent_ptr.assign(ns + 1, 0);
-    for (int s = 0; s < ns; ++s) S.aent_ptr[s + 1] = S.aent_ptr[s] + cnt[s + 1];
-    S.aent_src.resize(S.aent_ptr[ns]);
-    S.aent_dst.resize(S.aent_ptr[ns]);
-    std::vector<int64_t> fill(S.aent_ptr.begin(), S.aent_ptr.end() - 1);
-    for (int64_t p = 0; p < nnz_in; ++p) {
-      const int s = ent_sn[p];
-      if (s < 0) continue;
-      int64_t q = fill[s]++;
-      S.aent_src[q] = p;
-      S.aent_dst[q] = (int)(S.amap[p] - S.front_pos[s]);
+    // counting sort of the entries by supernode, the entries of one supernode in input order: pieces of the entry range count on
+    // their own, a piece writes behind the pieces before it (the same lists for every piece count)
+    {
+      const int np = map_threads;
+      std::vector<std::vector<int>> pcnt(np);
+      std::vector<int64_t> plo(np, 0), phi(np, 0);
+      std::string perr = parallel_pieces(nnz_in, np, [&](int64_t lo, int64_t hi, int t) {
+        plo[t] = lo; phi[t] = hi;
+        std::vector<int>& c = pcnt[t];
+        c.assign(ns, 0);
+        for (int64_t p = lo; p < hi; ++p) if (ent_sn[p] >= 0) ++c[ent_sn[p]];
+      });
+      if (!perr.empty()) return perr;
+      S.aent_ptr.assign(ns + 1, 0);
+      for (int s = 0; s < ns; ++s) {
+        int64_t c = 0;
+        for (int t = 0; t < np; ++t) if (!pcnt[t].empty()) { const int x = pcnt[t][s]; pcnt[t][s] = (int)c; c += x; }   // offset of piece t inside supernode s
+        cnt[s + 1] = c;
+        S.aent_ptr[s + 1] = S.aent_ptr[s] + c;
+      }
+      S.aent_src.resize(S.aent_ptr[ns]);
+      S.aent_dst.resize(S.aent_ptr[ns]);
+      perr = parallel_pieces(np, np, [&](int64_t tlo, int64_t thi, int) {
+        for (int64_t t = tlo; t < thi; ++t) {
+          if (pcnt[t].empty()) continue;
+          std::vector<int>& off = pcnt[t];
+          for (int64_t p = plo[t]; p < phi[t]; ++p) {
+            const int s = ent_sn[p];
+            if (s < 0) continue;
+            const int64_t q = S.aent_ptr[s] + off[s]++;
+            S.aent_src[q] = p;
+            S.aent_dst[q] = (int)(S.amap[p] - S.front_pos[s]);
+          }
+        }
+      });
+      if (!perr.empty()) return perr;
     }
     // inside a supernode keep the entries sorted by destination: the big-front assemble kernel
     // locates the entries of a column block by binary search
@@ -608,6 +639,7 @@ static std::string analyze_one(int64_t n64, const int64_t* colptr, const int64_t
     }
   }
   if (opts.ordering == 1 || opts.ordering == 2) S.ordering_used = opts.ordering;
+  lap("levels, chain");
   return "";
 }
 
@@ -654,6 +686,8 @@ std::string analyze_pattern(int64_t n64, const int64_t* colptr, const int64_t* r
     // when the dissection's plan is ready and its top separator is small -- at most trust_frac of the graph: the graph has the
     // separators the method lives on (S-metric 7 %, S-C5 0.2 %; the fully random S-C3 variant, where minimum degree wins: above 25 %) --
     // the minimum-degree candidate is abandoned where it stands and the dissection is taken without a flop comparison.
+    const auto t_start = std::chrono::steady_clock::now();
+    auto since = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count(); };
     static const double trust_frac = getenv("OKKT_MLND_TRUST_FRAC") ? atof(getenv("OKKT_MLND_TRUST_FRAC")) : 0.12;
     std::atomic<bool> cancel_amd{false};
     auto run_b = [&] {
@@ -661,6 +695,7 @@ std::string analyze_pattern(int64_t n64, const int64_t* colptr, const int64_t* r
         eb = analyze_one(n64, colptr, rowval, index_base, ob, user_perm, Sb, nullptr, false);
         espec = eb.empty() && Sb.ordering_used == 5 ? "" : "no dissection plan";
         if (espec.empty() && Sb.top_separator >= 0 && (double)Sb.top_separator <= trust_frac * (double)n64 && Sb.flops_exact >= 1e9) cancel_amd.store(true);
+        if (dbg) fprintf(stderr, "okkt: analyze dissection plan ready at %.3f s\n", since());
       } catch (const std::exception& ex) { eb = std::string("dissection candidate: ") + ex.what(); espec = eb; }
       catch (...) { eb = "dissection candidate failed"; espec = eb; }
     };
@@ -676,8 +711,13 @@ std::string analyze_pattern(int64_t n64, const int64_t* colptr, const int64_t* r
     try { ea = analyze_one(n64, colptr, rowval, index_base, oa, user_perm, Sa, nullptr, true, &cancel_amd); }
     catch (const std::exception& ex) { ea = std::string("minimum-degree analysis: ") + ex.what(); }
     catch (...) { ea = "minimum-degree analysis failed"; }
+    const auto tj0 = std::chrono::steady_clock::now();
+    if (dbg) fprintf(stderr, "okkt: analyze minimum degree returned at %.3f s (%s)\n", since(), ea.c_str());
     if (b_started) tb.join();
+    const auto tj1 = std::chrono::steady_clock::now();
     if (c_started) tc.join(); else run_c();
+    if (dbg) fprintf(stderr, "okkt: analyze joins: minimum degree returned, then %.3f s for the dissection thread, %.3f s for the level-structure thread\n",
+                     std::chrono::duration<double>(tj1 - tj0).count(), std::chrono::duration<double>(std::chrono::steady_clock::now() - tj1).count());
     const bool skipped = ea == "cancelled" && cancel_amd.load() && espec.empty();
     if (skipped) {
       // the level-structure candidate still has a say (mesh-like graphs): it must beat the dissection by 10 %
@@ -693,6 +733,7 @@ std::string analyze_pattern(int64_t n64, const int64_t* colptr, const int64_t* r
       }
       S = std::move(Sb);
       S.amd_skipped = true;
+      if (dbg) fprintf(stderr, "okkt: analyze plan taken at %.3f s\n", since());
       return "";
     }
     if (!ea.empty()) return ea;
