@@ -74,6 +74,13 @@ int main() {
     for (int t = 0; t < n / 4; ++t) { const int a = (int)(rng() % n), b = (int)(rng() % n); if (a != b) e.insert({a, b}); }
     for (int o : {0, 5}) bad += run("small-world", n, e, o);
   }
+  {   // the same shape at 24 000: the sizes from which the cut statistics and the induced subgraphs go to helper threads as well
+    const int n = 24000;
+    std::set<std::pair<int, int>> e;
+    for (int i = 0; i < n; ++i) for (int d = 1; d <= 12; d += 3) if (i + d < n) e.insert({i, i + d});
+    for (int t = 0; t < n / 4; ++t) { const int a = (int)(rng() % n), b = (int)(rng() % n); if (a != b) e.insert({a, b}); }
+    bad += run("small-world-24k", n, e, 5);
+  }
   {   // arrow
     const int n = 600;
     std::set<std::pair<int, int>> e;
