@@ -106,23 +106,29 @@ def test_automatic_mode_keeps_the_ordering_with_fewer_factor_flops():
 
 
 def test_dissection_does_not_depend_on_the_thread_count():
-    # every rank of a sharded run analyses the same pattern and must get the same permutation whatever its host offers
+    # every rank of a sharded run analyses the same pattern and must get the same permutation whatever its host offers.  24 000 vertices:
+    # the size from which the contraction of the coarsening, the cut statistics of the refinement and the induced subgraphs of the
+    # dissection go to helper threads (round 5) -- the plan (permutation, elimination tree, structure statistics) must not notice
     code = (
-        "import sys; sys.path.insert(0, %r)\n"
+        "import sys, hashlib; sys.path.insert(0, %r)\n"
         "import numpy as np, scipy.sparse as sp\n"
         "from onephase_jl_amd import synth\n"
         "from onephase_jl_amd.linear_system_solvers import finalize_b, initialize_b, linear_solver_HIP\n"
-        "prob = synth.make_problem(3000, 4500, j_per_row=10, h_per_col=5, seed=7)\n"
+        "prob = synth.make_problem(9600, 14400, j_per_row=10, h_per_col=5, seed=7)\n"
         "K = sp.tril(synth.augmented_matrix(prob, with_upper=False), format='csc')\n"
         "s = linear_solver_HIP('symmetric', host_symbolic_only=1, ordering=5); initialize_b(s); s.analyze(K)\n"
-        "print(','.join(map(str, s.perm().tolist()))); finalize_b(s)\n" % ROOT)
+        "st = s.stats(); et = s.etree()\n"
+        "et = b''.join(np.ascontiguousarray(a).tobytes() for a in (et if isinstance(et, (tuple, list)) else [et]))\n"
+        "print(len(s.perm()), hashlib.sha1(s.perm().tobytes()).hexdigest(), hashlib.sha1(et).hexdigest(),\n"
+        "      *[st[k] for k in ('nnzL', 'nnzL_stored', 'flops_exact', 'nsuper', 'nlevels', 'max_front', 'sum_rowidx', 'critical_pivots', 'top_separator')])\n"
+        "finalize_b(s)\n" % ROOT)
     outs = []
-    for threads in ("1", "3", "8"):
+    for threads in ("1", "3", "8", "64"):
         env = dict(os.environ, OKKT_ANALYZE_THREADS=threads)
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(r.stdout.strip())
-    assert outs[0] == outs[1] == outs[2] and len(outs[0].split(",")) == 7500
+    assert outs[0] == outs[1] == outs[2] == outs[3] and outs[0].split()[0] == "24000"
 
 
 def test_metric_like_pattern_at_reduced_size_prefers_the_dissection(monkeypatch):
