@@ -1006,6 +1006,11 @@ std::string dalloc(Numeric& N, size_t count, T** out, bool zero) {
     // non-blocking: without this wait the first factorisation can race with the zero fill of its own buffers
     OKKT_HIP_TRY(hipMemset(p, 0, bytes));
     OKKT_HIP_TRY(hipStreamSynchronize(nullptr));
+  } else if (getenv("OKKT_DEBUG_POISON")) {
+    // debug: what is not zeroed (the front arena: the strict upper triangles of the fronts are never written) starts as NaNs instead of
+    // whatever the allocator hands back -- a kernel that masks a stray read by multiplying with zero shows up (round 5: fuzz case 5000/126)
+    OKKT_HIP_TRY(hipMemset(p, 0xFF, bytes));
+    OKKT_HIP_TRY(hipStreamSynchronize(nullptr));
   }
   *out = (T*)p;
   return "";

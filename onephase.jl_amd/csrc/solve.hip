@@ -1241,7 +1241,12 @@ __global__ __launch_bounds__(kMidThreads) void k_bwd_mid(DevPlan P, const int* _
 #pragma unroll
     for (int u = 0; u < NPF; ++u) {
       const int c = cfirst + hw + 32 * u;
-      if (c < c0) __builtin_memcpy(&v[u], F + (size_t)c * f + c0 + pp, 16);
+      if (c < c0) {
+        if (nb >= 2) __builtin_memcpy(&v[u], F + (size_t)c * f + c0 + pp, 16);
+        // a one-row step has no pair: the second value would be the row below the pivot block -- or, in a front without such rows, the
+        // never-written entry above the next column's diagonal, whose NaN survives the multiplication by the zero that masks it
+        else { v[u][0] = F[(size_t)c * f + c0]; v[u][1] = 0.0; }
+      }
     }
   };
   double xr[4];

@@ -13,7 +13,10 @@ seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 scale = float(sys.argv[3]) if len(sys.argv) > 3 else 1.0
 fails = 0
 fam_count = {}
+import os
+only = int(os.environ["FUZZ_ONLY"]) if "FUZZ_ONLY" in os.environ else None      # FUZZ_ONLY=<case>: that case alone (same seeds)
 for case in range(cases):
+    if only is not None and case != only: continue
     rng = np.random.default_rng(1000 * seed0 + case)
     fam = ["random", "band", "arrow", "blocks", "grid", "dense_rows", "wide_band", "tree"][case % 8]
     n = int(rng.integers(1, int(700 * scale)))

@@ -57,4 +57,18 @@ for prob in (synth.hanging_chain(N_h=300, seed=2), synth.make_config("S-small", 
     xd = np.linalg.solve(Ms.toarray(), b)
     assert np.max(np.abs(x - xd)) <= 1e-8 * max(1.0, np.max(np.abs(xd)))
     finalize_b(h)
+# one dense front of every shape of the last 64-column step of the block substitution (one row, an odd and an even short step, a full one):
+# a front without rows below its pivot block, where a pair load behind the last row would reach a never-written entry (OKKT_DEBUG_POISON)
+for n in (129, 130, 191, 193, 256, 257, 321, 383):
+    B = rng.normal(size=(n, n))
+    M = B + B.T + np.diag(np.where(rng.random(n) < 0.5, 1.0, -1.0) * (3.0 * np.sqrt(n)))
+    w = np.linalg.eigvalsh(M)
+    h = linear_solver_HIP("symmetric")
+    initialize_b(h)
+    assert h.ls_factor_b(sp.csc_matrix(np.tril(M)), int((w > 0).sum()), int((w < 0).sum())) == 1
+    b = rng.normal(size=n)
+    x = h.ls_solve(b)
+    xd = np.linalg.solve(M, b)
+    assert np.max(np.abs(x - xd)) <= 1e-9 * max(1.0, np.max(np.abs(xd))), (n, np.max(np.abs(x - xd)))
+    finalize_b(h)
 print("VARIANT_OK")

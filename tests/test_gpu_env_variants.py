@@ -43,6 +43,9 @@ VARIANTS = [
     {"OKKT_FLOW": "0"},                                           # small-front tasks: one launch per level instead of one for all levels
     {"OKKT_DF_GROUP": "2", "OKKT_DF_WORKERS": "48"},              # the dataflow launch with pairs of panels on 48 workers
     {"OKKT_ORDERING_TEST": "3"},                                  # (read by the case) AMD instead of the automatic choice
+    {"OKKT_DEBUG_POISON": "1"},                                   # the front arena starts as NaNs (never-written upper triangles): no kernel may let one through
+    {"OKKT_DEBUG_POISON": "1", "OKKT_SOLVE_MID": "1024"},
+    {"OKKT_DEBUG_POISON": "1", "OKKT_SOLVE_MID": "0"},
 ]
 
 
