@@ -116,10 +116,10 @@ template <class F>
 void run_parts(std::atomic<int>* tf, int want, F&& f) {
   int got = 0;
   if (tf) while (got < want - 1) { if (tf->fetch_sub(1) > 0) ++got; else { tf->fetch_add(1); break; } }
+  std::vector<std::thread> th;
+  try { th.reserve(got); } catch (...) { if (tf) tf->fetch_add(got); got = 0; }      // no memory for the handles: this thread alone
   const int T = got + 1;
   std::atomic<bool> failed{false};
-  std::vector<std::thread> th;
-  th.reserve(got);
   bool inline_failed = false;
   for (int t = 1; t < T; ++t) {
     bool spawned = false;
