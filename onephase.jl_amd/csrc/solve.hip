@@ -1237,16 +1237,15 @@ __global__ __launch_bounds__(kMidThreads) void k_bwd_mid(DevPlan P, const int* _
   auto load_cols = [&](int c0, int cfirst, d2_t (&v)[NPF]) {
     if (c0 < 0) return;
     const int nb = min(64, k - c0);
-    const int pp = min(2 * hl, max(nb - 2, 0));      // a short last step: clamped pair (masked when used)
+    // a short last step: clamped pair (masked when used).  A one-row step (nb = 1) takes the pair that ENDS in its row, (c0 - 1, c0):
+    // the pair starting there would reach the row below the pivot block -- or, in a front without such rows, the never-written entry
+    // above the next column's diagonal, whose NaN survives the multiplication by the zero that masks it (fuzz, round 5).  Row c0 - 1 is
+    // on or below the diagonal of every column c < c0: written, finite.
+    const int pp = min(2 * hl, nb - 2);
 #pragma unroll
     for (int u = 0; u < NPF; ++u) {
       const int c = cfirst + hw + 32 * u;
-      if (c < c0) {
-        if (nb >= 2) __builtin_memcpy(&v[u], F + (size_t)c * f + c0 + pp, 16);
-        // a one-row step has no pair: the second value would be the row below the pivot block -- or, in a front without such rows, the
-        // never-written entry above the next column's diagonal, whose NaN survives the multiplication by the zero that masks it
-        else { v[u][0] = F[(size_t)c * f + c0]; v[u][1] = 0.0; }
-      }
+      if (c < c0) __builtin_memcpy(&v[u], F + (size_t)c * f + c0 + pp, 16);
     }
   };
   double xr[4];
@@ -1291,7 +1290,7 @@ __global__ __launch_bounds__(kMidThreads) void k_bwd_mid(DevPlan P, const int* _
     __syncthreads();
     {
       // the step's solution at this lane's row pair (zero beyond a short last step; an odd nb: its last row is the SECOND value of the clamped pair)
-      const int pp = min(2 * hl, max(nb - 2, 0));
+      const int pp = min(2 * hl, nb - 2);      // as in load_cols (-1 for a one-row step: its row is the second value, the case below)
       double x0[R], x1[R];
 #pragma unroll
       for (int r = 0; r < R; ++r) {
