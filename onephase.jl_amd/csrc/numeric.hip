@@ -1563,8 +1563,11 @@ static std::string factor_sched(Numeric& N, DevPlan P, const std::vector<LevelSc
       {
         // LDS-resident columns up to 2048 rows (16 KiB per wave); smaller fronts take less LDS for more waves per CU
         static const int lcol_max = getenv("OKKT_ASM_LCOL") ? atoi(getenv("OKKT_ASM_LCOL")) : 2048;
-        int lcol = 256;
-        while (lcol < g.maxf && lcol < lcol_max) lcol *= 2;
+        // (the level's longest column rounded up to 64 rows, not to a power of two: 1 100 rows are 36 KiB per workgroup and four
+        // workgroups per CU where 2 048 were 64 KiB and two -- the kernel hides the latency of its dependent record fetches by waves:
+        // S-metric 16.78 -> 16.60 ms, S-C5 3.91 -> 3.83.  The later, shorter columns in launches of their own with still less LDS:
+        // measured, slower -- every extra launch of a level is a serial bubble, S-C5 3.83 -> 3.89 / 3.92 / 3.97 ms with 2 / 3 / 4 ranges)
+        int lcol = std::min(lcol_max, std::max(256, (g.maxf + 63) / 64 * 64));
         if (lcol_max <= 0) lcol = 0;
         // lower levels (many fronts, short items): loads of four items batched; upper levels: item after item
         static const int chunked = getenv("OKKT_ASM_CHUNKED") ? atoi(getenv("OKKT_ASM_CHUNKED")) : 1;
