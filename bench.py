@@ -266,6 +266,7 @@ def main():
     hip.dev_free(d_vals); hip.dev_free(d_rhs); hip.dev_free(d_sol)
     inertia_final = hip.inertia
     perm_metric = hip.perm()
+    gpu_metric = {"d": hip.diag(), "inertia": tuple(hip.inertia), "rhs": rhs, "x": x} if rank == 0 else None
     finalize_b(hip)
     if rank == 0:
         if world == 1 and not args.no_live_pmc and "ROCPROFILER_REGISTER_LIBRARY" not in os.environ and "ROCP_TOOL_LIBRARIES" not in os.environ:
@@ -289,7 +290,7 @@ def main():
             except Exception as exc:
                 out["config"]["sharded_model"] = {"error": f"{type(exc).__name__}: {str(exc)[:200]}"}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"], out["parity"] = cpu_baseline(args.cpu_sample, st, K, perm_metric, n, m, local_rank)
+            out["cpu_baseline"], out["parity"] = cpu_baseline(args.cpu_sample, st, K, perm_metric, n, m, local_rank, gpu_metric)
             # BASELINE.md holds no published number for this metric (the reference publishes none), so vs_baseline stays null.  The
             # ratio against the CPU port timed beside the GPU in this run is reported under its own name: it is a stand-in for the
             # reference's CHOLMOD path, not the reference (advisor, round 3)
@@ -546,7 +547,7 @@ def host_cores():
         return os.cpu_count() or 1
 
 
-def cpu_baseline(sample_cfg, st_metric, K_metric, perm_metric, n_metric, m_metric, device):
+def cpu_baseline(sample_cfg, st_metric, K_metric, perm_metric, n_metric, m_metric, device, gpu_metric=None):
     """cpu_baseline + parity legs (outside the timed region, rank 0 at N = 1).
 
     CPU side: the supernodal multifrontal port (oracle/okkt_oracle_mf.c, the algorithm class of
@@ -612,6 +613,19 @@ def cpu_baseline(sample_cfg, st_metric, K_metric, perm_metric, n_metric, m_metri
         t0 = time.perf_counter(); mfm._analyze(K_metric); t_sym_m = time.perf_counter() - t0
         t0 = time.perf_counter(); rcm = mfm.ls_factor_b(K_metric, n_metric, m_metric); xm = mfm.ls_solve(bm); dt_m = time.perf_counter() - t0
         direct = {"seconds": dt_m, "analyze_seconds": t_sym_m, "rc": int(rcm), "gflops": st_metric["flops_exact"] / dt_m / 1e9}
+        if gpu_metric is not None:
+            # parity at the metric size itself (round-5 review, 5b): the factor the timed region produced against the CPU port's on the
+            # same pivot order -- inertia counts, sign(D) entry by entry, D, and the timed solve's solution
+            d_cpu = mfm.diag()
+            x_cpu = mfm.ls_solve(gpu_metric["rhs"])
+            parity["metric_size"] = {
+                "workload": f"the metric workload (n={n_metric}, m={m_metric}), HIP path vs oracle/okkt_oracle_mf.c ({used} threads), same permutation",
+                "inertia_equal": bool(tuple(gpu_metric["inertia"][:3]) == tuple(mfm.inertia()[:3]) == (n_metric, m_metric, 0)),
+                "sign_D_equal": bool(np.array_equal(np.sign(gpu_metric["d"]), np.sign(d_cpu))),
+                "max_rel_err_D": float(np.max(np.abs(gpu_metric["d"] - d_cpu) / np.abs(d_cpu))),
+                "rel_err_x": float(np.max(np.abs(gpu_metric["x"] - x_cpu)) / np.max(np.abs(x_cpu))),
+                "tolerance_D": 1e-7, "tolerance_x": 1e-7,
+            }
         del mfm
     value = 1.0 / direct["seconds"] if direct else 1.0 / est
     # independent datapoint: SuperLU through scipy on the same sample, its own ordering, analysis included

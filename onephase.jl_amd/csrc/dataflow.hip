@@ -1016,6 +1016,9 @@ std::string df_setup(Numeric& N) {
     OKKT_HIP_TRY(hipMalloc(&p, bytes));
     N.allocations.push_back(p);
     OKKT_HIP_TRY(hipMemset(p, 0, bytes));
+    // the handle's streams are non-blocking: nothing else orders this null-stream fill before the first factorisation's own clear and
+    // launch (dalloc() documents the same race for its zero fills; advisor, round 5)
+    OKKT_HIP_TRY(hipStreamSynchronize(nullptr));
     d.df_state = (int*)p;
     N.df_heads = d.df_state + total;
   }

@@ -123,6 +123,9 @@ int okkt_dist_counts(okkt_handle h, int64_t out[4]) {
   if (!numeric_read_counts(h->N, h->stream, cnt).empty())
     return solver_set_error(h, OKKT_ERR_HIP, "download of the pivot counts failed");
   for (int i = 0; i < 4; ++i) out[i] = (int64_t)cnt[i];
+  // a hand-off that ran into its bound leaves incomplete pivot counts: an error of its own, never an inertia failure the delta loop
+  // would answer with a larger shift (advisor, round 5)
+  if (cnt[5] != 0) return solver_set_error(h, OKKT_ERR_INTERNAL, "a hand-off inside a launch timed out");
   return OKKT_OK;
 }
 
@@ -268,9 +271,28 @@ int okkt_dist_comm_init(okkt_handle h, int nranks, int rank, const void* id) {
   dist_free_buffers(h);
   const size_t cb = h->S.boundary_cb.empty() ? 0 : (size_t)h->S.boundary_cb.back(), cv = h->S.boundary_cv.empty() ? 0 : (size_t)h->S.boundary_cv.back();
   if (hipMalloc((void**)&h->dist_cb, std::max<size_t>(cb, 1) * 8) != hipSuccess || hipMalloc((void**)&h->dist_cv, std::max<size_t>(cv, 1) * 8) != hipSuccess ||
-      hipMalloc((void**)&h->dist_x, std::max<size_t>((size_t)h->S.n, 1) * 8) != hipSuccess || hipMalloc((void**)&h->dist_counts, 4 * sizeof(long long)) != hipSuccess)
+      hipMalloc((void**)&h->dist_x, std::max<size_t>((size_t)h->S.n, 1) * 8) != hipSuccess || hipMalloc((void**)&h->dist_counts, 8 * sizeof(long long)) != hipSuccess)
     return solver_set_error(h, OKKT_ERR_ALLOC, "exchange buffers");
   h->dist_cb_cap = cb; h->dist_cv_cap = cv; h->dist_x_cap = (size_t)h->S.n;
+  // Every rank analysed the pattern on its own: the plans must be the same plan.  A digest of the permutation, the supernode
+  // partition and the cut is compared across the ranks (max == min of the digest's two halves); ranks that disagree would pack
+  // contribution blocks of different sizes and hang in the first collective (advisor, round 5).
+  if (nranks > 1) {
+    uint64_t dg = 1469598103934665603ull;
+    auto mix = [&](uint64_t v) { dg ^= v; dg *= 1099511628211ull; dg = (dg << 23) | (dg >> 41); };
+    for (int v : h->S.perm) mix((uint64_t)(uint32_t)v);
+    for (int v : h->S.sn_col0) mix((uint64_t)(uint32_t)v);
+    for (int v : h->S.sn_owner) mix((uint64_t)(uint32_t)v);
+    for (int v : h->S.boundary) mix((uint64_t)(uint32_t)v);
+    long long hv[4] = {(long long)(dg >> 32), (long long)(dg & 0xffffffffull), -(long long)(dg >> 32), -(long long)(dg & 0xffffffffull)};   // max of (x, -x) = (max, -min)
+    if (hipMemcpyAsync(h->dist_counts, hv, sizeof(hv), hipMemcpyHostToDevice, h->stream) != hipSuccess) return solver_set_error(h, OKKT_ERR_HIP, "digest upload");
+    OKKT_NCCL(h, "ncclAllReduce(plan digest)", a.AllReduce(h->dist_counts, h->dist_counts, 4, ncclInt64, ncclMax, comm, h->stream));
+    long long rv[4] = {0, 0, 0, 0};
+    if (hipMemcpyAsync(rv, h->dist_counts, sizeof(rv), hipMemcpyDeviceToHost, h->stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess)
+      return solver_set_error(h, OKKT_ERR_HIP, "digest download");
+    if (rv[0] != -rv[2] || rv[1] != -rv[3])
+      return solver_set_error(h, OKKT_ERR_INVALID, "the ranks analysed different plans (permutation / partition digests differ): use the same options and pattern on every rank");
+  }
   return OKKT_OK;
 }
 
@@ -323,14 +345,15 @@ int okkt_dist_factor(okkt_handle h, const double* d_nzval, int64_t n, int64_t m,
     if (!e.empty()) return solver_set_error(h, OKKT_ERR_HIP, e);
   }
   numeric_sum_counts_device(h->N, h->dist_counts);
-  if (h->rccl_nranks > 1) OKKT_NCCL(h, "ncclAllReduce(pivot counts)", a.AllReduce(h->dist_counts, h->dist_counts, 4, ncclInt64, ncclSum, comm, st));
-  long long tot[4] = {0, 0, 0, 0};
+  if (h->rccl_nranks > 1) OKKT_NCCL(h, "ncclAllReduce(pivot counts)", a.AllReduce(h->dist_counts, h->dist_counts, 5, ncclInt64, ncclSum, comm, st));
+  long long tot[5] = {0, 0, 0, 0, 0};      // pos, neg, zero, nonfinite, time-outs of in-launch waits (summed over the ranks)
   if (hipMemcpyAsync(tot, h->dist_counts, sizeof(tot), hipMemcpyDeviceToHost, st) != hipSuccess) return solver_set_error(h, OKKT_ERR_HIP, "count download");
   (void)hipEventRecord(h->ev1, st);
   rc = sync_or_fail(h, "sharded factorisation");
   if (rc != OKKT_OK) return rc;
   float ms = 0;
   if (hipEventElapsedTime(&ms, h->ev0, h->ev1) == hipSuccess) h->last_factor_ms = ms;
+  if (tot[4] != 0) return solver_set_error(h, OKKT_ERR_INTERNAL, "a hand-off inside a launch timed out on one of the ranks");
   if (inertia_out) { inertia_out->pos = tot[0]; inertia_out->neg = tot[1]; inertia_out->zero = tot[2]; inertia_out->nonfinite = tot[3]; }
   const int64_t t64[4] = {tot[0], tot[1], tot[2], tot[3]};
   return okkt_dist_finish(h, t64);

@@ -1886,6 +1886,7 @@ __global__ void k_exchange_x(int n, const int* __restrict__ col_owner, const int
 
 __global__ void k_sum_counts(const unsigned long long* __restrict__ counters, long long* __restrict__ out) {
   const int c = threadIdx.x;
+  if (c == 4) out[4] = (long long)counters[5];      // the time-out word of the in-launch waits: the sharded paths must fail on it, not retry (advisor, round 5)
   if (c >= 4) return;
   unsigned long long sum = 0;
   for (int q = 0; q < kCountSlots; ++q) sum += counters[(size_t)q * kCountStride + c];

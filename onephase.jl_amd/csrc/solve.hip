@@ -1397,6 +1397,7 @@ std::string solve_setup(const Symbolic& S, Numeric& N) {
   // 384: 9.3e-10, 1.26 / 8.4e-9, 1.76; 512: 9.3e-10, 1.26 / 1.3e-8, 1.89; 1024: 1.6e-9, 1.78 / 9.6e-9, 2.05 -- the many fronts of
   // 129 .. 256 columns carry the error, the few wide ones the time
   d.solve_mid = std::min(getenv("OKKT_SOLVE_MID") ? atoi(getenv("OKKT_SOLVE_MID")) : 384, kSB);
+  if (kSolveBlock != 1024) d.solve_mid = 0;      // the mid kernels' LDS (static 66.5 KB + R * (kSB + 1024) doubles) is sized for 1024-column blocks: a 2048-column build keeps the explicit inverses (advisor, round 5)
   if (N.solve_flow || N.nb != 128) d.solve_mid = 0;      // (the flow experiment has its own block products; the 64-column inverses are read out of 128-column blocks)
   const int ns = S.nsuper;
   std::vector<int> ssched;

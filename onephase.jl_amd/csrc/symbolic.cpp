@@ -727,21 +727,27 @@ std::string analyze_pattern(int64_t n64, const int64_t* colptr, const int64_t* r
     if (c_started) tc.join(); else run_c();
     if (dbg) fprintf(stderr, "okkt: analyze joins: minimum degree returned, then %.3f s for the dissection thread, %.3f s for the level-structure thread\n",
                      std::chrono::duration<double>(tj1 - tj0).count(), std::chrono::duration<double>(std::chrono::steady_clock::now() - tj1).count());
-    const bool skipped = ea == "cancelled" && cancel_amd.load() && espec.empty();
-    if (skipped) {
+    // The decision is a function of the DATA only (advisor, round 5): the trust rule is evaluated again here, behind both joins, whether
+    // or not minimum degree happened to finish before the dissection thread raised the flag -- the flag only saves time.  Every rank of a
+    // sharded run and every repetition on a loaded host therefore takes the same permutation.
+    const bool trusted = espec.empty() && Sb.top_separator >= 0 && (double)Sb.top_separator <= trust_frac * (double)n64 && Sb.flops_exact >= 1e9;
+    const bool amd_done = ea.empty();      // minimum degree ran to the end: its statistics are reported (flops_other), they do not decide
+    if (trusted) {
       // the level-structure candidate still has a say (mesh-like graphs): it must beat the dissection by 10 %
       const bool lv = ec.empty() && Sc.ordering_used == 4 && Sc.flops_exact < 0.9 * Sb.flops_exact;
       if (dbg)
-        fprintf(stderr, "okkt: analyze candidates: AMD abandoned (top separator %ld of %ld) | nested dissection flops %.4g nnz(L) %ld | level-structure dissection flops %.4g -> %s\n",
-                (long)Sb.top_separator, (long)n64, Sb.flops_exact, (long)Sb.nnzL, Sc.flops_exact, lv ? "level-structure dissection" : "nested dissection");
+        fprintf(stderr, "okkt: analyze candidates: AMD %s (top separator %ld of %ld) | nested dissection flops %.4g nnz(L) %ld | level-structure dissection flops %.4g -> %s\n",
+                amd_done ? "not consulted" : "abandoned", (long)Sb.top_separator, (long)n64, Sb.flops_exact, (long)Sb.nnzL, Sc.flops_exact, lv ? "level-structure dissection" : "nested dissection");
       if (lv) {
         const std::vector<int> ord = Sc.perm;
         std::string e2 = analyze_one(n64, colptr, rowval, index_base, oc, user_perm, S, &ord, false);
-        S.amd_skipped = true; S.flops_other = Sb.flops_exact;
+        S.amd_skipped = !amd_done; S.flops_other = Sb.flops_exact;
         return e2;
       }
+      const double fa = amd_done ? Sa.flops_exact : 0.0;
       S = std::move(Sb);
-      S.amd_skipped = true;
+      S.amd_skipped = !amd_done;
+      if (amd_done) S.flops_other = fa;      // the loser's flops when they are known anyway (advisor: a silently worse plan shows in the stats)
       if (dbg) fprintf(stderr, "okkt: analyze plan taken at %.3f s\n", since());
       return "";
     }

@@ -23,14 +23,16 @@ mutable struct HIP_KKT_solver <: abstract_KKT_system_solver
     reduct_factors::Class_reduction_factors
     resident_rhs::Any                            # the System_rhs object whose triple okkt_kkt_system_rhs left in HBM (nothing: none)
 
-    function HIP_KKT_solver(kind::Symbol)
+    function HIP_KKT_solver(kind::Symbol, opts::Union{Nothing,OkktOpts}=nothing)      # opts: okkt_opts_from_pars(pars.kkt), linear_solver_hip.jl
         this = new()
         this.ready = :not_ready
         this.kind = Dict(:schur => 0, :symmetric => 1, :clever_symmetric => 2, :schur_direct => 3)[kind]
         this.pattern_set = false
         this.resident_rhs = nothing
         h = Ref{Ptr{Cvoid}}(C_NULL)
-        rc = ccall((:okkt_kkt_create, OKKT_LIB), Cint, (Ref{Ptr{Cvoid}}, Ptr{Cvoid}, Cint), h, C_NULL, this.kind)
+        rc = opts === nothing ?
+             ccall((:okkt_kkt_create, OKKT_LIB), Cint, (Ref{Ptr{Cvoid}}, Ptr{Cvoid}, Cint), h, C_NULL, this.kind) :
+             ccall((:okkt_kkt_create, OKKT_LIB), Cint, (Ref{Ptr{Cvoid}}, Ref{OkktOpts}, Cint), h, Ref(opts), this.kind)
         rc == 0 || error("okkt_kkt_create failed with code $rc")
         this.handle = h[]
         finalizer(s -> ccall((:okkt_kkt_destroy, OKKT_LIB), Cint, (Ptr{Cvoid},), s.handle), this)

@@ -18,20 +18,61 @@ struct OkktInertia
     nonfinite::Int64
 end
 
+# okkt_opts of include/okkt.h, field for field (an isbits struct has C layout: six Int32, four Float64, four Int32 = 72 bytes)
+struct OkktOpts
+    device::Int32
+    host_symbolic_only::Int32
+    ordering::Int32
+    relax_always::Int32
+    relax_small::Int32
+    relax_mid::Int32
+    relax_small_frac::Float64
+    relax_mid_frac::Float64
+    relax_any_frac::Float64
+    inertia_tol::Float64
+    small_front_max::Int32
+    panel_nb::Int32
+    early_exit::Int32
+    reserved::Int32
+end
+
+function okkt_default_opts()
+    o = Ref(OkktOpts(0, 0, 0, 0, 0, 0, 0.0, 0.0, 0.0, 0.0, 0, 0, 0, 0))
+    ccall((:okkt_default_opts, OKKT_LIB), Cint, (Ref{OkktOpts},), o)
+    return o[]
+end
+
+# The back-end's own knobs ride in pars.kkt like the reference's `ma97_u` (parameters.jl:13,25 -> linear_solver_HSL(..., pars.kkt.ma97_u),
+# kkt_system_solver.jl:247): the fields hip_device, hip_ordering, hip_relax_always / _small / _mid, hip_relax_small_frac / _mid_frac /
+# _any_frac, hip_inertia_tol of Class_kkt_solver_options (INTEGRATION.md, edit 4), set through the existing plumbing, e.g.
+# "kkt!hip_ordering" => 3 (create_pars_JuMP, JuMPinterface.jl:570-586).  -1 / 0.0 keep the library's default.
+function okkt_opts_from_pars(kkt)
+    d = okkt_default_opts()
+    pick(v, dflt) = v > 0 ? v : dflt
+    return OkktOpts(kkt.hip_device >= 0 ? Int32(kkt.hip_device) : d.device, d.host_symbolic_only,
+                    kkt.hip_ordering != 0 ? Int32(kkt.hip_ordering) : d.ordering,
+                    Int32(pick(kkt.hip_relax_always, d.relax_always)), Int32(pick(kkt.hip_relax_small, d.relax_small)), Int32(pick(kkt.hip_relax_mid, d.relax_mid)),
+                    pick(kkt.hip_relax_small_frac, d.relax_small_frac), pick(kkt.hip_relax_mid_frac, d.relax_mid_frac), pick(kkt.hip_relax_any_frac, d.relax_any_frac),
+                    kkt.hip_inertia_tol > 0 ? kkt.hip_inertia_tol : d.inertia_tol,
+                    d.small_front_max, d.panel_nb, d.early_exit, d.reserved)
+end
+
 mutable struct linear_solver_HIP <: abstract_linear_system_solver
     handle::Ptr{Cvoid}
     sym::Symbol            # :definite (Cholesky semantics) or :symmetric (LDL', inertia from sign(D))
     safe_mode::Bool
     recycle::Bool
     inertia::OkktInertia
+    opts::Union{Nothing,OkktOpts}      # nothing: okkt_create(NULL) = the library's defaults
 
-    function linear_solver_HIP(sym::Symbol, safe_mode::Bool, recycle::Bool)
+    function linear_solver_HIP(sym::Symbol, safe_mode::Bool, recycle::Bool, opts::Union{Nothing,OkktOpts}=nothing)
         this = new()
         this.handle = C_NULL
         this.sym = sym
         this.safe_mode = safe_mode
         this.recycle = recycle
         this.inertia = OkktInertia(0, 0, 0, 0)
+        this.opts = opts
         return this
     end
 end
@@ -44,7 +85,9 @@ end
 function initialize!(solver::linear_solver_HIP)
     if solver.handle == C_NULL
         h = Ref{Ptr{Cvoid}}(C_NULL)
-        rc = ccall((:okkt_create, OKKT_LIB), Cint, (Ref{Ptr{Cvoid}}, Ptr{Cvoid}), h, C_NULL)   # NULL = default options
+        rc = solver.opts === nothing ?
+             ccall((:okkt_create, OKKT_LIB), Cint, (Ref{Ptr{Cvoid}}, Ptr{Cvoid}), h, C_NULL) :             # NULL = default options
+             ccall((:okkt_create, OKKT_LIB), Cint, (Ref{Ptr{Cvoid}}, Ref{OkktOpts}), h, Ref(solver.opts))  # pars.kkt.hip_* (okkt_opts_from_pars)
         rc == 0 || error("okkt_create failed with code $rc (no HIP device? the KKT path has no CPU fallback)")
         solver.handle = h[]
         # Early exit stays OFF at this level: ls_factor! cannot know whether its caller will solve with a factorisation

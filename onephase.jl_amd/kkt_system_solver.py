@@ -92,6 +92,40 @@ class Class_kkt_solver_options:   # parameters.jl:4-46 (the entries the path rea
     # The option cannot run in the reference; the mirror keeps the field and fails the same way instead of inventing a meaning.
     ItRefine_BigFloat: bool = False
     kkt_system_rescale: str = "none"    # parameters.jl:24 (:none | :u_only | :u_and_x), clever_symmetric only
+    # The HIP back-end's knobs, carried the way the reference carries a back-end's own option (`ma97_u`, parameters.jl:13,25, handed to
+    # linear_solver_HSL by pick_KKT_solver, kkt_system_solver.jl:247): plain fields of pars.kkt, reachable through the JuMP option
+    # strings "kkt!hip_ordering" etc. (create_pars_JuMP, JuMPinterface.jl:570-586).  They map one to one onto okkt_opts
+    # (include/okkt.h); -1 / 0.0 = the library's default.
+    hip_device: int = -1                # okkt_opts.device: HIP device ordinal, -1 = the current device
+    hip_ordering: int = 0               # okkt_opts.ordering: 0 automatic, 3 minimum degree always (the reference's class of order), 4 / 5 dissections
+    hip_relax_always: int = -1          # okkt_opts.relax_always / relax_small / relax_mid: supernode amalgamation widths
+    hip_relax_small: int = -1
+    hip_relax_mid: int = -1
+    hip_relax_small_frac: float = 0.0   # okkt_opts.relax_small_frac / relax_mid_frac / relax_any_frac: explicit-zero fractions
+    hip_relax_mid_frac: float = 0.0
+    hip_relax_any_frac: float = 0.0
+    hip_inertia_tol: float = 1e-20      # okkt_opts.inertia_tol (julia.jl:73)
+
+
+def okkt_opts_from_pars(kkt):
+    """pars.kkt.hip_* -> the keyword options of HIP_KKT_solver / linear_solver_HIP (= fields of okkt_opts).  Only what differs from
+    the library's defaults is passed, so okkt_default_opts stays the single source of the defaults."""
+    o = {}
+    if kkt.hip_device >= 0:
+        o["device"] = int(kkt.hip_device)
+    if kkt.hip_ordering != 0:
+        o["ordering"] = int(kkt.hip_ordering)
+    for name in ("relax_always", "relax_small", "relax_mid"):
+        v = getattr(kkt, "hip_" + name)
+        if v > 0:
+            o[name] = int(v)
+    for name in ("relax_small_frac", "relax_mid_frac", "relax_any_frac"):
+        v = getattr(kkt, "hip_" + name)
+        if v > 0.0:
+            o[name] = float(v)
+    if kkt.hip_inertia_tol != 1e-20:
+        o["inertia_tol"] = float(kkt.hip_inertia_tol)
+    return o
 
 
 @dataclass
@@ -490,5 +524,5 @@ def pick_KKT_solver(pars):
     if pars.kkt.linear_solver_type != "HIP":
         raise OkktError("pick a valid solver!")
     if pars.kkt.kkt_solver_type in ("schur", "schur_direct", "symmetric", "clever_symmetric"):
-        return HIP_KKT_solver(pars.kkt.kkt_solver_type, pars)
+        return HIP_KKT_solver(pars.kkt.kkt_solver_type, pars, **okkt_opts_from_pars(pars.kkt))
     raise OkktError("pick a solver!")

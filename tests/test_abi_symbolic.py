@@ -216,3 +216,16 @@ def test_banded_kkt_switches_to_nested_dissection():
     assert nd.stats()["ordering_used"] == 4 and sorted(nd.perm().tolist()) == list(range(prob2["n"] + prob2["m"]))
     o = oracle.linear_solver_ORACLE("symmetric", perm=nd.perm())
     assert o.ls_factor_b(K2, prob2["n"], prob2["m"]) == 1
+
+
+def test_hip_options_of_the_parameter_tree_map_onto_okkt_opts():
+    # kkt.hip_* (the reference's option plumbing: src/parameters.jl:4-46, JuMPinterface.jl:570-586) -> keyword options = okkt_opts fields
+    from onephase_jl_amd import kkt_system_solver as KS
+    from onephase_jl_amd import _lib as L
+    kkt = KS.Class_kkt_solver_options()
+    assert KS.okkt_opts_from_pars(kkt) == {}                       # defaults: nothing overrides okkt_default_opts
+    kkt.hip_device, kkt.hip_ordering, kkt.hip_relax_always, kkt.hip_relax_mid_frac, kkt.hip_inertia_tol = 2, 3, 32, 0.3, 1e-18
+    o = KS.okkt_opts_from_pars(kkt)
+    assert o == {"device": 2, "ordering": 3, "relax_always": 32, "relax_mid_frac": 0.3, "inertia_tol": 1e-18}
+    names = {f[0] for f in L.OkktOpts._fields_}
+    assert set(o) <= names                                         # every key is a field of the C struct

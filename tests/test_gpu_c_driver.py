@@ -1,0 +1,47 @@
+"""A caller of the C ABI that is not Python: onephase.jl_amd/csrc/abi_driver.c (plain C, gcc, include/okkt.h) factors and solves the
+reference's two test_linear_solvers matrices on the device (/root/reference/test/linear_system_solvers.jl:58-116) and prints the
+solutions; they are compared here with the golden answers (tests/golden/kkt_known_answers.json, dense LAPACK)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "onephase.jl_amd", "csrc")
+EXE = os.path.join(CSRC, "build", "abi_driver")
+
+
+def build_driver():
+    subprocess.check_call(["make", "-s", "-C", CSRC, "abi_driver"])
+    assert os.path.exists(EXE)
+
+
+def test_c_driver_compiles_against_the_header_and_fails_loudly_without_a_device():
+    import torch
+    build_driver()
+    if torch.cuda.is_available():
+        pytest.skip("a device is present: the GPU test below runs the driver")
+    r = subprocess.run([EXE] + ["1"] * 10, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    assert r.returncode == 1 and "okkt_create" in r.stderr          # OKKT_ERR_NO_DEVICE: no CPU fallback behind the ABI
+
+
+@pytest.mark.gpu
+def test_c_driver_reproduces_the_reference_linear_solver_test(golden):
+    build_driver()
+    recs = golden["linear_solvers"]
+    assert len(recs) == 2
+    for which, rec in enumerate(recs):
+        b = np.asarray(rec["b"])
+        r = subprocess.run([EXE] + [repr(float(v)) for v in b], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        lines = [ln.split() for ln in r.stdout.splitlines()]
+        assert lines[-1] == ["ok"]
+        got = {(int(t[1]), int(t[2]), int(t[3])): np.array([float(v) for v in t[4:]]) for t in lines if t and t[0] == "x"}
+        assert len(got) == 8
+        x_ref = np.asarray(rec["x"])
+        for upper in (0, 1):
+            for kind in (0, 1):
+                x = got[(which, upper, kind)]          # the driver solves both matrices with the b it is given
+                assert np.linalg.norm(x - x_ref) < 1e-9, (which, upper, kind)      # the reference's bar (test/linear_system_solvers.jl:62)
+                assert np.max(np.abs(x - x_ref)) <= 1e-14

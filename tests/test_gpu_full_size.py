@@ -139,6 +139,12 @@ def _forward_errors(name, nthreads):
     o = oracle.linear_solver_ORACLE_MF("symmetric", perm=h.perm(), nthreads=nthreads)
     o._analyze(K)
     assert o.ls_factor_b(K, n, m) == 1
+    # the factor itself against the multithreaded CPU port on the same pivot order (round-5 review, 5b: at the metric size only the
+    # forward error was compared): inertia counts equal, sign(D) equal entry by entry, D within TOL_D
+    assert tuple(h.inertia[:3]) == tuple(o.inertia()[:3]) == (n, m, 0), (h.inertia, o.inertia())
+    d_h, d_o = h.diag(), o.diag()
+    assert np.array_equal(np.sign(d_h), np.sign(d_o))
+    assert np.max(np.abs(d_h - d_o) / np.abs(d_o)) <= TOL_D
     rng = np.random.default_rng(3)
     out = []
     for b in rng.normal(size=(2, n + m)):

@@ -577,3 +577,34 @@ def test_batched_directions_equal_the_one_by_one_ones(kind):
         assert abs(kerr.ratio - k.kkt_err_norm.ratio) <= 1e-6 * max(k.kkt_err_norm.ratio, 1e-12) + 1e-14
         assert d.mu == k.dir.mu and d.primal_scale == k.dir.primal_scale
     k.finalize_b()
+
+
+def test_hip_options_travel_through_pick_KKT_solver():
+    # The back-end's knobs are fields of pars.kkt (kkt.hip_*), read by pick_KKT_solver's :HIP branch and handed to okkt_kkt_create as an
+    # okkt_opts struct -- the way the reference hands pars.kkt.ma97_u to linear_solver_HSL (src/kkt_system_solver/kkt_system_solver.jl:247;
+    # option plumbing src/parameters.jl:4-46, src/JuMPinterface.jl:570-586).  Two knobs whose effect can be read back from the handle:
+    # the ordering (ordering_used of the plan) and the zero-pivot tolerance (the inertia counts).
+    prob = synth.make_config("S-C3-random-small", seed=0, well_scaled=True)
+    it = synth_iterate(prob, KS.Class_iterate, 0)
+    seen = {}
+    for ordering in (0, 1, 3):
+        pars = KS.Class_parameters()
+        pars.kkt.kkt_solver_type = "symmetric"
+        pars.kkt.hip_ordering = ordering
+        k = KS.pick_KKT_solver(pars)
+        k.initialize_b(it); k.form_system_b(it)
+        assert k.factor_b(1e-8) == 1
+        st = k.linear_solver_stats()
+        seen[ordering] = (st["ordering_used"], st["nnzL"])
+        k.finalize_b()
+    assert seen[1][0] == 1 and seen[3][0] == 0                     # natural order / minimum degree, as asked
+    assert seen[1][1] > seen[3][1]                                 # ... and it is a different plan: the natural order fills more
+    # inertia_tol: with an absurdly large tolerance every pivot counts as zero -> inertia flag 0 (julia.jl:73-78)
+    pars = KS.Class_parameters()
+    pars.kkt.kkt_solver_type = "symmetric"
+    pars.kkt.hip_inertia_tol = 1e300
+    k = KS.pick_KKT_solver(pars)
+    k.initialize_b(it); k.form_system_b(it)
+    assert k.factor_b(1e-8) == 0
+    assert k.inertia[2] == prob["n"] + prob["m"], k.inertia
+    k.finalize_b()
