@@ -634,7 +634,7 @@ int64_t okkt_debug_dataflow_queue(int32_t nfronts, const int32_t* f, const int32
     }
     std::vector<okkt::DfTask> q;
     double model = 0;
-    okkt::df_build_queue(fronts, workers, group & 255, std::max(1, (group >> 8) & 255), (group >> 16) & 1, (group >> 17) & 1, q, &model, (group >> 18) & 1);
+    okkt::df_build_queue(fronts, workers, group & 255, std::max(1, (group >> 8) & 255), (group >> 16) & 1, (group >> 17) & 1, q, &model, (group >> 18) & 1, (group >> 19) & 1);
     if (model_us) *model_us = model;
     for (int64_t t = 0; t < (int64_t)q.size() && t < cap; ++t) {
       tasks[4 * t] = q[t].front; tasks[4 * t + 1] = q[t].type_nq; tasks[4 * t + 2] = q[t].ij; tasks[4 * t + 3] = q[t].q0;

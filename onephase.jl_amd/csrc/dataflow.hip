@@ -45,6 +45,10 @@ constexpr int kDfThreadsC = 512;   // threads of a worker
 #define OKKT_DF_STAGGER 1
 #endif
 constexpr bool kDfStagger = OKKT_DF_STAGGER != 0;   // waves 4 - 7 of a worker request the next operand chunk half a chunk behind waves 0 - 3
+#ifndef OKKT_DF_PROG
+#define OKKT_DF_PROG 1
+#endif
+constexpr bool kDfProg = OKKT_DF_PROG != 0;   // round 6: the diagonal block reports its finished 32-column blocks (front_device.h, diag2_body<LPROG>) and TU follows in lockstep (df_tu_lock)
 constexpr int kDfDiagMfmaWaves = 6;   // MFMA waves of the diagonal-block factorisation in a worker (four or six: the same time)
 constexpr int kDfKC = OKKT_DF_KC;           // panel columns per ring slot of the update tasks
 constexpr int kDfStages = OKKT_DF_STAGES;   // operand ring of the update tasks: 16-column chunks in LDS (one workgroup per CU: nobody else covers a chunk that is late)
@@ -646,6 +650,301 @@ __device__ __forceinline__ bool df_tu_tile(const DevPlan& P, int s, int q, int r
   return true;
 }
 
+// ---- TU in lockstep with D(q) (round 6) ---------------------------------------------------------------------------------------------
+// The chain between two diagonal blocks was D(q) 32 us -> TU(q) 28 us (stage L(q, q) and the 32 x 32 inverses, solve the 128 rows, update
+// the diagonal tile (q + 1, q + 1)) -> D(q + 1): 60 us per 128 pivot columns whatever is left to update -- the bound of every front's tail and
+// of every configuration but the metric one.  Nothing in TU needs ALL of D(q): the blocked substitution W_b = (A_b - sum_{p < b} W_p L_bp^T)
+// X_bb^T needs column block p of L(q, q) when it reaches block p, and the tile update is a sum over the panel's columns in ascending
+// order.  diag2_body<LPROG> reports its 32-column blocks as their L entries and pivots reach memory (sub-state b + 1 in the slot
+// (q, q + 1) of the tile states); this task, popped beside D(q) as before, follows one block behind.  Per column block b:
+//   1. the report arrives -> every thread stages L(b' > b, b) and, for the inverting wave, the diagonal block L(b, b);
+//   2. wave 7 inverts L(b, b) -- the column-oriented forward substitution of diag2_body's tail, the same operations in the same order:
+//      bitwise the X_bb that D(q) itself computes later for everybody else -- WHILE waves 0 - 6 store W and L of block b - 1 and apply
+//      W_(b - 1) to the diagonal tile (8 k-steps of the units' MFMA loop, k ascending as before: bitwise the same tile);
+//   3. W_b = t_b X_bb^T, W_b into the LDS image (two images: the next block's step 2 reads this one), then RIGHT-looking t_b' -= W_b L_b'b^T
+//      for the later blocks (every entry receives its terms in the order of the left-looking df_tu_tile: bitwise the same W).
+// Behind D(q)'s last report only block 3 is left.  One worker per block row: the TA / TU split bought 6 us of a 28-us step.
+// The inverses cost this worker 3.2 us per block on a wave that does nothing else; inside D(q) they cost every micro-step (see
+// front_device.h).  The twenty 32 x 16 units of the tile are dealt to waves 0 - 6 (kTuLockUnits).
+__device__ const unsigned char kTuLockUnits[8][3] = {{0, 10, 19}, {4, 14, 23}, {1, 18, 27}, {5, 22, 31}, {9, 3, 2}, {13, 7, 6}, {11, 15, 255}, {255, 255, 255}};
+constexpr size_t kDfTuLockLds = ((size_t)3 * kIB * kIB + 2 * 32 * kXld + 64 + 2 * ((size_t)32 * kSyrkLd + 32)) * sizeof(double);
+__device__ __forceinline__ bool df_tu_lock(const DevPlan& P, int s, int q, int r0, int rlim, const int* sub_state, int dval, int* diag_state, int* row_state,
+                                           bool with_d, int* s_flag, double* sm, long long* marks) {
+  constexpr int NBLK = 4, NB = 128;
+  int tid_ = threadIdx.x;
+  asm volatile("" : "+v"(tid_));
+  const int tid = tid_, lane = tid & 63, wv = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(wv);
+  const int col0 = P.sn_col0[s];
+  const int f = (int)(P.row_ptr[s + 1] - P.row_ptr[s]);
+  const int j0 = q * NB;      // q + 1 < KB: panel q is a whole block column
+  double* F = P.arena + P.front_pos[s];
+  double* Wb = P.wbuf + P.wbuf_pos[s] + (size_t)j0 * f;
+  double* Sb = sm;                                    // three staged 32 x 32 blocks: L(b', b) for b' = b + 1 .. 3 (leading dimension kIB)
+  double* Li = sm + 3 * kIB * kIB;                    // L(b, b) for the inverting wave, leading dimension kXld
+  double* Xi = Li + 32 * kXld;                        // its inverse, leading dimension kXld
+  double* rdv = Xi + 32 * kXld;                       // 2 x 32 reciprocal pivots (block parity)
+  double* Wl0 = rdv + 64;                             // two W images [32 panel columns][kSyrkLd] (block parity): W(r0 + r, j0 + 32 b + p) at p * kSyrkLd + r
+  constexpr size_t kWlStride = (size_t)32 * kSyrkLd + 32;
+  const int trow = wv * 16 + (lane & 15);             // row of the tile this lane solves
+  const int row = r0 + trow;
+  const int rowc = min(row, f - 1);
+  const bool valid = row < rlim;
+  const int lk = lane >> 4, li = lane & 3;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  double t[NBLK * 8];
+#pragma unroll
+  for (int qq = 0; qq < NBLK * 8; ++qq) {
+    const int c = 4 * qq + lk;
+    t[qq] = keep_f64(F[(size_t)(j0 + c) * f + rowc], valid);
+  }
+  constexpr int NU = 3;
+  int ucode[NU];
+#pragma unroll
+  for (int u = 0; u < NU; ++u) ucode[u] = __builtin_amdgcn_readfirstlane((int)kTuLockUnits[wave][u]);
+  auto unit_on = [&](int u) { return ucode[u] != 255 && r0 + 32 * (ucode[u] & 3) < rlim && r0 + 16 * (ucode[u] >> 2) < rlim; };
+  double acc[NU][4][2];
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+#pragma unroll
+    for (int cg = 0; cg < 4; ++cg) { acc[u][cg][0] = 0.0; acc[u][cg][1] = 0.0; }
+    if (!unit_on(u)) continue;
+    const int r = r0 + 32 * (ucode[u] & 3) + 2 * l15;
+    const int rcl = min(r, f - 2);
+    const int shift = r - rcl;
+#pragma unroll
+    for (int cg = 0; cg < 4; ++cg) {
+      const int c = r0 + 16 * (ucode[u] >> 2) + cg * 4 + l4;
+      const double* colp = F + (size_t)min(c, f - 1) * f;
+      d2_t v;
+      __builtin_memcpy(&v, colp + rcl, 16);
+      const double e0 = shift == 0 ? v[0] : v[1];
+      acc[u][cg][0] = keep_f64(e0, r < rlim && c < rlim && r >= c);
+      acc[u][cg][1] = keep_f64(v[1], shift == 0 && r + 1 < rlim && c < rlim && r + 1 >= c);
+    }
+  }
+  auto await = [&](const int* state, int least, int* flag) -> bool {
+    if (wave == 0) {
+      int ok = 1, spins = 0;
+      long long t0w = 0;
+      for (;;) {
+        if (__builtin_amdgcn_readfirstlane(ld_state(state)) >= least) break;
+        const int stop = P.want_neg >= 0 ? __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&P.counters[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : 0;
+        const int dead = __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&P.counters[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        if (stop | dead) { ok = 0; break; }
+        if (wait_expired(spins, t0w)) {
+          if (lane == 0) atomicExch(&P.counters[5], 1ull);
+          ok = 0;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      *flag = ok;
+    }
+    __syncthreads();
+    return __builtin_amdgcn_readfirstlane(*flag) != 0;
+  };
+  const int nrow = min(rlim - r0, 128);
+  // W and L = W D^-1 of column block pb (its image and reciprocals: parity pb & 1) to memory, then the units' 8 k-steps of that block
+  auto store_and_update = [&](int pb, int first_thread, int nthreads) {
+    const double* Wl = Wl0 + (size_t)(pb & 1) * kWlStride;
+    const double* rd2 = rdv + (pb & 1) * 32;
+    if (tid >= first_thread && tid < first_thread + nthreads) {
+      for (int idx = tid - first_thread; idx < 32 * 64; idx += nthreads) {
+        const int p = idx >> 6, x2 = (idx & 63) * 2;
+        d2_t w;
+        __builtin_memcpy(&w, Wl + (size_t)p * kSyrkLd + x2, 16);
+        const double rp = rd2[p];
+        const d2_t l = (d2_t){w[0] * rp, w[1] * rp};
+        double* wdst = Wb + (size_t)(pb * kIB + p) * f + r0 + x2;
+        double* ldst = F + (size_t)(j0 + pb * kIB + p) * f + r0 + x2;
+        if (x2 + 1 < nrow) { st_sc1_f64x2(wdst, w); st_sc1_f64x2(ldst, l); }
+        else if (x2 < nrow) { st_agent_f64(wdst, w[0]); st_agent_f64(ldst, l[0]); }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      if (!unit_on(u)) continue;
+      const double* bw = Wl + 32 * (ucode[u] & 3) + 2 * l15;
+      const double* bl = Wl + 16 * (ucode[u] >> 2) + (lane & 3);
+      double nrd, nav[4];
+      d2_t nbv;
+      auto fetch = [&](int kk) {
+        nrd = rd2[kk * 4 + l4];
+        __builtin_memcpy(&nbv, bw + (kk * 4 + l4) * kSyrkLd, 16);
+#pragma unroll
+        for (int cg = 0; cg < 4; ++cg) nav[cg] = bl[(kk * 4 + l4) * kSyrkLd + cg * 4];
+      };
+      fetch(0);
+#pragma unroll
+      for (int kk = 0; kk < kIB / 4; ++kk) {
+        double av[4];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const d2_t bv = nbv;
+#pragma unroll
+        for (int cg = 0; cg < 4; ++cg) av[cg] = nav[cg] * nrd;
+        fetch(min(kk + 1, kIB / 4 - 1));
+#pragma unroll
+        for (int cg = 0; cg < 4; ++cg) {
+          acc[u][cg][0] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[cg], bv[0], acc[u][cg][0], 0, 0, 1 /* neg A */);
+          acc[u][cg][1] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[cg], bv[1], acc[u][cg][1], 0, 0, 1 /* neg A */);
+        }
+      }
+    }
+  };
+  // X = inv(L(b, b)) by one wave: diag2_body's tail, operation for operation (lane c keeps the even rows of column c, lane c + 32 the odd
+  // ones; x[p] crosses with v_permlane32_swap; column p + 1 of L requested before the FMAs of column p)
+  auto invert_block = [&]() {
+    const int c = lane & 31, hf = lane >> 5;
+    const double* Lh = Li + hf;
+    double v[16], la[16], lb[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] = (2 * j + hf == c) ? 1.0 : 0.0;
+    auto both = [&](double x, int owner) {
+      const unsigned lo = (unsigned)__double2loint(x), hi = (unsigned)__double2hiint(x);
+      const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+      const auto bq = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+      return owner == 0 ? __hiloint2double((int)bq[0], (int)a[0]) : __hiloint2double((int)bq[1], (int)a[1]);
+    };
+#pragma unroll
+    for (int j = 0; j < 16; ++j) la[j] = Lh[2 * j];
+#pragma unroll
+    for (int p = 0; p < 32; p += 2) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int j = (p + 2) / 2; j < 16; ++j) lb[j] = Lh[2 * j + (p + 1) * kXld];
+      {
+        const double mine = (p >= c) ? v[p / 2] : 0.0;
+        const double xp = both(mine, 0);
+        v[p / 2] = hf == 0 ? xp : __builtin_fma(-la[p / 2], xp, v[p / 2]);
+#pragma unroll
+        for (int j = p / 2 + 1; j < 16; ++j) v[j] = __builtin_fma(-la[j], xp, v[j]);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (p + 2 < 32) {
+#pragma unroll
+        for (int j = (p + 2) / 2; j < 16; ++j) la[j] = Lh[2 * j + (p + 2) * kXld];
+      }
+      {
+        const double mine = (p + 1 >= c) ? v[p / 2] : 0.0;
+        const double xp = both(mine, 1);
+        v[p / 2] = hf == 1 ? xp : v[p / 2];
+#pragma unroll
+        for (int j = p / 2 + 1; j < 16; ++j) v[j] = __builtin_fma(-lb[j], xp, v[j]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) Xi[(2 * j + hf) + c * kXld] = v[j];
+  };
+  auto block_step = [&](auto bc) -> bool {
+    constexpr int b = decltype(bc)::value;
+    // (the barrier inside the wait also separates this block's staging from the previous block's readers of the same LDS)
+    if (!await(sub_state, b + 1, s_flag + (b & 1))) return false;
+    if (marks && tid == 0 && b == 0) marks[0] = wall_clock64();             // the first column block of D(q) has arrived
+    if (marks && tid == 0 && b == NBLK - 1) marks[1] = wall_clock64();      // the last one: L(q, q) and D are complete
+    {
+      const int e = tid * 2;                 // 2 consecutive rows of one column per thread and block
+      const int cc = e / kIB, rr = e - cc * kIB;
+      const int gc = b * kIB + cc;
+#pragma unroll
+      for (int bi = b; bi < NBLK; ++bi) {
+        const int gr = bi * kIB + rr;
+        const double* src = F + (size_t)(j0 + gc) * f + j0 + gr;
+        const double v0 = src[0], v1 = src[1];
+        if (bi == b) { Li[rr + cc * kXld] = v0; Li[rr + 1 + cc * kXld] = v1; }      // (entries on and above the diagonal are never read)
+        else { const d2_t v = (d2_t){v0, v1}; __builtin_memcpy(Sb + (size_t)(bi - b - 1) * kIB * kIB + e, &v, 16); }
+      }
+      if (tid < kIB) rdv[(b & 1) * 32 + tid] = 1.0 / P.dvals[col0 + j0 + b * kIB + tid];
+    }
+    __syncthreads();
+    // wave 7 inverts; the others send block b - 1 on its way and apply it to the diagonal tile
+    if (wave == 7) invert_block();
+    else if (b > 0) store_and_update(b - 1, 0, 7 * 64);
+    __syncthreads();
+    {
+      // W_b = t_b X_bb^T (X_bb lower triangular), then the later blocks lose W_b L_b'b^T
+      double wt[8];
+#pragma unroll
+      for (int gp = 0; gp < 8; ++gp) {
+        wt[gp] = 0.0;
+#pragma unroll
+        for (int g = 0; g <= gp; ++g)
+          wt[gp] = __builtin_amdgcn_mfma_f64_4x4x4f64(Xi[(gp * 4 + li) + (g * 4 + lk) * kXld], t[b * 8 + g], wt[gp], 0, 0, 0);
+      }
+#pragma unroll
+      for (int gp = 0; gp < 8; ++gp) t[b * 8 + gp] = wt[gp];
+      double* Wl = Wl0 + (size_t)(b & 1) * kWlStride;
+#pragma unroll
+      for (int gp = 0; gp < 8; ++gp) Wl[(size_t)(4 * gp + lk) * kSyrkLd + trow] = t[b * 8 + gp];      // rows past the block row are zero
+#pragma unroll
+      for (int bi = b + 1; bi < NBLK; ++bi) {
+        const double* Lb = Sb + (size_t)(bi - b - 1) * kIB * kIB;
+#pragma unroll
+        for (int gp = 0; gp < 8; ++gp)
+#pragma unroll
+          for (int g = 0; g < 8; ++g)
+            t[bi * 8 + gp] = __builtin_amdgcn_mfma_f64_4x4x4f64(Lb[(gp * 4 + li) + (g * 4 + lk) * kIB], t[b * 8 + g], t[bi * 8 + gp], 0, 0, 1 /* neg A */);
+      }
+    }
+    return true;
+  };
+  if (!block_step(std::integral_constant<int, 0>())) return false;
+  if (!block_step(std::integral_constant<int, 1>())) return false;
+  if (!block_step(std::integral_constant<int, 2>())) return false;
+  if (!block_step(std::integral_constant<int, 3>())) return false;
+  __syncthreads();                                         // the last W block is in its image
+  if (marks && tid == 0) marks[2] = wall_clock64();        // rows solved
+  store_and_update(NBLK - 1, 0, kDfThreadsC);
+  if (marks && tid == 0) marks[3] = wall_clock64();        // diagonal tile updated
+  if (!with_d) {
+    // the diagonal tile to memory: it is what D(q + 1) waits for.  Every storing wave drains, the workgroup meets, one wave publishes
+    // (the block row's W and L left block by block above: the worker's publication of tile (q + 1, q) drains them)
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      if (!unit_on(u)) continue;
+      const int r = r0 + 32 * (ucode[u] & 3) + 2 * l15;
+#pragma unroll
+      for (int cg = 0; cg < 4; ++cg) {
+        const int c = r0 + 16 * (ucode[u] >> 2) + cg * 4 + l4;
+        if (c >= rlim) continue;
+        double* colp = F + (size_t)c * f;
+        if (r + 1 < rlim && r >= c) {
+          st_sc1_f64x2(colp + r, (d2_t){acc[u][cg][0], acc[u][cg][1]});
+        } else {
+          if (r < rlim && r >= c) st_agent_f64(colp + r, acc[u][cg][0]);
+          if (r + 1 < rlim && r + 1 >= c) st_agent_f64(colp + r + 1, acc[u][cg][1]);
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (wave == 0) __hip_atomic_store(diag_state, dval, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // tile (q + 1, q + 1) has received panel q
+  } else {
+    // TU(q) + D(q + 1) in one task: the updated tile is handed to the diagonal-block factorisation through LDS (column-major, leading
+    // dimension kDfTileLd, over everything this function kept there)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();                     // every wave has read its part of the W image
+    double* Tl = sm;
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      if (!unit_on(u)) continue;
+      const int r = 32 * (ucode[u] & 3) + 2 * l15;
+#pragma unroll
+      for (int cg = 0; cg < 4; ++cg) {
+        const int c = 16 * (ucode[u] >> 2) + cg * 4 + l4;
+        const d2_t v = (d2_t){acc[u][cg][0], acc[u][cg][1]};
+        __builtin_memcpy(Tl + (size_t)c * kDfTileLd + r, &v, 16);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (wave == 0) __hip_atomic_store(row_state, dval, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // tile (q + 1, q): W and L of the block row are in memory
+  }
+  return true;
+}
+
 // ---- U: tiles (i .. i + R - 1, j) -= W[rows, j0 .. j0 + nb) * L[columns of block j, j0 .. j0 + nb)^T ------------------------------
 // k_big_syrk's tile (numeric.hip: 128 x 128 per workgroup of 2 x 4 waves, v_mfma_f64_4x4x4 with neg-A, both operand panels through
 // an LDS-DMA ring of two 16-column chunks) with a row limit (the last pivot block of a front may be shorter than 128 rows) and sc1
@@ -808,7 +1107,7 @@ __device__ __forceinline__ void df_syrk_tiles(const DevPlan& P, int s, int j0, i
 }
 
 constexpr int kDfThreads = kDfThreadsC;
-constexpr size_t kDfLds = std::max(std::max(std::max(OKKT_DIAG2_LDS_DOUBLES(kMW) * sizeof(double), kDfTuLds), (size_t)kDfStages * 2 * kDfKC * kSyrkLd * sizeof(double)), kDfTlLds);   // diag2_body's and df_tu_tile's; the other roles need less
+constexpr size_t kDfLds = std::max(std::max(std::max(std::max(OKKT_DIAG2_LDS_DOUBLES(kMW) * sizeof(double), kDfTuLds), (size_t)kDfStages * 2 * kDfKC * kSyrkLd * sizeof(double)), kDfTlLds), std::max(kDfTuLockLds, (size_t)128 * kDfTileLd * sizeof(double)));   // diag2_body's and df_tu_tile's; the other roles need less
 
 // counters[5] = a wait ran into its bound, three seconds of wall clock (or another worker's did): every worker leaves, the factorisation
 // fails with "a hand-off timed out" and the solves return NaN -- never numbers computed from tiles that had not arrived
@@ -903,7 +1202,7 @@ __global__ __launch_bounds__(kDfThreads, 1) void k_front_dataflow(DevPlan P, con
     int* mine;
     int newv, npub = 1;
     if (type == kDfD) {
-      if (!(dbg & 1)) diag2_body<true, kDiag2MW, kDfDiagMfmaWaves>(P, s, i, 128, tol, sm, nullptr, 0, tlog ? tlog + (size_t)t * 8 + 4 : nullptr);
+      if (!(dbg & 1)) diag2_body<true, kDiag2MW, kDfDiagMfmaWaves, kDfProg>(P, s, i, 128, tol, sm, nullptr, 0, tlog ? tlog + (size_t)t * 8 + 4 : nullptr, (kDfProg && (nq & 8) && i + 1 < KB) ? st + (size_t)i * TB + i + 1 : nullptr);
       mine = st + (size_t)i * TB + i; newv = i + 1;
     } else if (type == kDfT) {
       if (!(dbg & 2)) df_trsm_tile(P, s, j, df_block_lo(i, KB, k, f), df_block_lo(i + 1, KB, k, f), sm);
@@ -917,12 +1216,18 @@ __global__ __launch_bounds__(kDfThreads, 1) void k_front_dataflow(DevPlan P, con
       const bool with_d = type == kDfTU && (nq & 2);
       const int part = type == kDfTA ? 1 : ((nq & 4) ? 2 : 0);
       int* hs = st + (size_t)j * TB + i;          // the unused upper slot (q, q + 1): the state of the upper half
+#ifndef OKKT_DF_NO_LOCK
+      if (kDfProg && (nq & 8)) {      // in lockstep with D(q): the sub-states of D(q) live in the slot hs
+        if (!df_tu_lock(P, s, j, df_block_lo(i, KB, k, f), df_block_lo(i + 1, KB, k, f), hs, j + 1, st + (size_t)i * TB + i, st + (size_t)i * TB + j, with_d,
+                        &s_ctl[2], sm, tlog ? tlog + (size_t)t * 8 + 4 : nullptr)) return;
+      } else
+#endif
       if (!df_tu_tile(P, s, j, df_block_lo(i, KB, k, f), df_block_lo(i + 1, KB, k, f), st + (size_t)j * TB + j, j + 1, st + (size_t)i * TB + i, st + (size_t)i * TB + j, hs, part, with_d,
                       &s_ctl[2], sm, tlog ? tlog + (size_t)t * 8 + 4 : nullptr)) return;
       if (type == kDfTA) {
         mine = hs; newv = 2;
       } else if (with_d) {
-        diag2_body<true, kDiag2MW, kDfDiagMfmaWaves>(P, s, i, 128, tol, sm, sm, kDfTileLd);
+        diag2_body<true, kDiag2MW, kDfDiagMfmaWaves, kDfProg>(P, s, i, 128, tol, sm, sm, kDfTileLd, nullptr, (kDfProg && (nq & 8) && i + 1 < KB) ? st + (size_t)i * TB + i + 1 : nullptr);
         mine = st + (size_t)i * TB + i; newv = i + 1;          // tile (q + 1, q) was published inside the task
       } else {
         mine = st + (size_t)i * TB + j; newv = j + 1;
@@ -966,6 +1271,10 @@ std::string df_setup(Numeric& N) {
   N.df_fuse_d = getenv("OKKT_DF_FUSE_D") ? atoi(getenv("OKKT_DF_FUSE_D")) : 1;
   N.df_split_tu = getenv("OKKT_DF_SPLIT_TU") ? atoi(getenv("OKKT_DF_SPLIT_TU")) : 1;
   N.df_fuse_tl = getenv("OKKT_DF_FUSE_TL") ? atoi(getenv("OKKT_DF_FUSE_TL")) : 1;
+  // OFF by default: built, bitwise equal, and slower (72 us between two diagonal blocks instead of 60) -- the tiles TU(q + 1) starts from arrive
+  // through D(q) -> T / TL(q + 2, q) -> the lone last-panel updates of (q + 2, q + 1) and (q + 2, q + 2) about when D(q + 1) ENDS, so the
+  // follower has nothing to follow and runs its four block steps (9 us each with its own inversions) behind D(q + 1); DESIGN.md section 4
+  N.df_lockstep = kDfProg ? (getenv("OKKT_DF_LOCKSTEP") ? atoi(getenv("OKKT_DF_LOCKSTEP")) : 0) : 0;
   N.df_rows = getenv("OKKT_DF_ROWS") ? std::max(1, std::min(atoi(getenv("OKKT_DF_ROWS")), 8)) : 1;
   OKKT_HIP_TRY(hipFuncSetAttribute((const void*)k_front_dataflow, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
   auto do_sched = [&](std::vector<LevelSchedule>& levels) {
@@ -986,7 +1295,7 @@ std::string df_setup(Numeric& N) {
         g.df_flops += (double)k * f * f - (double)k * k * f + (double)k * k * k / 3.0;
       }
       double model = 0;
-      df_build_queue(fronts, N.df_workers, N.df_group, N.df_rows, N.df_fuse_d != 0, N.df_split_tu != 0, q, &model, N.df_fuse_tl != 0);
+      df_build_queue(fronts, N.df_workers, N.df_group, N.df_rows, N.df_fuse_d != 0, N.df_split_tu != 0 && !N.df_lockstep, q, &model, N.df_fuse_tl != 0, N.df_lockstep != 0);
       g.df_off = (int64_t)all.size();
       g.df_cnt = (int)q.size();
       g.df_head = nheads++;

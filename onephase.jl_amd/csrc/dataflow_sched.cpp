@@ -59,7 +59,8 @@ struct FrontGrid {
 }  // namespace
 
 void df_build_queue(const std::vector<DfFront>& fronts, int workers, int group, int rows_per_task, bool fuse_d, bool split_tu, std::vector<DfTask>& out, double* model_us,
-                    bool fuse_tl) {
+                    bool fuse_tl, bool lockstep) {
+  if (lockstep) split_tu = false;      // one worker follows D(q) block by block (dataflow.hip, df_tu_lock): nothing left to split
   const int G = std::max(1, group);
   const int RT = std::max(1, std::min(rows_per_task, 8));
   // Time model (us, measured on MI355X with one workgroup per CU: D 39-45, T 25-32, U 25-30 at K = 128 and 45-52 at K = 256, TU 40
@@ -175,9 +176,9 @@ void df_build_queue(const std::vector<DfFront>& fronts, int workers, int group, 
         const int lo = std::min(nd.i * 128, gg.k), hi = std::min(lo + 128, gg.k);      // nd.i = q + 1 < KB: a pivot block
         const bool split = split_tu && hi - lo > 64;
         if (split) out.push_back({fronts[nd.front].s, kDfTA | (1 << 8) | (1 << 16), nd.i | (nd.j << 16), nd.q0});
-        out.push_back({fronts[nd.front].s, kDfTU | (((fuse_d ? 2 : 1) | (split ? 4 : 0)) << 8) | (nd.rows << 16), nd.i | (nd.j << 16), nd.q0});
+        out.push_back({fronts[nd.front].s, kDfTU | (((fuse_d ? 2 : 1) | (split ? 4 : 0) | (lockstep ? 8 : 0)) << 8) | (nd.rows << 16), nd.i | (nd.j << 16), nd.q0});
       } else if (!(fuse_d && nd.type == kDfD && nd.i > 0))
-        out.push_back({fronts[nd.front].s, nd.type | (nd.nq << 8) | (nd.rows << 16), nd.i | (nd.j << 16), nd.q0});
+        out.push_back({fronts[nd.front].s, nd.type | ((nd.nq | ((lockstep && nd.type == kDfD) ? 8 : 0)) << 8) | (nd.rows << 16), nd.i | (nd.j << 16), nd.q0});      // D with bit 8: report the finished 32-column blocks
       if (nd.type == kDfTL)      // the update (14 us) runs ahead of D(q); the solve, the stores and the hand-off behind it
         nd.dur = (float)(std::max(now + 14.0 * bulk_scale, dend[nd.front][nd.j]) + 22.0 * bulk_scale - now);
       running.push({now + nd.dur, x});
@@ -186,7 +187,7 @@ void df_build_queue(const std::vector<DfFront>& fronts, int workers, int group, 
         dend[nd.front][nd.i] = now + nd.dur;
         if (nd.i + 1 < grids[nd.front].KB) {      // TU(q) starts beside D(q) and ends 24 us behind it
           const int64_t tu = grids[nd.front].offTU + nd.i;
-          nodes[tu].dur = nd.dur + chain_scale * 40.0f;
+          nodes[tu].dur = nd.dur + chain_scale * (lockstep ? 14.0f : 40.0f);      // lockstep: only the last 32-column block is left behind D(q)
           release(tu);
         }
         if (fuse_tl && nd.i > 0) {                // ... and so do the TL tasks of the block rows below

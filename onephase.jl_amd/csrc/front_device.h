@@ -127,8 +127,17 @@ __device__ __forceinline__ double ld_agent_f64(const double* p) { return __hip_a
 constexpr int kDiag2MW = OKKT_DIAG2_MW;     // columns per micro-step of diag2_body (8: round 3; 4 halves the redundant block factorisation of the row threads for twice the barriers)
 // tile_lds != nullptr (dataflow.hip, TU + D in one task): the block comes from LDS (column-major, leading dimension tile_ld, written
 // by the same workgroup) instead of the front in HBM; it overlaps this function's own LDS areas, hence the barrier behind the loads
-template <bool AG, int MW = kDiag2MW, int NMM = 4>
-__device__ __forceinline__ void diag2_body(const DevPlan& P, int s, int step, int NB, double tol, double* sm, const double* tile_lds = nullptr, int tile_ld = 0, long long* marks = nullptr) {
+// LPROG (round 6, the dataflow worker): the block reports its progress -- `sub_state` counts the 32-column blocks whose L entries and
+// pivots are in memory -- so that the task behind it on the critical path (TU(q), dataflow.hip df_tu_lock) works on column block b while
+// column block b + 1 is being factored.  The row waves wait for their own stores of column block b at the top of micro-step 4 b + 5,
+// in front of the next deferred outputs: the stores are a whole micro-step old by then (and the wait falls into the MFMA waves' head,
+// where the row waves idle), so the publication costs the loop nothing.  The inverses of the 32 x 32 diagonal blocks are NOT part of
+// the report (they stay in the tail): the follower inverts the blocks itself.  (A form with the inversions inside the loop on a wave
+// of their own and a storing wave -- four MFMA waves instead of six -- published complete blocks but took 55 us per diagonal block
+// instead of 32: scripts/experiments/r06_diag2_prog_service_waves.patch.)
+template <bool AG, int MW = kDiag2MW, int NMM = 4, bool LPROG = false>
+__device__ __forceinline__ void diag2_body(const DevPlan& P, int s, int step, int NB, double tol, double* sm, const double* tile_lds = nullptr, int tile_ld = 0, long long* marks = nullptr,
+                                           int* sub_state = nullptr) {
   static_assert(MW == 8 || MW == 4, "micro-panels of 4 or 8 columns");
   constexpr int NE = MW / 4;                   // MFMA k-steps (4 columns each) per micro-panel
   constexpr int PER = 16 / MW;                 // micro-panels per 16-column tile
@@ -235,12 +244,15 @@ __device__ __forceinline__ void diag2_body(const DevPlan& P, int s, int step, in
       dpiv[r] = my_d;
       if (rv) {
         if (AG) st_agent_f64(&Fr[(size_t)i * f], my_d); else Fr[(size_t)i * f] = my_d;
+        if constexpr (LPROG) st_agent_f64(&P.dvals[col0 + j0 + r], my_d);      // the follower needs the pivots with the block, not behind the loop
         Ldr[i * kXld] = my_d;
       }
     }
   };
   for (int ms = 0; ms < nms; ++ms) {
     const int p8 = ms * MW, pp = ms / PER, h = ms % PER;
+    const bool report = LPROG && sub_state != nullptr && ms >= 5 && ((ms - 5) & 3) == 0;      // column block (ms - 5) / 4: its last outputs left at the top of the previous micro-step
+    if (report && wave < 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     row_outputs();      // of micro-step ms - 1, beside the MFMA waves' head of this one
     const double* Lprev = LpB + ((ms + 1) & 1) * MW * kPLD;    // panels of micro-step ms - 1
     const double* Wprev = WpB + ((ms + 1) & 1) * MW * kPLD;
@@ -276,6 +288,7 @@ __device__ __forceinline__ void diag2_body(const DevPlan& P, int s, int step, in
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if (marks && tid == 0) { const long long tn = wall_clock64(); t_head += tn - tk; tk = tn; }
+    if (report && wave == 0 && lane == 0) __hip_atomic_store(sub_state, ((ms - 5) >> 2) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // both row waves have waited in front of the barrier
     if (!mm) {
       // row threads: 8 x 8 diagonal LDL^T redundantly in registers, own row solved, the panels -L and W written for the MFMA waves.
       // The entries nobody waits for inside the loop (L to memory, the block's copy for the inverses, the pivots) are written
@@ -333,9 +346,11 @@ __device__ __forceinline__ void diag2_body(const DevPlan& P, int s, int step, in
     if (marks && tid == 0) { const long long tn = wall_clock64(); t_rest += tn - tk; tk = tn; }
   }
   row_outputs();        // of the last micro-step; the inverses below read the block's copy, the pivot counts read dpiv
+  if (LPROG && sub_state != nullptr && wave < 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the whole of L and D is in memory ...
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
+  if (LPROG && sub_state != nullptr && wave == 0 && lane == 0) __hip_atomic_store(sub_state, (nb + 31) / 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ... and reported before the inverses are computed
   if (marks && tid == 0) { marks[0] = t_head; marks[1] = t_row; marks[2] = t_rest; marks[3] = wall_clock64(); }
   (void)my_d;
   if (wave == 4 || wave == 5) {

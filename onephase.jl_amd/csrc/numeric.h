@@ -100,7 +100,7 @@ struct DfFront { int s, f, k; };
 // queue of the fronts of one level in the start order of a simulated list schedule on `workers` workers; `group` panels per
 // update task where the tile allows it; model_us = the simulated makespan
 void df_build_queue(const std::vector<DfFront>& fronts, int workers, int group, int rows_per_task, bool fuse_d, bool split_tu, std::vector<DfTask>& out, double* model_us,
-                    bool fuse_tl = false);
+                    bool fuse_tl = false, bool lockstep = false);
 
 constexpr int kDfHeadStride = 16;   // queue counter of a level (word 0; one cache line per level)
 constexpr int kCountSlots = 64, kCountStride = 16;
@@ -197,6 +197,7 @@ struct Numeric {
   int df_group = 4;                    // panels per update task (K = 128 * group) where the column allows it (OKKT_DF_GROUP; S-metric 19.1 / 18.3 / 18.2 ms at 2 / 3 / 4)
   int df_fuse_d = 1;                   // D(q + 1) in the task of TU(q): the diagonal tile passes through LDS (OKKT_DF_FUSE_D=0: a task of its own)
   int df_split_tu = 1;                 // block rows of more than 64 rows: TU(q) as two tasks on two workers, TA(q) (upper 64 rows) and TU(q) (OKKT_DF_SPLIT_TU=0: one)
+  int df_lockstep = 0;                 // TU(q) in lockstep with the 32-column blocks of D(q) (df_tu_lock; OKKT_DF_LOCKSTEP=0: the split TA / TU of rounds 4 - 5 behind the whole of D(q))
   int df_fuse_tl = 1;                  // T(i, q) with the last update of its tile inside the task (TL), q >= 1 (OKKT_DF_FUSE_TL=0: separate tasks)
   int df_rows = 1;                     // row tiles per bulk update task (OKKT_DF_ROWS; 2 and 4 measured slower: the coarser tasks cost the schedule more than the shared prologue saves)
   int df_workers = 256;                // workers of the simulated schedule (and the grid of the launch): one workgroup per CU

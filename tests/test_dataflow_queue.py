@@ -14,13 +14,13 @@ from onephase_jl_amd import _lib
 D, T, U, TU, TA, TL = 0, 1, 2, 3, 4, 5
 
 
-def build_queue(fronts, workers=256, group=2, rows=1, fuse_d=False, split=False, fuse_tl=False):
+def build_queue(fronts, workers=256, group=2, rows=1, fuse_d=False, split=False, fuse_tl=False, lock=False):
     lib = _lib.load()
     n = len(fronts)
     f = (C.c_int32 * n)(*[a for a, _ in fronts])
     k = (C.c_int32 * n)(*[b for _, b in fronts])
     model = C.c_double(0)
-    group = group | (rows << 8) | ((1 if fuse_d else 0) << 16) | ((1 if split else 0) << 17) | ((1 if fuse_tl else 0) << 18)
+    group = group | (rows << 8) | ((1 if fuse_d else 0) << 16) | ((1 if split else 0) << 17) | ((1 if fuse_tl else 0) << 18) | ((1 if lock else 0) << 19)
     cnt = lib.okkt_debug_dataflow_queue(n, f, k, workers, group, None, 0, C.byref(model))
     assert cnt >= 0
     buf = (C.c_int32 * (4 * max(cnt, 1)))()
@@ -203,6 +203,16 @@ def test_queue_replays_to_the_partial_factorisation(fronts, group, rows, fused, 
     tasks, model = build_queue(fronts, workers=16, group=group, rows=rows, fuse_d=fused, split=split, fuse_tl=tl)
     assert model > 0
     replay(fronts, tasks, group, fused, split, fuse_tl=tl)
+
+
+@pytest.mark.parametrize("fronts", CASES)
+@pytest.mark.parametrize("group,rows,fused,tl", [(4, 1, True, True), (2, 2, False, False)])
+def test_lockstep_queue_replays_to_the_partial_factorisation(fronts, group, rows, fused, tl):
+    # round 6: TU(q) in lockstep with D(q) -- one task per block row (no TA whatever `split` says), flagged with bit 8 of its nq field
+    tasks, model = build_queue(fronts, workers=16, group=group, rows=rows, fuse_d=fused, split=True, fuse_tl=tl, lock=True)
+    assert model > 0 and not any(t[1] == TA for t in tasks)
+    assert all(t[2] & 8 for t in tasks if t[1] == TU)
+    replay(fronts, tasks, group, fused, False, fuse_tl=tl)
 
 
 def test_queue_is_the_same_every_time_and_scales():

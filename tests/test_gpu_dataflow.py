@@ -39,12 +39,14 @@ def test_dataflow_equals_the_per_step_launches_bit_for_bit(case, tmp_path):
 @pytest.mark.parametrize("env", [{"OKKT_DF_GROUP": "1"}, {"OKKT_DF_GROUP": "2"}, {"OKKT_DF_GROUP": "3", "OKKT_DF_ROWS": "2"}, {"OKKT_DF_ROWS": "4"},
                                  {"OKKT_DF_WORKERS": "7"}, {"OKKT_DF_WORKERS": "64", "OKKT_DF_MODEL_CHAIN": "2.0"}, {"OKKT_DF_SPLIT_TU": "0"},
                                  {"OKKT_DF_SPLIT_TU": "0", "OKKT_DF_FUSE_D": "0"}, {"OKKT_DF_FUSE_D": "0"},
-                                 {"OKKT_DF_FUSE_TL": "0"}, {"OKKT_DF_FUSE_TL": "0", "OKKT_DF_FUSE_D": "0", "OKKT_DF_GROUP": "2"}],
+                                 {"OKKT_DF_FUSE_TL": "0"}, {"OKKT_DF_FUSE_TL": "0", "OKKT_DF_FUSE_D": "0", "OKKT_DF_GROUP": "2"},
+                                 {"OKKT_DF_LOCKSTEP": "1"}, {"OKKT_DF_LOCKSTEP": "1", "OKKT_DF_WORKERS": "5"}, {"OKKT_DF_LOCKSTEP": "1", "OKKT_DF_FUSE_D": "0"}],
                          ids=lambda e: ",".join(f"{k[8:]}={v}" for k, v in e.items()))
 def test_every_queue_shape_gives_the_same_factor(env, tmp_path):
     """The grouping of the panels, the number of row tiles per task, the number of workers, the time model, one or two workers for
-    the block row behind a diagonal block, the diagonal block as a task of its own and the last update of a tile inside its panel task
-    (TL) only change the ORDER of the queue and who computes what; the factor does not depend on it."""
+    the block row behind a diagonal block, the diagonal block as a task of its own, the last update of a tile inside its panel task
+    (TL) and the block row behind a diagonal block in lockstep with it (round 6: OKKT_DF_LOCKSTEP=1, an experiment that is off by
+    default) or behind the whole of it only change the ORDER of the queue and who computes what; the factor does not depend on it."""
     a = run_case("dense2600", {"OKKT_DATAFLOW": "1"}, tmp_path, "default")
     e = {"OKKT_DATAFLOW": "1"}
     e.update(env)

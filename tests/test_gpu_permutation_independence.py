@@ -70,9 +70,11 @@ def test_observables_do_not_depend_on_the_oracles_pivot_order(name, kind, which)
     status, num_fac, delta = k.ipopt_strategy_b(it)
     perm = oracle_perm(prob, kind, which)
     hip_perm = np.asarray(k.linear_solver_perm())
+    if perm is None and np.array_equal(hip_perm, np.arange(len(hip_perm))):
+        # (the Schur matrix of the hanging chain is dense -- the length constraint touches every u -- and minimum degree leaves a dense
+        # matrix in its natural order: the oracle then takes the REVERSED order, so that the two pivot orders do differ)
+        perm = np.arange(len(hip_perm), dtype=np.int64)[::-1].copy()
     assert perm is None or not np.array_equal(perm, hip_perm)      # really a different pivot order
-    if perm is None:
-        assert not np.array_equal(hip_perm, np.arange(len(hip_perm)))
     ko = KO.pick_KKT_solver(kind, perm=perm)
     ko.initialize_b(oit)
     ko.form_system_b(oit)
