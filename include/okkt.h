@@ -100,7 +100,7 @@ typedef struct {
   int64_t nnzL_stored;    /* panel entries actually stored (with relaxation zeros) */
   double flops_exact;     /* sum_j c_j^2  (SURVEY 8d factor flops) */
   double flops_stored;    /* dense-front flops executed */
-  int64_t arena_bytes;    /* HBM bytes of the front arena (sum f^2 * 8) */
+  int64_t arena_bytes;    /* HBM bytes of the front arena as allocated (before the device plan exists: sum f^2 * 8) */
   int64_t nsuper;
   int64_t nlevels;
   int64_t max_front;
@@ -116,6 +116,8 @@ typedef struct {
   int64_t top_separator;   /* multilevel dissection: vertices of the top-level separator (-1: none) */
   int64_t amd_skipped;     /* automatic ordering: 1 = minimum degree was abandoned (small top separator), no flop comparison was made */
   double flops_other;      /* automatic ordering: factor flops of the candidate that lost the comparison (0: none, or skipped) */
+  int64_t arena_dense_bytes; /* what the front arena would take with a dense f x f buffer per front (sum f^2 * 8: the layout of rounds 1 - 5);
+                              * arena_bytes is the arena as allocated -- L panels + the region the contribution blocks share by lifetime */
 } okkt_stats;
 
 /* ---- level 1: linear solver ------------------------------------------------------------ */

@@ -80,6 +80,7 @@ class OkktStats(C.Structure):
         ("top_separator", C.c_int64),
         ("amd_skipped", C.c_int64),
         ("flops_other", C.c_double),
+        ("arena_dense_bytes", C.c_int64),
     ]
 
     def as_dict(self):

@@ -419,7 +419,7 @@ int okkt_get_stats(okkt_handle h, okkt_stats* out) {
   out->nnzL_stored = S.nnzL_stored;
   out->flops_exact = S.flops_exact;
   out->flops_stored = S.flops_stored;
-  out->arena_bytes = S.arena_doubles * 8;
+  out->arena_bytes = (h->N.arena_doubles > 0 ? h->N.arena_doubles : S.arena_doubles) * 8;      // as allocated (panels + the shared contribution-block region) once the device plan exists
   out->nsuper = S.nsuper;
   out->nlevels = S.nlevels;
   out->max_front = S.max_front;
@@ -441,6 +441,7 @@ int okkt_get_stats(okkt_handle h, okkt_stats* out) {
   out->top_separator = h->S.top_separator;
   out->amd_skipped = h->S.amd_skipped ? 1 : 0;
   out->flops_other = h->S.flops_other;
+  out->arena_dense_bytes = S.arena_doubles * 8;
   return OKKT_OK;
 }
 
@@ -532,7 +533,7 @@ int okkt_get_factor_csc(okkt_handle h, int64_t* colptr_out, int64_t* rowval_out,
       const int64_t f = S.row_ptr[s + 1] - S.row_ptr[s];
       const int64_t k = S.sn_col0[s + 1] - S.sn_col0[s];
       front.resize((size_t)(f * k));
-      if (hipMemcpy(front.data(), h->N.d.arena + S.front_pos[s], (size_t)(f * k) * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
+      if (hipMemcpy(front.data(), h->N.d.arena + h->N.front_pos_host[s], (size_t)(f * k) * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
         return solver_set_error(h, OKKT_ERR_HIP, "download of a front failed");
       for (int64_t lc = 0; lc < k; ++lc) {
         colptr_out[S.sn_col0[s] + lc] = q;

@@ -49,6 +49,10 @@ constexpr bool kDfStagger = OKKT_DF_STAGGER != 0;   // waves 4 - 7 of a worker r
 #define OKKT_DF_PROG 1
 #endif
 constexpr bool kDfProg = OKKT_DF_PROG != 0;   // round 6: the diagonal block reports its finished 32-column blocks (front_device.h, diag2_body<LPROG>) and TU follows in lockstep (df_tu_lock)
+#ifndef OKKT_DF_MACRO
+#define OKKT_DF_MACRO 1
+#endif
+constexpr bool kDfMacro = OKKT_DF_MACRO != 0;   // update tasks on pairs of row tiles as one macro tile (df_syrk_macro)
 constexpr int kDfDiagMfmaWaves = 6;   // MFMA waves of the diagonal-block factorisation in a worker (four or six: the same time)
 constexpr int kDfKC = OKKT_DF_KC;           // panel columns per ring slot of the update tasks
 constexpr int kDfStages = OKKT_DF_STAGES;   // operand ring of the update tasks: 16-column chunks in LDS (one workgroup per CU: nobody else covers a chunk that is late)
@@ -391,7 +395,7 @@ __device__ __forceinline__ bool df_tu_tile(const DevPlan& P, int s, int q, int r
 #pragma unroll
     for (int cg = 0; cg < 4; ++cg) {
       const int c = r0 + 16 * (ucode[u] >> 2) + cg * 4 + l4;
-      const double* colp = F + (size_t)min(c, f - 1) * f;
+      const double* colp = F + (size_t)min(c, rlim - 1) * f;      // (columns of a pivot tile: clamped inside the panel)
       d2_t v;
       __builtin_memcpy(&v, colp + rcl, 16);
       const double e0 = shift == 0 ? v[0] : v[1];
@@ -715,7 +719,7 @@ __device__ __forceinline__ bool df_tu_lock(const DevPlan& P, int s, int q, int r
 #pragma unroll
     for (int cg = 0; cg < 4; ++cg) {
       const int c = r0 + 16 * (ucode[u] >> 2) + cg * 4 + l4;
-      const double* colp = F + (size_t)min(c, f - 1) * f;
+      const double* colp = F + (size_t)min(c, rlim - 1) * f;      // (columns of a pivot tile: clamped inside the panel)
       d2_t v;
       __builtin_memcpy(&v, colp + rcl, 16);
       const double e0 = shift == 0 ? v[0] : v[1];
@@ -971,6 +975,7 @@ __device__ __forceinline__ void df_syrk_tiles(const DevPlan& P, int s, int j0, i
   const int ct0 = df_block_lo(j, KB, k, f), clim = df_block_lo(j + 1, KB, k, f);
   const int cbase = ct0 + (wv >> 1) * WCW;
   double* F = P.arena + P.front_pos[s];
+  double* Fc = F + (j >= KB ? P.cb_shift[s] : 0);      // the tile column's base: a block of the contribution block lives in the shared region
   const double* Wcol = P.wbuf + P.wbuf_pos[s] + (size_t)j0 * f + lane * 2;
   const double* Lg = F + (size_t)j0 * f + ct0 + lane * 2;
   const int l15 = lane & 15, l4 = lane >> 4;
@@ -998,7 +1003,7 @@ __device__ __forceinline__ void df_syrk_tiles(const DevPlan& P, int s, int j0, i
 #pragma unroll
     for (int cg = 0; cg < NCG; ++cg) {
       const int c = cbase + cg * 4 + l4;
-      const double* colp = F + (size_t)min(c, f - 1) * f;
+      const double* colp = Fc + (size_t)min(c, clim - 1) * f;      // (clamped inside the tile column: a pivot block never reads past its panel)
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int rr = rbase + 2 * l15 + 32 * h;
@@ -1083,7 +1088,7 @@ __device__ __forceinline__ void df_syrk_tiles(const DevPlan& P, int s, int j0, i
         for (int cg = 0; cg < NCG; ++cg) {
           const int c = cbase + cg * 4 + l4;
           if (c >= clim) continue;
-          double* colp = F + (size_t)c * f;
+          double* colp = Fc + (size_t)c * f;
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
             const int rr = rbase + 2 * l15 + 32 * h;
@@ -1106,8 +1111,132 @@ __device__ __forceinline__ void df_syrk_tiles(const DevPlan& P, int s, int j0, i
   // the ring's slots are reused by the next task of this workgroup: every wave is done reading them behind the caller's barrier
 }
 
+// ---- U on a MACRO tile (round 6): the tiles (i, j) and (i + 1, j), i > j, of one tile column in ONE pass --------------------------------
+// What bounds the single-tile loop above: not the matrix pipe (80 % of its issue rate) and not the operand stream (it arrives a chunk
+// ahead) but the LDS PIPE -- a wave reads 12 doubles (4 row fragments + 8 column fragments) per k-step of 32 MFMAs, eight waves, 4 cycles
+// per 64-lane b64 read: 384 of the 512 cycles the matrix pipe needs for the same k-step, bank conflicts (0.14) on top.  The register tile
+// per wave is what sets that ratio.  Here a wave owns 128 rows x 32 columns -- one whole row tile of the pair and a quarter of the tile
+// column: 8 + 8 fragments per 64 MFMAs, 256 LDS cycles per 512 -- with 64 accumulators (128 VGPRs; the worker has 256).  The operand ring
+// holds both W tiles and the L tile, 16 panel columns per slot (3 x 16 x 144 doubles, two slots: 108 KB).  Every entry receives its
+// products in ascending k as in the single-tile task: bitwise the same tiles.  The queue builder hands out pairs only while a front is
+// in its update-bound phase (dataflow_sched.cpp, OKKT_DF_ROWS_BIG / _MINKB / _AHEAD).
+constexpr int kMacroKC = 16;
+constexpr size_t kDfMacroLds = (size_t)2 * 3 * kMacroKC * kSyrkLd * sizeof(double);
+__device__ __forceinline__ void df_syrk_macro(const DevPlan& P, int s, int j0, int nb, int i, int j, int KB, int k, double* sm, long long* marks) {
+  constexpr int KC = kMacroKC, STAGES = 2;
+  constexpr int DMA = 3 * KC / 8;        // LDS-DMA instructions per wave and chunk (48 one-KiB rows over eight waves)
+  int tid_ = threadIdx.x;
+  asm volatile("" : "+v"(tid_));
+  const int tid = tid_, lane = tid & 63, wv = tid >> 6;
+  const int f = (int)(P.row_ptr[s + 1] - P.row_ptr[s]);
+  const int ct0 = df_block_lo(j, KB, k, f), clim = df_block_lo(j + 1, KB, k, f);
+  const int rt = wv & 1;                                   // the row tile of the pair this wave owns
+  const int cbase = ct0 + (wv >> 1) * 32;
+  const int rt0 = df_block_lo(i + rt, KB, k, f), rlim = df_block_lo(i + rt + 1, KB, k, f);
+  double* F = P.arena + P.front_pos[s];
+  double* Fc = F + (j >= KB ? P.cb_shift[s] : 0);
+  const double* Wcol = P.wbuf + P.wbuf_pos[s] + (size_t)j0 * f + lane * 2;
+  const double* Lg = F + (size_t)j0 * f + ct0 + lane * 2;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const int nchunk = (nb + KC - 1) / KC;
+  const int r0a = df_block_lo(i, KB, k, f), r0b = df_block_lo(i + 1, KB, k, f);
+  // slot layout: [3 arrays: W of tile i, W of tile i + 1, L][KC panel columns][kSyrkLd]
+  static_assert(KC == 16, "the request pattern below deals 48 rows to eight waves: rows wv and 8 + wv of each of the three arrays");
+  const double* wa = Wcol + r0a;
+  const double* wb = Wcol + r0b;
+  const double* zp = P.zero_page + lane * 2;
+  auto issue = [&](int g) {
+    double* slot = sm + (size_t)(g % STAGES) * 3 * KC * kSyrkLd;
+#pragma unroll
+    for (int qq = 0; qq < DMA; ++qq) {
+      const int prow = (qq & 1) * 8 + wv;                  // panel column inside the chunk; array qq / 2
+      const int p = g * KC + prow;
+      const double* base = qq < 2 ? wa : (qq < 4 ? wb : Lg);
+      const double* in = base + (size_t)min(p, nb - 1) * f;
+      const double* src = p < nb ? in : zp;
+      __builtin_amdgcn_global_load_lds(src, (lds_void_t*)(slot + (size_t)((qq >> 1) * KC + prow) * kSyrkLd), 16, 0, 0);
+    }
+  };
+  // the wave's C block: 128 rows x 32 columns, pairs of rows (2 l15 + 32 h, + 1), column cbase + 4 cg + l4 -- loaded straight into the
+  // accumulators (clamped addresses, no branches) and masked in place
+  d2_t acc[8][4];
+#pragma unroll
+  for (int cg = 0; cg < 8; ++cg) {
+    const int c = cbase + cg * 4 + l4;
+    const double* colp = Fc + (size_t)min(c, clim - 1) * f;
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      const int rr = rt0 + 2 * l15 + 32 * h;
+      __builtin_memcpy(&acc[cg][h], colp + min(rr, f - 2), 16);
+    }
+  }
+  asm volatile("" ::: "memory");
+#pragma unroll
+  for (int cg = 0; cg < 8; ++cg) {
+    const int c = cbase + cg * 4 + l4;
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      const int rr = rt0 + 2 * l15 + 32 * h;
+      const int shift = rr - min(rr, f - 2);      // 0 in the interior, 1 when rr is the last row, >= 2 outside
+      const double e0 = shift == 0 ? acc[cg][h][0] : acc[cg][h][1];
+      const double e1 = acc[cg][h][1];
+      acc[cg][h][0] = keep_f64(e0, rr < rlim && c < clim);
+      acc[cg][h][1] = keep_f64(e1, shift == 0 && rr + 1 < rlim && c < clim);
+    }
+  }
+  issue(0);
+  const bool active = rt0 < rlim && cbase < clim;
+  for (int g = 0; g < nchunk; ++g) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // chunk g has landed (the next one is requested behind the barrier)
+    __builtin_amdgcn_s_barrier();
+    if (marks && g == 0 && tid == 0) { marks[0] = wall_clock64(); marks[3] = -(long long)clock64(); }
+    const bool late = kDfStagger && wv >= 4;
+    const bool more = g + 1 < nchunk;
+    if (more && !late) issue(g + 1);
+    if (active) {
+      const double* slot = sm + (size_t)(g % STAGES) * 3 * KC * kSyrkLd;
+      const double* bw = slot + (size_t)rt * KC * kSyrkLd + 2 * l15;
+      const double* bl = slot + (size_t)2 * KC * kSyrkLd + (wv >> 1) * 32 + (lane & 3);
+#pragma unroll
+      for (int kk = 0; kk < KC / 4; ++kk) {
+        if (kk == KC / 8 && more && late) issue(g + 1);
+        double bv[8];
+#pragma unroll
+        for (int rb = 0; rb < 8; ++rb) bv[rb] = bw[(kk * 4 + l4) * kSyrkLd + (rb & 1) + 32 * (rb >> 1)];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          double av[4];
+#pragma unroll
+          for (int qq = 0; qq < 4; ++qq) av[qq] = bl[(kk * 4 + l4) * kSyrkLd + (half * 4 + qq) * 4];
+#pragma unroll
+          for (int qq = 0; qq < 4; ++qq)
+#pragma unroll
+            for (int rb = 0; rb < 8; ++rb)
+              acc[half * 4 + qq][rb >> 1][rb & 1] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[qq], bv[rb], acc[half * 4 + qq][rb >> 1][rb & 1], 0, 0, 1 /* neg A */);
+        }
+      }
+    } else if (more && late) issue(g + 1);
+  }
+  if (marks && tid == 0) { marks[1] = wall_clock64(); marks[3] += (long long)clock64(); }
+  if (active) {
+#pragma unroll
+    for (int cg = 0; cg < 8; ++cg) {
+      const int c = cbase + cg * 4 + l4;
+      if (c >= clim) continue;
+      double* colp = Fc + (size_t)c * f;
+#pragma unroll
+      for (int h = 0; h < 4; ++h) {
+        const int rr = rt0 + 2 * l15 + 32 * h;
+        if (rr + 1 < rlim) st_sc1_f64x2(colp + rr, acc[cg][h]);
+        else if (rr < rlim) st_agent_f64(colp + rr, acc[cg][h][0]);
+      }
+    }
+  }
+  if (marks && tid == 0) marks[2] = wall_clock64();
+}
+
 constexpr int kDfThreads = kDfThreadsC;
-constexpr size_t kDfLds = std::max(std::max(std::max(std::max(OKKT_DIAG2_LDS_DOUBLES(kMW) * sizeof(double), kDfTuLds), (size_t)kDfStages * 2 * kDfKC * kSyrkLd * sizeof(double)), kDfTlLds), std::max(kDfTuLockLds, (size_t)128 * kDfTileLd * sizeof(double)));   // diag2_body's and df_tu_tile's; the other roles need less
+constexpr size_t kDfLds = std::max(std::max(std::max(std::max(OKKT_DIAG2_LDS_DOUBLES(kMW) * sizeof(double), kDfTuLds), (size_t)kDfStages * 2 * kDfKC * kSyrkLd * sizeof(double)), kDfTlLds), std::max(std::max(kDfTuLockLds, kDfMacroLds), (size_t)128 * kDfTileLd * sizeof(double)));   // diag2_body's and df_tu_tile's; the other roles need less
 
 // counters[5] = a wait ran into its bound, three seconds of wall clock (or another worker's did): every worker leaves, the factorisation
 // fails with "a hand-off timed out" and the solves return NaN -- never numbers computed from tiles that had not arrived
@@ -1234,7 +1363,11 @@ __global__ __launch_bounds__(kDfThreads, 1) void k_front_dataflow(DevPlan P, con
       }
     } else {
       const int j0 = q0 * 128;
-      if (!(dbg & 4)) df_syrk_tiles<kDfKC, kDfStages, true, kDfStagger>(P, s, j0, min(nq * 128, k - j0), i, rows, j, KB, k, sm, tlog ? tlog + (size_t)t * 8 + 4 : nullptr);
+      // a pair of row tiles below the diagonal tile: one macro tile (a wave owns 128 x 32 of it); everything else tile by tile
+      if (!(dbg & 4)) {
+        if (kDfMacro && rows == 2 && i > j && P.df_macro) df_syrk_macro(P, s, j0, min(nq * 128, k - j0), i, j, KB, k, sm, tlog ? tlog + (size_t)t * 8 + 4 : nullptr);
+        else df_syrk_tiles<kDfKC, kDfStages, true, kDfStagger>(P, s, j0, min(nq * 128, k - j0), i, rows, j, KB, k, sm, tlog ? tlog + (size_t)t * 8 + 4 : nullptr);
+      }
       mine = st + (size_t)i * TB + j; newv = q0 + nq; npub = rows;
     }
     // the next queue position is requested now: the atomic's round trip (1 us) runs beside the drain of this task's stores
@@ -1271,6 +1404,7 @@ std::string df_setup(Numeric& N) {
   N.df_fuse_d = getenv("OKKT_DF_FUSE_D") ? atoi(getenv("OKKT_DF_FUSE_D")) : 1;
   N.df_split_tu = getenv("OKKT_DF_SPLIT_TU") ? atoi(getenv("OKKT_DF_SPLIT_TU")) : 1;
   N.df_fuse_tl = getenv("OKKT_DF_FUSE_TL") ? atoi(getenv("OKKT_DF_FUSE_TL")) : 1;
+  d.df_macro = getenv("OKKT_DF_MACRO") ? atoi(getenv("OKKT_DF_MACRO")) : 1;
   // OFF by default: built, bitwise equal, and slower (72 us between two diagonal blocks instead of 60) -- the tiles TU(q + 1) starts from arrive
   // through D(q) -> T / TL(q + 2, q) -> the lone last-panel updates of (q + 2, q + 1) and (q + 2, q + 2) about when D(q + 1) ENDS, so the
   // follower has nothing to follow and runs its four block steps (9 us each with its own inversions) behind D(q + 1); DESIGN.md section 4

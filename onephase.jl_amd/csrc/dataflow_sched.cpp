@@ -126,7 +126,24 @@ void df_build_queue(const std::vector<DfFront>& fronts, int workers, int group, 
       for (int c = 0; c < ng; ++c) {
         const int q0 = gs[c], nq = gs[c + 1] - gs[c];
         const bool lone_last = j < KB && c + 1 == ng;
-        const int R = (j < KB && c + kLonePanels >= ng) ? 1 : RT;
+        // Row tiles per bulk task.  Two row tiles per task cost 17 % less per tile (one pop, one wait, one drain; the next C tile in
+        // flight) and lost it all in the schedule when every bulk task carried them (round 4: 19.5 ms against 18.85) or the tasks far
+        // from the diagonal did (round 5: 17.0 - 17.8 against 16.8): coarser tasks starve the tails.  Round 6 gates it in TIME, not in
+        // space: the tasks of a panel group carry `rows_big` tiles only while the front still has `rows_ahead` block columns to go
+        // behind the group and is long enough to have an update-bound phase at all (`rows_minkb` pivot blocks) -- the 96 %-busy phase of
+        // the metric workload's root and of the front below it; every tail keeps single tiles.
+        static const int rows_big = getenv("OKKT_DF_ROWS_BIG") ? std::max(1, std::min(atoi(getenv("OKKT_DF_ROWS_BIG")), 8)) : 1;
+        static const int rows_minkb = getenv("OKKT_DF_ROWS_MINKB") ? atoi(getenv("OKKT_DF_ROWS_MINKB")) : 32;
+        static const int rows_ahead = getenv("OKKT_DF_ROWS_AHEAD") ? atoi(getenv("OKKT_DF_ROWS_AHEAD")) : 24;
+        // ... and in SPACE, by the distance of the tile column from the group's last panel: the chain reaches column j that many
+        // steps later, and a task that feeds it must be done by then -- a pair of tiles takes 157 us where one takes 88, and the pairs
+        // next to the panel made the chain wait (103 us per block column in a phase where half the workers were idle; task log of the
+        // metric workload's root).  The contribution block's columns (j >= KB) are nobody's input inside this launch.
+        static const int rows_coldist = getenv("OKKT_DF_ROWS_COLDIST") ? atoi(getenv("OKKT_DF_ROWS_COLDIST")) : 4;
+        const int q_last = gs[c + 1] - 1;                                   // last panel of the group
+        const bool far = j >= KB || j - q_last >= rows_coldist;
+        const int RG = (rows_big > 1 && far && KB >= rows_minkb && KB - 1 - q_last >= rows_ahead) ? std::max(RT, rows_big) : RT;
+        const int R = (j < KB && c + kLonePanels >= ng) ? 1 : RG;
         for (int i = j; i < TB;) {
           const int rows = i == j ? 1 : std::min(R, TB - i);
           const bool in_tu = i == j && lone_last;                  // the last panel of a diagonal pivot tile: part of TU(j - 1)

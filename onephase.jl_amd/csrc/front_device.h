@@ -26,6 +26,10 @@ __device__ __forceinline__ double keep_f64(double v, bool keep) {
   return __longlong_as_double(__double_as_longlong(v) & (keep ? -1ll : 0ll));
 }
 
+// offset to add to F + c * f for column c of front s: zero for a pivot column, the front's shift into the shared contribution-block
+// region otherwise (numeric.h, DevPlan::cb_shift)
+__device__ __forceinline__ int64_t cb_off(const DevPlan& P, int s, int c, int k) { return c >= k ? P.cb_shift[s] : 0; }
+
 __device__ __forceinline__ unsigned wave_sum(unsigned v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
   return v;

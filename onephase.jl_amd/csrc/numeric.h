@@ -24,6 +24,11 @@ struct DevPlan {
   int64_t* row_ptr = nullptr;
   int* rows = nullptr;
   int64_t* front_pos = nullptr;
+  // Contribution blocks released (round 6): front_pos[s] is the base of the front's L PANEL (f rows x k columns, leading dimension f);
+  // column c >= k of the front lives at front_pos[s] + c * f + cb_shift[s] -- in a region that fronts with disjoint lifetimes share
+  // (numeric_setup: a block lives from its front's level to its parent's).  All zeros when the release is off (partitioned plans): the
+  // front is then the dense f x f buffer of rounds 1 - 5.
+  int64_t* cb_shift = nullptr;
   int64_t* child_ptr = nullptr;
   int* children = nullptr;
   int64_t* rel_ptr = nullptr;
@@ -89,6 +94,7 @@ struct DevPlan {
   double* zero_page = nullptr;  // 2 KiB of zeros (source of out-of-panel LDS-DMA rows)
   // dataflow factorisation of the big fronts (dataflow.hip): per tile (i, j) of a big front's 128-block grid the number of tasks that
   // have been applied to it (updates, then the factorisation of the tile itself), TB x TB ints per front
+  int df_macro = 1;                  // update tasks on pairs of row tiles run as one macro tile (dataflow.hip, df_syrk_macro; OKKT_DF_MACRO=0: tile after tile)
   int* df_state = nullptr;
   int64_t* df_state_pos = nullptr;   // [nsuper] offset of the front's states, -1 for small fronts
 };
@@ -197,6 +203,10 @@ struct Numeric {
   int df_group = 4;                    // panels per update task (K = 128 * group) where the column allows it (OKKT_DF_GROUP; S-metric 19.1 / 18.3 / 18.2 ms at 2 / 3 / 4)
   int df_fuse_d = 1;                   // D(q + 1) in the task of TU(q): the diagonal tile passes through LDS (OKKT_DF_FUSE_D=0: a task of its own)
   int df_split_tu = 1;                 // block rows of more than 64 rows: TU(q) as two tasks on two workers, TA(q) (upper 64 rows) and TU(q) (OKKT_DF_SPLIT_TU=0: one)
+  std::vector<int64_t> front_pos_host;     // the device plan's front_pos (panel bases)
+  int64_t arena_doubles = 0;               // doubles of the front arena as allocated (panels + the shared contribution-block region)
+  int64_t cb_region_doubles = 0;           // ... of which the contribution-block region
+  int release_cb = 1;                      // OKKT_RELEASE_CB (0: every front keeps its f x f buffer for the plan's lifetime)
   int df_lockstep = 0;                 // TU(q) in lockstep with the 32-column blocks of D(q) (df_tu_lock; OKKT_DF_LOCKSTEP=0: the split TA / TU of rounds 4 - 5 behind the whole of D(q))
   int df_fuse_tl = 1;                  // T(i, q) with the last update of its tile inside the task (TL), q >= 1 (OKKT_DF_FUSE_TL=0: separate tasks)
   int df_rows = 1;                     // row tiles per bulk update task (OKKT_DF_ROWS; 2 and 4 measured slower: the coarser tasks cost the schedule more than the shared prologue saves)

@@ -15,6 +15,7 @@
 // adds the children's contribution blocks in a fixed order -- no floating-point atomics.
 #include "numeric.h"
 #include "front_device.h"
+#include <map>
 
 #include <algorithm>
 #include <cmath>
@@ -145,7 +146,7 @@ __global__ __launch_bounds__(TPB) void k_front_small(DevPlan P, const int* __res
     const int kc = P.sn_col0[c + 1] - P.sn_col0[c];
     const int fc = (int)(P.row_ptr[c + 1] - P.row_ptr[c]);
     const int rc = fc - kc;
-    const double* C = P.arena + P.front_pos[c];
+    const double* C = P.arena + P.front_pos[c] + P.cb_shift[c];      // only the child's contribution block (columns >= kc) is read
     const int* rl = P.rel + P.rel_ptr[c];
     if (FLOW && c < t_lo) flow_wait(flags + c, wait_epoch, P.counters);      // a child task of this launch (workgroup-uniform)
     for (int jj = grp; jj < rc; jj += G) {
@@ -158,7 +159,7 @@ __global__ __launch_bounds__(TPB) void k_front_small(DevPlan P, const int* __res
   ldl_partial_lds<TPB>(F, wcol, ldf, f, k);
   // write back: L panel (rows >= col), contribution block (lower), D, inertia counts
   for (int c = grp; c < f; c += G) {
-    double* dst = front + (size_t)c * f;
+    double* dst = front + (size_t)c * f + cb_off(P, s, c, k);
     if (FLOW && c >= k) { for (int i = c + lane; i < f; i += 32) flow_st(dst + i, F[i + c * ldf]); }
     else for (int i = c + lane; i < f; i += 32) dst[i] = F[i + c * ldf];
   }
@@ -315,7 +316,7 @@ __global__ __launch_bounds__(256) void k_big_assemble(DevPlan P, const int* __re
   const int f = (int)(P.row_ptr[s + 1] - P.row_ptr[s]);
   const int pc = blockIdx.x * 4 + wv;
   if (pc >= f) return;
-  double* col = P.arena + P.front_pos[s] + (size_t)pc * f + pc;   // first row of the lower triangle: (pc, pc)
+  double* col = P.arena + P.front_pos[s] + (size_t)pc * f + pc + cb_off(P, s, pc, k);   // first row of the lower triangle: (pc, pc)
   const int nrow = f - pc;
   if (nrow <= lcol) {
     double* buf = sm + (size_t)wv * lcol;
@@ -422,7 +423,7 @@ __global__ __launch_bounds__(256) void k_big_assemble_chunked(DevPlan P, const i
       }
     }
   }
-  double* col = P.arena + P.front_pos[s] + (size_t)pc * f + r0;
+  double* col = P.arena + P.front_pos[s] + (size_t)pc * f + r0 + cb_off(P, s, pc, k);
   for (int i = lane; i < n; i += 64) col[i] = base[i];
 }
 
@@ -850,6 +851,7 @@ __global__ __launch_bounds__(kSyrkNW * 64, kSyrkNW / 2) void k_big_syrk(DevPlan 
   const int cbase = ct0 + (wv >> 1) * WCW;
   const bool active = !(rbase + 63 < cbase) && rbase < f && cbase < climit;
   double* F = P.arena + P.front_pos[s];
+  const int kfront = P.sn_col0[s + 1] - P.sn_col0[s];      // columns from here on live in the shared contribution-block region (cb_off)
   const double* Wg = P.wbuf + P.wbuf_pos[s] + (size_t)wofs * f + rt0 + lane * 2;
   const double* Lg = F + (size_t)j0 * f + ct0 + lane * 2;
   const int l15 = lane & 15, l4 = lane >> 4;
@@ -881,7 +883,7 @@ __global__ __launch_bounds__(kSyrkNW * 64, kSyrkNW / 2) void k_big_syrk(DevPlan 
 #pragma unroll
   for (int cg = 0; cg < NCG; ++cg) {
     const int c = cbase + cg * 4 + l4;
-    const double* colp = F + (size_t)min(c, f - 1) * f;
+    const double* colp = F + (size_t)min(c, f - 1) * f + cb_off(P, s, min(c, f - 1), kfront);
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int r = rbase + 2 * l15 + 32 * h;
@@ -946,7 +948,7 @@ __global__ __launch_bounds__(kSyrkNW * 64, kSyrkNW / 2) void k_big_syrk(DevPlan 
   for (int cg = 0; cg < NCG; ++cg) {
     const int c = cbase + cg * 4 + l4;
     if (c >= climit) continue;
-    double* colp = F + (size_t)c * f;
+    double* colp = F + (size_t)c * f + cb_off(P, s, c, kfront);
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int r = rbase + 2 * l15 + 32 * h;
@@ -1046,7 +1048,6 @@ std::string numeric_setup(const Symbolic& S, const SymbolicOptions& opts, hipStr
   UP(sn_col0, S.sn_col0);
   UP(row_ptr, S.row_ptr);
   UP(rows, S.rows);
-  UP(front_pos, S.front_pos);
   UP(child_ptr, S.child_ptr);
   UP(children, S.children);
   UP(rel_ptr, S.rel_ptr);
@@ -1163,6 +1164,20 @@ std::string numeric_setup(const Symbolic& S, const SymbolicOptions& opts, hipStr
         int c = f <= 32 ? 0 : (f <= 64 ? 1 : (f <= N.small_max ? 2 : 3));
         cls[c].push_back(s);
       }
+      // A level that holds big fronts AND a handful of lone mid-size fronts (33 .. small_max rows, one front per unit) ran those in a
+      // launch of their own in front of the big fronts' assembly, and in two more launches per solve: the metric workload has exactly
+      // one such front -- 67 us of the factorisation's critical path and 21 + 19 us of every solve for one workgroup.  They join the big
+      // fronts of their level instead (round-5 review, item 3a): a front of 33 .. 128 rows is one or two tiles of the dataflow launch and
+      // a "thin" front of the solves.  OKKT_FOLD_LONE = how many such fronts a level may hold for the rule to apply (0: never).
+      static const int fold_lone = getenv("OKKT_FOLD_LONE") ? atoi(getenv("OKKT_FOLD_LONE")) : 3;
+      if (fold_lone > 0 && !cls[3].empty() && !cls[1].empty() + !cls[2].empty() > 0 && (int)(cls[1].size() + cls[2].size()) <= fold_lone) {
+        for (int c = 1; c <= 2; ++c) {
+          std::vector<int> keep;
+          for (int s : cls[c]) (task_lo[s] == s ? cls[3] : keep).push_back(s);
+          cls[c].swap(keep);
+        }
+      }
+      if (getenv("OKKT_DEBUG_FRONTS")) fprintf(stderr, "okkt: level %d units by class: %zu (<= 32) %zu (<= 64) %zu (<= small_max) %zu (big)\n", l, cls[0].size(), cls[1].size(), cls[2].size(), cls[3].size());
       for (int c = 0; c < kNumClasses; ++c) {
         auto& v = cls[c];
         // longest tasks first (they finish last), then larger fronts first
@@ -1229,6 +1244,88 @@ std::string numeric_setup(const Symbolic& S, const SymbolicOptions& opts, hipStr
     if (!(e = upload(N, unit_parent, &d.unit_parent)).empty()) return e;
   }
   if (getenv("OKKT_DEBUG_FRONTS")) fprintf(stderr, "okkt: %d levels of units (%d levels of fronts), %lld tasks of small fronts, longest %d\n", nulev, S.nlevels, (long long)N.n_tasks, N.max_task_len);
+  // ---- front arena (round 6: contribution blocks released).  Rounds 1 - 5 gave every front a dense f x f buffer for the plan's lifetime
+  // ("sized for 288 GB"): 11.8 GB for the 0.86 GB factor of the metric workload, so that a ten times larger system of the same family
+  // did not fit one GPU.  Only the L panel (f x k) has to stay -- the solves read it; the r x r contribution block is dead once the parent
+  // front has been assembled.  The panels are laid out one after the other; a contribution block (stored as the r trailing columns of the
+  // front WITH the front's leading dimension, so that every kernel keeps addressing column c at F + c f) gets a place in a shared region
+  // from a lifetime-aware first-fit allocator run over the schedule: alive from the epoch of its front to the epoch of its parent --
+  // an epoch being one level of units, except that the leading levels that run as ONE launch (flow levels) are one epoch: a task of
+  // that launch starts as soon as its own children are done, whatever the rest of its level is doing.
+  // Partitioned plans keep the f x f buffers (boundary blocks cross the local / top schedules and the exchange kernels).
+  N.release_cb = getenv("OKKT_RELEASE_CB") ? atoi(getenv("OKKT_RELEASE_CB")) : 1;
+  if (parted) N.release_cb = 0;
+  std::vector<int64_t> fpos(ns + 1, 0), cbshift(ns, 0);
+  if (!N.release_cb) {
+    for (int s2 = 0; s2 <= ns; ++s2) fpos[s2] = S.front_pos[s2];
+    N.arena_doubles = S.arena_doubles;
+    N.cb_region_doubles = 0;
+  } else {
+    for (int s2 = 0; s2 < ns; ++s2) {
+      const int64_t f = S.row_ptr[s2 + 1] - S.row_ptr[s2], k = S.sn_col0[s2 + 1] - S.sn_col0[s2];
+      fpos[s2 + 1] = fpos[s2] + ((f * k + 1) & ~(int64_t)1);      // even: 16-byte pairs stay aligned where they were
+    }
+    const int64_t panels = fpos[ns];
+    auto epoch_of = [&](int s2) { const int l = ulevel[unit_root[s2]]; return l < N.flow_levels ? 0 : l - std::max(N.flow_levels, 1) + 1; };
+    const int nep = std::max(1, nulev - std::max(N.flow_levels, 1) + 1) + 1;
+    std::vector<std::vector<int>> born(nep), dies(nep);
+    for (int s2 = 0; s2 < ns; ++s2) {
+      const int64_t f = S.row_ptr[s2 + 1] - S.row_ptr[s2], k = S.sn_col0[s2 + 1] - S.sn_col0[s2];
+      if (f == k) continue;
+      const int p2 = S.sn_parent[s2];
+      born[epoch_of(s2)].push_back(s2);
+      dies[p2 >= 0 ? epoch_of(p2) : nep - 1].push_back(s2);
+    }
+    // free list: offset -> size, coalesced; best fit
+    std::map<int64_t, int64_t> freeb;
+    int64_t top = 0;
+    std::vector<int64_t> cbo(ns, -1), cbsz(ns, 0);
+    auto release = [&](int64_t off, int64_t sz) {
+      auto it = freeb.emplace(off, sz).first;
+      auto nx = std::next(it);
+      if (nx != freeb.end() && it->first + it->second == nx->first) { it->second += nx->second; freeb.erase(nx); }
+      if (it != freeb.begin()) { auto pv = std::prev(it); if (pv->first + pv->second == it->first) { pv->second += it->second; freeb.erase(it); it = pv; } }
+      if (it->first + it->second == top) { top = it->first; freeb.erase(it); }
+    };
+    for (int ep = 0; ep < nep; ++ep) {
+      std::vector<int>& v = born[ep];
+      std::stable_sort(v.begin(), v.end(), [&](int a, int b) {
+        const int64_t fa = S.row_ptr[a + 1] - S.row_ptr[a], fb = S.row_ptr[b + 1] - S.row_ptr[b];
+        const int64_t sa = fa * (fa - (S.sn_col0[a + 1] - S.sn_col0[a])), sb = fb * (fb - (S.sn_col0[b + 1] - S.sn_col0[b]));
+        return sa > sb;
+      });
+      for (int s2 : v) {
+        const int64_t f = S.row_ptr[s2 + 1] - S.row_ptr[s2], k = S.sn_col0[s2 + 1] - S.sn_col0[s2];
+        const int64_t sz = ((f - k) * f + 1) & ~(int64_t)1;
+        auto best = freeb.end();
+        for (auto it = freeb.begin(); it != freeb.end(); ++it)
+          if (it->second >= sz && (best == freeb.end() || it->second < best->second)) best = it;
+        int64_t off;
+        if (best != freeb.end()) {
+          off = best->first;
+          const int64_t rest = best->second - sz;
+          freeb.erase(best);
+          if (rest > 0) freeb.emplace(off + sz, rest);
+        } else { off = top; top += sz; }
+        cbo[s2] = off; cbsz[s2] = sz;
+      }
+      for (int s2 : dies[ep]) if (cbo[s2] >= 0) release(cbo[s2], cbsz[s2]);
+    }
+    int64_t region = 0;
+    for (int s2 = 0; s2 < ns; ++s2) if (cbo[s2] >= 0) region = std::max(region, cbo[s2] + cbsz[s2]);
+    for (int s2 = 0; s2 < ns; ++s2) {
+      if (cbo[s2] < 0) continue;
+      const int64_t f = S.row_ptr[s2 + 1] - S.row_ptr[s2], k = S.sn_col0[s2 + 1] - S.sn_col0[s2];
+      cbshift[s2] = (panels + cbo[s2]) - (fpos[s2] + k * f);
+    }
+    N.arena_doubles = panels + region;
+    N.cb_region_doubles = region;
+    if (getenv("OKKT_DEBUG_FRONTS")) fprintf(stderr, "okkt: front arena %.3f GB (panels %.3f, shared contribution-block region %.3f) instead of %.3f GB of f x f buffers\n",
+                                            N.arena_doubles * 8e-9, panels * 8e-9, region * 8e-9, S.arena_doubles * 8e-9);
+  }
+  N.front_pos_host = fpos;
+  if (!(e = upload(N, fpos, &d.front_pos)).empty()) return e;
+  if (!(e = upload(N, cbshift, &d.cb_shift)).empty()) return e;
   for (int s2 = 0; s2 < ns; ++s2) if (wpos[s2] >= 0 && wparity[s2]) wpos[s2] += wregion[0];
   const int64_t wtotal = wregion[0] + wregion[1];
   if (!(e = upload(N, wpos, &d.wbuf_pos)).empty()) return e;
@@ -1318,7 +1415,7 @@ std::string numeric_setup(const Symbolic& S, const SymbolicOptions& opts, hipStr
           ea_rc[slot] = (int)(fc - kc);
           ea_rel[slot] = S.rel_ptr[c];
           ea_cut[slot] = cut_pos[c];
-          ea_src[slot] = S.front_pos[c] + (kc + ea_jj[slot]) * fc + kc;   // arena offset of the child's CB column, row 0 of the CB
+          ea_src[slot] = fpos[c] + cbshift[c] + (kc + ea_jj[slot]) * fc + kc;   // arena offset of the child's CB column, row 0 of the CB
         }
       }
     }
@@ -1344,7 +1441,8 @@ std::string numeric_setup(const Symbolic& S, const SymbolicOptions& opts, hipStr
     // zero-filled once: the parts of a block beyond a front's last pivot column are never written and are read as zeros
     if (!(e = dalloc(N, (size_t)invl_total, &d.invl, true)).empty()) return e;
   }
-  if (!(e = dalloc(N, (size_t)S.arena_doubles + 512, &d.arena, false)).empty()) return e;
+  // (+ a tail of slack: loads on clamped addresses stay inside the allocation whatever a masked lane computes)
+  if (!(e = dalloc(N, (size_t)N.arena_doubles + 512 + (size_t)S.max_front * 2, &d.arena, false)).empty()) return e;
   if (!(e = dalloc(N, (size_t)S.n, &d.dvals, true)).empty()) return e;
   if (!(e = dalloc(N, (size_t)S.n, &d.diagadd, true)).empty()) return e;
   // kMaxRhs right-hand sides travel through the sweeps together (solve.hip)
@@ -1854,7 +1952,7 @@ __global__ void k_pack_cb(DevPlan P, const int* __restrict__ bnd, const int64_t*
   const int k = P.sn_col0[s + 1] - P.sn_col0[s];
   const int f = (int)(P.row_ptr[s + 1] - P.row_ptr[s]);
   const int r = f - k;
-  double* F = P.arena + P.front_pos[s] + (size_t)k * f + k;
+  double* F = P.arena + P.front_pos[s] + (size_t)k * f + k + P.cb_shift[s];
   double* B = buf + off[blockIdx.x];
   for (int64_t idx = threadIdx.x; idx < (int64_t)r * r; idx += blockDim.x) {
     const int j = (int)(idx / r), i = (int)(idx - (int64_t)j * r);

@@ -20,6 +20,9 @@ CONFIGS = {
     # the small one is what the scalar oracle affords in a test
     "S-C3-random": dict(n=10_000, m=20_000, j_per_row=20, h_per_col=8, p_far=1.0),
     "S-C3-random-small": dict(n=1_000, m=2_000, j_per_row=20, h_per_col=8, p_far=1.0),
+    # the metric family at four times the size (n + m = 4e5; the largest front stays below the 46 000 rows the 32-bit local offsets allow): what the release of the contribution blocks (round 6) is for -- with an
+    # f x f buffer per front the arena of this instance does not fit one GPU
+    "S-metric-4x": dict(n=160_000, m=240_000, j_per_row=24, h_per_col=10),
     "S-small": dict(n=400, m=600, j_per_row=6, h_per_col=4),
     "S-tiny": dict(n=40, m=60, j_per_row=4, h_per_col=3),
 }

@@ -40,6 +40,7 @@ def test_dataflow_equals_the_per_step_launches_bit_for_bit(case, tmp_path):
                                  {"OKKT_DF_WORKERS": "7"}, {"OKKT_DF_WORKERS": "64", "OKKT_DF_MODEL_CHAIN": "2.0"}, {"OKKT_DF_SPLIT_TU": "0"},
                                  {"OKKT_DF_SPLIT_TU": "0", "OKKT_DF_FUSE_D": "0"}, {"OKKT_DF_FUSE_D": "0"},
                                  {"OKKT_DF_FUSE_TL": "0"}, {"OKKT_DF_FUSE_TL": "0", "OKKT_DF_FUSE_D": "0", "OKKT_DF_GROUP": "2"},
+                                 {"OKKT_DF_ROWS_BIG": "2", "OKKT_DF_ROWS_MINKB": "8", "OKKT_DF_ROWS_AHEAD": "4"}, {"OKKT_DF_ROWS_BIG": "4", "OKKT_DF_ROWS_MINKB": "4", "OKKT_DF_ROWS_AHEAD": "1", "OKKT_DF_GROUP": "2"},
                                  {"OKKT_DF_LOCKSTEP": "1"}, {"OKKT_DF_LOCKSTEP": "1", "OKKT_DF_WORKERS": "5"}, {"OKKT_DF_LOCKSTEP": "1", "OKKT_DF_FUSE_D": "0"}],
                          ids=lambda e: ",".join(f"{k[8:]}={v}" for k, v in e.items()))
 def test_every_queue_shape_gives_the_same_factor(env, tmp_path):
@@ -51,6 +52,16 @@ def test_every_queue_shape_gives_the_same_factor(env, tmp_path):
     e = {"OKKT_DATAFLOW": "1"}
     e.update(env)
     b = run_case("dense2600", e, tmp_path, "variant")
+    assert np.array_equal(a["d"], b["d"]) and np.array_equal(a["Ldata"], b["Ldata"]) and np.array_equal(a["x"], b["x"])
+
+
+def test_released_contribution_blocks_give_the_same_factor(tmp_path):
+    """Round 6: the fronts' contribution blocks share a region of the arena by lifetime (numeric_setup) instead of living in an f x f
+    buffer per front; OKKT_RELEASE_CB=0 keeps the buffers of rounds 1 - 5.  Same arithmetic, other addresses: bit for bit the same factor
+    on BASELINE config 3 (every front shape of a real elimination tree, small-front tasks and big fronts)."""
+    a = run_case("S-C3", {"OKKT_RELEASE_CB": "0"}, tmp_path, "dense_buffers")
+    b = run_case("S-C3", {"OKKT_RELEASE_CB": "1"}, tmp_path, "released")
+    assert int(a["rc"]) == 1 and int(b["rc"]) == 1
     assert np.array_equal(a["d"], b["d"]) and np.array_equal(a["Ldata"], b["Ldata"]) and np.array_equal(a["x"], b["x"])
 
 
