@@ -1090,14 +1090,17 @@ std::string numeric_setup(const Symbolic& S, const SymbolicOptions& opts, hipStr
   const double task_abs = getenv("OKKT_TASK_ABS") ? atof(getenv("OKKT_TASK_ABS")) : (level_nd ? 12.0 : 48.0);
   const double task_ratio = getenv("OKKT_TASK_RATIO") ? atof(getenv("OKKT_TASK_RATIO")) : (level_nd ? 1.1 : 1.5);
   std::vector<int> task_lo(ns), unit_root(ns), ulevel(ns, 0);
-  {
-    auto fof = [&](int s2) { return (int)(S.row_ptr[s2 + 1] - S.row_ptr[s2]); };
+  auto fof = [&](int s2) { return (int)(S.row_ptr[s2 + 1] - S.row_ptr[s2]); };
+  // forbid[s]: front s is a unit of its own (neither the root nor a member of a multi-front task); see the second pass below
+  std::vector<char> forbid(ns, 0);
+  auto form_units = [&]() {
+    std::fill(ulevel.begin(), ulevel.end(), 0);
     std::vector<char> allsmall(ns), assigned(ns, 0);
     std::vector<int> first(ns);
     std::vector<double> ctot(ns), cpath(ns), cmaxchild(ns, 0.0);
     for (int s2 = 0; s2 < ns; ++s2) {
       const int f = fof(s2), k = S.sn_col0[s2 + 1] - S.sn_col0[s2];
-      allsmall[s2] = f <= N.small_max;
+      allsmall[s2] = f <= N.small_max && !forbid[s2];
       first[s2] = s2;
       ctot[s2] = 1.0 + (double)f * f * k / 8192.0;
       cpath[s2] = ctot[s2];
@@ -1125,6 +1128,34 @@ std::string numeric_setup(const Symbolic& S, const SymbolicOptions& opts, hipStr
       if (p2 < 0 || unit_root[p2] == unit_root[s2]) continue;
       ulevel[unit_root[p2]] = std::max(ulevel[unit_root[p2]], ulevel[unit_root[s2]] + 1);
     }
+  };
+  form_units();
+  {
+    // Second pass (round 6).  A level WITHOUT big fronts whose tasks are nearly all one-wave tasks (fronts of at most 32 rows) but for
+    // a handful with a mid-size front ran that handful in launches of its own -- one 256-thread workgroup for 67 us of the
+    // factorisation's critical path and 21 + 19 us of every solve at the metric size (53 869 one-wave tasks and ONE task with a
+    // front of 65 .. 128 rows in level 0).  Those mid-size fronts become units of their own: they move up to the level above their
+    // children, where the rule in build() below lets them join the big fronts of that level; what is left of their subtrees is
+    // one-wave tasks like everything around it.
+    static const int lone_max = getenv("OKKT_FOLD_LONE") ? atoi(getenv("OKKT_FOLD_LONE")) : 3;
+    int nl = 0;
+    for (int s2 = 0; s2 < ns; ++s2) if (unit_root[s2] == s2) nl = std::max(nl, ulevel[s2] + 1);
+    std::vector<int> nbig(nl, 0), nmid(nl, 0), nwave(nl, 0);
+    auto unit_maxf = [&](int s2) { int f = 0; for (int t = task_lo[s2]; t <= s2; ++t) f = std::max(f, fof(t)); return f; };
+    for (int s2 = 0; s2 < ns; ++s2) {
+      if (unit_root[s2] != s2) continue;
+      const int f = unit_maxf(s2);
+      ++(f <= 32 ? nwave : (f <= N.small_max ? nmid : nbig))[ulevel[s2]];
+    }
+    bool any = false;
+    if (lone_max > 0 && use_tasks && !parted)
+      for (int s2 = 0; s2 < ns; ++s2) {
+        if (unit_root[s2] != s2) continue;
+        const int l = ulevel[s2];
+        if (nbig[l] != 0 || nmid[l] == 0 || nmid[l] > lone_max || nwave[l] < 64 || unit_maxf(s2) <= 32) continue;
+        for (int t = task_lo[s2]; t <= s2; ++t) if (fof(t) > 32) { forbid[t] = 1; any = true; }
+      }
+    if (any) form_units();
   }
   int nulev = 0;
   for (int s2 = 0; s2 < ns; ++s2) if (unit_root[s2] == s2) nulev = std::max(nulev, ulevel[s2] + 1);
