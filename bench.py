@@ -207,7 +207,7 @@ def main():
         # (scripts/profile_bench.sh; FETCH_SIZE doubled as the MI355X guide prescribes for 16-byte-per-lane streams):
         # counters cannot be read from inside the timed process, so the committed summary of the latest round is quoted
         traffic = None
-        for name in ("r05_dataflow_pmc.json", "r04_dataflow_pmc.json",):
+        for name in ("r06_dataflow_pmc.json", "r05_dataflow_pmc.json", "r04_dataflow_pmc.json",):
             pmc = os.path.join(ROOT, "profiles", name)
             if os.path.exists(pmc):
                 try:
@@ -274,10 +274,10 @@ def main():
             live, detail = live_traffic(args.config)
             if live is not None:
                 out["roofline"]["traffic"] = live
-            detail.setdefault("source", "committed summary profiles/r05_dataflow_pmc.json (live passes failed)")
+            detail.setdefault("source", "committed summary profiles/r06_dataflow_pmc.json (live passes failed)")
             out["roofline"]["traffic_detail"] = detail
         else:
-            out["roofline"]["traffic_detail"] = {"source": "committed summary profiles/r05_dataflow_pmc.json (scripts/profile_r05.sh)"}
+            out["roofline"]["traffic_detail"] = {"source": "committed summary profiles/r06_dataflow_pmc.json (scripts/profile_r06.sh)"}
         if world == 1 and not args.no_kkt_level:
             out["config"]["kkt_level"] = kkt_level_breakdown(prob, local_rank)
         if world == 1 and not args.no_sharded_model:
