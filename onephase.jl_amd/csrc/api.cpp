@@ -39,13 +39,13 @@ int solver_ensure_numeric(okkt_solver_s* h) {
   if (const char* fl = getenv("OKKT_FLOW")) h->N.flow = atoi(fl);   // read by the set-up
   if (const char* df = getenv("OKKT_DATAFLOW")) h->N.dataflow = atoi(df);
   if (const char* sf = getenv("OKKT_SOLVE_FLOW")) h->N.solve_flow = atoi(sf);   // read by the set-up (it sizes the partial-product buffers)
+  if (const char* sw = getenv("OKKT_SOLVE_FUSE_WIDE_MAX")) h->N.solve_fuse_wide_max = atoi(sw);   // read by the set-up (the experiment keeps the explicit inverses for every front)
   std::string e = numeric_setup(h->S, h->sopts, h->stream, h->N);
   if (const char* sh = getenv("OKKT_SPLIT_HEAD")) h->N.split_head = atoi(sh);
   if (const char* d2 = getenv("OKKT_DIAG2")) h->N.diag2 = atoi(d2);
   if (const char* fd = getenv("OKKT_FUSE_DIAG_TRSM")) h->N.fuse_diag_trsm = atoi(fd);
   if (const char* ss = getenv("OKKT_SOLVE_SPLIT_SMALL")) h->N.solve_split_small = atoi(ss);
   if (const char* su = getenv("OKKT_SOLVE_FUSE")) h->N.solve_fuse = atoi(su);
-  if (const char* sw = getenv("OKKT_SOLVE_FUSE_WIDE_MAX")) h->N.solve_fuse_wide_max = atoi(sw);
   if (const char* mt = getenv("OKKT_LA_MIN_TILES")) h->N.la_min_tiles = atoi(mt);
   if (!e.empty()) { numeric_release(h->N); return solver_set_error(h, OKKT_ERR_HIP, e); }
   h->numeric_ready = true;

@@ -52,6 +52,10 @@ constexpr bool kDfProg = OKKT_DF_PROG != 0;   // round 6: the diagonal block rep
 #ifndef OKKT_DF_MACRO
 #define OKKT_DF_MACRO 1
 #endif
+#ifndef OKKT_DF_ROT
+#define OKKT_DF_ROT 0
+#endif
+constexpr bool kDfRot = OKKT_DF_ROT != 0;   // update tasks: the column fragments of a k-step from ONE LDS read + lane rotations (df_syrk_tiles); bitwise equal, 12 % SLOWER (see there)
 constexpr bool kDfMacro = OKKT_DF_MACRO != 0;   // update tasks on pairs of row tiles as one macro tile (df_syrk_macro)
 constexpr int kDfDiagMfmaWaves = 6;   // MFMA waves of the diagonal-block factorisation in a worker (four or six: the same time)
 constexpr int kDfKC = OKKT_DF_KC;           // panel columns per ring slot of the update tasks
@@ -949,6 +953,14 @@ __device__ __forceinline__ bool df_tu_lock(const DevPlan& P, int s, int q, int r
   return true;
 }
 
+// a double rotated by CTRL - 0x120 lanes inside every row of 16 lanes (DPP row_ror on the two halves: VALU, no LDS)
+template <int CTRL>
+__device__ __forceinline__ double df_row_ror(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+
 // ---- U: tiles (i .. i + R - 1, j) -= W[rows, j0 .. j0 + nb) * L[columns of block j, j0 .. j0 + nb)^T ------------------------------
 // k_big_syrk's tile (numeric.hip: 128 x 128 per workgroup of 2 x 4 waves, v_mfma_f64_4x4x4 with neg-A, both operand panels through
 // an LDS-DMA ring of two 16-column chunks) with a row limit (the last pivot block of a front may be shorter than 128 rows) and sc1
@@ -957,6 +969,15 @@ __device__ __forceinline__ bool df_tu_lock(const DevPlan& P, int s, int q, int r
 // chunks: the C tile of the next row block is requested while the current one is in its main loop (raw pairs in registers, masked
 // when the accumulators switch), its first operand chunk follows the last chunk of the current tile through the ring, and the
 // stores of a finished tile drain behind the next tile's first chunk.
+// kDfRot (round 6): the loop is bound by the CU's LDS pipe (12 x ds_read_b64 per k-step and wave, eight waves, one pipe).  A column fragment
+// holds 16 distinct doubles (4 columns x 4 k) replicated over the four blocks of v_mfma_f64_4x4x4; instead ONE read fetches 16 columns x 4 k
+// (one double per lane) and the other three operands are that register rotated by 4 / 8 / 12 lanes inside every row of 16 lanes (DPP, VALU):
+// block t of MFMA m multiplies with column group (t -+ m) & 3 -- the same 16 x 16 products in the same k order, dealt to the accumulators
+// in a skewed order that col_of() below (C tile loads, masks, stores) follows.  6 reads per k-step; scripts/lds_dpp_probe.hip.
+// Measured (MI355X): bitwise the same factor (tests/test_gpu_dataflow.py with -DOKKT_DF_ROT=1) and SLOWER -- the probe's loop 21.8 instead of
+// 19.0 cycles per MFMA and SIMD, S-metric 19.2 instead of 17.1 ms: the 12 v_mov_b32_dpp of a k-step do not hide behind the MFMAs, each costs
+// the wave ~ 7.5 issue cycles, more than the LDS read it replaces.  The loop is bound by what a pair of waves can ISSUE per MFMA slot (LDS
+// reads and VALU alike), which is why the wider register tile (df_syrk_macro: fewer operand instructions per MFMA) helps and this does not.  Off.
 // KC / STAGES: panel columns per ring slot and slots (32 x 2 for the one-workgroup-per-CU worker; 16 x 2 = 72 KB was the 128-VGPR
 // bulk kernel's of the two-kernel form, scripts/experiments/r05_two_kernel_form.patch); MULTI: a task may carry several row tiles
 // (the next C tile in a second register set); STAGGER: see below.
@@ -979,6 +1000,19 @@ __device__ __forceinline__ void df_syrk_tiles(const DevPlan& P, int s, int j0, i
   const double* Wcol = P.wbuf + P.wbuf_pos[s] + (size_t)j0 * f + lane * 2;
   const double* Lg = F + (size_t)j0 * f + ct0 + lane * 2;
   const int l15 = lane & 15, l4 = lane >> 4;
+  // kDfRot: the column group (of four) that MFMA m of a half multiplies with in this lane's block -- whatever the rotation brought there
+  const int quad = (lane >> 2) & 3;
+  int grp1 = quad, grp2 = quad, grp3 = quad;
+  if constexpr (kDfRot) {
+    grp1 = __builtin_amdgcn_update_dpp(0, quad, 0x124, 0xf, 0xf, false);
+    grp2 = __builtin_amdgcn_update_dpp(0, quad, 0x128, 0xf, 0xf, false);
+    grp3 = __builtin_amdgcn_update_dpp(0, quad, 0x12C, 0xf, 0xf, false);
+  }
+  auto col_of = [&](int cg) {      // the column of accumulator group cg in this lane
+    if constexpr (!kDfRot) return cbase + cg * 4 + l4;
+    const int m = cg & 3;
+    return cbase + (cg >> 2) * 16 + (m == 0 ? quad : m == 1 ? grp1 : m == 2 ? grp2 : grp3) * 4 + l4;
+  };
   const int nchunk = (nb + kDfKC - 1) / kDfKC;
   const int total = R * nchunk;
   // operand chunk g of the stream: chunk g % nchunk of row tile g / nchunk
@@ -1002,7 +1036,7 @@ __device__ __forceinline__ void df_syrk_tiles(const DevPlan& P, int s, int j0, i
     const int rbase = df_block_lo(i + r, KB, k, f) + (wv & 1) * 64;
 #pragma unroll
     for (int cg = 0; cg < NCG; ++cg) {
-      const int c = cbase + cg * 4 + l4;
+      const int c = col_of(cg);
       const double* colp = Fc + (size_t)min(c, clim - 1) * f;      // (clamped inside the tile column: a pivot block never reads past its panel)
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
@@ -1017,7 +1051,7 @@ __device__ __forceinline__ void df_syrk_tiles(const DevPlan& P, int s, int j0, i
     const int rlim = df_block_lo(i + r + 1, KB, k, f);
 #pragma unroll
     for (int cg = 0; cg < NCG; ++cg) {
-      const int c = cbase + cg * 4 + l4;
+      const int c = col_of(cg);
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int rr = rbase + 2 * l15 + 32 * h;
@@ -1060,7 +1094,7 @@ __device__ __forceinline__ void df_syrk_tiles(const DevPlan& P, int s, int j0, i
     if (active) {
       const double* slot = sm + (size_t)(g % STAGES) * 2 * kDfKC * kSyrkLd;
       const double* bw = slot + (wv & 1) * 64 + 2 * l15;
-      const double* bl = slot + kDfKC * kSyrkLd + (wv >> 1) * WCW + (lane & 3);
+      const double* bl = slot + kDfKC * kSyrkLd + (wv >> 1) * WCW + (kDfRot ? l15 : (lane & 3));
 #pragma unroll
       for (int kk = 0; kk < kDfKC / 4; ++kk) {
         if (kk == (KC / 8) && more && late) issue(g + STAGES - 1);
@@ -1071,7 +1105,12 @@ __device__ __forceinline__ void df_syrk_tiles(const DevPlan& P, int s, int j0, i
         for (int half = 0; half < NCG / 4; ++half) {
           double av[4];
 #pragma unroll
-          for (int qq = 0; qq < 4; ++qq) av[qq] = bl[(kk * 4 + l4) * kSyrkLd + (half * 4 + qq) * 4];
+          for (int qq = 0; qq < 4; ++qq) if (!kDfRot || qq == 0) av[qq] = bl[(kk * 4 + l4) * kSyrkLd + (half * 4 + qq) * 4];
+          if constexpr (kDfRot) {      // 16 columns x 4 k in one read; the other three fragments are that register rotated inside the rows of 16 lanes
+            av[1] = df_row_ror<0x124>(av[0]);
+            av[2] = df_row_ror<0x128>(av[0]);
+            av[3] = df_row_ror<0x12C>(av[0]);
+          }
 #pragma unroll
           for (int qq = 0; qq < 4; ++qq)
 #pragma unroll
@@ -1086,7 +1125,7 @@ __device__ __forceinline__ void df_syrk_tiles(const DevPlan& P, int s, int j0, i
       if (active) {
 #pragma unroll
         for (int cg = 0; cg < NCG; ++cg) {
-          const int c = cbase + cg * 4 + l4;
+          const int c = col_of(cg);
           if (c >= clim) continue;
           double* colp = Fc + (size_t)c * f;
 #pragma unroll

@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void k_xinv_init(DevPlan P, const int* __restr
   const int k = P.sn_col0[s + 1] - P.sn_col0[s];
   int c0, kb, ld; int64_t off;
   xblock(k, b, c0, kb, ld, off);
-  if (kb <= 0) return;
+  if (kb <= 0 || (P.solve_mid && k <= P.solve_mid)) return;      // (nobody reads the explicit inverse of a front that goes through block substitution)
   const int ti = blockIdx.x;
   if (ti * NB >= kb) return;
   double* X = P.xinv + P.xinv_pos[s] + off;
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) void k_xinv_gemm(DevPlan P, const int* __restr
   const int f = (int)(P.row_ptr[s + 1] - P.row_ptr[s]);
   int c0, kb, ld; int64_t off;
   xblock(k, b, c0, kb, ld, off);
-  if (kb <= 0) return;
+  if (kb <= 0 || (P.solve_mid && k <= P.solve_mid)) return;
   const int p = blockIdx.y;
   const int r0 = (2 * p + 1) * sz, q0 = 2 * p * sz;       // rows of the lower half, columns of the left half (inside the block)
   if (r0 >= kb) return;
@@ -1112,7 +1112,7 @@ __global__ __launch_bounds__(kMidThreads) void k_fwd_mid(DevPlan P, const int* _
   const int col0 = P.sn_col0[s];
   const int k = P.sn_col0[s + 1] - col0;
   const int f = (int)(P.row_ptr[s + 1] - P.row_ptr[s]);
-  if (k <= NB || k > P.solve_mid) return;
+  if (k > P.solve_mid) return;      // (a pivot block of up to NB columns: a thin front routed through the wide fronts' launches)
   const double* F = P.arena + P.front_pos[s];
   const double* X = P.invl + P.invl_pos[s];
   const int q = tid & 3, pr = tid >> 2;      // column quarter (neighbouring lanes) and row pair of the row update
@@ -1228,7 +1228,7 @@ __global__ __launch_bounds__(kMidThreads) void k_bwd_mid(DevPlan P, const int* _
   const int col0 = P.sn_col0[s];
   const int k = P.sn_col0[s + 1] - col0;
   const int f = (int)(P.row_ptr[s + 1] - P.row_ptr[s]);
-  if (k <= NB || k > P.solve_mid) return;
+  if (k > P.solve_mid) return;      // (a pivot block of up to NB columns: a thin front routed through the wide fronts' launches)
   const double* F = P.arena + P.front_pos[s];
   const double* X = P.invl + P.invl_pos[s];
   const int clast = ((k - 1) >> 6) << 6;
@@ -1398,11 +1398,12 @@ std::string solve_setup(const Symbolic& S, Numeric& N) {
   // 129 .. 256 columns carry the error, the few wide ones the time
   d.solve_mid = std::min(getenv("OKKT_SOLVE_MID") ? atoi(getenv("OKKT_SOLVE_MID")) : 384, kSB);
   if (kSolveBlock != 1024) d.solve_mid = 0;      // the mid kernels' LDS (static 66.5 KB + R * (kSB + 1024) doubles) is sized for 1024-column blocks: a 2048-column build keeps the explicit inverses (advisor, round 5)
-  if (N.solve_flow || N.nb != 128) d.solve_mid = 0;      // (the flow experiment has its own block products; the 64-column inverses are read out of 128-column blocks)
+  if (N.solve_flow || N.solve_fuse_wide_max > 0 || N.nb != 128) d.solve_mid = 0;      // (the flow and fused-wide experiments have their own block products with the explicit inverses; the 64-column inverses are read out of 128-column blocks)
   const int ns = S.nsuper;
   std::vector<int> ssched;
   std::vector<int64_t> xinv_pos(ns, -1), ypart_pos(ns, -1), ythin_pos(ns, -1), sver_pos(ns, -1);
   int64_t xtot = 0, ytot = 0, ttot = 0, vtot = 0;
+  static const int route_thin = getenv("OKKT_SOLVE_ROUTE_THIN") ? atoi(getenv("OKKT_SOLVE_ROUTE_THIN")) : 1;
   auto build = [&](const std::vector<LevelSchedule>& levels, std::vector<SolveLevel>& out) {
     out.assign(levels.size(), SolveLevel());
     for (size_t l = 0; l < levels.size(); ++l) {
@@ -1413,6 +1414,12 @@ std::string solve_setup(const Symbolic& S, Numeric& N) {
         const int s = N.sched_host[g.off + q];
         (N.sn_k[s] <= N.nb ? thin : wide).push_back(s);
       }
+      // A level that has wide fronts anyway runs the block-substitution launch for them (k_fwd_mid / k_bwd_mid, one workgroup per front) and
+      // the panel launches behind it; its thin fronts (k <= NB) then cost a launch of their own per sweep on top -- 20 us of critical path
+      // per level and sweep for a few hundred KB.  They go through the wide fronts' launches instead (round 6): a pivot block of up to NB
+      // columns is one or two 64-column steps of the same substitution -- and more accurate than the product with its 128 x 128 inverse
+      // (DESIGN.md section 5).  Levels without a wide front keep the fused thin launch (one launch instead of two).
+      if (route_thin && d.solve_mid >= N.nb && !thin.empty() && !wide.empty()) { wide.insert(wide.end(), thin.begin(), thin.end()); thin.clear(); }
       L.thin_off = (int)ssched.size(); L.thin_cnt = (int)thin.size();
       for (int s : thin) { ssched.push_back(s); if (ythin_pos[s] < 0) { ythin_pos[s] = ttot; ttot += (int64_t)kMaxRhs * 128; } L.thin_maxf = std::max(L.thin_maxf, N.sn_f[s]); L.thin_maxk = std::max(L.thin_maxk, N.sn_k[s]); L.thin_maxr = std::max(L.thin_maxr, N.sn_f[s] - N.sn_k[s]); }
       L.wide_off = (int)ssched.size(); L.wide_cnt = (int)wide.size();
