@@ -163,12 +163,13 @@ def _forward_errors(name, nthreads):
 
 def test_smetric_forward_error_against_the_extended_precision_solution():
     """The metric workload itself (round-3 review: its widest fronts take the solves through the 1024-column explicit inverses and had
-    only a residual check): the same bound as S-C3 below -- the HIP solution may be at most 8 x less accurate than the CPU
-    restatement's, both measured against the extended-precision solution.  One multithreaded CPU factorisation (5 - 25 s)."""
+    only a residual check): the same bound as S-C3 below -- the HIP solution may be at most 2 x less accurate than the CPU
+    restatement's (8 x until round 5), both measured against the extended-precision solution.  One multithreaded CPU factorisation (5 - 25 s)."""
     import os
-    # absolute bound 1e-7 here: the CPU restatement itself is at 7e-9 ... 1e-8 on this matrix (measured: HIP 1.9e-8 ... 2.0e-8)
+    # the CPU restatement itself is at 7e-9 ... 1e-8 on this matrix; HIP measured 1.9e-8 ... 2.0e-8 in round 4, 6.9e-9 / 8.9e-9 with the block
+    # substitution of round 5, 4.7e-9 / 4.9e-9 since the thin fronts of the upper levels go through it as well (round 6)
     for e_o, e_h in _forward_errors("S-metric", max(1, min(os.cpu_count() or 1, 32))):
-        assert e_h <= 1e-7 and e_h <= 8.0 * e_o + 1e-12, (e_h, e_o)
+        assert e_h <= 1e-7 and e_h <= 2.0 * e_o + 1e-12, (e_h, e_o)
 
 
 def test_sc5_forward_error_against_the_extended_precision_solution():
@@ -176,20 +177,22 @@ def test_sc5_forward_error_against_the_extended_precision_solution():
     solves through explicit inverses of the whole pivot block (recursive doubling): 1.18e-8 and 3.4e-9 on the two vectors of this test
     against 3.7e-10 and 6.9e-10 for the CPU restatement -- outside the 1e-8 of the other comparisons.  `scripts/solve_emulation.py`
     located the loss (explicit inverses are as good as substitution up to 64 columns and 5 - 40 x worse from 128 on), and these fronts
-    now go through block substitution in 64-column steps (csrc/solve.hip, k_fwd_mid / k_bwd_mid): measured 4.4e-10 and 9.3e-10.
-    Asserted: the stated tolerance on x for every vector, and at most 4 x the restatement's error (worst against worst)."""
+    now go through block substitution in 64-column steps (csrc/solve.hip, k_fwd_mid / k_bwd_mid): measured 9.4e-10 and 4.0e-10 (round 6).
+    Asserted: the stated tolerance on x for every vector, and at most 2 x the restatement's error (worst against worst; 4 x until round 5)."""
     errs = _forward_errors("S-C5", 8)
     worst_o = max(e_o for e_o, _ in errs)
     for e_o, e_h in errs:
         assert e_h <= TOL_X, (e_h, e_o)
-    assert max(e_h for _, e_h in errs) <= 4.0 * worst_o + 1e-12, errs
+    assert max(e_h for _, e_h in errs) <= 2.0 * worst_o + 1e-12, errs
 
 
 def test_sc3_forward_error_against_the_extended_precision_solution():
     """Both solutions against the TRUE solution of the fp64 matrix (the oracle's solve refined with long-double residuals until the
     correction is at rounding level) instead of against each other: the HIP path may not be less accurate than the CPU restatement by
     more than a small factor.  This is what caught an amalgamation setting that was 12 % faster on S-C5 and wrong by 3.5e-8 instead of
-    2e-9 (fronts of 256-512 pivot columns take the solves through the explicit inverses of the 2048-column blocks)."""
+    2e-9 (fronts of 256-512 pivot columns take the solves through the explicit inverses of the 2048-column blocks).
+    Round 6 (the round-5 review's bound): at most 2 x the restatement's error -- measured 1.9e-9 / 1.6e-9 against 1.5e-9 / 2.1e-9 since the
+    pivot blocks of up to 128 columns of the upper levels are solved by block substitution as well (5.0e-9 / 3.2e-9 before: 8 x was the bound)."""
     prob = synth.make_config("S-C3", seed=0)
     n, m = prob["n"], prob["m"]
     K = synth.augmented_matrix(prob, delta=1e-8)
@@ -210,7 +213,7 @@ def test_sc3_forward_error_against_the_extended_precision_solution():
         xh = h.ls_solve(b)
         sc = np.max(np.abs(xt))
         e_o, e_h = np.max(np.abs(xo - xt)) / sc, np.max(np.abs(xh - xt)) / sc
-        assert e_h <= TOL_X and e_h <= 8.0 * e_o + 1e-12, (e_h, e_o)
+        assert e_h <= TOL_X and e_h <= 2.0 * e_o + 1e-12, (e_h, e_o)
     finalize_b(h)
 
 
