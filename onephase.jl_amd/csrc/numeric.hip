@@ -201,7 +201,11 @@ __device__ __forceinline__ int lower_bound_dev(const int* a, int n, int key) {
 #ifndef OKKT_ASM_BATCH_CHUNKED
 #define OKKT_ASM_BATCH_CHUNKED 4
 #endif
+#ifndef OKKT_ASM_UNROLL
+#define OKKT_ASM_UNROLL 4
+#endif
 constexpr int kAsmBatch = OKKT_ASM_BATCH, kAsmBatchChunked = OKKT_ASM_BATCH_CHUNKED;
+constexpr int kAsmUnroll = OKKT_ASM_UNROLL;      // 64-row groups of an item whose index and value loads are in flight together (round 6: 8 instead of 4 is SLOWER -- S-metric 17.3 against 17.1 ms, S-C5 3.95 / 3.87: the registers cost waves, and waves are what hides the latency here)
 template <bool LDS, bool BATCH>
 __device__ __forceinline__ void assemble_column(const DevPlan& P, int s, int pc, int f, int k, int col0, double* __restrict__ buf) {
   const int lane = threadIdx.x & 63;
@@ -246,15 +250,15 @@ __device__ __forceinline__ void assemble_column(const DevPlan& P, int s, int pc,
       const double* Ccol = P.arena + src_n;
       if (q + 1 < q1) { const EaRec r = P.ea_rec[q + 1]; src_n = r.src; rel_n = r.rel; rc_n = r.rc; jj_n = r.jj; }
       int ii = jj + lane;
-      for (; ii + 192 < rc; ii += 256) {
-        int d[4];
-        double v[4], o[4];
+      for (; ii + 64 * (kAsmUnroll - 1) < rc; ii += 64 * kAsmUnroll) {
+        int d[kAsmUnroll];
+        double v[kAsmUnroll], o[kAsmUnroll];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) d[u] = rl[ii + 64 * u] - pc;
+        for (int u = 0; u < kAsmUnroll; ++u) d[u] = rl[ii + 64 * u] - pc;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { v[u] = Ccol[ii + 64 * u]; o[u] = buf[d[u]]; }
+        for (int u = 0; u < kAsmUnroll; ++u) { v[u] = Ccol[ii + 64 * u]; o[u] = buf[d[u]]; }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) buf[d[u]] = o[u] + v[u];
+        for (int u = 0; u < kAsmUnroll; ++u) buf[d[u]] = o[u] + v[u];
       }
       for (; ii < rc; ii += 64) buf[rl[ii] - pc] += Ccol[ii];
       __threadfence_block();
@@ -284,15 +288,15 @@ __device__ __forceinline__ void assemble_column(const DevPlan& P, int s, int pc,
         const int* rl = P.rel + rel[u];
         const double* Ccol = P.arena + src[u];
         int ii = jj[u] + 64 + lane;
-        for (; ii + 192 < rc[u]; ii += 256) {
-          int dd[4];
-          double vv[4], oo[4];
+        for (; ii + 64 * (kAsmUnroll - 1) < rc[u]; ii += 64 * kAsmUnroll) {
+          int dd[kAsmUnroll];
+          double vv[kAsmUnroll], oo[kAsmUnroll];
 #pragma unroll
-          for (int w = 0; w < 4; ++w) dd[w] = rl[ii + 64 * w] - pc;
+          for (int w = 0; w < kAsmUnroll; ++w) dd[w] = rl[ii + 64 * w] - pc;
 #pragma unroll
-          for (int w = 0; w < 4; ++w) { vv[w] = Ccol[ii + 64 * w]; oo[w] = buf[dd[w]]; }
+          for (int w = 0; w < kAsmUnroll; ++w) { vv[w] = Ccol[ii + 64 * w]; oo[w] = buf[dd[w]]; }
 #pragma unroll
-          for (int w = 0; w < 4; ++w) buf[dd[w]] = oo[w] + vv[w];
+          for (int w = 0; w < kAsmUnroll; ++w) buf[dd[w]] = oo[w] + vv[w];
         }
         for (; ii < rc[u]; ii += 64) buf[rl[ii] - pc] += Ccol[ii];
         __threadfence_block();
@@ -408,15 +412,15 @@ __global__ __launch_bounds__(256) void k_big_assemble_chunked(DevPlan P, const i
         const int* rl = P.rel + rel[u];
         const double* Ccol = P.arena + src[u];
         int ii = lo[u] + 64 + lane;
-        for (; ii + 192 < hi[u]; ii += 256) {
-          int dd[4];
-          double vv[4], oo[4];
+        for (; ii + 64 * (kAsmUnroll - 1) < hi[u]; ii += 64 * kAsmUnroll) {
+          int dd[kAsmUnroll];
+          double vv[kAsmUnroll], oo[kAsmUnroll];
 #pragma unroll
-          for (int w = 0; w < 4; ++w) dd[w] = rl[ii + 64 * w] - r0;
+          for (int w = 0; w < kAsmUnroll; ++w) dd[w] = rl[ii + 64 * w] - r0;
 #pragma unroll
-          for (int w = 0; w < 4; ++w) { vv[w] = Ccol[ii + 64 * w]; oo[w] = base[dd[w]]; }
+          for (int w = 0; w < kAsmUnroll; ++w) { vv[w] = Ccol[ii + 64 * w]; oo[w] = base[dd[w]]; }
 #pragma unroll
-          for (int w = 0; w < 4; ++w) base[dd[w]] = oo[w] + vv[w];
+          for (int w = 0; w < kAsmUnroll; ++w) base[dd[w]] = oo[w] + vv[w];
         }
         for (; ii < hi[u]; ii += 64) base[rl[ii] - r0] += Ccol[ii];
         __threadfence_block();
@@ -1558,16 +1562,32 @@ std::string numeric_read_counts(Numeric& N, hipStream_t stream, unsigned long lo
 static std::string factor_sched(Numeric& N, DevPlan P, const std::vector<LevelSchedule>& levels, const std::vector<SolveLevel>& slevels,
                                 const LaneStreams& ss, double tol, bool in_loop_check, bool& inv_on_aux, size_t l_begin = 0, size_t l_end = (size_t)-1);
 
+// the words a factorisation starts from zero, in ONE launch: three hipMemsetAsync are three fill kernels of 4 - 5 us each, 14 of the 108 us
+// a CUTEst-size system (BASELINE config 2) takes to factor (round 6, profiles/r06_small_configs_trace.txt)
+__global__ __launch_bounds__(256) void k_zero_words(unsigned* __restrict__ a, size_t na, unsigned* __restrict__ b, size_t nb, unsigned* __restrict__ c, size_t nc) {
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < na + nb + nc; i += stride) {
+    if (i < na) a[i] = 0u;
+    else if (i < na + nb) b[i - na] = 0u;
+    else c[i - na - nb] = 0u;
+  }
+}
+
 std::string numeric_factor_enqueue(Numeric& N, const double* d_vals, double tol, int which, bool reset_counters) {
   DevPlan P = N.d;
   P.vals = d_vals;
   hipStream_t st = N.stream;
-  if (reset_counters) OKKT_HIP_TRY(hipMemsetAsync(P.counters, 0, (size_t)kCountSlots * kCountStride * sizeof(unsigned long long), st));
-  // the arrival counters of the fused backward launches are reset by their consumer; a sweep that was cut short (a wait that ran into
-  // its bound) leaves a residue that would let the next solve's consumer start early: cleared with the time-out word (advisor, round 3)
-  if (reset_counters && N.solve_counters) OKKT_HIP_TRY(hipMemsetAsync(N.solve_counters, 0, (size_t)N.d.nsuper * sizeof(int), st));
-  if (N.dataflow && P.df_state) {
-    OKKT_HIP_TRY(hipMemsetAsync(P.df_state, 0, ((size_t)N.df_state_ints + (size_t)N.n_df_heads * kDfHeadStride) * sizeof(int), st));   // tile states, queue heads
+  {
+    // the pivot counters; the arrival counters of the fused backward launches (reset by their consumer, but a sweep that was cut short -- a
+    // wait that ran into its bound -- leaves a residue that would let the next solve's consumer start early: cleared with the time-out word,
+    // advisor, round 3); the tile states and queue heads of the dataflow launches
+    const size_t na = reset_counters ? (size_t)kCountSlots * kCountStride * (sizeof(unsigned long long) / sizeof(unsigned)) : 0;
+    const size_t nb = (reset_counters && N.solve_counters) ? (size_t)N.d.nsuper : 0;
+    const size_t nc = (N.dataflow && P.df_state) ? (size_t)N.df_state_ints + (size_t)N.n_df_heads * kDfHeadStride : 0;
+    if (na + nb + nc) {
+      const unsigned grid = (unsigned)std::min<size_t>(2048, (na + nb + nc + 1023) / 1024);
+      hipLaunchKernelGGL(k_zero_words, dim3(grid), dim3(256), 0, st, (unsigned*)P.counters, na, (unsigned*)N.solve_counters, nb, (unsigned*)P.df_state, nc);
+    }
   }
   if (N.early_check && N.early_device && which == 0 && N.levels_top.empty() && reset_counters) { P.want_pos = N.early_n; P.want_neg = N.early_m; }
   N.la_used = 0;
