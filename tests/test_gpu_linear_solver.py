@@ -475,7 +475,7 @@ def test_levels_of_small_fronts_in_one_launch(case, nrhs):
         else:
             x = h.ls_solve(B[0])[None, :]
         st = h.stats()
-        assert st["last_factor_ms"] < 50.0 and st["last_solve_ms"] < 50.0, st
+        assert st["last_factor_ms"] < 300.0 and st["last_solve_ms"] < 300.0, st      # (a hand-off that ran into its time-out costs >= 700 ms)
         X.append(np.array(x))
     xd = np.linalg.solve(Ms, B.T).T
     assert np.max(np.abs(X[0] - xd)) <= 1e-8 * max(1.0, np.max(np.abs(xd)))
