@@ -1090,7 +1090,9 @@ __device__ __forceinline__ void df_syrk_tiles(const DevPlan& P, int s, int j0, i
     if constexpr (MULTI) { if (ch == pre && r + 1 < R) { load_c(r + 1); plain_until = g + STAGES; } }
     const int rt0 = df_block_lo(i + r, KB, k, f), rlim = df_block_lo(i + r + 1, KB, k, f);
     const int rbase = rt0 + (wv & 1) * 64;
-    const bool active = !(rbase + 63 < cbase) && rbase < rlim && cbase < clim;
+    // (timing experiment, OKKT_DEBUG_DF_HALF: a bulk task skips the products of every other chunk -- WRONG numbers, the operand stream and everything
+    // around the loop unchanged: does the launch get faster when the bulk work gets cheaper?)
+    const bool active = !(rbase + 63 < cbase) && rbase < rlim && cbase < clim && !(P.df_dbg_half && nb >= 256 && (g & 1));
     if (active) {
       const double* slot = sm + (size_t)(g % STAGES) * 2 * kDfKC * kSyrkLd;
       const double* bw = slot + (wv & 1) * 64 + 2 * l15;
@@ -1274,6 +1276,251 @@ __device__ __forceinline__ void df_syrk_macro(const DevPlan& P, int s, int j0, i
   if (marks && tid == 0) marks[2] = wall_clock64();
 }
 
+// ---- U tasks CHAINED (round 6): a worker streams bulk update tasks without leaving the operand ring --------------------------------------
+// The factorisation's time at S-metric is 6.6 ms + 2 740 worker-ms / workers (measured with 96 ... 256 workers: scripts/r06_workers.sh): 62 % of
+// it is the workers' THROUGHPUT, and an update task spends 11 of its 91 us outside the MFMA loop -- pop and readiness 2.1, C tile and first
+// operand chunk 5.2, stores 2.6, drain and publication 1.3.  Two or four row tiles per task hid that (-17 % per tile, round 4) and lost more
+// in the schedule: tasks twice as long, tiles published at the end of the pair.  Here the granularity stays one tile per task.  While
+// a worker is in the last seven chunks of a bulk tile that lies far enough from the panel (DevPlan::df_chain block columns behind its last
+// panel) it takes its next queue position early; if that task is another update of one tile with at least two panels it polls its
+// tile states ONCE and, if they are there, requests the next C tile into the second register set (the
+// machinery of the multi-row task) -- every step issues its loads in one chunk iteration and reads them in the next, behind the
+// vmcnt(0) the ring needs anyway, so nobody waits for a round trip.  At the end of the tile the stores leave, the next tile's first
+// operand chunk is already in the ring, and the finished tile is published one chunk later (its stores have drained behind that
+// iteration's wait).  A task that is of another kind, or whose inputs are not there yet, is simply the worker's next task (t_claim).  Same products in the same
+// order: bitwise the same tiles.
+struct DfUPar {      // wave-uniform parameters of one single-tile update task
+  int s, f, k, KB, TB, i, j, q0, nq, j0, nb, nchunk, ct0, clim, rt0, rlim, t;
+  double* F; double* Fc; const double* Wb;
+};
+__device__ __forceinline__ void df_upar(const DevPlan& P, DfUPar& u, int t, int s, int i, int j, int q0, int nq) {
+  u.t = t; u.s = s; u.i = i; u.j = j; u.q0 = q0; u.nq = nq;
+  u.k = P.sn_col0[s + 1] - P.sn_col0[s];
+  u.f = (int)(P.row_ptr[s + 1] - P.row_ptr[s]);
+  u.KB = (u.k + 127) >> 7;
+  u.TB = u.KB + ((u.f - u.k + 127) >> 7);
+  u.j0 = q0 * 128;
+  u.nb = min(nq * 128, u.k - u.j0);
+  u.nchunk = (u.nb + kDfKC - 1) / kDfKC;
+  u.ct0 = df_block_lo(j, u.KB, u.k, u.f); u.clim = df_block_lo(j + 1, u.KB, u.k, u.f);
+  u.rt0 = df_block_lo(i, u.KB, u.k, u.f); u.rlim = df_block_lo(i + 1, u.KB, u.k, u.f);
+  u.F = P.arena + P.front_pos[s];
+  u.Fc = u.F + (j >= u.KB ? P.cb_shift[s] : 0);
+  u.Wb = P.wbuf + P.wbuf_pos[s] + (size_t)u.j0 * u.f;
+}
+constexpr int kChainLead = 7;      // chunk iterations between the look at the queue head and the end of the tile (five steps + the C tile + the first chunk)
+// returns through t_last the queue position of the LAST tile of the chain (the caller drains and publishes it: mine / newv), through
+// t_claim a claimed task that has not been started (-1: none)
+__device__ __forceinline__ void df_syrk_chain(const DevPlan& P, const DfTask* __restrict__ tasks, int ntasks, int* __restrict__ head, int t0, int s0, int i0, int j0_, int q00, int nq0,
+                                              int* s_nxt, double* sm, long long* tlog, int** mine, int* newv, int* t_last, int* t_claim) {
+  constexpr int NW = kSyrkNW, KC = kDfKC;
+  static_assert(kDfStages == 2, "the chained stream waits for every chunk with vmcnt(0): a ring of two slots");
+  constexpr int WCW = 128 / (NW / 2), NCG = WCW / 4;
+  int tid_ = threadIdx.x;
+  asm volatile("" : "+v"(tid_));
+  const int tid = tid_, lane = tid & 63, wv = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(wv);
+  const int l15 = lane & 15, l4 = lane >> 4;
+  DfUPar cur, nxt;
+  df_upar(P, cur, t0, s0, i0, j0_, q00, nq0);
+  nxt = cur;
+  auto issue = [&](const DfUPar& u, int ch, int slotid) {
+    double* slot = sm + (size_t)slotid * 2 * KC * kSyrkLd;
+    const double* Wg = u.Wb + u.rt0 + lane * 2;
+    const double* Lg = u.F + (size_t)u.j0 * u.f + u.ct0 + lane * 2;
+#pragma unroll
+    for (int qq = 0; qq < KC / NW; ++qq) {
+      const int prow = qq * NW + wv;
+      const int p = ch * KC + prow;
+      const double* wsrc = p < u.nb ? Wg + (size_t)p * u.f : P.zero_page + lane * 2;
+      const double* lsrc = p < u.nb ? Lg + (size_t)p * u.f : P.zero_page + lane * 2;
+      __builtin_amdgcn_global_load_lds(wsrc, (lds_void_t*)(slot + prow * kSyrkLd), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(lsrc, (lds_void_t*)(slot + (KC + prow) * kSyrkLd), 16, 0, 0);
+    }
+  };
+  d2_t raw[NCG][2];
+  auto load_c = [&](const DfUPar& u) {
+    const int rbase = u.rt0 + (wv & 1) * 64, cbase = u.ct0 + (wv >> 1) * WCW;
+#pragma unroll
+    for (int cg = 0; cg < NCG; ++cg) {
+      const int c = cbase + cg * 4 + l4;
+      const double* colp = u.Fc + (size_t)min(c, u.clim - 1) * u.f;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int rr = rbase + 2 * l15 + 32 * h;
+        __builtin_memcpy(&raw[cg][h], colp + min(rr, u.f - 2), 16);
+      }
+    }
+  };
+  double acc[NCG][4];
+  auto mask_c = [&](const DfUPar& u) {
+    const int rbase = u.rt0 + (wv & 1) * 64, cbase = u.ct0 + (wv >> 1) * WCW;
+#pragma unroll
+    for (int cg = 0; cg < NCG; ++cg) {
+      const int c = cbase + cg * 4 + l4;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int rr = rbase + 2 * l15 + 32 * h;
+        const int shift = rr - min(rr, u.f - 2);
+        const double e0 = shift == 0 ? raw[cg][h][0] : raw[cg][h][1];
+        acc[cg][2 * h] = keep_f64(e0, rr < u.rlim && c < u.clim && rr >= c);
+        acc[cg][2 * h + 1] = keep_f64(raw[cg][h][1], shift == 0 && rr + 1 < u.rlim && c < u.clim && rr + 1 >= c);
+      }
+    }
+  };
+  auto store_c = [&](const DfUPar& u) {
+    const int rbase = u.rt0 + (wv & 1) * 64, cbase = u.ct0 + (wv >> 1) * WCW;
+    if ((rbase + 63 < cbase) || rbase >= u.rlim || cbase >= u.clim) return;
+#pragma unroll
+    for (int cg = 0; cg < NCG; ++cg) {
+      const int c = cbase + cg * 4 + l4;
+      if (c >= u.clim) continue;
+      double* colp = u.Fc + (size_t)c * u.f;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int rr = rbase + 2 * l15 + 32 * h;
+        if (rr + 1 < u.rlim && rr >= c) {
+          st_sc1_f64x2(colp + rr, (d2_t){acc[cg][2 * h], acc[cg][2 * h + 1]});
+        } else {
+          if (rr < u.rlim && rr >= c) st_agent_f64(colp + rr, acc[cg][2 * h]);
+          if (rr + 1 < u.rlim && rr + 1 >= c) st_agent_f64(colp + rr + 1, acc[cg][2 * h + 1]);
+        }
+      }
+    }
+  };
+  if (wave == 0) s_nxt[0] = 0;
+  load_c(cur);
+  asm volatile("" ::: "memory");
+  mask_c(cur);
+  issue(cur, 0, 0);
+  int G = 0, c = 0;                    // chunks since the start of the chain (ring slot = G & 1), chunk of the current tile
+  int have = 0;                        // 0: no next tile; 2: its C tile is on its way, its first chunk follows the current tile's last
+  int claimed = -1;                    // a claimed task whose inputs were not there at the one look
+  int* pend = nullptr; int pendv = 0, pendt = -1;      // the finished tile that is published behind the next iteration's wait
+  // wave 0's look at the queue, one step per chunk iteration (loads requested in one step are read in the next)
+  int stage = 0, qh = 0, rs = 0, rtn = 0, rij = 0, rq0 = 0, st0 = 0, st1 = 0, st2 = 0, stopw = 0;
+  int nk = 0, nf = 0; long long nsp = 0;
+  for (;;) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // chunk G has landed; so has everything else this wave has asked for, and its stores have drained
+    __builtin_amdgcn_s_barrier();
+    // a tile looks for a successor only if it is long enough for the five steps and itself far from the panel (its own publication moves
+    // one chunk back when it has one)
+    const bool looks = P.df_chain > 0 && cur.nchunk >= kChainLead && c >= cur.nchunk - kChainLead && cur.j - (cur.q0 + cur.nq - 1) >= P.df_chain;
+    if (pend) {      // the previous tile of the chain: every wave's stores have drained behind this iteration's wait
+      if (wave == 0 && lane == 0) __hip_atomic_store(pend, pendv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (tlog && tid == 0) tlog[(size_t)pendt * 8 + 2] = wall_clock64();
+      pend = nullptr;
+    }
+    const int announced = __builtin_amdgcn_readfirstlane(s_nxt[0]);      // written by wave 0 in the previous iteration (stage 4)
+    if (stage == 5) {
+      stage = 6;
+      if (announced == 2) {
+        const int nt = __builtin_amdgcn_readfirstlane(s_nxt[1]), ns = __builtin_amdgcn_readfirstlane(s_nxt[2]), ntn = __builtin_amdgcn_readfirstlane(s_nxt[3]);
+        const int nij = __builtin_amdgcn_readfirstlane(s_nxt[4]), nq0 = __builtin_amdgcn_readfirstlane(s_nxt[5]);
+        df_upar(P, nxt, nt, ns, nij & 0xffff, nij >> 16, nq0, (ntn >> 8) & 255);
+        have = 2;
+      } else if (announced == 1) claimed = __builtin_amdgcn_readfirstlane(s_nxt[1]);
+    }
+    const bool late = kDfStagger && wv >= 4;
+    const bool last = c + 1 == cur.nchunk;
+    const bool more = !last || have == 2;
+    auto issue_next = [&]() { if (!last) issue(cur, c + 1, (G + 1) & 1); else issue(nxt, 0, (G + 1) & 1); };
+    if (more && !late) issue_next();
+    if (have == 2 && stage == 6) { load_c(nxt); stage = 7; }      // the next C tile: plain loads, read behind a later iteration's wait
+    if (wave == 0 && looks && stage < 5) {
+      if (stage == 0) {
+        // the worker's next queue position, taken early (what the caller does at the end of a task): from here on the task is this worker's,
+        // chained or not.  (A look at the head followed by a compare-and-swap two steps later practically never succeeds: in the busy phase
+        // another worker pops every 0.3 us.)
+        qh = 0;
+        if (lane == 0) qh = atomicAdd(head, 1);
+        stage = 1;
+      } else if (stage == 1) {
+        qh = __builtin_amdgcn_readfirstlane(qh);
+        rs = 0; rtn = 255; rij = 0; rq0 = 0;
+        if (qh < ntasks) {
+          const DfTask tk = tasks[qh];
+          rs = tk.front; rtn = tk.type_nq; rij = tk.ij; rq0 = tk.q0;
+        }
+        stage = 2;
+      } else if (stage == 2) {
+        rs = __builtin_amdgcn_readfirstlane(rs); rtn = __builtin_amdgcn_readfirstlane(rtn); rij = __builtin_amdgcn_readfirstlane(rij); rq0 = __builtin_amdgcn_readfirstlane(rq0);
+        nk = P.sn_col0[rs + 1] - P.sn_col0[rs];
+        nf = (int)(P.row_ptr[rs + 1] - P.row_ptr[rs]);
+        nsp = P.df_state_pos[rs];
+        if (tlog && lane == 0 && qh < ntasks) { tlog[(size_t)qh * 8] = wall_clock64(); tlog[(size_t)qh * 8 + 3] = blockIdx.x; }
+        stage = 3;
+      } else if (stage == 3) {
+        const int ty = rtn & 255, nqn = (rtn >> 8) & 255, rw = rtn >> 16;
+        st0 = st1 = st2 = -1; stopw = 1;
+        if (ty == kDfU && rw <= 1 && nqn >= 2) {      // another update of one tile with at least two panels: its three tile states, once
+          const int in = rij & 0xffff, jn = rij >> 16, ql = rq0 + nqn - 1;
+          const int KBn = (nk + 127) >> 7, TBn = KBn + ((nf - nk + 127) >> 7);
+          const int* stn = P.df_state + nsp;
+          st0 = ld_state(stn + (size_t)in * TBn + ql);      // row operand: block row i of the group's last panel
+          st1 = ld_state(stn + (size_t)in * TBn + jn);      // the tile itself: the panels before the group applied
+          st2 = ld_state(stn + (size_t)jn * TBn + ql);      // column operand
+          stopw = (int)__hip_atomic_load(&P.counters[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) | (P.want_neg >= 0 ? (int)__hip_atomic_load(&P.counters[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0);
+        }
+        stage = 4;
+      } else if (stage == 4) {
+        const int nqn = (rtn >> 8) & 255, ql = rq0 + nqn - 1;
+        const bool ready = __builtin_amdgcn_readfirstlane(stopw) == 0 && __builtin_amdgcn_readfirstlane(st0) >= ql + 1 && __builtin_amdgcn_readfirstlane(st1) >= rq0 && __builtin_amdgcn_readfirstlane(st2) >= ql + 1;
+        if (ready) {
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          if (tlog && lane == 0) tlog[(size_t)qh * 8 + 1] = wall_clock64();
+        }
+        s_nxt[1] = qh; s_nxt[2] = rs; s_nxt[3] = rtn; s_nxt[4] = rij; s_nxt[5] = rq0;
+        s_nxt[0] = ready ? 2 : 1;      // every lane writes the same words
+        stage = 5;
+      }
+    }
+    if (wave != 0 && looks && stage < 5) stage = stage + 1;      // the other waves count the steps along (the same iterations in every wave)
+    {
+      const int rbase = cur.rt0 + (wv & 1) * 64, cbase = cur.ct0 + (wv >> 1) * WCW;
+      const bool active = !(rbase + 63 < cbase) && rbase < cur.rlim && cbase < cur.clim;
+      if (active) {
+        const double* slot = sm + (size_t)(G & 1) * 2 * KC * kSyrkLd;
+        const double* bw = slot + (wv & 1) * 64 + 2 * l15;
+        const double* bl = slot + KC * kSyrkLd + (wv >> 1) * WCW + (lane & 3);
+#pragma unroll
+        for (int kk = 0; kk < KC / 4; ++kk) {
+          if (kk == (KC / 8) && more && late) issue_next();
+          double bv[4];
+#pragma unroll
+          for (int rb = 0; rb < 4; ++rb) bv[rb] = bw[(kk * 4 + l4) * kSyrkLd + (rb & 1) + 32 * (rb >> 1)];
+#pragma unroll
+          for (int half = 0; half < NCG / 4; ++half) {
+            double av[4];
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) av[qq] = bl[(kk * 4 + l4) * kSyrkLd + (half * 4 + qq) * 4];
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq)
+#pragma unroll
+              for (int rb = 0; rb < 4; ++rb)
+                acc[half * 4 + qq][rb] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[qq], bv[rb], acc[half * 4 + qq][rb], 0, 0, 1 /* neg A */);
+          }
+        }
+      } else if (more && late) issue_next();
+    }
+    ++G;
+    if (!last) { ++c; continue; }
+    // the tile is done: its stores leave (write-through); either the next tile of the chain takes over the accumulators or the caller
+    // drains and publishes
+    store_c(cur);
+    if (have != 2) break;
+    pend = P.df_state + P.df_state_pos[cur.s] + (size_t)cur.i * cur.TB + cur.j; pendv = cur.q0 + cur.nq; pendt = cur.t;
+    mask_c(nxt);
+    cur = nxt;
+    have = 0; c = 0; stage = 0;
+    if (wave == 0) s_nxt[0] = 0;
+  }
+  *mine = P.df_state + P.df_state_pos[cur.s] + (size_t)cur.i * cur.TB + cur.j;
+  *newv = cur.q0 + cur.nq;
+  *t_last = cur.t;
+  *t_claim = claimed;
+}
+
 constexpr int kDfThreads = kDfThreadsC;
 constexpr size_t kDfLds = std::max(std::max(std::max(std::max(OKKT_DIAG2_LDS_DOUBLES(kMW) * sizeof(double), kDfTuLds), (size_t)kDfStages * 2 * kDfKC * kSyrkLd * sizeof(double)), kDfTlLds), std::max(std::max(kDfTuLockLds, kDfMacroLds), (size_t)128 * kDfTileLd * sizeof(double)));   // diag2_body's and df_tu_tile's; the other roles need less
 
@@ -1282,6 +1529,7 @@ constexpr size_t kDfLds = std::max(std::max(std::max(std::max(OKKT_DIAG2_LDS_DOU
 __global__ __launch_bounds__(kDfThreads, 1) void k_front_dataflow(DevPlan P, const DfTask* __restrict__ tasks, int ntasks, int* __restrict__ head, double tol, int drop, int dbg, long long* __restrict__ tlog) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   __shared__ int s_ctl[8];
+  __shared__ int s_nxt[8];      // df_syrk_chain: the next tile of a chain, announced by wave 0
   const int tid = threadIdx.x;
   // The scheduling code runs on WAVE 0 as a whole (a wave-uniform branch, every lane polls the same words): with an `if (tid == 0)`
   // around it hipcc threads the branch through the loop header, the structurizer turns the worker's loop into two nested loops and
@@ -1369,6 +1617,7 @@ __global__ __launch_bounds__(kDfThreads, 1) void k_front_dataflow(DevPlan P, con
     int* st = P.df_state + P.df_state_pos[s];
     int* mine;
     int newv, npub = 1;
+    int t_done = t, t_hold = -1;      // chained update tasks: the last tile of the chain (published below), a claimed task that has not been started
     if (type == kDfD) {
       if (!(dbg & 1)) diag2_body<true, kDiag2MW, kDfDiagMfmaWaves, kDfProg>(P, s, i, 128, tol, sm, nullptr, 0, tlog ? tlog + (size_t)t * 8 + 4 : nullptr, (kDfProg && (nq & 8) && i + 1 < KB) ? st + (size_t)i * TB + i + 1 : nullptr);
       mine = st + (size_t)i * TB + i; newv = i + 1;
@@ -1403,22 +1652,23 @@ __global__ __launch_bounds__(kDfThreads, 1) void k_front_dataflow(DevPlan P, con
     } else {
       const int j0 = q0 * 128;
       // a pair of row tiles below the diagonal tile: one macro tile (a wave owns 128 x 32 of it); everything else tile by tile
+      mine = st + (size_t)i * TB + j; newv = q0 + nq; npub = rows;
       if (!(dbg & 4)) {
         if (kDfMacro && rows == 2 && i > j && P.df_macro) df_syrk_macro(P, s, j0, min(nq * 128, k - j0), i, j, KB, k, sm, tlog ? tlog + (size_t)t * 8 + 4 : nullptr);
+        else if (P.df_chain > 0 && rows == 1 && nq >= 2) df_syrk_chain(P, tasks, ntasks, head, t, s, i, j, q0, nq, s_nxt, sm, tlog, &mine, &newv, &t_done, &t_hold);
         else df_syrk_tiles<kDfKC, kDfStages, true, kDfStagger>(P, s, j0, min(nq * 128, k - j0), i, rows, j, KB, k, sm, tlog ? tlog + (size_t)t * 8 + 4 : nullptr);
       }
-      mine = st + (size_t)i * TB + j; newv = q0 + nq; npub = rows;
     }
     // the next queue position is requested now: the atomic's round trip (1 us) runs beside the drain of this task's stores
     int t_pre = 0;
-    if (wave == 0 && (tid & 63) == 0) t_pre = atomicAdd(head, 1);
+    if (wave == 0 && (tid & 63) == 0 && t_hold < 0) t_pre = atomicAdd(head, 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every storing wave: its sc1 stores have been acknowledged
     __syncthreads();                                      // ... and every wave is done with the LDS of this task and with s_ctl
-    if (tlog && tid == 0) tlog[(size_t)t * 8 + 2] = wall_clock64();
+    if (tlog && tid == 0) tlog[(size_t)t_done * 8 + 2] = wall_clock64();
     if (wave == 0) {      // lane r publishes row tile r of the task (one tile for every kind but the bulk updates)
       const int ln = tid & 63;
       if (ln < npub) __hip_atomic_store(mine + (size_t)ln * TB, newv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      t_ahead = __builtin_amdgcn_readfirstlane(t_pre);
+      t_ahead = t_hold >= 0 ? t_hold : __builtin_amdgcn_readfirstlane(t_pre);
     }
   }
 }
@@ -1444,6 +1694,10 @@ std::string df_setup(Numeric& N) {
   N.df_split_tu = getenv("OKKT_DF_SPLIT_TU") ? atoi(getenv("OKKT_DF_SPLIT_TU")) : 1;
   N.df_fuse_tl = getenv("OKKT_DF_FUSE_TL") ? atoi(getenv("OKKT_DF_FUSE_TL")) : 1;
   d.df_macro = getenv("OKKT_DF_MACRO") ? atoi(getenv("OKKT_DF_MACRO")) : 1;
+  // chained update tasks (df_syrk_chain): a bulk tile is followed by the next bulk tile of the queue without leaving the operand ring when that tile lies
+  // at least this many block columns behind its group's last panel; 0 = off
+  d.df_dbg_half = getenv("OKKT_DEBUG_DF_HALF") ? atoi(getenv("OKKT_DEBUG_DF_HALF")) : 0;
+  d.df_chain = getenv("OKKT_DF_CHAIN") ? std::max(0, atoi(getenv("OKKT_DF_CHAIN"))) : 3;
   // OFF by default: built, bitwise equal, and slower (72 us between two diagonal blocks instead of 60) -- the tiles TU(q + 1) starts from arrive
   // through D(q) -> T / TL(q + 2, q) -> the lone last-panel updates of (q + 2, q + 1) and (q + 2, q + 2) about when D(q + 1) ENDS, so the
   // follower has nothing to follow and runs its four block steps (9 us each with its own inversions) behind D(q + 1); DESIGN.md section 4

@@ -41,13 +41,15 @@ def test_dataflow_equals_the_per_step_launches_bit_for_bit(case, tmp_path):
                                  {"OKKT_DF_SPLIT_TU": "0", "OKKT_DF_FUSE_D": "0"}, {"OKKT_DF_FUSE_D": "0"},
                                  {"OKKT_DF_FUSE_TL": "0"}, {"OKKT_DF_FUSE_TL": "0", "OKKT_DF_FUSE_D": "0", "OKKT_DF_GROUP": "2"},
                                  {"OKKT_DF_ROWS_BIG": "2", "OKKT_DF_ROWS_MINKB": "8", "OKKT_DF_ROWS_AHEAD": "4"}, {"OKKT_DF_ROWS_BIG": "4", "OKKT_DF_ROWS_MINKB": "4", "OKKT_DF_ROWS_AHEAD": "1", "OKKT_DF_GROUP": "2"},
-                                 {"OKKT_DF_LOCKSTEP": "1"}, {"OKKT_DF_LOCKSTEP": "1", "OKKT_DF_WORKERS": "5"}, {"OKKT_DF_LOCKSTEP": "1", "OKKT_DF_FUSE_D": "0"}],
+                                 {"OKKT_DF_LOCKSTEP": "1"}, {"OKKT_DF_LOCKSTEP": "1", "OKKT_DF_WORKERS": "5"}, {"OKKT_DF_LOCKSTEP": "1", "OKKT_DF_FUSE_D": "0"},
+                                 {"OKKT_DF_CHAIN": "1"}, {"OKKT_DF_CHAIN": "3", "OKKT_DF_WORKERS": "7"}, {"OKKT_DF_CHAIN": "1", "OKKT_DF_GROUP": "8", "OKKT_DF_WORKERS": "16"}],
                          ids=lambda e: ",".join(f"{k[8:]}={v}" for k, v in e.items()))
 def test_every_queue_shape_gives_the_same_factor(env, tmp_path):
     """The grouping of the panels, the number of row tiles per task, the number of workers, the time model, one or two workers for
     the block row behind a diagonal block, the diagonal block as a task of its own, the last update of a tile inside its panel task
     (TL) and the block row behind a diagonal block in lockstep with it (round 6: OKKT_DF_LOCKSTEP=1, an experiment that is off by
-    default) or behind the whole of it only change the ORDER of the queue and who computes what; the factor does not depend on it."""
+    default) or behind the whole of it, and update tasks chained on a worker without leaving the operand ring (round 6: OKKT_DF_CHAIN, off
+    by default) only change the ORDER of the queue and who computes what; the factor does not depend on it."""
     a = run_case("dense2600", {"OKKT_DATAFLOW": "1"}, tmp_path, "default")
     e = {"OKKT_DATAFLOW": "1"}
     e.update(env)
