@@ -125,7 +125,11 @@ int solver_solve_device(okkt_solver_s* h, const double* d_rhs, double* d_sol, in
 
 extern "C" {
 
-const char* okkt_version(void) { return "onephase-kkt-mi355x 0.1 (gfx950)"; }
+const char* okkt_version(void) {
+  // (the product library carries none of the experimental roles of the dataflow kernel; libonephase_kkt_exp.so carries all three)
+  static const std::string v = std::string("onephase-kkt-mi355x 0.1 (gfx950; dataflow roles: ") + okkt::df_build_flags() + ")";
+  return v.c_str();
+}
 
 int okkt_default_opts(okkt_opts* o) {
   if (!o) return OKKT_ERR_INVALID;

@@ -45,16 +45,27 @@ constexpr int kDfThreadsC = 512;   // threads of a worker
 #define OKKT_DF_STAGGER 1
 #endif
 constexpr bool kDfStagger = OKKT_DF_STAGGER != 0;   // waves 4 - 7 of a worker request the next operand chunk half a chunk behind waves 0 - 3
+// The experiments of round 6 -- the block row in lockstep with its diagonal block (OKKT_DF_PROG), macro tiles (OKKT_DF_MACRO), chained update tasks
+// (OKKT_DF_CHAIN_BUILD) -- are bitwise equal, not faster, and NOT part of the product library: a persistent kernel pays for every role it carries
+// (S-C3 / S-C5 1 % slower with the first two compiled in and switched off, S-metric 2.5 % with the third).  `make` builds them into a second
+// library, libonephase_kkt_exp.so (all three on), which the GPU tests of those variants load through OKKT_LIB_PATH.
 #ifndef OKKT_DF_PROG
-#define OKKT_DF_PROG 1
+#define OKKT_DF_PROG 0
 #endif
 constexpr bool kDfProg = OKKT_DF_PROG != 0;   // round 6: the diagonal block reports its finished 32-column blocks (front_device.h, diag2_body<LPROG>) and TU follows in lockstep (df_tu_lock)
 #ifndef OKKT_DF_MACRO
-#define OKKT_DF_MACRO 1
+#define OKKT_DF_MACRO 0
 #endif
 #ifndef OKKT_DF_ROT
 #define OKKT_DF_ROT 0
 #endif
+#ifndef OKKT_DF_CHAIN_BUILD
+#define OKKT_DF_CHAIN_BUILD 0
+#endif
+// chained update tasks (df_syrk_chain) and the half-work timing experiment are compiled in only on request: with the role in the kernel and switched
+// OFF at run time every other role got slower (S-metric 16.97 -> 17.39 ms, S-C3 + 1.5 %, S-C5 + 1.3 % on one box: twice the scalar-register spills,
+// a longer instruction stream for the persistent workers) -- round 6, profiles/r06_chain_role_in_kernel_ab.txt
+constexpr bool kDfChain = OKKT_DF_CHAIN_BUILD != 0;
 constexpr bool kDfRot = OKKT_DF_ROT != 0;   // update tasks: the column fragments of a k-step from ONE LDS read + lane rotations (df_syrk_tiles); bitwise equal, 12 % SLOWER (see there)
 constexpr bool kDfMacro = OKKT_DF_MACRO != 0;   // update tasks on pairs of row tiles as one macro tile (df_syrk_macro)
 constexpr int kDfDiagMfmaWaves = 6;   // MFMA waves of the diagonal-block factorisation in a worker (four or six: the same time)
@@ -1092,7 +1103,7 @@ __device__ __forceinline__ void df_syrk_tiles(const DevPlan& P, int s, int j0, i
     const int rbase = rt0 + (wv & 1) * 64;
     // (timing experiment, OKKT_DEBUG_DF_HALF: a bulk task skips the products of every other chunk -- WRONG numbers, the operand stream and everything
     // around the loop unchanged: does the launch get faster when the bulk work gets cheaper?)
-    const bool active = !(rbase + 63 < cbase) && rbase < rlim && cbase < clim && !(P.df_dbg_half && nb >= 256 && (g & 1));
+    const bool active = !(rbase + 63 < cbase) && rbase < rlim && cbase < clim && !(kDfChain && P.df_dbg_half && nb >= 256 && (g & 1));
     if (active) {
       const double* slot = sm + (size_t)(g % STAGES) * 2 * kDfKC * kSyrkLd;
       const double* bw = slot + (wv & 1) * 64 + 2 * l15;
@@ -1655,7 +1666,7 @@ __global__ __launch_bounds__(kDfThreads, 1) void k_front_dataflow(DevPlan P, con
       mine = st + (size_t)i * TB + j; newv = q0 + nq; npub = rows;
       if (!(dbg & 4)) {
         if (kDfMacro && rows == 2 && i > j && P.df_macro) df_syrk_macro(P, s, j0, min(nq * 128, k - j0), i, j, KB, k, sm, tlog ? tlog + (size_t)t * 8 + 4 : nullptr);
-        else if (P.df_chain > 0 && rows == 1 && nq >= 2) df_syrk_chain(P, tasks, ntasks, head, t, s, i, j, q0, nq, s_nxt, sm, tlog, &mine, &newv, &t_done, &t_hold);
+        else if (kDfChain && P.df_chain > 0 && rows == 1 && nq >= 2) df_syrk_chain(P, tasks, ntasks, head, t, s, i, j, q0, nq, s_nxt, sm, tlog, &mine, &newv, &t_done, &t_hold);
         else df_syrk_tiles<kDfKC, kDfStages, true, kDfStagger>(P, s, j0, min(nq * 128, k - j0), i, rows, j, KB, k, sm, tlog ? tlog + (size_t)t * 8 + 4 : nullptr);
       }
     }
@@ -1674,6 +1685,8 @@ __global__ __launch_bounds__(kDfThreads, 1) void k_front_dataflow(DevPlan P, con
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------------------------
+
+const char* df_build_flags() { return kDfProg ? (kDfMacro ? (kDfChain ? "lockstep=1 macro=1 chain=1" : "lockstep=1 macro=1 chain=0") : "lockstep=1 macro=0") : (kDfMacro || kDfChain ? "mixed" : "lockstep=0 macro=0 chain=0"); }
 
 std::string df_setup(Numeric& N) {
   DevPlan& d = N.d;
@@ -1696,7 +1709,7 @@ std::string df_setup(Numeric& N) {
   d.df_macro = getenv("OKKT_DF_MACRO") ? atoi(getenv("OKKT_DF_MACRO")) : 1;
   // chained update tasks (df_syrk_chain): a bulk tile is followed by the next bulk tile of the queue without leaving the operand ring when that tile lies
   // at least this many block columns behind its group's last panel; 0 = off
-  d.df_dbg_half = getenv("OKKT_DEBUG_DF_HALF") ? atoi(getenv("OKKT_DEBUG_DF_HALF")) : 0;
+  d.df_dbg_half = (kDfChain && getenv("OKKT_DEBUG_DF_HALF")) ? atoi(getenv("OKKT_DEBUG_DF_HALF")) : 0;
   d.df_chain = getenv("OKKT_DF_CHAIN") ? std::max(0, atoi(getenv("OKKT_DF_CHAIN"))) : 3;
   // OFF by default: built, bitwise equal, and slower (72 us between two diagonal blocks instead of 60) -- the tiles TU(q + 1) starts from arrive
   // through D(q) -> T / TL(q + 2, q) -> the lone last-panel updates of (q + 2, q + 1) and (q + 2, q + 2) about when D(q + 1) ENDS, so the

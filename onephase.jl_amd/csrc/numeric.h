@@ -263,6 +263,7 @@ std::string numeric_solve_enqueue(Numeric& N, int R);
 void launch_set_shift(const Numeric& N, double delta, int64_t nshift);
 // dataflow.hip: the big fronts of one level (class-3 segment g, already assembled) as one persistent launch on `st`
 std::string df_setup(Numeric& N);
+const char* df_build_flags();      // which optional roles the dataflow kernel of this library carries (dataflow.hip)
 std::string df_launch(Numeric& N, const DevPlan& P, const Segment& g, hipStream_t st, double tol);
 
 }  // namespace okkt

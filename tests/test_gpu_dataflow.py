@@ -36,25 +36,49 @@ def test_dataflow_equals_the_per_step_launches_bit_for_bit(case, tmp_path):
     assert np.array_equal(a["x"], b["x"])
 
 
+EXP = {"OKKT_LIB_PATH": os.path.join(ROOT, "onephase.jl_amd", "libonephase_kkt_exp.so")}      # the experiments of round 6 live in a library of their own (csrc/Makefile)
+
+
+def _exp(**e):
+    d = dict(EXP)
+    d.update(e)
+    return d
+
+
 @pytest.mark.parametrize("env", [{"OKKT_DF_GROUP": "1"}, {"OKKT_DF_GROUP": "2"}, {"OKKT_DF_GROUP": "3", "OKKT_DF_ROWS": "2"}, {"OKKT_DF_ROWS": "4"},
                                  {"OKKT_DF_WORKERS": "7"}, {"OKKT_DF_WORKERS": "64", "OKKT_DF_MODEL_CHAIN": "2.0"}, {"OKKT_DF_SPLIT_TU": "0"},
                                  {"OKKT_DF_SPLIT_TU": "0", "OKKT_DF_FUSE_D": "0"}, {"OKKT_DF_FUSE_D": "0"},
                                  {"OKKT_DF_FUSE_TL": "0"}, {"OKKT_DF_FUSE_TL": "0", "OKKT_DF_FUSE_D": "0", "OKKT_DF_GROUP": "2"},
-                                 {"OKKT_DF_ROWS_BIG": "2", "OKKT_DF_ROWS_MINKB": "8", "OKKT_DF_ROWS_AHEAD": "4"}, {"OKKT_DF_ROWS_BIG": "4", "OKKT_DF_ROWS_MINKB": "4", "OKKT_DF_ROWS_AHEAD": "1", "OKKT_DF_GROUP": "2"},
-                                 {"OKKT_DF_LOCKSTEP": "1"}, {"OKKT_DF_LOCKSTEP": "1", "OKKT_DF_WORKERS": "5"}, {"OKKT_DF_LOCKSTEP": "1", "OKKT_DF_FUSE_D": "0"},
-                                 {"OKKT_DF_CHAIN": "1"}, {"OKKT_DF_CHAIN": "3", "OKKT_DF_WORKERS": "7"}, {"OKKT_DF_CHAIN": "1", "OKKT_DF_GROUP": "8", "OKKT_DF_WORKERS": "16"}],
-                         ids=lambda e: ",".join(f"{k[8:]}={v}" for k, v in e.items()))
+                                 EXP,
+                                 _exp(OKKT_DF_ROWS_BIG="2", OKKT_DF_ROWS_MINKB="8", OKKT_DF_ROWS_AHEAD="4"), _exp(OKKT_DF_ROWS_BIG="4", OKKT_DF_ROWS_MINKB="4", OKKT_DF_ROWS_AHEAD="1", OKKT_DF_GROUP="2"),
+                                 _exp(OKKT_DF_LOCKSTEP="1"), _exp(OKKT_DF_LOCKSTEP="1", OKKT_DF_WORKERS="5"), _exp(OKKT_DF_LOCKSTEP="1", OKKT_DF_FUSE_D="0"),
+                                 _exp(OKKT_DF_CHAIN="1"), _exp(OKKT_DF_CHAIN="3", OKKT_DF_WORKERS="7"), _exp(OKKT_DF_CHAIN="1", OKKT_DF_GROUP="8", OKKT_DF_WORKERS="16")],
+                         ids=lambda e: ",".join(("exp" if k == "OKKT_LIB_PATH" else f"{k[8:]}={v}") for k, v in e.items()))
 def test_every_queue_shape_gives_the_same_factor(env, tmp_path):
     """The grouping of the panels, the number of row tiles per task, the number of workers, the time model, one or two workers for
     the block row behind a diagonal block, the diagonal block as a task of its own, the last update of a tile inside its panel task
     (TL) and the block row behind a diagonal block in lockstep with it (round 6: OKKT_DF_LOCKSTEP=1, an experiment that is off by
     default) or behind the whole of it, and update tasks chained on a worker without leaving the operand ring (round 6: OKKT_DF_CHAIN, off
-    by default) only change the ORDER of the queue and who computes what; the factor does not depend on it."""
+    by default) only change the ORDER of the queue and who computes what; the factor does not depend on it.  The last three kinds are
+    compiled into libonephase_kkt_exp.so only ("exp": that library with its defaults against the product library).  That the variants do run there:
+    test_the_experiments_library_runs_its_roles."""
     a = run_case("dense2600", {"OKKT_DATAFLOW": "1"}, tmp_path, "default")
     e = {"OKKT_DATAFLOW": "1"}
     e.update(env)
     b = run_case("dense2600", e, tmp_path, "variant")
     assert np.array_equal(a["d"], b["d"]) and np.array_equal(a["Ldata"], b["Ldata"]) and np.array_equal(a["x"], b["x"])
+
+
+def test_the_experiments_library_runs_its_roles():
+    """The variants above that load libonephase_kkt_exp.so would pass trivially if that library were the product library under another
+    name: its version string names the roles its dataflow kernel was compiled with, the product library's says it has none."""
+    import ctypes
+    prod = ctypes.CDLL(os.path.join(ROOT, "onephase.jl_amd", "libonephase_kkt.so"))
+    exp = ctypes.CDLL(EXP["OKKT_LIB_PATH"])
+    for lib in (prod, exp):
+        lib.okkt_version.restype = ctypes.c_char_p
+    assert b"lockstep=0 macro=0 chain=0" in prod.okkt_version()
+    assert b"lockstep=1 macro=1 chain=1" in exp.okkt_version()
 
 
 def test_released_contribution_blocks_give_the_same_factor(tmp_path):
