@@ -993,7 +993,7 @@ __device__ __forceinline__ double df_row_ror(double v) {
 // bulk kernel's of the two-kernel form, scripts/experiments/r05_two_kernel_form.patch); MULTI: a task may carry several row tiles
 // (the next C tile in a second register set); STAGGER: see below.
 template <int KC, int STAGES, bool MULTI, bool STAGGER>
-__device__ __forceinline__ void df_syrk_tiles(const DevPlan& P, int s, int j0, int nb, int i, int R_, int j, int KB, int k, double* sm, long long* marks) {
+__device__ __forceinline__ void df_syrk_tiles(const DevPlan& P, int s, int j0, int nb, int i, int R_, int j, int KB, int k, double* sm, long long* marks, int* pub0 = nullptr, int pub_stride = 0, int pub_val = 0) {
   constexpr int NW = kSyrkNW;
   constexpr int kDfKC = KC;
   const int R = MULTI ? R_ : 1;
@@ -1078,6 +1078,10 @@ __device__ __forceinline__ void df_syrk_tiles(const DevPlan& P, int s, int j0, i
   mask_c(0);
 #pragma unroll
   for (int g = 0; g < STAGES - 1; ++g) if (g < total) issue(g);
+  // pub0 (round 6): a row tile of a multi-tile task is published as soon as its stores have drained -- behind the wait of the first chunk
+  // iteration of the NEXT row tile -- instead of with the whole task (the caller then publishes the last row tile only): the tiles of a pair
+  // used to become visible one tile's time late
+  int pend_r = -1;
   int plain_until = 0;                     // chunks up to this one are waited for with vmcnt(0): ordinary loads / stores sit between the operand requests
   const int pre = min(2, nchunk - 1);      // chunk of a tile behind whose operand request the next tile's C is requested
   int r = 0, ch = 0;
@@ -1090,6 +1094,12 @@ __device__ __forceinline__ void df_syrk_tiles(const DevPlan& P, int s, int j0, i
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
+    if constexpr (MULTI) {
+      if (pend_r >= 0) {      // every wave's stores of that row tile have drained behind this iteration's vmcnt(0)
+        if (tid == 0) __hip_atomic_store(pub0 + (size_t)pend_r * pub_stride, pub_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        pend_r = -1;
+      }
+    }
     if (marks && g == 0 && tid == 0) { marks[0] = wall_clock64(); marks[3] = -(long long)clock64(); }       // C tile and the first operand chunk have landed; shader clock at the start of the main loop
     // the slot written next was last read one iteration ago; everyone is past that barrier.  Waves k and k + 4 share a SIMD and run
     // the same program: waves 0 - 3 request the next chunk right here, waves 4 - 7 in the middle of their MFMAs, so that one wave's
@@ -1155,6 +1165,7 @@ __device__ __forceinline__ void df_syrk_tiles(const DevPlan& P, int s, int j0, i
       }
       ch = 0;
       plain_until = g + STAGES;
+      if constexpr (MULTI) { if (pub0 && r + 1 < R) pend_r = r; }
       ++r;
       if constexpr (MULTI) { if (r < R) mask_c(r); }
     }
@@ -1667,7 +1678,10 @@ __global__ __launch_bounds__(kDfThreads, 1) void k_front_dataflow(DevPlan P, con
       if (!(dbg & 4)) {
         if (kDfMacro && rows == 2 && i > j && P.df_macro) df_syrk_macro(P, s, j0, min(nq * 128, k - j0), i, j, KB, k, sm, tlog ? tlog + (size_t)t * 8 + 4 : nullptr);
         else if (kDfChain && P.df_chain > 0 && rows == 1 && nq >= 2) df_syrk_chain(P, tasks, ntasks, head, t, s, i, j, q0, nq, s_nxt, sm, tlog, &mine, &newv, &t_done, &t_hold);
-        else df_syrk_tiles<kDfKC, kDfStages, true, kDfStagger>(P, s, j0, min(nq * 128, k - j0), i, rows, j, KB, k, sm, tlog ? tlog + (size_t)t * 8 + 4 : nullptr);
+        else if (rows > 1 && P.df_early_pub) {      // the row tiles but the last are published from inside the task, as their stores drain
+          df_syrk_tiles<kDfKC, kDfStages, true, kDfStagger>(P, s, j0, min(nq * 128, k - j0), i, rows, j, KB, k, sm, tlog ? tlog + (size_t)t * 8 + 4 : nullptr, mine, TB, newv);
+          mine += (size_t)(rows - 1) * TB; npub = 1;
+        } else df_syrk_tiles<kDfKC, kDfStages, true, kDfStagger>(P, s, j0, min(nq * 128, k - j0), i, rows, j, KB, k, sm, tlog ? tlog + (size_t)t * 8 + 4 : nullptr);
       }
     }
     // the next queue position is requested now: the atomic's round trip (1 us) runs beside the drain of this task's stores
@@ -1707,6 +1721,7 @@ std::string df_setup(Numeric& N) {
   N.df_split_tu = getenv("OKKT_DF_SPLIT_TU") ? atoi(getenv("OKKT_DF_SPLIT_TU")) : 1;
   N.df_fuse_tl = getenv("OKKT_DF_FUSE_TL") ? atoi(getenv("OKKT_DF_FUSE_TL")) : 1;
   d.df_macro = getenv("OKKT_DF_MACRO") ? atoi(getenv("OKKT_DF_MACRO")) : 1;
+  d.df_early_pub = getenv("OKKT_DF_EARLY_PUB") ? atoi(getenv("OKKT_DF_EARLY_PUB")) : 1;      // multi-tile update tasks publish every row tile as its stores drain (round 6; 0: with the task)
   // chained update tasks (df_syrk_chain): a bulk tile is followed by the next bulk tile of the queue without leaving the operand ring when that tile lies
   // at least this many block columns behind its group's last panel; 0 = off
   d.df_dbg_half = (kDfChain && getenv("OKKT_DEBUG_DF_HALF")) ? atoi(getenv("OKKT_DEBUG_DF_HALF")) : 0;

@@ -94,6 +94,7 @@ struct DevPlan {
   double* zero_page = nullptr;  // 2 KiB of zeros (source of out-of-panel LDS-DMA rows)
   // dataflow factorisation of the big fronts (dataflow.hip): per tile (i, j) of a big front's 128-block grid the number of tasks that
   // have been applied to it (updates, then the factorisation of the tile itself), TB x TB ints per front
+  int df_early_pub = 1;              // multi-tile update tasks: a row tile is published as soon as its stores have drained (dataflow.hip, df_syrk_tiles)
   int df_dbg_half = 0;               // timing experiment: bulk update tasks skip the products of every other operand chunk (wrong numbers)
   int df_chain = 0;                  // chained update tasks: least distance (block columns) of a chained tile from its group's last panel; 0 = off (dataflow.hip, df_syrk_chain; OKKT_DF_CHAIN)
   int df_macro = 1;                  // update tasks on pairs of row tiles run as one macro tile (dataflow.hip, df_syrk_macro; OKKT_DF_MACRO=0: tile after tile)
