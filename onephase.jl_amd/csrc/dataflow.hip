@@ -66,6 +66,14 @@ constexpr bool kDfProg = OKKT_DF_PROG != 0;   // round 6: the diagonal block rep
 // OFF at run time every other role got slower (S-metric 16.97 -> 17.39 ms, S-C3 + 1.5 %, S-C5 + 1.3 % on one box: twice the scalar-register spills,
 // a longer instruction stream for the persistent workers) -- round 6, profiles/r06_chain_role_in_kernel_ab.txt
 constexpr bool kDfChain = OKKT_DF_CHAIN_BUILD != 0;
+#ifndef OKKT_DF_LOG_BUILD
+#define OKKT_DF_LOG_BUILD 0
+#endif
+// the per-task time stamps (OKKT_DEBUG_DATAFLOW=16 + OKKT_DF_LOG) and the switches that skip task bodies (1 / 2 / 4) are instrumentation of the
+// same kind: with them compiled out S-metric is 1.6 % faster (17.06 against 17.33 ms), S-C3 0.8 %, S-C5 1.6 % (82 instead of 101 scalar-register
+// spills, a shorter instruction stream).  libonephase_kkt_log.so (the product kernel + this instrumentation) and the experiments library have them;
+// OKKT_DEBUG_DATAFLOW=8 (synchronise and report every launch) works everywhere.
+constexpr bool kDfLog = OKKT_DF_LOG_BUILD != 0;
 constexpr bool kDfRot = OKKT_DF_ROT != 0;   // update tasks: the column fragments of a k-step from ONE LDS read + lane rotations (df_syrk_tiles); bitwise equal, 12 % SLOWER (see there)
 constexpr bool kDfMacro = OKKT_DF_MACRO != 0;   // update tasks on pairs of row tiles as one macro tile (df_syrk_macro)
 constexpr int kDfDiagMfmaWaves = 6;   // MFMA waves of the diagonal-block factorisation in a worker (four or six: the same time)
@@ -1553,6 +1561,7 @@ __global__ __launch_bounds__(kDfThreads, 1) void k_front_dataflow(DevPlan P, con
   __shared__ int s_ctl[8];
   __shared__ int s_nxt[8];      // df_syrk_chain: the next tile of a chain, announced by wave 0
   const int tid = threadIdx.x;
+  if constexpr (!kDfLog) { tlog = nullptr; dbg = 0; }      // (the product library: no instrumentation in the kernel)
   // The scheduling code runs on WAVE 0 as a whole (a wave-uniform branch, every lane polls the same words): with an `if (tid == 0)`
   // around it hipcc threads the branch through the loop header, the structurizer turns the worker's loop into two nested loops and
   // lanes 1 .. 63 of wave 0 run ahead into the next s_barrier while lane 0 is masked off -- the workgroup hangs (round 4, first run)
@@ -1700,7 +1709,11 @@ __global__ __launch_bounds__(kDfThreads, 1) void k_front_dataflow(DevPlan P, con
 
 // ---- host side ------------------------------------------------------------------------------------------------------------------
 
-const char* df_build_flags() { return kDfProg ? (kDfMacro ? (kDfChain ? "lockstep=1 macro=1 chain=1" : "lockstep=1 macro=1 chain=0") : "lockstep=1 macro=0") : (kDfMacro || kDfChain ? "mixed" : "lockstep=0 macro=0 chain=0"); }
+const char* df_build_flags() {
+  if (kDfProg && kDfMacro && kDfChain) return kDfLog ? "lockstep=1 macro=1 chain=1 log=1" : "lockstep=1 macro=1 chain=1 log=0";
+  if (!kDfProg && !kDfMacro && !kDfChain) return kDfLog ? "lockstep=0 macro=0 chain=0 log=1" : "lockstep=0 macro=0 chain=0 log=0";
+  return "mixed";
+}
 
 std::string df_setup(Numeric& N) {
   DevPlan& d = N.d;
@@ -1792,7 +1805,13 @@ std::string df_setup(Numeric& N) {
 std::string df_launch(Numeric& N, const DevPlan& P, const Segment& g, hipStream_t st, double tol) {
   if (g.df_cnt <= 0) return "";
   static const int drop = getenv("OKKT_DEBUG_DROP_HANDOFF") ? atoi(getenv("OKKT_DEBUG_DROP_HANDOFF")) : 0;
-  static const int dbg = getenv("OKKT_DEBUG_DATAFLOW") ? atoi(getenv("OKKT_DEBUG_DATAFLOW")) : 0;   // 1 / 2 / 4: skip the bodies of D / T / U (wrong results), 8: synchronise and report every launch, 16: per-task time stamps appended to $OKKT_DF_LOG
+  static const int dbg_env = getenv("OKKT_DEBUG_DATAFLOW") ? atoi(getenv("OKKT_DEBUG_DATAFLOW")) : 0;   // 1 / 2 / 4: skip the bodies of D / T / U (wrong results), 8: synchronise and report every launch, 16: per-task time stamps appended to $OKKT_DF_LOG
+  static const int dbg = kDfLog ? dbg_env : (dbg_env & 8);
+  static const bool warned = [] {
+    if (!kDfLog && (dbg_env & ~8)) fprintf(stderr, "okkt: OKKT_DEBUG_DATAFLOW=%d: the task log and the body switches are compiled into libonephase_kkt_log.so and libonephase_kkt_exp.so only (OKKT_LIB_PATH); ignored here\n", dbg_env);
+    return true;
+  }();
+  (void)warned;
   const int grid = std::min(g.df_cnt, N.df_workers);
   long long* tlog = nullptr;
   if (dbg & 16) { OKKT_HIP_TRY(hipMalloc((void**)&tlog, (size_t)g.df_cnt * 8 * sizeof(long long))); OKKT_HIP_TRY(hipMemsetAsync(tlog, 0, (size_t)g.df_cnt * 8 * sizeof(long long), st)); }   // debug only: per task pop / ready / end ticks (10 ns) and the worker

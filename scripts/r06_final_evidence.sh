@@ -8,7 +8,8 @@ bash scripts/profile_r06.sh r06 > gpurun_out/profile_r06.log 2>&1
 timeout 900 python3 bench.py > $OUT/r06_bench.json 2> gpurun_out/r06_bench.err
 for c in S-metric S-C3 S-C5; do
   rm -f /tmp/dflog.txt
-  OKKT_DATAFLOW=1 OKKT_DEBUG_DATAFLOW=16 OKKT_DF_LOG=/tmp/dflog.txt timeout 600 python3 scripts/df_check.py --run $c /tmp/x.npz > /dev/null 2>&1
+  # (the task log is instrumentation the product library does not carry: libonephase_kkt_log.so = the product kernel + the log)
+  OKKT_LIB_PATH=$PWD/onephase.jl_amd/libonephase_kkt_log.so OKKT_DATAFLOW=1 OKKT_DEBUG_DATAFLOW=16 OKKT_DF_LOG=/tmp/dflog.txt timeout 600 python3 scripts/df_check.py --run $c /tmp/x.npz > /dev/null 2>&1
   python3 scripts/df_log.py /tmp/dflog.txt > $OUT/r06_dataflow_tasks_$c.txt 2>&1
 done
 : > $OUT/r06_forward_error.txt

@@ -79,8 +79,8 @@ def test_the_experiments_library_runs_its_roles():
     exp = ctypes.CDLL(EXP["OKKT_LIB_PATH"])
     for lib in (prod, exp):
         lib.okkt_version.restype = ctypes.c_char_p
-    assert b"lockstep=0 macro=0 chain=0" in prod.okkt_version()
-    assert b"lockstep=1 macro=1 chain=1" in exp.okkt_version()
+    assert b"lockstep=0 macro=0 chain=0 log=0" in prod.okkt_version()
+    assert b"lockstep=1 macro=1 chain=1 log=1" in exp.okkt_version()
 
 
 def test_released_contribution_blocks_give_the_same_factor(tmp_path):
