@@ -74,6 +74,16 @@ constexpr bool kDfChain = OKKT_DF_CHAIN_BUILD != 0;
 // spills, a shorter instruction stream).  libonephase_kkt_log.so (the product kernel + this instrumentation) and the experiments library have them;
 // OKKT_DEBUG_DATAFLOW=8 (synchronise and report every launch) works everywhere.
 constexpr bool kDfLog = OKKT_DF_LOG_BUILD != 0;
+#ifndef OKKT_DF_PIPE
+#define OKKT_DF_PIPE 0
+#endif
+#ifndef OKKT_DF_MULTI
+#define OKKT_DF_MULTI 0
+#endif
+// update tasks that carry several row tiles (OKKT_DF_ROWS, OKKT_DF_ROWS_BIG: measured slower since round 4) need a second set of C-tile registers in the
+// update role; the product library's role has one (the pipelined fragment reads below take the room), the experiments library keeps both
+constexpr bool kDfMulti = OKKT_DF_MULTI != 0;
+constexpr bool kDfPipe = OKKT_DF_PIPE != 0;      // update tasks: operand fragments requested one step ahead of their MFMAs, reads and waits by hand (df_syrk_tiles); bitwise equal, no gain in the kernel: off
 constexpr bool kDfRot = OKKT_DF_ROT != 0;   // update tasks: the column fragments of a k-step from ONE LDS read + lane rotations (df_syrk_tiles); bitwise equal, 12 % SLOWER (see there)
 constexpr bool kDfMacro = OKKT_DF_MACRO != 0;   // update tasks on pairs of row tiles as one macro tile (df_syrk_macro)
 constexpr int kDfDiagMfmaWaves = 6;   // MFMA waves of the diagonal-block factorisation in a worker (four or six: the same time)
@@ -1126,27 +1136,76 @@ __device__ __forceinline__ void df_syrk_tiles(const DevPlan& P, int s, int j0, i
       const double* slot = sm + (size_t)(g % STAGES) * 2 * kDfKC * kSyrkLd;
       const double* bw = slot + (wv & 1) * 64 + 2 * l15;
       const double* bl = slot + kDfKC * kSyrkLd + (wv >> 1) * WCW + (kDfRot ? l15 : (lane & 3));
-#pragma unroll
-      for (int kk = 0; kk < kDfKC / 4; ++kk) {
-        if (kk == (KC / 8) && more && late) issue(g + STAGES - 1);
-        double bv[4];
-#pragma unroll
-        for (int rb = 0; rb < 4; ++rb) bv[rb] = bw[(kk * 4 + l4) * kSyrkLd + (rb & 1) + 32 * (rb >> 1)];
-#pragma unroll
-        for (int half = 0; half < NCG / 4; ++half) {
-          double av[4];
-#pragma unroll
-          for (int qq = 0; qq < 4; ++qq) if (!kDfRot || qq == 0) av[qq] = bl[(kk * 4 + l4) * kSyrkLd + (half * 4 + qq) * 4];
-          if constexpr (kDfRot) {      // 16 columns x 4 k in one read; the other three fragments are that register rotated inside the rows of 16 lanes
-            av[1] = df_row_ror<0x124>(av[0]);
-            av[2] = df_row_ror<0x128>(av[0]);
-            av[3] = df_row_ror<0x12C>(av[0]);
+      if constexpr (kDfRot || !kDfPipe) {
+  #pragma unroll
+        for (int kk = 0; kk < kDfKC / 4; ++kk) {
+          if (kk == (KC / 8) && more && late) issue(g + STAGES - 1);
+          double bv[4];
+  #pragma unroll
+          for (int rb = 0; rb < 4; ++rb) bv[rb] = bw[(kk * 4 + l4) * kSyrkLd + (rb & 1) + 32 * (rb >> 1)];
+  #pragma unroll
+          for (int half = 0; half < NCG / 4; ++half) {
+            double av[4];
+  #pragma unroll
+            for (int qq = 0; qq < 4; ++qq) if (!kDfRot || qq == 0) av[qq] = bl[(kk * 4 + l4) * kSyrkLd + (half * 4 + qq) * 4];
+            if constexpr (kDfRot) {      // 16 columns x 4 k in one read; the other three fragments are that register rotated inside the rows of 16 lanes
+              av[1] = df_row_ror<0x124>(av[0]);
+              av[2] = df_row_ror<0x128>(av[0]);
+              av[3] = df_row_ror<0x12C>(av[0]);
+            }
+  #pragma unroll
+            for (int qq = 0; qq < 4; ++qq)
+  #pragma unroll
+              for (int rb = 0; rb < 4; ++rb)
+                acc[half * 4 + qq][rb] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[qq], bv[rb], acc[half * 4 + qq][rb], 0, 0, 1 /* neg A */);
           }
+        }
+      } else {
+        // kDfPipe (round 6): the operand fragments of step st + 1 (a k-step half: four column fragments, every other step the four row fragments of
+        // the next k-step too) are requested BEFORE the sixteen MFMAs of step st, in a second register set: hipcc's own schedule requests a step's
+        // fragments right in front of its MFMAs and waits lgkmcnt(0) -- fine while the SIMD's other wave has MFMAs to issue, but behind every chunk
+        // barrier both waves of a SIMD stand at the same reads.  scripts/lds_dpp_probe.hip (MODE 3): 19.3 instead of 21.7 cycles per MFMA and SIMD
+        // with the operand stream running, 17.8 / 19.0 without.  IN THE KERNEL (-DOKKT_DF_PIPE=1: bitwise the same factor) the chunk takes 10 547 cycles
+        // against 10 355 with hipcc's own order, S-metric / S-C3 / S-C5 unchanged: under the real operand stream and at the 2.0 GHz the chip runs at
+        // under this load, the loop is not waiting for its LDS reads.  Off.
+        static_assert(NCG == 8, "two halves of four column groups per k-step");
+        // The reads and their waits are written by hand: with LDS-DMA in the loop hipcc waits lgkmcnt(0) for reads it has just issued.  LDS returns
+        // in order, so lgkmcnt(2) / lgkmcnt(4) in front of a step's MFMAs means "everything but the reads just requested" (two read2_b64 for the
+        // next step's column fragments, two more b128 when it starts a new k-step); the waits carry the step's operands as in / out registers so that
+        // its MFMAs stay behind them, and a sched_barrier closes every step.
+        const unsigned ba = (unsigned)(size_t)(bl + l4 * kSyrkLd);      // LDS byte addresses of the column / row fragments of k-step 0
+        const unsigned bb = (unsigned)(size_t)(bw + l4 * kSyrkLd);
+        d2_t B0[2], B1[2], A0[2], A1[2];      // two buffers each: [0] = values (0, 1), [1] = values (2, 3)
+        auto ldb = [&](int kk, d2_t (&bq)[2]) {
+          const unsigned ad = bb + kk * 4 * kSyrkLd * 8;
+          asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:256" : "=&v"(bq[0]), "=&v"(bq[1]) : "v"(ad));
+        };
+        auto lda = [&](int kk, int half, d2_t (&aq)[2]) {
+          const unsigned ad = ba + kk * 4 * kSyrkLd * 8 + half * 128;
+          asm volatile("ds_read2_b64 %0, %2 offset1:4\n\tds_read2_b64 %1, %2 offset0:8 offset1:12" : "=&v"(aq[0]), "=&v"(aq[1]) : "v"(ad));
+        };
+        ldb(0, B0);
+        lda(0, 0, A0);
+#pragma unroll
+        for (int st = 0; st < 2 * (kDfKC / 4); ++st) {
+          const int kk = st >> 1, half = st & 1;
+          d2_t (&Ac)[2] = (st & 1) ? A1 : A0;
+          d2_t (&Bc)[2] = (kk & 1) ? B1 : B0;
+          if (st == 2 * (KC / 8) && more && late) issue(g + STAGES - 1);
+          if (st + 1 < 2 * (kDfKC / 4)) {
+            const int k2 = (st + 1) >> 1, h2 = (st + 1) & 1;
+            if (h2 == 0) ldb(k2, (k2 & 1) ? B1 : B0);
+            lda(k2, h2, ((st + 1) & 1) ? A1 : A0);
+          }
+          if (st + 1 >= 2 * (kDfKC / 4)) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(Ac[0]), "+v"(Ac[1]), "+v"(Bc[0]), "+v"(Bc[1]));
+          else if (((st + 1) & 1) == 0) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(Ac[0]), "+v"(Ac[1]), "+v"(Bc[0]), "+v"(Bc[1]));
+          else asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(Ac[0]), "+v"(Ac[1]), "+v"(Bc[0]), "+v"(Bc[1]));
 #pragma unroll
           for (int qq = 0; qq < 4; ++qq)
 #pragma unroll
             for (int rb = 0; rb < 4; ++rb)
-              acc[half * 4 + qq][rb] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[qq], bv[rb], acc[half * 4 + qq][rb], 0, 0, 1 /* neg A */);
+              acc[half * 4 + qq][rb] = __builtin_amdgcn_mfma_f64_4x4x4f64(Ac[qq >> 1][qq & 1], Bc[rb >> 1][rb & 1], acc[half * 4 + qq][rb], 0, 0, 1 /* neg A */);
+          __builtin_amdgcn_sched_barrier(0);      // nothing moves across the step boundary
         }
       }
     } else if (more && late) issue(g + STAGES - 1);      // a wave without a piece of this tile still stages its rows
@@ -1687,10 +1746,10 @@ __global__ __launch_bounds__(kDfThreads, 1) void k_front_dataflow(DevPlan P, con
       if (!(dbg & 4)) {
         if (kDfMacro && rows == 2 && i > j && P.df_macro) df_syrk_macro(P, s, j0, min(nq * 128, k - j0), i, j, KB, k, sm, tlog ? tlog + (size_t)t * 8 + 4 : nullptr);
         else if (kDfChain && P.df_chain > 0 && rows == 1 && nq >= 2) df_syrk_chain(P, tasks, ntasks, head, t, s, i, j, q0, nq, s_nxt, sm, tlog, &mine, &newv, &t_done, &t_hold);
-        else if (rows > 1 && P.df_early_pub) {      // the row tiles but the last are published from inside the task, as their stores drain
-          df_syrk_tiles<kDfKC, kDfStages, true, kDfStagger>(P, s, j0, min(nq * 128, k - j0), i, rows, j, KB, k, sm, tlog ? tlog + (size_t)t * 8 + 4 : nullptr, mine, TB, newv);
+        else if (kDfMulti && rows > 1 && P.df_early_pub) {      // the row tiles but the last are published from inside the task, as their stores drain
+          df_syrk_tiles<kDfKC, kDfStages, kDfMulti, kDfStagger>(P, s, j0, min(nq * 128, k - j0), i, rows, j, KB, k, sm, tlog ? tlog + (size_t)t * 8 + 4 : nullptr, mine, TB, newv);
           mine += (size_t)(rows - 1) * TB; npub = 1;
-        } else df_syrk_tiles<kDfKC, kDfStages, true, kDfStagger>(P, s, j0, min(nq * 128, k - j0), i, rows, j, KB, k, sm, tlog ? tlog + (size_t)t * 8 + 4 : nullptr);
+        } else df_syrk_tiles<kDfKC, kDfStages, kDfMulti, kDfStagger>(P, s, j0, min(nq * 128, k - j0), i, rows, j, KB, k, sm, tlog ? tlog + (size_t)t * 8 + 4 : nullptr);
       }
     }
     // the next queue position is requested now: the atomic's round trip (1 us) runs beside the drain of this task's stores
@@ -1710,8 +1769,8 @@ __global__ __launch_bounds__(kDfThreads, 1) void k_front_dataflow(DevPlan P, con
 // ---- host side ------------------------------------------------------------------------------------------------------------------
 
 const char* df_build_flags() {
-  if (kDfProg && kDfMacro && kDfChain) return kDfLog ? "lockstep=1 macro=1 chain=1 log=1" : "lockstep=1 macro=1 chain=1 log=0";
-  if (!kDfProg && !kDfMacro && !kDfChain) return kDfLog ? "lockstep=0 macro=0 chain=0 log=1" : "lockstep=0 macro=0 chain=0 log=0";
+  if (kDfProg && kDfMacro && kDfChain && kDfMulti) return kDfLog ? "lockstep=1 macro=1 chain=1 log=1" : "lockstep=1 macro=1 chain=1 log=0";
+  if (!kDfProg && !kDfMacro && !kDfChain && !kDfMulti) return kDfLog ? "lockstep=0 macro=0 chain=0 log=1" : "lockstep=0 macro=0 chain=0 log=0";
   return "mixed";
 }
 
@@ -1743,7 +1802,7 @@ std::string df_setup(Numeric& N) {
   // through D(q) -> T / TL(q + 2, q) -> the lone last-panel updates of (q + 2, q + 1) and (q + 2, q + 2) about when D(q + 1) ENDS, so the
   // follower has nothing to follow and runs its four block steps (9 us each with its own inversions) behind D(q + 1); DESIGN.md section 4
   N.df_lockstep = kDfProg ? (getenv("OKKT_DF_LOCKSTEP") ? atoi(getenv("OKKT_DF_LOCKSTEP")) : 0) : 0;
-  N.df_rows = getenv("OKKT_DF_ROWS") ? std::max(1, std::min(atoi(getenv("OKKT_DF_ROWS")), 8)) : 1;
+  N.df_rows = (kDfMulti && getenv("OKKT_DF_ROWS")) ? std::max(1, std::min(atoi(getenv("OKKT_DF_ROWS")), 8)) : 1;
   OKKT_HIP_TRY(hipFuncSetAttribute((const void*)k_front_dataflow, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
   auto do_sched = [&](std::vector<LevelSchedule>& levels) {
     for (LevelSchedule& L : levels) {
@@ -1763,7 +1822,7 @@ std::string df_setup(Numeric& N) {
         g.df_flops += (double)k * f * f - (double)k * k * f + (double)k * k * k / 3.0;
       }
       double model = 0;
-      df_build_queue(fronts, N.df_workers, N.df_group, N.df_rows, N.df_fuse_d != 0, N.df_split_tu != 0 && !N.df_lockstep, q, &model, N.df_fuse_tl != 0, N.df_lockstep != 0);
+      df_build_queue(fronts, N.df_workers, N.df_group, N.df_rows, N.df_fuse_d != 0, N.df_split_tu != 0 && !N.df_lockstep, q, &model, N.df_fuse_tl != 0, N.df_lockstep != 0, kDfMulti);
       g.df_off = (int64_t)all.size();
       g.df_cnt = (int)q.size();
       g.df_head = nheads++;

@@ -59,8 +59,9 @@ struct FrontGrid {
 }  // namespace
 
 void df_build_queue(const std::vector<DfFront>& fronts, int workers, int group, int rows_per_task, bool fuse_d, bool split_tu, std::vector<DfTask>& out, double* model_us,
-                    bool fuse_tl, bool lockstep) {
-  if (lockstep) split_tu = false;      // one worker follows D(q) block by block (dataflow.hip, df_tu_lock): nothing left to split
+                    bool fuse_tl, bool lockstep, bool multi_rows) {
+  if (lockstep) split_tu = false;
+  if (!multi_rows) rows_per_task = 1;      // (a library whose update role carries one tile per task: dataflow.hip, kDfMulti)      // one worker follows D(q) block by block (dataflow.hip, df_tu_lock): nothing left to split
   const int G = std::max(1, group);
   const int RT = std::max(1, std::min(rows_per_task, 8));
   // Time model (us, measured on MI355X with one workgroup per CU: D 39-45, T 25-32, U 25-30 at K = 128 and 45-52 at K = 256, TU 40
@@ -142,7 +143,7 @@ void df_build_queue(const std::vector<DfFront>& fronts, int workers, int group, 
         static const int rows_coldist = getenv("OKKT_DF_ROWS_COLDIST") ? atoi(getenv("OKKT_DF_ROWS_COLDIST")) : 4;
         const int q_last = gs[c + 1] - 1;                                   // last panel of the group
         const bool far = j >= KB || j - q_last >= rows_coldist;
-        const int RG = (rows_big > 1 && far && KB >= rows_minkb && KB - 1 - q_last >= rows_ahead) ? std::max(RT, rows_big) : RT;
+        const int RG = (multi_rows && rows_big > 1 && far && KB >= rows_minkb && KB - 1 - q_last >= rows_ahead) ? std::max(RT, rows_big) : RT;
         const int R = (j < KB && c + kLonePanels >= ng) ? 1 : RG;
         for (int i = j; i < TB;) {
           const int rows = i == j ? 1 : std::min(R, TB - i);

@@ -109,7 +109,7 @@ struct DfFront { int s, f, k; };
 // queue of the fronts of one level in the start order of a simulated list schedule on `workers` workers; `group` panels per
 // update task where the tile allows it; model_us = the simulated makespan
 void df_build_queue(const std::vector<DfFront>& fronts, int workers, int group, int rows_per_task, bool fuse_d, bool split_tu, std::vector<DfTask>& out, double* model_us,
-                    bool fuse_tl = false, bool lockstep = false);
+                    bool fuse_tl = false, bool lockstep = false, bool multi_rows = true);
 
 constexpr int kDfHeadStride = 16;   // queue counter of a level (word 0; one cache line per level)
 constexpr int kCountSlots = 64, kCountStride = 16;

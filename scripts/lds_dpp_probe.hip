@@ -75,6 +75,73 @@ __global__ __launch_bounds__(512, 1) void k(const double* __restrict__ W, const 
             for (int rb = 0; rb < 4; ++rb) acc[half * 4 + qq][rb] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[qq], bv[rb], acc[half * 4 + qq][rb], 0, 0, 1);
         }
       }
+    } else if (MODE == 3) {
+      // MODE 3: as MODE 2 with the LDS reads and their waits written by hand (the compiler waits lgkmcnt(0) for reads it has just issued as soon as
+      // LDS-DMA is in the loop): in-order LDS returns, lgkmcnt(2) / lgkmcnt(4) in front of the MFMAs of a step
+      typedef double d2v __attribute__((ext_vector_type(2)));
+      const unsigned ba = (unsigned)(size_t)(slot + KC * kLd + (wv >> 1) * 32 + (lane & 3) + l4 * kLd) * 1u;      // LDS byte address of the column fragments, k-step 0
+      const unsigned bb = (unsigned)(size_t)(bw + l4 * kLd);
+      d2v B0[2], B1[2], A0[2], A1[2];      // two buffers each: [0] = values (0,1), [1] = values (2,3)
+      auto ldb = [&](int kk, d2v (&b)[2]) {
+        const unsigned ad = bb + kk * 4 * kLd * 8;
+        asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:256" : "=&v"(b[0]), "=&v"(b[1]) : "v"(ad));
+      };
+      auto lda = [&](int kk, int half, d2v (&a)[2]) {
+        const unsigned ad = ba + kk * 4 * kLd * 8 + half * 128;
+        asm volatile("ds_read2_b64 %0, %2 offset1:4\n\tds_read2_b64 %1, %2 offset0:8 offset1:12" : "=&v"(a[0]), "=&v"(a[1]) : "v"(ad));
+      };
+      ldb(0, B0);
+      lda(0, 0, A0);
+#pragma unroll
+      for (int st = 0; st < 2 * (KC / 4); ++st) {
+        const int kk = st >> 1, half = st & 1;
+        d2v (&Ac)[2] = (st & 1) ? A1 : A0;
+        d2v (&Bc)[2] = (kk & 1) ? B1 : B0;
+        if (st + 1 < 2 * (KC / 4)) {
+          const int k2 = (st + 1) >> 1, h2 = (st + 1) & 1;
+          if (h2 == 0) ldb(k2, (k2 & 1) ? B1 : B0);
+          lda(k2, h2, ((st + 1) & 1) ? A1 : A0);
+        }
+        // everything older than the reads just requested has returned
+        if (st + 1 >= 2 * (KC / 4)) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(Ac[0]), "+v"(Ac[1]), "+v"(Bc[0]), "+v"(Bc[1]));
+        else if (((st + 1) & 1) == 0) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(Ac[0]), "+v"(Ac[1]), "+v"(Bc[0]), "+v"(Bc[1]));
+        else asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(Ac[0]), "+v"(Ac[1]), "+v"(Bc[0]), "+v"(Bc[1]));
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq)
+#pragma unroll
+          for (int rb = 0; rb < 4; ++rb) acc[half * 4 + qq][rb] = __builtin_amdgcn_mfma_f64_4x4x4f64(Ac[qq >> 1][qq & 1], Bc[rb >> 1][rb & 1], acc[half * 4 + qq][rb], 0, 0, 1);
+        __builtin_amdgcn_sched_barrier(0);      // nothing moves across the step boundary
+      }
+    } else if (MODE == 2) {
+      // MODE 2: the kernel's loop with the operand reads of step s + 1 (a k-step half: 4 column fragments, every other step 4 row fragments too)
+      // requested BEFORE the 16 MFMAs of step s, the order pinned with sched_group_barrier (DS reads, then MFMAs)
+      const double* bl = slot + KC * kLd + (wv >> 1) * 32 + (lane & 3);
+      double bvb[2][4], avb[2][4];
+      auto ld_b = [&](int kk, double (&b)[4]) {
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) b[rb] = bw[(kk * 4 + l4) * kLd + (rb & 1) + 32 * (rb >> 1)];
+      };
+      auto ld_a = [&](int kk, int half, double (&a)[4]) {
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) a[qq] = bl[(kk * 4 + l4) * kLd + (half * 4 + qq) * 4];
+      };
+      ld_b(0, bvb[0]);
+      ld_a(0, 0, avb[0]);
+#pragma unroll
+      for (int st = 0; st < 2 * (KC / 4); ++st) {
+        const int kk = st >> 1, half = st & 1;
+        if (st + 1 < 2 * (KC / 4)) {
+          const int k2 = (st + 1) >> 1, h2 = (st + 1) & 1;
+          if (h2 == 0) ld_b(k2, bvb[k2 & 1]);
+          ld_a(k2, h2, avb[(st + 1) & 1]);
+        }
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq)
+#pragma unroll
+          for (int rb = 0; rb < 4; ++rb) acc[half * 4 + qq][rb] = __builtin_amdgcn_mfma_f64_4x4x4f64(avb[st & 1][qq], bvb[kk & 1][rb], acc[half * 4 + qq][rb], 0, 0, 1);
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);      // the DS reads of the next step first ...
+        __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);     // ... then this step's MFMAs
+      }
     } else {
       const double* bl = slot + KC * kLd + (wv >> 1) * 32 + l15;
 #pragma unroll
@@ -105,7 +172,7 @@ __global__ __launch_bounds__(512, 1) void k(const double* __restrict__ W, const 
 #pragma unroll
   for (int cg = 0; cg < 8; ++cg) {
     const int half = cg >> 2, m = cg & 3;
-    const int col = (wv >> 1) * 32 + (MODE == 0 ? cg * 4 : half * 16 + grp[m] * 4) + l4;
+    const int col = (wv >> 1) * 32 + (MODE != 1 ? cg * 4 : half * 16 + grp[m] * 4) + l4;
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb) {
       const int row = (wv & 1) * 64 + 2 * l15 + (rb & 1) + 32 * (rb >> 1);
@@ -150,5 +217,9 @@ int main() {
   run<1, 0>("rotated column fragments, no DMA", ncu);
   run<0, 1>("kernel's loop (12 LDS reads), DMA", ncu);
   run<1, 1>("rotated column fragments, DMA", ncu);
+  run<2, 0>("reads of the next step before the MFMAs, no DMA", ncu);
+  run<2, 1>("reads of the next step before the MFMAs, DMA", ncu);
+  run<3, 0>("... with hand-written reads and waits, no DMA", ncu);
+  run<3, 1>("... with hand-written reads and waits, DMA", ncu);
   return 0;
 }

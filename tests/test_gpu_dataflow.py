@@ -45,12 +45,12 @@ def _exp(**e):
     return d
 
 
-@pytest.mark.parametrize("env", [{"OKKT_DF_GROUP": "1"}, {"OKKT_DF_GROUP": "2"}, {"OKKT_DF_GROUP": "3", "OKKT_DF_ROWS": "2"}, {"OKKT_DF_ROWS": "4"},
+@pytest.mark.parametrize("env", [{"OKKT_DF_GROUP": "1"}, {"OKKT_DF_GROUP": "2"}, _exp(OKKT_DF_GROUP="3", OKKT_DF_ROWS="2"), _exp(OKKT_DF_ROWS="4"),
                                  {"OKKT_DF_WORKERS": "7"}, {"OKKT_DF_WORKERS": "64", "OKKT_DF_MODEL_CHAIN": "2.0"}, {"OKKT_DF_SPLIT_TU": "0"},
                                  {"OKKT_DF_SPLIT_TU": "0", "OKKT_DF_FUSE_D": "0"}, {"OKKT_DF_FUSE_D": "0"},
                                  {"OKKT_DF_FUSE_TL": "0"}, {"OKKT_DF_FUSE_TL": "0", "OKKT_DF_FUSE_D": "0", "OKKT_DF_GROUP": "2"},
-                                 {"OKKT_DF_ROWS": "4", "OKKT_DF_EARLY_PUB": "0"}, {"OKKT_DF_ROWS_BIG": "2", "OKKT_DF_ROWS_MINKB": "8", "OKKT_DF_ROWS_AHEAD": "4"},
-                                 {"OKKT_DF_ROWS_BIG": "3", "OKKT_DF_ROWS_MINKB": "4", "OKKT_DF_ROWS_AHEAD": "1", "OKKT_DF_ROWS_COLDIST": "0", "OKKT_DF_WORKERS": "9"},
+                                 _exp(OKKT_DF_ROWS="4", OKKT_DF_EARLY_PUB="0"), _exp(OKKT_DF_ROWS_BIG="2", OKKT_DF_ROWS_MINKB="8", OKKT_DF_ROWS_AHEAD="4", OKKT_DF_MACRO="0"),
+                                 _exp(OKKT_DF_ROWS_BIG="3", OKKT_DF_ROWS_MINKB="4", OKKT_DF_ROWS_AHEAD="1", OKKT_DF_ROWS_COLDIST="0", OKKT_DF_WORKERS="9"),
                                  EXP,
                                  _exp(OKKT_DF_ROWS_BIG="2", OKKT_DF_ROWS_MINKB="8", OKKT_DF_ROWS_AHEAD="4"), _exp(OKKT_DF_ROWS_BIG="4", OKKT_DF_ROWS_MINKB="4", OKKT_DF_ROWS_AHEAD="1", OKKT_DF_GROUP="2"),
                                  _exp(OKKT_DF_LOCKSTEP="1"), _exp(OKKT_DF_LOCKSTEP="1", OKKT_DF_WORKERS="5"), _exp(OKKT_DF_LOCKSTEP="1", OKKT_DF_FUSE_D="0"),
