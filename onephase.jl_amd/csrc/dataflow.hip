@@ -78,10 +78,11 @@ constexpr bool kDfLog = OKKT_DF_LOG_BUILD != 0;
 #define OKKT_DF_PIPE 0
 #endif
 #ifndef OKKT_DF_MULTI
-#define OKKT_DF_MULTI 0
+#define OKKT_DF_MULTI 1
 #endif
 // update tasks that carry several row tiles (OKKT_DF_ROWS, OKKT_DF_ROWS_BIG: measured slower since round 4) need a second set of C-tile registers in the
-// update role; the product library's role has one (the pipelined fragment reads below take the room), the experiments library keeps both
+// update role.  -DOKKT_DF_MULTI=0 leaves it out; measured (round 6, four A/B pairs on one box): the kernel WITH it is the faster one -- S-metric 17.07 against
+// 17.17 ms, S-C3 2.95 against 2.99 -- register allocation, not logic: kept
 constexpr bool kDfMulti = OKKT_DF_MULTI != 0;
 constexpr bool kDfPipe = OKKT_DF_PIPE != 0;      // update tasks: operand fragments requested one step ahead of their MFMAs, reads and waits by hand (df_syrk_tiles); bitwise equal, no gain in the kernel: off
 constexpr bool kDfRot = OKKT_DF_ROT != 0;   // update tasks: the column fragments of a k-step from ONE LDS read + lane rotations (df_syrk_tiles); bitwise equal, 12 % SLOWER (see there)
@@ -1769,8 +1770,8 @@ __global__ __launch_bounds__(kDfThreads, 1) void k_front_dataflow(DevPlan P, con
 // ---- host side ------------------------------------------------------------------------------------------------------------------
 
 const char* df_build_flags() {
-  if (kDfProg && kDfMacro && kDfChain && kDfMulti) return kDfLog ? "lockstep=1 macro=1 chain=1 log=1" : "lockstep=1 macro=1 chain=1 log=0";
-  if (!kDfProg && !kDfMacro && !kDfChain && !kDfMulti) return kDfLog ? "lockstep=0 macro=0 chain=0 log=1" : "lockstep=0 macro=0 chain=0 log=0";
+  if (kDfProg && kDfMacro && kDfChain) return kDfLog ? "lockstep=1 macro=1 chain=1 log=1" : "lockstep=1 macro=1 chain=1 log=0";
+  if (!kDfProg && !kDfMacro && !kDfChain) return kDfLog ? "lockstep=0 macro=0 chain=0 log=1" : "lockstep=0 macro=0 chain=0 log=0";
   return "mixed";
 }
 
